@@ -1,0 +1,185 @@
+/* =============================================================================
+ * l3dpp_hip.h -- C-ABI of the MI355X-native Line3D++ matching/scoring hot path.
+ *
+ * Shared library: line3dpp_amd/csrc/libl3dpp_hip.so (hand-written HIP, gfx950).
+ * Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repository manhofer/Line3Dpp).  Two layers are exported:
+ *
+ *   (1) context layer  -- replaces the slice of class L3DPP::Line3D that drives the hot
+ *       path: addImage (explicit segments) / matchImages / the affinity part of
+ *       reconstruct3Dlines, with accessors that hand back matches_, estimated_position3D_
+ *       and A_ in the reference's own POD layouts (Match, Segment3D fields, CLEdge,
+ *       SparseMatrix COO) so clustering / optimisation can run unchanged.
+ *   (2) seam layer     -- replaces the accelerator seam the reference already has in
+ *       cudawrapper.h:54-80 (match_lines_GPU / score_matches_GPU), for a maintainer who
+ *       wants to keep Line3D's own driver loop and only swap the kernels.
+ *
+ * All functions return 0 on success or a negative l3d_status; l3d_last_error() gives text.
+ * Semantics follow the reference CPU path (line3D.cc), not its CUDA path.
+ * ===========================================================================*/
+#ifndef L3DPP_HIP_H_
+#define L3DPP_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- PODs with the reference's exact layout -------------------------------------- */
+
+/* L3DPP::Match, commons.h:186-203 (40 bytes) */
+typedef struct l3d_match {
+    uint32_t src_camID_, src_segID_, tgt_camID_, tgt_segID_;
+    float overlap_score_, score3D_;
+    float depth_p1_, depth_p2_, depth_q1_, depth_q2_;
+} l3d_match;
+
+/* L3DPP::Segment2D, commons.h:104-131 */
+typedef struct l3d_segment2d { uint32_t camID_, segID_; } l3d_segment2d;
+
+/* the data members of L3DPP::Segment3D, segment3D.h:99-115 (P1,P2,dir double; length float; valid) */
+typedef struct l3d_segment3d {
+    double P1[3], P2[3], dir[3];
+    float length_;
+    uint32_t valid_;
+} l3d_segment3d;
+
+/* L3DPP::CLEdge, clustering.h:47-51 */
+typedef struct l3d_cledge { int32_t i_, j_; float w_; } l3d_cledge;
+
+/* float4 entry of L3DPP::SparseMatrix (sparsematrix.cc:40: (i, j, w, 0)) */
+typedef struct l3d_float4 { float x, y, z, w; } l3d_float4;
+
+/* one phase-A result slot: what a (src segment, rank) of a directed view pair holds.
+ * 32 bytes; this is also the record the multi-GPU all-gather exchanges. */
+typedef struct l3d_slot {
+    uint32_t tgt_seg;   /* 0xFFFFFFFF = empty */
+    float overlap;
+    float depth_p1, depth_p2, depth_q1, depth_q2;
+    float score3D;      /* written when the src view is processed (scoringCPU) */
+    uint32_t flags;     /* bit0: survived the src view's orientation filter */
+} l3d_slot;
+
+typedef enum l3d_status {
+    L3D_OK = 0,
+    L3D_ERR_ARG = -1,          /* bad argument */
+    L3D_ERR_IMAGE_SMALL = -2,  /* line3D.cc:119 */
+    L3D_ERR_ID_IN_USE = -3,    /* line3D.cc:130 */
+    L3D_ERR_NO_NEIGHBORS = -4, /* line3D.cc:154 */
+    L3D_ERR_NO_SEGMENTS = -5,  /* line3D.cc:188 */
+    L3D_ERR_NO_VIEWS = -6,     /* line3D.cc:385 */
+    L3D_ERR_STATE = -7,        /* call order */
+    L3D_ERR_HIP = -8,          /* HIP runtime error */
+    L3D_ERR_LIMIT = -9         /* size limit of this build */
+} l3d_status;
+
+typedef struct l3d_ctx l3d_ctx;
+
+/* Line3D::matchImages arguments, line3D.h:143-148 (defaults commons.h:51-55) */
+typedef struct l3d_match_params {
+    float sigma_position;             /* 2.5  */
+    float sigma_angle;                /* 10.0 */
+    uint32_t num_neighbors;           /* 10   */
+    float epipolar_overlap;           /* 0.25 */
+    int32_t kNN;                      /* 10   */
+    float const_regularization_depth; /* -1   */
+} l3d_match_params;
+
+const char* l3d_last_error(void);
+/* build info: "gfx950;..." */
+const char* l3d_build_info(void);
+
+/* ---- (1) context layer ------------------------------------------------------------- */
+
+/* Line3D::Line3D (line3D.cc:6-69) with neighbors_by_worldpoints=false, use_GPU=true.
+ * `device` = HIP device ordinal.  `stream` = hipStream_t to launch on (0 = default stream). */
+l3d_ctx* l3d_create(int device, void* stream);
+void l3d_destroy(l3d_ctx*);
+
+/* Line3D::addImage (line3D.cc:112-227) with explicit `line_segments` and explicit neighbour
+ * list; the image contributes only width/height.  segs4 = M x (x1,y1,x2,y2) pixels. */
+int l3d_add_view(l3d_ctx*, uint32_t camID, const float* segs4, uint32_t M, const double K[9],
+                 const double R[9], const double t[3], uint32_t width, uint32_t height,
+                 float median_depth, const uint32_t* neighbors, uint32_t n_neighbors);
+
+/* Line3D::matchImages (line3D.cc:375-497): the whole call on this context's GPU. */
+int l3d_match_images(l3d_ctx*, const l3d_match_params*);
+
+/* matchImages split in three for pair-sharded multi-GPU runs (one process per GPU):
+ *   l3d_match_begin   param clamps, translate(), per-view k, neighbour sets, directed pair
+ *                     list (line3D.cc:394-485, 704-741), upload + per-view precompute
+ *   l3d_match_pairs   matchingCPU (line3D.cc:900-1015) for the pairs [first, first+count) of
+ *                     the pair list -> their slots in the slot buffer
+ *   (exchange: all-gather of the slot buffer, done by the caller, e.g. RCCL through
+ *    torch.distributed on the device pointer l3d_slot_buffer() returns)
+ *   l3d_match_finish  per view, ascending camID: checkMatchOrientation, scoringCPU,
+ *                     storeInverseMatches, filterMatches (line3D.cc:745-773); untranslate() */
+int l3d_match_begin(l3d_ctx*, const l3d_match_params*);
+int l3d_num_pairs(l3d_ctx*, uint32_t* n);
+int l3d_get_pairs(l3d_ctx*, uint32_t* src_cam, uint32_t* tgt_cam, uint64_t* slot_offset /* in slots */);
+int l3d_match_pairs(l3d_ctx*, uint32_t first, uint32_t count);
+int l3d_slot_buffer(l3d_ctx*, void** dev_ptr, uint64_t* n_slots);
+int l3d_match_finish(l3d_ctx*);
+
+/* The affinity part of Line3D::reconstruct3Dlines: translate(), med_scene_depth_lines_,
+ * computingAffinityMatrix(), untranslate() (line3D.cc:1749-1778, 1852-2023; collinearity off). */
+int l3d_compute_affinity(l3d_ctx*);
+
+/* block the calling thread until everything queued on the context's stream has finished */
+int l3d_synchronize(l3d_ctx*);
+
+/* ---- accessors (host copies, reference layouts) ------------------------------------ */
+
+/* number of directed pair tests matchImages performed: sum Ms*Mt */
+int l3d_pair_tests(l3d_ctx*, uint64_t* n);
+/* matches_[camID] after matchImages: CSR over the view's segments.
+ * seg_offsets has M+1 entries.  Call with out=NULL to get the count. */
+int l3d_get_matches(l3d_ctx*, uint32_t camID, l3d_match* out, uint64_t cap, uint32_t* seg_offsets,
+                    uint64_t* n);
+/* fresh phase-A slots of one directed pair: Ms x K slots (K = kNN) */
+int l3d_get_pair_slots(l3d_ctx*, uint32_t pair_index, l3d_slot* out, uint64_t cap, uint32_t* Ms,
+                       uint32_t* K);
+/* estimated_position3D_ (+ entry_map_ keys), ordered by (camID, segID). Coordinates are in the
+ * translated frame matchImages works in (the reference never untranslates them). */
+int l3d_num_best(l3d_ctx*, uint32_t* n);
+int l3d_get_best(l3d_ctx*, l3d_segment2d* seg2d, l3d_segment3d* seg3d, l3d_match* best);
+/* per view: View::k(), View::median_depth() after matchImages */
+int l3d_view_info(l3d_ctx*, uint32_t camID, float* k, float* median_depth);
+int l3d_translation(l3d_ctx*, double t[3]);
+/* A_ (CLEdge list, both (i,j) and (j,i)), local2global_ and med_scene_depth_lines_ */
+int l3d_num_affinity(l3d_ctx*, uint32_t* n_edges, uint32_t* n_rows);
+int l3d_get_affinity(l3d_ctx*, l3d_cledge* edges, l3d_segment2d* local2global, float* med_scene_depth_lines);
+/* L3DPP::SparseMatrix(A_, n_rows, 1.0, sort_by_row) (sparsematrix.cc:8-60): entries float4(i,j,w,0)
+ * sorted by row or column, start_indices[n_rows] with -1 for empty rows/columns */
+int l3d_get_sparse_matrix(l3d_ctx*, int sort_by_row, l3d_float4* entries, int32_t* start_indices);
+
+/* timing of the last calls, milliseconds of GPU time from HIP events on the context's stream */
+typedef struct l3d_timings {
+    float begin_ms;        /* upload + per-view precompute kernels */
+    float match_pairs_ms;  /* phase A: pair-matching kernel(s) */
+    float finish_ms;       /* phase B: per-view chain */
+    float affinity_ms;
+    uint32_t match_kernel_launches;
+    float match_kernel_ms; /* the pair-matching kernel alone */
+} l3d_timings;
+int l3d_get_timings(l3d_ctx*, l3d_timings*);
+
+/* ---- (2) seam layer ------------------------------------------------------------------ */
+
+/* Replaces match_lines_GPU (cudawrapper.h:54-63; caller Line3D::matchingGPU line3D.cc:1040-1074)
+ * with CPU-path semantics (Line3D::matchingCPU line3D.cc:900-1015).  Host pointers in and out.
+ * F, RtKinv_* are row-major 3x3 doubles, C_* camera centres (already translated, line3D.cc:436).
+ * kNN must be > 0 here.  out_slots: Ms x kNN slots, rows sorted by (overlap desc, tgt_seg asc).
+ * Returns the number of matches in *num_matches. */
+int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const float* lines_tgt4, uint32_t Mt,
+                    const double F[9], const double RtKinv_src[9], const double RtKinv_tgt[9],
+                    const double C_src[3], const double C_tgt[3], uint32_t width, uint32_t height,
+                    float epi_overlap, int32_t kNN, l3d_slot* out_slots, uint64_t* num_matches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* L3DPP_HIP_H_ */

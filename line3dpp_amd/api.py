@@ -1,0 +1,210 @@
+"""Host-side mirror of the reference's public interface for the hot path.
+
+`Line3D` follows class L3DPP::Line3D (line3D.h:61-424): `addImage`, `matchImages`,
+and the affinity part of `reconstruct3Dlines`, with the reference's argument names, defaults
+(commons.h:40-70) and error behaviour: errors are printed with the `[L3D++] ERROR:` prefix and the
+call returns without raising (line3D.cc:119-126, 385-391); `last_status` holds the l3d_status
+code.  All compute runs in libl3dpp_hip.so (HIP, gfx950) through the C-ABI in
+include/l3dpp_hip.h.  The reference is C++; this Python front-end exists for the tests, the
+bench and torch.distributed plumbing -- the C++ facade over the same C-ABI is
+include/line3dpp/line3D.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (CLEDGE_DTYPE, EMPTY, FLOAT4_DTYPE, MATCH_DTYPE, SEGMENT2D_DTYPE, SEGMENT3D_DTYPE, SLOT_DTYPE,
+                   MatchParams, Timings, ptr)
+
+# commons.h:40-70
+L3D_DEF_MATCHING_NEIGHBORS = 10
+L3D_DEF_EPIPOLAR_OVERLAP = 0.25
+L3D_DEF_KNN = 10
+L3D_DEF_SCORING_POS_REGULARIZER = 2.5
+L3D_DEF_SCORING_ANG_REGULARIZER = 10.0
+L3D_DEF_MIN_VISIBILITY_T = 3
+
+
+class Line3D:
+    PREFIX = "[L3D++] "
+
+    def __init__(self, output_folder="", load_segments=False, max_img_width=-1, max_line_segments=3000,
+                 neighbors_by_worldpoints=False, use_GPU=True, device=0, stream=0, verbose=False):
+        if neighbors_by_worldpoints:
+            raise NotImplementedError("worldpoint-derived neighbours (line3D.cc:578-699) are outside the hot path; "
+                                      "pass explicit neighbour lists (neighbors_by_worldpoints=false)")
+        self.L = _lib.load()
+        self.verbose = verbose
+        self.last_status = 0
+        self._M = {}
+        self.h = self.L.l3d_create(int(device), C.c_void_p(stream))
+        if not self.h:
+            raise RuntimeError("l3d_create failed: " + _lib.last_error())
+        self.h = C.c_void_p(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.l3d_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- error behaviour of the reference: print and return ---------------------------------
+    def _check(self, rc, what):
+        self.last_status = rc
+        if rc != 0:
+            print(f"{self.PREFIX}ERROR: {what}: {_lib.last_error()} [{rc}]")
+        return rc == 0
+
+    # Line3D::addImage(camID, image, K, R, t, median_depth, wps_or_neighbors, line_segments), line3D.h:104-108
+    def addImage(self, camID, image_size, K, R, t, median_depth, wps_or_neighbors, line_segments):
+        """image_size = (cols, rows) stands in for the cv::Mat, which only contributes its size once
+        `line_segments` are given (line3D.cc:119,198)."""
+        segs = np.ascontiguousarray(line_segments, np.float32).reshape(-1, 4)
+        K = np.ascontiguousarray(K, np.float64).reshape(3, 3)
+        R = np.ascontiguousarray(R, np.float64).reshape(3, 3)
+        t = np.ascontiguousarray(t, np.float64).reshape(3)
+        nb = np.ascontiguousarray(list(wps_or_neighbors), np.uint32)
+        rc = self.L.l3d_add_view(self.h, int(camID), ptr(segs), len(segs), ptr(K), ptr(R), ptr(t),
+                                 int(image_size[0]), int(image_size[1]), float(median_depth), ptr(nb), len(nb))
+        if self._check(rc, f"addImage [{camID}]"):
+            self._M[int(camID)] = len(segs)
+
+    def add_scene(self, scene):
+        for v in scene.views:
+            self.addImage(v.cam, (v.width, v.height), v.K, v.R, v.t, v.median_depth, v.neighbors, v.segs)
+
+    def _params(self, sigma_position, sigma_angle, num_neighbors, epipolar_overlap, kNN, const_regularization_depth):
+        return MatchParams(float(sigma_position), float(sigma_angle), int(num_neighbors), float(epipolar_overlap),
+                           int(kNN), float(const_regularization_depth))
+
+    # Line3D::matchImages, line3D.h:143-148
+    def matchImages(self, sigma_position=L3D_DEF_SCORING_POS_REGULARIZER, sigma_angle=L3D_DEF_SCORING_ANG_REGULARIZER,
+                    num_neighbors=L3D_DEF_MATCHING_NEIGHBORS, epipolar_overlap=L3D_DEF_EPIPOLAR_OVERLAP,
+                    kNN=L3D_DEF_KNN, const_regularization_depth=-1.0):
+        p = self._params(sigma_position, sigma_angle, num_neighbors, epipolar_overlap, kNN, const_regularization_depth)
+        return self._check(self.L.l3d_match_images(self.h, C.byref(p)), "matchImages")
+
+    # split form for pair-sharded runs (see line3dpp_amd/dist.py)
+    def matchBegin(self, sigma_position=L3D_DEF_SCORING_POS_REGULARIZER, sigma_angle=L3D_DEF_SCORING_ANG_REGULARIZER,
+                   num_neighbors=L3D_DEF_MATCHING_NEIGHBORS, epipolar_overlap=L3D_DEF_EPIPOLAR_OVERLAP,
+                   kNN=L3D_DEF_KNN, const_regularization_depth=-1.0):
+        p = self._params(sigma_position, sigma_angle, num_neighbors, epipolar_overlap, kNN, const_regularization_depth)
+        return self._check(self.L.l3d_match_begin(self.h, C.byref(p)), "matchBegin")
+
+    def matchPairs(self, first, count):
+        return self._check(self.L.l3d_match_pairs(self.h, int(first), int(count)), "matchPairs")
+
+    def matchFinish(self):
+        return self._check(self.L.l3d_match_finish(self.h), "matchFinish")
+
+    # the affinity part of Line3D::reconstruct3Dlines, line3D.h:162-166 / line3D.cc:1749-1778
+    def computeAffinity(self):
+        return self._check(self.L.l3d_compute_affinity(self.h), "computeAffinity")
+
+    def set_brute_force(self, on):
+        self.L.l3d_set_brute_force(self.h, int(on))
+
+    # ---- accessors ----------------------------------------------------------------------------
+    def numImages(self):
+        return len(self._M)
+
+    def pairs(self):
+        n = C.c_uint32()
+        self.L.l3d_num_pairs(self.h, C.byref(n))
+        s = np.zeros(n.value, np.uint32); t = np.zeros(n.value, np.uint32); off = np.zeros(n.value, np.uint64)
+        self.L.l3d_get_pairs(self.h, ptr(s), ptr(t), ptr(off))
+        return np.stack([s, t], 1), off
+
+    def slot_buffer(self):
+        p = C.c_void_p(); n = C.c_uint64()
+        self.L.l3d_slot_buffer(self.h, C.byref(p), C.byref(n))
+        return p.value, n.value
+
+    def pair_tests(self):
+        n = C.c_uint64()
+        self.L.l3d_pair_tests(self.h, C.byref(n))
+        return n.value
+
+    def pair_slots(self, pair_index):
+        Ms = C.c_uint32(); K = C.c_uint32()
+        if not self._check(self.L.l3d_get_pair_slots(self.h, pair_index, None, 0, C.byref(Ms), C.byref(K)), "pair_slots"):
+            return None
+        out = np.zeros((Ms.value, K.value), SLOT_DTYPE)
+        self._check(self.L.l3d_get_pair_slots(self.h, pair_index, ptr(out), out.size, C.byref(Ms), C.byref(K)),
+                    "pair_slots")
+        return out
+
+    def matches(self, camID):
+        """matches_[camID] as (Match records, CSR offsets over the view's segments)"""
+        M = self._M[camID]
+        n = C.c_uint64()
+        off = np.zeros(M + 1, np.uint32)
+        if not self._check(self.L.l3d_get_matches(self.h, camID, None, 0, ptr(off), C.byref(n)), "matches"):
+            return None, None
+        out = np.zeros(max(n.value, 1), MATCH_DTYPE)
+        self._check(self.L.l3d_get_matches(self.h, camID, ptr(out), n.value, ptr(off), C.byref(n)), "matches")
+        return out[:n.value], off
+
+    def best(self):
+        """estimated_position3D_: (Segment2D keys, Segment3D, best Match), ordered by (camID, segID)"""
+        n = C.c_uint32()
+        self.L.l3d_num_best(self.h, C.byref(n))
+        s2 = np.zeros(n.value, SEGMENT2D_DTYPE); s3 = np.zeros(n.value, SEGMENT3D_DTYPE); m = np.zeros(n.value, MATCH_DTYPE)
+        if n.value:
+            self._check(self.L.l3d_get_best(self.h, ptr(s2), ptr(s3), ptr(m)), "best")
+        return s2, s3, m
+
+    def view_info(self, camID):
+        k = C.c_float(); md = C.c_float()
+        self.L.l3d_view_info(self.h, camID, C.byref(k), C.byref(md))
+        return dict(k=np.float32(k.value), median_depth=np.float32(md.value))
+
+    def translation(self):
+        t = np.zeros(3)
+        self.L.l3d_translation(self.h, ptr(t))
+        return t
+
+    def affinity(self):
+        """A_ (CLEdge array), local2global_ (Segment2D per matrix row), med_scene_depth_lines_"""
+        ne = C.c_uint32(); nr = C.c_uint32()
+        if not self._check(self.L.l3d_num_affinity(self.h, C.byref(ne), C.byref(nr)), "affinity"):
+            return None, None, None
+        e = np.zeros(max(ne.value, 1), CLEDGE_DTYPE); l2g = np.zeros(max(nr.value, 1), SEGMENT2D_DTYPE)
+        msdl = C.c_float()
+        self.L.l3d_get_affinity(self.h, ptr(e), ptr(l2g), C.byref(msdl))
+        return e[:ne.value], l2g[:nr.value], np.float32(msdl.value)
+
+    def sparse_matrix(self, sort_by_row=False):
+        """L3DPP::SparseMatrix(A_, n_rows, 1.0f, sort_by_row): (float4 entries, int start_indices)"""
+        ne = C.c_uint32(); nr = C.c_uint32()
+        self.L.l3d_num_affinity(self.h, C.byref(ne), C.byref(nr))
+        ent = np.zeros(max(ne.value, 1), FLOAT4_DTYPE); start = np.zeros(max(nr.value, 1), np.int32)
+        self._check(self.L.l3d_get_sparse_matrix(self.h, int(sort_by_row), ptr(ent), ptr(start)), "sparse_matrix")
+        return ent[:ne.value], start[:nr.value]
+
+    def timings(self):
+        t = Timings()
+        self.L.l3d_get_timings(self.h, C.byref(t))
+        return {f: getattr(t, f) for f, _ in Timings._fields_}
+
+
+def match_lines(lines_src, lines_tgt, F, RtKinv_src, RtKinv_tgt, C_src, C_tgt, width, height, epi_overlap=0.25,
+                kNN=10, device=0):
+    """Seam-level call replacing match_lines_GPU (cudawrapper.h:54-63) with CPU-path semantics."""
+    L = _lib.load()
+    a = np.ascontiguousarray(lines_src, np.float32).reshape(-1, 4)
+    b = np.ascontiguousarray(lines_tgt, np.float32).reshape(-1, 4)
+    arrs = [np.ascontiguousarray(x, np.float64) for x in (F, RtKinv_src, RtKinv_tgt, C_src, C_tgt)]
+    out = np.zeros((len(a), kNN), SLOT_DTYPE)
+    n = C.c_uint64()
+    rc = L.l3d_match_lines(device, ptr(a), len(a), ptr(b), len(b), *[ptr(x) for x in arrs], width, height,
+                           float(epi_overlap), int(kNN), ptr(out), C.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"l3d_match_lines failed [{rc}]: {_lib.last_error()}")
+    return out, n.value

@@ -1,0 +1,343 @@
+// k_match.hip -- phase A: all-pairs epipolar matching of 2D segments for directed view pairs.
+//
+// Replaces Line3D::matchingCPU (line3D.cc:900-1015) + mutualOverlap (:1086-1165) +
+// triangulationDepths (:1168-1193) and the reference's K_match_lines/host-heap pipeline
+// (cudawrapper.cu:186-253, 549-658) with a design that never materialises the Ms x Mt matrix:
+//
+//   workgroup  = (directed pair, block of 256 source segments), 4 wave64
+//   lane       = one source segment; its two epipolar lines live in VGPRs (fp32, unit normal,
+//                image-centre origin)
+//   target view streams through LDS tiles of 16-byte SegF records; every lane reads the same
+//                record (LDS broadcast, conflict free)
+//   fp32 pre-filter (conservative) -> __ballot -> popcount-prefix compaction of
+//                the few survivors into a per-wave LDS ring
+//   ring holds >= 64 candidates -> the wave drains 64 of them, one per lane, through the EXACT
+//                double-precision pair test (l3d_dev.h exact_pair, reference CPU semantics)
+//   accepted candidates are inserted into the per-source-segment top-K in LDS (kNN selection by
+//                (overlap desc, tgt asc)); the K-th best overlap feeds back into the lane's
+//                pre-filter threshold, so the candidate rate decays as the row fills
+//   epilogue   = rank the <= K winners of each row and write the fixed-slot row (32 B slots)
+//
+// Roofline: compulsory HBM traffic per directed pair is 16*(Ms+Mt) B read + 32*K*Ms B written;
+// per pair test that is < 0.2 B against ~30 fp32 VALU issues, so the kernel is VALU-issue bound
+// (DESIGN.md §roofline).  No MFMA: there is no contraction here.
+#include "l3d_dev.h"
+#include "l3d_kernels.h"
+
+namespace l3d {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kTile = 1024;        // target records per LDS tile (16 KiB)
+constexpr int kRing = 512;         // per-wave candidate ring (entries); >= 63 + 4*64
+constexpr float kKappa = 1.0e-2f;  // pre-filter slack, px: margin = kKappa * max|1/d| + kKappa0
+constexpr float kKappa0 = 2.0e-4f;
+
+struct Lds {
+    float4* tile;        // [kTile]
+    volatile uint32_t* ring;      // [4][kRing]
+    volatile uint32_t* cnt;       // [kBlock]
+    volatile float* minov;        // [kBlock]
+    volatile uint32_t* claim;     // [kBlock]
+    volatile float* top_ov;       // [kBlock*K]
+    volatile uint32_t* top_ix;    // [kBlock*K]
+};
+
+__device__ __forceinline__ Lds carve(char* base, uint32_t K) {
+    Lds l;
+    l.tile = (float4*)base; base += sizeof(float4) * kTile;
+    l.ring = (volatile uint32_t*)base; base += 4 * kRing * sizeof(uint32_t);
+    l.cnt = (volatile uint32_t*)base; base += kBlock * 4;
+    l.minov = (volatile float*)base; base += kBlock * 4;
+    l.claim = (volatile uint32_t*)base; base += kBlock * 4;
+    l.top_ov = (volatile float*)base; base += (size_t)kBlock * K * 4;
+    l.top_ix = (volatile uint32_t*)base;
+    return l;
+}
+
+// conservative fp32 test "could overlap(src, tgt) exceed thr?".  (e?x,e?y) are unit normals of the
+// two epipolar lines, e?z their offsets w.r.t. the image centre; q = (q1 - centre, q1 - q2).
+// s_i = a_i / d_i is the position of the intersection of epipolar line i with the target line in
+// units of the target segment (q1 -> 0, q2 -> 1).  NaN/inf from degenerate d fall through as
+// "candidate" and are sorted out by the exact test.
+__device__ __forceinline__ bool prefilter(float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
+                                          const float4 q, float thr) {
+    float a1 = __builtin_fmaf(e1x, q.x, __builtin_fmaf(e1y, q.y, e1z));
+    float a2 = __builtin_fmaf(e2x, q.x, __builtin_fmaf(e2y, q.y, e2z));
+    float d1 = __builtin_fmaf(e1x, q.z, e1y * q.w);
+    float d2 = __builtin_fmaf(e2x, q.z, e2y * q.w);
+    float r1 = __builtin_amdgcn_rcpf(d1);
+    float r2 = __builtin_amdgcn_rcpf(d2);
+    float s1 = a1 * r1, s2 = a2 * r2;
+    float lo = fminf(s1, s2), hi = fmaxf(s1, s2);
+    float inner = fminf(hi, 1.0f) - fmaxf(lo, 0.0f);
+    float outer = fmaxf(hi, 1.0f) - fminf(lo, 0.0f);
+    float rmax = fmaxf(fabsf(r1), fabsf(r2));
+    float t = __builtin_fmaf(-kKappa, rmax, thr - kKappa0);
+    float u = __builtin_fmaf(-t, outer, inner);
+    return !(u <= 0.0f);
+}
+
+}  // namespace
+
+// MODE 0: bounded kNN (top-K rows)   MODE 1: count accepted matches per row (kNN <= 0, pass 1)
+// MODE 2: write every accepted match in ascending target order (kNN <= 0, pass 2)
+// BRUTE: skip the pre-filter (every pair goes through the exact test) -- on-GPU check that the
+//        pre-filter never loses a match.
+template <int MODE, bool BRUTE>
+__global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __restrict__ views,
+                                                           const PairDesc* __restrict__ pairs,
+                                                           const WorkItem* __restrict__ work, uint32_t nwork,
+                                                           Slot* __restrict__ slots,
+                                                           uint32_t* __restrict__ row_counts, float thr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // XCD-aware order: consecutive work items (same pair => same target view) go to one XCD
+    // (block b runs on XCD b % 8, MI355X_MICROARCH.md), so the target view stays in that XCD's L2.
+    const uint32_t per_xcd = (nwork + 7) / 8;
+    const uint32_t w = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (w >= nwork) return;
+    const WorkItem wi = work[w];
+    const PairDesc& pd = pairs[wi.pair];
+    const ViewDev& vs = views[pd.src];
+    const ViewDev& vt = views[pd.tgt];
+    const uint32_t K = pd.K, Ms = pd.Ms, Mt = pd.Mt;
+    Lds L = carve(smem, MODE == 0 ? K : 0);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    volatile uint32_t* ring = L.ring + wave * kRing;
+    const uint32_t src = wi.src0 + tid;
+    const bool active = src < Ms;
+
+    double F[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) F[i] = pd.F[i];
+
+    // ---- prologue: this lane's two epipolar lines, normalised, image-centre origin, fp32 ----
+    float e1x = 0, e1y = 0, e1z = 0, e2x = 0, e2y = 0, e2z = 0;
+    float thrL = __builtin_inff();   // dead lane: never a candidate
+    if (active) {
+        const float4 s = vs.seg4[src];
+        d3 e1 = mul33(F, d3{(double)s.x, (double)s.y, 1.0});
+        d3 e2 = mul33(F, d3{(double)s.z, (double)s.w, 1.0});
+        double n1 = sqrt(e1.x * e1.x + e1.y * e1.y), n2 = sqrt(e2.x * e2.x + e2.y * e2.y);
+        // a vanishing (ex,ey) makes every intersection invalid in the reference (|z| <= 1e-12 up to
+        // scale); such a row only ever produces NaNs here and is rejected by the exact test.
+        if (n1 > 0.0 && n2 > 0.0) {
+            double cx = (double)vt.cx, cy = (double)vt.cy;
+            e1x = (float)(e1.x / n1); e1y = (float)(e1.y / n1);
+            e1z = (float)((e1.z + (e1.x * cx + e1.y * cy)) / n1);
+            e2x = (float)(e2.x / n2); e2y = (float)(e2.y / n2);
+            e2z = (float)((e2.z + (e2.x * cx + e2.y * cy)) / n2);
+            thrL = thr;
+        }
+    }
+    L.cnt[tid] = 0;
+    L.minov[tid] = thr;
+    L.claim[tid] = kEmpty;
+    uint32_t head = 0, tail = 0;   // wave-uniform ring cursors
+
+    // one exact test per lane on up to 64 queued candidates, then kNN insertion
+    auto drain = [&]() {
+        const uint32_t n = min(64u, tail - head);
+        const bool has = lane < n;
+        const uint32_t ent = ring[(head + lane) & (kRing - 1)];
+        head += n;
+        const uint32_t sl = ent >> 23, tg = ent & 0x7FFFFFu;
+        bool pending = false;
+        PairResult res{};
+        if (has) {
+            const uint32_t sg = wi.src0 + sl;
+            pending = exact_pair(F, vs.seg4[sg], vt.seg4[tg], vs.segx[sg], vt.segx[tg], vs.C, vt.C, thr, res);
+        }
+        // several candidates of one drain may belong to the same row: lowest lane first, so a row
+        // always sees its candidates in ascending target order
+        while (__ballot(pending)) {
+            if (pending) atomicMin((uint32_t*)&L.claim[sl], lane);
+            const bool win = pending && (L.claim[sl] == lane);
+            if (win) {
+                L.claim[sl] = kEmpty;
+                pending = false;
+                const uint32_t c = L.cnt[sl];
+                if (MODE == 1) {
+                    L.cnt[sl] = c + 1;
+                } else if (MODE == 2) {
+                    Slot o;
+                    o.tgt_seg = tg; o.overlap = res.overlap;
+                    o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
+                    o.score3D = 0.0f; o.flags = 0;
+                    if (c < K) slots[pd.slot_off + (uint64_t)(wi.src0 + sl) * K + c] = o;
+                    L.cnt[sl] = c + 1;
+                } else {
+                    volatile float* ov = L.top_ov + (size_t)sl * K;
+                    volatile uint32_t* ix = L.top_ix + (size_t)sl * K;
+                    if (c < K) {
+                        ov[c] = res.overlap; ix[c] = tg;
+                        L.cnt[sl] = c + 1;
+                        if (c + 1 == K) {
+                            float m = res.overlap;
+                            for (uint32_t j = 0; j < K; ++j) m = fminf(m, ov[j]);
+                            L.minov[sl] = m;
+                        }
+                    } else {
+                        // replace the worst entry if the newcomer beats it
+                        uint32_t wj = 0; float wo = ov[0]; uint32_t wx = ix[0];
+                        for (uint32_t j = 1; j < K; ++j) {
+                            const float o = ov[j]; const uint32_t x = ix[j];
+                            if (better(wo, wx, o, x)) { wo = o; wx = x; wj = j; }
+                        }
+                        if (better(res.overlap, tg, wo, wx)) {
+                            ov[wj] = res.overlap; ix[wj] = tg;
+                            float m = res.overlap;
+                            for (uint32_t j = 0; j < K; ++j) m = fminf(m, ov[j]);
+                            L.minov[sl] = m;
+                        }
+                    }
+                }
+            }
+        }
+        // feed the K-th best overlap back into the owning lane's pre-filter threshold
+        if (MODE == 0 && active && thrL < __builtin_inff()) thrL = fmaxf(thr, L.minov[tid]);
+    };
+
+    // ---- main loop: stream the target view through LDS ----
+    const SegF* __restrict__ tf = vt.segf;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t ent_hi = tid << 23;
+    for (uint32_t t0 = 0; t0 < Mt; t0 += kTile) {
+        const uint32_t n = min((uint32_t)kTile, Mt - t0);
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += kBlock) L.tile[i] = *(const float4*)&tf[t0 + i];
+        __syncthreads();
+        uint32_t j = 0;
+        for (; j + 4 <= n; j += 4) {
+            const float4 q0 = L.tile[j], q1 = L.tile[j + 1], q2 = L.tile[j + 2], q3 = L.tile[j + 3];
+            const bool c0 = BRUTE ? active : prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL);
+            const bool c1 = BRUTE ? active : prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL);
+            const bool c2 = BRUTE ? active : prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL);
+            const bool c3 = BRUTE ? active : prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q3, thrL);
+            const uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3);
+            if (m0 | m1 | m2 | m3) {
+                const uint32_t tb = t0 + j;
+                if (c0) ring[(tail + __popcll(m0 & lt_mask)) & (kRing - 1)] = ent_hi | tb;
+                tail += __popcll(m0);
+                if (c1) ring[(tail + __popcll(m1 & lt_mask)) & (kRing - 1)] = ent_hi | (tb + 1);
+                tail += __popcll(m1);
+                if (c2) ring[(tail + __popcll(m2 & lt_mask)) & (kRing - 1)] = ent_hi | (tb + 2);
+                tail += __popcll(m2);
+                if (c3) ring[(tail + __popcll(m3 & lt_mask)) & (kRing - 1)] = ent_hi | (tb + 3);
+                tail += __popcll(m3);
+                while (tail - head >= 64) drain();
+            }
+        }
+        for (; j < n; ++j) {
+            const float4 q0 = L.tile[j];
+            const bool c0 = BRUTE ? active : prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL);
+            const uint64_t m0 = __ballot(c0);
+            if (m0) {
+                if (c0) ring[(tail + __popcll(m0 & lt_mask)) & (kRing - 1)] = ent_hi | (t0 + j);
+                tail += __popcll(m0);
+                while (tail - head >= 64) drain();
+            }
+        }
+    }
+    while (tail != head) drain();
+
+    // ---- epilogue ----
+    if (!active) return;
+    const uint32_t c = L.cnt[tid];
+    if (MODE == 1) {
+        row_counts[pd.row_off + src] = c;
+        return;
+    }
+    Slot* row = slots + pd.slot_off + (uint64_t)src * K;
+    Slot empty;
+    empty.tgt_seg = kEmpty; empty.overlap = 0; empty.dp1 = empty.dp2 = empty.dq1 = empty.dq2 = 0;
+    empty.score3D = 0; empty.flags = 0;
+    if (MODE == 2) {
+        for (uint32_t j = min(c, K); j < K; ++j) row[j] = empty;
+        return;
+    }
+    // rank the winners by (overlap desc, tgt asc) and recompute their depths (identical arithmetic
+    // to the acceptance test, so identical values)
+    volatile float* ov = L.top_ov + (size_t)tid * K;
+    volatile uint32_t* ix = L.top_ix + (size_t)tid * K;
+    const float4 s4 = vs.seg4[src];
+    const SegX sx = vs.segx[src];
+    for (uint32_t j = 0; j < c; ++j) {
+        const float oj = ov[j]; const uint32_t xj = ix[j];
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < c; ++i) rank += better(ov[i], ix[i], oj, xj) ? 1u : 0u;
+        PairResult res{};
+        exact_pair(F, s4, vt.seg4[xj], sx, vt.segx[xj], vs.C, vt.C, thr, res);
+        Slot o;
+        o.tgt_seg = xj; o.overlap = res.overlap;
+        o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
+        o.score3D = 0.0f; o.flags = 0;
+        row[rank] = o;
+    }
+    for (uint32_t j = c; j < K; ++j) row[j] = empty;
+}
+
+size_t match_lds_bytes(int mode, uint32_t K) {
+    return sizeof(float4) * kTile + 4 * kRing * 4 + 3 * kBlock * 4 + (mode == 0 ? (size_t)kBlock * K * 8 : 0);
+}
+
+hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,
+                              const WorkItem* work, uint32_t nwork, uint32_t maxK, Slot* slots,
+                              uint32_t* row_counts, float thr, hipStream_t stream) {
+    if (nwork == 0) return hipSuccess;
+    const uint32_t grid = ((nwork + 7) / 8) * 8;
+    const size_t lds = match_lds_bytes(mode, maxK);
+#define L3D_LAUNCH(M, B)                                                                                  \
+    do {                                                                                                  \
+        hipError_t e = hipFuncSetAttribute((const void*)k_match_pairs<M, B>,                              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        if (e != hipSuccess) return e;                                                                    \
+        hipLaunchKernelGGL((k_match_pairs<M, B>), dim3(grid), dim3(kBlock), lds, stream, views, pairs,    \
+                           work, nwork, slots, row_counts, thr);                                          \
+    } while (0)
+    if (mode == 0) { if (brute) L3D_LAUNCH(0, true); else L3D_LAUNCH(0, false); }
+    else if (mode == 1) { if (brute) L3D_LAUNCH(1, true); else L3D_LAUNCH(1, false); }
+    else { if (brute) L3D_LAUNCH(2, true); else L3D_LAUNCH(2, false); }
+#undef L3D_LAUNCH
+    return hipGetLastError();
+}
+
+// ---- per-view precompute (after translate) ---------------------------------------------------
+__global__ void k_prep_view(const float4* __restrict__ seg4, uint32_t M, const double* __restrict__ consts,
+                            SegX* __restrict__ segx, SegF* __restrict__ segf, float cx, float cy) {
+    // consts: RtKinv[9], C[3]
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    double A[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) A[k] = consts[k];
+    const d3 C{consts[9], consts[10], consts[11]};
+    const float4 s = seg4[i];
+    const double ax = s.x, ay = s.y, bx = s.z, by = s.w;
+    const d3 r1 = normalized(mul33(A, d3{ax, ay, 1.0}));
+    const d3 r2 = normalized(mul33(A, d3{bx, by, 1.0}));
+    const d3 n = normalized(cross(r1, r2));
+    const d3 rm = normalized(mul33(A, d3{0.5 * (ax + bx), 0.5 * (ay + by), 1.0}));
+    SegX o;
+    o.r1[0] = r1.x; o.r1[1] = r1.y; o.r1[2] = r1.z;
+    o.r2[0] = r2.x; o.r2[1] = r2.y; o.r2[2] = r2.z;
+    o.n[0] = n.x; o.n[1] = n.y; o.n[2] = n.z;
+    o.cn = dot(C, n);
+    o.rm[0] = rm.x; o.rm[1] = rm.y; o.rm[2] = rm.z;
+    segx[i] = o;
+    SegF f;
+    f.qx = (float)(ax - (double)cx); f.qy = (float)(ay - (double)cy);
+    f.dx = (float)(ax - bx); f.dy = (float)(ay - by);
+    segf[i] = f;
+}
+
+hipError_t launch_prep_view(const float4* seg4, uint32_t M, const double* consts_dev, SegX* segx, SegF* segf,
+                            float cx, float cy, hipStream_t stream) {
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prep_view, dim3((M + 255) / 256), dim3(256), 0, stream, seg4, M, consts_dev, segx, segf,
+                       cx, cy);
+    return hipGetLastError();
+}
+
+}  // namespace l3d

@@ -1,0 +1,800 @@
+// l3d_api.hip -- C-ABI entry points of libl3dpp_hip.so (include/l3dpp_hip.h) and the host-side
+// driver that mirrors Line3D::addImage / matchImages / computingAffinityMatrix
+// (line3D.cc:112-227, 375-497, 702-778, 1749-1778, 1852-1979).  No CPU fallback exists: every
+// compute step is a HIP kernel launch; without a usable device the calls fail with L3D_ERR_HIP.
+#include <algorithm>
+#include <memory>
+#include <mutex>
+
+#include "l3d_host.h"
+
+namespace l3d {
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+
+// ---- prototypes of the launchers in k_views.hip / k_affinity.hip -------------------------------
+hipError_t launch_list_count(const ViewDev*, const PairDesc*, uint32_t pair, uint64_t nslots, int outgoing, Slot*,
+                             uint32_t* cnt, hipStream_t);
+hipError_t launch_list_fill(const PairDesc*, uint32_t pair, uint64_t nslots, int outgoing, const Slot*,
+                            const uint32_t* off, uint32_t* cur, Entry*, hipStream_t);
+hipError_t launch_zero_u32(uint32_t*, uint64_t n, hipStream_t);
+hipError_t launch_scan(const uint32_t* cnt, uint32_t n, uint32_t* off, uint32_t* total, hipStream_t);
+hipError_t launch_entry_prep(const ViewDev*, uint32_t vi, const Entry*, const uint32_t* off, uint32_t n, DEntry*,
+                             hipStream_t);
+hipError_t launch_score(const uint32_t* off, uint32_t M, DEntry*, Slot*, uint32_t* max_score_bits,
+                        float two_sigA_sqr, float min_sim, hipStream_t);
+hipError_t launch_filter(const uint32_t* off, uint32_t M, DEntry*, const uint32_t* max_score_bits,
+                         uint32_t* surv_cnt, uint32_t* has_best, uint32_t* best_pos, hipStream_t);
+hipError_t launch_filter_write(const ViewDev*, uint32_t vi, const uint32_t* off, uint32_t M, const DEntry*,
+                               const uint32_t* surv_off, const uint32_t* hyp_off, const uint32_t* best_pos,
+                               Match* surv, uint32_t* surv_tv, int32_t* hyp_index, uint32_t hyp_base, HypRec*,
+                               float* depths, hipStream_t);
+hipError_t launch_median_depth(const float* depths, const uint32_t* n_hyp_ptr, float* out, hipStream_t);
+hipError_t launch_aff_sim(const ViewAff*, uint32_t V, uint32_t N, const HypRec*, const float* msdl,
+                          float two_sigA_sqr, float* simv, int32_t* ca, int32_t* cb, hipStream_t);
+hipError_t launch_aff_flag(const ViewAff*, uint32_t V, uint32_t N, const float* simv, const int32_t* ca,
+                           const int32_t* cb, uint32_t* flag, hipStream_t);
+hipError_t launch_fill_u32(uint32_t*, uint32_t n, uint32_t val, hipStream_t);
+hipError_t launch_aff_touch(uint32_t N, const uint32_t* flag, const uint32_t* epos, const int32_t* ca,
+                            const int32_t* cb, uint32_t* first_touch, hipStream_t);
+hipError_t launch_aff_mark(uint32_t H, const uint32_t* first_touch, uint32_t* touch_flag, hipStream_t);
+hipError_t launch_aff_emit(uint32_t N, const uint32_t* flag, const uint32_t* epos, const int32_t* ca,
+                           const int32_t* cb, const float* simv, const uint32_t* first_touch,
+                           const uint32_t* touch_rank, const HypRec*, void* edges, void* local2global, hipStream_t);
+
+}  // namespace l3d
+
+using namespace l3d;
+
+struct l3d_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;                                  // view_mutex_/view_reserve_mutex_ stand-in
+    std::map<uint32_t, std::unique_ptr<HostView>> views;   // views_ (ascending camID)
+    std::vector<HostView*> order;                   // view index -> view (ascending camID)
+    std::vector<float> views_avg_depths;            // views_avg_depths_
+    // params (matchImages)
+    float sigma_p = 2.5f, sigma_a = 10.0f, two_sigA_sqr = 200.0f, epipolar_overlap = 0.25f;
+    float const_regularization_depth = -1.0f, med_scene_depth = (float)kEps, med_scene_depth_lines = 0.0f;
+    int kNN = 10, num_neighbors = 10;
+    bool fixed3Dregularizer = false;
+    bool brute = false;                             // test hook: disable the fp32 pre-filter
+    d3 translation{0, 0, 0};
+    // state
+    enum { IDLE, BEGUN, MATCHED } state = IDLE;
+    bool affinity_done = false;
+    std::vector<PairDesc> pairs;
+    std::vector<uint32_t> pair_src_cam, pair_tgt_cam;
+    std::vector<char> pair_done;
+    uint64_t n_slots = 0, pair_tests = 0;
+    uint32_t n_rows_total = 0;
+    // device
+    DevBuf<ViewDev> d_views;
+    DevBuf<PairDesc> d_pairs;
+    DevBuf<WorkItem> d_work;
+    DevBuf<Slot> d_slots;
+    DevBuf<uint32_t> d_row_counts;
+    DevBuf<double> d_consts;                        // per view: RtKinv[9], C[3]
+    // phase-B scratch
+    DevBuf<uint32_t> d_cnt, d_off, d_cur, d_surv_cnt, d_has_best, d_best_pos, d_surv_off_tmp, d_hyp_off, d_scal;
+    DevBuf<Entry> d_ents;
+    DevBuf<DEntry> d_dents;
+    DevBuf<float> d_depths, d_medians;              // d_medians[V]
+    DevBuf<HypRec> d_hyps;
+    uint32_t n_hyps = 0;
+    // affinity
+    DevBuf<ViewAff> d_vaff;
+    DevBuf<float> d_simv, d_msdl;
+    DevBuf<int32_t> d_ca, d_cb;
+    DevBuf<uint32_t> d_flag, d_epos, d_first_touch, d_touch_flag, d_touch_rank, d_aff_scal;
+    DevBuf<l3d_cledge> d_edges;
+    DevBuf<l3d_segment2d> d_l2g;
+    std::vector<l3d_cledge> edges;
+    std::vector<l3d_segment2d> l2g;
+    // per-view surviving-match target-view arrays
+    std::vector<DevBuf<uint32_t>*> surv_tv;
+    // timings
+    hipEvent_t ev[8] = {};
+    l3d_timings tm{};
+};
+
+namespace {
+
+int fail(int code, const std::string& msg) { set_error(msg); return code; }
+
+// View::View, view.cc:6-42
+void init_view(HostView& v, const double K[9], const double R[9], const double t[3]) {
+    std::memcpy(v.K.m, K, 72);
+    std::memcpy(v.R.m, R, 72);
+    v.t = d3{t[0], t[1], t[2]};
+    v.pp = d3{v.K.m[2], v.K.m[5], 1.0};
+    v.Kinv = m3_inv(v.K);
+    v.Rt = m3_t(v.R);
+    v.RtKinv = m3_mul(v.Rt, v.Kinv);
+    v.C = mul33(v.Rt.m, d3{-1.0 * v.t.x, -1.0 * v.t.y, -1.0 * v.t.z});
+}
+
+// View::translate, view.cc:510-514
+void translate_view(HostView& v, const d3& d) {
+    v.C = v.C + d;
+    const d3 rc = mul33(v.R.m, v.C);
+    v.t = d3{-rc.x, -rc.y, -rc.z};
+}
+
+// Line3D::translate, line3D.cc:500-536
+void translate(l3d_ctx& c) {
+    double tr[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i) {
+        std::vector<double> coords;
+        for (auto* v : c.order) {
+            const double val = i == 0 ? v->C.x : (i == 1 ? v->C.y : v->C.z);
+            if (std::fabs(val) > kEps) coords.push_back(val);
+        }
+        if (!coords.empty()) {
+            std::sort(coords.begin(), coords.end());
+            tr[i] = coords[coords.size() / 2];
+        }
+    }
+    c.translation = d3{tr[0], tr[1], tr[2]};
+    for (auto* v : c.order) translate_view(*v, d3{-tr[0], -tr[1], -tr[2]});
+}
+void untranslate(l3d_ctx& c) {  // line3D.cc:539-545
+    for (auto* v : c.order) translate_view(*v, c.translation);
+}
+
+// View::getSpecificSpatialReg, view.cc:307-314
+float spatial_reg(const HostView& v, float r) {
+    const d3 a = normalized(mul33(v.RtKinv.m, v.pp));
+    const d3 b = normalized(mul33(v.RtKinv.m, v.pp + d3{(double)r, 0.0, 0.0}));
+    const double alpha = std::acos(std::fmin(std::fmax(dot(a, b), -1.0), 1.0));
+    return (float)std::sin(alpha);
+}
+
+// Line3D::getFundamentalMatrix, line3D.cc:874-892
+void fundamental(const HostView& s, const HostView& t, double F[9]) {
+    const M3 R = m3_mul(t.R, m3_t(s.R));
+    const d3 Rt1 = mul33(R.m, s.t);
+    const d3 tt = t.t - Rt1;
+    const M3 T{{0.0, -tt.z, tt.y, tt.z, 0.0, -tt.x, -tt.y, tt.x, 0.0}};
+    const M3 E = m3_mul(T, R);
+    const M3 Fm = m3_mul(m3_mul(m3_inv(m3_t(t.K)), E), m3_inv(s.K));
+    std::memcpy(F, Fm.m, 72);
+}
+
+int upload_views(l3d_ctx& c) {
+    const size_t V = c.order.size();
+    L3D_HIP_CHECK(c.d_views.reserve(V));
+    L3D_HIP_CHECK(c.d_consts.reserve(V * 12));
+    std::vector<ViewDev> hv(V);
+    std::vector<double> consts(V * 12);
+    for (size_t i = 0; i < V; ++i) {
+        HostView& v = *c.order[i];
+        ViewDev& d = hv[i];
+        d.C[0] = v.C.x; d.C[1] = v.C.y; d.C[2] = v.C.z;
+        std::memcpy(d.RtKinv, v.RtKinv.m, 72);
+        d.seg4 = v.d_seg4.p; d.segf = v.d_segf.p; d.segx = v.d_segx.p;
+        d.M = v.M; d.cam = v.cam; d.k = v.k;
+        d.cx = 0.5f * (float)v.width; d.cy = 0.5f * (float)v.height; d.pad = 0;
+        std::memcpy(&consts[12 * i], v.RtKinv.m, 72);
+        consts[12 * i + 9] = v.C.x; consts[12 * i + 10] = v.C.y; consts[12 * i + 11] = v.C.z;
+    }
+    L3D_HIP_CHECK(hipMemcpyAsync(c.d_views.p, hv.data(), V * sizeof(ViewDev), hipMemcpyHostToDevice, c.stream));
+    L3D_HIP_CHECK(hipMemcpyAsync(c.d_consts.p, consts.data(), consts.size() * 8, hipMemcpyHostToDevice, c.stream));
+    L3D_HIP_CHECK(hipStreamSynchronize(c.stream));  // host staging vectors go out of scope
+    for (size_t i = 0; i < V; ++i) {
+        HostView& v = *c.order[i];
+        L3D_HIP_CHECK(launch_prep_view(v.d_seg4.p, v.M, c.d_consts.p + 12 * i, v.d_segx.p, v.d_segf.p,
+                                       0.5f * (float)v.width, 0.5f * (float)v.height, c.stream));
+    }
+    return L3D_OK;
+}
+
+float ev_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* l3d_last_error(void) { return g_err.c_str(); }
+const char* l3d_build_info(void) { return "libl3dpp_hip gfx950 hip fp-contract=off"; }
+
+l3d_ctx* l3d_create(int device, void* stream) {
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed: no usable HIP device"); return nullptr; }
+    auto* c = new l3d_ctx();
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); delete c; return nullptr; }
+    return c;
+}
+
+void l3d_destroy(l3d_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->views) {
+        HostView& v = *kv.second;
+        v.d_seg4.release(); v.d_segf.release(); v.d_segx.release();
+        v.d_surv_off.release(); v.d_surv.release(); v.d_hyp.release();
+    }
+    for (auto* b : c->surv_tv) { b->release(); delete b; }
+    c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release();
+    c->d_row_counts.release(); c->d_consts.release(); c->d_cnt.release(); c->d_off.release();
+    c->d_cur.release(); c->d_surv_cnt.release(); c->d_has_best.release(); c->d_best_pos.release();
+    c->d_surv_off_tmp.release(); c->d_hyp_off.release(); c->d_scal.release(); c->d_ents.release();
+    c->d_dents.release(); c->d_depths.release(); c->d_medians.release(); c->d_hyps.release();
+    c->d_vaff.release(); c->d_simv.release(); c->d_msdl.release(); c->d_ca.release(); c->d_cb.release();
+    c->d_flag.release(); c->d_epos.release(); c->d_first_touch.release(); c->d_touch_flag.release();
+    c->d_touch_rank.release(); c->d_aff_scal.release(); c->d_edges.release(); c->d_l2g.release();
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int l3d_set_brute_force(l3d_ctx* c, int on) {  // test hook (not in the public header's main flow)
+    if (!c) return L3D_ERR_ARG;
+    c->brute = on != 0;
+    return L3D_OK;
+}
+
+int l3d_add_view(l3d_ctx* c, uint32_t camID, const float* segs4, uint32_t M, const double K[9], const double R[9],
+                 const double t[3], uint32_t width, uint32_t height, float median_depth, const uint32_t* neighbors,
+                 uint32_t n_neighbors) {
+    if (!c || !K || !R || !t) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (std::max(width, height) < 800) return fail(L3D_ERR_IMAGE_SMALL, "image is too small for reliable results");
+    if (c->views.count(camID)) return fail(L3D_ERR_ID_IN_USE, "camera ID already in use");
+    if (n_neighbors == 0 || !neighbors) return fail(L3D_ERR_NO_NEIGHBORS, "view has no visual neighbors");
+    if (M == 0 || !segs4) return fail(L3D_ERR_NO_SEGMENTS, "no line segments");
+    if (M >= (1u << 23)) return fail(L3D_ERR_LIMIT, "more than 2^23 segments per view");
+    (void)hipSetDevice(c->device);
+    auto v = std::make_unique<HostView>();
+    v->cam = camID; v->M = M;
+    v->segs.assign(segs4, segs4 + 4 * (size_t)M);
+    v->width = width; v->height = height;
+    v->initial_median_depth = (float)std::fmax(std::fabs(median_depth), kEps);
+    init_view(*v, K, R, t);
+    v->fixed_nbrs.assign(neighbors, neighbors + n_neighbors);
+    L3D_HIP_CHECK(v->d_seg4.reserve(M));
+    L3D_HIP_CHECK(v->d_segf.reserve(M));
+    L3D_HIP_CHECK(v->d_segx.reserve(M));
+    L3D_HIP_CHECK(hipMemcpy(v->d_seg4.p, v->segs.data(), (size_t)M * 16, hipMemcpyHostToDevice));
+    c->views_avg_depths.push_back((float)std::fmax(median_depth, kEps));
+    c->views[camID] = std::move(v);
+    c->order.clear();
+    for (auto& kv : c->views) { kv.second->index = (uint32_t)c->order.size(); c->order.push_back(kv.second.get()); }
+    c->state = l3d_ctx::IDLE;
+    c->affinity_done = false;
+    return L3D_OK;
+}
+
+int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
+    if (!c || !p) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->views.empty()) return fail(L3D_ERR_NO_VIEWS, "no images to match");
+    (void)hipSetDevice(c->device);
+    // parameter clamps, line3D.cc:394-413
+    c->num_neighbors = std::max(int(p->num_neighbors), 2);
+    c->sigma_p = p->sigma_position;
+    c->sigma_a = std::fmin(std::fabs(p->sigma_angle), 90.0f);
+    c->two_sigA_sqr = 2.0f * c->sigma_a * c->sigma_a;
+    c->epipolar_overlap = std::fmin(std::fabs(p->epipolar_overlap), 0.99f);
+    c->kNN = p->kNN;
+    c->const_regularization_depth = p->const_regularization_depth;
+    if (c->sigma_p < 0.0f) { c->fixed3Dregularizer = true; c->sigma_p = std::fabs(c->sigma_p); }
+    else { c->fixed3Dregularizer = false; c->sigma_p = std::fmax(0.1f, c->sigma_p); }
+    if (c->kNN > 4096) return fail(L3D_ERR_LIMIT, "kNN > 4096");
+    c->affinity_done = false;
+    c->n_hyps = 0;
+    // line3D.cc:426-433
+    c->med_scene_depth = c->const_regularization_depth;
+    if (c->const_regularization_depth < 0.0f && c->fixed3Dregularizer && !c->views_avg_depths.empty()) {
+        std::sort(c->views_avg_depths.begin(), c->views_avg_depths.end());
+        c->med_scene_depth = c->views_avg_depths[c->views_avg_depths.size() / 2];
+    }
+    L3D_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
+    translate(*c);
+    for (auto* v : c->order) {
+        if (!c->fixed3Dregularizer) v->k = spatial_reg(*v, c->sigma_p);      // computeSpatialRegularizer
+        else v->k = c->sigma_p / c->med_scene_depth;                          // update_k, view.h:124-127
+        v->median_depth = 0.0f;
+        v->n_surv = 0; v->n_hyp = 0;
+        v->out_pairs.clear(); v->in_pairs.clear();
+    }
+    // fixed neighbours, line3D.cc:467-479 (sets persist across calls like visual_neighbors_)
+    for (auto* v : c->order)
+        if (v->visual_nbrs.empty())
+            for (uint32_t n : v->fixed_nbrs)
+                if (c->views.count(n)) v->visual_nbrs.insert(n);
+    // directed pair list, line3D.cc:704-741
+    c->pairs.clear(); c->pair_src_cam.clear(); c->pair_tgt_cam.clear();
+    std::map<uint32_t, std::set<uint32_t>> matched;
+    uint64_t slot_off = 0; uint32_t row_off = 0;
+    c->pair_tests = 0;
+    for (auto* v : c->order)
+        for (uint32_t tcam : v->visual_nbrs) {
+            if (matched[v->cam].count(tcam)) continue;
+            HostView* t = c->views[tcam].get();
+            PairDesc pd;
+            fundamental(*v, *t, pd.F);
+            pd.src = v->index; pd.tgt = t->index; pd.Ms = v->M; pd.Mt = t->M;
+            pd.K = c->kNN > 0 ? (uint32_t)c->kNN : 0u;
+            pd.row_off = row_off; pd.slot_off = slot_off;
+            slot_off += (uint64_t)pd.Ms * pd.K; row_off += pd.Ms;
+            const uint32_t pi = (uint32_t)c->pairs.size();
+            v->out_pairs.push_back(pi);
+            if (t->index > v->index) t->in_pairs.push_back(pi);   // inverse only if tgt not yet processed (:1680)
+            c->pairs.push_back(pd);
+            c->pair_src_cam.push_back(v->cam); c->pair_tgt_cam.push_back(tcam);
+            c->pair_tests += (uint64_t)pd.Ms * pd.Mt;
+            matched[v->cam].insert(tcam); matched[tcam].insert(v->cam);
+        }
+    c->n_slots = slot_off; c->n_rows_total = row_off;
+    c->pair_done.assign(c->pairs.size(), 0);
+    int rc = upload_views(*c);
+    if (rc) return rc;
+    L3D_HIP_CHECK(c->d_pairs.reserve(std::max<size_t>(c->pairs.size(), 1)));
+    if (!c->pairs.empty())
+        L3D_HIP_CHECK(hipMemcpy(c->d_pairs.p, c->pairs.data(), c->pairs.size() * sizeof(PairDesc),
+                                hipMemcpyHostToDevice));
+    if (c->kNN > 0) L3D_HIP_CHECK(c->d_slots.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    L3D_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
+    c->tm = l3d_timings{};
+    c->state = l3d_ctx::BEGUN;
+    return L3D_OK;
+}
+
+int l3d_num_pairs(l3d_ctx* c, uint32_t* n) {
+    if (!c || !n) return fail(L3D_ERR_ARG, "null argument");
+    *n = (uint32_t)c->pairs.size();
+    return L3D_OK;
+}
+
+int l3d_get_pairs(l3d_ctx* c, uint32_t* s, uint32_t* t, uint64_t* off) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    for (size_t i = 0; i < c->pairs.size(); ++i) {
+        if (s) s[i] = c->pair_src_cam[i];
+        if (t) t[i] = c->pair_tgt_cam[i];
+        if (off) off[i] = c->pairs[i].slot_off;
+    }
+    return L3D_OK;
+}
+
+static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count) {
+    std::vector<WorkItem> work;
+    uint32_t maxK = 0;
+    for (uint32_t p = first; p < first + count; ++p) {
+        const PairDesc& pd = c->pairs[p];
+        maxK = std::max(maxK, pd.K);
+        for (uint32_t s0 = 0; s0 < pd.Ms; s0 += 256) work.push_back(WorkItem{p, s0});
+    }
+    if (work.empty()) return L3D_OK;
+    if (match_lds_bytes(mode, maxK) > 160 * 1024) return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
+    L3D_HIP_CHECK(c->d_work.reserve(work.size()));
+    L3D_HIP_CHECK(hipMemcpyAsync(c->d_work.p, work.data(), work.size() * sizeof(WorkItem), hipMemcpyHostToDevice,
+                                 c->stream));
+    L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
+    L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
+    L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)work.size(),
+                                     maxK, c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, c->stream));
+    L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));
+    L3D_HIP_CHECK(hipEventSynchronize(c->ev[5]));
+    c->tm.match_kernel_ms += ev_ms(c->ev[4], c->ev[5]);
+    c->tm.match_kernel_launches += 1;
+    return L3D_OK;
+}
+
+int l3d_match_pairs(l3d_ctx* c, uint32_t first, uint32_t count) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->state != l3d_ctx::BEGUN) return fail(L3D_ERR_STATE, "l3d_match_begin must precede l3d_match_pairs");
+    if ((uint64_t)first + count > c->pairs.size()) return fail(L3D_ERR_ARG, "pair range out of bounds");
+    (void)hipSetDevice(c->device);
+    L3D_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+    int rc = L3D_OK;
+    if (c->kNN > 0) {
+        rc = run_match_kernel(c, 0, first, count);
+    } else {
+        // kNN <= 0: keep every accepted match (line3D.cc:987-992): count, size the rows, fill
+        if (first != 0 || count != c->pairs.size())
+            return fail(L3D_ERR_LIMIT, "kNN <= 0 needs all pairs in one l3d_match_pairs call");
+        L3D_HIP_CHECK(c->d_row_counts.reserve(std::max<uint32_t>(c->n_rows_total, 1)));
+        rc = run_match_kernel(c, 1, first, count);
+        if (rc) return rc;
+        std::vector<uint32_t> counts(c->n_rows_total);
+        L3D_HIP_CHECK(hipMemcpy(counts.data(), c->d_row_counts.p, counts.size() * 4, hipMemcpyDeviceToHost));
+        uint64_t slot_off = 0;
+        for (auto& pd : c->pairs) {
+            uint32_t k = 1;
+            for (uint32_t r = 0; r < pd.Ms; ++r) k = std::max(k, counts[pd.row_off + r]);
+            pd.K = k; pd.slot_off = slot_off;
+            slot_off += (uint64_t)pd.Ms * k;
+        }
+        c->n_slots = slot_off;
+        L3D_HIP_CHECK(c->d_slots.reserve(std::max<uint64_t>(c->n_slots, 1)));
+        L3D_HIP_CHECK(hipMemcpy(c->d_pairs.p, c->pairs.data(), c->pairs.size() * sizeof(PairDesc),
+                                hipMemcpyHostToDevice));
+        rc = run_match_kernel(c, 2, first, count);
+    }
+    if (rc) return rc;
+    L3D_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    L3D_HIP_CHECK(hipEventSynchronize(c->ev[3]));
+    c->tm.match_pairs_ms += ev_ms(c->ev[2], c->ev[3]);
+    for (uint32_t p = first; p < first + count; ++p) c->pair_done[p] = 1;
+    return L3D_OK;
+}
+
+int l3d_slot_buffer(l3d_ctx* c, void** dev_ptr, uint64_t* n_slots) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    if (dev_ptr) *dev_ptr = c->d_slots.p;
+    if (n_slots) *n_slots = c->n_slots;
+    return L3D_OK;
+}
+
+// phase B: line3D.cc:745-773 for every view in ascending camID order
+int l3d_match_finish(l3d_ctx* c) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->state != l3d_ctx::BEGUN) return fail(L3D_ERR_STATE, "l3d_match_begin must precede l3d_match_finish");
+    (void)hipSetDevice(c->device);
+    hipStream_t st = c->stream;
+    const size_t V = c->order.size();
+    // scratch sizes
+    uint32_t maxM = 0; uint64_t max_ents = 0, total_hyp_cap = 0;
+    for (auto* v : c->order) {
+        maxM = std::max(maxM, v->M);
+        uint64_t e = 0;
+        for (uint32_t p : v->out_pairs) e += (uint64_t)c->pairs[p].Ms * c->pairs[p].K;
+        for (uint32_t p : v->in_pairs) e += (uint64_t)c->pairs[p].Ms * c->pairs[p].K;
+        max_ents = std::max(max_ents, e);
+        total_hyp_cap += v->M;
+    }
+    if (max_ents >= (1ull << 32)) return fail(L3D_ERR_LIMIT, "more than 2^32 hypotheses in one view");
+    L3D_HIP_CHECK(c->d_cnt.reserve(maxM + 1)); L3D_HIP_CHECK(c->d_off.reserve(maxM + 1));
+    L3D_HIP_CHECK(c->d_cur.reserve(maxM + 1)); L3D_HIP_CHECK(c->d_surv_cnt.reserve(maxM + 1));
+    L3D_HIP_CHECK(c->d_has_best.reserve(maxM + 1)); L3D_HIP_CHECK(c->d_best_pos.reserve(maxM + 1));
+    L3D_HIP_CHECK(c->d_surv_off_tmp.reserve(maxM + 1)); L3D_HIP_CHECK(c->d_hyp_off.reserve(maxM + 1));
+    L3D_HIP_CHECK(c->d_scal.reserve(4 * V + 4));   // per view: n_ents, max_score_bits, n_surv, n_hyp
+    L3D_HIP_CHECK(c->d_ents.reserve(std::max<uint64_t>(max_ents, 1)));
+    L3D_HIP_CHECK(c->d_dents.reserve(std::max<uint64_t>(max_ents, 1)));
+    L3D_HIP_CHECK(c->d_depths.reserve(2 * (size_t)maxM + 2));
+    L3D_HIP_CHECK(c->d_medians.reserve(V));
+    L3D_HIP_CHECK(c->d_hyps.reserve(std::max<uint64_t>(total_hyp_cap, 1)));
+    while (c->surv_tv.size() < V) c->surv_tv.push_back(new DevBuf<uint32_t>());
+    L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
+    L3D_HIP_CHECK(hipMemsetAsync(c->d_scal.p, 0, (4 * V + 4) * 4, st));
+    uint32_t hyp_base = 0;
+    for (size_t vi = 0; vi < V; ++vi) {
+        HostView& v = *c->order[vi];
+        uint32_t* scal = c->d_scal.p + 4 * vi;
+        L3D_HIP_CHECK(hipMemsetAsync(c->d_cnt.p, 0, (v.M + 1) * 4, st));
+        L3D_HIP_CHECK(hipMemsetAsync(c->d_cur.p, 0, (v.M + 1) * 4, st));
+        for (uint32_t p : v.in_pairs)
+            L3D_HIP_CHECK(launch_list_count(c->d_views.p, c->d_pairs.p, p, (uint64_t)c->pairs[p].Ms * c->pairs[p].K, 0,
+                                            c->d_slots.p, c->d_cnt.p, st));
+        for (uint32_t p : v.out_pairs)
+            L3D_HIP_CHECK(launch_list_count(c->d_views.p, c->d_pairs.p, p, (uint64_t)c->pairs[p].Ms * c->pairs[p].K, 1,
+                                            c->d_slots.p, c->d_cnt.p, st));
+        L3D_HIP_CHECK(launch_scan(c->d_cnt.p, v.M, c->d_off.p, scal + 0, st));
+        for (uint32_t p : v.in_pairs)
+            L3D_HIP_CHECK(launch_list_fill(c->d_pairs.p, p, (uint64_t)c->pairs[p].Ms * c->pairs[p].K, 0, c->d_slots.p,
+                                           c->d_off.p, c->d_cur.p, c->d_ents.p, st));
+        for (uint32_t p : v.out_pairs)
+            L3D_HIP_CHECK(launch_list_fill(c->d_pairs.p, p, (uint64_t)c->pairs[p].Ms * c->pairs[p].K, 1, c->d_slots.p,
+                                           c->d_off.p, c->d_cur.p, c->d_ents.p, st));
+        // the entry count is needed on the host to size the launches of this view
+        uint32_t n_ents = 0;
+        L3D_HIP_CHECK(hipMemcpyAsync(&n_ents, scal + 0, 4, hipMemcpyDeviceToHost, st));
+        L3D_HIP_CHECK(hipStreamSynchronize(st));
+        L3D_HIP_CHECK(launch_entry_prep(c->d_views.p, (uint32_t)vi, c->d_ents.p, c->d_off.p, n_ents, c->d_dents.p, st));
+        L3D_HIP_CHECK(launch_score(c->d_off.p, v.M, c->d_dents.p, c->d_slots.p, scal + 1, c->two_sigA_sqr, 0.5f, st));
+        L3D_HIP_CHECK(launch_filter(c->d_off.p, v.M, c->d_dents.p, scal + 1, c->d_surv_cnt.p, c->d_has_best.p,
+                                    c->d_best_pos.p, st));
+        L3D_HIP_CHECK(launch_scan(c->d_surv_cnt.p, v.M, c->d_surv_off_tmp.p, scal + 2, st));
+        L3D_HIP_CHECK(launch_scan(c->d_has_best.p, v.M, c->d_hyp_off.p, scal + 3, st));
+        uint32_t ns[2] = {0, 0};
+        L3D_HIP_CHECK(hipMemcpyAsync(ns, scal + 2, 8, hipMemcpyDeviceToHost, st));
+        L3D_HIP_CHECK(hipStreamSynchronize(st));
+        v.n_surv = ns[0]; v.n_hyp = ns[1]; v.hyp_base = hyp_base;
+        L3D_HIP_CHECK(v.d_surv_off.reserve(v.M + 1));
+        L3D_HIP_CHECK(v.d_surv.reserve(std::max<uint32_t>(v.n_surv, 1)));
+        L3D_HIP_CHECK(c->surv_tv[vi]->reserve(std::max<uint32_t>(v.n_surv, 1)));
+        L3D_HIP_CHECK(v.d_hyp.reserve(v.M));
+        L3D_HIP_CHECK(hipMemcpyAsync(v.d_surv_off.p, c->d_surv_off_tmp.p, (v.M + 1) * 4, hipMemcpyDeviceToDevice, st));
+        L3D_HIP_CHECK(launch_filter_write(c->d_views.p, (uint32_t)vi, c->d_off.p, v.M, c->d_dents.p, v.d_surv_off.p,
+                                          c->d_hyp_off.p, c->d_best_pos.p, v.d_surv.p, c->surv_tv[vi]->p, v.d_hyp.p,
+                                          hyp_base, c->d_hyps.p, c->d_depths.p, st));
+        L3D_HIP_CHECK(launch_median_depth(c->d_depths.p, scal + 3, c->d_medians.p + vi, st));
+        hyp_base += v.n_hyp;
+    }
+    c->n_hyps = hyp_base;
+    // View::update_median_depth for every view (line3D.cc:1665-1668); in fixed-regulariser mode k is
+    // re-set to the same sigma_p/med_scene_depth value, so k is unchanged either way
+    std::vector<float> med(V);
+    L3D_HIP_CHECK(hipMemcpyAsync(med.data(), c->d_medians.p, V * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
+    L3D_HIP_CHECK(hipStreamSynchronize(st));
+    for (size_t vi = 0; vi < V; ++vi) c->order[vi]->median_depth = med[vi];
+    c->tm.finish_ms = ev_ms(c->ev[6], c->ev[7]);
+    c->tm.begin_ms = ev_ms(c->ev[0], c->ev[1]);
+    untranslate(*c);   // line3D.cc:493
+    c->state = l3d_ctx::MATCHED;
+    return L3D_OK;
+}
+
+int l3d_match_images(l3d_ctx* c, const l3d_match_params* p) {
+    int rc = l3d_match_begin(c, p);
+    if (rc) return rc;
+    rc = l3d_match_pairs(c, 0, (uint32_t)c->pairs.size());
+    if (rc) return rc;
+    return l3d_match_finish(c);
+}
+
+int l3d_compute_affinity(l3d_ctx* c) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->state != l3d_ctx::MATCHED) return fail(L3D_ERR_STATE, "matchImages must precede the affinity step");
+    (void)hipSetDevice(c->device);
+    hipStream_t st = c->stream;
+    const size_t V = c->order.size();
+    c->edges.clear(); c->l2g.clear();
+    // translate()/untranslate() (line3D.cc:1749,1820) only move camera centres, which the affinity
+    // terms never read; they are applied to keep the host state identical to the reference's.
+    translate(*c);
+    // med_scene_depth_lines_, line3D.cc:1759-1774
+    std::vector<float> sd;
+    for (auto* v : c->order) if (v->median_depth > kEps) sd.push_back(v->median_depth);
+    if (!sd.empty()) { std::sort(sd.begin(), sd.end()); c->med_scene_depth_lines = sd[sd.size() / 2]; }
+    else c->med_scene_depth_lines = 0.0f;
+    std::vector<ViewAff> va(V);
+    uint32_t N = 0;
+    for (size_t vi = 0; vi < V; ++vi) {
+        HostView& v = *c->order[vi];
+        va[vi].surv_off = v.d_surv_off.p; va[vi].surv = v.d_surv.p; va[vi].surv_tv = c->surv_tv[vi]->p;
+        va[vi].hyp = v.d_hyp.p; va[vi].median_depth = c->d_medians.p + vi; va[vi].k = v.k; va[vi].M = v.M;
+        va[vi].cand_base = N; va[vi].pad = 0;
+        N += v.n_surv;
+    }
+    const uint32_t H = c->n_hyps;
+    L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
+    if (N > 0 && H > 0) {
+        L3D_HIP_CHECK(c->d_vaff.reserve(V)); L3D_HIP_CHECK(c->d_msdl.reserve(1));
+        L3D_HIP_CHECK(c->d_simv.reserve(N)); L3D_HIP_CHECK(c->d_ca.reserve(N)); L3D_HIP_CHECK(c->d_cb.reserve(N));
+        L3D_HIP_CHECK(c->d_flag.reserve(N + 1)); L3D_HIP_CHECK(c->d_epos.reserve(N + 1));
+        L3D_HIP_CHECK(c->d_first_touch.reserve(H)); L3D_HIP_CHECK(c->d_aff_scal.reserve(2));
+        L3D_HIP_CHECK(hipMemcpyAsync(c->d_vaff.p, va.data(), V * sizeof(ViewAff), hipMemcpyHostToDevice, st));
+        L3D_HIP_CHECK(hipMemcpyAsync(c->d_msdl.p, &c->med_scene_depth_lines, 4, hipMemcpyHostToDevice, st));
+        L3D_HIP_CHECK(launch_aff_sim(c->d_vaff.p, (uint32_t)V, N, c->d_hyps.p, c->d_msdl.p, c->two_sigA_sqr,
+                                     c->d_simv.p, c->d_ca.p, c->d_cb.p, st));
+        L3D_HIP_CHECK(launch_aff_flag(c->d_vaff.p, (uint32_t)V, N, c->d_simv.p, c->d_ca.p, c->d_cb.p, c->d_flag.p, st));
+        L3D_HIP_CHECK(launch_scan(c->d_flag.p, N, c->d_epos.p, c->d_aff_scal.p, st));
+        uint32_t E = 0;
+        L3D_HIP_CHECK(hipMemcpyAsync(&E, c->d_aff_scal.p, 4, hipMemcpyDeviceToHost, st));
+        L3D_HIP_CHECK(hipStreamSynchronize(st));
+        if (E > 0) {
+            L3D_HIP_CHECK(c->d_touch_flag.reserve(2 * (size_t)E + 1));
+            L3D_HIP_CHECK(c->d_touch_rank.reserve(2 * (size_t)E + 1));
+            L3D_HIP_CHECK(c->d_edges.reserve(2 * (size_t)E));
+            L3D_HIP_CHECK(c->d_l2g.reserve(H));
+            L3D_HIP_CHECK(launch_fill_u32(c->d_first_touch.p, H, kEmpty, st));
+            L3D_HIP_CHECK(hipMemsetAsync(c->d_touch_flag.p, 0, (2 * (size_t)E + 1) * 4, st));
+            L3D_HIP_CHECK(launch_aff_touch(N, c->d_flag.p, c->d_epos.p, c->d_ca.p, c->d_cb.p, c->d_first_touch.p, st));
+            L3D_HIP_CHECK(launch_aff_mark(H, c->d_first_touch.p, c->d_touch_flag.p, st));
+            L3D_HIP_CHECK(launch_scan(c->d_touch_flag.p, 2 * E, c->d_touch_rank.p, c->d_aff_scal.p + 1, st));
+            L3D_HIP_CHECK(launch_aff_emit(N, c->d_flag.p, c->d_epos.p, c->d_ca.p, c->d_cb.p, c->d_simv.p,
+                                          c->d_first_touch.p, c->d_touch_rank.p, c->d_hyps.p, c->d_edges.p,
+                                          c->d_l2g.p, st));
+            uint32_t rows = 0;
+            L3D_HIP_CHECK(hipMemcpyAsync(&rows, c->d_aff_scal.p + 1, 4, hipMemcpyDeviceToHost, st));
+            L3D_HIP_CHECK(hipStreamSynchronize(st));
+            c->edges.resize(2 * (size_t)E);
+            c->l2g.resize(rows);
+            L3D_HIP_CHECK(hipMemcpyAsync(c->edges.data(), c->d_edges.p, c->edges.size() * sizeof(l3d_cledge),
+                                         hipMemcpyDeviceToHost, st));
+            L3D_HIP_CHECK(hipMemcpyAsync(c->l2g.data(), c->d_l2g.p, rows * sizeof(l3d_segment2d),
+                                         hipMemcpyDeviceToHost, st));
+        }
+    }
+    L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
+    L3D_HIP_CHECK(hipStreamSynchronize(st));
+    c->tm.affinity_ms = ev_ms(c->ev[6], c->ev[7]);
+    untranslate(*c);
+    c->affinity_done = true;
+    return L3D_OK;
+}
+
+int l3d_synchronize(l3d_ctx* c) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return L3D_OK;
+}
+
+int l3d_pair_tests(l3d_ctx* c, uint64_t* n) {
+    if (!c || !n) return fail(L3D_ERR_ARG, "null argument");
+    *n = c->pair_tests;
+    return L3D_OK;
+}
+
+int l3d_get_matches(l3d_ctx* c, uint32_t camID, l3d_match* out, uint64_t cap, uint32_t* seg_offsets, uint64_t* n) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    if (c->state != l3d_ctx::MATCHED) return fail(L3D_ERR_STATE, "no matches yet");
+    auto f = c->views.find(camID);
+    if (f == c->views.end()) return fail(L3D_ERR_ARG, "unknown camera ID");
+    HostView& v = *f->second;
+    (void)hipSetDevice(c->device);
+    if (n) *n = v.n_surv;
+    if (seg_offsets)
+        L3D_HIP_CHECK(hipMemcpy(seg_offsets, v.d_surv_off.p, (v.M + 1) * 4, hipMemcpyDeviceToHost));
+    if (out) {
+        const uint64_t m = std::min<uint64_t>(cap, v.n_surv);
+        if (m) L3D_HIP_CHECK(hipMemcpy(out, v.d_surv.p, m * sizeof(l3d_match), hipMemcpyDeviceToHost));
+    }
+    return L3D_OK;
+}
+
+int l3d_get_pair_slots(l3d_ctx* c, uint32_t pi, l3d_slot* out, uint64_t cap, uint32_t* Ms, uint32_t* K) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    if (pi >= c->pairs.size() || !c->pair_done[pi]) return fail(L3D_ERR_STATE, "pair not matched");
+    const PairDesc& pd = c->pairs[pi];
+    if (Ms) *Ms = pd.Ms;
+    if (K) *K = pd.K;
+    (void)hipSetDevice(c->device);
+    if (out) {
+        const uint64_t m = std::min<uint64_t>(cap, (uint64_t)pd.Ms * pd.K);
+        L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (m) L3D_HIP_CHECK(hipMemcpy(out, c->d_slots.p + pd.slot_off, m * sizeof(l3d_slot), hipMemcpyDeviceToHost));
+    }
+    return L3D_OK;
+}
+
+int l3d_num_best(l3d_ctx* c, uint32_t* n) {
+    if (!c || !n) return fail(L3D_ERR_ARG, "null argument");
+    *n = c->state == l3d_ctx::MATCHED ? c->n_hyps : 0;
+    return L3D_OK;
+}
+
+int l3d_get_best(l3d_ctx* c, l3d_segment2d* seg2d, l3d_segment3d* seg3d, l3d_match* best) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    if (c->state != l3d_ctx::MATCHED) return fail(L3D_ERR_STATE, "no matches yet");
+    (void)hipSetDevice(c->device);
+    std::vector<HypRec> h(c->n_hyps);
+    if (c->n_hyps) L3D_HIP_CHECK(hipMemcpy(h.data(), c->d_hyps.p, h.size() * sizeof(HypRec), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); ++i) {
+        if (seg2d) { seg2d[i].camID_ = h[i].m.src_cam; seg2d[i].segID_ = h[i].m.src_seg; }
+        if (seg3d) {
+            std::memcpy(seg3d[i].P1, h[i].P1, 24); std::memcpy(seg3d[i].P2, h[i].P2, 24);
+            std::memcpy(seg3d[i].dir, h[i].dir, 24);
+            seg3d[i].length_ = h[i].length; seg3d[i].valid_ = h[i].valid;
+        }
+        if (best) std::memcpy(&best[i], &h[i].m, sizeof(l3d_match));
+    }
+    return L3D_OK;
+}
+
+int l3d_view_info(l3d_ctx* c, uint32_t camID, float* k, float* median_depth) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    auto f = c->views.find(camID);
+    if (f == c->views.end()) return fail(L3D_ERR_ARG, "unknown camera ID");
+    if (k) *k = f->second->k;
+    if (median_depth) *median_depth = f->second->median_depth;
+    return L3D_OK;
+}
+
+int l3d_translation(l3d_ctx* c, double t[3]) {
+    if (!c || !t) return fail(L3D_ERR_ARG, "null argument");
+    t[0] = c->translation.x; t[1] = c->translation.y; t[2] = c->translation.z;
+    return L3D_OK;
+}
+
+int l3d_num_affinity(l3d_ctx* c, uint32_t* n_edges, uint32_t* n_rows) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    if (!c->affinity_done) return fail(L3D_ERR_STATE, "l3d_compute_affinity has not run");
+    if (n_edges) *n_edges = (uint32_t)c->edges.size();
+    if (n_rows) *n_rows = (uint32_t)c->l2g.size();
+    return L3D_OK;
+}
+
+int l3d_get_affinity(l3d_ctx* c, l3d_cledge* edges, l3d_segment2d* l2g, float* msdl) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    if (!c->affinity_done) return fail(L3D_ERR_STATE, "l3d_compute_affinity has not run");
+    if (edges && !c->edges.empty()) std::memcpy(edges, c->edges.data(), c->edges.size() * sizeof(l3d_cledge));
+    if (l2g && !c->l2g.empty()) std::memcpy(l2g, c->l2g.data(), c->l2g.size() * sizeof(l3d_segment2d));
+    if (msdl) *msdl = c->med_scene_depth_lines;
+    return L3D_OK;
+}
+
+// SparseMatrix::SparseMatrix(entries, n, 1.0f, sort_by_row), sparsematrix.cc:8-60.  std::list::sort is
+// stable, so equal keys keep A_'s order.
+int l3d_get_sparse_matrix(l3d_ctx* c, int sort_by_row, l3d_float4* entries, int32_t* start_indices) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    if (!c->affinity_done) return fail(L3D_ERR_STATE, "l3d_compute_affinity has not run");
+    std::vector<l3d_cledge> e = c->edges;
+    if (sort_by_row)
+        std::stable_sort(e.begin(), e.end(), [](const l3d_cledge& a, const l3d_cledge& b) {
+            return a.i_ < b.i_ || (a.i_ == b.i_ && a.j_ < b.j_); });   // sortCLEdgesByRow, clustering.h
+    else
+        std::stable_sort(e.begin(), e.end(), [](const l3d_cledge& a, const l3d_cledge& b) {
+            return a.j_ < b.j_ || (a.j_ == b.j_ && a.i_ < b.i_); });   // sortCLEdgesByCol
+    if (start_indices) for (size_t i = 0; i < c->l2g.size(); ++i) start_indices[i] = -1;
+    int cur = -1;
+    for (size_t pos = 0; pos < e.size(); ++pos) {
+        if (entries) entries[pos] = l3d_float4{(float)e[pos].i_, (float)e[pos].j_, e[pos].w_, 0.0f};
+        const int rc = sort_by_row ? e[pos].i_ : e[pos].j_;
+        if (rc != cur) { if (start_indices) start_indices[rc] = (int)pos; cur = rc; }
+    }
+    return L3D_OK;
+}
+
+int l3d_get_timings(l3d_ctx* c, l3d_timings* t) {
+    if (!c || !t) return fail(L3D_ERR_ARG, "null argument");
+    *t = c->tm;
+    return L3D_OK;
+}
+
+// seam layer: match_lines_GPU replacement (cudawrapper.h:54-63) with CPU-path semantics
+int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const float* lines_tgt4, uint32_t Mt,
+                    const double F[9], const double RtKinv_src[9], const double RtKinv_tgt[9], const double C_src[3],
+                    const double C_tgt[3], uint32_t width, uint32_t height, float epi_overlap, int32_t kNN,
+                    l3d_slot* out_slots, uint64_t* num_matches) {
+    if (!lines_src4 || !lines_tgt4 || !F || !RtKinv_src || !RtKinv_tgt || !C_src || !C_tgt || !out_slots)
+        return fail(L3D_ERR_ARG, "null argument");
+    if (kNN <= 0) return fail(L3D_ERR_ARG, "l3d_match_lines needs kNN > 0");
+    if (Ms == 0 || Mt == 0) { if (num_matches) *num_matches = 0; return L3D_OK; }
+    if (hipSetDevice(device) != hipSuccess) return fail(L3D_ERR_HIP, "hipSetDevice failed: no usable HIP device");
+    const uint32_t M[2] = {Ms, Mt};
+    const float* lines[2] = {lines_src4, lines_tgt4};
+    const double* A[2] = {RtKinv_src, RtKinv_tgt};
+    const double* Cc[2] = {C_src, C_tgt};
+    DevBuf<float4> seg4[2]; DevBuf<SegF> segf[2]; DevBuf<SegX> segx[2];
+    DevBuf<double> consts; DevBuf<ViewDev> dv; DevBuf<PairDesc> dp; DevBuf<WorkItem> dw; DevBuf<Slot> ds;
+    auto cleanup = [&]() {
+        for (int i = 0; i < 2; ++i) { seg4[i].release(); segf[i].release(); segx[i].release(); }
+        consts.release(); dv.release(); dp.release(); dw.release(); ds.release();
+    };
+    int rc = [&]() -> int {
+        ViewDev hv[2];
+        double hc[24];
+        L3D_HIP_CHECK(consts.reserve(24));
+        for (int i = 0; i < 2; ++i) {
+            L3D_HIP_CHECK(seg4[i].reserve(M[i])); L3D_HIP_CHECK(segf[i].reserve(M[i])); L3D_HIP_CHECK(segx[i].reserve(M[i]));
+            L3D_HIP_CHECK(hipMemcpy(seg4[i].p, lines[i], (size_t)M[i] * 16, hipMemcpyHostToDevice));
+            std::memcpy(hc + 12 * i, A[i], 72); std::memcpy(hc + 12 * i + 9, Cc[i], 24);
+            std::memcpy(hv[i].C, Cc[i], 24); std::memcpy(hv[i].RtKinv, A[i], 72);
+            hv[i].seg4 = seg4[i].p; hv[i].segf = segf[i].p; hv[i].segx = segx[i].p;
+            hv[i].M = M[i]; hv[i].cam = (uint32_t)i; hv[i].k = 0;
+            hv[i].cx = 0.5f * (float)width; hv[i].cy = 0.5f * (float)height; hv[i].pad = 0;
+        }
+        L3D_HIP_CHECK(hipMemcpy(consts.p, hc, sizeof(hc), hipMemcpyHostToDevice));
+        for (int i = 0; i < 2; ++i)
+            L3D_HIP_CHECK(launch_prep_view(seg4[i].p, M[i], consts.p + 12 * i, segx[i].p, segf[i].p, hv[i].cx, hv[i].cy, 0));
+        PairDesc pd;
+        std::memcpy(pd.F, F, 72);
+        pd.src = 0; pd.tgt = 1; pd.Ms = Ms; pd.Mt = Mt; pd.K = (uint32_t)kNN; pd.row_off = 0; pd.slot_off = 0;
+        std::vector<WorkItem> work;
+        for (uint32_t s0 = 0; s0 < Ms; s0 += 256) work.push_back(WorkItem{0, s0});
+        if (match_lds_bytes(0, pd.K) > 160 * 1024) return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
+        L3D_HIP_CHECK(dv.reserve(2)); L3D_HIP_CHECK(dp.reserve(1)); L3D_HIP_CHECK(dw.reserve(work.size()));
+        L3D_HIP_CHECK(ds.reserve((size_t)Ms * pd.K));
+        L3D_HIP_CHECK(hipMemcpy(dv.p, hv, sizeof(hv), hipMemcpyHostToDevice));
+        L3D_HIP_CHECK(hipMemcpy(dp.p, &pd, sizeof(pd), hipMemcpyHostToDevice));
+        L3D_HIP_CHECK(hipMemcpy(dw.p, work.data(), work.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
+        const float thr = std::fmin(std::fabs(epi_overlap), 0.99f);
+        L3D_HIP_CHECK(launch_match_pairs(0, false, dv.p, dp.p, dw.p, (uint32_t)work.size(), pd.K, ds.p, nullptr, thr, 0));
+        L3D_HIP_CHECK(hipDeviceSynchronize());
+        L3D_HIP_CHECK(hipMemcpy(out_slots, ds.p, (size_t)Ms * pd.K * sizeof(Slot), hipMemcpyDeviceToHost));
+        return L3D_OK;
+    }();
+    cleanup();
+    if (rc == L3D_OK && num_matches) {
+        uint64_t n = 0;
+        for (uint64_t i = 0; i < (uint64_t)Ms * (uint32_t)kNN; ++i) n += out_slots[i].tgt_seg != kEmpty;
+        *num_matches = n;
+    }
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,241 @@
+// l3d_dev.h -- shared host/device PODs and double-precision geometry helpers of the HIP path.
+//
+// Arithmetic contract (DESIGN.md §"precision"): everything that decides set membership is
+// evaluated in double exactly as the reference CPU path does (float inputs promoted to double,
+// float where the reference stores float), with the operation order written out here and FMA
+// contraction disabled at compile time (-ffp-contract=off).  fp32 is used only for the
+// conservative pre-filter of the all-pairs loop, never for a value that is stored.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define L3D_HD __host__ __device__ __forceinline__
+
+namespace l3d {
+
+constexpr double kEps = 1e-12;              // L3D_EPS, commons.h:97
+constexpr float kPi_1_32 = 0.098174771f;    // L3D_PI_1_32, commons.h:101
+constexpr float kPi_31_32 = 3.043417886f;   // L3D_PI_31_32, commons.h:102
+constexpr float kMinBestScore3D = 0.75f;    // L3D_DEF_MIN_BEST_SCORE_3D, commons.h:60
+constexpr float kMinBestScorePerc = 0.10f;  // L3D_DEF_MIN_BEST_SCORE_PERC, commons.h:61
+constexpr float kMinAffinity = 0.50f;       // L3D_DEF_MIN_AFFINITY, commons.h:68
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+
+struct d3 { double x, y, z; };
+
+L3D_HD d3 operator+(const d3& a, const d3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+L3D_HD d3 operator-(const d3& a, const d3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+L3D_HD d3 operator*(const d3& a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+// Eigen's unrolled 3-term reduction: a0 + (a1 + a2)
+L3D_HD double dot(const d3& a, const d3& b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+L3D_HD d3 cross(const d3& a, const d3& b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+L3D_HD double norm(const d3& a) { return sqrt(dot(a, a)); }
+L3D_HD d3 normalized(const d3& a) { double n = norm(a); return {a.x / n, a.y / n, a.z / n}; }
+// row-major 3x3 times vector, accumulated left to right
+L3D_HD d3 mul33(const double* A, const d3& v) {
+    return {(A[0] * v.x + A[1] * v.y) + A[2] * v.z, (A[3] * v.x + A[4] * v.y) + A[5] * v.z,
+            (A[6] * v.x + A[7] * v.y) + A[8] * v.z};
+}
+
+// ---- device-resident per-segment records ------------------------------------------------
+// exact (double) invariants of one 2D segment of one view; built by k_prep_view after
+// translate().  rays = normalize(RtKinv * p) (view.cc:317-321); n = normalize(r1 x r2) and
+// cn = C.n are the plane terms Line3D::triangulationDepths (line3D.cc:1180-1191) recomputes
+// for every pair; rm = ray through the segment mid-point (view.cc:466-481).
+struct SegX {
+    double r1[3], r2[3], n[3], cn, rm[3];
+};  // 13 doubles = 104 B
+
+// fp32 pre-filter record of a segment in the target role: end point 1 relative to the image
+// centre and the end-point difference.
+struct __attribute__((aligned(16))) SegF {
+    float qx, qy, dx, dy;
+};
+
+// phase-A / exchange slot (include/l3dpp_hip.h: l3d_slot)
+struct __attribute__((aligned(16))) Slot {
+    uint32_t tgt_seg;
+    float overlap;
+    float dp1, dp2, dq1, dq2;
+    float score3D;
+    uint32_t flags;
+};
+static_assert(sizeof(Slot) == 32, "slot is 32 bytes");
+constexpr uint32_t kSlotAlive = 1u;     // survived the src view's orientation filter
+constexpr uint32_t kSlotInvAlive = 2u;  // inverse (tgt-view) copy survived the tgt view's orientation filter
+
+// reference Match (commons.h:186-203)
+struct Match {
+    uint32_t src_cam, src_seg, tgt_cam, tgt_seg;
+    float overlap, score3D, dp1, dp2, dq1, dq2;
+};
+static_assert(sizeof(Match) == 40, "Match is 40 bytes");
+
+// per-view constants + device pointers (device copy lives in an array indexed by view index)
+struct ViewDev {
+    double C[3];       // camera centre, translated frame
+    double RtKinv[9];
+    const float4* seg4;  // raw segments
+    const SegF* segf;
+    const SegX* segx;
+    uint32_t M;
+    uint32_t cam;
+    float k;           // View::k_
+    float cx, cy;      // image centre used by the fp32 pre-filter
+    uint32_t pad;
+};
+
+// one directed view pair (line3D.cc:719-741)
+struct PairDesc {
+    double F[9];        // getFundamentalMatrix(src,tgt), row-major
+    uint32_t src, tgt;  // view indices
+    uint32_t Ms, Mt;
+    uint32_t K;         // slots per src segment
+    uint32_t row_off;   // first row of this pair in the per-row count array (kNN <= 0 mode)
+    uint64_t slot_off;  // first slot of this pair in the slot buffer
+};
+
+// ---- phase-B records ------------------------------------------------------------------------
+// one hypothesis of the view being processed, as gathered (unsorted) from the pair slots
+struct Entry {
+    uint64_t key;      // canonical order inside the segment's list (reference single-thread order)
+    uint64_t origin;   // slot index of a fresh match (score write-back) or ~0 for an inverse match
+    uint32_t seg, tgt_view, tgt_seg;
+    float overlap, dp1, dp2, dq1, dq2, score3D;
+    uint32_t pad;
+};
+static_assert(sizeof(Entry) == 56, "Entry is 56 bytes");
+
+// the same hypothesis at its canonical position, with what scoring needs
+struct DEntry {
+    double dir[3];     // unprojected 3D direction (Segment3D::dir_)
+    uint64_t origin;
+    float length, dp1, dp2, dq1, dq2, reg1, reg2, overlap, score3D;
+    uint32_t tgt_view, tgt_seg, seg, keep;
+    uint32_t pad;
+};
+static_assert(sizeof(DEntry) == 88, "DEntry is 88 bytes");
+
+// one entry of estimated_position3D_: Segment3D + Match (line3D.cc:1637-1646)
+struct HypRec {
+    double P1[3], P2[3], dir[3];
+    float length;
+    uint32_t valid;
+    Match m;
+    uint32_t view, pad;
+};
+static_assert(sizeof(HypRec) == 128, "HypRec is 128 bytes");
+
+// per-view tables the affinity kernels read
+struct ViewAff {
+    const uint32_t* surv_off;   // [M+1]
+    const Match* surv;          // surviving matches, canonical order
+    const uint32_t* surv_tv;    // target view index of each surviving match
+    const int32_t* hyp;         // [M] global hypothesis index or -1
+    const float* median_depth;  // device scalar (View::median_depth_)
+    float k;
+    uint32_t M;
+    uint32_t cand_base;         // first candidate (= surviving match) of this view in the flat order
+    uint32_t pad;
+};
+
+// ---- the exact pair test (reference CPU semantics) -----------------------------------------
+
+// Line3D::pointOnSegment, line3D.cc:1077-1083 (2D part of homogeneous points)
+L3D_HD bool point_on_segment(double xx, double xy, double p1x, double p1y, double p2x, double p2y) {
+    double v1x = p1x - xx, v1y = p1y - xy, v2x = p2x - xx, v2y = p2y - xy;
+    return (v1x * v2x + v1y * v2y) < kEps;
+}
+
+// Line3D::mutualOverlap, line3D.cc:1086-1165, on 4 collinear points with z == 1
+L3D_HD float mutual_overlap(const double px[4], const double py[4]) {
+    if (!(point_on_segment(px[0], py[0], px[2], py[2], px[3], py[3]) ||
+          point_on_segment(px[1], py[1], px[2], py[2], px[3], py[3]) ||
+          point_on_segment(px[2], py[2], px[0], py[0], px[1], py[1]) ||
+          point_on_segment(px[3], py[3], px[0], py[0], px[1], py[1])))
+        return 0.0f;
+    float max_dist = 0.0f;
+    int outer1 = 0, outer2 = 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) {
+            double dx = px[i] - px[j], dy = py[i] - py[j];
+            float dist = (float)sqrt(dx * dx + dy * dy);  // (dz = 0 exactly)
+            if (dist > max_dist) { max_dist = dist; outer1 = i; outer2 = j; }
+        }
+    }
+    if (max_dist < 1.0f) return 0.0f;
+    int inner1, inner2;
+    if (outer1 == 0) {
+        if (outer2 == 1) { inner1 = 2; inner2 = 3; }
+        else if (outer2 == 2) { inner1 = 1; inner2 = 3; }
+        else { inner1 = 1; inner2 = 2; }
+    } else if (outer1 == 1) {
+        inner1 = 0;
+        inner2 = (outer2 == 2) ? 3 : 2;
+    } else { inner1 = 0; inner2 = 1; }
+    // select without dynamic indexing
+    double ax = inner1 == 0 ? px[0] : (inner1 == 1 ? px[1] : px[2]);
+    double ay = inner1 == 0 ? py[0] : (inner1 == 1 ? py[1] : py[2]);
+    double bx = inner2 == 1 ? px[1] : (inner2 == 2 ? px[2] : px[3]);
+    double by = inner2 == 1 ? py[1] : (inner2 == 2 ? py[2] : py[3]);
+    double dx = ax - bx, dy = ay - by;
+    return (float)(sqrt(dx * dx + dy * dy) / (double)max_dist);
+}
+
+struct PairResult {
+    float overlap;
+    float dp1, dp2, dq1, dq2;
+};
+
+// epipolar-overlap part of Line3D::matchingCPU, line3D.cc:919-958.  s = src segment, t = tgt
+// segment (raw float pixels), F row-major.  Returns the overlap score (0 when the epipolar
+// intersection is invalid).
+L3D_HD float exact_overlap(const double* F, float sx1, float sy1, float sx2, float sy2, float tx1, float ty1,
+                           float tx2, float ty2) {
+    d3 p1{(double)sx1, (double)sy1, 1.0}, p2{(double)sx2, (double)sy2, 1.0};
+    d3 e1 = mul33(F, p1), e2 = mul33(F, p2);
+    d3 q1{(double)tx1, (double)ty1, 1.0}, q2{(double)tx2, (double)ty2, 1.0};
+    d3 l2 = cross(q1, q2);
+    d3 x1 = cross(l2, e1), x2 = cross(l2, e2);
+    if (!(fabs(x1.z) > kEps && fabs(x2.z) > kEps)) return 0.0f;
+    double px[4] = {x1.x / x1.z, x2.x / x2.z, q1.x, q2.x};
+    double py[4] = {x1.y / x1.z, x2.y / x2.z, q1.y, q2.y};
+    return mutual_overlap(px, py);
+}
+
+// Line3D::triangulationDepths, line3D.cc:1168-1193, with the per-segment invariants hoisted:
+// depths of the two rays ra, rb (camera centre Ca) w.r.t. the plane (n, cn = Cplane.n).
+L3D_HD void tri_depths(const double* Ca, const double* ra, const double* rb, const double* n, double cn,
+                       double& d1, double& d2) {
+    d3 N{n[0], n[1], n[2]}, A{ra[0], ra[1], ra[2]}, B{rb[0], rb[1], rb[2]}, C1{Ca[0], Ca[1], Ca[2]};
+    double da = dot(A, N), db = dot(B, N);
+    if (fabs(da) < kEps || fabs(db) < kEps) { d1 = -1.0; d2 = -1.0; return; }
+    double num = cn - dot(N, C1);
+    d1 = num / da;
+    d2 = num / db;
+}
+
+// full acceptance test of one (src seg, tgt seg) pair: line3D.cc:931-995
+L3D_HD bool exact_pair(const double* F, const float4& s, const float4& t, const SegX& sx, const SegX& tx,
+                       const double* Cs, const double* Ct, float thr, PairResult& out) {
+    float ov = exact_overlap(F, s.x, s.y, s.z, s.w, t.x, t.y, t.z, t.w);
+    if (!(ov > thr)) return false;
+    double ds1, ds2, dt1, dt2;
+    tri_depths(Cs, sx.r1, sx.r2, tx.n, tx.cn, ds1, ds2);
+    tri_depths(Ct, tx.r1, tx.r2, sx.n, sx.cn, dt1, dt2);
+    if (!(ds1 > kEps && ds2 > kEps && dt1 > kEps && dt2 > kEps)) return false;
+    out.overlap = ov;
+    out.dp1 = (float)ds1; out.dp2 = (float)ds2; out.dq1 = (float)dt1; out.dq2 = (float)dt2;
+    return true;
+}
+
+// (overlap desc, tgt asc) total order used for the kNN selection
+L3D_HD bool better(float ova, uint32_t ia, float ovb, uint32_t ib) {
+    return ova > ovb || (ova == ovb && ia < ib);
+}
+
+}  // namespace l3d

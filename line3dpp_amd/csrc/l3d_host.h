@@ -1,0 +1,95 @@
+// l3d_host.h -- host-side state of libl3dpp_hip.so (the part of class L3DPP::Line3D / L3DPP::View
+// the hot path needs), plus small RAII helpers for HIP memory.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/l3dpp_hip.h"
+#include "l3d_dev.h"
+#include "l3d_kernels.h"
+
+namespace l3d {
+
+void set_error(const std::string& s);
+#define L3D_HIP_CHECK(expr)                                                                       \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            l3d::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+            return L3D_ERR_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+// device buffer that grows but never shrinks (freed with the context)
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// ---- host double 3x3 algebra (mirrors Eigen's fixed-size behaviour; see l3d_dev.h) -------------
+struct M3 { double m[9]; };
+inline M3 m3_mul(const M3& A, const M3& B) {
+    M3 C;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            C.m[3 * i + j] = (A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j]) + A.m[3 * i + 2] * B.m[6 + j];
+    return C;
+}
+inline M3 m3_t(const M3& A) {
+    M3 T;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T.m[3 * i + j] = A.m[3 * j + i];
+    return T;
+}
+inline M3 m3_inv(const M3& A) {  // cofactor formula (Eigen compute_inverse_size3)
+    const double* a = A.m;
+    const double c00 = a[4] * a[8] - a[5] * a[7], c10 = a[5] * a[6] - a[3] * a[8], c20 = a[3] * a[7] - a[4] * a[6];
+    const double det = a[0] * c00 + (a[1] * c10 + a[2] * c20);
+    const double id = 1.0 / det;
+    return M3{{c00 * id, (a[2] * a[7] - a[1] * a[8]) * id, (a[1] * a[5] - a[2] * a[4]) * id,
+               c10 * id, (a[0] * a[8] - a[2] * a[6]) * id, (a[2] * a[3] - a[0] * a[5]) * id,
+               c20 * id, (a[1] * a[6] - a[0] * a[7]) * id, (a[0] * a[4] - a[1] * a[3]) * id}};
+}
+
+// L3DPP::View (view.h:49-223), hot-path members only
+struct HostView {
+    uint32_t cam = 0, M = 0, index = 0;
+    std::vector<float> segs;
+    M3 K, R, Kinv, Rt, RtKinv;
+    d3 t{0, 0, 0}, C{0, 0, 0}, pp{0, 0, 0};
+    uint32_t width = 0, height = 0;
+    float initial_median_depth = 0, k = 0, median_depth = 0;
+    std::vector<uint32_t> fixed_nbrs;   // fixed_visual_neighbors_[cam]
+    std::set<uint32_t> visual_nbrs;     // visual_neighbors_[cam]
+    // device
+    DevBuf<float4> d_seg4;
+    DevBuf<SegF> d_segf;
+    DevBuf<SegX> d_segx;
+    // pairs touching this view (indices into Ctx::pairs)
+    std::vector<uint32_t> out_pairs;    // this view is src, ascending tgt
+    std::vector<uint32_t> in_pairs;     // this view is tgt and src < this (inverse matches), ascending src
+    // phase-B results (device): surviving matches CSR + best hypotheses
+    DevBuf<uint32_t> d_surv_off;        // [M+1]
+    DevBuf<Match> d_surv;               // surviving matches, canonical order
+    uint32_t n_surv = 0;
+    DevBuf<int32_t> d_hyp;              // [M] index into the global hypothesis array or -1
+    uint32_t hyp_base = 0, n_hyp = 0;
+};
+
+}  // namespace l3d
