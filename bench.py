@@ -1,0 +1,145 @@
+"""bench.py -- headline benchmark of the Line3D++ matching/scoring hot path on MI355X.
+
+A "step" = one full pass of the hot path over one synthetic scene:
+    Line3D::matchImages (pair matching -> orientation filter -> 3D scoring -> inverse matches ->
+    hypothesis collapse) + the affinity fill of Line3D::reconstruct3Dlines.
+Metric (BASELINE.json): million segment-pair scores per second = sum over matched directed view pairs
+of Ms*Mt, divided by the wall time of the step, whole job over all ranks.  Segment arrays are resident
+in HBM before the timed region (uploaded at addImage).  Workload at N=1: BASELINE config C1
+(synthetic 64 views x 2000 segments/view, 10 visual neighbours).
+
+N>1 (torchrun, one rank per GPU): the directed view pairs are sharded over the ranks, slot slices are
+all-gathered over RCCL, the per-view chain is replicated ("scaling": "strong": same scene at every N).
+
+Prints ONE JSON line with `roofline` (pair-matching kernel, HIP events on its launch stream) and
+`cpu_baseline` (the CPU oracle = port of the reference OpenMP path, timed on this box, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C1", help="BASELINE config: C1 | C2 | C3 | C4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from line3dpp_amd import dist as l3d_dist
+    from line3dpp_amd.api import Line3D
+    from line3dpp_amd.scene import CONFIGS, make_config
+
+    scene = make_config(args.config)
+    cfg = CONFIGS[args.config]
+    l3d = Line3D(device=local_rank)
+    l3d.add_scene(scene)            # segment arrays now resident in HBM
+    pair_tests, pairs = scene.pair_tests()
+    kNN = 10
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    def step():
+        ok = l3d_dist.match_images_sharded(l3d, rank, world, device=device, kNN=kNN)
+        assert ok, "matchImages failed"
+        assert l3d.computeAffinity(), "affinity failed"
+
+    for _ in range(args.warmup):
+        step()
+    kern_ms, kern_launches, phase = 0.0, 0, dict(begin=0.0, match=0.0, finish=0.0, affinity=0.0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        tm = l3d.timings()
+        kern_ms += tm["match_kernel_ms"]; kern_launches += tm["match_kernel_launches"]
+        phase["begin"] += tm["begin_ms"]; phase["match"] += tm["match_pairs_ms"]
+        phase["finish"] += tm["finish_ms"]; phase["affinity"] += tm["affinity_ms"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = pair_tests / (dt / args.steps) / 1e6
+
+    # ---- roofline of the dominant kernel (k_match_pairs), this rank's launches ----
+    M = {v.cam: len(v.segs) for v in scene.views}
+    ranges = l3d_dist.pair_ranges([M[s] * M[t] for s, t in pairs], world)
+    f, c = ranges[rank]
+    my_pairs = pairs[f:f + c]
+    # algorithmic bytes per launch (SURVEY.md §8d / DESIGN.md): per directed pair 16*(Ms+Mt) B of segment
+    # records read + 32*kNN*Ms B of result slots written
+    algo_bytes = sum(16 * (M[s] + M[t]) + 32 * kNN * M[s] for s, t in my_pairs)
+    my_tests = sum(M[s] * M[t] for s, t in my_pairs)
+    avg_ms = kern_ms / max(kern_launches, 1)
+    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 6), "traffic": None,
+                "kernel": "k_match_pairs<0,false>", "kernel_ms": round(avg_ms, 4),
+                "kernel_pair_tests_per_s": round(my_tests / (avg_ms * 1e-3), 1) if avg_ms > 0 else 0.0,
+                "note": "VALU-issue bound by design (<0.2 B per pair test); see DESIGN.md roofline"}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.oracle import Oracle, lib
+        threads = args.cpu_threads or (os.cpu_count() or 1)
+        o = Oracle(threads=threads)
+        o.add_scene(scene)
+        t1 = time.perf_counter()
+        o.match_images(kNN=kNN)
+        o.compute_affinity()
+        cdt = time.perf_counter() - t1
+        cpu_baseline = {"value": round(pair_tests / cdt / 1e6, 2), "unit": "M segment-pair scores/s",
+                        "cores": threads, "kind": "port",
+                        "sample": f"full {args.config} workload once ({pair_tests} pair tests, {cdt:.2f} s), "
+                                  f"OpenMP oracle = restatement of the reference CPU path"}
+
+    if rank == 0:
+        out = {
+            "metric": "M segment-pair scores/sec", "value": round(value, 2), "unit": "M segment-pair scores/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: synthetic {cfg['n_views']} views x {cfg['n_segs']} segments/view, "
+                                   f"{cfg['n_neighbors']} visual neighbours, kNN=10, sigma_p=2.5px, sigma_a=10deg, "
+                                   f"epipolar_overlap=0.25; matchImages + affinity fill",
+                       "pair_tests_per_step": pair_tests, "directed_pairs": len(pairs),
+                       "parallelism": f"pair-sharded x{world}" if world > 1 else "single GPU"},
+            "phase_ms": {k: round(v / args.steps, 4) for k, v in phase.items()},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -122,6 +122,8 @@ int l3d_num_pairs(l3d_ctx*, uint32_t* n);
 int l3d_get_pairs(l3d_ctx*, uint32_t* src_cam, uint32_t* tgt_cam, uint64_t* slot_offset /* in slots */);
 int l3d_match_pairs(l3d_ctx*, uint32_t first, uint32_t count);
 int l3d_slot_buffer(l3d_ctx*, void** dev_ptr, uint64_t* n_slots);
+/* tell the context that the caller's exchange has filled in the slots of all other pairs */
+int l3d_slots_exchanged(l3d_ctx*);
 int l3d_match_finish(l3d_ctx*);
 
 /* The affinity part of Line3D::reconstruct3Dlines: translate(), med_scene_depth_lines_,
@@ -155,6 +157,10 @@ int l3d_get_affinity(l3d_ctx*, l3d_cledge* edges, l3d_segment2d* local2global, f
 /* L3DPP::SparseMatrix(A_, n_rows, 1.0, sort_by_row) (sparsematrix.cc:8-60): entries float4(i,j,w,0)
  * sorted by row or column, start_indices[n_rows] with -1 for empty rows/columns */
 int l3d_get_sparse_matrix(l3d_ctx*, int sort_by_row, l3d_float4* entries, int32_t* start_indices);
+
+/* test hook: route every segment pair through the exact double-precision test (no fp32 pre-filter);
+ * used by the tests to prove that the pre-filter never loses a match */
+int l3d_set_brute_force(l3d_ctx*, int on);
 
 /* timing of the last calls, milliseconds of GPU time from HIP events on the context's stream */
 typedef struct l3d_timings {

@@ -42,7 +42,7 @@ EXPORTS = [
     "l3d_match_begin", "l3d_num_pairs", "l3d_get_pairs", "l3d_match_pairs", "l3d_slot_buffer", "l3d_match_finish",
     "l3d_compute_affinity", "l3d_synchronize", "l3d_pair_tests", "l3d_get_matches", "l3d_get_pair_slots",
     "l3d_num_best", "l3d_get_best", "l3d_view_info", "l3d_translation", "l3d_num_affinity", "l3d_get_affinity",
-    "l3d_get_sparse_matrix", "l3d_get_timings", "l3d_match_lines", "l3d_set_brute_force",
+    "l3d_get_sparse_matrix", "l3d_get_timings", "l3d_match_lines", "l3d_set_brute_force", "l3d_slots_exchanged",
 ]
 
 _lib = None
@@ -87,6 +87,7 @@ def load():
     L.l3d_match_lines.argtypes = [i32, vp, u32, vp, u32, vp, vp, vp, vp, vp, u32, u32, f32, C.c_int32, vp,
                                   C.POINTER(u64)]
     L.l3d_set_brute_force.argtypes = [vp, i32]
+    L.l3d_slots_exchanged.argtypes = [vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("l3d_last_error", "l3d_build_info", "l3d_create", "l3d_destroy"):

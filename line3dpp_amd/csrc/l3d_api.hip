@@ -235,7 +235,14 @@ void l3d_destroy(l3d_ctx* c) {
     delete c;
 }
 
-int l3d_set_brute_force(l3d_ctx* c, int on) {  // test hook (not in the public header's main flow)
+int l3d_slots_exchanged(l3d_ctx* c) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    if (c->state != l3d_ctx::BEGUN) return fail(L3D_ERR_STATE, "l3d_match_begin must precede l3d_slots_exchanged");
+    std::fill(c->pair_done.begin(), c->pair_done.end(), 1);
+    return L3D_OK;
+}
+
+int l3d_set_brute_force(l3d_ctx* c, int on) {  // test hook
     if (!c) return L3D_ERR_ARG;
     c->brute = on != 0;
     return L3D_OK;

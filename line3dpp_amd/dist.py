@@ -1,0 +1,87 @@
+"""Pair-sharded matchImages across the GPUs of one node (one process per GPU).
+
+Phase A (Line3D::matchingCPU per directed view pair, line3D.cc:728-735) reads only static per-view
+arrays, so the directed pairs are independent units: every rank holds all views (<= 34 MB even for
+the largest BASELINE config), matches a contiguous, cost-balanced range of the pair list, and the
+ranks then exchange their slices of the fixed-layout slot buffer (32-byte l3d_slot records) with an
+all-gather over RCCL/xGMI.  Phase B (the per-view chain, line3D.cc:745-773) is order dependent in
+ascending camID and is replicated on every rank after the exchange (SURVEY.md §8e option 1).
+
+The exchange is written as one in-place broadcast per owning rank: slices are uneven, and
+`ncclBroadcast` of a slice of the one shared buffer is the all-gather(v) primitive RCCL offers.
+Works with backend "nccl" (= RCCL, device buffers) and "gloo" (CPU tensors, used by the tests).
+"""
+import numpy as np
+
+
+def pair_ranges(costs, world_size):
+    """Split pairs [0, n) into `world_size` contiguous ranges of roughly equal total cost.
+
+    costs[i] = Ms*Mt of pair i.  Returns [(first, count)] * world_size (count may be 0)."""
+    costs = np.asarray(costs, np.float64)
+    n = len(costs)
+    if n == 0:
+        return [(0, 0)] * world_size
+    cum = np.concatenate([[0.0], np.cumsum(costs)])
+    total = cum[-1]
+    bounds = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        b = int(np.searchsorted(cum, target, side="left"))
+        # pick the boundary closest to the target
+        if b > 0 and abs(cum[b - 1] - target) <= abs(cum[min(b, n)] - target):
+            b -= 1
+        bounds.append(min(max(b, bounds[-1]), n))
+    bounds.append(n)
+    return [(bounds[r], bounds[r + 1] - bounds[r]) for r in range(world_size)]
+
+
+def slot_byte_ranges(ranges, slot_offsets, n_slots, slot_bytes=32):
+    """byte range of the slot buffer owned by each rank, given per-pair slot offsets"""
+    off = list(map(int, slot_offsets)) + [int(n_slots)]
+    return [(off[f] * slot_bytes, off[f + c] * slot_bytes) for f, c in ranges]
+
+
+def exchange_slots(buf, byte_ranges, group=None):
+    """In-place all-gather(v): after the call every rank's `buf` (flat uint8 torch tensor) holds every
+    rank's slice.  byte_ranges[r] = (lo, hi) owned by rank r."""
+    import torch.distributed as dist
+    for r, (lo, hi) in enumerate(byte_ranges):
+        if hi > lo:
+            dist.broadcast(buf[lo:hi], src=r if group is None else dist.get_global_rank(group, r), group=group)
+
+
+class _DevMem:
+    """raw device pointer -> torch tensor without a copy (__cuda_array_interface__, HIP/ROCm torch)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def device_tensor(ptr, nbytes, device):
+    import torch
+    return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
+
+
+def match_images_sharded(l3d, rank, world_size, device=None, group=None, **params):
+    """matchImages with phase A sharded over `world_size` ranks.  `l3d` is a line3dpp_amd.Line3D that
+    already holds all views (every rank adds the same views)."""
+    if not l3d.matchBegin(**params):
+        return False
+    pairs, slot_off = l3d.pairs()
+    M = l3d._M
+    costs = [M[int(s)] * M[int(t)] for s, t in pairs]
+    ranges = pair_ranges(costs, world_size)
+    first, count = ranges[rank]
+    if count and not l3d.matchPairs(first, count):
+        return False
+    if world_size > 1:
+        ptr, n_slots = l3d.slot_buffer()
+        if n_slots:
+            buf = device_tensor(ptr, n_slots * 32, device)
+            exchange_slots(buf, slot_byte_ranges(ranges, slot_off, n_slots), group)
+            import torch
+            torch.cuda.synchronize(device)
+        # every pair is now present on this rank
+        l3d.L.l3d_slots_exchanged(l3d.h)
+    return l3d.matchFinish()

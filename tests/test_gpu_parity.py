@@ -1,0 +1,327 @@
+"""GPU parity tests (pytest -m gpu, real MI355X): the HIP path behind the C-ABI against the CPU oracle.
+
+Bar (north_star): affinity entries and 3D end points within 1e-4 relative.  What is actually asserted
+is stronger wherever the arithmetic allows it: phase-A matches (sets, overlap, four depths) are
+bit-exact, sets of surviving matches / best hypotheses / affinity edges are identical, and float
+values that pass through expf/acos agree to REL_TOL.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from line3dpp_amd._lib import EMPTY
+from line3dpp_amd.scene import ViewData, Scene, make_scene
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "small_scene.npz")
+
+
+def _gpu(scene, **kw):
+    from line3dpp_amd.api import Line3D
+    g = Line3D()
+    g.add_scene(scene)
+    assert g.numImages() == scene.n_views
+    return g
+
+
+def _oracle(scene, **kw):
+    from oracle.oracle import Oracle
+    o = Oracle(threads=kw.pop("threads", 8), **kw)
+    o.add_scene(scene)
+    return o
+
+
+def _check_phase_a(g, scene, kNN, epi=0.25, allow_tie_order=True):
+    o = _oracle(scene)
+    o.begin_match(kNN=kNN, epi_overlap=epi)
+    pairs, _ = g.pairs()
+    assert np.array_equal(pairs, np.array(scene.pair_tests()[1], np.uint32).reshape(-1, 2))
+    total = 0
+    for pi, (s, t) in enumerate(pairs):
+        om, _ = o.match_pair(int(s), int(t))
+        r = H.compare_pair(g.pair_slots(pi), om)
+        assert not r["missing"] and not r["extra"], (pi, r["missing"][:3], r["extra"][:3])
+        assert r["bit_exact"], f"pair {pi}: overlap/depths differ from the oracle (max rel {r['max_rel']})"
+        total += r["n_cpu"]
+    o.end_match()
+    assert total > 0
+    return total
+
+
+@pytest.mark.parametrize("n_views,n_segs,nn,kNN,seed", [
+    (6, 300, 4, 10, 1),
+    (5, 257, 2, 1, 2),      # ragged: one lane past a full 256 block
+    (4, 63, 2, 3, 3),       # less than one wave
+    (4, 1000, 2, 25, 4),    # K larger than the default
+    (3, 1, 2, 10, 5),       # single segment per view
+])
+def test_phase_a_bit_exact(n_views, n_segs, nn, kNN, seed):
+    sc = make_scene(n_views, n_segs, n_neighbors=nn, seed=seed)
+    g = _gpu(sc)
+    assert g.matchBegin(kNN=kNN) and g.matchPairs(0, len(g.pairs()[0]))
+    _check_phase_a(g, sc, kNN)
+    assert g.matchFinish()
+
+
+def test_phase_a_views_of_different_size_and_overlap_threshold():
+    sc = make_scene(5, 400, n_neighbors=4, seed=7)
+    for i, v in enumerate(sc.views):      # ragged views: 400, 333, 266, ...
+        v.segs = v.segs[:400 - 67 * i].copy()
+    g = _gpu(sc)
+    assert g.matchBegin(kNN=7, epipolar_overlap=0.6) and g.matchPairs(0, len(g.pairs()[0]))
+    _check_phase_a(g, sc, 7, epi=0.6)
+
+
+def test_prefilter_never_loses_a_match():
+    """fp32 pre-filter + ring compaction vs the brute-force path (every pair through the exact test),
+    at a size the CPU oracle would need minutes for; also at 4x image scale (larger coordinates)."""
+    for scale, seed in ((1.0, 21), (4.0, 22)):
+        sc = make_scene(4, 3000, n_neighbors=2, seed=seed)
+        if scale != 1.0:
+            for v in sc.views:
+                v.segs = (v.segs * scale).astype(np.float32); v.K = v.K.copy(); v.K[:2] *= scale
+                v.width = int(v.width * scale); v.height = int(v.height * scale)
+        out = []
+        for brute in (0, 1):
+            g = _gpu(sc)
+            g.set_brute_force(brute)
+            assert g.matchBegin(kNN=10) and g.matchPairs(0, len(g.pairs()[0]))
+            out.append([g.pair_slots(pi) for pi in range(len(g.pairs()[0]))])
+        for a, b in zip(*out):
+            assert np.array_equal(a, b)
+        assert sum(int((a["tgt_seg"] != EMPTY).sum()) for a in out[0]) > 1000
+
+
+def test_keep_all_mode_knn_zero():
+    sc = make_scene(4, 260, n_neighbors=2, seed=8)
+    g = _gpu(sc)
+    assert g.matchBegin(kNN=0) and g.matchPairs(0, len(g.pairs()[0]))
+    o = _oracle(sc); o.begin_match(kNN=0)
+    for pi, (s, t) in enumerate(g.pairs()[0]):
+        om, off = o.match_pair(int(s), int(t))
+        sl = g.pair_slots(pi)
+        r = H.compare_pair(sl, om)
+        assert not r["missing"] and not r["extra"] and r["bit_exact"] and r["order_mismatch"] == 0
+    o.end_match()
+    assert g.matchFinish() and g.computeAffinity()
+    o2 = _oracle(sc); o2.match_images(kNN=0); o2.compute_affinity()
+    _compare_final(g, o2, sc)
+
+
+def _compare_final(g, o, sc, exact_sets=True):
+    n_surv = 0
+    for v in sc.views:
+        gm, goff = g.matches(v.cam); om, ooff = o.matches(v.cam)
+        r = H.compare_matches(gm, om)
+        assert not r["missing"] and not r["extra"], (v.cam, r["missing"][:3], r["extra"][:3])
+        assert r["max_rel"] <= H.REL_TOL
+        assert np.array_equal(goff, ooff)
+        # same order inside every list (canonical order == reference single-thread order)
+        assert np.array_equal(gm["tgt_cam"], om["tgt_cam"]) and np.array_equal(gm["tgt_seg"], om["tgt_seg"])
+        gi, oi = g.view_info(v.cam), o.view_info(v.cam)
+        assert gi["k"] == oi["k"]
+        assert H.rel_close(gi["median_depth"], oi["median_depth"])
+        n_surv += len(om)
+    s2, s3, bm = g.best(); cs, geo, ln, obm = o.best()
+    assert np.array_equal(np.stack([s2["cam"], s2["seg"]], 1), cs)
+    gg = np.concatenate([s3["P1"], s3["P2"], s3["dir"]], 1)
+    assert np.all(H.rel_close(gg, geo)), "3D end points of the best hypotheses"
+    assert np.all(H.rel_close(bm["score3D"], obm["score3D"]))
+    assert np.array_equal(bm["tgt_cam"], obm["tgt_cam"]) and np.array_equal(bm["tgt_seg"], obm["tgt_seg"])
+    ge, gl, gms = g.affinity(); oe, ol = o.affinity()
+    assert H.rel_close(gms, o.med_scene_depth_lines())
+    gmap = H.affinity_map(ge, np.stack([gl["cam"], gl["seg"]], 1)); omap = H.affinity_map(oe, ol)
+    assert set(gmap) == set(omap)
+    assert all(H.rel_close(gmap[k], omap[k]) for k in omap)
+    # row ids and edge order are the reference's single-thread first-touch order
+    assert np.array_equal(ge["i"], oe["i"]) and np.array_equal(ge["j"], oe["j"])
+    assert np.array_equal(np.stack([gl["cam"], gl["seg"]], 1), ol)
+    return n_surv, len(cs), len(oe)
+
+
+@pytest.mark.parametrize("n_views,n_segs,nn,seed", [(8, 300, 4, 1), (12, 500, 6, 2), (7, 129, 2, 3)])
+def test_full_pipeline_parity(n_views, n_segs, nn, seed):
+    sc = make_scene(n_views, n_segs, n_neighbors=nn, seed=seed)
+    g = _gpu(sc)
+    assert g.matchImages() and g.computeAffinity()
+    o = _oracle(sc); o.match_images(); o.compute_affinity()
+    n_surv, n_best, n_edges = _compare_final(g, o, sc)
+    assert n_surv > 50 and n_best > 20 and n_edges > 20
+    assert g.pair_tests() == o.pair_tests() == sc.pair_tests()[0]
+
+
+def test_scored_lists_before_filter_match_oracle():
+    """score3D of every hypothesis (fresh + inverse) right after scoring, via the slot score write-back
+    of fresh matches: compares with the oracle's pre-filter snapshot."""
+    sc = make_scene(6, 250, n_neighbors=4, seed=13)
+    g = _gpu(sc)
+    assert g.matchImages()
+    o = _oracle(sc, record_scored=True); o.match_images()
+    pairs, _ = g.pairs()
+    checked = 0
+    for pi, (s, t) in enumerate(pairs):
+        sl = g.pair_slots(pi)
+        sm, soff = o.scored(int(s))
+        od = {(int(x["src_seg"]), int(x["tgt_seg"])): float(x["score3D"]) for x in sm if x["tgt_cam"] == t}
+        for r in range(sl.shape[0]):
+            for x in sl[r]:
+                if x["tgt_seg"] == EMPTY:
+                    continue
+                key = (r, int(x["tgt_seg"]))
+                alive = bool(x["flags"] & 1)
+                assert alive == (key in od), "orientation filter decision"
+                if alive:
+                    assert H.rel_close(x["score3D"], od[key]) or abs(x["score3D"] - od[key]) < 1e-6
+                    checked += 1
+    assert checked > 1000
+
+
+def test_fixed_regularizer_mode_sigma_in_metres():
+    sc = make_scene(6, 200, n_neighbors=4, seed=17)
+    g = _gpu(sc)
+    assert g.matchImages(sigma_position=-0.05) and g.computeAffinity()
+    o = _oracle(sc); o.match_images(sigma_p=-0.05); o.compute_affinity()
+    _compare_final(g, o, sc)
+
+
+def test_asymmetric_neighbours_and_sparse_cam_ids():
+    """neighbour lists need not be symmetric and camIDs need not be dense (line3D.cc:704-741 direction rule,
+    inverse matches only towards unprocessed views)."""
+    sc = make_scene(7, 220, n_neighbors=4, seed=19)
+    remap = {i: 10 + 7 * i for i in range(7)}
+    for v in sc.views:
+        v.neighbors = [remap[n] for n in v.neighbors if (v.cam + n) % 3 != 0] or [remap[(v.cam + 1) % 7]]
+        v.cam = remap[v.cam]
+    g = _gpu(sc)
+    assert g.matchImages() and g.computeAffinity()
+    o = _oracle(sc); o.match_images(); o.compute_affinity()
+    assert np.array_equal(g.pairs()[0], o.pairs())
+    _compare_final(g, o, sc)
+
+
+def test_golden_fixture_gpu():
+    from tools.make_golden import PARAMS, flat_matches, golden_scene
+    gold = np.load(GOLDEN)
+    sc = golden_scene()
+    g = _gpu(sc)
+    assert g.matchImages(sigma_position=PARAMS["sigma_p"], sigma_angle=PARAMS["sigma_a"], kNN=PARAMS["kNN"],
+                         epipolar_overlap=PARAMS["epi_overlap"]) and g.computeAffinity()
+    m = flat_matches(g.matches, [v.cam for v in sc.views])
+    assert m.shape == gold["matches"].shape
+    assert np.array_equal(m[:, :4], gold["matches"][:, :4])
+    assert np.all(H.rel_close(m[:, 4:], gold["matches"][:, 4:]))
+    s2, s3, bm = g.best()
+    assert np.array_equal(np.stack([s2["cam"], s2["seg"]], 1), gold["best_keys"])
+    assert np.all(H.rel_close(np.concatenate([s3["P1"], s3["P2"], s3["dir"]], 1), gold["best_geo"]))
+    ge, gl, _ = g.affinity()
+    assert np.array_equal(np.stack([ge["i"], ge["j"]], 1), gold["edges"][:, :2].astype(np.int64))
+    assert np.all(H.rel_close(ge["w"], gold["edges"][:, 2]))
+    assert np.array_equal(np.stack([gl["cam"], gl["seg"]], 1), gold["l2g"])
+
+
+def test_seam_level_match_lines():
+    """l3d_match_lines (replaces match_lines_GPU, cudawrapper.h:54-63) against matchingCPU of the oracle."""
+    from line3dpp_amd.api import match_lines
+    sc = make_scene(3, 350, n_neighbors=2, seed=23)
+    o = _oracle(sc); o.begin_match(kNN=6)
+    F = o.fundamental(0, 1)
+    vs, vt = sc.views[0], sc.views[1]
+    info0, info1 = o.view_info(0), o.view_info(1)
+    A0 = vs.R.T @ np.linalg.inv(vs.K); A1 = vt.R.T @ np.linalg.inv(vt.K)
+    slots, n = match_lines(vs.segs, vt.segs, F, A0, A1, info0["C"], info1["C"], vs.width, vs.height, 0.25, 6)
+    om, _ = o.match_pair(0, 1)
+    o.end_match()
+    r = H.compare_pair(slots, om)
+    assert n == len(om) and not r["missing"] and not r["extra"]
+    assert r["max_rel"] < 1e-5      # RtKinv passed in comes from numpy's inverse, not the cofactor formula
+
+
+def test_error_behaviour_mirrors_reference():
+    from line3dpp_amd.api import Line3D
+    sc = make_scene(3, 40, n_neighbors=2, seed=2)
+    v = sc.views[0]
+    g = Line3D()
+    assert not g.matchImages() and g.last_status == -6                 # no images (line3D.cc:385)
+    g.addImage(0, (700, 500), v.K, v.R, v.t, 1.0, [1], v.segs); assert g.last_status == -2   # too small (:119)
+    g.addImage(0, (v.width, v.height), v.K, v.R, v.t, 1.0, [], v.segs); assert g.last_status == -4  # (:154)
+    g.addImage(0, (v.width, v.height), v.K, v.R, v.t, 1.0, [1], v.segs); assert g.last_status == 0
+    g.addImage(0, (v.width, v.height), v.K, v.R, v.t, 1.0, [1], v.segs); assert g.last_status == -3  # ID in use (:130)
+    assert g.numImages() == 1
+    assert not g.computeAffinity() and g.last_status == -7             # reconstruct before match (:1712)
+    # a view whose neighbours do not exist is matched with nobody and yields nothing
+    assert g.matchImages()
+    m, off = g.matches(0)
+    assert len(m) == 0 and g.best()[0].size == 0
+
+
+def test_determinism_and_idempotence():
+    sc = make_scene(8, 400, n_neighbors=4, seed=29)
+    g = _gpu(sc)
+    runs = []
+    for _ in range(2):
+        assert g.matchImages() and g.computeAffinity()
+        runs.append(([g.matches(v.cam)[0].tobytes() for v in sc.views], g.best()[1].tobytes(), g.affinity()[0].tobytes()))
+    assert runs[0] == runs[1], "a second matchImages on the same context reproduces the first bit for bit"
+    g2 = _gpu(sc)
+    assert g2.matchImages() and g2.computeAffinity()
+    assert runs[0][2] == g2.affinity()[0].tobytes()
+
+
+def test_sparse_matrix_export():
+    sc = make_scene(8, 300, n_neighbors=4, seed=31)
+    g = _gpu(sc)
+    assert g.matchImages() and g.computeAffinity()
+    e, l2g, _ = g.affinity()
+    for by_row in (False, True):
+        ent, start = g.sparse_matrix(sort_by_row=by_row)
+        assert len(ent) == len(e) and len(start) == len(l2g) and np.all(ent["w"] == 0)
+        key = ent["x"] if by_row else ent["y"]
+        assert np.all(np.diff(key) >= 0)
+        for rc in range(len(l2g)):
+            pos = np.nonzero(key == rc)[0]
+            assert start[rc] == (pos[0] if len(pos) else -1)
+        got = sorted(zip(ent["x"].astype(int), ent["y"].astype(int), ent["z"]))
+        assert got == sorted(zip(e["i"], e["j"], e["w"]))
+
+
+def test_properties_at_full_c1_size():
+    """BASELINE config C1 (64 views x 2000 segments, 10 neighbours) -- size-independent properties."""
+    from line3dpp_amd.scene import make_config
+    sc = make_config("C1")
+    g = _gpu(sc)
+    assert g.matchImages() and g.computeAffinity()
+    assert g.pair_tests() == 1_280_000_000
+    pairs, _ = g.pairs()
+    assert len(pairs) == 320
+    rng = np.random.default_rng(0)
+    for pi in rng.choice(len(pairs), 12, replace=False):
+        sl = g.pair_slots(int(pi))
+        valid = sl["tgt_seg"] != EMPTY
+        assert np.all(valid[:, :-1] >= valid[:, 1:]), "valid slots form a prefix of every row"
+        ov = np.where(valid, sl["overlap"], -1.0)
+        assert np.all(ov[:, :-1] >= ov[:, 1:]), "rows sorted by overlap, best first"
+        assert np.all(sl["overlap"][valid] > 0.25) and np.all(sl["overlap"][valid] <= 1.0 + 1e-6)
+        for f in ("d_p1", "d_p2", "d_q1", "d_q2"):
+            assert np.all(sl[f][valid] > 1e-12)
+        for r in range(0, sl.shape[0], 97):
+            t = sl["tgt_seg"][r][valid[r]]
+            assert len(set(t.tolist())) == len(t)
+    e, l2g, msdl = g.affinity()
+    amap = H.affinity_map(e, np.stack([l2g["cam"], l2g["seg"]], 1))
+    assert len(amap) * 2 == len(e) and min(amap.values()) > 0.5 and max(amap.values()) <= 1.0
+    s2, s3, bm = g.best()
+    assert np.all(bm["score3D"] > 0.75)
+    keys = s2["cam"].astype(np.int64) * (1 << 32) + s2["seg"]
+    assert np.all(np.diff(keys) > 0), "best hypotheses ordered by (camID, segID), at most one per segment"
+    hyp = set(map(tuple, np.stack([s2["cam"], s2["seg"]], 1).tolist()))
+    assert set(map(tuple, np.stack([l2g["cam"], l2g["seg"]], 1).tolist())) <= hyp
+    lim_ok = 0
+    for v in sc.views[::8]:
+        m, off = g.matches(v.cam)
+        if len(m):
+            assert np.all(m["score3D"] > 0)
+            lim_ok += 1
+    assert lim_ok > 0

@@ -1,0 +1,95 @@
+"""CPU tests of the host side: C-ABI exports, scene generator, pair list, sharding, loud failure
+without a GPU.  No compute call is made here (there is no GPU in the CPU container)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from line3dpp_amd import _lib, dist
+from line3dpp_amd.scene import CONFIGS, make_scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "l3dpp_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(l3d_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    L = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/l3dpp_hip.h but not exported"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert b"gfx950" in L.l3d_build_info()
+
+
+def test_pod_layouts_match_reference():
+    # commons.h:186-203 Match = 4 x u32 + 6 x f32; clustering.h:47-51 CLEdge = 2 x int + float
+    assert _lib.MATCH_DTYPE.itemsize == 40 and _lib.CLEDGE_DTYPE.itemsize == 12
+    assert _lib.SEGMENT2D_DTYPE.itemsize == 8 and _lib.SLOT_DTYPE.itemsize == 32
+    assert [n for n in _lib.MATCH_DTYPE.names] == ["src_cam", "src_seg", "tgt_cam", "tgt_seg", "overlap", "score3D",
+                                                  "d_p1", "d_p2", "d_q1", "d_q2"]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a box without a GPU")
+def test_fails_loudly_without_gpu():
+    from line3dpp_amd.api import Line3D
+    with pytest.raises(RuntimeError, match="no usable HIP device"):
+        Line3D()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "SO_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_scene_generator_is_deterministic_and_well_formed():
+    a = make_scene(6, 200, n_neighbors=4, seed=9)
+    b = make_scene(6, 200, n_neighbors=4, seed=9)
+    for va, vb in zip(a.views, b.views):
+        assert np.array_equal(va.segs, vb.segs) and np.array_equal(va.R, vb.R)
+        assert va.segs.shape == (200, 4) and va.segs.dtype == np.float32
+        length = np.hypot(va.segs[:, 0] - va.segs[:, 2], va.segs[:, 1] - va.segs[:, 3])
+        assert np.all(np.diff(length) <= 1e-3), "sorted by length, longest first (line3D.cc:323-360)"
+        assert length.min() >= 19.0
+        assert va.segs[:, [0, 2]].min() >= 0 and va.segs[:, [0, 2]].max() <= va.width - 1
+        assert np.allclose(va.R @ va.R.T, np.eye(3), atol=1e-12)
+        assert len(va.neighbors) == 4 and va.cam not in va.neighbors
+
+
+def test_pair_counts_match_survey():
+    # C1 320 directed pairs / 1.28e9 tests
+    views = CONFIGS["C1"]["n_views"]; M = CONFIGS["C1"]["n_segs"]
+    sc = make_scene(views, 8, n_neighbors=CONFIGS["C1"]["n_neighbors"], seed=1)
+    tests, pairs = sc.pair_tests()
+    assert len(pairs) == 320
+    assert len(pairs) * M * M == 1_280_000_000
+    # direction rule (line3D.cc:704-741): every unordered neighbour pair exactly once, src = first visitor
+    assert len({tuple(sorted(p)) for p in pairs}) == len(pairs)
+    assert all(s < t or s not in sc.views[t].neighbors for s, t in pairs)
+
+
+def test_pair_ranges_cover_and_balance():
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 3, 8):
+        costs = rng.integers(1, 100, 57)
+        r = dist.pair_ranges(costs, world)
+        assert len(r) == world and r[0][0] == 0 and sum(c for _, c in r) == 57
+        for (f0, c0), (f1, c1) in zip(r, r[1:]):
+            assert f0 + c0 == f1
+        loads = [costs[f:f + c].sum() for f, c in r]
+        assert max(loads) <= costs.sum() / world + costs.max()
+    assert dist.pair_ranges([], 4) == [(0, 0)] * 4
+    assert dist.pair_ranges([5], 4)[-1] == (0, 1) or sum(c for _, c in dist.pair_ranges([5], 4)) == 1
+
+
+def test_slot_byte_ranges():
+    ranges = [(0, 2), (2, 1), (3, 0)]
+    off = [0, 100, 250]
+    br = dist.slot_byte_ranges(ranges, off, 400)
+    assert br == [(0, 250 * 32), (250 * 32, 400 * 32), (400 * 32, 400 * 32)]

@@ -1,0 +1,54 @@
+"""Generates tests/golden/small_scene.npz: the oracle's output on a small deterministic scene.
+
+The reference has no golden vectors for the hot path and cannot be run here, so this
+fixture freezes the oracle restatement (oracle/l3d_oracle.cpp); it is the file both the oracle tests
+and the GPU parity tests compare against.  Re-run only when the oracle is deliberately changed:
+    python tools/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from line3dpp_amd.scene import make_scene  # noqa: E402
+
+PARAMS = dict(sigma_p=2.5, sigma_a=10.0, num_neighbors=10, epi_overlap=0.25, kNN=10, const_reg_depth=-1.0)
+
+
+def golden_scene():
+    return make_scene(10, 300, n_neighbors=4, seed=20260925)
+
+
+def flat_matches(get, cams):
+    rows = []
+    for c in cams:
+        m, off = get(c)
+        for r in m:
+            rows.append((r["src_cam"], r["src_seg"], r["tgt_cam"], r["tgt_seg"], r["overlap"], r["score3D"],
+                         r["d_p1"], r["d_p2"], r["d_q1"], r["d_q2"]))
+    return np.array(rows, np.float64).reshape(-1, 10)
+
+
+def run_oracle(scene):
+    from oracle.oracle import Oracle
+    o = Oracle(threads=1)
+    o.add_scene(scene)
+    o.match_images(**PARAMS)
+    o.compute_affinity()
+    cams = [v.cam for v in scene.views]
+    cs, geo, ln, bm = o.best()
+    e, l2g = o.affinity()
+    return dict(matches=flat_matches(o.matches, cams), best_keys=cs.astype(np.int64), best_geo=geo,
+                edges=np.stack([e["i"].astype(np.float64), e["j"].astype(np.float64), e["w"].astype(np.float64)], 1),
+                l2g=l2g.astype(np.int64),
+                medians=np.array([o.view_info(c)["median_depth"] for c in cams], np.float64),
+                ks=np.array([o.view_info(c)["k"] for c in cams], np.float64))
+
+
+if __name__ == "__main__":
+    out = run_oracle(golden_scene())
+    path = os.path.join(ROOT, "tests", "golden", "small_scene.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: v.shape for k, v in out.items()})
