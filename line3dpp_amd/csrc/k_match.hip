@@ -114,7 +114,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
 
     // ---- prologue: this lane's two epipolar lines, normalised, image-centre origin, fp32 ----
     float e1x = 0, e1y = 0, e1z = 0, e2x = 0, e2y = 0, e2z = 0;
-    float thrL = __builtin_inff();   // dead lane: never a candidate
+    float thrL = thr;
+    bool live = false;               // dead lane (row >= Ms or degenerate epipolar line): never a candidate
     if (active) {
         const float4 s = vs.seg4[src];
         d3 e1 = mul33(F, d3{(double)s.x, (double)s.y, 1.0});
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
             e1z = (float)((e1.z + (e1.x * cx + e1.y * cy)) / n1);
             e2x = (float)(e2.x / n2); e2y = (float)(e2.y / n2);
             e2z = (float)((e2.z + (e2.x * cx + e2.y * cy)) / n2);
-            thrL = thr;
+            live = true;
         }
     }
     L.cnt[tid] = 0;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
             }
         }
         // feed the K-th best overlap back into the owning lane's pre-filter threshold
-        if (MODE == 0 && active && thrL < __builtin_inff()) thrL = fmaxf(thr, L.minov[tid]);
+        if (MODE == 0 && live) thrL = fmaxf(thr, L.minov[tid]);
     };
 
     // ---- main loop: stream the target view through LDS ----
@@ -211,10 +212,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
         uint32_t j = 0;
         for (; j + 4 <= n; j += 4) {
             const float4 q0 = L.tile[j], q1 = L.tile[j + 1], q2 = L.tile[j + 2], q3 = L.tile[j + 3];
-            const bool c0 = BRUTE ? active : prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL);
-            const bool c1 = BRUTE ? active : prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL);
-            const bool c2 = BRUTE ? active : prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL);
-            const bool c3 = BRUTE ? active : prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q3, thrL);
+            const bool c0 = BRUTE ? active : (live && prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
+            const bool c1 = BRUTE ? active : (live && prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL));
+            const bool c2 = BRUTE ? active : (live && prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL));
+            const bool c3 = BRUTE ? active : (live && prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q3, thrL));
             const uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3);
             if (m0 | m1 | m2 | m3) {
                 const uint32_t tb = t0 + j;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
         }
         for (; j < n; ++j) {
             const float4 q0 = L.tile[j];
-            const bool c0 = BRUTE ? active : prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL);
+            const bool c0 = BRUTE ? active : (live && prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
             const uint64_t m0 = __ballot(c0);
             if (m0) {
                 if (c0) ring[(tail + __popcll(m0 & lt_mask)) & (kRing - 1)] = ent_hi | (t0 + j);
