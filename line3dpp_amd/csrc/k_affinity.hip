@@ -58,40 +58,29 @@ __device__ __forceinline__ float sim_affinity(const HypRec& h1, const HypRec& h2
     return fminf(sim_a, fminf(sim_p1, sim_p2));
 }
 
-// view owning flat candidate c: largest v with cand_base[v] <= c
-__device__ __forceinline__ uint32_t find_view(const ViewAff* va, uint32_t V, uint32_t c) {
-    uint32_t lo = 0, hi = V;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (va[mid].cand_base <= c) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
 }  // namespace
 
-__global__ void k_aff_sim(const ViewAff* __restrict__ va, uint32_t V, uint32_t N, const HypRec* __restrict__ hyps,
+// candidate c = surviving match c of the global pool (views ascending, segments ascending, list order)
+__global__ void k_aff_sim(uint32_t N, const uint32_t* __restrict__ surv_sg, const uint32_t* __restrict__ surv_tg,
+                          const int32_t* __restrict__ hyp_of_seg, const HypRec* __restrict__ hyps,
+                          const ViewAff* __restrict__ va, const float* __restrict__ medians,
                           const float* __restrict__ msdl_ptr, float two_sigA_sqr, float* __restrict__ simv,
                           int32_t* __restrict__ cand_a, int32_t* __restrict__ cand_b) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= N) return;
-    const uint32_t v = find_view(va, V, c);
-    const ViewAff& A = va[v];
-    const uint32_t pos = c - A.cand_base;
-    const Match m2 = A.surv[pos];
-    const uint32_t tv = A.surv_tv[pos];
-    const int32_t ha = A.hyp[m2.src_seg];
-    const ViewAff& B = va[tv];
-    const int32_t hb = B.hyp[m2.tgt_seg];
+    const int32_t ha = hyp_of_seg[surv_sg[c]], hb = hyp_of_seg[surv_tg[c]];
     float sim = 0.0f;
-    if (ha >= 0 && hb >= 0)
-        sim = sim_affinity(hyps[ha], hyps[hb], A.k, *A.median_depth, B.k, *B.median_depth, *msdl_ptr, two_sigA_sqr);
+    if (ha >= 0 && hb >= 0) {
+        const uint32_t v1 = hyps[ha].view, v2 = hyps[hb].view;
+        sim = sim_affinity(hyps[ha], hyps[hb], va[v1].k, medians[v1], va[v2].k, medians[v2], *msdl_ptr, two_sigA_sqr);
+    }
     simv[c] = sim;
     cand_a[c] = ha;
     cand_b[c] = hb;
 }
 
-__global__ void k_aff_flag(const ViewAff* __restrict__ va, uint32_t V, uint32_t N, const float* __restrict__ simv,
+__global__ void k_aff_flag(uint32_t N, const uint32_t* __restrict__ surv_off, const uint32_t* __restrict__ surv_sg,
+                           const uint32_t* __restrict__ surv_tg, const float* __restrict__ simv,
                            const int32_t* __restrict__ cand_a, const int32_t* __restrict__ cand_b,
                            uint32_t* __restrict__ flag) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,19 +88,13 @@ __global__ void k_aff_flag(const ViewAff* __restrict__ va, uint32_t V, uint32_t 
     uint32_t f = 0;
     if (simv[c] > kMinAffinity) {
         f = 1;
-        const int32_t ha = cand_a[c], hb = cand_b[c];
-        if (hb < ha) {
+        if (cand_b[c] < cand_a[c]) {
             // the target segment's own hypothesis was visited earlier: if its list holds the reverse
             // match and that one passed, the pair is already `used` (line3D.cc:1988)
-            const uint32_t v = find_view(va, V, c);
-            const ViewAff& A = va[v];
-            const uint32_t pos = c - A.cand_base;
-            const Match m2 = A.surv[pos];
-            const uint32_t tv = A.surv_tv[pos];
-            const ViewAff& B = va[tv];
-            for (uint32_t i = B.surv_off[m2.tgt_seg]; i < B.surv_off[m2.tgt_seg + 1]; ++i) {
-                if (B.surv_tv[i] == v && B.surv[i].tgt_seg == m2.src_seg) {
-                    if (simv[B.cand_base + i] > kMinAffinity) f = 0;
+            const uint32_t sg = surv_sg[c], tg = surv_tg[c];
+            for (uint32_t i = surv_off[tg]; i < surv_off[tg + 1]; ++i) {
+                if (surv_tg[i] == sg) {
+                    if (simv[i] > kMinAffinity) f = 0;
                     break;
                 }
             }
@@ -166,16 +149,18 @@ __global__ void k_aff_emit(uint32_t N, const uint32_t* __restrict__ flag, const 
 // ---- launchers ---------------------------------------------------------------------------------
 static inline dim3 grid1(uint32_t n, uint32_t b = 256) { return dim3((n + b - 1) / b); }
 
-hipError_t launch_aff_sim(const ViewAff* va, uint32_t V, uint32_t N, const HypRec* hyps, const float* msdl,
+hipError_t launch_aff_sim(uint32_t N, const uint32_t* surv_sg, const uint32_t* surv_tg, const int32_t* hyp_of_seg,
+                          const HypRec* hyps, const ViewAff* va, const float* medians, const float* msdl,
                           float two_sigA_sqr, float* simv, int32_t* ca, int32_t* cb, hipStream_t st) {
     if (!N) return hipSuccess;
-    hipLaunchKernelGGL(k_aff_sim, grid1(N, 128), dim3(128), 0, st, va, V, N, hyps, msdl, two_sigA_sqr, simv, ca, cb);
+    hipLaunchKernelGGL(k_aff_sim, grid1(N, 128), dim3(128), 0, st, N, surv_sg, surv_tg, hyp_of_seg, hyps, va, medians,
+                       msdl, two_sigA_sqr, simv, ca, cb);
     return hipGetLastError();
 }
-hipError_t launch_aff_flag(const ViewAff* va, uint32_t V, uint32_t N, const float* simv, const int32_t* ca,
-                           const int32_t* cb, uint32_t* flag, hipStream_t st) {
+hipError_t launch_aff_flag(uint32_t N, const uint32_t* surv_off, const uint32_t* surv_sg, const uint32_t* surv_tg,
+                           const float* simv, const int32_t* ca, const int32_t* cb, uint32_t* flag, hipStream_t st) {
     if (!N) return hipSuccess;
-    hipLaunchKernelGGL(k_aff_flag, grid1(N), dim3(256), 0, st, va, V, N, simv, ca, cb, flag);
+    hipLaunchKernelGGL(k_aff_flag, grid1(N), dim3(256), 0, st, N, surv_off, surv_sg, surv_tg, simv, ca, cb, flag);
     return hipGetLastError();
 }
 hipError_t launch_fill_u32(uint32_t* p, uint32_t n, uint32_t val, hipStream_t st) {

@@ -1,17 +1,27 @@
-// k_views.hip -- phase B: the per-view chain of Line3D::computeMatches (line3D.cc:745-773), run for
-// one source view at a time in ascending camID order (the order dependence is real: view v's
-// hypothesis lists contain inverse matches whose presence depends on the scores of earlier views).
+// k_views.hip -- phase B: the per-view part of Line3D::computeMatches (line3D.cc:745-773).
 //
-//   k_list_count / k_list_fill : gather the view's hypotheses (fresh slots of its outgoing pairs +
-//        role-swapped slots of incoming pairs whose source view scored them > 0,
-//        storeInverseMatches line3D.cc:1672-1699) and apply checkMatchOrientation (:811-858)
-//   k_entry_prep  : canonical (= reference single-thread) list order by rank-sort on a 64-bit key,
-//                   unprojection + spatial regularisers of every hypothesis (scoringCPU :1233-1248)
-//   k_score       : one wave per 2D segment, O(L^2) similarityForScoring (:1417-1446) with the
-//                   reference's per-camera replace/subtract accumulation (:1255-1274)
-//   k_filter_*    : filterMatches (:1586-1669): 10 % of the view's best score, first strict maximum,
-//                   0.75 gate, surviving lists + best 3D hypothesis per segment
-//   k_median_depth: View::update_median_depth input (sorted[n/2], :1657-1668)
+// The reference processes views in ascending camID order, and view v's hypothesis lists contain the
+// inverse matches of earlier views u < v whose score was > 0 (storeInverseMatches, :1672-1699): a true
+// sequential chain.  Only ONE bit per inverse hypothesis depends on that chain ("did u score it > 0?");
+// everything else is geometry.  So the work is split in three:
+//
+//   pre-pass (all views at once, chain independent)
+//     k_orient_all      checkMatchOrientation (:811-858) of every slot in its source frame and, for pairs
+//                       that will hand inverse matches to their target, in the target frame; per-segment
+//                       hypothesis counts
+//     scan + k_fill_all + k_entry_prep_all
+//                       every 2D segment's list of potential hypotheses in canonical (= reference
+//                       single-thread) order, with the unprojected 3D direction and the spatial
+//                       regularisers scoring needs (scoringCPU :1233-1248)
+//   chain (one launch per view, ascending camID)
+//     k_score_view      one wave per 2D segment, O(L^2) similarityForScoring (:1417-1446) with the
+//                       reference's per-camera replace/subtract accumulation (:1255-1274); an inverse
+//                       hypothesis takes part only if its source view's kernel (an earlier launch on the
+//                       same stream) wrote score3D > 0 into the shared slot
+//   post-pass (all views at once)
+//     k_filter_all / scans / k_filter_write_all / k_median_all
+//                       filterMatches (:1586-1669): 10 % of the view's best score, first strict maximum,
+//                       0.75 gate, surviving lists, best 3D hypothesis per segment, per-view median depth
 #include "l3d_dev.h"
 #include "l3d_kernels.h"
 
@@ -50,117 +60,79 @@ __device__ __forceinline__ bool orientation_ok(const double* C, const SegX& sx, 
 
 }  // namespace
 
-// One thread per slot of one pair touching view v.  `outgoing`: v is the pair's source (fresh
-// matches, p-depths); otherwise v is the target and the slot is an inverse match (q-depths) that
-// exists only if the source view kept it (kSlotAlive) and scored it > 0 (line3D.cc:1680).
-__global__ void k_list_count(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs, uint32_t pair,
-                             int outgoing, Slot* __restrict__ slots, uint32_t* __restrict__ cnt) {
-    const PairDesc& pd = pairs[pair];
+// ---- pre-pass ---------------------------------------------------------------------------------------
+// grid = (slot blocks, pairs).  One thread per slot.
+__global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+                             const uint32_t* __restrict__ seg_base, Slot* __restrict__ slots,
+                             uint32_t* __restrict__ cnt) {
+    const PairDesc& pd = pairs[blockIdx.y];
     const uint64_t n = (uint64_t)pd.Ms * pd.K;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Slot* sp = slots + pd.slot_off + i;
     const Slot s = *sp;
     if (s.tgt_seg == kEmpty) return;
-    if (outgoing) {
-        const ViewDev& v = views[pd.src];
-        const uint32_t seg = (uint32_t)(i / pd.K);
-        const bool ok = orientation_ok(v.C, v.segx[seg], s.dp1, s.dp2);
-        sp->flags = ok ? kSlotAlive : 0u;
-        sp->score3D = 0.0f;
-        if (ok) atomicAdd(&cnt[seg], 1u);
-    } else {
-        if (!(s.flags & kSlotAlive) || !(s.score3D > 0.0f)) return;
-        const ViewDev& v = views[pd.tgt];
-        const uint32_t seg = s.tgt_seg;
-        const bool ok = orientation_ok(v.C, v.segx[seg], s.dq1, s.dq2);
-        if (ok) {
-            sp->flags = s.flags | kSlotInvAlive;
-            atomicAdd(&cnt[seg], 1u);
+    const ViewDev& vs = views[pd.src];
+    const uint32_t row = (uint32_t)(i / pd.K);
+    uint32_t flags = 0;
+    if (orientation_ok(vs.C, vs.segx[row], s.dp1, s.dp2)) {
+        flags = kSlotAlive;
+        atomicAdd(&cnt[seg_base[pd.src] + row], 1u);
+        // inverse copy: only towards a view that is processed later (line3D.cc:1680)
+        if (pd.tgt > pd.src) {
+            const ViewDev& vt = views[pd.tgt];
+            if (orientation_ok(vt.C, vt.segx[s.tgt_seg], s.dq1, s.dq2)) {
+                flags |= kSlotInvAlive;
+                atomicAdd(&cnt[seg_base[pd.tgt] + s.tgt_seg], 1u);
+            }
         }
     }
+    sp->flags = flags;
+    sp->score3D = 0.0f;
 }
 
-__global__ void k_list_fill(const PairDesc* __restrict__ pairs, uint32_t pair, int outgoing,
-                            const Slot* __restrict__ slots, const uint32_t* __restrict__ off,
-                            uint32_t* __restrict__ cur, Entry* __restrict__ ents) {
-    const PairDesc& pd = pairs[pair];
+__global__ void k_fill_all(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ seg_base,
+                           const Slot* __restrict__ slots, const uint32_t* __restrict__ off,
+                           uint32_t* __restrict__ cur, Entry* __restrict__ ents) {
+    const PairDesc& pd = pairs[blockIdx.y];
     const uint64_t n = (uint64_t)pd.Ms * pd.K;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Slot s = slots[pd.slot_off + i];
-    if (s.tgt_seg == kEmpty) return;
+    if (s.tgt_seg == kEmpty || !(s.flags & kSlotAlive)) return;
     const uint32_t row = (uint32_t)(i / pd.K), j = (uint32_t)(i % pd.K);
     Entry e;
-    if (outgoing) {
-        if (!(s.flags & kSlotAlive)) return;
-        e.seg = row; e.tgt_view = pd.tgt; e.tgt_seg = s.tgt_seg;
-        e.dp1 = s.dp1; e.dp2 = s.dp2; e.dq1 = s.dq1; e.dq2 = s.dq2;
-        e.key = (1ull << 52) | ((uint64_t)pd.tgt << 32) | j;
-        e.origin = pd.slot_off + i;
-    } else {
-        if (!(s.flags & kSlotInvAlive)) return;
-        e.seg = s.tgt_seg; e.tgt_view = pd.src; e.tgt_seg = row;
-        e.dp1 = s.dq1; e.dp2 = s.dq2; e.dq1 = s.dp1; e.dq2 = s.dp2;
-        e.key = ((uint64_t)pd.src << 32) | row;
-        e.origin = ~0ull;
+    e.ref = pd.slot_off + i;
+    e.gseg = seg_base[pd.src] + row;
+    e.view = pd.src; e.tgt_view = pd.tgt; e.pair = blockIdx.y; e.pad = 0;
+    e.dp1 = s.dp1; e.dp2 = s.dp2;
+    e.key = (1ull << 52) | ((uint64_t)pd.tgt << 32) | j;   // fresh: after the inverse ones, by (tgt view, rank)
+    e.inverse = 0;
+    ents[off[e.gseg] + atomicAdd(&cur[e.gseg], 1u)] = e;
+    if (s.flags & kSlotInvAlive) {
+        e.gseg = seg_base[pd.tgt] + s.tgt_seg;
+        e.view = pd.tgt; e.tgt_view = pd.src;
+        e.dp1 = s.dq1; e.dp2 = s.dq2;
+        e.key = ((uint64_t)pd.src << 32) | row;            // inverse: by (src view, src segment)
+        e.inverse = 1;
+        ents[off[e.gseg] + atomicAdd(&cur[e.gseg], 1u)] = e;
     }
-    e.overlap = s.overlap;
-    e.score3D = 0.0f;
-    const uint32_t pos = off[e.seg] + atomicAdd(&cur[e.seg], 1u);
-    ents[pos] = e;
 }
 
-// clear the kSlotInvAlive marks of an incoming pair after the fill (so a second matchImages call
-// starts clean); folded into fill's successor for simplicity
-__global__ void k_zero_u32(uint32_t* p, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0u;
-}
-
-// single-workgroup exclusive scan of cnt[0..n) -> off[0..n], off[n] = total (also to *total)
-__global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ cnt, uint32_t n,
-                                               uint32_t* __restrict__ off, uint32_t* __restrict__ total) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + tid;
-        const uint32_t v = i < n ? cnt[i] : 0u;
-        uint32_t x = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d);
-            if (lane >= (uint32_t)d) x += y;
-        }
-        if (lane == 63) wsum[wave] = x;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t w = 0; w < wave; ++w) woff += wsum[w];
-        const uint32_t c = carry;
-        if (i < n) off[i] = c + woff + x - v;
-        __syncthreads();
-        if (tid == 1023) carry = c + woff + x;
-        __syncthreads();
-    }
-    if (tid == 0) { off[n] = carry; if (total) *total = carry; }
-}
-
-// One thread per hypothesis of the view: rank inside its segment's list (canonical order) and the
-// derived quantities scoring needs.  Reads ents (fill order), writes dents (sorted).
-__global__ void k_entry_prep(const ViewDev* __restrict__ views, uint32_t vi, const Entry* __restrict__ ents,
-                             const uint32_t* __restrict__ off, uint32_t n, DEntry* __restrict__ dents) {
+// One thread per hypothesis: rank inside its segment's list (canonical order) and the derived
+// quantities scoring needs.  Reads ents (fill order), writes dents (sorted).
+__global__ void k_entry_prep_all(const ViewDev* __restrict__ views, const uint32_t* __restrict__ seg_base,
+                                 const Entry* __restrict__ ents, const uint32_t* __restrict__ off,
+                                 const uint32_t* __restrict__ n_ptr, DEntry* __restrict__ dents) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= *n_ptr) return;
     const Entry e = ents[i];
-    const uint32_t b = off[e.seg], en = off[e.seg + 1];
+    const uint32_t b = off[e.gseg], en = off[e.gseg + 1];
     uint32_t rank = 0;
     for (uint32_t j = b; j < en; ++j) rank += (ents[j].key < e.key) ? 1u : 0u;
-    const ViewDev& v = views[vi];
+    const ViewDev& v = views[e.view];
     const ViewDev& vt = views[e.tgt_view];
-    const SegX& sx = v.segx[e.seg];
+    const SegX& sx = v.segx[e.gseg - seg_base[e.view]];
     const Seg3 s3 = unproject(v.C, sx.r1, sx.r2, e.dp1, e.dp2);
     // scoringCPU line3D.cc:1236-1248
     const float k = v.k;
@@ -173,63 +145,66 @@ __global__ void k_entry_prep(const ViewDev* __restrict__ views, uint32_t vi, con
     reg2 = 0.5f * (reg2 + 2.0f * sig2_t * sig2_t);
     DEntry d;
     d.dir[0] = s3.dir.x; d.dir[1] = s3.dir.y; d.dir[2] = s3.dir.z;
-    d.length = s3.length;
-    d.dp1 = e.dp1; d.dp2 = e.dp2; d.dq1 = e.dq1; d.dq2 = e.dq2;
-    d.reg1 = reg1; d.reg2 = reg2;
-    d.tgt_view = e.tgt_view; d.tgt_seg = e.tgt_seg;
-    d.overlap = e.overlap; d.score3D = 0.0f;
-    d.origin = e.origin;
-    d.seg = e.seg; d.keep = 0;
+    d.ref = e.ref;
+    d.dp1 = e.dp1; d.dp2 = e.dp2; d.reg1 = reg1; d.reg2 = reg2;
+    d.score3D = 0.0f;
+    d.tgt_view = e.tgt_view;
+    d.flags = (e.inverse ? kDInverse : 0u) | (s3.length < kEps ? kDZeroLen : 0u);
+    d.pair = e.pair;
     dents[b + rank] = d;
 }
 
-// similarityForScoring (line3D.cc:1417-1446) for hypotheses a (the scored one) and b of the same
-// 2D segment.  Decisions are taken on the float quantities the reference compares; acos/exp are
+// ---- chain ------------------------------------------------------------------------------------------
+// similarityForScoring (line3D.cc:1417-1446) for hypotheses a (the scored one) and b of the same 2D
+// segment.  Decisions are taken on the float quantities the reference compares; acos/exp are
 // evaluated in double and rounded to float (glibc's expf/acos differ from that by < 1 float ulp).
 struct SimConst {
     float two_sigA_sqr;
     float min_sim;     // L3D_DEF_MIN_SIMILARITY_3D
 };
-__device__ __forceinline__ float sim_scoring(const double* dira, float lena, float adp1, float adp2, float reg1,
-                                             float reg2, const double* dirb, float lenb, float bdp1, float bdp2,
+__device__ __forceinline__ float sim_scoring(const double* dira, bool zeroa, float adp1, float adp2, float reg1,
+                                             float reg2, const double* dirb, bool zerob, float bdp1, float bdp2,
                                              const SimConst sc) {
-    if (lena < kEps || lenb < kEps) return 0.0f;
-    const float dot_p = (float)dot(d3{dira[0], dira[1], dira[2]}, d3{dirb[0], dirb[1], dirb[2]});
-    // cheap exact rejections first: |dot| small => angle far beyond any sigma; positional terms
+    if (zeroa || zerob) return 0.0f;
     const float d1 = adp1 - bdp1, d2 = adp2 - bdp2;
     const float y1 = -d1 * d1 / reg1, y2 = -d2 * d2 / reg2;
-    // expf(y) > 0.5 needs y > -0.6932 (ln 0.5 = -0.693147); -0.70 is a safe early-out bound
-    if (sc.min_sim >= 0.5f && (y1 < -0.70f || y2 < -0.70f)) return 0.0f;
+    // expf(y) > 0.5 needs y > ln 0.5 = -0.693147...; -0.70 is a safe early-out bound (NaN falls through)
+    if (y1 < -0.70f || y2 < -0.70f) return 0.0f;
+    const float dot_p = (float)dot(d3{dira[0], dira[1], dira[2]}, d3{dirb[0], dirb[1], dirb[2]});
     float angle = (float)(acos((double)fmaxf(fminf(dot_p, 1.0f), -1.0f)) / M_PI * 180.0f);
     if (angle > 90.0f) angle = 180.0f - angle;
     const float ya = -angle * angle / sc.two_sigA_sqr;
-    if (sc.min_sim >= 0.5f && ya < -0.70f) return 0.0f;
+    if (ya < -0.70f) return 0.0f;
     const float sim_a = (float)exp((double)ya);
     const float sim_p = fminf((float)exp((double)y1), (float)exp((double)y2));
     const float sim = fminf(sim_a, sim_p);
     return sim > sc.min_sim ? sim : 0.0f;
 }
 
-// One wave per 2D segment.  Lanes own hypotheses M (strided by 64); the inner loop walks all
-// hypotheses M2 of the segment in canonical order from LDS.
+// One wave per 2D segment of view `vi`.  Lanes own hypotheses M (strided by 64); the inner loop walks
+// all present hypotheses M2 of the segment in canonical order from LDS.
 constexpr int kScoreChunk = 64;
-__global__ __launch_bounds__(256) void k_score(const uint32_t* __restrict__ off, uint32_t M,
-                                               DEntry* __restrict__ dents, Slot* __restrict__ slots,
-                                               uint32_t* __restrict__ max_score_bits, SimConst sc) {
+__global__ __launch_bounds__(256) void k_score_view(uint32_t g0, uint32_t M, const uint32_t* __restrict__ off,
+                                                    DEntry* __restrict__ dents, Slot* __restrict__ slots,
+                                                    uint32_t* __restrict__ max_score_bits, SimConst sc) {
     __shared__ double s_dir[4][kScoreChunk][3];
-    __shared__ float s_len[4][kScoreChunk], s_dp1[4][kScoreChunk], s_dp2[4][kScoreChunk];
-    __shared__ uint32_t s_cam[4][kScoreChunk];
+    __shared__ float s_dp1[4][kScoreChunk], s_dp2[4][kScoreChunk];
+    __shared__ uint32_t s_cam[4][kScoreChunk], s_flg[4][kScoreChunk];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t seg = blockIdx.x * 4 + wave;
     if (seg >= M) return;
-    const uint32_t b = off[seg], L = off[seg + 1] - b;
+    const uint32_t b = off[g0 + seg], L = off[g0 + seg + 1] - b;
     if (L == 0) return;
     float vmax = 0.0f;
     for (uint32_t m0 = 0; m0 < L; m0 += 64) {
         const uint32_t mi = m0 + lane;
-        const bool act = mi < L;
+        bool act = mi < L;
         DEntry a;
-        if (act) a = dents[b + mi];
+        if (act) {
+            a = dents[b + mi];
+            // an inverse hypothesis exists only if its source view scored the match > 0 (line3D.cc:1680)
+            if ((a.flags & kDInverse) && !(slots[a.ref].score3D > 0.0f)) act = false;
+        }
         float score3D = 0.0f, cur = 0.0f;
         uint32_t cur_cam = kEmpty;
         for (uint32_t c0 = 0; c0 < L; c0 += kScoreChunk) {
@@ -237,21 +212,24 @@ __global__ __launch_bounds__(256) void k_score(const uint32_t* __restrict__ off,
             __builtin_amdgcn_wave_barrier();
             if (lane < cn) {
                 const DEntry& o = dents[b + c0 + lane];
+                uint32_t f = o.flags;
+                if ((f & kDInverse) && !(slots[o.ref].score3D > 0.0f)) f |= kDAbsent;
                 s_dir[wave][lane][0] = o.dir[0]; s_dir[wave][lane][1] = o.dir[1]; s_dir[wave][lane][2] = o.dir[2];
-                s_len[wave][lane] = o.length; s_dp1[wave][lane] = o.dp1; s_dp2[wave][lane] = o.dp2;
-                s_cam[wave][lane] = o.tgt_view;
+                s_dp1[wave][lane] = o.dp1; s_dp2[wave][lane] = o.dp2;
+                s_cam[wave][lane] = o.tgt_view; s_flg[wave][lane] = f;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (act) {
                 for (uint32_t j = 0; j < cn; ++j) {
-                    const uint32_t cam2 = s_cam[wave][j];
-                    if (cam2 == a.tgt_view) continue;
-                    const float sim = sim_scoring(a.dir, a.length, a.dp1, a.dp2, a.reg1, a.reg2, s_dir[wave][j],
-                                                  s_len[wave][j], s_dp1[wave][j], s_dp2[wave][j], sc);
-                    // per-camera maximum with the reference's replace/subtract pattern; hypotheses
-                    // of one target camera are contiguous in canonical order
+                    const uint32_t cam2 = s_cam[wave][j], f2 = s_flg[wave][j];
+                    if (cam2 == a.tgt_view || (f2 & kDAbsent)) continue;
+                    const float sim = sim_scoring(a.dir, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
+                                                  s_dir[wave][j], (f2 & kDZeroLen) != 0, s_dp1[wave][j],
+                                                  s_dp2[wave][j], sc);
+                    // per-camera maximum with the reference's replace/subtract pattern; hypotheses of one
+                    // target camera are contiguous in canonical order
                     if (cam2 == cur_cam) {
                         if (sim > cur) { score3D -= cur; score3D += sim; cur = sim; }
                     } else {
@@ -260,10 +238,13 @@ __global__ __launch_bounds__(256) void k_score(const uint32_t* __restrict__ off,
                 }
             }
         }
-        if (act) {
-            dents[b + mi].score3D = score3D;
-            if (a.origin != ~0ull) slots[a.origin].score3D = score3D;
-            vmax = fmaxf(vmax, score3D);
+        if (mi < L) {
+            dents[b + mi].score3D = act ? score3D : 0.0f;
+            dents[b + mi].flags = act ? (a.flags | kDPresent) : (a.flags & ~kDPresent);
+            if (act) {
+                if (!(a.flags & kDInverse)) slots[a.ref].score3D = score3D;
+                vmax = fmaxf(vmax, score3D);
+            }
         }
     }
 #pragma unroll
@@ -271,60 +252,104 @@ __global__ __launch_bounds__(256) void k_score(const uint32_t* __restrict__ off,
     if (lane == 0 && vmax > 0.0f) atomicMax(max_score_bits, __float_as_uint(vmax));
 }
 
-// filterMatches, line3D.cc:1602-1653: one thread per segment walks its list in canonical order.
-__global__ void k_filter(const uint32_t* __restrict__ off, uint32_t M, DEntry* __restrict__ dents,
-                         const uint32_t* __restrict__ max_score_bits, uint32_t* __restrict__ surv_cnt,
-                         uint32_t* __restrict__ has_best, uint32_t* __restrict__ best_pos) {
-    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
-    if (seg >= M) return;
-    const float max_score = __uint_as_float(*max_score_bits);
-    const float lim = kMinBestScorePerc * max_score;
-    const uint32_t b = off[seg], e = off[seg + 1];
+// ---- post-pass --------------------------------------------------------------------------------------
+// filterMatches, line3D.cc:1602-1653: one wave per 2D segment (global segment id), lists in canonical order.
+__global__ __launch_bounds__(256) void k_filter_all(uint32_t G, const uint32_t* __restrict__ off,
+                                                    const uint32_t* __restrict__ gseg_view,
+                                                    DEntry* __restrict__ dents,
+                                                    const uint32_t* __restrict__ max_score_bits,
+                                                    uint32_t* __restrict__ surv_cnt, uint32_t* __restrict__ has_best,
+                                                    uint32_t* __restrict__ best_pos) {
+    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
+    if (g >= G) return;
+    const uint32_t b = off[g], L = off[g + 1] - b;
+    const float lim = kMinBestScorePerc * __uint_as_float(max_score_bits[gseg_view[g]]);
     float best = 0.0f;
     uint32_t bpos = kEmpty, kept = 0;
-    for (uint32_t i = b; i < e; ++i) {
-        const float s = dents[i].score3D;
-        if (s > 0.0f && s > lim) {
-            ++kept;
-            if (s > best) { best = s; bpos = i; }
+    for (uint32_t m0 = 0; m0 < L; m0 += 64) {
+        const uint32_t i = b + m0 + lane;
+        bool keep = false;
+        float s = 0.0f;
+        if (m0 + lane < L) {
+            const DEntry& d = dents[i];
+            s = d.score3D;
+            keep = (d.flags & kDPresent) && s > 0.0f && s > lim;
+        }
+        kept += (uint32_t)__popcll(__ballot(keep));
+        const float sv = keep ? s : 0.0f;
+        float mx = sv;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+        if (mx > best) {   // first strict maximum: the lowest position holding the chunk maximum
+            const uint64_t who = __ballot(keep && sv == mx);
+            best = mx;
+            bpos = b + m0 + (uint32_t)__ffsll((long long)who) - 1u;
         }
     }
     const bool ok = best > kMinBestScore3D;
     if (ok)
-        for (uint32_t i = b; i < e; ++i) {
-            const float s = dents[i].score3D;
-            dents[i].keep = (s > 0.0f && s > lim) ? 1u : 0u;
+        for (uint32_t m0 = 0; m0 < L; m0 += 64) {
+            const uint32_t i = b + m0 + lane;
+            if (m0 + lane < L) {
+                DEntry& d = dents[i];
+                const float s = d.score3D;
+                const bool keep = (d.flags & kDPresent) && s > 0.0f && s > lim;
+                d.flags = keep ? (d.flags | kDKeep) : (d.flags & ~kDKeep);
+            }
         }
-    surv_cnt[seg] = ok ? kept : 0u;
-    has_best[seg] = ok ? 1u : 0u;
-    best_pos[seg] = ok ? bpos : kEmpty;
+    if (lane == 0) {
+        surv_cnt[g] = ok ? kept : 0u;
+        has_best[g] = ok ? 1u : 0u;
+        best_pos[g] = ok ? bpos : kEmpty;
+    }
+}
+
+__device__ __forceinline__ void make_match(const ViewDev* views, uint32_t view, uint32_t seg, const DEntry& d,
+                                           const Slot& s, uint32_t row_of_slot, Match& m, uint32_t& tgt_seg) {
+    // a fresh hypothesis reads its slot as is; an inverse one swaps the roles (line3D.cc:1682-1692)
+    const bool inv = (d.flags & kDInverse) != 0;
+    tgt_seg = inv ? row_of_slot : s.tgt_seg;
+    m.src_cam = views[view].cam; m.src_seg = seg;
+    m.tgt_cam = views[d.tgt_view].cam; m.tgt_seg = tgt_seg;
+    m.overlap = s.overlap; m.score3D = d.score3D;
+    m.dp1 = d.dp1; m.dp2 = d.dp2;
+    m.dq1 = inv ? s.dp1 : s.dq1; m.dq2 = inv ? s.dp2 : s.dq2;
 }
 
 // write the surviving matches (reference Match layout) and the best hypothesis of every segment
-__global__ void k_filter_write(const ViewDev* __restrict__ views, uint32_t vi, const uint32_t* __restrict__ off,
-                               uint32_t M, const DEntry* __restrict__ dents, const uint32_t* __restrict__ surv_off,
-                               const uint32_t* __restrict__ hyp_off, const uint32_t* __restrict__ best_pos,
-                               Match* __restrict__ surv, uint32_t* __restrict__ surv_tv,
-                               int32_t* __restrict__ hyp_index, uint32_t hyp_base,
-                               HypRec* __restrict__ hyps, float* __restrict__ depths) {
-    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
-    if (seg >= M) return;
-    const ViewDev& v = views[vi];
-    const uint32_t bp = best_pos[seg];
-    if (bp == kEmpty) { hyp_index[seg] = -1; return; }
-    uint32_t w = surv_off[seg];
-    for (uint32_t i = off[seg]; i < off[seg + 1]; ++i) {
+__global__ void k_filter_write_all(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+                                   const uint32_t* __restrict__ seg_base, uint32_t G,
+                                   const uint32_t* __restrict__ gseg_view, const uint32_t* __restrict__ off,
+                                   const DEntry* __restrict__ dents, const Slot* __restrict__ slots,
+                                   const uint32_t* __restrict__ surv_off,
+                                   const uint32_t* __restrict__ hyp_off, const uint32_t* __restrict__ best_pos,
+                                   Match* __restrict__ surv, uint32_t* __restrict__ surv_tg,
+                                   uint32_t* __restrict__ surv_sg, int32_t* __restrict__ hyp_of_seg,
+                                   HypRec* __restrict__ hyps, float* __restrict__ depths) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const uint32_t bp = best_pos[g];
+    if (bp == kEmpty) { hyp_of_seg[g] = -1; return; }
+    const uint32_t view = gseg_view[g], seg = g - seg_base[view];
+    const ViewDev& v = views[view];
+    uint32_t w = surv_off[g];
+    for (uint32_t i = off[g]; i < off[g + 1]; ++i) {
         const DEntry& d = dents[i];
-        if (!d.keep) continue;
-        Match m;
-        m.src_cam = v.cam; m.src_seg = seg; m.tgt_cam = views[d.tgt_view].cam; m.tgt_seg = d.tgt_seg;
-        m.overlap = d.overlap; m.score3D = d.score3D;
-        m.dp1 = d.dp1; m.dp2 = d.dp2; m.dq1 = d.dq1; m.dq2 = d.dq2;
-        surv_tv[w] = d.tgt_view;
+        if (!(d.flags & kDKeep)) continue;
+        const Slot s = slots[d.ref];
+        const PairDesc& pd = pairs[d.pair];
+        const uint32_t row = (uint32_t)((d.ref - pd.slot_off) / pd.K);
+        Match m; uint32_t tseg;
+        make_match(views, view, seg, d, s, row, m, tseg);
+        surv_tg[w] = seg_base[d.tgt_view] + tseg;
+        surv_sg[w] = g;
         surv[w++] = m;
     }
     const DEntry& d = dents[bp];
-    const uint32_t h = hyp_off[seg];
+    const Slot s = slots[d.ref];
+    const PairDesc& pd = pairs[d.pair];
+    const uint32_t row = (uint32_t)((d.ref - pd.slot_off) / pd.K);
+    const uint32_t h = hyp_off[g];
     HypRec r;
     const SegX& sx = v.segx[seg];
     const Seg3 s3 = unproject(v.C, sx.r1, sx.r2, d.dp1, d.dp2);   // unprojectMatch(best,true), :1638
@@ -333,26 +358,29 @@ __global__ void k_filter_write(const ViewDev* __restrict__ views, uint32_t vi, c
     r.dir[0] = s3.dir.x; r.dir[1] = s3.dir.y; r.dir[2] = s3.dir.z;
     r.length = s3.length;
     r.valid = s3.length > 0.0f ? 1u : 0u;
-    r.m.src_cam = v.cam; r.m.src_seg = seg; r.m.tgt_cam = views[d.tgt_view].cam; r.m.tgt_seg = d.tgt_seg;
-    r.m.overlap = d.overlap; r.m.score3D = d.score3D;
-    r.m.dp1 = d.dp1; r.m.dp2 = d.dp2; r.m.dq1 = d.dq1; r.m.dq2 = d.dq2;
-    r.view = vi; r.pad = 0;
-    hyps[hyp_base + h] = r;
-    hyp_index[seg] = (int32_t)(hyp_base + h);
+    uint32_t tseg;
+    make_match(views, view, seg, d, s, row, r.m, tseg);
+    r.view = view; r.pad = 0;
+    hyps[h] = r;
+    hyp_of_seg[g] = (int32_t)h;
     depths[2 * h] = d.dp1;
     depths[2 * h + 1] = d.dp2;
 }
 
 // median = sorted(depths)[n/2] by 4-pass radix select on the (positive) float bit patterns;
-// n == 0 -> L3D_EPS (line3D.cc:1658).  Single workgroup; n is at most 2*M.
-__global__ __launch_bounds__(1024) void k_median_depth(const float* __restrict__ depths,
-                                                       const uint32_t* __restrict__ n_hyp_ptr,
-                                                       float* __restrict__ out_median) {
+// n == 0 -> L3D_EPS (line3D.cc:1658).  One workgroup per view.
+__global__ __launch_bounds__(1024) void k_median_all(const float* __restrict__ depths,
+                                                     const uint32_t* __restrict__ hyp_off,
+                                                     const uint32_t* __restrict__ seg_base,
+                                                     float* __restrict__ out_median) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_prefix, s_rank;
-    const uint32_t n = 2u * (*n_hyp_ptr);
+    const uint32_t v = blockIdx.x;
+    const uint32_t h0 = hyp_off[seg_base[v]], h1 = hyp_off[seg_base[v + 1]];
+    const uint32_t n = 2u * (h1 - h0);
+    const float* dv = depths + 2u * h0;
     if (n == 0) {
-        if (threadIdx.x == 0) *out_median = (float)kEps;
+        if (threadIdx.x == 0) out_median[v] = (float)kEps;
         return;
     }
     if (threadIdx.x == 0) { s_prefix = 0; s_rank = n / 2; }
@@ -364,7 +392,7 @@ __global__ __launch_bounds__(1024) void k_median_depth(const float* __restrict__
         const uint32_t prefix = s_prefix;
         const uint32_t himask = pass == 3 ? 0u : (0xFFFFFFFFu << (shift + 8));
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint32_t bits = __float_as_uint(depths[i]);
+            const uint32_t bits = __float_as_uint(dv[i]);
             if ((bits & himask) == prefix) atomicAdd(&hist[(bits >> shift) & 255u], 1u);
         }
         __syncthreads();
@@ -379,64 +407,153 @@ __global__ __launch_bounds__(1024) void k_median_depth(const float* __restrict__
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out_median = __uint_as_float(s_prefix);
+    if (threadIdx.x == 0) out_median[v] = __uint_as_float(s_prefix);
 }
 
-// ---- launchers --------------------------------------------------------------------------------
-hipError_t launch_list_count(const ViewDev* views, const PairDesc* pairs, uint32_t pair, uint64_t nslots,
-                             int outgoing, Slot* slots, uint32_t* cnt, hipStream_t st) {
-    if (!nslots) return hipSuccess;
-    hipLaunchKernelGGL(k_list_count, dim3((uint32_t)((nslots + 255) / 256)), dim3(256), 0, st, views, pairs, pair,
-                       outgoing, slots, cnt);
+// ---- exclusive scan of uint32 arrays of any length: block sums, scan of sums, downsweep ------------
+constexpr uint32_t kScanBlock = 1024, kScanItems = 4, kScanTile = kScanBlock * kScanItems;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wsum /*[17]*/, uint32_t& block_total) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t w = 0; w < kScanBlock / 64; ++w) { const uint32_t t = wsum[w]; wsum[w] = acc; acc += t; }
+        wsum[16] = acc;
+    }
+    __syncthreads();
+    block_total = wsum[16];
+    const uint32_t r = wsum[wave] + x - v;
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_sums(const uint32_t* __restrict__ in, uint32_t n,
+                                                          uint32_t* __restrict__ sums) {
+    __shared__ uint32_t wsum[17];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanItems; ++k) v += (base + k < n) ? in[base + k] : 0u;
+    uint32_t total;
+    (void)block_exclusive_scan(v, wsum, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_top(uint32_t* __restrict__ sums, uint32_t nb,
+                                                         uint32_t* __restrict__ total_out) {
+    __shared__ uint32_t wsum[17];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nb; b0 += kScanBlock) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t v = i < nb ? sums[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, wsum, total);
+        const uint32_t c = carry;
+        if (i < nb) sums[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_down(const uint32_t* __restrict__ in, uint32_t n,
+                                                          const uint32_t* __restrict__ sums,
+                                                          uint32_t* __restrict__ out, const uint32_t* total) {
+    __shared__ uint32_t wsum[17];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t a[kScanItems];
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanItems; ++k) { a[k] = (base + k < n) ? in[base + k] : 0u; v += a[k]; }
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan(v, wsum, tot) + sums[blockIdx.x];
+#pragma unroll
+    for (uint32_t k = 0; k < kScanItems; ++k) {
+        if (base + k < n) out[base + k] = ex;
+        ex += a[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+}
+
+// out[0..n] = exclusive scan of in[0..n) (out[n] = total, also stored to *total).  tmp: >= n/4096+2 words.
+hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, uint32_t* total, hipStream_t st) {
+    const uint32_t nb = (n + kScanTile - 1) / kScanTile;
+    if (nb == 0) {
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, st, tmp, 0u, total);
+        hipLaunchKernelGGL(k_scan_down, dim3(1), dim3(kScanBlock), 0, st, in, 0u, tmp, out, total);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(kScanBlock), 0, st, in, n, tmp);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, st, tmp, nb, total);
+    hipLaunchKernelGGL(k_scan_down, dim3(nb), dim3(kScanBlock), 0, st, in, n, tmp, out, total);
     return hipGetLastError();
 }
-hipError_t launch_list_fill(const PairDesc* pairs, uint32_t pair, uint64_t nslots, int outgoing, const Slot* slots,
-                            const uint32_t* off, uint32_t* cur, Entry* ents, hipStream_t st) {
-    if (!nslots) return hipSuccess;
-    hipLaunchKernelGGL(k_list_fill, dim3((uint32_t)((nslots + 255) / 256)), dim3(256), 0, st, pairs, pair, outgoing,
-                       slots, off, cur, ents);
+
+// ---- launchers --------------------------------------------------------------------------------------
+hipError_t launch_orient_all(const ViewDev* views, const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots,
+                             const uint32_t* seg_base, Slot* slots, uint32_t* cnt, hipStream_t st) {
+    if (!n_pairs || !max_slots) return hipSuccess;
+    hipLaunchKernelGGL(k_orient_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, views,
+                       pairs, seg_base, slots, cnt);
     return hipGetLastError();
 }
-hipError_t launch_zero_u32(uint32_t* p, uint64_t n, hipStream_t st) {
-    if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_zero_u32, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, p, n);
+hipError_t launch_fill_all(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
+                           const Slot* slots, const uint32_t* off, uint32_t* cur, Entry* ents, hipStream_t st) {
+    if (!n_pairs || !max_slots) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, pairs,
+                       seg_base, slots, off, cur, ents);
     return hipGetLastError();
 }
-hipError_t launch_scan(const uint32_t* cnt, uint32_t n, uint32_t* off, uint32_t* total, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, cnt, n, off, total);
+hipError_t launch_entry_prep_all(const ViewDev* views, const uint32_t* seg_base, const Entry* ents,
+                                 const uint32_t* off, const uint32_t* n_ptr, uint32_t n_upper, DEntry* dents,
+                                 hipStream_t st) {
+    if (!n_upper) return hipSuccess;
+    hipLaunchKernelGGL(k_entry_prep_all, dim3((n_upper + 127) / 128), dim3(128), 0, st, views, seg_base, ents, off,
+                       n_ptr, dents);
     return hipGetLastError();
 }
-hipError_t launch_entry_prep(const ViewDev* views, uint32_t vi, const Entry* ents, const uint32_t* off, uint32_t n,
-                             DEntry* dents, hipStream_t st) {
-    if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_entry_prep, dim3((n + 127) / 128), dim3(128), 0, st, views, vi, ents, off, n, dents);
-    return hipGetLastError();
-}
-hipError_t launch_score(const uint32_t* off, uint32_t M, DEntry* dents, Slot* slots, uint32_t* max_score_bits,
-                        float two_sigA_sqr, float min_sim, hipStream_t st) {
+hipError_t launch_score_view(uint32_t g0, uint32_t M, const uint32_t* off, DEntry* dents, Slot* slots,
+                             uint32_t* max_score_bits, float two_sigA_sqr, float min_sim, hipStream_t st) {
     if (!M) return hipSuccess;
     SimConst sc{two_sigA_sqr, min_sim};
-    hipLaunchKernelGGL(k_score, dim3((M + 3) / 4), dim3(256), 0, st, off, M, dents, slots, max_score_bits, sc);
+    hipLaunchKernelGGL(k_score_view, dim3((M + 3) / 4), dim3(256), 0, st, g0, M, off, dents, slots, max_score_bits, sc);
     return hipGetLastError();
 }
-hipError_t launch_filter(const uint32_t* off, uint32_t M, DEntry* dents, const uint32_t* max_score_bits,
-                         uint32_t* surv_cnt, uint32_t* has_best, uint32_t* best_pos, hipStream_t st) {
-    if (!M) return hipSuccess;
-    hipLaunchKernelGGL(k_filter, dim3((M + 127) / 128), dim3(128), 0, st, off, M, dents, max_score_bits, surv_cnt,
-                       has_best, best_pos);
+hipError_t launch_filter_all(uint32_t G, const uint32_t* off, const uint32_t* gseg_view, DEntry* dents,
+                             const uint32_t* max_score_bits, uint32_t* surv_cnt, uint32_t* has_best,
+                             uint32_t* best_pos, hipStream_t st) {
+    if (!G) return hipSuccess;
+    hipLaunchKernelGGL(k_filter_all, dim3((G + 3) / 4), dim3(256), 0, st, G, off, gseg_view, dents, max_score_bits,
+                       surv_cnt, has_best, best_pos);
     return hipGetLastError();
 }
-hipError_t launch_filter_write(const ViewDev* views, uint32_t vi, const uint32_t* off, uint32_t M,
-                               const DEntry* dents, const uint32_t* surv_off, const uint32_t* hyp_off,
-                               const uint32_t* best_pos, Match* surv, uint32_t* surv_tv, int32_t* hyp_index,
-                               uint32_t hyp_base, HypRec* hyps, float* depths, hipStream_t st) {
-    if (!M) return hipSuccess;
-    hipLaunchKernelGGL(k_filter_write, dim3((M + 127) / 128), dim3(128), 0, st, views, vi, off, M, dents, surv_off,
-                       hyp_off, best_pos, surv, surv_tv, hyp_index, hyp_base, hyps, depths);
+hipError_t launch_filter_write_all(const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base, uint32_t G,
+                                   const uint32_t* gseg_view, const uint32_t* off, const DEntry* dents,
+                                   const Slot* slots, const uint32_t* surv_off,
+                                   const uint32_t* hyp_off, const uint32_t* best_pos, Match* surv, uint32_t* surv_tg,
+                                   uint32_t* surv_sg, int32_t* hyp_of_seg, HypRec* hyps, float* depths,
+                                   hipStream_t st) {
+    if (!G) return hipSuccess;
+    hipLaunchKernelGGL(k_filter_write_all, dim3((G + 127) / 128), dim3(128), 0, st, views, pairs, seg_base, G,
+                       gseg_view, off, dents, slots, surv_off, hyp_off, best_pos, surv, surv_tg, surv_sg,
+                       hyp_of_seg, hyps, depths);
     return hipGetLastError();
 }
-hipError_t launch_median_depth(const float* depths, const uint32_t* n_hyp_ptr, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_median_depth, dim3(1), dim3(1024), 0, st, depths, n_hyp_ptr, out);
+hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base,
+                             float* out, hipStream_t st) {
+    if (!V) return hipSuccess;
+    hipLaunchKernelGGL(k_median_all, dim3(V), dim3(1024), 0, st, depths, hyp_off, seg_base, out);
     return hipGetLastError();
 }
 

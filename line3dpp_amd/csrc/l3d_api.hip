@@ -14,27 +14,30 @@ static thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
 
 // ---- prototypes of the launchers in k_views.hip / k_affinity.hip -------------------------------
-hipError_t launch_list_count(const ViewDev*, const PairDesc*, uint32_t pair, uint64_t nslots, int outgoing, Slot*,
-                             uint32_t* cnt, hipStream_t);
-hipError_t launch_list_fill(const PairDesc*, uint32_t pair, uint64_t nslots, int outgoing, const Slot*,
-                            const uint32_t* off, uint32_t* cur, Entry*, hipStream_t);
-hipError_t launch_zero_u32(uint32_t*, uint64_t n, hipStream_t);
-hipError_t launch_scan(const uint32_t* cnt, uint32_t n, uint32_t* off, uint32_t* total, hipStream_t);
-hipError_t launch_entry_prep(const ViewDev*, uint32_t vi, const Entry*, const uint32_t* off, uint32_t n, DEntry*,
-                             hipStream_t);
-hipError_t launch_score(const uint32_t* off, uint32_t M, DEntry*, Slot*, uint32_t* max_score_bits,
-                        float two_sigA_sqr, float min_sim, hipStream_t);
-hipError_t launch_filter(const uint32_t* off, uint32_t M, DEntry*, const uint32_t* max_score_bits,
-                         uint32_t* surv_cnt, uint32_t* has_best, uint32_t* best_pos, hipStream_t);
-hipError_t launch_filter_write(const ViewDev*, uint32_t vi, const uint32_t* off, uint32_t M, const DEntry*,
-                               const uint32_t* surv_off, const uint32_t* hyp_off, const uint32_t* best_pos,
-                               Match* surv, uint32_t* surv_tv, int32_t* hyp_index, uint32_t hyp_base, HypRec*,
-                               float* depths, hipStream_t);
-hipError_t launch_median_depth(const float* depths, const uint32_t* n_hyp_ptr, float* out, hipStream_t);
-hipError_t launch_aff_sim(const ViewAff*, uint32_t V, uint32_t N, const HypRec*, const float* msdl,
-                          float two_sigA_sqr, float* simv, int32_t* ca, int32_t* cb, hipStream_t);
-hipError_t launch_aff_flag(const ViewAff*, uint32_t V, uint32_t N, const float* simv, const int32_t* ca,
-                           const int32_t* cb, uint32_t* flag, hipStream_t);
+hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, uint32_t* total, hipStream_t);
+hipError_t launch_orient_all(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
+                             const uint32_t* seg_base, Slot*, uint32_t* cnt, hipStream_t);
+hipError_t launch_fill_all(const PairDesc*, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
+                           const Slot*, const uint32_t* off, uint32_t* cur, Entry*, hipStream_t);
+hipError_t launch_entry_prep_all(const ViewDev*, const uint32_t* seg_base, const Entry*, const uint32_t* off,
+                                 const uint32_t* n_ptr, uint32_t n_upper, DEntry*, hipStream_t);
+hipError_t launch_score_view(uint32_t g0, uint32_t M, const uint32_t* off, DEntry*, Slot*, uint32_t* max_score_bits,
+                             float two_sigA_sqr, float min_sim, hipStream_t);
+hipError_t launch_filter_all(uint32_t G, const uint32_t* off, const uint32_t* gseg_view, DEntry*,
+                             const uint32_t* max_score_bits, uint32_t* surv_cnt, uint32_t* has_best,
+                             uint32_t* best_pos, hipStream_t);
+hipError_t launch_filter_write_all(const ViewDev*, const PairDesc*, const uint32_t* seg_base, uint32_t G,
+                                   const uint32_t* gseg_view, const uint32_t* off, const DEntry*, const Slot*,
+                                   const uint32_t* surv_off, const uint32_t* hyp_off, const uint32_t* best_pos,
+                                   Match* surv, uint32_t* surv_tg, uint32_t* surv_sg, int32_t* hyp_of_seg, HypRec*,
+                                   float* depths, hipStream_t);
+hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base,
+                             float* out, hipStream_t);
+hipError_t launch_aff_sim(uint32_t N, const uint32_t* surv_sg, const uint32_t* surv_tg, const int32_t* hyp_of_seg,
+                          const HypRec*, const ViewAff*, const float* medians, const float* msdl, float two_sigA_sqr,
+                          float* simv, int32_t* ca, int32_t* cb, hipStream_t);
+hipError_t launch_aff_flag(uint32_t N, const uint32_t* surv_off, const uint32_t* surv_sg, const uint32_t* surv_tg,
+                           const float* simv, const int32_t* ca, const int32_t* cb, uint32_t* flag, hipStream_t);
 hipError_t launch_fill_u32(uint32_t*, uint32_t n, uint32_t val, hipStream_t);
 hipError_t launch_aff_touch(uint32_t N, const uint32_t* flag, const uint32_t* epos, const int32_t* ca,
                             const int32_t* cb, uint32_t* first_touch, hipStream_t);
@@ -76,24 +79,28 @@ struct l3d_ctx {
     DevBuf<Slot> d_slots;
     DevBuf<uint32_t> d_row_counts;
     DevBuf<double> d_consts;                        // per view: RtKinv[9], C[3]
-    // phase-B scratch
-    DevBuf<uint32_t> d_cnt, d_off, d_cur, d_surv_cnt, d_has_best, d_best_pos, d_surv_off_tmp, d_hyp_off, d_scal;
+    // phase B (global over all views; G = sum of M)
+    uint32_t G = 0, n_ents = 0, n_surv = 0, n_hyps = 0;
+    std::vector<uint32_t> seg_base;                 // [V+1]
+    DevBuf<uint32_t> d_seg_base, d_gseg_view, d_cnt, d_off, d_cur, d_scan_tmp, d_scal, d_max_score;
+    DevBuf<uint32_t> d_surv_cnt, d_has_best, d_best_pos, d_surv_off, d_hyp_off, d_surv_tg, d_surv_sg;
     DevBuf<Entry> d_ents;
     DevBuf<DEntry> d_dents;
+    DevBuf<Match> d_surv;
+    DevBuf<int32_t> d_hyp_of_seg;
     DevBuf<float> d_depths, d_medians;              // d_medians[V]
     DevBuf<HypRec> d_hyps;
-    uint32_t n_hyps = 0;
+    std::vector<uint32_t> h_surv_off, h_hyp_off;    // lazily fetched for the accessors
+    bool host_offsets_valid = false;
     // affinity
     DevBuf<ViewAff> d_vaff;
     DevBuf<float> d_simv, d_msdl;
     DevBuf<int32_t> d_ca, d_cb;
-    DevBuf<uint32_t> d_flag, d_epos, d_first_touch, d_touch_flag, d_touch_rank, d_aff_scal;
+    DevBuf<uint32_t> d_flag, d_epos, d_first_touch, d_touch_flag, d_touch_rank;
     DevBuf<l3d_cledge> d_edges;
     DevBuf<l3d_segment2d> d_l2g;
     std::vector<l3d_cledge> edges;
     std::vector<l3d_segment2d> l2g;
-    // per-view surviving-match target-view arrays
-    std::vector<DevBuf<uint32_t>*> surv_tv;
     // timings
     hipEvent_t ev[8] = {};
     l3d_timings tm{};
@@ -220,17 +227,17 @@ void l3d_destroy(l3d_ctx* c) {
     for (auto& kv : c->views) {
         HostView& v = *kv.second;
         v.d_seg4.release(); v.d_segf.release(); v.d_segx.release();
-        v.d_surv_off.release(); v.d_surv.release(); v.d_hyp.release();
     }
-    for (auto* b : c->surv_tv) { b->release(); delete b; }
     c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release();
-    c->d_row_counts.release(); c->d_consts.release(); c->d_cnt.release(); c->d_off.release();
-    c->d_cur.release(); c->d_surv_cnt.release(); c->d_has_best.release(); c->d_best_pos.release();
-    c->d_surv_off_tmp.release(); c->d_hyp_off.release(); c->d_scal.release(); c->d_ents.release();
-    c->d_dents.release(); c->d_depths.release(); c->d_medians.release(); c->d_hyps.release();
+    c->d_row_counts.release(); c->d_consts.release();
+    c->d_seg_base.release(); c->d_gseg_view.release(); c->d_cnt.release(); c->d_off.release(); c->d_cur.release();
+    c->d_scan_tmp.release(); c->d_scal.release(); c->d_max_score.release(); c->d_surv_cnt.release();
+    c->d_has_best.release(); c->d_best_pos.release(); c->d_surv_off.release(); c->d_hyp_off.release();
+    c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_ents.release(); c->d_dents.release(); c->d_surv.release();
+    c->d_hyp_of_seg.release(); c->d_depths.release(); c->d_medians.release(); c->d_hyps.release();
     c->d_vaff.release(); c->d_simv.release(); c->d_msdl.release(); c->d_ca.release(); c->d_cb.release();
     c->d_flag.release(); c->d_epos.release(); c->d_first_touch.release(); c->d_touch_flag.release();
-    c->d_touch_rank.release(); c->d_aff_scal.release(); c->d_edges.release(); c->d_l2g.release();
+    c->d_touch_rank.release(); c->d_edges.release(); c->d_l2g.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
@@ -309,7 +316,6 @@ int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
         if (!c->fixed3Dregularizer) v->k = spatial_reg(*v, c->sigma_p);      // computeSpatialRegularizer
         else v->k = c->sigma_p / c->med_scene_depth;                          // update_k, view.h:124-127
         v->median_depth = 0.0f;
-        v->n_surv = 0; v->n_hyp = 0;
         v->out_pairs.clear(); v->in_pairs.clear();
     }
     // fixed neighbours, line3D.cc:467-479 (sets persist across calls like visual_neighbors_)
@@ -442,90 +448,85 @@ int l3d_slot_buffer(l3d_ctx* c, void** dev_ptr, uint64_t* n_slots) {
     return L3D_OK;
 }
 
-// phase B: line3D.cc:745-773 for every view in ascending camID order
+// phase B: line3D.cc:745-773 for every view in ascending camID order (k_views.hip)
 int l3d_match_finish(l3d_ctx* c) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->state != l3d_ctx::BEGUN) return fail(L3D_ERR_STATE, "l3d_match_begin must precede l3d_match_finish");
     (void)hipSetDevice(c->device);
     hipStream_t st = c->stream;
-    const size_t V = c->order.size();
-    // scratch sizes
-    uint32_t maxM = 0; uint64_t max_ents = 0, total_hyp_cap = 0;
-    for (auto* v : c->order) {
-        maxM = std::max(maxM, v->M);
-        uint64_t e = 0;
-        for (uint32_t p : v->out_pairs) e += (uint64_t)c->pairs[p].Ms * c->pairs[p].K;
-        for (uint32_t p : v->in_pairs) e += (uint64_t)c->pairs[p].Ms * c->pairs[p].K;
-        max_ents = std::max(max_ents, e);
-        total_hyp_cap += v->M;
-    }
-    if (max_ents >= (1ull << 32)) return fail(L3D_ERR_LIMIT, "more than 2^32 hypotheses in one view");
-    L3D_HIP_CHECK(c->d_cnt.reserve(maxM + 1)); L3D_HIP_CHECK(c->d_off.reserve(maxM + 1));
-    L3D_HIP_CHECK(c->d_cur.reserve(maxM + 1)); L3D_HIP_CHECK(c->d_surv_cnt.reserve(maxM + 1));
-    L3D_HIP_CHECK(c->d_has_best.reserve(maxM + 1)); L3D_HIP_CHECK(c->d_best_pos.reserve(maxM + 1));
-    L3D_HIP_CHECK(c->d_surv_off_tmp.reserve(maxM + 1)); L3D_HIP_CHECK(c->d_hyp_off.reserve(maxM + 1));
-    L3D_HIP_CHECK(c->d_scal.reserve(4 * V + 4));   // per view: n_ents, max_score_bits, n_surv, n_hyp
-    L3D_HIP_CHECK(c->d_ents.reserve(std::max<uint64_t>(max_ents, 1)));
-    L3D_HIP_CHECK(c->d_dents.reserve(std::max<uint64_t>(max_ents, 1)));
-    L3D_HIP_CHECK(c->d_depths.reserve(2 * (size_t)maxM + 2));
-    L3D_HIP_CHECK(c->d_medians.reserve(V));
-    L3D_HIP_CHECK(c->d_hyps.reserve(std::max<uint64_t>(total_hyp_cap, 1)));
-    while (c->surv_tv.size() < V) c->surv_tv.push_back(new DevBuf<uint32_t>());
+    const uint32_t V = (uint32_t)c->order.size(), P = (uint32_t)c->pairs.size();
+    // global segment ids
+    c->seg_base.assign(V + 1, 0);
+    for (uint32_t vi = 0; vi < V; ++vi) c->seg_base[vi + 1] = c->seg_base[vi] + c->order[vi]->M;
+    const uint32_t G = c->G = c->seg_base[V];
+    std::vector<uint32_t> gseg_view(G);
+    for (uint32_t vi = 0; vi < V; ++vi)
+        std::fill(gseg_view.begin() + c->seg_base[vi], gseg_view.begin() + c->seg_base[vi + 1], vi);
+    uint64_t max_slots = 0;
+    for (auto& pd : c->pairs) max_slots = std::max<uint64_t>(max_slots, (uint64_t)pd.Ms * pd.K);
+    if (2 * c->n_slots >= (1ull << 32)) return fail(L3D_ERR_LIMIT, "more than 2^32 hypotheses");
+    L3D_HIP_CHECK(c->d_seg_base.reserve(V + 1)); L3D_HIP_CHECK(c->d_gseg_view.reserve(G + 1));
+    L3D_HIP_CHECK(c->d_cnt.reserve(G + 1)); L3D_HIP_CHECK(c->d_off.reserve(G + 1)); L3D_HIP_CHECK(c->d_cur.reserve(G + 1));
+    L3D_HIP_CHECK(c->d_scan_tmp.reserve(G / 4096 + 1024)); L3D_HIP_CHECK(c->d_scal.reserve(8));
+    L3D_HIP_CHECK(c->d_max_score.reserve(V + 1));
+    L3D_HIP_CHECK(c->d_surv_cnt.reserve(G + 1)); L3D_HIP_CHECK(c->d_has_best.reserve(G + 1));
+    L3D_HIP_CHECK(c->d_best_pos.reserve(G + 1)); L3D_HIP_CHECK(c->d_surv_off.reserve(G + 1));
+    L3D_HIP_CHECK(c->d_hyp_off.reserve(G + 1)); L3D_HIP_CHECK(c->d_hyp_of_seg.reserve(G + 1));
+    L3D_HIP_CHECK(c->d_medians.reserve(V + 1));
+    L3D_HIP_CHECK(hipMemcpyAsync(c->d_seg_base.p, c->seg_base.data(), (V + 1) * 4, hipMemcpyHostToDevice, st));
+    L3D_HIP_CHECK(hipMemcpyAsync(c->d_gseg_view.p, gseg_view.data(), (size_t)G * 4, hipMemcpyHostToDevice, st));
+    L3D_HIP_CHECK(hipStreamSynchronize(st));   // gseg_view is a local
     L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
-    L3D_HIP_CHECK(hipMemsetAsync(c->d_scal.p, 0, (4 * V + 4) * 4, st));
-    uint32_t hyp_base = 0;
-    for (size_t vi = 0; vi < V; ++vi) {
-        HostView& v = *c->order[vi];
-        uint32_t* scal = c->d_scal.p + 4 * vi;
-        L3D_HIP_CHECK(hipMemsetAsync(c->d_cnt.p, 0, (v.M + 1) * 4, st));
-        L3D_HIP_CHECK(hipMemsetAsync(c->d_cur.p, 0, (v.M + 1) * 4, st));
-        for (uint32_t p : v.in_pairs)
-            L3D_HIP_CHECK(launch_list_count(c->d_views.p, c->d_pairs.p, p, (uint64_t)c->pairs[p].Ms * c->pairs[p].K, 0,
-                                            c->d_slots.p, c->d_cnt.p, st));
-        for (uint32_t p : v.out_pairs)
-            L3D_HIP_CHECK(launch_list_count(c->d_views.p, c->d_pairs.p, p, (uint64_t)c->pairs[p].Ms * c->pairs[p].K, 1,
-                                            c->d_slots.p, c->d_cnt.p, st));
-        L3D_HIP_CHECK(launch_scan(c->d_cnt.p, v.M, c->d_off.p, scal + 0, st));
-        for (uint32_t p : v.in_pairs)
-            L3D_HIP_CHECK(launch_list_fill(c->d_pairs.p, p, (uint64_t)c->pairs[p].Ms * c->pairs[p].K, 0, c->d_slots.p,
-                                           c->d_off.p, c->d_cur.p, c->d_ents.p, st));
-        for (uint32_t p : v.out_pairs)
-            L3D_HIP_CHECK(launch_list_fill(c->d_pairs.p, p, (uint64_t)c->pairs[p].Ms * c->pairs[p].K, 1, c->d_slots.p,
-                                           c->d_off.p, c->d_cur.p, c->d_ents.p, st));
-        // the entry count is needed on the host to size the launches of this view
-        uint32_t n_ents = 0;
-        L3D_HIP_CHECK(hipMemcpyAsync(&n_ents, scal + 0, 4, hipMemcpyDeviceToHost, st));
-        L3D_HIP_CHECK(hipStreamSynchronize(st));
-        L3D_HIP_CHECK(launch_entry_prep(c->d_views.p, (uint32_t)vi, c->d_ents.p, c->d_off.p, n_ents, c->d_dents.p, st));
-        L3D_HIP_CHECK(launch_score(c->d_off.p, v.M, c->d_dents.p, c->d_slots.p, scal + 1, c->two_sigA_sqr, 0.5f, st));
-        L3D_HIP_CHECK(launch_filter(c->d_off.p, v.M, c->d_dents.p, scal + 1, c->d_surv_cnt.p, c->d_has_best.p,
-                                    c->d_best_pos.p, st));
-        L3D_HIP_CHECK(launch_scan(c->d_surv_cnt.p, v.M, c->d_surv_off_tmp.p, scal + 2, st));
-        L3D_HIP_CHECK(launch_scan(c->d_has_best.p, v.M, c->d_hyp_off.p, scal + 3, st));
-        uint32_t ns[2] = {0, 0};
-        L3D_HIP_CHECK(hipMemcpyAsync(ns, scal + 2, 8, hipMemcpyDeviceToHost, st));
-        L3D_HIP_CHECK(hipStreamSynchronize(st));
-        v.n_surv = ns[0]; v.n_hyp = ns[1]; v.hyp_base = hyp_base;
-        L3D_HIP_CHECK(v.d_surv_off.reserve(v.M + 1));
-        L3D_HIP_CHECK(v.d_surv.reserve(std::max<uint32_t>(v.n_surv, 1)));
-        L3D_HIP_CHECK(c->surv_tv[vi]->reserve(std::max<uint32_t>(v.n_surv, 1)));
-        L3D_HIP_CHECK(v.d_hyp.reserve(v.M));
-        L3D_HIP_CHECK(hipMemcpyAsync(v.d_surv_off.p, c->d_surv_off_tmp.p, (v.M + 1) * 4, hipMemcpyDeviceToDevice, st));
-        L3D_HIP_CHECK(launch_filter_write(c->d_views.p, (uint32_t)vi, c->d_off.p, v.M, c->d_dents.p, v.d_surv_off.p,
-                                          c->d_hyp_off.p, c->d_best_pos.p, v.d_surv.p, c->surv_tv[vi]->p, v.d_hyp.p,
-                                          hyp_base, c->d_hyps.p, c->d_depths.p, st));
-        L3D_HIP_CHECK(launch_median_depth(c->d_depths.p, scal + 3, c->d_medians.p + vi, st));
-        hyp_base += v.n_hyp;
-    }
-    c->n_hyps = hyp_base;
+    L3D_HIP_CHECK(hipMemsetAsync(c->d_cnt.p, 0, ((size_t)G + 1) * 4, st));
+    L3D_HIP_CHECK(hipMemsetAsync(c->d_cur.p, 0, ((size_t)G + 1) * 4, st));
+    L3D_HIP_CHECK(hipMemsetAsync(c->d_max_score.p, 0, ((size_t)V + 1) * 4, st));
+    L3D_HIP_CHECK(hipMemsetAsync(c->d_scal.p, 0, 8 * 4, st));
+    // ---- pre-pass: orientation flags, per-segment lists in canonical order ----
+    L3D_HIP_CHECK(launch_orient_all(c->d_views.p, c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p,
+                                    c->d_cnt.p, st));
+    L3D_HIP_CHECK(launch_scan(c->d_cnt.p, G, c->d_off.p, c->d_scan_tmp.p, c->d_scal.p + 0, st));
+    uint32_t n_ents = 0;
+    L3D_HIP_CHECK(hipMemcpyAsync(&n_ents, c->d_scal.p + 0, 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipStreamSynchronize(st));
+    c->n_ents = n_ents;
+    L3D_HIP_CHECK(c->d_ents.reserve(std::max<uint32_t>(n_ents, 1)));
+    L3D_HIP_CHECK(c->d_dents.reserve(std::max<uint32_t>(n_ents, 1)));
+    L3D_HIP_CHECK(launch_fill_all(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_off.p, c->d_cur.p,
+                                  c->d_ents.p, st));
+    L3D_HIP_CHECK(launch_entry_prep_all(c->d_views.p, c->d_seg_base.p, c->d_ents.p, c->d_off.p, c->d_scal.p + 0,
+                                        n_ents, c->d_dents.p, st));
+    // ---- chain: one scoring launch per view, ascending camID ----
+    for (uint32_t vi = 0; vi < V; ++vi)
+        L3D_HIP_CHECK(launch_score_view(c->seg_base[vi], c->order[vi]->M, c->d_off.p, c->d_dents.p, c->d_slots.p,
+                                        c->d_max_score.p + vi, c->two_sigA_sqr, 0.5f, st));
+    // ---- post-pass: filterMatches for all views ----
+    L3D_HIP_CHECK(launch_filter_all(G, c->d_off.p, c->d_gseg_view.p, c->d_dents.p, c->d_max_score.p, c->d_surv_cnt.p,
+                                    c->d_has_best.p, c->d_best_pos.p, st));
+    L3D_HIP_CHECK(launch_scan(c->d_surv_cnt.p, G, c->d_surv_off.p, c->d_scan_tmp.p, c->d_scal.p + 1, st));
+    L3D_HIP_CHECK(launch_scan(c->d_has_best.p, G, c->d_hyp_off.p, c->d_scan_tmp.p, c->d_scal.p + 2, st));
+    uint32_t nh[2] = {0, 0};
+    L3D_HIP_CHECK(hipMemcpyAsync(nh, c->d_scal.p + 1, 8, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipStreamSynchronize(st));
+    c->n_surv = nh[0]; c->n_hyps = nh[1];
+    L3D_HIP_CHECK(c->d_surv.reserve(std::max<uint32_t>(c->n_surv, 1)));
+    L3D_HIP_CHECK(c->d_surv_tg.reserve(std::max<uint32_t>(c->n_surv, 1)));
+    L3D_HIP_CHECK(c->d_surv_sg.reserve(std::max<uint32_t>(c->n_surv, 1)));
+    L3D_HIP_CHECK(c->d_hyps.reserve(std::max<uint32_t>(c->n_hyps, 1)));
+    L3D_HIP_CHECK(c->d_depths.reserve(2 * (size_t)c->n_hyps + 2));
+    L3D_HIP_CHECK(launch_filter_write_all(c->d_views.p, c->d_pairs.p, c->d_seg_base.p, G, c->d_gseg_view.p,
+                                          c->d_off.p, c->d_dents.p, c->d_slots.p, c->d_surv_off.p, c->d_hyp_off.p,
+                                          c->d_best_pos.p, c->d_surv.p, c->d_surv_tg.p, c->d_surv_sg.p,
+                                          c->d_hyp_of_seg.p, c->d_hyps.p, c->d_depths.p, st));
+    L3D_HIP_CHECK(launch_median_all(V, c->d_depths.p, c->d_hyp_off.p, c->d_seg_base.p, c->d_medians.p, st));
     // View::update_median_depth for every view (line3D.cc:1665-1668); in fixed-regulariser mode k is
     // re-set to the same sigma_p/med_scene_depth value, so k is unchanged either way
     std::vector<float> med(V);
-    L3D_HIP_CHECK(hipMemcpyAsync(med.data(), c->d_medians.p, V * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipMemcpyAsync(med.data(), c->d_medians.p, (size_t)V * 4, hipMemcpyDeviceToHost, st));
     L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
     L3D_HIP_CHECK(hipStreamSynchronize(st));
-    for (size_t vi = 0; vi < V; ++vi) c->order[vi]->median_depth = med[vi];
+    for (uint32_t vi = 0; vi < V; ++vi) c->order[vi]->median_depth = med[vi];
+    c->host_offsets_valid = false;
     c->tm.finish_ms = ev_ms(c->ev[6], c->ev[7]);
     c->tm.begin_ms = ev_ms(c->ev[0], c->ev[1]);
     untranslate(*c);   // line3D.cc:493
@@ -547,7 +548,7 @@ int l3d_compute_affinity(l3d_ctx* c) {
     if (c->state != l3d_ctx::MATCHED) return fail(L3D_ERR_STATE, "matchImages must precede the affinity step");
     (void)hipSetDevice(c->device);
     hipStream_t st = c->stream;
-    const size_t V = c->order.size();
+    const uint32_t V = (uint32_t)c->order.size();
     c->edges.clear(); c->l2g.clear();
     // translate()/untranslate() (line3D.cc:1749,1820) only move camera centres, which the affinity
     // terms never read; they are applied to keep the host state identical to the reference's.
@@ -558,29 +559,25 @@ int l3d_compute_affinity(l3d_ctx* c) {
     if (!sd.empty()) { std::sort(sd.begin(), sd.end()); c->med_scene_depth_lines = sd[sd.size() / 2]; }
     else c->med_scene_depth_lines = 0.0f;
     std::vector<ViewAff> va(V);
-    uint32_t N = 0;
-    for (size_t vi = 0; vi < V; ++vi) {
-        HostView& v = *c->order[vi];
-        va[vi].surv_off = v.d_surv_off.p; va[vi].surv = v.d_surv.p; va[vi].surv_tv = c->surv_tv[vi]->p;
-        va[vi].hyp = v.d_hyp.p; va[vi].median_depth = c->d_medians.p + vi; va[vi].k = v.k; va[vi].M = v.M;
-        va[vi].cand_base = N; va[vi].pad = 0;
-        N += v.n_surv;
-    }
-    const uint32_t H = c->n_hyps;
+    for (uint32_t vi = 0; vi < V; ++vi) { va[vi].k = c->order[vi]->k; va[vi].pad = 0; }
+    const uint32_t N = c->n_surv, H = c->n_hyps;
     L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
     if (N > 0 && H > 0) {
         L3D_HIP_CHECK(c->d_vaff.reserve(V)); L3D_HIP_CHECK(c->d_msdl.reserve(1));
         L3D_HIP_CHECK(c->d_simv.reserve(N)); L3D_HIP_CHECK(c->d_ca.reserve(N)); L3D_HIP_CHECK(c->d_cb.reserve(N));
         L3D_HIP_CHECK(c->d_flag.reserve(N + 1)); L3D_HIP_CHECK(c->d_epos.reserve(N + 1));
-        L3D_HIP_CHECK(c->d_first_touch.reserve(H)); L3D_HIP_CHECK(c->d_aff_scal.reserve(2));
+        L3D_HIP_CHECK(c->d_first_touch.reserve(H));
+        L3D_HIP_CHECK(c->d_scan_tmp.reserve(std::max<size_t>(N, 2 * (size_t)N) / 4096 + 1024));
         L3D_HIP_CHECK(hipMemcpyAsync(c->d_vaff.p, va.data(), V * sizeof(ViewAff), hipMemcpyHostToDevice, st));
         L3D_HIP_CHECK(hipMemcpyAsync(c->d_msdl.p, &c->med_scene_depth_lines, 4, hipMemcpyHostToDevice, st));
-        L3D_HIP_CHECK(launch_aff_sim(c->d_vaff.p, (uint32_t)V, N, c->d_hyps.p, c->d_msdl.p, c->two_sigA_sqr,
-                                     c->d_simv.p, c->d_ca.p, c->d_cb.p, st));
-        L3D_HIP_CHECK(launch_aff_flag(c->d_vaff.p, (uint32_t)V, N, c->d_simv.p, c->d_ca.p, c->d_cb.p, c->d_flag.p, st));
-        L3D_HIP_CHECK(launch_scan(c->d_flag.p, N, c->d_epos.p, c->d_aff_scal.p, st));
+        L3D_HIP_CHECK(launch_aff_sim(N, c->d_surv_sg.p, c->d_surv_tg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_vaff.p,
+                                     c->d_medians.p, c->d_msdl.p, c->two_sigA_sqr, c->d_simv.p, c->d_ca.p, c->d_cb.p,
+                                     st));
+        L3D_HIP_CHECK(launch_aff_flag(N, c->d_surv_off.p, c->d_surv_sg.p, c->d_surv_tg.p, c->d_simv.p, c->d_ca.p,
+                                      c->d_cb.p, c->d_flag.p, st));
+        L3D_HIP_CHECK(launch_scan(c->d_flag.p, N, c->d_epos.p, c->d_scan_tmp.p, c->d_scal.p + 3, st));
         uint32_t E = 0;
-        L3D_HIP_CHECK(hipMemcpyAsync(&E, c->d_aff_scal.p, 4, hipMemcpyDeviceToHost, st));
+        L3D_HIP_CHECK(hipMemcpyAsync(&E, c->d_scal.p + 3, 4, hipMemcpyDeviceToHost, st));
         L3D_HIP_CHECK(hipStreamSynchronize(st));
         if (E > 0) {
             L3D_HIP_CHECK(c->d_touch_flag.reserve(2 * (size_t)E + 1));
@@ -591,12 +588,12 @@ int l3d_compute_affinity(l3d_ctx* c) {
             L3D_HIP_CHECK(hipMemsetAsync(c->d_touch_flag.p, 0, (2 * (size_t)E + 1) * 4, st));
             L3D_HIP_CHECK(launch_aff_touch(N, c->d_flag.p, c->d_epos.p, c->d_ca.p, c->d_cb.p, c->d_first_touch.p, st));
             L3D_HIP_CHECK(launch_aff_mark(H, c->d_first_touch.p, c->d_touch_flag.p, st));
-            L3D_HIP_CHECK(launch_scan(c->d_touch_flag.p, 2 * E, c->d_touch_rank.p, c->d_aff_scal.p + 1, st));
+            L3D_HIP_CHECK(launch_scan(c->d_touch_flag.p, 2 * E, c->d_touch_rank.p, c->d_scan_tmp.p, c->d_scal.p + 4, st));
             L3D_HIP_CHECK(launch_aff_emit(N, c->d_flag.p, c->d_epos.p, c->d_ca.p, c->d_cb.p, c->d_simv.p,
                                           c->d_first_touch.p, c->d_touch_rank.p, c->d_hyps.p, c->d_edges.p,
                                           c->d_l2g.p, st));
             uint32_t rows = 0;
-            L3D_HIP_CHECK(hipMemcpyAsync(&rows, c->d_aff_scal.p + 1, 4, hipMemcpyDeviceToHost, st));
+            L3D_HIP_CHECK(hipMemcpyAsync(&rows, c->d_scal.p + 4, 4, hipMemcpyDeviceToHost, st));
             L3D_HIP_CHECK(hipStreamSynchronize(st));
             c->edges.resize(2 * (size_t)E);
             c->l2g.resize(rows);
@@ -626,6 +623,17 @@ int l3d_pair_tests(l3d_ctx* c, uint64_t* n) {
     return L3D_OK;
 }
 
+static int fetch_host_offsets(l3d_ctx* c) {
+    if (c->host_offsets_valid) return L3D_OK;
+    c->h_surv_off.assign((size_t)c->G + 1, 0);
+    c->h_hyp_off.assign((size_t)c->G + 1, 0);
+    L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
+    L3D_HIP_CHECK(hipMemcpy(c->h_surv_off.data(), c->d_surv_off.p, ((size_t)c->G + 1) * 4, hipMemcpyDeviceToHost));
+    L3D_HIP_CHECK(hipMemcpy(c->h_hyp_off.data(), c->d_hyp_off.p, ((size_t)c->G + 1) * 4, hipMemcpyDeviceToHost));
+    c->host_offsets_valid = true;
+    return L3D_OK;
+}
+
 int l3d_get_matches(l3d_ctx* c, uint32_t camID, l3d_match* out, uint64_t cap, uint32_t* seg_offsets, uint64_t* n) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
     if (c->state != l3d_ctx::MATCHED) return fail(L3D_ERR_STATE, "no matches yet");
@@ -633,12 +641,15 @@ int l3d_get_matches(l3d_ctx* c, uint32_t camID, l3d_match* out, uint64_t cap, ui
     if (f == c->views.end()) return fail(L3D_ERR_ARG, "unknown camera ID");
     HostView& v = *f->second;
     (void)hipSetDevice(c->device);
-    if (n) *n = v.n_surv;
-    if (seg_offsets)
-        L3D_HIP_CHECK(hipMemcpy(seg_offsets, v.d_surv_off.p, (v.M + 1) * 4, hipMemcpyDeviceToHost));
+    int rc = fetch_host_offsets(c);
+    if (rc) return rc;
+    const uint32_t g0 = c->seg_base[v.index], g1 = c->seg_base[v.index + 1];
+    const uint32_t base = c->h_surv_off[g0], cnt = c->h_surv_off[g1] - base;
+    if (n) *n = cnt;
+    if (seg_offsets) for (uint32_t s = 0; s <= v.M; ++s) seg_offsets[s] = c->h_surv_off[g0 + s] - base;
     if (out) {
-        const uint64_t m = std::min<uint64_t>(cap, v.n_surv);
-        if (m) L3D_HIP_CHECK(hipMemcpy(out, v.d_surv.p, m * sizeof(l3d_match), hipMemcpyDeviceToHost));
+        const uint64_t m = std::min<uint64_t>(cap, cnt);
+        if (m) L3D_HIP_CHECK(hipMemcpy(out, c->d_surv.p + base, m * sizeof(l3d_match), hipMemcpyDeviceToHost));
     }
     return L3D_OK;
 }

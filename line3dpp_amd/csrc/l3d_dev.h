@@ -98,25 +98,31 @@ struct PairDesc {
 };
 
 // ---- phase-B records ------------------------------------------------------------------------
-// one hypothesis of the view being processed, as gathered (unsorted) from the pair slots
+// one potential hypothesis of one 2D segment, as gathered (unsorted) from the pair slots
 struct Entry {
     uint64_t key;      // canonical order inside the segment's list (reference single-thread order)
-    uint64_t origin;   // slot index of a fresh match (score write-back) or ~0 for an inverse match
-    uint32_t seg, tgt_view, tgt_seg;
-    float overlap, dp1, dp2, dq1, dq2, score3D;
+    uint64_t ref;      // index of the slot it comes from
+    uint32_t gseg;     // global segment id = seg_base[view] + segment
+    uint32_t view, tgt_view, pair;
+    float dp1, dp2;    // depths of the owning view's segment end points
+    uint32_t inverse;  // 1: role-swapped copy of a match of an earlier view (line3D.cc:1682-1692)
     uint32_t pad;
 };
-static_assert(sizeof(Entry) == 56, "Entry is 56 bytes");
+static_assert(sizeof(Entry) == 48, "Entry is 48 bytes");
 
 // the same hypothesis at its canonical position, with what scoring needs
 struct DEntry {
     double dir[3];     // unprojected 3D direction (Segment3D::dir_)
-    uint64_t origin;
-    float length, dp1, dp2, dq1, dq2, reg1, reg2, overlap, score3D;
-    uint32_t tgt_view, tgt_seg, seg, keep;
-    uint32_t pad;
+    uint64_t ref;
+    float dp1, dp2, reg1, reg2, score3D;
+    uint32_t tgt_view, flags, pair;
 };
-static_assert(sizeof(DEntry) == 88, "DEntry is 88 bytes");
+static_assert(sizeof(DEntry) == 64, "DEntry is 64 bytes");
+constexpr uint32_t kDInverse = 1u;   // inverse hypothesis (exists only if the source view scored it > 0)
+constexpr uint32_t kDZeroLen = 2u;   // unprojected segment shorter than L3D_EPS
+constexpr uint32_t kDAbsent = 4u;    // (LDS only) inverse hypothesis that does not exist
+constexpr uint32_t kDPresent = 8u;   // took part in scoring
+constexpr uint32_t kDKeep = 16u;     // survives filterMatches
 
 // one entry of estimated_position3D_: Segment3D + Match (line3D.cc:1637-1646)
 struct HypRec {
@@ -128,16 +134,9 @@ struct HypRec {
 };
 static_assert(sizeof(HypRec) == 128, "HypRec is 128 bytes");
 
-// per-view tables the affinity kernels read
+// per-view scalars the affinity kernels read
 struct ViewAff {
-    const uint32_t* surv_off;   // [M+1]
-    const Match* surv;          // surviving matches, canonical order
-    const uint32_t* surv_tv;    // target view index of each surviving match
-    const int32_t* hyp;         // [M] global hypothesis index or -1
-    const float* median_depth;  // device scalar (View::median_depth_)
-    float k;
-    uint32_t M;
-    uint32_t cand_base;         // first candidate (= surviving match) of this view in the flat order
+    float k;              // View::k_
     uint32_t pad;
 };
 

@@ -84,12 +84,6 @@ struct HostView {
     // pairs touching this view (indices into Ctx::pairs)
     std::vector<uint32_t> out_pairs;    // this view is src, ascending tgt
     std::vector<uint32_t> in_pairs;     // this view is tgt and src < this (inverse matches), ascending src
-    // phase-B results (device): surviving matches CSR + best hypotheses
-    DevBuf<uint32_t> d_surv_off;        // [M+1]
-    DevBuf<Match> d_surv;               // surviving matches, canonical order
-    uint32_t n_surv = 0;
-    DevBuf<int32_t> d_hyp;              // [M] index into the global hypothesis array or -1
-    uint32_t hyp_base = 0, n_hyp = 0;
 };
 
 }  // namespace l3d
