@@ -181,39 +181,66 @@ __device__ __forceinline__ float sim_scoring(const double* dira, bool zeroa, flo
     return sim > sc.min_sim ? sim : 0.0f;
 }
 
-// One wave per 2D segment of view `vi`.  Lanes own hypotheses M (strided by 64); the inner loop walks
-// all present hypotheses M2 of the segment in canonical order from LDS.
+// One wave per 2D segment of view `vi`.  The hypotheses that exist (all fresh ones + the inverse ones
+// whose source view scored them > 0) are first compacted by ballot/popcount into an LDS index list;
+// then lanes own hypotheses M (strided by 64) and the inner loop walks all existing hypotheses M2 of
+// the segment in canonical order from LDS.
 constexpr int kScoreChunk = 64;
+constexpr uint32_t kIdxCap = 1024;   // per-wave LDS index list; longer lists take the uncompacted path
 __global__ __launch_bounds__(256) void k_score_view(uint32_t g0, uint32_t M, const uint32_t* __restrict__ off,
                                                     DEntry* __restrict__ dents, Slot* __restrict__ slots,
                                                     uint32_t* __restrict__ max_score_bits, SimConst sc) {
     __shared__ double s_dir[4][kScoreChunk][3];
     __shared__ float s_dp1[4][kScoreChunk], s_dp2[4][kScoreChunk];
     __shared__ uint32_t s_cam[4][kScoreChunk], s_flg[4][kScoreChunk];
+    __shared__ uint16_t s_idx[4][kIdxCap];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t seg = blockIdx.x * 4 + wave;
     if (seg >= M) return;
     const uint32_t b = off[g0 + seg], L = off[g0 + seg + 1] - b;
     if (L == 0) return;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const bool compact = L <= kIdxCap;
+    uint32_t Lp = L;   // number of existing hypotheses when compacted
+    if (compact) {
+        Lp = 0;
+        for (uint32_t m0 = 0; m0 < L; m0 += 64) {
+            bool present = false;
+            if (m0 + lane < L) {
+                const DEntry& d = dents[b + m0 + lane];
+                // an inverse hypothesis exists only if its source view scored the match > 0 (line3D.cc:1680)
+                present = !(d.flags & kDInverse) || (slots[d.ref].score3D > 0.0f);
+                if (!present) { dents[b + m0 + lane].score3D = 0.0f; dents[b + m0 + lane].flags = d.flags & ~kDPresent; }
+            }
+            const uint64_t m = __ballot(present);
+            if (present) s_idx[wave][Lp + (uint32_t)__popcll(m & lt_mask)] = (uint16_t)(m0 + lane);
+            Lp += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     float vmax = 0.0f;
-    for (uint32_t m0 = 0; m0 < L; m0 += 64) {
+    for (uint32_t m0 = 0; m0 < Lp; m0 += 64) {
         const uint32_t mi = m0 + lane;
-        bool act = mi < L;
+        const bool inrange = mi < Lp;
+        const uint32_t pa = inrange ? (compact ? (uint32_t)s_idx[wave][mi] : mi) : 0u;
+        bool act = inrange;
         DEntry a;
         if (act) {
-            a = dents[b + mi];
-            // an inverse hypothesis exists only if its source view scored the match > 0 (line3D.cc:1680)
-            if ((a.flags & kDInverse) && !(slots[a.ref].score3D > 0.0f)) act = false;
+            a = dents[b + pa];
+            if (!compact && (a.flags & kDInverse) && !(slots[a.ref].score3D > 0.0f)) act = false;
         }
         float score3D = 0.0f, cur = 0.0f;
         uint32_t cur_cam = kEmpty;
-        for (uint32_t c0 = 0; c0 < L; c0 += kScoreChunk) {
-            const uint32_t cn = min((uint32_t)kScoreChunk, L - c0);
+        for (uint32_t c0 = 0; c0 < Lp; c0 += kScoreChunk) {
+            const uint32_t cn = min((uint32_t)kScoreChunk, Lp - c0);
             __builtin_amdgcn_wave_barrier();
             if (lane < cn) {
-                const DEntry& o = dents[b + c0 + lane];
+                const uint32_t po = compact ? (uint32_t)s_idx[wave][c0 + lane] : (c0 + lane);
+                const DEntry& o = dents[b + po];
                 uint32_t f = o.flags;
-                if ((f & kDInverse) && !(slots[o.ref].score3D > 0.0f)) f |= kDAbsent;
+                if (!compact && (f & kDInverse) && !(slots[o.ref].score3D > 0.0f)) f |= kDAbsent;
                 s_dir[wave][lane][0] = o.dir[0]; s_dir[wave][lane][1] = o.dir[1]; s_dir[wave][lane][2] = o.dir[2];
                 s_dp1[wave][lane] = o.dp1; s_dp2[wave][lane] = o.dp2;
                 s_cam[wave][lane] = o.tgt_view; s_flg[wave][lane] = f;
@@ -238,9 +265,9 @@ __global__ __launch_bounds__(256) void k_score_view(uint32_t g0, uint32_t M, con
                 }
             }
         }
-        if (mi < L) {
-            dents[b + mi].score3D = act ? score3D : 0.0f;
-            dents[b + mi].flags = act ? (a.flags | kDPresent) : (a.flags & ~kDPresent);
+        if (inrange) {
+            dents[b + pa].score3D = act ? score3D : 0.0f;
+            dents[b + pa].flags = act ? (a.flags | kDPresent) : (a.flags & ~kDPresent);
             if (act) {
                 if (!(a.flags & kDInverse)) slots[a.ref].score3D = score3D;
                 vmax = fmaxf(vmax, score3D);
