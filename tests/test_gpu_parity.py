@@ -325,3 +325,35 @@ def test_properties_at_full_c1_size():
             assert np.all(m["score3D"] > 0)
             lim_ok += 1
     assert lim_ok > 0
+
+
+def test_cpp_facade_matches_python_front_end(tmp_path):
+    """include/line3dpp/line3D.h (C++ mirror of L3DPP::Line3D) driven like a reference main_*.cpp."""
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "facade_smoke")
+    lib_dir = os.path.join(root, "line3dpp_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "facade_smoke.cpp"), "-o", exe, "-L" + lib_dir,
+                           "-ll3dpp_hip", "-Wl,-rpath," + lib_dir])
+    sc = make_scene(8, 300, n_neighbors=4, seed=1)
+    path = str(tmp_path / "scene.bin")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", sc.n_views))
+        for v in sc.views:
+            f.write(struct.pack("<5I", v.cam, len(v.segs), v.width, v.height, len(v.neighbors)))
+            f.write(np.ascontiguousarray(v.K, np.float64).tobytes()); f.write(np.ascontiguousarray(v.R, np.float64).tobytes())
+            f.write(np.ascontiguousarray(v.t, np.float64).tobytes()); f.write(struct.pack("<f", v.median_depth))
+            f.write(np.asarray(v.neighbors, np.uint32).tobytes()); f.write(np.ascontiguousarray(v.segs, np.float32).tobytes())
+    out = subprocess.check_output([exe, path]).decode()
+    line = [l for l in out.splitlines() if l.startswith("RESULT")][0]
+    kv = dict(x.split("=") for x in line.split()[1:])
+    g = _gpu(sc)
+    assert g.matchImages() and g.computeAffinity()
+    ms = [g.matches(v.cam)[0] for v in sc.views]
+    assert int(kv["images"]) == 8 and int(kv["matches"]) == sum(len(m) for m in ms)
+    assert abs(float(kv["score_sum"]) - sum(float(m["score3D"].astype(np.float64).sum()) for m in ms)) < 1e-3
+    e, l2g, _ = g.affinity()
+    assert int(kv["hypotheses"]) == len(g.best()[0]) and int(kv["edges"]) == len(e) and int(kv["rows"]) == len(l2g)
+    assert abs(float(kv["wsum"]) - float(e["w"].astype(np.float64).sum())) < 1e-3
