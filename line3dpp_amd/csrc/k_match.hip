@@ -29,7 +29,7 @@ namespace l3d {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kTile = 1024;        // target records per LDS tile (16 KiB)
+constexpr int kTile = 512;         // target records per LDS tile (8 KiB)
 constexpr int kRing = 512;         // per-wave candidate ring (entries); >= 63 + 4*64
 constexpr float kKappa = 1.0e-2f;  // pre-filter slack, px: margin = kKappa * max|1/d| + kKappa0
 constexpr float kKappa0 = 2.0e-4f;
@@ -40,6 +40,7 @@ struct Lds {
     volatile uint32_t* cnt;       // [kBlock]
     volatile float* minov;        // [kBlock]
     volatile uint32_t* claim;     // [kBlock]
+    volatile uint32_t* minpos;    // [kBlock] slot of the worst entry of a full row
     volatile float* top_ov;       // [kBlock*K]
     volatile uint32_t* top_ix;    // [kBlock*K]
 };
@@ -51,6 +52,7 @@ __device__ __forceinline__ Lds carve(char* base, uint32_t K) {
     l.cnt = (volatile uint32_t*)base; base += kBlock * 4;
     l.minov = (volatile float*)base; base += kBlock * 4;
     l.claim = (volatile uint32_t*)base; base += kBlock * 4;
+    l.minpos = (volatile uint32_t*)base; base += kBlock * 4;
     l.top_ov = (volatile float*)base; base += (size_t)kBlock * K * 4;
     l.top_ix = (volatile uint32_t*)base;
     return l;
@@ -137,6 +139,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
     L.claim[tid] = kEmpty;
     uint32_t head = 0, tail = 0;   // wave-uniform ring cursors
 
+    // worst entry of a full row under (overlap desc, tgt asc): pipelined (non-volatile) LDS reads
+    auto rescan_worst = [&](uint32_t sl) {
+        const float* ov = (const float*)L.top_ov + (size_t)sl * K;
+        const uint32_t* ix = (const uint32_t*)L.top_ix + (size_t)sl * K;
+        uint32_t wj = 0; float wo = ov[0]; uint32_t wx = ix[0];
+        for (uint32_t j = 1; j < K; ++j) {
+            const float o = ov[j]; const uint32_t x = ix[j];
+            if (better(wo, wx, o, x)) { wo = o; wx = x; wj = j; }
+        }
+        L.minov[sl] = wo;
+        L.minpos[sl] = wj;
+    };
+
     // one exact test per lane on up to 64 queued candidates, then kNN insertion
     auto drain = [&]() {
         const uint32_t n = min(64u, tail - head);
@@ -148,7 +163,15 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
         PairResult res{};
         if (has) {
             const uint32_t sg = wi.src0 + sl;
-            pending = exact_pair(F, vs.seg4[sg], vt.seg4[tg], vs.segx[sg], vt.segx[tg], vs.C, vt.C, thr, res);
+            const float4 s4 = vs.seg4[sg], t4 = vt.seg4[tg];
+            const float ov = exact_overlap(F, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w);
+            // a full row only admits overlaps above its K-th best (a tie loses: candidates of a row arrive
+            // in ascending target order); minov == thr while the row is not full
+            const float need = (MODE == 0) ? L.minov[sl] : thr;
+            if (ov > need) {
+                res.overlap = ov;
+                pending = exact_depths(vs.segx[sg], vt.segx[tg], vs.C, vt.C, res);
+            }
         }
         // several candidates of one drain may belong to the same row: lowest lane first, so a row
         // always sees its candidates in ascending target order
@@ -174,30 +197,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
                     if (c < K) {
                         ov[c] = res.overlap; ix[c] = tg;
                         L.cnt[sl] = c + 1;
-                        if (c + 1 == K) {
-                            float m = res.overlap;
-                            for (uint32_t j = 0; j < K; ++j) m = fminf(m, ov[j]);
-                            L.minov[sl] = m;
-                        }
+                        if (c + 1 == K) rescan_worst(sl);
                     } else {
-                        // replace the worst entry if the newcomer beats it
-                        uint32_t wj = 0; float wo = ov[0]; uint32_t wx = ix[0];
-                        for (uint32_t j = 1; j < K; ++j) {
-                            const float o = ov[j]; const uint32_t x = ix[j];
-                            if (better(wo, wx, o, x)) { wo = o; wx = x; wj = j; }
-                        }
-                        if (better(res.overlap, tg, wo, wx)) {
+                        const uint32_t wj = L.minpos[sl];
+                        if (better(res.overlap, tg, L.minov[sl], ix[wj])) {
                             ov[wj] = res.overlap; ix[wj] = tg;
-                            float m = res.overlap;
-                            for (uint32_t j = 0; j < K; ++j) m = fminf(m, ov[j]);
-                            L.minov[sl] = m;
+                            rescan_worst(sl);
                         }
                     }
                 }
             }
         }
         // feed the K-th best overlap back into the owning lane's pre-filter threshold
-        if (MODE == 0 && live) thrL = fmaxf(thr, L.minov[tid]);
+        if (MODE == 0 && live) thrL = L.minov[tid];
     };
 
     // ---- main loop: stream the target view through LDS ----
@@ -258,20 +270,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
         for (uint32_t j = min(c, K); j < K; ++j) row[j] = empty;
         return;
     }
-    // rank the winners by (overlap desc, tgt asc) and recompute their depths (identical arithmetic
-    // to the acceptance test, so identical values)
-    volatile float* ov = L.top_ov + (size_t)tid * K;
-    volatile uint32_t* ix = L.top_ix + (size_t)tid * K;
-    const float4 s4 = vs.seg4[src];
+    // rank the winners by (overlap desc, tgt asc); the overlaps are in LDS, the depths are recomputed
+    // (identical arithmetic to the acceptance test, so identical values)
+    const float* ov = (const float*)L.top_ov + (size_t)tid * K;
+    const uint32_t* ix = (const uint32_t*)L.top_ix + (size_t)tid * K;
     const SegX sx = vs.segx[src];
     for (uint32_t j = 0; j < c; ++j) {
         const float oj = ov[j]; const uint32_t xj = ix[j];
         uint32_t rank = 0;
         for (uint32_t i = 0; i < c; ++i) rank += better(ov[i], ix[i], oj, xj) ? 1u : 0u;
         PairResult res{};
-        exact_pair(F, s4, vt.seg4[xj], sx, vt.segx[xj], vs.C, vt.C, thr, res);
+        exact_depths(sx, vt.segx[xj], vs.C, vt.C, res);
         Slot o;
-        o.tgt_seg = xj; o.overlap = res.overlap;
+        o.tgt_seg = xj; o.overlap = oj;
         o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
         o.score3D = 0.0f; o.flags = 0;
         row[rank] = o;
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
 }
 
 size_t match_lds_bytes(int mode, uint32_t K) {
-    return sizeof(float4) * kTile + 4 * kRing * 4 + 3 * kBlock * 4 + (mode == 0 ? (size_t)kBlock * K * 8 : 0);
+    return sizeof(float4) * kTile + 4 * kRing * 4 + 4 * kBlock * 4 + (mode == 0 ? (size_t)kBlock * K * 8 : 0);
 }
 
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,

@@ -148,41 +148,53 @@ L3D_HD bool point_on_segment(double xx, double xy, double p1x, double p1y, doubl
     return (v1x * v2x + v1y * v2y) < kEps;
 }
 
-// Line3D::mutualOverlap, line3D.cc:1086-1165, on 4 collinear points with z == 1
+// Line3D::mutualOverlap, line3D.cc:1086-1165, on 4 collinear points with z == 1.
+// The reference takes float(norm) of all 6 point pairs and keeps the first strict maximum.  float(sqrt(x))
+// is monotone in x, so when the largest squared distance exceeds every other one by more than 2^-21
+// relative (=> their square roots differ by more than one float ulp) the winner is known without the
+// other five square roots; only near-ties walk the reference's loop literally.  Same result bit for bit.
 L3D_HD float mutual_overlap(const double px[4], const double py[4]) {
     if (!(point_on_segment(px[0], py[0], px[2], py[2], px[3], py[3]) ||
           point_on_segment(px[1], py[1], px[2], py[2], px[3], py[3]) ||
           point_on_segment(px[2], py[2], px[0], py[0], px[1], py[1]) ||
           point_on_segment(px[3], py[3], px[0], py[0], px[1], py[1])))
         return 0.0f;
+    // pair order of the reference's double loop: (0,1),(0,2),(0,3),(1,2),(1,3),(2,3); the inner pair of
+    // outer pair k is pair 5-k (line3D.cc:1125-1159)
+    double d2[6];
+    {
+        double dx, dy;
+        dx = px[0] - px[1]; dy = py[0] - py[1]; d2[0] = dx * dx + dy * dy;
+        dx = px[0] - px[2]; dy = py[0] - py[2]; d2[1] = dx * dx + dy * dy;
+        dx = px[0] - px[3]; dy = py[0] - py[3]; d2[2] = dx * dx + dy * dy;
+        dx = px[1] - px[2]; dy = py[1] - py[2]; d2[3] = dx * dx + dy * dy;
+        dx = px[1] - px[3]; dy = py[1] - py[3]; d2[4] = dx * dx + dy * dy;
+        dx = px[2] - px[3]; dy = py[2] - py[3]; d2[5] = dx * dx + dy * dy;
+    }
+    double m2 = d2[0], inner2 = d2[5], second = 0.0;
+#pragma unroll
+    for (int k = 1; k < 6; ++k) {
+        if (d2[k] > m2) { second = m2; m2 = d2[k]; inner2 = d2[5 - k]; }
+        else if (d2[k] > second) second = d2[k];
+    }
+    if (second < m2 * (1.0 - 4.76837158203125e-7)) {   // 2^-21: no float tie possible
+        const float max_dist = (float)sqrt(m2);
+        if (max_dist < 1.0f) return 0.0f;
+        return (float)(sqrt(inner2) / (double)max_dist);
+    }
+    // near-tie: the reference's loop, literally
     float max_dist = 0.0f;
-    int outer1 = 0, outer2 = 3;
+    int outer = 0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int j = i + 1; j < 4; ++j) {
-            double dx = px[i] - px[j], dy = py[i] - py[j];
-            float dist = (float)sqrt(dx * dx + dy * dy);  // (dz = 0 exactly)
-            if (dist > max_dist) { max_dist = dist; outer1 = i; outer2 = j; }
-        }
+    for (int k = 0; k < 6; ++k) {
+        const float dist = (float)sqrt(d2[k]);
+        if (dist > max_dist) { max_dist = dist; outer = k; }
     }
     if (max_dist < 1.0f) return 0.0f;
-    int inner1, inner2;
-    if (outer1 == 0) {
-        if (outer2 == 1) { inner1 = 2; inner2 = 3; }
-        else if (outer2 == 2) { inner1 = 1; inner2 = 3; }
-        else { inner1 = 1; inner2 = 2; }
-    } else if (outer1 == 1) {
-        inner1 = 0;
-        inner2 = (outer2 == 2) ? 3 : 2;
-    } else { inner1 = 0; inner2 = 1; }
-    // select without dynamic indexing
-    double ax = inner1 == 0 ? px[0] : (inner1 == 1 ? px[1] : px[2]);
-    double ay = inner1 == 0 ? py[0] : (inner1 == 1 ? py[1] : py[2]);
-    double bx = inner2 == 1 ? px[1] : (inner2 == 2 ? px[2] : px[3]);
-    double by = inner2 == 1 ? py[1] : (inner2 == 2 ? py[2] : py[3]);
-    double dx = ax - bx, dy = ay - by;
-    return (float)(sqrt(dx * dx + dy * dy) / (double)max_dist);
+    double in2 = d2[5];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) in2 = (outer == k) ? d2[5 - k] : in2;
+    return (float)(sqrt(in2) / (double)max_dist);
 }
 
 struct PairResult {
@@ -218,18 +230,23 @@ L3D_HD void tri_depths(const double* Ca, const double* ra, const double* rb, con
     d2 = num / db;
 }
 
-// full acceptance test of one (src seg, tgt seg) pair: line3D.cc:931-995
-L3D_HD bool exact_pair(const double* F, const float4& s, const float4& t, const SegX& sx, const SegX& tx,
-                       const double* Cs, const double* Ct, float thr, PairResult& out) {
-    float ov = exact_overlap(F, s.x, s.y, s.z, s.w, t.x, t.y, t.z, t.w);
-    if (!(ov > thr)) return false;
+// depth part of the acceptance test: line3D.cc:960-980 (both triangulations, all four depths > 1e-12)
+L3D_HD bool exact_depths(const SegX& sx, const SegX& tx, const double* Cs, const double* Ct, PairResult& out) {
     double ds1, ds2, dt1, dt2;
     tri_depths(Cs, sx.r1, sx.r2, tx.n, tx.cn, ds1, ds2);
     tri_depths(Ct, tx.r1, tx.r2, sx.n, sx.cn, dt1, dt2);
     if (!(ds1 > kEps && ds2 > kEps && dt1 > kEps && dt2 > kEps)) return false;
-    out.overlap = ov;
     out.dp1 = (float)ds1; out.dp2 = (float)ds2; out.dq1 = (float)dt1; out.dq2 = (float)dt2;
     return true;
+}
+
+// full acceptance test of one (src seg, tgt seg) pair: line3D.cc:931-995
+L3D_HD bool exact_pair(const double* F, const float4& s, const float4& t, const SegX& sx, const SegX& tx,
+                       const double* Cs, const double* Ct, float thr, PairResult& out) {
+    const float ov = exact_overlap(F, s.x, s.y, s.z, s.w, t.x, t.y, t.z, t.w);
+    if (!(ov > thr)) return false;
+    out.overlap = ov;
+    return exact_depths(sx, tx, Cs, Ct, out);
 }
 
 // (overlap desc, tgt asc) total order used for the kNN selection
