@@ -27,6 +27,43 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
+def run_cpu_baseline(scene, args, pair_tests, kNN):
+    """The CPU oracle (OpenMP restatement of the reference CPU path) on this box's host cores.
+    The reference's structure (std::list / std::map / priority_queue per row, kept by the port) stops
+    scaling long before 256 threads, so the thread count is picked by a short scan on a sub-scene and
+    the full workload is then run once with the best count."""
+    import copy
+    from oracle.oracle import Oracle
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if args.cpu_threads:
+        best_t, scan = args.cpu_threads, {}
+    else:
+        sub = copy.copy(scene)
+        nsub = min(8, scene.n_views)
+        keep = {v.cam for v in scene.views[:nsub]}
+        sub.views = []
+        for v in scene.views[:nsub]:
+            w = copy.copy(v); w.neighbors = [n for n in v.neighbors if n in keep] or [scene.views[(v.cam + 1) % nsub].cam]
+            sub.views.append(w)
+        sub_tests = sub.pair_tests()[0]
+        scan = {}
+        for t in sorted({1, 8, 16, 32, 64, 128, ncpu}):
+            if t > ncpu:
+                continue
+            o = Oracle(threads=t); o.add_scene(sub)
+            t1 = time.perf_counter(); o.match_images(kNN=kNN); o.compute_affinity()
+            scan[t] = round(sub_tests / (time.perf_counter() - t1) / 1e6, 1)
+        best_t = max(scan, key=scan.get)
+    o = Oracle(threads=best_t); o.add_scene(scene)
+    t1 = time.perf_counter()
+    o.match_images(kNN=kNN); o.compute_affinity()
+    cdt = time.perf_counter() - t1
+    return {"value": round(pair_tests / cdt / 1e6, 2), "unit": "M segment-pair scores/s", "cores": best_t,
+            "kind": "port", "host_cpus": ncpu, "thread_scan_M_per_s": scan,
+            "sample": f"full {args.config} workload once ({pair_tests} pair tests, {cdt:.2f} s) with the thread count "
+                      f"that scored best on an 8-view sub-scene; OpenMP oracle = restatement of the reference CPU path"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,26 +138,24 @@ def main():
     my_tests = sum(M[s] * M[t] for s, t in my_pairs)
     avg_ms = kern_ms / max(kern_launches, 1)
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM traffic of one launch from the rocprofv3 PMC passes committed under profiles/ (PMC counters cannot
+    # be collected from inside this process); only quoted when it was measured on this very workload
+    traffic = None
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+        if tr["config"] == args.config and world == 1:
+            traffic = tr["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 6), "traffic": None,
+                "frac": round(achieved / 8000.0, 6), "traffic": traffic, "algorithmic_bytes": algo_bytes,
                 "kernel": "k_match_pairs<0,false>", "kernel_ms": round(avg_ms, 4),
                 "kernel_pair_tests_per_s": round(my_tests / (avg_ms * 1e-3), 1) if avg_ms > 0 else 0.0,
                 "note": "VALU-issue bound by design (<0.2 B per pair test); see DESIGN.md roofline"}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.oracle import Oracle, lib
-        threads = args.cpu_threads or (os.cpu_count() or 1)
-        o = Oracle(threads=threads)
-        o.add_scene(scene)
-        t1 = time.perf_counter()
-        o.match_images(kNN=kNN)
-        o.compute_affinity()
-        cdt = time.perf_counter() - t1
-        cpu_baseline = {"value": round(pair_tests / cdt / 1e6, 2), "unit": "M segment-pair scores/s",
-                        "cores": threads, "kind": "port",
-                        "sample": f"full {args.config} workload once ({pair_tests} pair tests, {cdt:.2f} s), "
-                                  f"OpenMP oracle = restatement of the reference CPU path"}
+        cpu_baseline = run_cpu_baseline(scene, args, pair_tests, kNN)
 
     if rank == 0:
         out = {

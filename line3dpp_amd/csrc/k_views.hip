@@ -167,8 +167,10 @@ __device__ __forceinline__ float sim_scoring(const double* dira, bool zeroa, flo
                                              const SimConst sc) {
     if (zeroa || zerob) return 0.0f;
     const float d1 = adp1 - bdp1, d2 = adp2 - bdp2;
+    // expf(y) > 0.5 needs y = -d*d/reg > ln 0.5 = -0.693147...  Division-free early-out with a safety
+    // margin (d*d > 0.72*reg => y < -0.70 even after rounding); NaN/inf fall through to the exact path.
+    if (d1 * d1 > 0.72f * reg1 || d2 * d2 > 0.72f * reg2) return 0.0f;
     const float y1 = -d1 * d1 / reg1, y2 = -d2 * d2 / reg2;
-    // expf(y) > 0.5 needs y > ln 0.5 = -0.693147...; -0.70 is a safe early-out bound (NaN falls through)
     if (y1 < -0.70f || y2 < -0.70f) return 0.0f;
     const float dot_p = (float)dot(d3{dira[0], dira[1], dira[2]}, d3{dirb[0], dirb[1], dirb[2]});
     float angle = (float)(acos((double)fmaxf(fminf(dot_p, 1.0f), -1.0f)) / M_PI * 180.0f);
