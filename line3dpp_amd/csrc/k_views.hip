@@ -9,10 +9,13 @@
 //     k_orient_all      checkMatchOrientation (:811-858) of every slot in its source frame and, for pairs
 //                       that will hand inverse matches to their target, in the target frame; per-segment
 //                       hypothesis counts
-//     scan + k_fill_all + k_entry_prep_all
-//                       every 2D segment's list of potential hypotheses in canonical (= reference
-//                       single-thread) order, with the unprojected 3D direction and the spatial
-//                       regularisers scoring needs (scoringCPU :1233-1248)
+//     scans + k_inv_fill  CSR offsets of every 2D segment's hypothesis list and a compact transposed index
+//                       (16-byte refs) of the slots that point at it as potential inverse matches
+//   chain (one launch per view, ascending camID)
+//     k_build_lists_all every 2D segment's list of potential hypotheses in canonical (= reference
+//                       single-thread) order -- inverse refs rank-sorted, fresh rows by ballot prefix, no
+//                       atomics -- with the unprojected 3D direction and the spatial regularisers scoring
+//                       needs (scoringCPU :1233-1248)
 //   chain (one launch per view, ascending camID)
 //     k_score_view      one wave per 2D segment, O(L^2) similarityForScoring (:1417-1446) with the
 //                       reference's per-camera replace/subtract accumulation (:1255-1274); an inverse
@@ -61,10 +64,12 @@ __device__ __forceinline__ bool orientation_ok(const double* C, const SegX& sx, 
 }  // namespace
 
 // ---- pre-pass ---------------------------------------------------------------------------------------
-// grid = (slot blocks, pairs).  One thread per slot.
+// grid = (slot blocks, pairs).  One thread per slot: orientation flags + list lengths.
+//   cnt_all[g]  hypotheses of global segment g (fresh alive + potential inverse) -> CSR of the lists
+//   cnt_inv[g]  potential inverse hypotheses of g -> CSR of the transposed index
 __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
                              const uint32_t* __restrict__ seg_base, Slot* __restrict__ slots,
-                             uint32_t* __restrict__ cnt) {
+                             uint32_t* __restrict__ cnt_all, uint32_t* __restrict__ cnt_inv) {
     const PairDesc& pd = pairs[blockIdx.y];
     const uint64_t n = (uint64_t)pd.Ms * pd.K;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,13 +82,14 @@ __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* 
     uint32_t flags = 0;
     if (orientation_ok(vs.C, vs.segx[row], s.dp1, s.dp2)) {
         flags = kSlotAlive;
-        atomicAdd(&cnt[seg_base[pd.src] + row], 1u);
+        atomicAdd(&cnt_all[seg_base[pd.src] + row], 1u);
         // inverse copy: only towards a view that is processed later (line3D.cc:1680)
         if (pd.tgt > pd.src) {
             const ViewDev& vt = views[pd.tgt];
             if (orientation_ok(vt.C, vt.segx[s.tgt_seg], s.dq1, s.dq2)) {
                 flags |= kSlotInvAlive;
-                atomicAdd(&cnt[seg_base[pd.tgt] + s.tgt_seg], 1u);
+                atomicAdd(&cnt_all[seg_base[pd.tgt] + s.tgt_seg], 1u);
+                atomicAdd(&cnt_inv[seg_base[pd.tgt] + s.tgt_seg], 1u);
             }
         }
     }
@@ -91,52 +97,30 @@ __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* 
     sp->score3D = 0.0f;
 }
 
-__global__ void k_fill_all(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ seg_base,
-                           const Slot* __restrict__ slots, const uint32_t* __restrict__ off,
-                           uint32_t* __restrict__ cur, Entry* __restrict__ ents) {
+// transposed index of the potential inverse hypotheses: which slots point at global segment g
+__global__ void k_inv_fill(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ seg_base,
+                           const Slot* __restrict__ slots, const uint32_t* __restrict__ inv_off,
+                           uint32_t* __restrict__ cur, InvRef* __restrict__ refs) {
     const PairDesc& pd = pairs[blockIdx.y];
+    if (pd.tgt <= pd.src) return;
     const uint64_t n = (uint64_t)pd.Ms * pd.K;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Slot s = slots[pd.slot_off + i];
-    if (s.tgt_seg == kEmpty || !(s.flags & kSlotAlive)) return;
-    const uint32_t row = (uint32_t)(i / pd.K), j = (uint32_t)(i % pd.K);
-    Entry e;
-    e.ref = pd.slot_off + i;
-    e.gseg = seg_base[pd.src] + row;
-    e.view = pd.src; e.tgt_view = pd.tgt; e.pair = blockIdx.y; e.pad = 0;
-    e.dp1 = s.dp1; e.dp2 = s.dp2;
-    e.key = (1ull << 52) | ((uint64_t)pd.tgt << 32) | j;   // fresh: after the inverse ones, by (tgt view, rank)
-    e.inverse = 0;
-    ents[off[e.gseg] + atomicAdd(&cur[e.gseg], 1u)] = e;
-    if (s.flags & kSlotInvAlive) {
-        e.gseg = seg_base[pd.tgt] + s.tgt_seg;
-        e.view = pd.tgt; e.tgt_view = pd.src;
-        e.dp1 = s.dq1; e.dp2 = s.dq2;
-        e.key = ((uint64_t)pd.src << 32) | row;            // inverse: by (src view, src segment)
-        e.inverse = 1;
-        ents[off[e.gseg] + atomicAdd(&cur[e.gseg], 1u)] = e;
-    }
+    if (s.tgt_seg == kEmpty || !(s.flags & kSlotInvAlive)) return;
+    const uint32_t g = seg_base[pd.tgt] + s.tgt_seg;
+    InvRef r;
+    r.src_view = pd.src; r.src_row = (uint32_t)(i / pd.K); r.pair = blockIdx.y; r.j = (uint32_t)(i % pd.K);
+    refs[inv_off[g] + atomicAdd(&cur[g], 1u)] = r;
 }
 
-// One thread per hypothesis: rank inside its segment's list (canonical order) and the derived
-// quantities scoring needs.  Reads ents (fill order), writes dents (sorted).
-__global__ void k_entry_prep_all(const ViewDev* __restrict__ views, const uint32_t* __restrict__ seg_base,
-                                 const Entry* __restrict__ ents, const uint32_t* __restrict__ off,
-                                 const uint32_t* __restrict__ n_ptr, DEntry* __restrict__ dents) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *n_ptr) return;
-    const Entry e = ents[i];
-    const uint32_t b = off[e.gseg], en = off[e.gseg + 1];
-    uint32_t rank = 0;
-    for (uint32_t j = b; j < en; ++j) rank += (ents[j].key < e.key) ? 1u : 0u;
-    const ViewDev& v = views[e.view];
-    const ViewDev& vt = views[e.tgt_view];
-    const SegX& sx = v.segx[e.gseg - seg_base[e.view]];
-    const Seg3 s3 = unproject(v.C, sx.r1, sx.r2, e.dp1, e.dp2);
-    // scoringCPU line3D.cc:1236-1248
+// scoringCPU line3D.cc:1233-1248: unprojection + spatial regularisers of one hypothesis
+__device__ __forceinline__ DEntry make_dentry(const ViewDev& v, const ViewDev& vt, const SegX& sx, float dp1,
+                                              float dp2, uint64_t ref, uint32_t tgt_view, uint32_t pair,
+                                              bool inverse) {
+    const Seg3 s3 = unproject(v.C, sx.r1, sx.r2, dp1, dp2);
     const float k = v.k;
-    const float sig1 = e.dp1 * k, sig2 = e.dp2 * k;
+    const float sig1 = dp1 * k, sig2 = dp2 * k;
     float reg1 = 2.0f * sig1 * sig1, reg2 = 2.0f * sig2 * sig2;
     const d3 ct{vt.C[0], vt.C[1], vt.C[2]};
     const float sig1_t = (float)(norm(s3.P1 - ct) * (double)vt.k);   // View::regularizerFrom3Dpoint
@@ -145,13 +129,106 @@ __global__ void k_entry_prep_all(const ViewDev* __restrict__ views, const uint32
     reg2 = 0.5f * (reg2 + 2.0f * sig2_t * sig2_t);
     DEntry d;
     d.dir[0] = s3.dir.x; d.dir[1] = s3.dir.y; d.dir[2] = s3.dir.z;
-    d.ref = e.ref;
-    d.dp1 = e.dp1; d.dp2 = e.dp2; d.reg1 = reg1; d.reg2 = reg2;
+    d.ref = ref;
+    d.dp1 = dp1; d.dp2 = dp2; d.reg1 = reg1; d.reg2 = reg2;
     d.score3D = 0.0f;
-    d.tgt_view = e.tgt_view;
-    d.flags = (e.inverse ? kDInverse : 0u) | (s3.length < kEps ? kDZeroLen : 0u);
-    d.pair = e.pair;
-    dents[b + rank] = d;
+    d.tgt_view = tgt_view;
+    d.flags = (inverse ? kDInverse : 0u) | (s3.length < kEps ? kDZeroLen : 0u);
+    d.pair = pair;
+    return d;
+}
+
+// Batched list build, one wave per 2D segment of any view (global segment id g): writes the segment's
+// hypotheses in canonical (= reference single-thread) order into dents[off[g] ...]:
+//   phase 1 (integer work): inverse refs rank-sorted by (source view, source segment), then the fresh rows
+//           of the view's outgoing pairs (ascending target) compacted by ballot/popcount prefix; only the
+//           descriptor fields of each DEntry are written;
+//   phase 2 (fp64 work, full lanes): unprojection + regularisers of every hypothesis.
+constexpr uint32_t kKeyCap = 512;   // per-wave LDS copy of the inverse sort keys
+__global__ __launch_bounds__(256) void k_build_lists_all(uint32_t G, const ViewDev* __restrict__ views,
+                                                         const PairDesc* __restrict__ pairs,
+                                                         const uint32_t* __restrict__ seg_base,
+                                                         const uint32_t* __restrict__ gseg_view,
+                                                         const uint32_t* __restrict__ vout_off,
+                                                         const uint32_t* __restrict__ vout_pairs,
+                                                         const uint32_t* __restrict__ off,
+                                                         const uint32_t* __restrict__ inv_off,
+                                                         const InvRef* __restrict__ refs,
+                                                         const Slot* __restrict__ slots, DEntry* __restrict__ dents) {
+    __shared__ uint64_t s_key[4][kKeyCap];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t g = blockIdx.x * 4 + wave;
+    if (g >= G) return;
+    const uint32_t b = off[g], L = off[g + 1] - b;
+    if (L == 0) return;
+    const uint32_t vi = gseg_view[g], seg = g - seg_base[vi];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    // ---- phase 1a: inverse hypotheses ----
+    const uint32_t ib = inv_off[g], n_inv = inv_off[g + 1] - ib;
+    const bool keys_in_lds = n_inv <= kKeyCap;
+    if (keys_in_lds) {
+        for (uint32_t m0 = 0; m0 < n_inv; m0 += 64)
+            if (m0 + lane < n_inv) {
+                const InvRef r = refs[ib + m0 + lane];
+                s_key[wave][m0 + lane] = ((uint64_t)r.src_view << 32) | r.src_row;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    for (uint32_t m0 = 0; m0 < n_inv; m0 += 64) {
+        if (m0 + lane < n_inv) {
+            const InvRef r = refs[ib + m0 + lane];
+            const uint64_t key = ((uint64_t)r.src_view << 32) | r.src_row;
+            uint32_t rank = 0;
+            if (keys_in_lds) {
+                for (uint32_t j = 0; j < n_inv; ++j) rank += (s_key[wave][j] < key) ? 1u : 0u;
+            } else {
+                for (uint32_t j = 0; j < n_inv; ++j) {
+                    const InvRef o = refs[ib + j];
+                    rank += ((((uint64_t)o.src_view << 32) | o.src_row) < key) ? 1u : 0u;
+                }
+            }
+            const PairDesc& pd = pairs[r.pair];
+            const uint64_t ref = pd.slot_off + (uint64_t)r.src_row * pd.K + r.j;
+            const Slot s = slots[ref];
+            DEntry& d = dents[b + rank];
+            d.ref = ref; d.dp1 = s.dq1; d.dp2 = s.dq2; d.tgt_view = r.src_view; d.pair = r.pair; d.flags = kDInverse;
+        }
+    }
+    // ---- phase 1b: fresh hypotheses ----
+    uint32_t pos = b + n_inv;
+    for (uint32_t q = vout_off[vi]; q < vout_off[vi + 1]; ++q) {
+        const uint32_t pi = vout_pairs[q];
+        const PairDesc& pd = pairs[pi];
+        const uint64_t row0 = pd.slot_off + (uint64_t)seg * pd.K;
+        for (uint32_t j0 = 0; j0 < pd.K; j0 += 64) {
+            bool alive = false;
+            Slot s;
+            if (j0 + lane < pd.K) {
+                s = slots[row0 + j0 + lane];
+                alive = s.tgt_seg != kEmpty && (s.flags & kSlotAlive);
+            }
+            const uint64_t m = __ballot(alive);
+            if (alive) {
+                DEntry& d = dents[pos + (uint32_t)__popcll(m & lt_mask)];
+                d.ref = row0 + j0 + lane; d.dp1 = s.dp1; d.dp2 = s.dp2; d.tgt_view = pd.tgt; d.pair = pi; d.flags = 0;
+            }
+            pos += (uint32_t)__popcll(m);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- phase 2: derived quantities, one hypothesis per lane ----
+    const ViewDev& v = views[vi];
+    const SegX sx = v.segx[seg];
+    for (uint32_t m0 = 0; m0 < L; m0 += 64) {
+        if (m0 + lane < L) {
+            DEntry& d = dents[b + m0 + lane];
+            d = make_dentry(v, views[d.tgt_view], sx, d.dp1, d.dp2, d.ref, d.tgt_view, d.pair, (d.flags & kDInverse) != 0);
+        }
+    }
 }
 
 // ---- chain ------------------------------------------------------------------------------------------
@@ -531,25 +608,27 @@ hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* 
 
 // ---- launchers --------------------------------------------------------------------------------------
 hipError_t launch_orient_all(const ViewDev* views, const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots,
-                             const uint32_t* seg_base, Slot* slots, uint32_t* cnt, hipStream_t st) {
+                             const uint32_t* seg_base, Slot* slots, uint32_t* cnt_all, uint32_t* cnt_inv,
+                             hipStream_t st) {
     if (!n_pairs || !max_slots) return hipSuccess;
     hipLaunchKernelGGL(k_orient_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, views,
-                       pairs, seg_base, slots, cnt);
+                       pairs, seg_base, slots, cnt_all, cnt_inv);
     return hipGetLastError();
 }
-hipError_t launch_fill_all(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
-                           const Slot* slots, const uint32_t* off, uint32_t* cur, Entry* ents, hipStream_t st) {
+hipError_t launch_inv_fill(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
+                           const Slot* slots, const uint32_t* inv_off, uint32_t* cur, InvRef* refs, hipStream_t st) {
     if (!n_pairs || !max_slots) return hipSuccess;
-    hipLaunchKernelGGL(k_fill_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, pairs,
-                       seg_base, slots, off, cur, ents);
+    hipLaunchKernelGGL(k_inv_fill, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, pairs,
+                       seg_base, slots, inv_off, cur, refs);
     return hipGetLastError();
 }
-hipError_t launch_entry_prep_all(const ViewDev* views, const uint32_t* seg_base, const Entry* ents,
-                                 const uint32_t* off, const uint32_t* n_ptr, uint32_t n_upper, DEntry* dents,
-                                 hipStream_t st) {
-    if (!n_upper) return hipSuccess;
-    hipLaunchKernelGGL(k_entry_prep_all, dim3((n_upper + 127) / 128), dim3(128), 0, st, views, seg_base, ents, off,
-                       n_ptr, dents);
+hipError_t launch_build_lists_all(uint32_t G, const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base,
+                                  const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
+                                  const uint32_t* off, const uint32_t* inv_off, const InvRef* refs, const Slot* slots,
+                                  DEntry* dents, hipStream_t st) {
+    if (!G) return hipSuccess;
+    hipLaunchKernelGGL(k_build_lists_all, dim3((G + 3) / 4), dim3(256), 0, st, G, views, pairs, seg_base, gseg_view,
+                       vout_off, vout_pairs, off, inv_off, refs, slots, dents);
     return hipGetLastError();
 }
 hipError_t launch_score_view(uint32_t g0, uint32_t M, const uint32_t* off, DEntry* dents, Slot* slots,

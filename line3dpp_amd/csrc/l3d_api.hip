@@ -16,11 +16,13 @@ void set_error(const std::string& s) { g_err = s; }
 // ---- prototypes of the launchers in k_views.hip / k_affinity.hip -------------------------------
 hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, uint32_t* total, hipStream_t);
 hipError_t launch_orient_all(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
-                             const uint32_t* seg_base, Slot*, uint32_t* cnt, hipStream_t);
-hipError_t launch_fill_all(const PairDesc*, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
-                           const Slot*, const uint32_t* off, uint32_t* cur, Entry*, hipStream_t);
-hipError_t launch_entry_prep_all(const ViewDev*, const uint32_t* seg_base, const Entry*, const uint32_t* off,
-                                 const uint32_t* n_ptr, uint32_t n_upper, DEntry*, hipStream_t);
+                             const uint32_t* seg_base, Slot*, uint32_t* cnt_all, uint32_t* cnt_inv, hipStream_t);
+hipError_t launch_inv_fill(const PairDesc*, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
+                           const Slot*, const uint32_t* inv_off, uint32_t* cur, InvRef*, hipStream_t);
+hipError_t launch_build_lists_all(uint32_t G, const ViewDev*, const PairDesc*, const uint32_t* seg_base,
+                                  const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
+                                  const uint32_t* off, const uint32_t* inv_off, const InvRef*, const Slot*, DEntry*,
+                                  hipStream_t);
 hipError_t launch_score_view(uint32_t g0, uint32_t M, const uint32_t* off, DEntry*, Slot*, uint32_t* max_score_bits,
                              float two_sigA_sqr, float min_sim, hipStream_t);
 hipError_t launch_filter_all(uint32_t G, const uint32_t* off, const uint32_t* gseg_view, DEntry*,
@@ -84,7 +86,9 @@ struct l3d_ctx {
     std::vector<uint32_t> seg_base;                 // [V+1]
     DevBuf<uint32_t> d_seg_base, d_gseg_view, d_cnt, d_off, d_cur, d_scan_tmp, d_scal, d_max_score;
     DevBuf<uint32_t> d_surv_cnt, d_has_best, d_best_pos, d_surv_off, d_hyp_off, d_surv_tg, d_surv_sg;
-    DevBuf<Entry> d_ents;
+    DevBuf<InvRef> d_refs;
+    DevBuf<uint32_t> d_cnt_inv, d_inv_off, d_vout_pairs, d_vout_off;
+    std::vector<uint32_t> vout_off;
     DevBuf<DEntry> d_dents;
     DevBuf<Match> d_surv;
     DevBuf<int32_t> d_hyp_of_seg;
@@ -233,7 +237,8 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_seg_base.release(); c->d_gseg_view.release(); c->d_cnt.release(); c->d_off.release(); c->d_cur.release();
     c->d_scan_tmp.release(); c->d_scal.release(); c->d_max_score.release(); c->d_surv_cnt.release();
     c->d_has_best.release(); c->d_best_pos.release(); c->d_surv_off.release(); c->d_hyp_off.release();
-    c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_ents.release(); c->d_dents.release(); c->d_surv.release();
+    c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_cnt_inv.release();
+    c->d_inv_off.release(); c->d_vout_pairs.release(); c->d_vout_off.release(); c->d_dents.release(); c->d_surv.release();
     c->d_hyp_of_seg.release(); c->d_depths.release(); c->d_medians.release(); c->d_hyps.release();
     c->d_vaff.release(); c->d_simv.release(); c->d_msdl.release(); c->d_ca.release(); c->d_cb.release();
     c->d_flag.release(); c->d_epos.release(); c->d_first_touch.release(); c->d_touch_flag.release();
@@ -478,24 +483,40 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(hipMemcpyAsync(c->d_gseg_view.p, gseg_view.data(), (size_t)G * 4, hipMemcpyHostToDevice, st));
     L3D_HIP_CHECK(hipStreamSynchronize(st));   // gseg_view is a local
     L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
+    // outgoing pairs of every view (ascending target), for the fresh part of the lists
+    c->vout_off.assign(V + 1, 0);
+    std::vector<uint32_t> vout;
+    for (uint32_t vi = 0; vi < V; ++vi) {
+        for (uint32_t p : c->order[vi]->out_pairs) vout.push_back(p);
+        c->vout_off[vi + 1] = (uint32_t)vout.size();
+    }
+    L3D_HIP_CHECK(c->d_vout_pairs.reserve(vout.size() + 1));
+    L3D_HIP_CHECK(c->d_vout_off.reserve(V + 1));
+    L3D_HIP_CHECK(hipMemcpyAsync(c->d_vout_off.p, c->vout_off.data(), ((size_t)V + 1) * 4, hipMemcpyHostToDevice, st));
+    L3D_HIP_CHECK(c->d_cnt_inv.reserve(G + 1)); L3D_HIP_CHECK(c->d_inv_off.reserve(G + 1));
+    if (!vout.empty())
+        L3D_HIP_CHECK(hipMemcpyAsync(c->d_vout_pairs.p, vout.data(), vout.size() * 4, hipMemcpyHostToDevice, st));
     L3D_HIP_CHECK(hipMemsetAsync(c->d_cnt.p, 0, ((size_t)G + 1) * 4, st));
+    L3D_HIP_CHECK(hipMemsetAsync(c->d_cnt_inv.p, 0, ((size_t)G + 1) * 4, st));
     L3D_HIP_CHECK(hipMemsetAsync(c->d_cur.p, 0, ((size_t)G + 1) * 4, st));
     L3D_HIP_CHECK(hipMemsetAsync(c->d_max_score.p, 0, ((size_t)V + 1) * 4, st));
     L3D_HIP_CHECK(hipMemsetAsync(c->d_scal.p, 0, 8 * 4, st));
-    // ---- pre-pass: orientation flags, per-segment lists in canonical order ----
+    // ---- pre-pass: orientation flags, list offsets, transposed index of potential inverse matches ----
     L3D_HIP_CHECK(launch_orient_all(c->d_views.p, c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p,
-                                    c->d_cnt.p, st));
+                                    c->d_cnt.p, c->d_cnt_inv.p, st));
     L3D_HIP_CHECK(launch_scan(c->d_cnt.p, G, c->d_off.p, c->d_scan_tmp.p, c->d_scal.p + 0, st));
-    uint32_t n_ents = 0;
-    L3D_HIP_CHECK(hipMemcpyAsync(&n_ents, c->d_scal.p + 0, 4, hipMemcpyDeviceToHost, st));
-    L3D_HIP_CHECK(hipStreamSynchronize(st));
-    c->n_ents = n_ents;
-    L3D_HIP_CHECK(c->d_ents.reserve(std::max<uint32_t>(n_ents, 1)));
+    L3D_HIP_CHECK(launch_scan(c->d_cnt_inv.p, G, c->d_inv_off.p, c->d_scan_tmp.p, c->d_scal.p + 5, st));
+    uint32_t tot[6] = {0, 0, 0, 0, 0, 0};
+    L3D_HIP_CHECK(hipMemcpyAsync(tot, c->d_scal.p, 6 * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipStreamSynchronize(st));   // also covers the local `vout`
+    const uint32_t n_ents = c->n_ents = tot[0], n_inv = tot[5];
     L3D_HIP_CHECK(c->d_dents.reserve(std::max<uint32_t>(n_ents, 1)));
-    L3D_HIP_CHECK(launch_fill_all(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_off.p, c->d_cur.p,
-                                  c->d_ents.p, st));
-    L3D_HIP_CHECK(launch_entry_prep_all(c->d_views.p, c->d_seg_base.p, c->d_ents.p, c->d_off.p, c->d_scal.p + 0,
-                                        n_ents, c->d_dents.p, st));
+    L3D_HIP_CHECK(c->d_refs.reserve(std::max<uint32_t>(n_inv, 1)));
+    L3D_HIP_CHECK(launch_inv_fill(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_inv_off.p,
+                                  c->d_cur.p, c->d_refs.p, st));
+    L3D_HIP_CHECK(launch_build_lists_all(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p,
+                                         c->d_vout_off.p, c->d_vout_pairs.p, c->d_off.p, c->d_inv_off.p, c->d_refs.p,
+                                         c->d_slots.p, c->d_dents.p, st));
     // ---- chain: one scoring launch per view, ascending camID ----
     for (uint32_t vi = 0; vi < V; ++vi)
         L3D_HIP_CHECK(launch_score_view(c->seg_base[vi], c->order[vi]->M, c->d_off.p, c->d_dents.p, c->d_slots.p,

@@ -110,6 +110,12 @@ struct Entry {
 };
 static_assert(sizeof(Entry) == 48, "Entry is 48 bytes");
 
+// transposed index entry: slot (pair, src_row, j) is a potential inverse hypothesis of its target segment
+struct InvRef {
+    uint32_t src_view, src_row, pair, j;
+};
+static_assert(sizeof(InvRef) == 16, "InvRef is 16 bytes");
+
 // the same hypothesis at its canonical position, with what scoring needs
 struct DEntry {
     double dir[3];     // unprojected 3D direction (Segment3D::dir_)
