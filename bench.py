@@ -33,7 +33,11 @@ def run_cpu_baseline(scene, args, pair_tests, kNN):
     scaling long before 256 threads, so the thread count is picked by a short scan on a sub-scene and
     the full workload is then run once with the best count."""
     import copy
-    from oracle.oracle import Oracle
+    from oracle import oracle as O
+    use_ref = O.have_reference()     # the reference's own line3D.cc/view.cc (oracle/_ref), else the restatement
+
+    def Oracle(threads):
+        return O.Oracle(threads=threads, reference=use_ref)
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     if args.cpu_threads:
         best_t, scan = args.cpu_threads, {}
@@ -59,9 +63,11 @@ def run_cpu_baseline(scene, args, pair_tests, kNN):
     o.match_images(kNN=kNN); o.compute_affinity()
     cdt = time.perf_counter() - t1
     return {"value": round(pair_tests / cdt / 1e6, 2), "unit": "M segment-pair scores/s", "cores": best_t,
-            "kind": "port", "host_cpus": ncpu, "thread_scan_M_per_s": scan,
+            "kind": "reference" if use_ref else "port", "host_cpus": ncpu, "thread_scan_M_per_s": scan,
             "sample": f"full {args.config} workload once ({pair_tests} pair tests, {cdt:.2f} s) with the thread count "
-                      f"that scored best on an 8-view sub-scene; OpenMP oracle = restatement of the reference CPU path"}
+                      f"that scored best on an 8-view sub-scene; " +
+                      ("the reference's own OpenMP CPU path (line3D.cc/view.cc compiled in place, oracle/_ref)" if use_ref
+                       else "OpenMP oracle = restatement of the reference CPU path")}
 
 
 def main():

@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libl3d_oracle.so")
+_REF_SO = os.path.join(_HERE, "_ref", "libl3d_ref.so")   # the reference's own sources, compiled in place
 
 # commons.h:186-203
 MATCH_DTYPE = np.dtype([
@@ -30,14 +31,25 @@ def build(force=False):
     return _SO
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        build()
-        L = C.CDLL(_SO)
+def have_reference():
+    """True if oracle/_ref/libl3d_ref.so (the reference's own line3D.cc/view.cc, built by oracle/Makefile
+    where /root/reference exists) is available."""
+    return os.path.exists(_REF_SO)
+
+
+def lib(reference=False):
+    key = "ref" if reference else "port"
+    if key not in _libs:
+        if reference:
+            if not have_reference():
+                raise RuntimeError("oracle/_ref/libl3d_ref.so is missing (needs /root/reference to build)")
+            L = C.CDLL(_REF_SO)
+        else:
+            build()
+            L = C.CDLL(_SO)
         vp, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int
         L.lo_create.restype = vp
         L.lo_destroy.argtypes = [vp]
@@ -68,8 +80,8 @@ def lib():
         L.lo_num_edges.argtypes = [vp]; L.lo_num_edges.restype = u32
         L.lo_num_rows.argtypes = [vp]; L.lo_num_rows.restype = u32
         L.lo_get_affinity.argtypes = [vp, vp, vp]
-        _lib = L
-    return _lib
+        _libs[key] = L
+    return _libs[key]
 
 
 def _p(a):
@@ -79,8 +91,11 @@ def _p(a):
 class Oracle:
     """Mirror of the slice of L3DPP::Line3D the hot path needs (explicit segments + neighbours)."""
 
-    def __init__(self, record_scored=False, threads=1):
-        self.L = lib()
+    def __init__(self, record_scored=False, threads=1, reference=False):
+        """reference=True drives the reference's own translation units (oracle/_ref) instead of the
+        restatement; stage-level calls (begin_match/match_pair/scored) exist only in the restatement."""
+        self.reference = reference
+        self.L = lib(reference)
         self.h = C.c_void_p(self.L.lo_create())
         self.L.lo_set_record_scored(self.h, int(record_scored))
         self.L.lo_set_threads(int(threads))

@@ -1,0 +1,210 @@
+// =============================================================================
+// oracle/ref_driver.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// C interface (same lo_* names as l3d_oracle.cpp, so oracle/oracle.py can load either library) over the
+// REFERENCE'S OWN line3D.cc / view.cc / clustering.cc, compiled in place from /root/reference against the
+// thin shim headers in oracle/ref_shim/ (Eigen subset with real arithmetic; Boost/OpenCV stand-ins for code
+// that the explicit-segments path never reaches).  Built by oracle/Makefile into oracle/_ref/ (git-ignored;
+// no reference source is copied into this repository).
+//
+// Purpose: pin the restatement (l3d_oracle.cpp) against the reference's real control flow and arithmetic,
+// and serve as bench.py's cpu_baseline of kind "reference" (its OpenMP CPU path).
+//
+// Private members of L3DPP::Line3D are read through the usual test-only access hack; it does not change
+// the class layout or the code generated for the reference's translation units.
+// =============================================================================
+#include <sstream>
+#include <iostream>
+#define private public
+#define protected public
+#include "line3D.h"
+#undef private
+#undef protected
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+struct Match40 {  // commons.h:186-203
+    uint32_t src_camID_, src_segID_, tgt_camID_, tgt_segID_;
+    float overlap_score_, score3D_, depth_p1_, depth_p2_, depth_q1_, depth_q2_;
+};
+static_assert(sizeof(L3DPP::Match) == 40, "Match layout");
+struct CLEdgeOut { int i_, j_; float w_; };
+
+struct Ref {
+    L3DPP::Line3D* l3d = nullptr;
+    std::map<uint32_t, uint32_t> M;
+    std::streambuf* old_cout = nullptr;
+    std::ostringstream sink;
+};
+
+struct Quiet {  // the reference prints progress to std::cout
+    std::streambuf* old;
+    std::ostringstream sink;
+    Quiet() : old(std::cout.rdbuf(sink.rdbuf())) {}
+    ~Quiet() { std::cout.rdbuf(old); }
+};
+
+}  // namespace
+
+extern "C" {
+
+void* lo_create() {
+    Quiet q;
+    Ref* r = new Ref();
+    // output folder only receives an (unused) L3D++_data directory; load_segments=false;
+    // neighbors_by_worldpoints=false (explicit neighbour lists); use_GPU=false
+    r->l3d = new L3DPP::Line3D("/tmp", false, -1, 3000, false, false);
+    return r;
+}
+void lo_destroy(void* p) { Ref* r = (Ref*)p; { Quiet q; delete r->l3d; } delete r; }
+void lo_set_record_scored(void*, int) {}
+void lo_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#endif
+}
+int lo_max_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+int lo_is_reference() { return 1; }
+
+int lo_add_view(void* p, uint32_t camID, const float* segs4, uint32_t M, const double* K, const double* R,
+                const double* t, uint32_t width, uint32_t height, float median_depth, const uint32_t* nbrs,
+                uint32_t n_nbrs) {
+    Ref* r = (Ref*)p;
+    Quiet q;
+    Eigen::Matrix3d Km, Rm; Eigen::Vector3d tv;
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) { Km(i, j) = K[3 * i + j]; Rm(i, j) = R[3 * i + j]; } tv(i) = t[i]; }
+    cv::Mat image; image.cols = (int)width; image.rows = (int)height;
+    std::list<unsigned int> nb(nbrs, nbrs + n_nbrs);
+    std::vector<cv::Vec4f> segs(M);
+    for (uint32_t i = 0; i < M; ++i) segs[i] = cv::Vec4f(segs4[4 * i], segs4[4 * i + 1], segs4[4 * i + 2], segs4[4 * i + 3]);
+    const size_t before = r->l3d->views_.size();
+    r->l3d->addImage(camID, image, Km, Rm, tv, median_depth, nb, segs);
+    if (r->l3d->views_.size() == before) return 1;
+    r->M[camID] = M;
+    return 0;
+}
+
+void lo_match_images(void* p, float sigma_p, float sigma_a, uint32_t num_neighbors, float epi_overlap, int kNN,
+                     float const_reg_depth) {
+    Quiet q;
+    ((Ref*)p)->l3d->matchImages(sigma_p, sigma_a, num_neighbors, epi_overlap, kNN, const_reg_depth);
+}
+
+// the part of Line3D::reconstruct3Dlines up to the affinity matrix, line3D.cc:1749-1778 -- statement for
+// statement, calling the reference's own (private) functions
+void lo_compute_affinity(void* p) {
+    Quiet q;
+    L3DPP::Line3D* l = ((Ref*)p)->l3d;
+    if (l->estimated_position3D_.size() == 0) return;
+    l->translate();
+    std::vector<float> scene_depths_lines;
+    for (std::map<unsigned int, L3DPP::View*>::const_iterator vit = l->views_.begin(); vit != l->views_.end(); ++vit)
+        if (vit->second->median_depth() > L3D_EPS) scene_depths_lines.push_back(vit->second->median_depth());
+    if (scene_depths_lines.size() > 0) {
+        std::sort(scene_depths_lines.begin(), scene_depths_lines.end());
+        l->med_scene_depth_lines_ = scene_depths_lines[scene_depths_lines.size() / 2];
+    } else {
+        l->med_scene_depth_lines_ = 0.0f;
+    }
+    l->computingAffinityMatrix();
+    l->untranslate();
+}
+
+// ---- accessors (same contracts as l3d_oracle.cpp) ----------------------------------------------------------
+uint64_t lo_get_matches(void* p, uint32_t cam, Match40* out, uint64_t cap, uint32_t* offsets) {
+    L3DPP::Line3D* l = ((Ref*)p)->l3d;
+    const std::vector<std::list<L3DPP::Match> >& rows = l->matches_[cam];
+    uint64_t n = 0;
+    for (size_t r = 0; r < rows.size(); ++r) {
+        if (offsets) offsets[r] = (uint32_t)n;
+        for (std::list<L3DPP::Match>::const_iterator it = rows[r].begin(); it != rows[r].end(); ++it) {
+            if (out && n < cap) std::memcpy(&out[n], &(*it), 40);
+            ++n;
+        }
+    }
+    if (offsets) offsets[rows.size()] = (uint32_t)n;
+    return n;
+}
+uint64_t lo_get_scored(void*, uint32_t, Match40*, uint64_t, uint32_t*) { return 0; }
+uint32_t lo_num_best(void* p) { return (uint32_t)((Ref*)p)->l3d->estimated_position3D_.size(); }
+// estimated_position3D_ is filled in thread-timing order under OpenMP (line3D.cc:1639-1646): hand it out
+// ordered by (camID, segID)
+void lo_get_best(void* p, uint32_t* camseg2, double* p1p2dir9, float* length, Match40* m) {
+    L3DPP::Line3D* l = ((Ref*)p)->l3d;
+    const size_t n = l->estimated_position3D_.size();
+    std::vector<size_t> ord(n);
+    for (size_t i = 0; i < n; ++i) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
+        const L3DPP::Match& ma = l->estimated_position3D_[a].second; const L3DPP::Match& mb = l->estimated_position3D_[b].second;
+        return ma.src_camID_ < mb.src_camID_ || (ma.src_camID_ == mb.src_camID_ && ma.src_segID_ < mb.src_segID_); });
+    for (size_t i = 0; i < n; ++i) {
+        const L3DPP::Segment3D& s = l->estimated_position3D_[ord[i]].first;
+        const L3DPP::Match& mm = l->estimated_position3D_[ord[i]].second;
+        camseg2[2 * i] = mm.src_camID_; camseg2[2 * i + 1] = mm.src_segID_;
+        double* o = p1p2dir9 + 9 * i;
+        const Eigen::Vector3d P1 = s.P1(), P2 = s.P2(), d = s.dir();
+        o[0] = P1.x(); o[1] = P1.y(); o[2] = P1.z(); o[3] = P2.x(); o[4] = P2.y(); o[5] = P2.z();
+        o[6] = d.x(); o[7] = d.y(); o[8] = d.z();
+        length[i] = s.length();
+        std::memcpy(&m[i], &mm, 40);
+    }
+}
+void lo_view_info(void* p, uint32_t cam, float* k, float* median_depth, double* C3, double* t3) {
+    L3DPP::View* v = ((Ref*)p)->l3d->views_[cam];
+    *k = v->k(); *median_depth = v->median_depth();
+    const Eigen::Vector3d C = v->C(), t = v->t();
+    for (int i = 0; i < 3; ++i) { C3[i] = C(i); t3[i] = t(i); }
+}
+void lo_translation(void* p, double* t3) {
+    const Eigen::Vector3d t = ((Ref*)p)->l3d->translation_;
+    for (int i = 0; i < 3; ++i) t3[i] = t(i);
+}
+float lo_med_scene_depth_lines(void* p) { return ((Ref*)p)->l3d->med_scene_depth_lines_; }
+uint32_t lo_num_edges(void* p) { return (uint32_t)((Ref*)p)->l3d->A_.size(); }
+uint32_t lo_num_rows(void* p) { return (uint32_t)((Ref*)p)->l3d->local2global_.size(); }
+void lo_get_affinity(void* p, CLEdgeOut* edges, uint32_t* local2global2) {
+    L3DPP::Line3D* l = ((Ref*)p)->l3d;
+    size_t i = 0;
+    for (std::list<L3DPP::CLEdge>::const_iterator it = l->A_.begin(); it != l->A_.end(); ++it, ++i) {
+        edges[i].i_ = it->i_; edges[i].j_ = it->j_; edges[i].w_ = it->w_;
+    }
+    for (std::map<int, L3DPP::Segment2D>::const_iterator it = l->local2global_.begin(); it != l->local2global_.end(); ++it) {
+        local2global2[2 * it->first] = it->second.camID();
+        local2global2[2 * it->first + 1] = it->second.segID();
+    }
+}
+uint32_t lo_num_pairs(void* p) {
+    L3DPP::Line3D* l = ((Ref*)p)->l3d;
+    uint32_t n = 0;
+    for (auto& kv : l->matched_) n += (uint32_t)kv.second.size();
+    return n / 2;
+}
+void lo_get_pairs(void*, uint32_t*, uint32_t*) {}
+uint64_t lo_pair_tests(void* p) {
+    L3DPP::Line3D* l = ((Ref*)p)->l3d;
+    uint64_t n = 0;
+    for (auto& kv : l->matched_)
+        for (unsigned int t : kv.second)
+            if (kv.first < t) n += (uint64_t)l->views_[kv.first]->num_lines() * l->views_[t]->num_lines();
+    return n;
+}
+// stage-level entry points exist only in the restatement
+void lo_begin_match(void*, float, float, uint32_t, float, int, float) {}
+void lo_end_match(void*) {}
+uint64_t lo_match_pair(void*, uint32_t, uint32_t, Match40*, uint64_t, uint32_t*) { return 0; }
+void lo_fundamental(void*, uint32_t, uint32_t, double*) {}
+
+}  // extern "C"

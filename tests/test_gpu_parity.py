@@ -357,3 +357,22 @@ def test_cpp_facade_matches_python_front_end(tmp_path):
     e, l2g, _ = g.affinity()
     assert int(kv["hypotheses"]) == len(g.best()[0]) and int(kv["edges"]) == len(e) and int(kv["rows"]) == len(l2g)
     assert abs(float(kv["wsum"]) - float(e["w"].astype(np.float64).sum())) < 1e-3
+
+
+def test_full_pipeline_vs_reference_own_code():
+    """HIP path against oracle/_ref = the reference's own line3D.cc/view.cc compiled in place (prebuilt library
+    shipped to the GPU box; skipped if it is absent)."""
+    from oracle import oracle as O
+    if not O.have_reference():
+        pytest.skip("oracle/_ref not built")
+    for (nv, ns, nn, seed, params) in ((10, 400, 6, 41, {}), (7, 260, 4, 42, dict(kNN=0)),
+                                       (8, 300, 4, 43, dict(sigma_p=-0.05))):
+        sc = make_scene(nv, ns, n_neighbors=nn, seed=seed)
+        g = _gpu(sc)
+        kw = dict(params)
+        if "sigma_p" in kw:
+            kw["sigma_position"] = kw.pop("sigma_p")
+        assert g.matchImages(**kw) and g.computeAffinity()
+        r = O.Oracle(threads=1, reference=True)
+        r.add_scene(sc); r.match_images(**params); r.compute_affinity()
+        _compare_final(g, r, sc)

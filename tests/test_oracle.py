@@ -1,8 +1,8 @@
 """CPU tests of the oracle (oracle/l3d_oracle.cpp): analytic known-answer checks of every stage of the
 hot path, and the committed golden fixture.  The reference ships no tests or golden vectors for this
-path and cannot be built here, so the oracle is pinned by geometry it must
-reproduce exactly-by-construction and by a frozen fixture of its own output ("parity unpinned" by
-the reference itself -- see DESIGN.md)."""
+path; the oracle is pinned (a) by tests/test_reference_pin.py against the reference's
+own line3D.cc/view.cc compiled in place (oracle/_ref), (b) by the golden vectors that build produced
+(tests/golden/small_scene.npz), and (c) here, by geometry it must reproduce exactly by construction."""
 import os
 
 import numpy as np
@@ -176,16 +176,15 @@ def test_param_clamps_and_errors():
 
 
 def test_golden_fixture():
-    """The frozen output of the oracle on a small scene (tools/make_golden.py): guards the oracle
-    against unintended changes; the HIP path is checked against the same file in test_gpu_parity."""
+    """tests/golden/small_scene.npz holds the output of the REFERENCE'S OWN CODE (oracle/_ref) on a small
+    scene (tools/make_golden.py); the restatement must reproduce it, and the HIP path is checked against the
+    same file in test_gpu_parity."""
     assert os.path.exists(GOLDEN), "run python tools/make_golden.py"
     g = np.load(GOLDEN)
     from tools.make_golden import golden_scene, run_oracle
     out = run_oracle(golden_scene())
+    assert "reference" in str(g["generator"])
     for k in ("matches", "best_keys", "best_geo", "edges", "l2g", "medians", "ks"):
         a, b = g[k], out[k]
         assert a.shape == b.shape, k
-        if a.dtype.kind == "f":
-            assert np.allclose(a, b, rtol=2e-7, atol=0), k   # libm expf/acos may differ in the last ulp
-        else:
-            assert np.array_equal(a, b), k
+        assert np.array_equal(a, b), k   # same libm, same arithmetic: bit-identical

@@ -1,8 +1,8 @@
-"""Generates tests/golden/small_scene.npz: the oracle's output on a small deterministic scene.
-
-The reference has no golden vectors for the hot path and cannot be run here, so this
-fixture freezes the oracle restatement (oracle/l3d_oracle.cpp); it is the file both the oracle tests
-and the GPU parity tests compare against.  Re-run only when the oracle is deliberately changed:
+"""Generates tests/golden/small_scene.npz: golden input/output vectors of the hot path on a small
+deterministic scene, produced by THE REFERENCE'S OWN CODE (oracle/_ref = line3D.cc / view.cc compiled in
+place from /root/reference against oracle/ref_shim; see oracle/Makefile).  /root/reference does not exist on
+the GPU box, so the vectors are committed; the oracle restatement and the HIP path are both tested against
+this file.  Regenerate (in the container that has /root/reference):
     python tools/make_golden.py
 """
 import os
@@ -31,9 +31,9 @@ def flat_matches(get, cams):
     return np.array(rows, np.float64).reshape(-1, 10)
 
 
-def run_oracle(scene):
+def run_oracle(scene, reference=False):
     from oracle.oracle import Oracle
-    o = Oracle(threads=1)
+    o = Oracle(threads=1, reference=reference)
     o.add_scene(scene)
     o.match_images(**PARAMS)
     o.compute_affinity()
@@ -48,7 +48,10 @@ def run_oracle(scene):
 
 
 if __name__ == "__main__":
-    out = run_oracle(golden_scene())
+    from oracle.oracle import have_reference
+    assert have_reference(), "oracle/_ref is not built: run `make -C oracle` where /root/reference exists"
+    out = run_oracle(golden_scene(), reference=True)
+    out["generator"] = np.array("reference line3D.cc/view.cc via oracle/_ref (shim headers)")
     path = os.path.join(ROOT, "tests", "golden", "small_scene.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {k: v.shape for k, v in out.items()})
