@@ -315,17 +315,16 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
     return hipGetLastError();
 }
 
-// ---- per-view precompute (after translate) ---------------------------------------------------
-__global__ void k_prep_view(const float4* __restrict__ seg4, uint32_t M, const double* __restrict__ consts,
-                            SegX* __restrict__ segx, SegF* __restrict__ segf, float cx, float cy) {
-    // consts: RtKinv[9], C[3]
+// ---- per-view precompute (after translate), all views in one launch: grid = (segment blocks, views) -----
+__global__ void k_prep_views(const ViewDev* __restrict__ views) {
+    const ViewDev& v = views[blockIdx.y];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
+    if (i >= v.M) return;
     double A[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) A[k] = consts[k];
-    const d3 C{consts[9], consts[10], consts[11]};
-    const float4 s = seg4[i];
+    for (int k = 0; k < 9; ++k) A[k] = v.RtKinv[k];
+    const d3 C{v.C[0], v.C[1], v.C[2]};
+    const float4 s = v.seg4[i];
     const double ax = s.x, ay = s.y, bx = s.z, by = s.w;
     const d3 r1 = normalized(mul33(A, d3{ax, ay, 1.0}));
     const d3 r2 = normalized(mul33(A, d3{bx, by, 1.0}));
@@ -337,18 +336,16 @@ __global__ void k_prep_view(const float4* __restrict__ seg4, uint32_t M, const d
     o.n[0] = n.x; o.n[1] = n.y; o.n[2] = n.z;
     o.cn = dot(C, n);
     o.rm[0] = rm.x; o.rm[1] = rm.y; o.rm[2] = rm.z;
-    segx[i] = o;
+    const_cast<SegX*>(v.segx)[i] = o;
     SegF f;
-    f.qx = (float)(ax - (double)cx); f.qy = (float)(ay - (double)cy);
+    f.qx = (float)(ax - (double)v.cx); f.qy = (float)(ay - (double)v.cy);
     f.dx = (float)(ax - bx); f.dy = (float)(ay - by);
-    segf[i] = f;
+    const_cast<SegF*>(v.segf)[i] = f;
 }
 
-hipError_t launch_prep_view(const float4* seg4, uint32_t M, const double* consts_dev, SegX* segx, SegF* segf,
-                            float cx, float cy, hipStream_t stream) {
-    if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_prep_view, dim3((M + 255) / 256), dim3(256), 0, stream, seg4, M, consts_dev, segx, segf,
-                       cx, cy);
+hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, hipStream_t stream) {
+    if (!n_views || !max_M) return hipSuccess;
+    hipLaunchKernelGGL(k_prep_views, dim3((max_M + 255) / 256, n_views), dim3(256), 0, stream, views);
     return hipGetLastError();
 }
 

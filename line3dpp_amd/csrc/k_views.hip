@@ -16,8 +16,12 @@
 //                       single-thread) order -- inverse refs rank-sorted, fresh rows by ballot prefix, no
 //                       atomics -- with the unprojected 3D direction and the spatial regularisers scoring
 //                       needs (scoringCPU :1233-1248)
+//     k_support_all     one wave per 2D segment: all L^2 similarityForScoring decisions -> support bitsets
 //   chain (one launch per view, ascending camID)
-//     k_score_view      one wave per 2D segment, O(L^2) similarityForScoring (:1417-1446) with the
+//     k_presence_view   one wave per 2D segment: which inverse hypotheses exist, which fresh ones are
+//                       supported -- pure bit operations on the support bitsets
+//   scores (all views at once)
+//     k_score_all       O(#supporters) similarityForScoring (:1417-1446) with the
 //                       reference's per-camera replace/subtract accumulation (:1255-1274); an inverse
 //                       hypothesis takes part only if its source view's kernel (an earlier launch on the
 //                       same stream) wrote score3D > 0 into the shared slot
@@ -260,94 +264,157 @@ __device__ __forceinline__ float sim_scoring(const double* dira, bool zeroa, flo
     return sim > sc.min_sim ? sim : 0.0f;
 }
 
-// One wave per 2D segment of view `vi`.  The hypotheses that exist (all fresh ones + the inverse ones
-// whose source view scored them > 0) are first compacted by ballot/popcount into an LDS index list;
-// then lanes own hypotheses M (strided by 64) and the inner loop walks all existing hypotheses M2 of
-// the segment in canonical order from LDS.
+// ---- support bitsets (batched), presence propagation (the chain), scores (batched) ---------------------
+// For hypothesis i of a segment with L potential hypotheses, S_i = { j : cam(j) != cam(i) and
+// similarityForScoring(i, j) > 0 } is a row of W = ceil(L/64) 64-bit words.  S_i does not depend on the chain.
+// Layout per global segment g: bits[boff[g] + i*W + w], i in [0, L]; row L is the presence mask P.
 constexpr int kScoreChunk = 64;
-constexpr uint32_t kIdxCap = 1024;   // per-wave LDS index list; longer lists take the uncompacted path
-__global__ __launch_bounds__(256) void k_score_view(uint32_t g0, uint32_t M, const uint32_t* __restrict__ off,
-                                                    DEntry* __restrict__ dents, Slot* __restrict__ slots,
-                                                    uint32_t* __restrict__ max_score_bits, SimConst sc) {
+
+// words per segment: (L+1) * ceil(L/64)
+__global__ void k_bits_len(uint32_t G, const uint32_t* __restrict__ off, uint32_t* __restrict__ len) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const uint32_t L = off[g + 1] - off[g];
+    len[g] = L ? (L + 1) * ((L + 63) / 64) : 0u;
+}
+
+// One wave per 2D segment (any view): all L x L similarity decisions, lanes own hypotheses i (strided by 64),
+// the inner loop walks chunks of 64 hypotheses j staged in LDS; each (i, chunk) yields one 64-bit word.
+__global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t* __restrict__ off,
+                                                     const uint32_t* __restrict__ boff,
+                                                     const DEntry* __restrict__ dents, uint64_t* __restrict__ bits,
+                                                     SimConst sc) {
     __shared__ double s_dir[4][kScoreChunk][3];
     __shared__ float s_dp1[4][kScoreChunk], s_dp2[4][kScoreChunk];
     __shared__ uint32_t s_cam[4][kScoreChunk], s_flg[4][kScoreChunk];
-    __shared__ uint16_t s_idx[4][kIdxCap];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t seg = blockIdx.x * 4 + wave;
-    if (seg >= M) return;
-    const uint32_t b = off[g0 + seg], L = off[g0 + seg + 1] - b;
+    const uint32_t g = blockIdx.x * 4 + wave;
+    if (g >= G) return;
+    const uint32_t b = off[g], L = off[g + 1] - b;
     if (L == 0) return;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const bool compact = L <= kIdxCap;
-    uint32_t Lp = L;   // number of existing hypotheses when compacted
-    if (compact) {
-        Lp = 0;
-        for (uint32_t m0 = 0; m0 < L; m0 += 64) {
-            bool present = false;
-            if (m0 + lane < L) {
-                const DEntry& d = dents[b + m0 + lane];
-                // an inverse hypothesis exists only if its source view scored the match > 0 (line3D.cc:1680)
-                present = !(d.flags & kDInverse) || (slots[d.ref].score3D > 0.0f);
-                if (!present) { dents[b + m0 + lane].score3D = 0.0f; dents[b + m0 + lane].flags = d.flags & ~kDPresent; }
-            }
-            const uint64_t m = __ballot(present);
-            if (present) s_idx[wave][Lp + (uint32_t)__popcll(m & lt_mask)] = (uint16_t)(m0 + lane);
-            Lp += (uint32_t)__popcll(m);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    float vmax = 0.0f;
-    for (uint32_t m0 = 0; m0 < Lp; m0 += 64) {
-        const uint32_t mi = m0 + lane;
-        const bool inrange = mi < Lp;
-        const uint32_t pa = inrange ? (compact ? (uint32_t)s_idx[wave][mi] : mi) : 0u;
-        bool act = inrange;
+    const uint32_t W = (L + 63) / 64;
+    uint64_t* rows = bits + boff[g];
+    for (uint32_t m0 = 0; m0 < L; m0 += 64) {
+        const uint32_t i = m0 + lane;
+        const bool act = i < L;
         DEntry a;
-        if (act) {
-            a = dents[b + pa];
-            if (!compact && (a.flags & kDInverse) && !(slots[a.ref].score3D > 0.0f)) act = false;
-        }
-        float score3D = 0.0f, cur = 0.0f;
-        uint32_t cur_cam = kEmpty;
-        for (uint32_t c0 = 0; c0 < Lp; c0 += kScoreChunk) {
-            const uint32_t cn = min((uint32_t)kScoreChunk, Lp - c0);
+        if (act) a = dents[b + i];
+        for (uint32_t c0 = 0; c0 < L; c0 += kScoreChunk) {
+            const uint32_t cn = min((uint32_t)kScoreChunk, L - c0);
             __builtin_amdgcn_wave_barrier();
             if (lane < cn) {
-                const uint32_t po = compact ? (uint32_t)s_idx[wave][c0 + lane] : (c0 + lane);
-                const DEntry& o = dents[b + po];
-                uint32_t f = o.flags;
-                if (!compact && (f & kDInverse) && !(slots[o.ref].score3D > 0.0f)) f |= kDAbsent;
+                const DEntry& o = dents[b + c0 + lane];
                 s_dir[wave][lane][0] = o.dir[0]; s_dir[wave][lane][1] = o.dir[1]; s_dir[wave][lane][2] = o.dir[2];
                 s_dp1[wave][lane] = o.dp1; s_dp2[wave][lane] = o.dp2;
-                s_cam[wave][lane] = o.tgt_view; s_flg[wave][lane] = f;
+                s_cam[wave][lane] = o.tgt_view; s_flg[wave][lane] = o.flags;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (act) {
+                uint64_t word = 0;
                 for (uint32_t j = 0; j < cn; ++j) {
-                    const uint32_t cam2 = s_cam[wave][j], f2 = s_flg[wave][j];
-                    if (cam2 == a.tgt_view || (f2 & kDAbsent)) continue;
+                    if (s_cam[wave][j] == a.tgt_view) continue;
                     const float sim = sim_scoring(a.dir, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
-                                                  s_dir[wave][j], (f2 & kDZeroLen) != 0, s_dp1[wave][j],
+                                                  s_dir[wave][j], (s_flg[wave][j] & kDZeroLen) != 0, s_dp1[wave][j],
                                                   s_dp2[wave][j], sc);
-                    // per-camera maximum with the reference's replace/subtract pattern; hypotheses of one
-                    // target camera are contiguous in canonical order
-                    if (cam2 == cur_cam) {
-                        if (sim > cur) { score3D -= cur; score3D += sim; cur = sim; }
-                    } else {
-                        score3D += sim; cur = sim; cur_cam = cam2;
+                    word |= (uint64_t)(sim > 0.0f) << j;
+                }
+                rows[(size_t)i * W + c0 / 64] = word;
+            }
+        }
+    }
+}
+
+// THE CHAIN: one launch per view in ascending camID order, one wave per 2D segment of the view.
+//   presence: a fresh hypothesis always exists; an inverse one exists iff the source view found its match
+//             supported (score3D > 0  <=>  some existing hypothesis of another camera has similarity > 0.5),
+//             which that view's launch recorded as kSlotPositive in the shared slot (line3D.cc:1680)
+//   support:  fresh hypothesis i is positive iff S_i intersects the presence mask
+__global__ __launch_bounds__(256) void k_presence_view(uint32_t g0, uint32_t M, const uint32_t* __restrict__ off,
+                                                       const uint32_t* __restrict__ boff,
+                                                       const DEntry* __restrict__ dents, uint64_t* __restrict__ bits,
+                                                       Slot* __restrict__ slots) {
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t seg = blockIdx.x * 4 + wave;
+    if (seg >= M) return;
+    const uint32_t g = g0 + seg;
+    const uint32_t b = off[g], L = off[g + 1] - b;
+    if (L == 0) return;
+    const uint32_t W = (L + 63) / 64;
+    uint64_t* rows = bits + boff[g];
+    uint64_t* P = rows + (size_t)L * W;
+    for (uint32_t w = 0; w < W; ++w) {
+        const uint32_t j = w * 64 + lane;
+        bool present = false;
+        if (j < L) {
+            const DEntry& d = dents[b + j];
+            present = !(d.flags & kDInverse) || (slots[d.ref].flags & kSlotPositive);
+        }
+        const uint64_t m = __ballot(present);
+        if (lane == 0) P[w] = m;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (uint32_t m0 = 0; m0 < L; m0 += 64) {
+        const uint32_t i = m0 + lane;
+        if (i < L) {
+            const DEntry& d = dents[b + i];
+            if (!(d.flags & kDInverse)) {
+                uint64_t any = 0;
+                for (uint32_t w = 0; w < W; ++w) any |= rows[(size_t)i * W + w] & P[w];
+                if (any) slots[d.ref].flags |= kSlotPositive;
+            }
+        }
+    }
+}
+
+// scores of all views (batched): for every existing hypothesis i walk the existing supporters (S_i & P) in
+// canonical order with the reference's per-camera replace/subtract accumulation (line3D.cc:1255-1274); a zero
+// similarity never changes that accumulation, so visiting only the supporters gives the same float result.
+__global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* __restrict__ off,
+                                                   const uint32_t* __restrict__ boff,
+                                                   const uint32_t* __restrict__ gseg_view,
+                                                   DEntry* __restrict__ dents, const uint64_t* __restrict__ bits,
+                                                   Slot* __restrict__ slots, uint32_t* __restrict__ max_score_bits,
+                                                   SimConst sc) {
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t g = blockIdx.x * 4 + wave;
+    if (g >= G) return;
+    const uint32_t b = off[g], L = off[g + 1] - b;
+    if (L == 0) return;
+    const uint32_t W = (L + 63) / 64;
+    const uint64_t* rows = bits + boff[g];
+    const uint64_t* P = rows + (size_t)L * W;
+    float vmax = 0.0f;
+    for (uint32_t m0 = 0; m0 < L; m0 += 64) {
+        const uint32_t i = m0 + lane;
+        if (i < L) {
+            const bool present = (P[i >> 6] >> (i & 63)) & 1ull;
+            DEntry a = dents[b + i];
+            float score3D = 0.0f, cur = 0.0f;
+            uint32_t cur_cam = kEmpty;
+            if (present) {
+                for (uint32_t w = 0; w < W; ++w) {
+                    uint64_t m = rows[(size_t)i * W + w] & P[w];
+                    while (m) {
+                        const uint32_t j = w * 64 + (uint32_t)__ffsll((long long)m) - 1u;
+                        m &= m - 1;
+                        const DEntry& o = dents[b + j];
+                        const float sim = sim_scoring(a.dir, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
+                                                      o.dir, (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc);
+                        if (o.tgt_view == cur_cam) {
+                            if (sim > cur) { score3D -= cur; score3D += sim; cur = sim; }
+                        } else {
+                            score3D += sim; cur = sim; cur_cam = o.tgt_view;
+                        }
                     }
                 }
             }
-        }
-        if (inrange) {
-            dents[b + pa].score3D = act ? score3D : 0.0f;
-            dents[b + pa].flags = act ? (a.flags | kDPresent) : (a.flags & ~kDPresent);
-            if (act) {
+            dents[b + i].score3D = score3D;
+            dents[b + i].flags = present ? (a.flags | kDPresent) : (a.flags & ~kDPresent);
+            if (present) {
                 if (!(a.flags & kDInverse)) slots[a.ref].score3D = score3D;
                 vmax = fmaxf(vmax, score3D);
             }
@@ -355,7 +422,7 @@ __global__ __launch_bounds__(256) void k_score_view(uint32_t g0, uint32_t M, con
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
-    if (lane == 0 && vmax > 0.0f) atomicMax(max_score_bits, __float_as_uint(vmax));
+    if (lane == 0 && vmax > 0.0f) atomicMax(&max_score_bits[gseg_view[g]], __float_as_uint(vmax));
 }
 
 // ---- post-pass --------------------------------------------------------------------------------------
@@ -631,11 +698,31 @@ hipError_t launch_build_lists_all(uint32_t G, const ViewDev* views, const PairDe
                        vout_off, vout_pairs, off, inv_off, refs, slots, dents);
     return hipGetLastError();
 }
-hipError_t launch_score_view(uint32_t g0, uint32_t M, const uint32_t* off, DEntry* dents, Slot* slots,
-                             uint32_t* max_score_bits, float two_sigA_sqr, float min_sim, hipStream_t st) {
-    if (!M) return hipSuccess;
+hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, hipStream_t st) {
+    if (!G) return hipSuccess;
+    hipLaunchKernelGGL(k_bits_len, dim3((G + 255) / 256), dim3(256), 0, st, G, off, len);
+    return hipGetLastError();
+}
+hipError_t launch_support_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry* dents,
+                              uint64_t* bits, float two_sigA_sqr, float min_sim, hipStream_t st) {
+    if (!G) return hipSuccess;
     SimConst sc{two_sigA_sqr, min_sim};
-    hipLaunchKernelGGL(k_score_view, dim3((M + 3) / 4), dim3(256), 0, st, g0, M, off, dents, slots, max_score_bits, sc);
+    hipLaunchKernelGGL(k_support_all, dim3((G + 3) / 4), dim3(256), 0, st, G, off, boff, dents, bits, sc);
+    return hipGetLastError();
+}
+hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff,
+                                const DEntry* dents, uint64_t* bits, Slot* slots, hipStream_t st) {
+    if (!M) return hipSuccess;
+    hipLaunchKernelGGL(k_presence_view, dim3((M + 3) / 4), dim3(256), 0, st, g0, M, off, boff, dents, bits, slots);
+    return hipGetLastError();
+}
+hipError_t launch_score_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view,
+                            DEntry* dents, const uint64_t* bits, Slot* slots, uint32_t* max_score_bits,
+                            float two_sigA_sqr, float min_sim, hipStream_t st) {
+    if (!G) return hipSuccess;
+    SimConst sc{two_sigA_sqr, min_sim};
+    hipLaunchKernelGGL(k_score_all, dim3((G + 3) / 4), dim3(256), 0, st, G, off, boff, gseg_view, dents, bits, slots,
+                       max_score_bits, sc);
     return hipGetLastError();
 }
 hipError_t launch_filter_all(uint32_t G, const uint32_t* off, const uint32_t* gseg_view, DEntry* dents,

@@ -23,8 +23,14 @@ hipError_t launch_build_lists_all(uint32_t G, const ViewDev*, const PairDesc*, c
                                   const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
                                   const uint32_t* off, const uint32_t* inv_off, const InvRef*, const Slot*, DEntry*,
                                   hipStream_t);
-hipError_t launch_score_view(uint32_t g0, uint32_t M, const uint32_t* off, DEntry*, Slot*, uint32_t* max_score_bits,
-                             float two_sigA_sqr, float min_sim, hipStream_t);
+hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, hipStream_t);
+hipError_t launch_support_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry*, uint64_t* bits,
+                              float two_sigA_sqr, float min_sim, hipStream_t);
+hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff, const DEntry*,
+                                uint64_t* bits, Slot*, hipStream_t);
+hipError_t launch_score_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view, DEntry*,
+                            const uint64_t* bits, Slot*, uint32_t* max_score_bits, float two_sigA_sqr, float min_sim,
+                            hipStream_t);
 hipError_t launch_filter_all(uint32_t G, const uint32_t* off, const uint32_t* gseg_view, DEntry*,
                              const uint32_t* max_score_bits, uint32_t* surv_cnt, uint32_t* has_best,
                              uint32_t* best_pos, hipStream_t);
@@ -87,6 +93,8 @@ struct l3d_ctx {
     DevBuf<uint32_t> d_seg_base, d_gseg_view, d_cnt, d_off, d_cur, d_scan_tmp, d_scal, d_max_score;
     DevBuf<uint32_t> d_surv_cnt, d_has_best, d_best_pos, d_surv_off, d_hyp_off, d_surv_tg, d_surv_sg;
     DevBuf<InvRef> d_refs;
+    DevBuf<uint64_t> d_bits;
+    DevBuf<uint32_t> d_bits_len, d_boff;
     DevBuf<uint32_t> d_cnt_inv, d_inv_off, d_vout_pairs, d_vout_off;
     std::vector<uint32_t> vout_off;
     DevBuf<DEntry> d_dents;
@@ -176,9 +184,8 @@ void fundamental(const HostView& s, const HostView& t, double F[9]) {
 int upload_views(l3d_ctx& c) {
     const size_t V = c.order.size();
     L3D_HIP_CHECK(c.d_views.reserve(V));
-    L3D_HIP_CHECK(c.d_consts.reserve(V * 12));
     std::vector<ViewDev> hv(V);
-    std::vector<double> consts(V * 12);
+    uint32_t max_M = 0;
     for (size_t i = 0; i < V; ++i) {
         HostView& v = *c.order[i];
         ViewDev& d = hv[i];
@@ -187,17 +194,11 @@ int upload_views(l3d_ctx& c) {
         d.seg4 = v.d_seg4.p; d.segf = v.d_segf.p; d.segx = v.d_segx.p;
         d.M = v.M; d.cam = v.cam; d.k = v.k;
         d.cx = 0.5f * (float)v.width; d.cy = 0.5f * (float)v.height; d.pad = 0;
-        std::memcpy(&consts[12 * i], v.RtKinv.m, 72);
-        consts[12 * i + 9] = v.C.x; consts[12 * i + 10] = v.C.y; consts[12 * i + 11] = v.C.z;
+        max_M = std::max(max_M, v.M);
     }
     L3D_HIP_CHECK(hipMemcpyAsync(c.d_views.p, hv.data(), V * sizeof(ViewDev), hipMemcpyHostToDevice, c.stream));
-    L3D_HIP_CHECK(hipMemcpyAsync(c.d_consts.p, consts.data(), consts.size() * 8, hipMemcpyHostToDevice, c.stream));
-    L3D_HIP_CHECK(hipStreamSynchronize(c.stream));  // host staging vectors go out of scope
-    for (size_t i = 0; i < V; ++i) {
-        HostView& v = *c.order[i];
-        L3D_HIP_CHECK(launch_prep_view(v.d_seg4.p, v.M, c.d_consts.p + 12 * i, v.d_segx.p, v.d_segf.p,
-                                       0.5f * (float)v.width, 0.5f * (float)v.height, c.stream));
-    }
+    L3D_HIP_CHECK(hipStreamSynchronize(c.stream));  // host staging vector goes out of scope
+    L3D_HIP_CHECK(launch_prep_views(c.d_views.p, (uint32_t)V, max_M, c.stream));
     return L3D_OK;
 }
 
@@ -237,7 +238,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_seg_base.release(); c->d_gseg_view.release(); c->d_cnt.release(); c->d_off.release(); c->d_cur.release();
     c->d_scan_tmp.release(); c->d_scal.release(); c->d_max_score.release(); c->d_surv_cnt.release();
     c->d_has_best.release(); c->d_best_pos.release(); c->d_surv_off.release(); c->d_hyp_off.release();
-    c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_cnt_inv.release();
+    c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_bits.release(); c->d_bits_len.release(); c->d_boff.release(); c->d_cnt_inv.release();
     c->d_inv_off.release(); c->d_vout_pairs.release(); c->d_vout_off.release(); c->d_dents.release(); c->d_surv.release();
     c->d_hyp_of_seg.release(); c->d_depths.release(); c->d_medians.release(); c->d_hyps.release();
     c->d_vaff.release(); c->d_simv.release(); c->d_msdl.release(); c->d_ca.release(); c->d_cb.release();
@@ -473,7 +474,7 @@ int l3d_match_finish(l3d_ctx* c) {
     if (2 * c->n_slots >= (1ull << 32)) return fail(L3D_ERR_LIMIT, "more than 2^32 hypotheses");
     L3D_HIP_CHECK(c->d_seg_base.reserve(V + 1)); L3D_HIP_CHECK(c->d_gseg_view.reserve(G + 1));
     L3D_HIP_CHECK(c->d_cnt.reserve(G + 1)); L3D_HIP_CHECK(c->d_off.reserve(G + 1)); L3D_HIP_CHECK(c->d_cur.reserve(G + 1));
-    L3D_HIP_CHECK(c->d_scan_tmp.reserve(G / 4096 + 1024)); L3D_HIP_CHECK(c->d_scal.reserve(8));
+    L3D_HIP_CHECK(c->d_scan_tmp.reserve(G / 4096 + 1024)); L3D_HIP_CHECK(c->d_scal.reserve(16));
     L3D_HIP_CHECK(c->d_max_score.reserve(V + 1));
     L3D_HIP_CHECK(c->d_surv_cnt.reserve(G + 1)); L3D_HIP_CHECK(c->d_has_best.reserve(G + 1));
     L3D_HIP_CHECK(c->d_best_pos.reserve(G + 1)); L3D_HIP_CHECK(c->d_surv_off.reserve(G + 1));
@@ -500,27 +501,36 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(hipMemsetAsync(c->d_cnt_inv.p, 0, ((size_t)G + 1) * 4, st));
     L3D_HIP_CHECK(hipMemsetAsync(c->d_cur.p, 0, ((size_t)G + 1) * 4, st));
     L3D_HIP_CHECK(hipMemsetAsync(c->d_max_score.p, 0, ((size_t)V + 1) * 4, st));
-    L3D_HIP_CHECK(hipMemsetAsync(c->d_scal.p, 0, 8 * 4, st));
+    L3D_HIP_CHECK(hipMemsetAsync(c->d_scal.p, 0, 16 * 4, st));
     // ---- pre-pass: orientation flags, list offsets, transposed index of potential inverse matches ----
     L3D_HIP_CHECK(launch_orient_all(c->d_views.p, c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p,
                                     c->d_cnt.p, c->d_cnt_inv.p, st));
     L3D_HIP_CHECK(launch_scan(c->d_cnt.p, G, c->d_off.p, c->d_scan_tmp.p, c->d_scal.p + 0, st));
     L3D_HIP_CHECK(launch_scan(c->d_cnt_inv.p, G, c->d_inv_off.p, c->d_scan_tmp.p, c->d_scal.p + 5, st));
-    uint32_t tot[6] = {0, 0, 0, 0, 0, 0};
-    L3D_HIP_CHECK(hipMemcpyAsync(tot, c->d_scal.p, 6 * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(c->d_bits_len.reserve(G + 1)); L3D_HIP_CHECK(c->d_boff.reserve(G + 1));
+    L3D_HIP_CHECK(launch_bits_len(G, c->d_off.p, c->d_bits_len.p, st));
+    L3D_HIP_CHECK(launch_scan(c->d_bits_len.p, G, c->d_boff.p, c->d_scan_tmp.p, c->d_scal.p + 6, st));
+    uint32_t tot[7] = {0, 0, 0, 0, 0, 0, 0};
+    L3D_HIP_CHECK(hipMemcpyAsync(tot, c->d_scal.p, 7 * 4, hipMemcpyDeviceToHost, st));
     L3D_HIP_CHECK(hipStreamSynchronize(st));   // also covers the local `vout`
-    const uint32_t n_ents = c->n_ents = tot[0], n_inv = tot[5];
+    const uint32_t n_ents = c->n_ents = tot[0], n_inv = tot[5], n_words = tot[6];
     L3D_HIP_CHECK(c->d_dents.reserve(std::max<uint32_t>(n_ents, 1)));
     L3D_HIP_CHECK(c->d_refs.reserve(std::max<uint32_t>(n_inv, 1)));
+    L3D_HIP_CHECK(c->d_bits.reserve(std::max<uint32_t>(n_words, 1)));
     L3D_HIP_CHECK(launch_inv_fill(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_inv_off.p,
                                   c->d_cur.p, c->d_refs.p, st));
     L3D_HIP_CHECK(launch_build_lists_all(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p,
                                          c->d_vout_off.p, c->d_vout_pairs.p, c->d_off.p, c->d_inv_off.p, c->d_refs.p,
                                          c->d_slots.p, c->d_dents.p, st));
-    // ---- chain: one scoring launch per view, ascending camID ----
+    // all L^2 similarity decisions of all segments (chain independent)
+    L3D_HIP_CHECK(launch_support_all(G, c->d_off.p, c->d_boff.p, c->d_dents.p, c->d_bits.p, c->two_sigA_sqr, 0.5f, st));
+    // ---- chain: one bit-propagation launch per view, ascending camID ----
     for (uint32_t vi = 0; vi < V; ++vi)
-        L3D_HIP_CHECK(launch_score_view(c->seg_base[vi], c->order[vi]->M, c->d_off.p, c->d_dents.p, c->d_slots.p,
-                                        c->d_max_score.p + vi, c->two_sigA_sqr, 0.5f, st));
+        L3D_HIP_CHECK(launch_presence_view(c->seg_base[vi], c->order[vi]->M, c->d_off.p, c->d_boff.p, c->d_dents.p,
+                                           c->d_bits.p, c->d_slots.p, st));
+    // scores of all views
+    L3D_HIP_CHECK(launch_score_all(G, c->d_off.p, c->d_boff.p, c->d_gseg_view.p, c->d_dents.p, c->d_bits.p,
+                                   c->d_slots.p, c->d_max_score.p, c->two_sigA_sqr, 0.5f, st));
     // ---- post-pass: filterMatches for all views ----
     L3D_HIP_CHECK(launch_filter_all(G, c->d_off.p, c->d_gseg_view.p, c->d_dents.p, c->d_max_score.p, c->d_surv_cnt.p,
                                     c->d_has_best.p, c->d_best_pos.p, st));
@@ -807,9 +817,6 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
             hv[i].M = M[i]; hv[i].cam = (uint32_t)i; hv[i].k = 0;
             hv[i].cx = 0.5f * (float)width; hv[i].cy = 0.5f * (float)height; hv[i].pad = 0;
         }
-        L3D_HIP_CHECK(hipMemcpy(consts.p, hc, sizeof(hc), hipMemcpyHostToDevice));
-        for (int i = 0; i < 2; ++i)
-            L3D_HIP_CHECK(launch_prep_view(seg4[i].p, M[i], consts.p + 12 * i, segx[i].p, segf[i].p, hv[i].cx, hv[i].cy, 0));
         PairDesc pd;
         std::memcpy(pd.F, F, 72);
         pd.src = 0; pd.tgt = 1; pd.Ms = Ms; pd.Mt = Mt; pd.K = (uint32_t)kNN; pd.row_off = 0; pd.slot_off = 0;
@@ -819,6 +826,7 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         L3D_HIP_CHECK(dv.reserve(2)); L3D_HIP_CHECK(dp.reserve(1)); L3D_HIP_CHECK(dw.reserve(work.size()));
         L3D_HIP_CHECK(ds.reserve((size_t)Ms * pd.K));
         L3D_HIP_CHECK(hipMemcpy(dv.p, hv, sizeof(hv), hipMemcpyHostToDevice));
+        L3D_HIP_CHECK(launch_prep_views(dv.p, 2, std::max(Ms, Mt), 0));
         L3D_HIP_CHECK(hipMemcpy(dp.p, &pd, sizeof(pd), hipMemcpyHostToDevice));
         L3D_HIP_CHECK(hipMemcpy(dw.p, work.data(), work.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
         const float thr = std::fmin(std::fabs(epi_overlap), 0.99f);

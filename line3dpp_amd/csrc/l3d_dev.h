@@ -65,6 +65,7 @@ struct __attribute__((aligned(16))) Slot {
 static_assert(sizeof(Slot) == 32, "slot is 32 bytes");
 constexpr uint32_t kSlotAlive = 1u;     // survived the src view's orientation filter
 constexpr uint32_t kSlotInvAlive = 2u;  // inverse (tgt-view) copy survived the tgt view's orientation filter
+constexpr uint32_t kSlotPositive = 4u;  // the source view scored the match > 0 (so its inverse copy exists)
 
 // reference Match (commons.h:186-203)
 struct Match {

@@ -14,7 +14,6 @@ size_t match_lds_bytes(int mode, uint32_t K);
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,
                               const WorkItem* work, uint32_t nwork, uint32_t maxK, Slot* slots,
                               uint32_t* row_counts, float thr, hipStream_t stream);
-hipError_t launch_prep_view(const float4* seg4, uint32_t M, const double* consts_dev, SegX* segx, SegF* segf,
-                            float cx, float cy, hipStream_t stream);
+hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, hipStream_t stream);
 
 }  // namespace l3d
