@@ -278,15 +278,19 @@ __global__ void k_bits_len(uint32_t G, const uint32_t* __restrict__ off, uint32_
     len[g] = L ? (L + 1) * ((L + 63) / 64) : 0u;
 }
 
-// One wave per 2D segment (any view): all L x L similarity decisions, lanes own hypotheses i (strided by 64),
-// the inner loop walks chunks of 64 hypotheses j staged in LDS; each (i, chunk) yields one 64-bit word.
+// One wave per 2D segment (any view): the similarity decisions of the segment's hypotheses.
+// similarityForScoring(i, j) can only exceed 0.5 if |dp1_i - dp1_j| <= sqrt(0.72 * reg1_i) (first early-out of
+// sim_scoring), so the hypotheses are rank-sorted by dp1 in LDS and hypothesis i evaluates only the
+// contiguous window of candidates inside that radius (found by binary search) instead of all L: O(L^2) cheap
+// compares for the sort + O(L * window) evaluations.  Lists longer than kSortCap take the all-pairs loop.
+constexpr uint32_t kSortCap = 1024;
 __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t* __restrict__ off,
                                                      const uint32_t* __restrict__ boff,
                                                      const DEntry* __restrict__ dents, uint64_t* __restrict__ bits,
                                                      SimConst sc) {
-    __shared__ double s_dir[4][kScoreChunk][3];
-    __shared__ float s_dp1[4][kScoreChunk], s_dp2[4][kScoreChunk];
-    __shared__ uint32_t s_cam[4][kScoreChunk], s_flg[4][kScoreChunk];
+    __shared__ float s_key[4][kSortCap];      // dp1 in canonical order, then reused: dp1 in sorted order
+    __shared__ float s_sorted[4][kSortCap];
+    __shared__ uint16_t s_sidx[4][kSortCap];  // canonical index of sorted position
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t g = blockIdx.x * 4 + wave;
     if (g >= G) return;
@@ -294,33 +298,73 @@ __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t*
     if (L == 0) return;
     const uint32_t W = (L + 63) / 64;
     uint64_t* rows = bits + boff[g];
+    if (L <= kSortCap) {
+        for (uint32_t m0 = 0; m0 < L; m0 += 64)
+            if (m0 + lane < L) s_key[wave][m0 + lane] = dents[b + m0 + lane].dp1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t m0 = 0; m0 < L; m0 += 64) {
+            const uint32_t i = m0 + lane;
+            if (i < L) {
+                const float k = s_key[wave][i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < L; ++j) {
+                    const float o = s_key[wave][j];
+                    rank += (o < k || (o == k && j < i)) ? 1u : 0u;
+                }
+                s_sorted[wave][rank] = k;
+                s_sidx[wave][rank] = (uint16_t)i;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t m0 = 0; m0 < L; m0 += 64) {
+            const uint32_t i = m0 + lane;
+            if (i < L) {
+                const DEntry a = dents[b + i];
+                for (uint32_t w = 0; w < W; ++w) rows[(size_t)i * W + w] = 0ull;
+                // window of candidates: |dp1_j - dp1_i| <= r  (r padded against float rounding)
+                float r = sqrtf(0.72f * a.reg1) * 1.0001f + 1e-30f;
+                uint32_t lo = 0, hi = L;
+                if (r < 1e30f) {   // also false for NaN: then the whole list is the window
+                    const float kl = a.dp1 - r, kh = a.dp1 + r;
+                    uint32_t x = 0, y = L;          // first position with key >= kl
+                    while (x < y) { const uint32_t m = (x + y) >> 1; if (s_sorted[wave][m] < kl) x = m + 1; else y = m; }
+                    lo = x;
+                    y = L;                          // first position with key > kh
+                    while (x < y) { const uint32_t m = (x + y) >> 1; if (s_sorted[wave][m] <= kh) x = m + 1; else y = m; }
+                    hi = x;
+                }
+                for (uint32_t p = lo; p < hi; ++p) {
+                    const uint32_t j = s_sidx[wave][p];
+                    const DEntry& o = dents[b + j];
+                    if (o.tgt_view == a.tgt_view) continue;
+                    const float sim = sim_scoring(a.dir, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
+                                                  o.dir, (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc);
+                    if (sim > 0.0f) rows[(size_t)i * W + (j >> 6)] |= 1ull << (j & 63);
+                }
+            }
+        }
+        return;
+    }
+    // ---- all-pairs loop for very long lists ----
     for (uint32_t m0 = 0; m0 < L; m0 += 64) {
         const uint32_t i = m0 + lane;
-        const bool act = i < L;
-        DEntry a;
-        if (act) a = dents[b + i];
-        for (uint32_t c0 = 0; c0 < L; c0 += kScoreChunk) {
-            const uint32_t cn = min((uint32_t)kScoreChunk, L - c0);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < cn) {
-                const DEntry& o = dents[b + c0 + lane];
-                s_dir[wave][lane][0] = o.dir[0]; s_dir[wave][lane][1] = o.dir[1]; s_dir[wave][lane][2] = o.dir[2];
-                s_dp1[wave][lane] = o.dp1; s_dp2[wave][lane] = o.dp2;
-                s_cam[wave][lane] = o.tgt_view; s_flg[wave][lane] = o.flags;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (act) {
+        if (i < L) {
+            const DEntry a = dents[b + i];
+            for (uint32_t w = 0; w < W; ++w) {
                 uint64_t word = 0;
-                for (uint32_t j = 0; j < cn; ++j) {
-                    if (s_cam[wave][j] == a.tgt_view) continue;
+                const uint32_t jn = min(64u, L - w * 64);
+                for (uint32_t jj = 0; jj < jn; ++jj) {
+                    const DEntry& o = dents[b + w * 64 + jj];
+                    if (o.tgt_view == a.tgt_view) continue;
                     const float sim = sim_scoring(a.dir, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
-                                                  s_dir[wave][j], (s_flg[wave][j] & kDZeroLen) != 0, s_dp1[wave][j],
-                                                  s_dp2[wave][j], sc);
-                    word |= (uint64_t)(sim > 0.0f) << j;
+                                                  o.dir, (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc);
+                    word |= (uint64_t)(sim > 0.0f) << jj;
                 }
-                rows[(size_t)i * W + c0 / 64] = word;
+                rows[(size_t)i * W + w] = word;
             }
         }
     }
