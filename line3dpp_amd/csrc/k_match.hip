@@ -280,7 +280,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
         uint32_t rank = 0;
         for (uint32_t i = 0; i < c; ++i) rank += better(ov[i], ix[i], oj, xj) ? 1u : 0u;
         PairResult res{};
-        exact_depths(sx, vt.segx[xj], vs.C, vt.C, res);
+        const SegX tx = vt.segx[xj];
+        exact_depths(sx, tx, vs.C, vt.C, res);
         Slot o;
         o.tgt_seg = xj; o.overlap = oj;
         o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;

@@ -38,33 +38,6 @@ namespace {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
-// Segment3D(C + r1*d1, C + r2*d2): view.cc:356-371 + segment3D.h:47-66
-struct Seg3 {
-    d3 P1, P2, dir;
-    float length;
-};
-__device__ __forceinline__ Seg3 unproject(const double* C, const double* r1, const double* r2, float d1, float d2) {
-    const d3 c{C[0], C[1], C[2]};
-    const d3 a = c + d3{r1[0], r1[1], r1[2]} * (double)d1;
-    const d3 b = c + d3{r2[0], r2[1], r2[2]} * (double)d2;
-    Seg3 s;
-    s.length = (float)norm(a - b);
-    if (s.length > kEps) {
-        s.P1 = a; s.P2 = b; s.dir = normalized(b - a);
-    } else {
-        s.P1 = d3{0, 0, 0}; s.P2 = d3{0, 0, 0}; s.dir = d3{0, 0, 0}; s.length = 0.0f;
-    }
-    return s;
-}
-
-// checkMatchOrientation: line3D.cc:831-839, view.cc:466-484
-__device__ __forceinline__ bool orientation_ok(const double* C, const SegX& sx, float d1, float d2) {
-    const Seg3 s = unproject(C, sx.r1, sx.r2, d1, d2);
-    const double dp = dot(d3{sx.rm[0], sx.rm[1], sx.rm[2]}, s.dir);
-    const double ang = acos(fmin(fmax(dp, -1.0), 1.0));
-    return ang > (double)kPi_1_32 && ang < (double)kPi_31_32;
-}
-
 }  // namespace
 
 // ---- pre-pass ---------------------------------------------------------------------------------------
@@ -99,6 +72,24 @@ __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* 
     }
     sp->flags = flags;
     sp->score3D = 0.0f;
+}
+
+// counting pass when the orientation flags were already written by the matching kernel's epilogue (kNN > 0)
+__global__ void k_count_all(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ seg_base,
+                            const Slot* __restrict__ slots, uint32_t* __restrict__ cnt_all,
+                            uint32_t* __restrict__ cnt_inv) {
+    const PairDesc& pd = pairs[blockIdx.y];
+    const uint64_t n = (uint64_t)pd.Ms * pd.K;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2 tf = *(const uint2*)((const char*)(slots + pd.slot_off + i) + 0);   // tgt_seg
+    const uint32_t flags = slots[pd.slot_off + i].flags;
+    if (tf.x == kEmpty || !(flags & kSlotAlive)) return;
+    atomicAdd(&cnt_all[seg_base[pd.src] + (uint32_t)(i / pd.K)], 1u);
+    if (flags & kSlotInvAlive) {
+        atomicAdd(&cnt_all[seg_base[pd.tgt] + tf.x], 1u);
+        atomicAdd(&cnt_inv[seg_base[pd.tgt] + tf.x], 1u);
+    }
 }
 
 // transposed index of the potential inverse hypotheses: which slots point at global segment g
@@ -158,7 +149,8 @@ __global__ __launch_bounds__(256) void k_build_lists_all(uint32_t G, const ViewD
                                                          const uint32_t* __restrict__ off,
                                                          const uint32_t* __restrict__ inv_off,
                                                          const InvRef* __restrict__ refs,
-                                                         const Slot* __restrict__ slots, DEntry* __restrict__ dents) {
+                                                         const Slot* __restrict__ slots, DEntry* __restrict__ dents,
+                                                         uint32_t* __restrict__ eref) {
     __shared__ uint64_t s_key[4][kKeyCap];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t g = blockIdx.x * 4 + wave;
@@ -231,6 +223,7 @@ __global__ __launch_bounds__(256) void k_build_lists_all(uint32_t G, const ViewD
         if (m0 + lane < L) {
             DEntry& d = dents[b + m0 + lane];
             d = make_dentry(v, views[d.tgt_view], sx, d.dp1, d.dp2, d.ref, d.tgt_view, d.pair, (d.flags & kDInverse) != 0);
+            eref[b + m0 + lane] = (uint32_t)d.ref;   // slot index; the first n_inv entries of a list are the inverse ones
         }
     }
 }
@@ -373,12 +366,15 @@ __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t*
 // THE CHAIN: one launch per view in ascending camID order, one wave per 2D segment of the view.
 //   presence: a fresh hypothesis always exists; an inverse one exists iff the source view found its match
 //             supported (score3D > 0  <=>  some existing hypothesis of another camera has similarity > 0.5),
-//             which that view's launch recorded as kSlotPositive in the shared slot (line3D.cc:1680)
+//             which that view's launch recorded in positive[slot] (line3D.cc:1680)
 //   support:  fresh hypothesis i is positive iff S_i intersects the presence mask
+constexpr uint32_t kPCap = 64;   // presence-mask words kept in LDS per wave (lists up to 4096 hypotheses)
 __global__ __launch_bounds__(256) void k_presence_view(uint32_t g0, uint32_t M, const uint32_t* __restrict__ off,
                                                        const uint32_t* __restrict__ boff,
-                                                       const DEntry* __restrict__ dents, uint64_t* __restrict__ bits,
-                                                       Slot* __restrict__ slots) {
+                                                       const uint32_t* __restrict__ inv_off,
+                                                       const uint32_t* __restrict__ eref,
+                                                       uint64_t* __restrict__ bits, uint8_t* __restrict__ positive) {
+    __shared__ uint64_t s_P[4][kPCap];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t seg = blockIdx.x * 4 + wave;
     if (seg >= M) return;
@@ -386,31 +382,24 @@ __global__ __launch_bounds__(256) void k_presence_view(uint32_t g0, uint32_t M, 
     const uint32_t b = off[g], L = off[g + 1] - b;
     if (L == 0) return;
     const uint32_t W = (L + 63) / 64;
+    const uint32_t n_inv = inv_off[g + 1] - inv_off[g];   // the inverse hypotheses come first in canonical order
     uint64_t* rows = bits + boff[g];
     uint64_t* P = rows + (size_t)L * W;
+    const bool in_lds = W <= kPCap;
     for (uint32_t w = 0; w < W; ++w) {
         const uint32_t j = w * 64 + lane;
-        bool present = false;
-        if (j < L) {
-            const DEntry& d = dents[b + j];
-            present = !(d.flags & kDInverse) || (slots[d.ref].flags & kSlotPositive);
-        }
+        const bool present = j < L && (j >= n_inv || positive[eref[b + j]] != 0);
         const uint64_t m = __ballot(present);
-        if (lane == 0) P[w] = m;
+        if (lane == 0) { P[w] = m; if (in_lds) s_P[wave][w] = m; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (uint32_t m0 = 0; m0 < L; m0 += 64) {
-        const uint32_t i = m0 + lane;
-        if (i < L) {
-            const DEntry& d = dents[b + i];
-            if (!(d.flags & kDInverse)) {
-                uint64_t any = 0;
-                for (uint32_t w = 0; w < W; ++w) any |= rows[(size_t)i * W + w] & P[w];
-                if (any) slots[d.ref].flags |= kSlotPositive;
-            }
-        }
+    for (uint32_t i = n_inv + lane; i < L; i += 64) {
+        uint64_t any = 0;
+        if (in_lds) for (uint32_t w = 0; w < W; ++w) any |= rows[(size_t)i * W + w] & s_P[wave][w];
+        else for (uint32_t w = 0; w < W; ++w) any |= rows[(size_t)i * W + w] & P[w];
+        if (any) positive[eref[b + i]] = 1;
     }
 }
 
@@ -726,6 +715,13 @@ hipError_t launch_orient_all(const ViewDev* views, const PairDesc* pairs, uint32
                        pairs, seg_base, slots, cnt_all, cnt_inv);
     return hipGetLastError();
 }
+hipError_t launch_count_all(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
+                            const Slot* slots, uint32_t* cnt_all, uint32_t* cnt_inv, hipStream_t st) {
+    if (!n_pairs || !max_slots) return hipSuccess;
+    hipLaunchKernelGGL(k_count_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, pairs,
+                       seg_base, slots, cnt_all, cnt_inv);
+    return hipGetLastError();
+}
 hipError_t launch_inv_fill(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
                            const Slot* slots, const uint32_t* inv_off, uint32_t* cur, InvRef* refs, hipStream_t st) {
     if (!n_pairs || !max_slots) return hipSuccess;
@@ -736,10 +732,10 @@ hipError_t launch_inv_fill(const PairDesc* pairs, uint32_t n_pairs, uint64_t max
 hipError_t launch_build_lists_all(uint32_t G, const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base,
                                   const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
                                   const uint32_t* off, const uint32_t* inv_off, const InvRef* refs, const Slot* slots,
-                                  DEntry* dents, hipStream_t st) {
+                                  DEntry* dents, uint32_t* eref, hipStream_t st) {
     if (!G) return hipSuccess;
     hipLaunchKernelGGL(k_build_lists_all, dim3((G + 3) / 4), dim3(256), 0, st, G, views, pairs, seg_base, gseg_view,
-                       vout_off, vout_pairs, off, inv_off, refs, slots, dents);
+                       vout_off, vout_pairs, off, inv_off, refs, slots, dents, eref);
     return hipGetLastError();
 }
 hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, hipStream_t st) {
@@ -755,9 +751,11 @@ hipError_t launch_support_all(uint32_t G, const uint32_t* off, const uint32_t* b
     return hipGetLastError();
 }
 hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff,
-                                const DEntry* dents, uint64_t* bits, Slot* slots, hipStream_t st) {
+                                const uint32_t* inv_off, const uint32_t* eref, uint64_t* bits, uint8_t* positive,
+                                hipStream_t st) {
     if (!M) return hipSuccess;
-    hipLaunchKernelGGL(k_presence_view, dim3((M + 3) / 4), dim3(256), 0, st, g0, M, off, boff, dents, bits, slots);
+    hipLaunchKernelGGL(k_presence_view, dim3((M + 3) / 4), dim3(256), 0, st, g0, M, off, boff, inv_off, eref, bits,
+                       positive);
     return hipGetLastError();
 }
 hipError_t launch_score_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view,

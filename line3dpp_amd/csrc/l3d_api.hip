@@ -17,17 +17,20 @@ void set_error(const std::string& s) { g_err = s; }
 hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, uint32_t* total, hipStream_t);
 hipError_t launch_orient_all(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
                              const uint32_t* seg_base, Slot*, uint32_t* cnt_all, uint32_t* cnt_inv, hipStream_t);
+hipError_t launch_count_all(const PairDesc*, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
+                            const Slot*, uint32_t* cnt_all, uint32_t* cnt_inv, hipStream_t);
 hipError_t launch_inv_fill(const PairDesc*, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
                            const Slot*, const uint32_t* inv_off, uint32_t* cur, InvRef*, hipStream_t);
 hipError_t launch_build_lists_all(uint32_t G, const ViewDev*, const PairDesc*, const uint32_t* seg_base,
                                   const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
                                   const uint32_t* off, const uint32_t* inv_off, const InvRef*, const Slot*, DEntry*,
-                                  hipStream_t);
+                                  uint32_t* eref, hipStream_t);
 hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, hipStream_t);
 hipError_t launch_support_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry*, uint64_t* bits,
                               float two_sigA_sqr, float min_sim, hipStream_t);
-hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff, const DEntry*,
-                                uint64_t* bits, Slot*, hipStream_t);
+hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff,
+                                const uint32_t* inv_off, const uint32_t* eref, uint64_t* bits, uint8_t* positive,
+                                hipStream_t);
 hipError_t launch_score_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view, DEntry*,
                             const uint64_t* bits, Slot*, uint32_t* max_score_bits, float two_sigA_sqr, float min_sim,
                             hipStream_t);
@@ -94,6 +97,8 @@ struct l3d_ctx {
     DevBuf<uint32_t> d_surv_cnt, d_has_best, d_best_pos, d_surv_off, d_hyp_off, d_surv_tg, d_surv_sg;
     DevBuf<InvRef> d_refs;
     DevBuf<uint64_t> d_bits;
+    DevBuf<uint32_t> d_eref;
+    DevBuf<uint8_t> d_positive;
     DevBuf<uint32_t> d_bits_len, d_boff;
     DevBuf<uint32_t> d_cnt_inv, d_inv_off, d_vout_pairs, d_vout_off;
     std::vector<uint32_t> vout_off;
@@ -238,7 +243,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_seg_base.release(); c->d_gseg_view.release(); c->d_cnt.release(); c->d_off.release(); c->d_cur.release();
     c->d_scan_tmp.release(); c->d_scal.release(); c->d_max_score.release(); c->d_surv_cnt.release();
     c->d_has_best.release(); c->d_best_pos.release(); c->d_surv_off.release(); c->d_hyp_off.release();
-    c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_bits.release(); c->d_bits_len.release(); c->d_boff.release(); c->d_cnt_inv.release();
+    c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_bits.release(); c->d_eref.release(); c->d_positive.release(); c->d_bits_len.release(); c->d_boff.release(); c->d_cnt_inv.release();
     c->d_inv_off.release(); c->d_vout_pairs.release(); c->d_vout_off.release(); c->d_dents.release(); c->d_surv.release();
     c->d_hyp_of_seg.release(); c->d_depths.release(); c->d_medians.release(); c->d_hyps.release();
     c->d_vaff.release(); c->d_simv.release(); c->d_msdl.release(); c->d_ca.release(); c->d_cb.release();
@@ -517,17 +522,20 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_dents.reserve(std::max<uint32_t>(n_ents, 1)));
     L3D_HIP_CHECK(c->d_refs.reserve(std::max<uint32_t>(n_inv, 1)));
     L3D_HIP_CHECK(c->d_bits.reserve(std::max<uint32_t>(n_words, 1)));
+    L3D_HIP_CHECK(c->d_eref.reserve(std::max<uint32_t>(n_ents, 1)));
+    L3D_HIP_CHECK(c->d_positive.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    L3D_HIP_CHECK(hipMemsetAsync(c->d_positive.p, 0, std::max<uint64_t>(c->n_slots, 1), st));
     L3D_HIP_CHECK(launch_inv_fill(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_inv_off.p,
                                   c->d_cur.p, c->d_refs.p, st));
     L3D_HIP_CHECK(launch_build_lists_all(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p,
                                          c->d_vout_off.p, c->d_vout_pairs.p, c->d_off.p, c->d_inv_off.p, c->d_refs.p,
-                                         c->d_slots.p, c->d_dents.p, st));
+                                         c->d_slots.p, c->d_dents.p, c->d_eref.p, st));
     // all L^2 similarity decisions of all segments (chain independent)
     L3D_HIP_CHECK(launch_support_all(G, c->d_off.p, c->d_boff.p, c->d_dents.p, c->d_bits.p, c->two_sigA_sqr, 0.5f, st));
     // ---- chain: one bit-propagation launch per view, ascending camID ----
     for (uint32_t vi = 0; vi < V; ++vi)
-        L3D_HIP_CHECK(launch_presence_view(c->seg_base[vi], c->order[vi]->M, c->d_off.p, c->d_boff.p, c->d_dents.p,
-                                           c->d_bits.p, c->d_slots.p, st));
+        L3D_HIP_CHECK(launch_presence_view(c->seg_base[vi], c->order[vi]->M, c->d_off.p, c->d_boff.p, c->d_inv_off.p,
+                                           c->d_eref.p, c->d_bits.p, c->d_positive.p, st));
     // scores of all views
     L3D_HIP_CHECK(launch_score_all(G, c->d_off.p, c->d_boff.p, c->d_gseg_view.p, c->d_dents.p, c->d_bits.p,
                                    c->d_slots.p, c->d_max_score.p, c->two_sigA_sqr, 0.5f, st));

@@ -65,7 +65,6 @@ struct __attribute__((aligned(16))) Slot {
 static_assert(sizeof(Slot) == 32, "slot is 32 bytes");
 constexpr uint32_t kSlotAlive = 1u;     // survived the src view's orientation filter
 constexpr uint32_t kSlotInvAlive = 2u;  // inverse (tgt-view) copy survived the tgt view's orientation filter
-constexpr uint32_t kSlotPositive = 4u;  // the source view scored the match > 0 (so its inverse copy exists)
 
 // reference Match (commons.h:186-203)
 struct Match {
@@ -255,6 +254,34 @@ L3D_HD bool exact_pair(const double* F, const float4& s, const float4& t, const 
     out.overlap = ov;
     return exact_depths(sx, tx, Cs, Ct, out);
 }
+
+// Segment3D(C + r1*d1, C + r2*d2): view.cc:356-371 + segment3D.h:47-66
+struct Seg3 {
+    d3 P1, P2, dir;
+    float length;
+};
+L3D_HD Seg3 unproject(const double* C, const double* r1, const double* r2, float d1, float d2) {
+    const d3 c{C[0], C[1], C[2]};
+    const d3 a = c + d3{r1[0], r1[1], r1[2]} * (double)d1;
+    const d3 b = c + d3{r2[0], r2[1], r2[2]} * (double)d2;
+    Seg3 s;
+    s.length = (float)norm(a - b);
+    if (s.length > kEps) {
+        s.P1 = a; s.P2 = b; s.dir = normalized(b - a);
+    } else {
+        s.P1 = d3{0, 0, 0}; s.P2 = d3{0, 0, 0}; s.dir = d3{0, 0, 0}; s.length = 0.0f;
+    }
+    return s;
+}
+
+// checkMatchOrientation: line3D.cc:831-839, view.cc:466-484
+L3D_HD bool orientation_ok(const double* C, const SegX& sx, float d1, float d2) {
+    const Seg3 s = unproject(C, sx.r1, sx.r2, d1, d2);
+    const double dp = dot(d3{sx.rm[0], sx.rm[1], sx.rm[2]}, s.dir);
+    const double ang = acos(fmin(fmax(dp, -1.0), 1.0));
+    return ang > (double)kPi_1_32 && ang < (double)kPi_31_32;
+}
+
 
 // (overlap desc, tgt asc) total order used for the kNN selection
 L3D_HD bool better(float ova, uint32_t ia, float ovb, uint32_t ib) {
