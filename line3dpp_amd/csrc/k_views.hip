@@ -261,7 +261,7 @@ __device__ __forceinline__ float sim_scoring(const double* dira, bool zeroa, flo
 // For hypothesis i of a segment with L potential hypotheses, S_i = { j : cam(j) != cam(i) and
 // similarityForScoring(i, j) > 0 } is a row of W = ceil(L/64) 64-bit words.  S_i does not depend on the chain.
 // Layout per global segment g: bits[boff[g] + i*W + w], i in [0, L]; row L is the presence mask P.
-constexpr int kScoreChunk = 64;
+
 
 // words per segment: (L+1) * ceil(L/64)
 __global__ void k_bits_len(uint32_t G, const uint32_t* __restrict__ off, uint32_t* __restrict__ len) {

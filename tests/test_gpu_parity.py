@@ -376,3 +376,50 @@ def test_full_pipeline_vs_reference_own_code():
         r = O.Oracle(threads=1, reference=True)
         r.add_scene(sc); r.match_images(**params); r.compute_affinity()
         _compare_final(g, r, sc)
+
+
+def test_large_views_tile_loop_parity():
+    """One pair of 16k-segment views (BASELINE C4 size): many LDS tiles per pass, top-K threshold feedback at
+    high candidate counts; bit-exact against matchingCPU of the oracle (8 OpenMP threads, ~2.7e8 pair tests)."""
+    sc = make_scene(2, 16384, n_neighbors=2, seed=51)
+    for v in sc.views:
+        v.neighbors = [1 - v.cam]
+    g = _gpu(sc)
+    assert g.matchBegin() and g.matchPairs(0, 1)
+    o = _oracle(sc); o.begin_match()
+    om, _ = o.match_pair(0, 1)
+    o.end_match()
+    r = H.compare_pair(g.pair_slots(0), om)
+    assert not r["missing"] and not r["extra"] and r["bit_exact"] and r["n_cpu"] > 100000
+
+
+def test_many_views_chain_properties():
+    """BASELINE C3-like: a long chain (256 views x 250 segments, two rings): full parity with the oracle."""
+    sc = make_scene(256, 250, n_neighbors=6, seed=53, rings=2, radius=22.0)
+    g = _gpu(sc)
+    assert g.matchImages() and g.computeAffinity()
+    o = _oracle(sc); o.match_images(); o.compute_affinity()
+    n_surv, n_best, n_edges = _compare_final(g, o, sc)
+    assert n_best > 1000
+
+
+def test_device_tensor_wraps_slot_buffer():
+    """line3dpp_amd.dist.device_tensor: the slot buffer as a torch tensor without a copy (what the RCCL
+    all-gather of the N>1 path operates on)."""
+    import torch
+    from line3dpp_amd import dist
+    from line3dpp_amd._lib import SLOT_DTYPE
+    sc = make_scene(4, 200, n_neighbors=2, seed=57)
+    g = _gpu(sc)
+    assert g.matchBegin() and g.matchPairs(0, len(g.pairs()[0]))
+    ptr, n_slots = g.slot_buffer()
+    t = dist.device_tensor(ptr, n_slots * 32, torch.device("cuda", 0))
+    assert t.dtype == torch.uint8 and t.numel() == n_slots * 32 and t.data_ptr() == ptr
+    host = np.frombuffer(t.cpu().numpy().tobytes(), SLOT_DTYPE)
+    pairs, off = g.pairs()
+    for pi in range(len(pairs)):
+        sl = g.pair_slots(pi)
+        assert np.array_equal(host[int(off[pi]):int(off[pi]) + sl.size], sl.reshape(-1))
+    # in-place write through the tensor is seen by the library (what a broadcast into the buffer does)
+    t[:32] = 0xFF
+    assert g.pair_slots(0).reshape(-1)[0]["tgt_seg"] == EMPTY
