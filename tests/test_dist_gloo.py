@@ -49,7 +49,12 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist_t.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        # world 2: 12 uniform pairs split evenly -> the single all-gather path; world 3 with ragged views ->
+        # uneven slices -> the broadcast path
         scene = make_scene(6, 90 + 7, n_neighbors=4, seed=4)
+        if world == 3:
+            for i, v in enumerate(scene.views):
+                v.segs = v.segs[:97 - 9 * i].copy()
         full, offs, n_slots, pairs, M = _slots_from_oracle(scene, 5)
         ranges = dist.pair_ranges([M[s] * M[t] for s, t in pairs], world)
         br = dist.slot_byte_ranges(ranges, offs, n_slots)
@@ -57,8 +62,8 @@ def _worker(rank, world, port, q):
         lo, hi = br[rank]
         mine[lo:hi] = full[lo:hi]            # this rank matched only its own pairs
         buf = torch.from_numpy(mine)
-        dist.exchange_slots(buf, br)
-        ok = bool(np.array_equal(buf.numpy(), full))
+        how = dist.exchange_slots(buf, br)
+        ok = bool(np.array_equal(buf.numpy(), full)) and how == ("all_gather" if world == 2 else "broadcast")
         covered = sum(h - l for l, h in br) == len(full)
         q.put((rank, ok, covered, [c for _, c in ranges]))
     finally:
