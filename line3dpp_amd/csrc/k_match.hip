@@ -34,27 +34,32 @@ constexpr int kRing = 512;         // per-wave candidate ring (entries); >= 63 +
 constexpr float kKappa = 1.0e-2f;  // pre-filter slack, px: margin = kKappa * max|1/d| + kKappa0
 constexpr float kKappa0 = 2.0e-4f;
 
+// All LDS pointers carry the LDS address space in their TYPE: a generic pointer that travels through a struct
+// or a lambda capture loses it and every access becomes a flat_load/flat_store (plus, for volatile, sc0 sc1
+// and an immediate s_waitcnt) instead of ds_read/ds_write.
+#define L3D_LDS __attribute__((address_space(3)))
+typedef float v4f __attribute__((ext_vector_type(4)));
 struct Lds {
-    float4* tile;        // [kTile]
-    volatile uint32_t* ring;      // [4][kRing]
-    volatile uint32_t* cnt;       // [kBlock]
-    volatile float* minov;        // [kBlock]
-    volatile uint32_t* claim;     // [kBlock]
-    volatile uint32_t* minpos;    // [kBlock] slot of the worst entry of a full row
-    volatile float* top_ov;       // [kBlock*K]
-    volatile uint32_t* top_ix;    // [kBlock*K]
+    L3D_LDS v4f* tile;                 // [kTile]
+    L3D_LDS volatile uint32_t* ring;   // [4][kRing]
+    L3D_LDS volatile uint32_t* cnt;    // [kBlock]
+    L3D_LDS volatile float* minov;     // [kBlock]
+    L3D_LDS volatile uint32_t* claim;  // [kBlock]
+    L3D_LDS volatile uint32_t* minpos; // [kBlock] slot of the worst entry of a full row
+    L3D_LDS volatile float* top_ov;    // [kBlock*K]
+    L3D_LDS volatile uint32_t* top_ix; // [kBlock*K]
 };
 
-__device__ __forceinline__ Lds carve(char* base, uint32_t K) {
+__device__ __forceinline__ Lds carve(L3D_LDS char* base, uint32_t K) {
     Lds l;
-    l.tile = (float4*)base; base += sizeof(float4) * kTile;
-    l.ring = (volatile uint32_t*)base; base += 4 * kRing * sizeof(uint32_t);
-    l.cnt = (volatile uint32_t*)base; base += kBlock * 4;
-    l.minov = (volatile float*)base; base += kBlock * 4;
-    l.claim = (volatile uint32_t*)base; base += kBlock * 4;
-    l.minpos = (volatile uint32_t*)base; base += kBlock * 4;
-    l.top_ov = (volatile float*)base; base += (size_t)kBlock * K * 4;
-    l.top_ix = (volatile uint32_t*)base;
+    l.tile = (L3D_LDS v4f*)base; base += sizeof(float4) * kTile;
+    l.ring = (L3D_LDS volatile uint32_t*)base; base += 4 * kRing * sizeof(uint32_t);
+    l.cnt = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
+    l.minov = (L3D_LDS volatile float*)base; base += kBlock * 4;
+    l.claim = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
+    l.minpos = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
+    l.top_ov = (L3D_LDS volatile float*)base; base += (size_t)kBlock * K * 4;
+    l.top_ix = (L3D_LDS volatile uint32_t*)base;
     return l;
 }
 
@@ -64,7 +69,7 @@ __device__ __forceinline__ Lds carve(char* base, uint32_t K) {
 // units of the target segment (q1 -> 0, q2 -> 1).  NaN/inf from degenerate d fall through as
 // "candidate" and are sorted out by the exact test.
 __device__ __forceinline__ bool prefilter(float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
-                                          const float4 q, float thr) {
+                                          const v4f q, float thr) {
     float a1 = __builtin_fmaf(e1x, q.x, __builtin_fmaf(e1y, q.y, e1z));
     float a2 = __builtin_fmaf(e2x, q.x, __builtin_fmaf(e2y, q.y, e2z));
     float d1 = __builtin_fmaf(e1x, q.z, e1y * q.w);
@@ -104,9 +109,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
     const ViewDev& vs = views[pd.src];
     const ViewDev& vt = views[pd.tgt];
     const uint32_t K = pd.K, Ms = pd.Ms, Mt = pd.Mt;
-    Lds L = carve(smem, MODE == 0 ? K : 0);
+    Lds L = carve((L3D_LDS char*)smem, MODE == 0 ? K : 0);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    volatile uint32_t* ring = L.ring + wave * kRing;
+    L3D_LDS volatile uint32_t* ring = L.ring + wave * kRing;
     const uint32_t src = wi.src0 + tid;
     const bool active = src < Ms;
 
@@ -141,8 +146,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
 
     // worst entry of a full row under (overlap desc, tgt asc): pipelined (non-volatile) LDS reads
     auto rescan_worst = [&](uint32_t sl) {
-        const float* ov = (const float*)L.top_ov + (size_t)sl * K;
-        const uint32_t* ix = (const uint32_t*)L.top_ix + (size_t)sl * K;
+        L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)sl * K;
+        L3D_LDS const uint32_t* ix = (L3D_LDS const uint32_t*)L.top_ix + (size_t)sl * K;
         uint32_t wj = 0; float wo = ov[0]; uint32_t wx = ix[0];
         for (uint32_t j = 1; j < K; ++j) {
             const float o = ov[j]; const uint32_t x = ix[j];
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
         // several candidates of one drain may belong to the same row: lowest lane first, so a row
         // always sees its candidates in ascending target order
         while (__ballot(pending)) {
-            if (pending) atomicMin((uint32_t*)&L.claim[sl], lane);
+            if (pending) __hip_atomic_fetch_min((L3D_LDS uint32_t*)&L.claim[sl], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const bool win = pending && (L.claim[sl] == lane);
             if (win) {
                 L.claim[sl] = kEmpty;
@@ -192,8 +197,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
                     if (c < K) slots[pd.slot_off + (uint64_t)(wi.src0 + sl) * K + c] = o;
                     L.cnt[sl] = c + 1;
                 } else {
-                    volatile float* ov = L.top_ov + (size_t)sl * K;
-                    volatile uint32_t* ix = L.top_ix + (size_t)sl * K;
+                    L3D_LDS volatile float* ov = L.top_ov + (size_t)sl * K;
+                    L3D_LDS volatile uint32_t* ix = L.top_ix + (size_t)sl * K;
                     if (c < K) {
                         ov[c] = res.overlap; ix[c] = tg;
                         L.cnt[sl] = c + 1;
@@ -213,41 +218,41 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
     };
 
     // ---- main loop: stream the target view through LDS ----
+    // Branch-free per test: dead lanes evaluate the pre-filter on zeros and are masked out of the ballot;
+    // the compaction prefix is v_mbcnt (population count of the ballot below this lane).
     const SegF* __restrict__ tf = vt.segf;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t ent_hi = tid << 23;
+    auto prefix = [&](uint64_t m) -> uint32_t {
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    };
     for (uint32_t t0 = 0; t0 < Mt; t0 += kTile) {
         const uint32_t n = min((uint32_t)kTile, Mt - t0);
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += kBlock) L.tile[i] = *(const float4*)&tf[t0 + i];
+        for (uint32_t i = tid; i < n; i += kBlock) L.tile[i] = *(const v4f*)&tf[t0 + i];
         __syncthreads();
         uint32_t j = 0;
         for (; j + 4 <= n; j += 4) {
-            const float4 q0 = L.tile[j], q1 = L.tile[j + 1], q2 = L.tile[j + 2], q3 = L.tile[j + 3];
-            const bool c0 = BRUTE ? active : (live && prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
-            const bool c1 = BRUTE ? active : (live && prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL));
-            const bool c2 = BRUTE ? active : (live && prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL));
-            const bool c3 = BRUTE ? active : (live && prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q3, thrL));
+            const v4f q0 = L.tile[j], q1 = L.tile[j + 1], q2 = L.tile[j + 2], q3 = L.tile[j + 3];
+            const bool c0 = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
+            const bool c1 = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL));
+            const bool c2 = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL));
+            const bool c3 = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q3, thrL));
             const uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3);
             if (m0 | m1 | m2 | m3) {
                 const uint32_t tb = t0 + j;
-                if (c0) ring[(tail + __popcll(m0 & lt_mask)) & (kRing - 1)] = ent_hi | tb;
-                tail += __popcll(m0);
-                if (c1) ring[(tail + __popcll(m1 & lt_mask)) & (kRing - 1)] = ent_hi | (tb + 1);
-                tail += __popcll(m1);
-                if (c2) ring[(tail + __popcll(m2 & lt_mask)) & (kRing - 1)] = ent_hi | (tb + 2);
-                tail += __popcll(m2);
-                if (c3) ring[(tail + __popcll(m3 & lt_mask)) & (kRing - 1)] = ent_hi | (tb + 3);
-                tail += __popcll(m3);
+                if (m0) { if (c0) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | tb; tail += __popcll(m0); }
+                if (m1) { if (c1) ring[(tail + prefix(m1)) & (kRing - 1)] = ent_hi | (tb + 1); tail += __popcll(m1); }
+                if (m2) { if (c2) ring[(tail + prefix(m2)) & (kRing - 1)] = ent_hi | (tb + 2); tail += __popcll(m2); }
+                if (m3) { if (c3) ring[(tail + prefix(m3)) & (kRing - 1)] = ent_hi | (tb + 3); tail += __popcll(m3); }
                 while (tail - head >= 64) drain();
             }
         }
         for (; j < n; ++j) {
-            const float4 q0 = L.tile[j];
-            const bool c0 = BRUTE ? active : (live && prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
+            const v4f q0 = L.tile[j];
+            const bool c0 = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
             const uint64_t m0 = __ballot(c0);
             if (m0) {
-                if (c0) ring[(tail + __popcll(m0 & lt_mask)) & (kRing - 1)] = ent_hi | (t0 + j);
+                if (c0) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | (t0 + j);
                 tail += __popcll(m0);
                 while (tail - head >= 64) drain();
             }
@@ -272,8 +277,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
     }
     // rank the winners by (overlap desc, tgt asc); the overlaps are in LDS, the depths are recomputed
     // (identical arithmetic to the acceptance test, so identical values)
-    const float* ov = (const float*)L.top_ov + (size_t)tid * K;
-    const uint32_t* ix = (const uint32_t*)L.top_ix + (size_t)tid * K;
+    L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)tid * K;
+    L3D_LDS const uint32_t* ix = (L3D_LDS const uint32_t*)L.top_ix + (size_t)tid * K;
     const SegX sx = vs.segx[src];
     for (uint32_t j = 0; j < c; ++j) {
         const float oj = ov[j]; const uint32_t xj = ix[j];
