@@ -46,7 +46,7 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 //   cnt_inv[g]  potential inverse hypotheses of g -> CSR of the transposed index
 __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
                              const uint32_t* __restrict__ seg_base, Slot* __restrict__ slots,
-                             uint32_t* __restrict__ cnt_all, uint32_t* __restrict__ cnt_inv) {
+                             uint32_t* __restrict__ cnt_all, uint32_t* __restrict__ cnt_inv, OrientThr othr) {
     const PairDesc& pd = pairs[blockIdx.y];
     const uint64_t n = (uint64_t)pd.Ms * pd.K;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -57,13 +57,13 @@ __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* 
     const ViewDev& vs = views[pd.src];
     const uint32_t row = (uint32_t)(i / pd.K);
     uint32_t flags = 0;
-    if (orientation_ok(vs.C, vs.segx[row], s.dp1, s.dp2)) {
+    if (orientation_ok(vs.C, vs.segx[row], s.dp1, s.dp2, othr)) {
         flags = kSlotAlive;
         atomicAdd(&cnt_all[seg_base[pd.src] + row], 1u);
         // inverse copy: only towards a view that is processed later (line3D.cc:1680)
         if (pd.tgt > pd.src) {
             const ViewDev& vt = views[pd.tgt];
-            if (orientation_ok(vt.C, vt.segx[s.tgt_seg], s.dq1, s.dq2)) {
+            if (orientation_ok(vt.C, vt.segx[s.tgt_seg], s.dq1, s.dq2, othr)) {
                 flags |= kSlotInvAlive;
                 atomicAdd(&cnt_all[seg_base[pd.tgt] + s.tgt_seg], 1u);
                 atomicAdd(&cnt_inv[seg_base[pd.tgt] + s.tgt_seg], 1u);
@@ -709,10 +709,10 @@ hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* 
 // ---- launchers --------------------------------------------------------------------------------------
 hipError_t launch_orient_all(const ViewDev* views, const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots,
                              const uint32_t* seg_base, Slot* slots, uint32_t* cnt_all, uint32_t* cnt_inv,
-                             hipStream_t st) {
+                             double thr_lo, double thr_hi, hipStream_t st) {
     if (!n_pairs || !max_slots) return hipSuccess;
     hipLaunchKernelGGL(k_orient_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, views,
-                       pairs, seg_base, slots, cnt_all, cnt_inv);
+                       pairs, seg_base, slots, cnt_all, cnt_inv, OrientThr{thr_lo, thr_hi});
     return hipGetLastError();
 }
 hipError_t launch_count_all(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,

@@ -16,7 +16,8 @@ void set_error(const std::string& s) { g_err = s; }
 // ---- prototypes of the launchers in k_views.hip / k_affinity.hip -------------------------------
 hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, uint32_t* total, hipStream_t);
 hipError_t launch_orient_all(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
-                             const uint32_t* seg_base, Slot*, uint32_t* cnt_all, uint32_t* cnt_inv, hipStream_t);
+                             const uint32_t* seg_base, Slot*, uint32_t* cnt_all, uint32_t* cnt_inv, double thr_lo,
+                             double thr_hi, hipStream_t);
 hipError_t launch_count_all(const PairDesc*, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
                             const Slot*, uint32_t* cnt_all, uint32_t* cnt_inv, hipStream_t);
 hipError_t launch_inv_fill(const PairDesc*, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
@@ -74,6 +75,7 @@ struct l3d_ctx {
     int kNN = 10, num_neighbors = 10;
     bool fixed3Dregularizer = false;
     bool brute = false;                             // test hook: disable the fp32 pre-filter
+    double orient_lo = -1.0, orient_hi = 1.0;       // dp window equivalent to acos(dp) in (PI/32, 31PI/32)
     d3 translation{0, 0, 0};
     // state
     enum { IDLE, BEGUN, MATCHED } state = IDLE;
@@ -207,6 +209,19 @@ int upload_views(l3d_ctx& c) {
     return L3D_OK;
 }
 
+// checkMatchOrientation keeps a match iff L3D_PI_1_32 < acos(dp) < L3D_PI_31_32 (line3D.cc:836, double compare
+// against the float constants).  acos is monotone non-increasing on [-1,1]: find by bisection over the doubles,
+// with this libm's acos, the largest dp with acos(dp) > PI/32 and the smallest dp with acos(dp) < 31PI/32.
+void orientation_thresholds(double& lo, double& hi) {
+    const double a1 = (double)kPi_1_32, a2 = (double)kPi_31_32;
+    double x = -1.0, y = 1.0;                 // pred(d) = acos(d) > a1 : true at -1, false at 1
+    for (int it = 0; it < 200 && std::nextafter(x, y) < y; ++it) { const double m = 0.5 * (x + y); if (std::acos(m) > a1) x = m; else y = m; }
+    hi = x;
+    x = -1.0; y = 1.0;                        // pred(d) = acos(d) < a2 : false at -1, true at 1
+    for (int it = 0; it < 200 && std::nextafter(x, y) < y; ++it) { const double m = 0.5 * (x + y); if (std::acos(m) < a2) y = m; else x = m; }
+    lo = y;
+}
+
 float ev_ms(hipEvent_t a, hipEvent_t b) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, a, b);
@@ -225,6 +240,7 @@ l3d_ctx* l3d_create(int device, void* stream) {
     auto* c = new l3d_ctx();
     c->device = device;
     c->stream = (hipStream_t)stream;
+    orientation_thresholds(c->orient_lo, c->orient_hi);
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); delete c; return nullptr; }
     return c;
@@ -509,7 +525,7 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(hipMemsetAsync(c->d_scal.p, 0, 16 * 4, st));
     // ---- pre-pass: orientation flags, list offsets, transposed index of potential inverse matches ----
     L3D_HIP_CHECK(launch_orient_all(c->d_views.p, c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p,
-                                    c->d_cnt.p, c->d_cnt_inv.p, st));
+                                    c->d_cnt.p, c->d_cnt_inv.p, c->orient_lo, c->orient_hi, st));
     L3D_HIP_CHECK(launch_scan(c->d_cnt.p, G, c->d_off.p, c->d_scan_tmp.p, c->d_scal.p + 0, st));
     L3D_HIP_CHECK(launch_scan(c->d_cnt_inv.p, G, c->d_inv_off.p, c->d_scan_tmp.p, c->d_scal.p + 5, st));
     L3D_HIP_CHECK(c->d_bits_len.reserve(G + 1)); L3D_HIP_CHECK(c->d_boff.reserve(G + 1));

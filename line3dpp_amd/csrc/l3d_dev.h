@@ -275,13 +275,15 @@ L3D_HD Seg3 unproject(const double* C, const double* r1, const double* r2, float
 }
 
 // checkMatchOrientation: line3D.cc:831-839, view.cc:466-484
-L3D_HD bool orientation_ok(const double* C, const SegX& sx, float d1, float d2) {
+// The reference decides on acos(dp) in (PI/32, 31PI/32) with dp clamped to [-1,1].  acos is monotone, so the
+// same decision is dp in [t.lo, t.hi] for two doubles the host finds once by bisection WITH THE SAME libm acos
+// the reference links (l3d_api.hip: orientation_thresholds) -- exact agreement and no device-side acos.
+struct OrientThr { double lo, hi; };
+L3D_HD bool orientation_ok(const double* C, const SegX& sx, float d1, float d2, const OrientThr t) {
     const Seg3 s = unproject(C, sx.r1, sx.r2, d1, d2);
-    const double dp = dot(d3{sx.rm[0], sx.rm[1], sx.rm[2]}, s.dir);
-    const double ang = acos(fmin(fmax(dp, -1.0), 1.0));
-    return ang > (double)kPi_1_32 && ang < (double)kPi_31_32;
+    const double dp = fmin(fmax(dot(d3{sx.rm[0], sx.rm[1], sx.rm[2]}, s.dir), -1.0), 1.0);
+    return dp >= t.lo && dp <= t.hi;
 }
-
 
 // (overlap desc, tgt asc) total order used for the kNN selection
 L3D_HD bool better(float ova, uint32_t ia, float ovb, uint32_t ib) {
