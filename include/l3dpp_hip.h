@@ -130,6 +130,22 @@ int l3d_match_finish(l3d_ctx*);
  * computingAffinityMatrix(), untranslate() (line3D.cc:1749-1778, 1852-2023; collinearity off). */
 int l3d_compute_affinity(l3d_ctx*);
 
+/* Line3D::reconstruct3Dlines (line3D.cc:1702-1824) up to the final 3D segments: translate(), affinity matrix
+ * (as l3d_compute_affinity), graph clustering (clustering.cc), 3D line per cluster, collinear 3D segments,
+ * filterTinySegments, untranslate().  Like a reference build without CUDA/Ceres, perform_diffusion and
+ * use_CERES are reported and ignored (line3D.cc:1733-1744); collinearity_t > 0 is not supported.
+ * The clustering / reconstruction tail is small sequential host work in the reference and runs on the host
+ * here as well. */
+int l3d_reconstruct_3d_lines(l3d_ctx*, uint32_t visibility_t, int perform_diffusion, float collinearity_t,
+                             int use_CERES, uint32_t max_iter_CERES);
+/* Line3D::get3Dlines (line3D.cc:2455-2463): lines3D_ flattened.  Line i owns the 3D segments
+ * [seg_offsets[i], seg_offsets[i+1]) (collinear3Dsegments_) and the residual 2D segments
+ * [res_offsets[i], res_offsets[i+1]) (underlyingCluster_.residuals_); cluster_lines[i] is
+ * underlyingCluster_.seg3D_, reference_views[i] its reference_view_.  Original (untranslated) frame. */
+int l3d_num_3d_lines(l3d_ctx*, uint32_t* n_lines, uint32_t* n_segments, uint32_t* n_residuals);
+int l3d_get_3d_lines(l3d_ctx*, uint32_t* seg_offsets, l3d_segment3d* segments, uint32_t* res_offsets,
+                     l3d_segment2d* residuals, l3d_segment3d* cluster_lines, uint32_t* reference_views);
+
 /* block the calling thread until everything queued on the context's stream has finished */
 int l3d_synchronize(l3d_ctx*);
 

@@ -107,6 +107,29 @@ class Line3D:
     def computeAffinity(self):
         return self._check(self.L.l3d_compute_affinity(self.h), "computeAffinity")
 
+    # Line3D::reconstruct3Dlines, line3D.h:162-166 (defaults commons.h:63-70)
+    def reconstruct3Dlines(self, visibility_t=L3D_DEF_MIN_VISIBILITY_T, perform_diffusion=False, collinearity_t=-1.0,
+                           use_CERES=False, max_iter_CERES=250):
+        if perform_diffusion:   # what a reference build without CUDA prints (line3D.cc:1733-1735)
+            print(f"{self.PREFIX}ERROR: diffusion not possible without CUDA! using graph clustering instead...")
+        if use_CERES:           # line3D.cc:1741-1743
+            print(f"{self.PREFIX}ERROR: CERES was not found! no optimization will be performed...")
+        return self._check(self.L.l3d_reconstruct_3d_lines(self.h, int(visibility_t), int(perform_diffusion),
+                                                           float(collinearity_t), int(use_CERES), int(max_iter_CERES)),
+                           "reconstruct3Dlines")
+
+    # Line3D::get3Dlines, line3D.h:173: list of FinalLine3D as dicts
+    def get3Dlines(self):
+        nl = C.c_uint32(); ns = C.c_uint32(); nr = C.c_uint32()
+        if not self._check(self.L.l3d_num_3d_lines(self.h, C.byref(nl), C.byref(ns), C.byref(nr)), "get3Dlines"):
+            return []
+        so = np.zeros(nl.value + 1, np.uint32); ro = np.zeros(nl.value + 1, np.uint32)
+        segs = np.zeros(max(ns.value, 1), SEGMENT3D_DTYPE); res = np.zeros(max(nr.value, 1), SEGMENT2D_DTYPE)
+        cl = np.zeros(max(nl.value, 1), SEGMENT3D_DTYPE); rv = np.zeros(max(nl.value, 1), np.uint32)
+        self.L.l3d_get_3d_lines(self.h, ptr(so), ptr(segs), ptr(ro), ptr(res), ptr(cl), ptr(rv))
+        return [dict(collinear3Dsegments=segs[so[i]:so[i + 1]], residuals=res[ro[i]:ro[i + 1]],
+                     cluster_line=cl[i], reference_view=int(rv[i])) for i in range(nl.value)]
+
     def set_brute_force(self, on):
         self.L.l3d_set_brute_force(self.h, int(on))
 

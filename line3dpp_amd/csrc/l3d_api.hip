@@ -7,6 +7,7 @@
 #include <mutex>
 
 #include "l3d_host.h"
+#include "l3d_recon.h"
 
 namespace l3d {
 
@@ -120,6 +121,8 @@ struct l3d_ctx {
     DevBuf<l3d_segment2d> d_l2g;
     std::vector<l3d_cledge> edges;
     std::vector<l3d_segment2d> l2g;
+    std::vector<ReconLine> lines3D;                 // lines3D_ (original frame)
+    bool lines_done = false;
     // timings
     hipEvent_t ev[8] = {};
     l3d_timings tm{};
@@ -330,6 +333,7 @@ int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
     else { c->fixed3Dregularizer = false; c->sigma_p = std::fmax(0.1f, c->sigma_p); }
     if (c->kNN > 4096) return fail(L3D_ERR_LIMIT, "kNN > 4096");
     c->affinity_done = false;
+    c->lines_done = false;
     c->n_hyps = 0;
     // line3D.cc:426-433
     c->med_scene_depth = c->const_regularization_depth;
@@ -597,17 +601,12 @@ int l3d_match_images(l3d_ctx* c, const l3d_match_params* p) {
     return l3d_match_finish(c);
 }
 
-int l3d_compute_affinity(l3d_ctx* c) {
-    if (!c) return fail(L3D_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(c->mu);
-    if (c->state != l3d_ctx::MATCHED) return fail(L3D_ERR_STATE, "matchImages must precede the affinity step");
+// med_scene_depth_lines_ + computingAffinityMatrix (line3D.cc:1759-1778) in the CURRENT (translated) frame
+static int affinity_core(l3d_ctx* c) {
     (void)hipSetDevice(c->device);
     hipStream_t st = c->stream;
     const uint32_t V = (uint32_t)c->order.size();
     c->edges.clear(); c->l2g.clear();
-    // translate()/untranslate() (line3D.cc:1749,1820) only move camera centres, which the affinity
-    // terms never read; they are applied to keep the host state identical to the reference's.
-    translate(*c);
     // med_scene_depth_lines_, line3D.cc:1759-1774
     std::vector<float> sd;
     for (auto* v : c->order) if (v->median_depth > kEps) sd.push_back(v->median_depth);
@@ -661,8 +660,93 @@ int l3d_compute_affinity(l3d_ctx* c) {
     L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
     L3D_HIP_CHECK(hipStreamSynchronize(st));
     c->tm.affinity_ms = ev_ms(c->ev[6], c->ev[7]);
-    untranslate(*c);
     c->affinity_done = true;
+    return L3D_OK;
+}
+
+
+int l3d_compute_affinity(l3d_ctx* c) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->state != l3d_ctx::MATCHED) return fail(L3D_ERR_STATE, "matchImages must precede the affinity step");
+    // translate()/untranslate() (line3D.cc:1749,1820) only move camera centres, which the affinity terms never
+    // read; they are applied to keep the host state identical to the reference's.
+    translate(*c);
+    const int rc = affinity_core(c);
+    untranslate(*c);
+    return rc;
+}
+
+// Line3D::reconstruct3Dlines, line3D.cc:1702-1824
+int l3d_reconstruct_3d_lines(l3d_ctx* c, uint32_t visibility_t, int perform_diffusion, float collinearity_t,
+                             int use_CERES, uint32_t max_iter_CERES) {
+    (void)max_iter_CERES;
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->state != l3d_ctx::MATCHED || c->n_hyps == 0)
+        return fail(L3D_ERR_STATE, "no clusterable segments! forgot to match lines?");   // line3D.cc:1712-1718
+    if (collinearity_t > 0.0f) return fail(L3D_ERR_LIMIT, "collinearity_t > 0 is not supported");
+    if (perform_diffusion) set_error("diffusion not available, using graph clustering instead");   // :1733-1735
+    if (use_CERES) set_error("CERES not available, no optimization will be performed");             // :1741-1743
+    const unsigned vis = std::max<unsigned>(visibility_t, 3);
+    c->lines3D.clear();
+    translate(*c);
+    int rc = affinity_core(c);
+    if (rc == L3D_OK) {
+        ReconInput in;
+        in.visibility_t = vis;
+        in.edges = c->edges;
+        in.l2g = c->l2g;
+        in.hyps.resize(c->n_hyps);
+        if (hipMemcpy(in.hyps.data(), c->d_hyps.p, in.hyps.size() * sizeof(HypRec), hipMemcpyDeviceToHost) != hipSuccess) {
+            untranslate(*c);
+            return fail(L3D_ERR_HIP, "copying the 3D hypotheses failed");
+        }
+        for (size_t i = 0; i < in.hyps.size(); ++i) in.entry_map[{in.hyps[i].m.src_cam, in.hyps[i].m.src_seg}] = i;
+        for (auto* v : c->order) in.views[v->cam] = v;
+        uint32_t ncl = 0, nvalid = 0;
+        reconstruct_lines(in, c->lines3D, &ncl, &nvalid);
+        // untranslate the lines (performTranslation(translation_), line3D.cc:559-574)
+        const d3 t = c->translation;
+        auto shift = [&](ReconSeg3D& s) { s.P1 = s.P1 + t; s.P2 = s.P2 + t; };
+        for (auto& L : c->lines3D) { for (auto& s : L.collinear) shift(s); shift(L.cluster_seg); }
+        c->lines_done = true;
+    }
+    untranslate(*c);
+    return rc;
+}
+
+int l3d_num_3d_lines(l3d_ctx* c, uint32_t* n_lines, uint32_t* n_segments, uint32_t* n_residuals) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    if (!c->lines_done) return fail(L3D_ERR_STATE, "l3d_reconstruct_3d_lines has not run");
+    uint32_t ns = 0, nr = 0;
+    for (auto& L : c->lines3D) { ns += (uint32_t)L.collinear.size(); nr += (uint32_t)L.residuals.size(); }
+    if (n_lines) *n_lines = (uint32_t)c->lines3D.size();
+    if (n_segments) *n_segments = ns;
+    if (n_residuals) *n_residuals = nr;
+    return L3D_OK;
+}
+
+int l3d_get_3d_lines(l3d_ctx* c, uint32_t* seg_offsets, l3d_segment3d* segments, uint32_t* res_offsets,
+                     l3d_segment2d* residuals, l3d_segment3d* cluster_lines, uint32_t* reference_views) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    if (!c->lines_done) return fail(L3D_ERR_STATE, "l3d_reconstruct_3d_lines has not run");
+    auto put = [](l3d_segment3d& o, const ReconSeg3D& s) {
+        o.P1[0] = s.P1.x; o.P1[1] = s.P1.y; o.P1[2] = s.P1.z; o.P2[0] = s.P2.x; o.P2[1] = s.P2.y; o.P2[2] = s.P2.z;
+        o.dir[0] = s.dir.x; o.dir[1] = s.dir.y; o.dir[2] = s.dir.z; o.length_ = s.length; o.valid_ = s.valid ? 1u : 0u;
+    };
+    uint32_t ns = 0, nr = 0;
+    for (size_t i = 0; i < c->lines3D.size(); ++i) {
+        const ReconLine& L = c->lines3D[i];
+        if (seg_offsets) seg_offsets[i] = ns;
+        if (res_offsets) res_offsets[i] = nr;
+        for (auto& s : L.collinear) { if (segments) put(segments[ns], s); ++ns; }
+        for (auto& r : L.residuals) { if (residuals) { residuals[nr].camID_ = r.first; residuals[nr].segID_ = r.second; } ++nr; }
+        if (cluster_lines) put(cluster_lines[i], L.cluster_seg);
+        if (reference_views) reference_views[i] = L.reference_view;
+    }
+    if (seg_offsets) seg_offsets[c->lines3D.size()] = ns;
+    if (res_offsets) res_offsets[c->lines3D.size()] = nr;
     return L3D_OK;
 }
 

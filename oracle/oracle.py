@@ -80,6 +80,10 @@ def lib(reference=False):
         L.lo_num_edges.argtypes = [vp]; L.lo_num_edges.restype = u32
         L.lo_num_rows.argtypes = [vp]; L.lo_num_rows.restype = u32
         L.lo_get_affinity.argtypes = [vp, vp, vp]
+        if reference:
+            L.lo_reconstruct.argtypes = [vp, u32]
+            L.lo_num_lines.argtypes = [vp, vp, vp, vp]
+            L.lo_get_lines.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         _libs[key] = L
     return _libs[key]
 
@@ -205,3 +209,21 @@ class Oracle:
         if ne:
             self.L.lo_get_affinity(self.h, _p(e), _p(l2g))
         return e[:ne], l2g[:nr]
+
+    # ---- reconstruction tail: only through the reference's own code (oracle/_ref) -------------------------
+    def reconstruct(self, visibility_t=3):
+        assert self.reference, "reconstruct3Dlines is run by the reference's own code only (oracle/_ref)"
+        self.L.lo_reconstruct(self.h, int(visibility_t))
+
+    def lines(self):
+        """lines3D_ as a list of dicts: collinear3Dsegments [n,9] (P1,P2,dir), residuals [m,2], cluster_line [9],
+        reference_view"""
+        assert self.reference
+        nl = C.c_uint32(); ns = C.c_uint32(); nr = C.c_uint32()
+        self.L.lo_num_lines(self.h, C.byref(nl), C.byref(ns), C.byref(nr))
+        so = np.zeros(nl.value + 1, np.uint32); ro = np.zeros(nl.value + 1, np.uint32)
+        segs = np.zeros((max(ns.value, 1), 9)); res = np.zeros((max(nr.value, 1), 2), np.uint32)
+        cl = np.zeros((max(nl.value, 1), 9)); rv = np.zeros(max(nl.value, 1), np.uint32)
+        self.L.lo_get_lines(self.h, _p(so), _p(segs), _p(ro), _p(res), _p(cl), _p(rv))
+        return [dict(collinear3Dsegments=segs[so[i]:so[i + 1]], residuals=res[ro[i]:ro[i + 1]], cluster_line=cl[i],
+                     reference_view=int(rv[i])) for i in range(nl.value)]

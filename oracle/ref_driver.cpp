@@ -201,6 +201,40 @@ uint64_t lo_pair_tests(void* p) {
             if (kv.first < t) n += (uint64_t)l->views_[kv.first]->num_lines() * l->views_[t]->num_lines();
     return n;
 }
+// Line3D::reconstruct3Dlines (graph clustering, no diffusion, no collinearity, no Ceres) and get3Dlines,
+// run by the reference's own code.  lines3D_ flattened like include/l3dpp_hip.h: l3d_get_3d_lines.
+void lo_reconstruct(void* p, uint32_t visibility_t) {
+    Quiet q;
+    ((Ref*)p)->l3d->reconstruct3Dlines(visibility_t, false, -1.0f, false, 250);
+}
+void lo_num_lines(void* p, uint32_t* n_lines, uint32_t* n_segments, uint32_t* n_residuals) {
+    std::vector<L3DPP::FinalLine3D> r;
+    ((Ref*)p)->l3d->get3Dlines(r);
+    uint32_t ns = 0, nr = 0;
+    for (size_t i = 0; i < r.size(); ++i) { ns += (uint32_t)r[i].collinear3Dsegments_.size(); nr += (uint32_t)r[i].underlyingCluster_.size(); }
+    *n_lines = (uint32_t)r.size(); *n_segments = ns; *n_residuals = nr;
+}
+// segments: 9 doubles (P1,P2,dir) each; cluster_lines: 9 doubles per line
+void lo_get_lines(void* p, uint32_t* seg_offsets, double* segments9, uint32_t* res_offsets, uint32_t* residuals2,
+                  double* cluster_lines9, uint32_t* reference_views) {
+    std::vector<L3DPP::FinalLine3D> r;
+    ((Ref*)p)->l3d->get3Dlines(r);
+    auto put = [](double* o, const L3DPP::Segment3D& s) {
+        const Eigen::Vector3d a = s.P1(), b = s.P2(), d = s.dir();
+        o[0] = a.x(); o[1] = a.y(); o[2] = a.z(); o[3] = b.x(); o[4] = b.y(); o[5] = b.z(); o[6] = d.x(); o[7] = d.y(); o[8] = d.z();
+    };
+    uint32_t ns = 0, nr = 0;
+    for (size_t i = 0; i < r.size(); ++i) {
+        seg_offsets[i] = ns; res_offsets[i] = nr;
+        for (std::list<L3DPP::Segment3D>::const_iterator it = r[i].collinear3Dsegments_.begin(); it != r[i].collinear3Dsegments_.end(); ++it) put(segments9 + 9 * (ns++), *it);
+        const std::list<L3DPP::Segment2D>* res = r[i].underlyingCluster_.residuals();
+        for (std::list<L3DPP::Segment2D>::const_iterator it = res->begin(); it != res->end(); ++it) { residuals2[2 * nr] = it->camID(); residuals2[2 * nr + 1] = it->segID(); ++nr; }
+        put(cluster_lines9 + 9 * i, r[i].underlyingCluster_.seg3D());
+        reference_views[i] = r[i].underlyingCluster_.reference_view();
+    }
+    seg_offsets[r.size()] = ns; res_offsets[r.size()] = nr;
+}
+
 // stage-level entry points exist only in the restatement
 void lo_begin_match(void*, float, float, uint32_t, float, int, float) {}
 void lo_end_match(void*) {}

@@ -423,3 +423,38 @@ def test_device_tensor_wraps_slot_buffer():
     # in-place write through the tensor is seen by the library (what a broadcast into the buffer does)
     t[:32] = 0xFF
     assert g.pair_slots(0).reshape(-1)[0]["tgt_seg"] == EMPTY
+
+
+def test_final_3d_lines_vs_reference_own_code():
+    """matchImages -> reconstruct3Dlines -> get3Dlines against the reference's own
+    clustering.cc / line3D.cc tail (oracle/_ref).  Same clusters (residual 2D segments), same reference view,
+    3D end points within 1e-4 relative (the 3x3 principal direction comes from two different Jacobi codes,
+    and its sign is free: end points are compared as unordered pairs)."""
+    from oracle import oracle as O
+    if not O.have_reference():
+        pytest.skip("oracle/_ref not built")
+    for (nv, ns, nn, seed, vis) in ((12, 500, 6, 61, 3), (16, 400, 8, 62, 4)):
+        sc = make_scene(nv, ns, n_neighbors=nn, seed=seed)
+        g = _gpu(sc)
+        assert g.matchImages() and g.reconstruct3Dlines(visibility_t=vis)
+        gl = g.get3Dlines()
+        r = O.Oracle(threads=1, reference=True)
+        r.add_scene(sc); r.match_images(); r.reconstruct(vis)
+        rl = r.lines()
+        assert len(gl) == len(rl) and len(gl) > 10
+        key = lambda res: tuple(sorted(map(tuple, np.asarray(res).reshape(-1, 2).tolist())))
+        rmap = {key(L["residuals"]): L for L in rl}
+        scale = 30.0   # scene extent: tolerance is relative to coordinates of this magnitude
+        for L in gl:
+            k = key(np.stack([L["residuals"]["cam"], L["residuals"]["seg"]], 1))
+            assert k in rmap, "cluster membership differs"
+            R = rmap[k]
+            assert L["reference_view"] == R["reference_view"]
+            assert len(L["collinear3Dsegments"]) == len(R["collinear3Dsegments"])
+            for a, b in zip(L["collinear3Dsegments"], R["collinear3Dsegments"]):
+                p = np.concatenate([a["P1"], a["P2"]]); q = b[:6]; qs = np.concatenate([b[3:6], b[0:3]])
+                err = min(np.abs(p - q).max(), np.abs(p - qs).max())
+                assert err <= H.REL_TOL * scale, err
+        # the affinity accessors still work after reconstruct3Dlines, and every residual has a hypothesis
+        hyp = set(map(tuple, np.stack([g.best()[0]["cam"], g.best()[0]["seg"]], 1).tolist()))
+        assert all(set(map(tuple, np.stack([L["residuals"]["cam"], L["residuals"]["seg"]], 1).tolist())) <= hyp for L in gl)
