@@ -97,6 +97,42 @@ public:
         if (rc != L3D_OK) std::cout << prefix_err_ << l3d_last_error() << std::endl;
     }
 
+    // void Line3D::reconstruct3Dlines(...), line3D.h:162-166: affinity matrix, graph clustering, 3D line per
+    // cluster, collinear 3D segments (no diffusion / collinearity / Ceres, like a reference build without them)
+    void reconstruct3Dlines(const unsigned int visibility_t = 3, const bool perform_diffusion = false,
+                            const float collinearity_t = -1.0f, const bool use_CERES = false,
+                            const unsigned int max_iter_CERES = 250) {
+        std::cout << std::endl << prefix_ << "[3] RECONSTRUCTION ===============================" << std::endl;
+        if (perform_diffusion) std::cout << prefix_err_ << "diffusion not possible without CUDA! using graph clustering instead..." << std::endl;
+        if (use_CERES) std::cout << prefix_err_ << "CERES was not found! no optimization will be performed..." << std::endl;
+        const int rc = l3d_reconstruct_3d_lines(ctx_, visibility_t, perform_diffusion, collinearity_t, use_CERES, max_iter_CERES);
+        if (rc != L3D_OK) std::cout << prefix_err_ << l3d_last_error() << std::endl;
+    }
+
+    // void Line3D::get3Dlines(std::vector<FinalLine3D>&), line3D.h:173 (FinalLine3D: segment3D.h:165-178)
+    struct FinalLine3D {
+        std::list<l3d_segment3d> collinear3Dsegments_;
+        l3d_segment3d underlyingCluster_seg3D_;
+        std::list<l3d_segment2d> underlyingCluster_residuals_;
+        unsigned int underlyingCluster_reference_view_;
+    };
+    void get3Dlines(std::vector<FinalLine3D>& result) {
+        result.clear();
+        uint32_t nl = 0, ns = 0, nr = 0;
+        if (l3d_num_3d_lines(ctx_, &nl, &ns, &nr) != L3D_OK) return;
+        std::vector<uint32_t> so(nl + 1), ro(nl + 1), rv(nl);
+        std::vector<l3d_segment3d> segs(ns), cl(nl);
+        std::vector<l3d_segment2d> res(nr);
+        l3d_get_3d_lines(ctx_, so.data(), segs.data(), ro.data(), res.data(), cl.data(), rv.data());
+        result.resize(nl);
+        for (uint32_t i = 0; i < nl; ++i) {
+            result[i].collinear3Dsegments_.assign(segs.begin() + so[i], segs.begin() + so[i + 1]);
+            result[i].underlyingCluster_residuals_.assign(res.begin() + ro[i], res.begin() + ro[i + 1]);
+            result[i].underlyingCluster_seg3D_ = cl[i];
+            result[i].underlyingCluster_reference_view_ = rv[i];
+        }
+    }
+
     size_t numImages() const { return num_lines_.size(); }
 
     // matches_[camID] rebuilt in the reference's container type (line3D.h:348)

@@ -43,6 +43,11 @@ int main(int argc, char** argv) {
     std::list<l3d_cledge> A; std::map<int, l3d_segment2d> l2g;
     l3d.affinity(A, l2g);
     double wsum = 0; for (auto& e : A) wsum += e.w_;
+    l3d.reconstruct3Dlines(3);
+    std::vector<L3DPP_HIP::Line3D::FinalLine3D> lines;
+    l3d.get3Dlines(lines);
+    size_t nseg3 = 0; for (auto& L : lines) nseg3 += L.collinear3Dsegments_.size();
+    printf("LINES lines=%zu segments=%zu\n", lines.size(), nseg3);
     printf("RESULT images=%zu matches=%zu score_sum=%.6f hypotheses=%zu edges=%zu rows=%zu wsum=%.6f\n",
            l3d.numImages(), n_matches, score_sum, hyp.size(), A.size(), l2g.size(), wsum);
     return 0;
