@@ -74,24 +74,6 @@ __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* 
     sp->score3D = 0.0f;
 }
 
-// counting pass when the orientation flags were already written by the matching kernel's epilogue (kNN > 0)
-__global__ void k_count_all(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ seg_base,
-                            const Slot* __restrict__ slots, uint32_t* __restrict__ cnt_all,
-                            uint32_t* __restrict__ cnt_inv) {
-    const PairDesc& pd = pairs[blockIdx.y];
-    const uint64_t n = (uint64_t)pd.Ms * pd.K;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint2 tf = *(const uint2*)((const char*)(slots + pd.slot_off + i) + 0);   // tgt_seg
-    const uint32_t flags = slots[pd.slot_off + i].flags;
-    if (tf.x == kEmpty || !(flags & kSlotAlive)) return;
-    atomicAdd(&cnt_all[seg_base[pd.src] + (uint32_t)(i / pd.K)], 1u);
-    if (flags & kSlotInvAlive) {
-        atomicAdd(&cnt_all[seg_base[pd.tgt] + tf.x], 1u);
-        atomicAdd(&cnt_inv[seg_base[pd.tgt] + tf.x], 1u);
-    }
-}
-
 // transposed index of the potential inverse hypotheses: which slots point at global segment g
 __global__ void k_inv_fill(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ seg_base,
                            const Slot* __restrict__ slots, const uint32_t* __restrict__ inv_off,
@@ -713,13 +695,6 @@ hipError_t launch_orient_all(const ViewDev* views, const PairDesc* pairs, uint32
     if (!n_pairs || !max_slots) return hipSuccess;
     hipLaunchKernelGGL(k_orient_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, views,
                        pairs, seg_base, slots, cnt_all, cnt_inv, OrientThr{thr_lo, thr_hi});
-    return hipGetLastError();
-}
-hipError_t launch_count_all(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
-                            const Slot* slots, uint32_t* cnt_all, uint32_t* cnt_inv, hipStream_t st) {
-    if (!n_pairs || !max_slots) return hipSuccess;
-    hipLaunchKernelGGL(k_count_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, pairs,
-                       seg_base, slots, cnt_all, cnt_inv);
     return hipGetLastError();
 }
 hipError_t launch_inv_fill(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,

@@ -19,8 +19,6 @@ hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* 
 hipError_t launch_orient_all(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
                              const uint32_t* seg_base, Slot*, uint32_t* cnt_all, uint32_t* cnt_inv, double thr_lo,
                              double thr_hi, hipStream_t);
-hipError_t launch_count_all(const PairDesc*, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
-                            const Slot*, uint32_t* cnt_all, uint32_t* cnt_inv, hipStream_t);
 hipError_t launch_inv_fill(const PairDesc*, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
                            const Slot*, const uint32_t* inv_off, uint32_t* cur, InvRef*, hipStream_t);
 hipError_t launch_build_lists_all(uint32_t G, const ViewDev*, const PairDesc*, const uint32_t* seg_base,
@@ -92,7 +90,6 @@ struct l3d_ctx {
     DevBuf<WorkItem> d_work;
     DevBuf<Slot> d_slots;
     DevBuf<uint32_t> d_row_counts;
-    DevBuf<double> d_consts;                        // per view: RtKinv[9], C[3]
     // phase B (global over all views; G = sum of M)
     uint32_t G = 0, n_ents = 0, n_surv = 0, n_hyps = 0;
     std::vector<uint32_t> seg_base;                 // [V+1]
@@ -258,7 +255,7 @@ void l3d_destroy(l3d_ctx* c) {
         v.d_seg4.release(); v.d_segf.release(); v.d_segx.release();
     }
     c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release();
-    c->d_row_counts.release(); c->d_consts.release();
+    c->d_row_counts.release();
     c->d_seg_base.release(); c->d_gseg_view.release(); c->d_cnt.release(); c->d_off.release(); c->d_cur.release();
     c->d_scan_tmp.release(); c->d_scal.release(); c->d_max_score.release(); c->d_surv_cnt.release();
     c->d_has_best.release(); c->d_best_pos.release(); c->d_surv_off.release(); c->d_hyp_off.release();

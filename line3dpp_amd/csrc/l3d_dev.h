@@ -98,18 +98,6 @@ struct PairDesc {
 };
 
 // ---- phase-B records ------------------------------------------------------------------------
-// one potential hypothesis of one 2D segment, as gathered (unsorted) from the pair slots
-struct Entry {
-    uint64_t key;      // canonical order inside the segment's list (reference single-thread order)
-    uint64_t ref;      // index of the slot it comes from
-    uint32_t gseg;     // global segment id = seg_base[view] + segment
-    uint32_t view, tgt_view, pair;
-    float dp1, dp2;    // depths of the owning view's segment end points
-    uint32_t inverse;  // 1: role-swapped copy of a match of an earlier view (line3D.cc:1682-1692)
-    uint32_t pad;
-};
-static_assert(sizeof(Entry) == 48, "Entry is 48 bytes");
-
 // transposed index entry: slot (pair, src_row, j) is a potential inverse hypothesis of its target segment
 struct InvRef {
     uint32_t src_view, src_row, pair, j;
@@ -126,7 +114,6 @@ struct DEntry {
 static_assert(sizeof(DEntry) == 64, "DEntry is 64 bytes");
 constexpr uint32_t kDInverse = 1u;   // inverse hypothesis (exists only if the source view scored it > 0)
 constexpr uint32_t kDZeroLen = 2u;   // unprojected segment shorter than L3D_EPS
-constexpr uint32_t kDAbsent = 4u;    // (LDS only) inverse hypothesis that does not exist
 constexpr uint32_t kDPresent = 8u;   // took part in scoring
 constexpr uint32_t kDKeep = 16u;     // survives filterMatches
 
