@@ -146,18 +146,21 @@ def main():
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # HBM traffic of one launch from the rocprofv3 PMC passes committed under profiles/ (PMC counters cannot
     # be collected from inside this process); only quoted when it was measured on this very workload
-    traffic = None
+    traffic, valu = None, None
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
         if tr["config"] == args.config and world == 1:
             traffic = tr["traffic_bytes_per_launch"]
+            # the roof that actually binds this kernel: VALU issue (SQ_ACTIVE_INST_VALU / SIMD cycles, PMC pass)
+            valu = {"bound": "valu", "busy_frac": tr["valu_busy_fraction"], "avg_waves_per_simd": tr["avg_waves_per_simd"],
+                    "valu_insts_per_wave": tr["valu_insts_per_wave"], "source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc)"}
     except Exception:
-        traffic = None
+        traffic, valu = None, None
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 6), "traffic": traffic, "algorithmic_bytes": algo_bytes,
                 "kernel": "k_match_pairs<0,false>", "kernel_ms": round(avg_ms, 4),
                 "kernel_pair_tests_per_s": round(my_tests / (avg_ms * 1e-3), 1) if avg_ms > 0 else 0.0,
-                "note": "VALU-issue bound by design (<0.2 B per pair test); see DESIGN.md roofline"}
+                "note": "VALU-issue bound by design (<0.2 B per pair test); see DESIGN.md roofline", "valu": valu}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
