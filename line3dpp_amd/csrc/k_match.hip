@@ -97,7 +97,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
                                                            const PairDesc* __restrict__ pairs,
                                                            const WorkItem* __restrict__ work, uint32_t nwork,
                                                            Slot* __restrict__ slots,
-                                                           uint32_t* __restrict__ row_counts, float thr) {
+                                                           uint32_t* __restrict__ row_counts, float thr,
+                                                           const CullPools cp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware order: consecutive work items (same pair => same target view) go to one XCD
     // (block b runs on XCD b % 8, MI355X_MICROARCH.md), so the target view stays in that XCD's L2.
@@ -112,8 +113,17 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
     Lds L = carve((L3D_LDS char*)smem, MODE == 0 ? K : 0);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     L3D_LDS volatile uint32_t* ring = L.ring + wave * kRing;
-    const uint32_t src = wi.src0 + tid;
-    const bool active = src < Ms;
+    // epipolar-band culling (kNN mode only: the keep-all rows must be filled in ascending target order)
+    const PairCull* pc = (MODE == 0 && !BRUTE && cp.cull && cp.cull[wi.pair].enabled) ? &cp.cull[wi.pair] : nullptr;
+    const bool cull = pc != nullptr;
+    const bool active = wi.src0 + tid < Ms;
+    uint32_t src = wi.src0 + tid;
+    float blo = __builtin_inff(), bhi = -__builtin_inff();   // this lane's tau band (empty for a dead lane)
+    if (cull && active) {
+        src = cp.src_perm[pc->s_off + wi.src0 + tid];
+        const float2 b = cp.src_band[pc->s_off + wi.src0 + tid];
+        blo = b.x; bhi = b.y;
+    }
 
     double F[9];
 #pragma unroll
@@ -143,6 +153,30 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
     L.minov[tid] = thr;
     L.claim[tid] = kEmpty;
     uint32_t head = 0, tail = 0;   // wave-uniform ring cursors
+    // tau band of the wave / of the block (hull of the live lanes)
+    float wlo = live ? blo : __builtin_inff(), whi = live ? bhi : -__builtin_inff();
+    float klo = wlo, khi = whi;
+    if (cull) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            wlo = fminf(wlo, __shfl_xor(wlo, o));
+            whi = fmaxf(whi, __shfl_xor(whi, o));
+        }
+        // exchange through the (still unused) rings; the barrier of the first tile load orders these reads
+        // before any ring write
+        L3D_LDS volatile float* x = (L3D_LDS volatile float*)L.ring;
+        if (lane == 0) { x[wave * kRing] = wlo; x[wave * kRing + 1] = whi; }
+        __syncthreads();
+        klo = fminf(fminf(x[0], x[kRing]), fminf(x[2 * kRing], x[3 * kRing]));
+        khi = fmaxf(fmaxf(x[1], x[kRing + 1]), fmaxf(x[2 * kRing + 1], x[3 * kRing + 1]));
+    }
+    // wave-uniform values: keep them in SGPRs so that the chunk tests are scalar branches
+    wlo = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(wlo)));
+    whi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(whi)));
+    klo = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(klo)));
+    khi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(khi)));
+    const uint32_t* __restrict__ tperm = cull ? cp.tgt_perm + pc->t_off : nullptr;
+    const float2* __restrict__ cband = cull ? cp.chunk_band + pc->c_off : nullptr;
 
     // worst entry of a full row under (overlap desc, tgt asc): pipelined (non-volatile) LDS reads
     auto rescan_worst = [&](uint32_t sl) {
@@ -163,23 +197,28 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
         const bool has = lane < n;
         const uint32_t ent = ring[(head + lane) & (kRing - 1)];
         head += n;
-        const uint32_t sl = ent >> 23, tg = ent & 0x7FFFFFu;
+        const uint32_t sl = ent >> 23;
+        uint32_t tg = ent & 0x7FFFFFu;
         bool pending = false;
         PairResult res{};
+        // the ring of a wave only holds rows of that wave: the source segment comes from the owning lane
+        const uint32_t sg = __shfl(src, sl & 63u);
         if (has) {
-            const uint32_t sg = wi.src0 + sl;
+            if (cull) tg = tperm[tg];
             const float4 s4 = vs.seg4[sg], t4 = vt.seg4[tg];
             const float ov = exact_overlap(F, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w);
-            // a full row only admits overlaps above its K-th best (a tie loses: candidates of a row arrive
-            // in ascending target order); minov == thr while the row is not full
+            // a full row only admits overlaps that beat its K-th best under (overlap desc, tgt asc); minov == thr
+            // while the row is not full.  Without culling the candidates of a row arrive in ascending target
+            // order and a tie always loses; with culling the order is arbitrary and the comparator at the
+            // insertion decides a tie.
             const float need = (MODE == 0) ? L.minov[sl] : thr;
-            if (ov > need) {
+            if (ov > need || (cull && ov == need && ov > thr)) {
                 res.overlap = ov;
                 pending = exact_depths(vs.segx[sg], vt.segx[tg], vs.C, vt.C, res);
             }
         }
-        // several candidates of one drain may belong to the same row: lowest lane first, so a row
-        // always sees its candidates in ascending target order
+        // several candidates of one drain may belong to the same row: one at a time, lowest lane first (without
+        // culling a row therefore sees its candidates in ascending target order, which MODE 2 relies on)
         while (__ballot(pending)) {
             if (pending) __hip_atomic_fetch_min((L3D_LDS uint32_t*)&L.claim[sl], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const bool win = pending && (L.claim[sl] == lane);
@@ -194,7 +233,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
                     o.tgt_seg = tg; o.overlap = res.overlap;
                     o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
                     o.score3D = 0.0f; o.flags = 0;
-                    if (c < K) slots[pd.slot_off + (uint64_t)(wi.src0 + sl) * K + c] = o;
+                    if (c < K) slots[pd.slot_off + (uint64_t)sg * K + c] = o;
                     L.cnt[sl] = c + 1;
                 } else {
                     L3D_LDS volatile float* ov = L.top_ov + (size_t)sl * K;
@@ -220,41 +259,60 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
     // ---- main loop: stream the target view through LDS ----
     // Branch-free per test: dead lanes evaluate the pre-filter on zeros and are masked out of the ballot;
     // the compaction prefix is v_mbcnt (population count of the ballot below this lane).
-    const SegF* __restrict__ tf = vt.segf;
+    const v4f* __restrict__ tf = cull ? (const v4f*)(cp.tgt_sf + pc->t_off) : (const v4f*)vt.segf;
     const uint32_t ent_hi = tid << 23;
     auto prefix = [&](uint64_t m) -> uint32_t {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     };
     for (uint32_t t0 = 0; t0 < Mt; t0 += kTile) {
         const uint32_t n = min((uint32_t)kTile, Mt - t0);
-        __syncthreads();
-        for (uint32_t i = tid; i < n; i += kBlock) L.tile[i] = *(const v4f*)&tf[t0 + i];
-        __syncthreads();
-        uint32_t j = 0;
-        for (; j + 4 <= n; j += 4) {
-            const v4f q0 = L.tile[j], q1 = L.tile[j + 1], q2 = L.tile[j + 2], q3 = L.tile[j + 3];
-            const bool c0 = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
-            const bool c1 = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL));
-            const bool c2 = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL));
-            const bool c3 = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q3, thrL));
-            const uint64_t m0 = __ballot(c0), m1 = __ballot(c1), m2 = __ballot(c2), m3 = __ballot(c3);
-            if (m0 | m1 | m2 | m3) {
-                const uint32_t tb = t0 + j;
-                if (m0) { if (c0) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | tb; tail += __popcll(m0); }
-                if (m1) { if (c1) ring[(tail + prefix(m1)) & (kRing - 1)] = ent_hi | (tb + 1); tail += __popcll(m1); }
-                if (m2) { if (c2) ring[(tail + prefix(m2)) & (kRing - 1)] = ent_hi | (tb + 2); tail += __popcll(m2); }
-                if (m3) { if (c3) ring[(tail + prefix(m3)) & (kRing - 1)] = ent_hi | (tb + 3); tail += __popcll(m3); }
-                while (tail - head >= 64) drain();
+        uint32_t wmask = 0xFFFFFFFFu;   // chunks of this tile the wave has to visit
+        if (cull) {
+            // block-uniform: skip the tile when none of its chunks can meet the block's band
+            bool need = false;
+            wmask = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < kTile / 64; ++c) {
+                if (c * 64 < n) {
+                    const float2 cb = cband[(t0 >> 6) + c];
+                    need |= !(cb.y < klo || cb.x > khi);
+                    wmask |= (cb.y < wlo || cb.x > whi) ? 0u : (1u << c);
+                }
             }
+            if (!need) continue;
         }
-        for (; j < n; ++j) {
-            const v4f q0 = L.tile[j];
-            const bool c0 = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
-            const uint64_t m0 = __ballot(c0);
-            if (m0) {
-                if (c0) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | (t0 + j);
-                tail += __popcll(m0);
-                while (tail - head >= 64) drain();
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += kBlock) L.tile[i] = tf[t0 + i];
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+            if (!((wmask >> (c0 >> 6)) & 1u)) continue;   // wave-uniform
+            const uint32_t ce = min(n, c0 + 64);
+            uint32_t j = c0;
+            for (; j + 4 <= ce; j += 4) {
+                const v4f q0 = L.tile[j], q1 = L.tile[j + 1], q2 = L.tile[j + 2], q3 = L.tile[j + 3];
+                const bool c0b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
+                const bool c1b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL));
+                const bool c2b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL));
+                const bool c3b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q3, thrL));
+                const uint64_t m0 = __ballot(c0b), m1 = __ballot(c1b), m2 = __ballot(c2b), m3 = __ballot(c3b);
+                if (m0 | m1 | m2 | m3) {
+                    const uint32_t tb = t0 + j;
+                    if (m0) { if (c0b) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | tb; tail += __popcll(m0); }
+                    if (m1) { if (c1b) ring[(tail + prefix(m1)) & (kRing - 1)] = ent_hi | (tb + 1); tail += __popcll(m1); }
+                    if (m2) { if (c2b) ring[(tail + prefix(m2)) & (kRing - 1)] = ent_hi | (tb + 2); tail += __popcll(m2); }
+                    if (m3) { if (c3b) ring[(tail + prefix(m3)) & (kRing - 1)] = ent_hi | (tb + 3); tail += __popcll(m3); }
+                    while (tail - head >= 64) drain();
+                }
+            }
+            for (; j < ce; ++j) {
+                const v4f q0 = L.tile[j];
+                const bool c0b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
+                const uint64_t m0 = __ballot(c0b);
+                if (m0) {
+                    if (c0b) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | (t0 + j);
+                    tail += __popcll(m0);
+                    while (tail - head >= 64) drain();
+                }
             }
         }
     }
@@ -302,7 +360,7 @@ size_t match_lds_bytes(int mode, uint32_t K) {
 
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,
                               const WorkItem* work, uint32_t nwork, uint32_t maxK, Slot* slots,
-                              uint32_t* row_counts, float thr, hipStream_t stream) {
+                              uint32_t* row_counts, float thr, CullPools pools, hipStream_t stream) {
     if (nwork == 0) return hipSuccess;
     const uint32_t grid = ((nwork + 7) / 8) * 8;
     const size_t lds = match_lds_bytes(mode, maxK);
@@ -312,12 +370,169 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
         if (e != hipSuccess) return e;                                                                    \
         hipLaunchKernelGGL((k_match_pairs<M, B>), dim3(grid), dim3(kBlock), lds, stream, views, pairs,    \
-                           work, nwork, slots, row_counts, thr);                                          \
+                           work, nwork, slots, row_counts, thr, pools);                                        \
     } while (0)
     if (mode == 0) { if (brute) L3D_LAUNCH(0, true); else L3D_LAUNCH(0, false); }
     else if (mode == 1) { if (brute) L3D_LAUNCH(1, true); else L3D_LAUNCH(1, false); }
     else { if (brute) L3D_LAUNCH(2, true); else L3D_LAUNCH(2, false); }
 #undef L3D_LAUNCH
+    return hipGetLastError();
+}
+
+// ---- epipolar-band culling: order the source rows and the target segments of each pair by tau ------------
+namespace {
+
+constexpr int kCullBlock = 1024;
+constexpr double kCullMinDen = 0.05;   // B.x of a usable point (B.centre == 1): the pencil line is not near-parallel
+                                       // to the transversal
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+
+struct Band { float lo, hi; uint32_t cls; };   // cls 0: unbounded, 1: widened by the direction term, 2: plain
+
+__device__ __forceinline__ Band make_band(double lo, double hi, uint32_t cls) {
+    Band b;
+    if (!(lo <= hi) || !(fabs(lo) < 1e30) || !(fabs(hi) < 1e30)) {   // NaN / overflow: never culled
+        b.lo = -__builtin_inff(); b.hi = __builtin_inff(); b.cls = 0;
+        return b;
+    }
+    // pad well beyond the fp64 rounding of tau and the fp32 rounding of the stored band
+    b.lo = (float)(lo - (0.01 + 1e-6 * fabs(lo)));
+    b.hi = (float)(hi + (0.01 + 1e-6 * fabs(hi)));
+    b.cls = cls;
+    return b;
+}
+
+// wedge of epipolar lines of a source segment: tau of F*p1 and F*p2
+__device__ __forceinline__ Band src_band(const PairCull& pc, const float4 s) {
+    const double d1 = pc.Bs[0] * s.x + pc.Bs[1] * s.y + pc.Bs[2];
+    const double d2 = pc.Bs[0] * s.z + pc.Bs[1] * s.w + pc.Bs[2];
+    if (!(d1 > kCullMinDen) || !(d2 > kCullMinDen)) return make_band(1.0, 0.0, 0);
+    const double t1 = (pc.As[0] * s.x + pc.As[1] * s.y + pc.As[2]) / d1;
+    const double t2 = (pc.As[0] * s.z + pc.As[1] * s.w + pc.As[2]) / d2;
+    return make_band(fmin(t1, t2), fmax(t1, t2), 2);
+}
+
+// pencil lines met by a target segment; widened to the pencil line parallel to it (tau of its direction) when
+// that line lies inside the span [slo, shi] of all source wedges: only then can a wedge contain the direction,
+// the one case in which the two intersection points enclose the segment from outside the tau interval
+__device__ __forceinline__ Band tgt_band(const PairCull& pc, const float4 s, float slo, float shi) {
+    const double d1 = pc.Bt[0] * s.x + pc.Bt[1] * s.y + pc.Bt[2];
+    const double d2 = pc.Bt[0] * s.z + pc.Bt[1] * s.w + pc.Bt[2];
+    if (!(d1 > kCullMinDen) || !(d2 > kCullMinDen)) return make_band(1.0, 0.0, 0);
+    const double t1 = (pc.At[0] * s.x + pc.At[1] * s.y + pc.At[2]) / d1;
+    const double t2 = (pc.At[0] * s.z + pc.At[1] * s.w + pc.At[2]) / d2;
+    double lo = fmin(t1, t2), hi = fmax(t1, t2);
+    const double dx = (double)s.z - (double)s.x, dy = (double)s.w - (double)s.y;
+    const double dd = pc.Bt[0] * dx + pc.Bt[1] * dy;
+    const double td = (pc.At[0] * dx + pc.At[1] * dy) / dd;   // +-inf: direction parallel to the transversal
+    uint32_t cls = 2;
+    if (!(td == td)) return make_band(1.0, 0.0, 0);            // zero-length segment
+    if (td >= (double)slo - 1.0 && td <= (double)shi + 1.0) { lo = fmin(lo, td); hi = fmax(hi, td); cls = 1; }
+    return make_band(lo, hi, cls);
+}
+
+// bitonic sort of n2 (power of two) 64-bit keys in LDS
+__device__ void lds_sort(uint64_t* keys, uint32_t n2) {
+    for (uint32_t k = 2; k <= n2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint64_t a = keys[i], b = keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+                }
+            }
+        }
+    __syncthreads();
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __restrict__ views,
+                                                             const PairDesc* __restrict__ pairs, uint32_t first,
+                                                             const CullPools cp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t p = first + blockIdx.x;
+    const PairCull& pc = cp.cull[p];
+    if (!pc.enabled) return;
+    const PairDesc& pd = pairs[p];
+    const ViewDev& vs = views[pd.src];
+    const ViewDev& vt = views[pd.tgt];
+    const uint32_t Ms = pd.Ms, Mt = pd.Mt;
+    uint32_t n2 = 64;
+    while (n2 < max(Ms, Mt)) n2 <<= 1;
+    uint64_t* keys = (uint64_t*)smem;
+    uint32_t* cb = (uint32_t*)(keys + n2);       // [2 * n2/64] chunk bands, orderable floats
+    __shared__ uint32_t span[2];
+    const uint32_t tid = threadIdx.x;
+
+    // ---- source rows: key = (class, lo, row) ----
+    if (tid == 0) { span[0] = 0xFFFFFFFFu; span[1] = 0u; }
+    __syncthreads();
+    for (uint32_t i = tid; i < n2; i += kCullBlock) {
+        uint64_t key = ~0ull;
+        if (i < Ms) {
+            const Band b = src_band(pc, vs.seg4[i]);
+            key = ((uint64_t)b.cls << 56) | ((uint64_t)f2ord(b.lo) << 24) | i;
+            if (b.cls) { atomicMin(&span[0], f2ord(b.lo)); atomicMax(&span[1], f2ord(b.hi)); }
+        }
+        keys[i] = key;
+    }
+    lds_sort(keys, n2);
+    for (uint32_t i = tid; i < Ms; i += kCullBlock) {
+        const uint32_t row = (uint32_t)(keys[i] & 0xFFFFFFu);
+        const Band b = src_band(pc, vs.seg4[row]);
+        cp.src_perm[pc.s_off + i] = row;
+        cp.src_band[pc.s_off + i] = make_float2(b.lo, b.hi);
+    }
+    // span of all bounded source wedges (empty: no bounded row -> nothing can be widened, nothing is culled
+    // either because every row band is unbounded)
+    const float slo = ord2f(span[0]), shi = ord2f(span[1]);
+    __syncthreads();
+
+    // ---- target segments ----
+    const uint32_t nchunk = (Mt + 63) / 64;
+    for (uint32_t i = tid; i < nchunk; i += kCullBlock) { cb[2 * i] = 0xFFFFFFFFu; cb[2 * i + 1] = 0u; }
+    for (uint32_t i = tid; i < n2; i += kCullBlock) {
+        uint64_t key = ~0ull;
+        if (i < Mt) {
+            const Band b = tgt_band(pc, vt.seg4[i], slo, shi);
+            key = ((uint64_t)b.cls << 56) | ((uint64_t)f2ord(b.lo) << 24) | i;
+        }
+        keys[i] = key;
+    }
+    lds_sort(keys, n2);
+    for (uint32_t i = tid; i < Mt; i += kCullBlock) {
+        const uint32_t seg = (uint32_t)(keys[i] & 0xFFFFFFu);
+        const Band b = tgt_band(pc, vt.seg4[seg], slo, shi);
+        cp.tgt_perm[pc.t_off + i] = seg;
+        cp.tgt_sf[pc.t_off + i] = *(const float4*)&vt.segf[seg];
+        atomicMin(&cb[2 * (i >> 6)], f2ord(b.lo));
+        atomicMax(&cb[2 * (i >> 6) + 1], f2ord(b.hi));
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nchunk; i += kCullBlock)
+        cp.chunk_band[pc.c_off + i] = make_float2(ord2f(cb[2 * i]), ord2f(cb[2 * i + 1]));
+}
+
+hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
+                               uint32_t max_M, CullPools pools, hipStream_t stream) {
+    if (!count || !pools.cull) return hipSuccess;
+    uint32_t n2 = 64;
+    while (n2 < max_M) n2 <<= 1;
+    const size_t lds = (size_t)n2 * 8 + (size_t)(n2 / 64) * 8;
+    hipError_t e = hipFuncSetAttribute((const void*)k_cull_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_cull_prepare, dim3(count), dim3(kCullBlock), lds, stream, views, pairs, first, pools);
     return hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
 // (line3D.cc:112-227, 375-497, 702-778, 1749-1778, 1852-1979).  No CPU fallback exists: every
 // compute step is a HIP kernel launch; without a usable device the calls fail with L3D_ERR_HIP.
 #include <algorithm>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
 
@@ -89,6 +90,13 @@ struct l3d_ctx {
     DevBuf<PairDesc> d_pairs;
     DevBuf<WorkItem> d_work;
     DevBuf<Slot> d_slots;
+    // epipolar-band culling pools (l3d_kernels.h)
+    std::vector<PairCull> cull;
+    DevBuf<PairCull> d_cull;
+    DevBuf<uint32_t> d_src_perm, d_tgt_perm;
+    DevBuf<float2> d_src_band, d_chunk_band;
+    DevBuf<float4> d_tgt_sf;
+    bool use_cull = true;
     DevBuf<uint32_t> d_row_counts;
     // phase B (global over all views; G = sum of M)
     uint32_t G = 0, n_ents = 0, n_surv = 0, n_hyps = 0;
@@ -188,6 +196,62 @@ void fundamental(const HostView& s, const HostView& t, double F[9]) {
     std::memcpy(F, Fm.m, 72);
 }
 
+// Epipolar-band culling set-up for one directed pair (k_match.hip / l3d_kernels.h PairCull): the epipole e in the
+// target image is the left null vector of F; the transversal runs through the target image centre c,
+// perpendicular to the direction from c towards e.  tau(x) is where the pencil line through x crosses it:
+//     target point/direction q:  l = e x q,  tau = -(l.c)/(l.n) = (At.q)/(Bt.q),  At = e x c, Bt = n x e
+//     source point p:            l = F p,    tau = -(l.c)/(l.n) = (As.p)/(Bs.p),  As = -F^T c, Bs = F^T n
+// Culling is only enabled when both denominators keep one sign (with margin) over the respective image, i.e.
+// no epipolar line that can occur is near-parallel to the transversal -- otherwise the pair streams unculled.
+void make_cull(const double F[9], double ws, double hs, double wt, double ht, PairCull& pc) {
+    pc.enabled = 0;
+    auto col = [&](int j) { return d3{F[j], F[3 + j], F[6 + j]}; };
+    double fn = 0;
+    for (int i = 0; i < 9; ++i) fn = std::fmax(fn, std::fabs(F[i]));
+    if (!(fn > 0.0) || !std::isfinite(fn)) return;
+    d3 e{0, 0, 0}; double best = 0;
+    const int pr[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (auto& q : pr) {
+        const d3 x = cross(col(q[0]), col(q[1]));
+        const double n = norm(x);
+        if (n > best) { best = n; e = x; }
+    }
+    if (!(best > 1e-30 * fn * fn)) return;
+    e = e * (1.0 / best);
+    for (int j = 0; j < 3; ++j)   // rank check: e^T F == 0 (all lines F p concurrent in e)
+        if (std::fabs(dot(e, col(j))) > 1e-10 * norm(col(j)) + 1e-300) return;
+    const d3 c{0.5 * wt, 0.5 * ht, 1.0};
+    double mx = e.x - c.x * e.z, my = e.y - c.y * e.z;          // direction centre -> epipole (up to sign)
+    const double ml = std::sqrt(mx * mx + my * my);
+    if (!(ml > 1e-12 * (std::fabs(e.x) + std::fabs(e.y) + std::fabs(e.z)))) return;
+    mx /= ml; my /= ml;
+    const d3 n{-my, mx, 0.0};
+    d3 At = cross(e, c), Bt = cross(n, e);
+    const double st = dot(Bt, c);
+    if (!(std::fabs(st) > 1e-300)) return;
+    At = At * (1.0 / st); Bt = Bt * (1.0 / st);
+    // As = -F^T c, Bs = F^T n
+    d3 As{-(F[0] * c.x + F[3] * c.y + F[6] * c.z), -(F[1] * c.x + F[4] * c.y + F[7] * c.z),
+          -(F[2] * c.x + F[5] * c.y + F[8] * c.z)};
+    d3 Bs{F[0] * n.x + F[3] * n.y, F[1] * n.x + F[4] * n.y, F[2] * n.x + F[5] * n.y};
+    const d3 cs{0.5 * ws, 0.5 * hs, 1.0};
+    const double ss = dot(Bs, cs);
+    if (!(std::fabs(ss) > 1e-300)) return;
+    As = As * (1.0 / ss); Bs = Bs * (1.0 / ss);
+    auto ok = [](const d3& B, double w, double h) {
+        const double mw = 0.05 * w, mh = 0.05 * h;
+        const double xs[2] = {-mw, w + mw}, ys[2] = {-mh, h + mh};
+        for (double x : xs) for (double y : ys) if (!(B.x * x + B.y * y + B.z >= 0.1)) return false;
+        return true;
+    };
+    if (!ok(Bt, wt, ht) || !ok(Bs, ws, hs)) return;
+    for (double v : {At.x, At.y, At.z, Bt.x, Bt.y, Bt.z, As.x, As.y, As.z, Bs.x, Bs.y, Bs.z})
+        if (!std::isfinite(v)) return;
+    pc.As[0] = As.x; pc.As[1] = As.y; pc.As[2] = As.z; pc.Bs[0] = Bs.x; pc.Bs[1] = Bs.y; pc.Bs[2] = Bs.z;
+    pc.At[0] = At.x; pc.At[1] = At.y; pc.At[2] = At.z; pc.Bt[0] = Bt.x; pc.Bt[1] = Bt.y; pc.Bt[2] = Bt.z;
+    pc.enabled = 1;
+}
+
 int upload_views(l3d_ctx& c) {
     const size_t V = c.order.size();
     L3D_HIP_CHECK(c.d_views.reserve(V));
@@ -241,6 +305,7 @@ l3d_ctx* l3d_create(int device, void* stream) {
     c->device = device;
     c->stream = (hipStream_t)stream;
     orientation_thresholds(c->orient_lo, c->orient_hi);
+    c->use_cull = std::getenv("L3D_NO_CULL") == nullptr;   // diagnostic switch: stream every pair unculled
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); delete c; return nullptr; }
     return c;
@@ -255,6 +320,8 @@ void l3d_destroy(l3d_ctx* c) {
         v.d_seg4.release(); v.d_segf.release(); v.d_segx.release();
     }
     c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release();
+    c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
+    c->d_chunk_band.release(); c->d_tgt_sf.release();
     c->d_row_counts.release();
     c->d_seg_base.release(); c->d_gseg_view.release(); c->d_cnt.release(); c->d_off.release(); c->d_cur.release();
     c->d_scan_tmp.release(); c->d_scal.release(); c->d_max_score.release(); c->d_surv_cnt.release();
@@ -352,7 +419,8 @@ int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
             for (uint32_t n : v->fixed_nbrs)
                 if (c->views.count(n)) v->visual_nbrs.insert(n);
     // directed pair list, line3D.cc:704-741
-    c->pairs.clear(); c->pair_src_cam.clear(); c->pair_tgt_cam.clear();
+    c->pairs.clear(); c->pair_src_cam.clear(); c->pair_tgt_cam.clear(); c->cull.clear();
+    uint64_t cs_off = 0, ct_off = 0; uint32_t cc_off = 0;
     std::map<uint32_t, std::set<uint32_t>> matched;
     uint64_t slot_off = 0; uint32_t row_off = 0;
     c->pair_tests = 0;
@@ -370,6 +438,12 @@ int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
             v->out_pairs.push_back(pi);
             if (t->index > v->index) t->in_pairs.push_back(pi);   // inverse only if tgt not yet processed (:1680)
             c->pairs.push_back(pd);
+            PairCull pc{};
+            if (c->use_cull && c->kNN > 0 && pd.Ms <= kCullMaxSegs && pd.Mt <= kCullMaxSegs && pd.Ms && pd.Mt)
+                make_cull(pd.F, v->width, v->height, t->width, t->height, pc);
+            pc.s_off = cs_off; pc.t_off = ct_off; pc.c_off = cc_off;
+            if (pc.enabled) { cs_off += pd.Ms; ct_off += pd.Mt; cc_off += (pd.Mt + 63) / 64; }
+            c->cull.push_back(pc);
             c->pair_src_cam.push_back(v->cam); c->pair_tgt_cam.push_back(tcam);
             c->pair_tests += (uint64_t)pd.Ms * pd.Mt;
             matched[v->cam].insert(tcam); matched[tcam].insert(v->cam);
@@ -383,6 +457,14 @@ int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
         L3D_HIP_CHECK(hipMemcpy(c->d_pairs.p, c->pairs.data(), c->pairs.size() * sizeof(PairDesc),
                                 hipMemcpyHostToDevice));
     if (c->kNN > 0) L3D_HIP_CHECK(c->d_slots.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    L3D_HIP_CHECK(c->d_cull.reserve(std::max<size_t>(c->cull.size(), 1)));
+    if (!c->cull.empty())
+        L3D_HIP_CHECK(hipMemcpy(c->d_cull.p, c->cull.data(), c->cull.size() * sizeof(PairCull), hipMemcpyHostToDevice));
+    L3D_HIP_CHECK(c->d_src_perm.reserve(std::max<uint64_t>(cs_off, 1)));
+    L3D_HIP_CHECK(c->d_src_band.reserve(std::max<uint64_t>(cs_off, 1)));
+    L3D_HIP_CHECK(c->d_tgt_perm.reserve(std::max<uint64_t>(ct_off, 1)));
+    L3D_HIP_CHECK(c->d_tgt_sf.reserve(std::max<uint64_t>(ct_off, 1)));
+    L3D_HIP_CHECK(c->d_chunk_band.reserve(std::max<uint32_t>(cc_off, 1)));
     L3D_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
     c->tm = l3d_timings{};
     c->state = l3d_ctx::BEGUN;
@@ -407,10 +489,11 @@ int l3d_get_pairs(l3d_ctx* c, uint32_t* s, uint32_t* t, uint64_t* off) {
 
 static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count) {
     std::vector<WorkItem> work;
-    uint32_t maxK = 0;
+    uint32_t maxK = 0, maxM = 0;
     for (uint32_t p = first; p < first + count; ++p) {
         const PairDesc& pd = c->pairs[p];
         maxK = std::max(maxK, pd.K);
+        if (c->cull[p].enabled) maxM = std::max(maxM, std::max(pd.Ms, pd.Mt));
         for (uint32_t s0 = 0; s0 < pd.Ms; s0 += 256) work.push_back(WorkItem{p, s0});
     }
     if (work.empty()) return L3D_OK;
@@ -420,8 +503,11 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
                                  c->stream));
     L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
     L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
+    CullPools pools{c->d_cull.p, c->d_src_perm.p, c->d_src_band.p, c->d_tgt_perm.p, c->d_tgt_sf.p, c->d_chunk_band.p};
+    if (mode != 0 || c->brute || !maxM) pools.cull = nullptr;
+    else L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
     L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)work.size(),
-                                     maxK, c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, c->stream));
+                                     maxK, c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, c->stream));
     L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));
     L3D_HIP_CHECK(hipEventSynchronize(c->ev[5]));
     c->tm.match_kernel_ms += ev_ms(c->ev[4], c->ev[5]);
@@ -935,7 +1021,8 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         L3D_HIP_CHECK(hipMemcpy(dp.p, &pd, sizeof(pd), hipMemcpyHostToDevice));
         L3D_HIP_CHECK(hipMemcpy(dw.p, work.data(), work.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
         const float thr = std::fmin(std::fabs(epi_overlap), 0.99f);
-        L3D_HIP_CHECK(launch_match_pairs(0, false, dv.p, dp.p, dw.p, (uint32_t)work.size(), pd.K, ds.p, nullptr, thr, 0));
+        L3D_HIP_CHECK(launch_match_pairs(0, false, dv.p, dp.p, dw.p, (uint32_t)work.size(), pd.K, ds.p, nullptr, thr,
+                                         CullPools{}, 0));
         L3D_HIP_CHECK(hipDeviceSynchronize());
         L3D_HIP_CHECK(hipMemcpy(out_slots, ds.p, (size_t)Ms * pd.K * sizeof(Slot), hipMemcpyDeviceToHost));
         return L3D_OK;

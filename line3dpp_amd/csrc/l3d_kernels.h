@@ -9,11 +9,35 @@ struct WorkItem {
     uint32_t src0;  // first source segment of the block
 };
 
+// Epipolar-band culling (k_match.hip): per directed pair, the pencil of epipolar lines in the target image
+// is parametrised by tau = (A.x)/(B.x), the coordinate at which the pencil line through x crosses a fixed
+// transversal through the image centre.  Source rows and target segments are ordered by tau so that a wave
+// can skip whole 64-segment chunks of targets whose tau band cannot meet the bands of its rows.
+struct PairCull {
+    double As[3], Bs[3];   // tau of the epipolar line F*p of a source point p: (As.p)/(Bs.p), Bs.centre == 1
+    double At[3], Bt[3];   // tau of a target point / direction q: (At.q)/(Bt.q), Bt.centre == 1
+    uint64_t s_off;        // first entry of this pair in the source pools
+    uint64_t t_off;        // first entry in the target pools
+    uint32_t c_off;        // first chunk band
+    uint32_t enabled;      // 0: geometry not suited (epipole in/near the image, degenerate F) -> plain streaming
+};
+struct CullPools {
+    const PairCull* cull;      // [n_pairs] or nullptr
+    uint32_t* src_perm;        // [sum Ms] source row visited at sorted position i
+    float2* src_band;          // [sum Ms] its tau band (lo, hi)
+    uint32_t* tgt_perm;        // [sum Mt] target segment at sorted position i
+    float4* tgt_sf;            // [sum Mt] SegF records in sorted order
+    float2* chunk_band;        // [sum ceil(Mt/64)] tau band of each 64-record chunk
+};
+constexpr uint32_t kCullMaxSegs = 16384;   // LDS sort capacity of k_cull_prepare
+
 // ---- k_match.hip ----
 size_t match_lds_bytes(int mode, uint32_t K);
+hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
+                               uint32_t max_M, CullPools pools, hipStream_t stream);
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,
                               const WorkItem* work, uint32_t nwork, uint32_t maxK, Slot* slots,
-                              uint32_t* row_counts, float thr, hipStream_t stream);
+                              uint32_t* row_counts, float thr, CullPools pools, hipStream_t stream);
 hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, hipStream_t stream);
 
 }  // namespace l3d
