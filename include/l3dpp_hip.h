@@ -186,6 +186,8 @@ typedef struct l3d_timings {
     float affinity_ms;
     uint32_t match_kernel_launches;
     float match_kernel_ms; /* the pair-matching kernel alone */
+    float cull_prepare_ms; /* ordering of rows/targets by epipolar band (part of match_pairs_ms) */
+    uint32_t culled_pairs; /* directed pairs matched with epipolar-band culling in the last matchImages */
 } l3d_timings;
 int l3d_get_timings(l3d_ctx*, l3d_timings*);
 

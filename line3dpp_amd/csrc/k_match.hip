@@ -38,6 +38,12 @@ constexpr float kKappa0 = 2.0e-4f;
 // or a lambda capture loses it and every access becomes a flat_load/flat_store (plus, for volatile, sc0 sc1
 // and an immediate s_waitcnt) instead of ds_read/ds_write.
 #define L3D_LDS __attribute__((address_space(3)))
+#ifdef L3D_STATS
+__device__ unsigned long long g_stats[8];   // 0 pre-filter tests, 1 candidates, 2 passed overlap, 3 accepted, 4 drains
+#define L3D_STAT(i, n) atomicAdd(&g_stats[i], (unsigned long long)(n))
+#else
+#define L3D_STAT(i, n) ((void)0)
+#endif
 typedef float v4f __attribute__((ext_vector_type(4)));
 struct Lds {
     L3D_LDS v4f* tile;                 // [kTile]
@@ -177,6 +183,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
     khi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(khi)));
     const uint32_t* __restrict__ tperm = cull ? cp.tgt_perm + pc->t_off : nullptr;
     const float2* __restrict__ cband = cull ? cp.chunk_band + pc->c_off : nullptr;
+    const float2* __restrict__ tband = cull ? cp.tgt_band + pc->t_off : nullptr;
 
     // worst entry of a full row under (overlap desc, tgt asc): pipelined (non-volatile) LDS reads
     auto rescan_worst = [&](uint32_t sl) {
@@ -195,6 +202,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
     auto drain = [&]() {
         const uint32_t n = min(64u, tail - head);
         const bool has = lane < n;
+        if (lane == 0) { L3D_STAT(1, n); L3D_STAT(4, 1); }
         const uint32_t ent = ring[(head + lane) & (kRing - 1)];
         head += n;
         const uint32_t sl = ent >> 23;
@@ -214,7 +222,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
             const float need = (MODE == 0) ? L.minov[sl] : thr;
             if (ov > need || (cull && ov == need && ov > thr)) {
                 res.overlap = ov;
+                L3D_STAT(2, 1);
                 pending = exact_depths(vs.segx[sg], vt.segx[tg], vs.C, vt.C, res);
+                if (pending) L3D_STAT(3, 1);
             }
         }
         // several candidates of one drain may belong to the same row: one at a time, lowest lane first (without
@@ -284,35 +294,67 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
         __syncthreads();
         for (uint32_t i = tid; i < n; i += kBlock) L.tile[i] = tf[t0 + i];
         __syncthreads();
-        for (uint32_t c0 = 0; c0 < n; c0 += 64) {
-            if (!((wmask >> (c0 >> 6)) & 1u)) continue;   // wave-uniform
-            const uint32_t ce = min(n, c0 + 64);
-            uint32_t j = c0;
-            for (; j + 4 <= ce; j += 4) {
-                const v4f q0 = L.tile[j], q1 = L.tile[j + 1], q2 = L.tile[j + 2], q3 = L.tile[j + 3];
-                const bool c0b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
-                const bool c1b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL));
-                const bool c2b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL));
-                const bool c3b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q3, thrL));
-                const uint64_t m0 = __ballot(c0b), m1 = __ballot(c1b), m2 = __ballot(c2b), m3 = __ballot(c3b);
-                if (m0 | m1 | m2 | m3) {
-                    const uint32_t tb = t0 + j;
-                    if (m0) { if (c0b) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | tb; tail += __popcll(m0); }
-                    if (m1) { if (c1b) ring[(tail + prefix(m1)) & (kRing - 1)] = ent_hi | (tb + 1); tail += __popcll(m1); }
-                    if (m2) { if (c2b) ring[(tail + prefix(m2)) & (kRing - 1)] = ent_hi | (tb + 2); tail += __popcll(m2); }
-                    if (m3) { if (c3b) ring[(tail + prefix(m3)) & (kRing - 1)] = ent_hi | (tb + 3); tail += __popcll(m3); }
-                    while (tail - head >= 64) drain();
+        if (cull) {
+            // per-target culling inside the chunks the wave visits: one band per lane -> ballot -> the wave walks
+            // the set bits (ascending), four targets per step
+            float2 bn = make_float2(__builtin_inff(), -__builtin_inff());
+            if (t0 + lane < Mt) bn = tband[t0 + lane];
+            for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+                const float2 b = bn;
+                const uint32_t nx = t0 + c0 + 64 + lane;
+                bn = make_float2(__builtin_inff(), -__builtin_inff());
+                if (c0 + 64 < n && nx < Mt) bn = tband[nx];
+                if (!((wmask >> (c0 >> 6)) & 1u)) continue;   // wave-uniform
+                uint64_t m = __ballot(!(b.y < wlo || b.x > whi));
+                while (m) {
+                    const uint32_t j0 = __builtin_ctzll(m); m &= m - 1;
+                    const bool v1 = m != 0; const uint32_t j1 = v1 ? __builtin_ctzll(m) : j0; m &= m - 1;
+                    const bool v2 = m != 0; const uint32_t j2 = v2 ? __builtin_ctzll(m) : j0; m &= m - 1;
+                    const bool v3 = m != 0; const uint32_t j3 = v3 ? __builtin_ctzll(m) : j0; m &= m - 1;
+                    const v4f q0 = L.tile[c0 + j0], q1 = L.tile[c0 + j1], q2 = L.tile[c0 + j2], q3 = L.tile[c0 + j3];
+                    const bool c0b = live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL);
+                    const bool c1b = v1 & live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL);
+                    const bool c2b = v2 & live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL);
+                    const bool c3b = v3 & live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q3, thrL);
+                    const uint64_t m0 = __ballot(c0b), m1 = __ballot(c1b), m2 = __ballot(c2b), m3 = __ballot(c3b);
+                    if (lane == 0) L3D_STAT(0, 64 * (1 + v1 + v2 + v3));
+                    if (m0 | m1 | m2 | m3) {
+                        const uint32_t tb = t0 + c0;
+                        if (m0) { if (c0b) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | (tb + j0); tail += __popcll(m0); }
+                        if (m1) { if (c1b) ring[(tail + prefix(m1)) & (kRing - 1)] = ent_hi | (tb + j1); tail += __popcll(m1); }
+                        if (m2) { if (c2b) ring[(tail + prefix(m2)) & (kRing - 1)] = ent_hi | (tb + j2); tail += __popcll(m2); }
+                        if (m3) { if (c3b) ring[(tail + prefix(m3)) & (kRing - 1)] = ent_hi | (tb + j3); tail += __popcll(m3); }
+                        while (tail - head >= 64) drain();
+                    }
                 }
             }
-            for (; j < ce; ++j) {
-                const v4f q0 = L.tile[j];
-                const bool c0b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
-                const uint64_t m0 = __ballot(c0b);
-                if (m0) {
-                    if (c0b) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | (t0 + j);
-                    tail += __popcll(m0);
-                    while (tail - head >= 64) drain();
-                }
+            continue;
+        }
+        uint32_t j = 0;
+        for (; j + 4 <= n; j += 4) {
+            const v4f q0 = L.tile[j], q1 = L.tile[j + 1], q2 = L.tile[j + 2], q3 = L.tile[j + 3];
+            const bool c0b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
+            const bool c1b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL));
+            const bool c2b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL));
+            const bool c3b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q3, thrL));
+            const uint64_t m0 = __ballot(c0b), m1 = __ballot(c1b), m2 = __ballot(c2b), m3 = __ballot(c3b);
+            if (m0 | m1 | m2 | m3) {
+                const uint32_t tb = t0 + j;
+                if (m0) { if (c0b) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | tb; tail += __popcll(m0); }
+                if (m1) { if (c1b) ring[(tail + prefix(m1)) & (kRing - 1)] = ent_hi | (tb + 1); tail += __popcll(m1); }
+                if (m2) { if (c2b) ring[(tail + prefix(m2)) & (kRing - 1)] = ent_hi | (tb + 2); tail += __popcll(m2); }
+                if (m3) { if (c3b) ring[(tail + prefix(m3)) & (kRing - 1)] = ent_hi | (tb + 3); tail += __popcll(m3); }
+                while (tail - head >= 64) drain();
+            }
+        }
+        for (; j < n; ++j) {
+            const v4f q0 = L.tile[j];
+            const bool c0b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
+            const uint64_t m0 = __ballot(c0b);
+            if (m0) {
+                if (c0b) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | (t0 + j);
+                tail += __popcll(m0);
+                while (tail - head >= 64) drain();
             }
         }
     }
@@ -344,7 +386,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
         for (uint32_t i = 0; i < c; ++i) rank += better(ov[i], ix[i], oj, xj) ? 1u : 0u;
         PairResult res{};
         const SegX tx = vt.segx[xj];
+#ifndef L3D_EXP_NOEPI
         exact_depths(sx, tx, vs.C, vt.C, res);
+#endif
         Slot o;
         o.tgt_seg = xj; o.overlap = oj;
         o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
@@ -516,6 +560,7 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
         const Band b = tgt_band(pc, vt.seg4[seg], slo, shi);
         cp.tgt_perm[pc.t_off + i] = seg;
         cp.tgt_sf[pc.t_off + i] = *(const float4*)&vt.segf[seg];
+        cp.tgt_band[pc.t_off + i] = make_float2(b.lo, b.hi);
         atomicMin(&cb[2 * (i >> 6)], f2ord(b.lo));
         atomicMax(&cb[2 * (i >> 6) + 1], f2ord(b.hi));
     }
@@ -571,3 +616,10 @@ hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t ma
 }
 
 }  // namespace l3d
+
+#ifdef L3D_STATS
+extern "C" void l3d_debug_stats(unsigned long long* out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(l3d::g_stats), sizeof(l3d::g_stats));
+    if (reset) { unsigned long long z[8] = {}; hipMemcpyToSymbol(HIP_SYMBOL(l3d::g_stats), z, sizeof(z)); }
+}
+#endif

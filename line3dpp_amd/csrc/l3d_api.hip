@@ -94,7 +94,7 @@ struct l3d_ctx {
     std::vector<PairCull> cull;
     DevBuf<PairCull> d_cull;
     DevBuf<uint32_t> d_src_perm, d_tgt_perm;
-    DevBuf<float2> d_src_band, d_chunk_band;
+    DevBuf<float2> d_src_band, d_chunk_band, d_tgt_band;
     DevBuf<float4> d_tgt_sf;
     bool use_cull = true;
     DevBuf<uint32_t> d_row_counts;
@@ -321,7 +321,7 @@ void l3d_destroy(l3d_ctx* c) {
     }
     c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release();
     c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
-    c->d_chunk_band.release(); c->d_tgt_sf.release();
+    c->d_chunk_band.release(); c->d_tgt_sf.release(); c->d_tgt_band.release();
     c->d_row_counts.release();
     c->d_seg_base.release(); c->d_gseg_view.release(); c->d_cnt.release(); c->d_off.release(); c->d_cur.release();
     c->d_scan_tmp.release(); c->d_scal.release(); c->d_max_score.release(); c->d_surv_cnt.release();
@@ -464,6 +464,7 @@ int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
     L3D_HIP_CHECK(c->d_src_band.reserve(std::max<uint64_t>(cs_off, 1)));
     L3D_HIP_CHECK(c->d_tgt_perm.reserve(std::max<uint64_t>(ct_off, 1)));
     L3D_HIP_CHECK(c->d_tgt_sf.reserve(std::max<uint64_t>(ct_off, 1)));
+    L3D_HIP_CHECK(c->d_tgt_band.reserve(std::max<uint64_t>(ct_off, 1)));
     L3D_HIP_CHECK(c->d_chunk_band.reserve(std::max<uint32_t>(cc_off, 1)));
     L3D_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
     c->tm = l3d_timings{};
@@ -502,15 +503,20 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     L3D_HIP_CHECK(hipMemcpyAsync(c->d_work.p, work.data(), work.size() * sizeof(WorkItem), hipMemcpyHostToDevice,
                                  c->stream));
     L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
-    L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
-    CullPools pools{c->d_cull.p, c->d_src_perm.p, c->d_src_band.p, c->d_tgt_perm.p, c->d_tgt_sf.p, c->d_chunk_band.p};
+    L3D_HIP_CHECK(hipEventRecord(c->ev[6], c->stream));
+    CullPools pools{c->d_cull.p, c->d_src_perm.p, c->d_src_band.p, c->d_tgt_perm.p, c->d_tgt_sf.p, c->d_tgt_band.p,
+                    c->d_chunk_band.p};
     if (mode != 0 || c->brute || !maxM) pools.cull = nullptr;
     else L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
+    L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
     L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)work.size(),
                                      maxK, c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, c->stream));
     L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));
     L3D_HIP_CHECK(hipEventSynchronize(c->ev[5]));
     c->tm.match_kernel_ms += ev_ms(c->ev[4], c->ev[5]);
+    c->tm.cull_prepare_ms += ev_ms(c->ev[6], c->ev[4]);
+    if (pools.cull)
+        for (uint32_t p = first; p < first + count; ++p) c->tm.culled_pairs += c->cull[p].enabled;
     c->tm.match_kernel_launches += 1;
     return L3D_OK;
 }
@@ -991,9 +997,11 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
     const double* Cc[2] = {C_src, C_tgt};
     DevBuf<float4> seg4[2]; DevBuf<SegF> segf[2]; DevBuf<SegX> segx[2];
     DevBuf<double> consts; DevBuf<ViewDev> dv; DevBuf<PairDesc> dp; DevBuf<WorkItem> dw; DevBuf<Slot> ds;
+    DevBuf<PairCull> dc; DevBuf<uint32_t> sperm, tperm; DevBuf<float2> sband, tband, cband; DevBuf<float4> tsf;
     auto cleanup = [&]() {
         for (int i = 0; i < 2; ++i) { seg4[i].release(); segf[i].release(); segx[i].release(); }
         consts.release(); dv.release(); dp.release(); dw.release(); ds.release();
+        dc.release(); sperm.release(); tperm.release(); sband.release(); tband.release(); cband.release(); tsf.release();
     };
     int rc = [&]() -> int {
         ViewDev hv[2];
@@ -1021,8 +1029,21 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         L3D_HIP_CHECK(hipMemcpy(dp.p, &pd, sizeof(pd), hipMemcpyHostToDevice));
         L3D_HIP_CHECK(hipMemcpy(dw.p, work.data(), work.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
         const float thr = std::fmin(std::fabs(epi_overlap), 0.99f);
+        // epipolar-band culling when F is a proper fundamental matrix and the epipoles are well outside the images
+        PairCull pc{};
+        if (Ms <= kCullMaxSegs && Mt <= kCullMaxSegs && std::getenv("L3D_NO_CULL") == nullptr)
+            make_cull(pd.F, width, height, width, height, pc);
+        CullPools pools{};
+        if (pc.enabled) {
+            L3D_HIP_CHECK(dc.reserve(1)); L3D_HIP_CHECK(sperm.reserve(Ms)); L3D_HIP_CHECK(sband.reserve(Ms));
+            L3D_HIP_CHECK(tperm.reserve(Mt)); L3D_HIP_CHECK(tsf.reserve(Mt)); L3D_HIP_CHECK(tband.reserve(Mt));
+            L3D_HIP_CHECK(cband.reserve((Mt + 63) / 64));
+            L3D_HIP_CHECK(hipMemcpy(dc.p, &pc, sizeof(pc), hipMemcpyHostToDevice));
+            pools = CullPools{dc.p, sperm.p, sband.p, tperm.p, tsf.p, tband.p, cband.p};
+            L3D_HIP_CHECK(launch_cull_prepare(dv.p, dp.p, 0, 1, std::max(Ms, Mt), pools, 0));
+        }
         L3D_HIP_CHECK(launch_match_pairs(0, false, dv.p, dp.p, dw.p, (uint32_t)work.size(), pd.K, ds.p, nullptr, thr,
-                                         CullPools{}, 0));
+                                         pools, 0));
         L3D_HIP_CHECK(hipDeviceSynchronize());
         L3D_HIP_CHECK(hipMemcpy(out_slots, ds.p, (size_t)Ms * pd.K * sizeof(Slot), hipMemcpyDeviceToHost));
         return L3D_OK;

@@ -27,6 +27,7 @@ struct CullPools {
     float2* src_band;          // [sum Ms] its tau band (lo, hi)
     uint32_t* tgt_perm;        // [sum Mt] target segment at sorted position i
     float4* tgt_sf;            // [sum Mt] SegF records in sorted order
+    float2* tgt_band;          // [sum Mt] their tau bands
     float2* chunk_band;        // [sum ceil(Mt/64)] tau band of each 64-record chunk
 };
 constexpr uint32_t kCullMaxSegs = 16384;   // LDS sort capacity of k_cull_prepare

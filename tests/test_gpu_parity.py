@@ -95,6 +95,43 @@ def test_prefilter_never_loses_a_match():
         assert sum(int((a["tgt_seg"] != EMPTY).sum()) for a in out[0]) > 1000
 
 
+def _forward_motion_scene(n_segs=600, seed=31):
+    """Two cameras on (almost) the same optical axis: the epipoles lie inside the images, the geometry the
+    epipolar-band culling must refuse (make_cull, l3d_api.hip) -- plus a third, sideways camera."""
+    rng = np.random.default_rng(seed)
+    w, h, f = 1600, 1200, 1400.0
+    K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1.0]])
+    P = rng.uniform([-6, -4, 14], [6, 4, 22], (4 * n_segs, 3))
+    Q = P + rng.normal(0, 0.8, P.shape)
+    views = []
+    for cam, C in enumerate([np.array([0.0, 0.0, 0.0]), np.array([0.15, -0.1, 2.0]), np.array([2.5, 0.2, 0.3])]):
+        R = np.eye(3); t = -R @ C
+        a = (K @ (P - C).T).T; b = (K @ (Q - C).T).T
+        a = a[:, :2] / a[:, 2:]; b = b[:, :2] / b[:, 2:]
+        ok = ((a >= 1).all(1) & (b >= 1).all(1) & (a[:, 0] < w - 1) & (b[:, 0] < w - 1) & (a[:, 1] < h - 1) &
+              (b[:, 1] < h - 1) & (np.hypot(*(a - b).T) > 8))
+        segs = np.concatenate([a, b], 1)[ok][:n_segs] + rng.normal(0, 0.3, (min(n_segs, int(ok.sum())), 4))
+        views.append(ViewData(cam, segs.astype(np.float32), K.copy(), R, t, w, h, 18.0, [c for c in range(3) if c != cam]))
+    return Scene(views, "forward-motion")
+
+
+def test_epipolar_culling_active_and_refused_where_unsound():
+    """Ring scenes match with epipolar-band culling on every pair; a forward-motion pair (epipole inside the
+    image) must fall back to plain streaming.  Both are bit-exact against the oracle."""
+    sc = make_scene(16, 400, n_neighbors=4, seed=41)
+    g = _gpu(sc)
+    assert g.matchBegin(kNN=10) and g.matchPairs(0, len(g.pairs()[0]))
+    assert g.timings()["culled_pairs"] > len(g.pairs()[0]) // 2
+    assert _check_phase_a(g, sc, 10) > 1000
+    fm = _forward_motion_scene()
+    g = _gpu(fm)
+    assert g.matchBegin(kNN=10) and g.matchPairs(0, len(g.pairs()[0]))
+    n_culled = g.timings()["culled_pairs"]
+    assert n_culled < len(g.pairs()[0])        # pair (0,1): epipole in the image -> refused
+    assert _check_phase_a(g, fm, 10) > 500
+    assert g.matchFinish()
+
+
 def test_keep_all_mode_knn_zero():
     sc = make_scene(4, 260, n_neighbors=2, seed=8)
     g = _gpu(sc)
