@@ -28,9 +28,8 @@ namespace l3d {
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kTile = 512;         // target records per LDS tile (8 KiB)
-constexpr int kRing = 512;         // per-wave candidate ring (entries); >= 63 + 4*64
+constexpr int kBlock = kMatchRows;  // one wave64 per workgroup: waves never wait for each other
+constexpr int kRing = 512;          // candidate ring (entries); >= 63 + 4*64
 constexpr float kKappa = 1.0e-2f;  // pre-filter slack, px: margin = kKappa * max|1/d| + kKappa0
 constexpr float kKappa0 = 2.0e-4f;
 
@@ -46,8 +45,7 @@ __device__ unsigned long long g_stats[8];   // 0 pre-filter tests, 1 candidates,
 #endif
 typedef float v4f __attribute__((ext_vector_type(4)));
 struct Lds {
-    L3D_LDS v4f* tile;                 // [kTile]
-    L3D_LDS volatile uint32_t* ring;   // [4][kRing]
+    L3D_LDS volatile uint32_t* ring;   // [kRing]
     L3D_LDS volatile uint32_t* cnt;    // [kBlock]
     L3D_LDS volatile float* minov;     // [kBlock]
     L3D_LDS volatile uint32_t* claim;  // [kBlock]
@@ -58,8 +56,7 @@ struct Lds {
 
 __device__ __forceinline__ Lds carve(L3D_LDS char* base, uint32_t K) {
     Lds l;
-    l.tile = (L3D_LDS v4f*)base; base += sizeof(float4) * kTile;
-    l.ring = (L3D_LDS volatile uint32_t*)base; base += 4 * kRing * sizeof(uint32_t);
+    l.ring = (L3D_LDS volatile uint32_t*)base; base += kRing * sizeof(uint32_t);
     l.cnt = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
     l.minov = (L3D_LDS volatile float*)base; base += kBlock * 4;
     l.claim = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
@@ -99,7 +96,7 @@ __device__ __forceinline__ bool prefilter(float e1x, float e1y, float e1z, float
 // BRUTE: skip the pre-filter (every pair goes through the exact test) -- on-GPU check that the
 //        pre-filter never loses a match.
 template <int MODE, bool BRUTE>
-__global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __restrict__ views,
+__global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restrict__ views,
                                                            const PairDesc* __restrict__ pairs,
                                                            const WorkItem* __restrict__ work, uint32_t nwork,
                                                            Slot* __restrict__ slots,
@@ -117,8 +114,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
     const ViewDev& vt = views[pd.tgt];
     const uint32_t K = pd.K, Ms = pd.Ms, Mt = pd.Mt;
     Lds L = carve((L3D_LDS char*)smem, MODE == 0 ? K : 0);
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    L3D_LDS volatile uint32_t* ring = L.ring + wave * kRing;
+    const uint32_t tid = threadIdx.x, lane = tid;
+    L3D_LDS volatile uint32_t* ring = L.ring;
     // epipolar-band culling (kNN mode only: the keep-all rows must be filled in ascending target order)
     const PairCull* pc = (MODE == 0 && !BRUTE && cp.cull && cp.cull[wi.pair].enabled) ? &cp.cull[wi.pair] : nullptr;
     const bool cull = pc != nullptr;
@@ -159,28 +156,17 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
     L.minov[tid] = thr;
     L.claim[tid] = kEmpty;
     uint32_t head = 0, tail = 0;   // wave-uniform ring cursors
-    // tau band of the wave / of the block (hull of the live lanes)
+    // tau band of the wave (hull of the live lanes), kept in SGPRs
     float wlo = live ? blo : __builtin_inff(), whi = live ? bhi : -__builtin_inff();
-    float klo = wlo, khi = whi;
     if (cull) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             wlo = fminf(wlo, __shfl_xor(wlo, o));
             whi = fmaxf(whi, __shfl_xor(whi, o));
         }
-        // exchange through the (still unused) rings; the barrier of the first tile load orders these reads
-        // before any ring write
-        L3D_LDS volatile float* x = (L3D_LDS volatile float*)L.ring;
-        if (lane == 0) { x[wave * kRing] = wlo; x[wave * kRing + 1] = whi; }
-        __syncthreads();
-        klo = fminf(fminf(x[0], x[kRing]), fminf(x[2 * kRing], x[3 * kRing]));
-        khi = fmaxf(fmaxf(x[1], x[kRing + 1]), fmaxf(x[2 * kRing + 1], x[3 * kRing + 1]));
     }
-    // wave-uniform values: keep them in SGPRs so that the chunk tests are scalar branches
     wlo = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(wlo)));
     whi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(whi)));
-    klo = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(klo)));
-    khi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(khi)));
     const uint32_t* __restrict__ tperm = cull ? cp.tgt_perm + pc->t_off : nullptr;
     const float2* __restrict__ cband = cull ? cp.chunk_band + pc->c_off : nullptr;
     const float2* __restrict__ tband = cull ? cp.tgt_band + pc->t_off : nullptr;
@@ -210,7 +196,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
         bool pending = false;
         PairResult res{};
         // the ring of a wave only holds rows of that wave: the source segment comes from the owning lane
-        const uint32_t sg = __shfl(src, sl & 63u);
+        const uint32_t sg = __shfl(src, sl);
         if (has) {
             if (cull) tg = tperm[tg];
             const float4 s4 = vs.seg4[sg], t4 = vt.seg4[tg];
@@ -274,87 +260,61 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
     auto prefix = [&](uint64_t m) -> uint32_t {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     };
-    for (uint32_t t0 = 0; t0 < Mt; t0 += kTile) {
-        const uint32_t n = min((uint32_t)kTile, Mt - t0);
-        uint32_t wmask = 0xFFFFFFFFu;   // chunks of this tile the wave has to visit
+    // The target view is visited in chunks of 64 records: lane l holds record l of the chunk in VGPRs and the wave
+    // walks the chunk by broadcasting one record at a time through SGPRs (v_readlane) -- no LDS tile, no barrier.
+    // With culling, 32 chunk bands are tested at once (one per lane), then inside a visited chunk one target band
+    // per lane; only the targets whose band meets the wave's band are walked (ascending order).
+    auto bc = [](float v, uint32_t j) -> float {
+        return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j));
+    };
+    const uint32_t nch = (Mt + 63) / 64;
+    for (uint32_t g0 = 0; g0 < nch; g0 += 32) {
+        uint32_t wm;
         if (cull) {
-            // block-uniform: skip the tile when none of its chunks can meet the block's band
-            bool need = false;
-            wmask = 0;
-#pragma unroll
-            for (uint32_t c = 0; c < kTile / 64; ++c) {
-                if (c * 64 < n) {
-                    const float2 cb = cband[(t0 >> 6) + c];
-                    need |= !(cb.y < klo || cb.x > khi);
-                    wmask |= (cb.y < wlo || cb.x > whi) ? 0u : (1u << c);
+            bool vis = false;
+            const uint32_t c = g0 + lane;
+            if (lane < 32 && c < nch) {
+                const float2 cb = cband[c];
+                vis = !(cb.y < wlo || cb.x > whi);
+            }
+            wm = (uint32_t)__ballot(vis);
+        } else {
+            wm = (nch - g0 >= 32) ? 0xFFFFFFFFu : ((1u << (nch - g0)) - 1u);
+        }
+        while (wm) {
+            const uint32_t tb = (g0 + (uint32_t)__builtin_ctz(wm)) * 64;
+            wm &= wm - 1;
+            const uint32_t ti = tb + lane;
+            v4f rec = {0, 0, 0, 0};
+            bool in = ti < Mt;
+            if (in) rec = tf[ti];
+            if (cull && in) {
+                const float2 b = tband[ti];
+                in = !(b.y < wlo || b.x > whi);
+            }
+            uint64_t m = __ballot(in);
+            while (m) {
+                const uint32_t j0 = __builtin_ctzll(m); m &= m - 1;
+                const bool v1 = m != 0; const uint32_t j1 = v1 ? __builtin_ctzll(m) : j0; m &= m - 1;
+                const bool v2 = m != 0; const uint32_t j2 = v2 ? __builtin_ctzll(m) : j0; m &= m - 1;
+                const bool v3 = m != 0; const uint32_t j3 = v3 ? __builtin_ctzll(m) : j0; m &= m - 1;
+                const v4f q0 = {bc(rec.x, j0), bc(rec.y, j0), bc(rec.z, j0), bc(rec.w, j0)};
+                const v4f q1 = {bc(rec.x, j1), bc(rec.y, j1), bc(rec.z, j1), bc(rec.w, j1)};
+                const v4f q2 = {bc(rec.x, j2), bc(rec.y, j2), bc(rec.z, j2), bc(rec.w, j2)};
+                const v4f q3 = {bc(rec.x, j3), bc(rec.y, j3), bc(rec.z, j3), bc(rec.w, j3)};
+                const bool c0b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
+                const bool c1b = v1 & (BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL)));
+                const bool c2b = v2 & (BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL)));
+                const bool c3b = v3 & (BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q3, thrL)));
+                const uint64_t m0 = __ballot(c0b), m1 = __ballot(c1b), m2 = __ballot(c2b), m3 = __ballot(c3b);
+                if (lane == 0) L3D_STAT(0, 64 * (1 + v1 + v2 + v3));
+                if (m0 | m1 | m2 | m3) {
+                    if (m0) { if (c0b) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | (tb + j0); tail += __popcll(m0); }
+                    if (m1) { if (c1b) ring[(tail + prefix(m1)) & (kRing - 1)] = ent_hi | (tb + j1); tail += __popcll(m1); }
+                    if (m2) { if (c2b) ring[(tail + prefix(m2)) & (kRing - 1)] = ent_hi | (tb + j2); tail += __popcll(m2); }
+                    if (m3) { if (c3b) ring[(tail + prefix(m3)) & (kRing - 1)] = ent_hi | (tb + j3); tail += __popcll(m3); }
+                    while (tail - head >= 64) drain();
                 }
-            }
-            if (!need) continue;
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < n; i += kBlock) L.tile[i] = tf[t0 + i];
-        __syncthreads();
-        if (cull) {
-            // per-target culling inside the chunks the wave visits: one band per lane -> ballot -> the wave walks
-            // the set bits (ascending), four targets per step
-            float2 bn = make_float2(__builtin_inff(), -__builtin_inff());
-            if (t0 + lane < Mt) bn = tband[t0 + lane];
-            for (uint32_t c0 = 0; c0 < n; c0 += 64) {
-                const float2 b = bn;
-                const uint32_t nx = t0 + c0 + 64 + lane;
-                bn = make_float2(__builtin_inff(), -__builtin_inff());
-                if (c0 + 64 < n && nx < Mt) bn = tband[nx];
-                if (!((wmask >> (c0 >> 6)) & 1u)) continue;   // wave-uniform
-                uint64_t m = __ballot(!(b.y < wlo || b.x > whi));
-                while (m) {
-                    const uint32_t j0 = __builtin_ctzll(m); m &= m - 1;
-                    const bool v1 = m != 0; const uint32_t j1 = v1 ? __builtin_ctzll(m) : j0; m &= m - 1;
-                    const bool v2 = m != 0; const uint32_t j2 = v2 ? __builtin_ctzll(m) : j0; m &= m - 1;
-                    const bool v3 = m != 0; const uint32_t j3 = v3 ? __builtin_ctzll(m) : j0; m &= m - 1;
-                    const v4f q0 = L.tile[c0 + j0], q1 = L.tile[c0 + j1], q2 = L.tile[c0 + j2], q3 = L.tile[c0 + j3];
-                    const bool c0b = live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL);
-                    const bool c1b = v1 & live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL);
-                    const bool c2b = v2 & live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL);
-                    const bool c3b = v3 & live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q3, thrL);
-                    const uint64_t m0 = __ballot(c0b), m1 = __ballot(c1b), m2 = __ballot(c2b), m3 = __ballot(c3b);
-                    if (lane == 0) L3D_STAT(0, 64 * (1 + v1 + v2 + v3));
-                    if (m0 | m1 | m2 | m3) {
-                        const uint32_t tb = t0 + c0;
-                        if (m0) { if (c0b) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | (tb + j0); tail += __popcll(m0); }
-                        if (m1) { if (c1b) ring[(tail + prefix(m1)) & (kRing - 1)] = ent_hi | (tb + j1); tail += __popcll(m1); }
-                        if (m2) { if (c2b) ring[(tail + prefix(m2)) & (kRing - 1)] = ent_hi | (tb + j2); tail += __popcll(m2); }
-                        if (m3) { if (c3b) ring[(tail + prefix(m3)) & (kRing - 1)] = ent_hi | (tb + j3); tail += __popcll(m3); }
-                        while (tail - head >= 64) drain();
-                    }
-                }
-            }
-            continue;
-        }
-        uint32_t j = 0;
-        for (; j + 4 <= n; j += 4) {
-            const v4f q0 = L.tile[j], q1 = L.tile[j + 1], q2 = L.tile[j + 2], q3 = L.tile[j + 3];
-            const bool c0b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
-            const bool c1b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL));
-            const bool c2b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL));
-            const bool c3b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q3, thrL));
-            const uint64_t m0 = __ballot(c0b), m1 = __ballot(c1b), m2 = __ballot(c2b), m3 = __ballot(c3b);
-            if (m0 | m1 | m2 | m3) {
-                const uint32_t tb = t0 + j;
-                if (m0) { if (c0b) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | tb; tail += __popcll(m0); }
-                if (m1) { if (c1b) ring[(tail + prefix(m1)) & (kRing - 1)] = ent_hi | (tb + 1); tail += __popcll(m1); }
-                if (m2) { if (c2b) ring[(tail + prefix(m2)) & (kRing - 1)] = ent_hi | (tb + 2); tail += __popcll(m2); }
-                if (m3) { if (c3b) ring[(tail + prefix(m3)) & (kRing - 1)] = ent_hi | (tb + 3); tail += __popcll(m3); }
-                while (tail - head >= 64) drain();
-            }
-        }
-        for (; j < n; ++j) {
-            const v4f q0 = L.tile[j];
-            const bool c0b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
-            const uint64_t m0 = __ballot(c0b);
-            if (m0) {
-                if (c0b) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | (t0 + j);
-                tail += __popcll(m0);
-                while (tail - head >= 64) drain();
             }
         }
     }
@@ -399,7 +359,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_match_pairs(const ViewDev* __rest
 }
 
 size_t match_lds_bytes(int mode, uint32_t K) {
-    return sizeof(float4) * kTile + 4 * kRing * 4 + 4 * kBlock * 4 + (mode == 0 ? (size_t)kBlock * K * 8 : 0);
+    return kRing * 4 + 4 * kBlock * 4 + (mode == 0 ? (size_t)kBlock * K * 8 : 0);
 }
 
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,

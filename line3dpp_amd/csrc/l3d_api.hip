@@ -495,7 +495,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         const PairDesc& pd = c->pairs[p];
         maxK = std::max(maxK, pd.K);
         if (c->cull[p].enabled) maxM = std::max(maxM, std::max(pd.Ms, pd.Mt));
-        for (uint32_t s0 = 0; s0 < pd.Ms; s0 += 256) work.push_back(WorkItem{p, s0});
+        for (uint32_t s0 = 0; s0 < pd.Ms; s0 += kMatchRows) work.push_back(WorkItem{p, s0});
     }
     if (work.empty()) return L3D_OK;
     if (match_lds_bytes(mode, maxK) > 160 * 1024) return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
@@ -1020,7 +1020,7 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         std::memcpy(pd.F, F, 72);
         pd.src = 0; pd.tgt = 1; pd.Ms = Ms; pd.Mt = Mt; pd.K = (uint32_t)kNN; pd.row_off = 0; pd.slot_off = 0;
         std::vector<WorkItem> work;
-        for (uint32_t s0 = 0; s0 < Ms; s0 += 256) work.push_back(WorkItem{0, s0});
+        for (uint32_t s0 = 0; s0 < Ms; s0 += kMatchRows) work.push_back(WorkItem{0, s0});
         if (match_lds_bytes(0, pd.K) > 160 * 1024) return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
         L3D_HIP_CHECK(dv.reserve(2)); L3D_HIP_CHECK(dp.reserve(1)); L3D_HIP_CHECK(dw.reserve(work.size()));
         L3D_HIP_CHECK(ds.reserve((size_t)Ms * pd.K));

@@ -4,9 +4,10 @@
 
 namespace l3d {
 
+constexpr int kMatchRows = 64;   // source rows per work item of k_match_pairs (one wave64)
 struct WorkItem {
     uint32_t pair;  // index into the pair array
-    uint32_t src0;  // first source segment of the block
+    uint32_t src0;  // first source row (position in the pair's row order) of the work item
 };
 
 // Epipolar-band culling (k_match.hip): per directed pair, the pencil of epipolar lines in the target image
