@@ -37,8 +37,12 @@ constexpr float kKappa0 = 2.0e-4f;
 // or a lambda capture loses it and every access becomes a flat_load/flat_store (plus, for volatile, sc0 sc1
 // and an immediate s_waitcnt) instead of ds_read/ds_write.
 #define L3D_LDS __attribute__((address_space(3)))
-#ifdef L3D_STATS
+// diagnostics builds only (-DL3D_STATS: candidate counters, slow; -DL3D_CYCLES: per-work-item timeline)
+#if defined(L3D_STATS) || defined(L3D_CYCLES)
 __device__ unsigned long long g_stats[8];   // 0 pre-filter tests, 1 candidates, 2 passed overlap, 3 accepted, 4 drains
+__device__ unsigned long long g_cycles[1 << 16][2];   // per work item: start, duration (wall_clock64 ticks)
+#endif
+#ifdef L3D_STATS
 #define L3D_STAT(i, n) atomicAdd(&g_stats[i], (unsigned long long)(n))
 #else
 #define L3D_STAT(i, n) ((void)0)
@@ -109,6 +113,9 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
     const uint32_t w = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (w >= nwork) return;
     const WorkItem wi = work[w];
+#if defined(L3D_STATS) || defined(L3D_CYCLES)
+    const unsigned long long t_start = wall_clock64();
+#endif
     const PairDesc& pd = pairs[wi.pair];
     const ViewDev& vs = views[pd.src];
     const ViewDev& vt = views[pd.tgt];
@@ -319,6 +326,9 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
         }
     }
     while (tail != head) drain();
+#if defined(L3D_STATS) || defined(L3D_CYCLES)
+    if (threadIdx.x == 0 && w < (1u << 16)) { g_cycles[w][0] = t_start; g_cycles[w][1] = wall_clock64() - t_start; }
+#endif
 
     // ---- epilogue ----
     if (!active) return;
@@ -577,9 +587,12 @@ hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t ma
 
 }  // namespace l3d
 
-#ifdef L3D_STATS
+#if defined(L3D_STATS) || defined(L3D_CYCLES)
 extern "C" void l3d_debug_stats(unsigned long long* out, int reset) {
     hipMemcpyFromSymbol(out, HIP_SYMBOL(l3d::g_stats), sizeof(l3d::g_stats));
     if (reset) { unsigned long long z[8] = {}; hipMemcpyToSymbol(HIP_SYMBOL(l3d::g_stats), z, sizeof(z)); }
+}
+extern "C" void l3d_debug_cycles(unsigned long long* out, int n) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(l3d::g_cycles), (size_t)n * 16);
 }
 #endif
