@@ -42,53 +42,86 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
 // ---- pre-pass ---------------------------------------------------------------------------------------
 // grid = (slot blocks, pairs).  One thread per slot: orientation flags + list lengths.
-//   cnt_all[g]  hypotheses of global segment g (fresh alive + potential inverse) -> CSR of the lists
-//   cnt_inv[g]  potential inverse hypotheses of g -> CSR of the transposed index
+//   cnt_pack[g] low word:  hypotheses of global segment g (fresh alive + potential inverse) -> CSR of the lists
+//               high word: potential inverse hypotheses of g -> CSR of the transposed index
+//   inv_pos[slot] position of the slot among the inverse refs of its target segment (kEmpty: none)
 __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
                              const uint32_t* __restrict__ seg_base, Slot* __restrict__ slots,
-                             uint32_t* __restrict__ cnt_all, uint32_t* __restrict__ cnt_inv, OrientThr othr) {
+                             unsigned long long* __restrict__ cnt_pack, uint32_t* __restrict__ inv_pos,
+                             OrientThr othr) {
     const PairDesc& pd = pairs[blockIdx.y];
     const uint64_t n = (uint64_t)pd.Ms * pd.K;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Slot* sp = slots + pd.slot_off + i;
-    const Slot s = *sp;
-    if (s.tgt_seg == kEmpty) return;
-    const ViewDev& vs = views[pd.src];
-    const uint32_t row = (uint32_t)(i / pd.K);
-    uint32_t flags = 0;
-    if (orientation_ok(vs.C, vs.segx[row], s.dp1, s.dp2, othr)) {
-        flags = kSlotAlive;
-        atomicAdd(&cnt_all[seg_base[pd.src] + row], 1u);
-        // inverse copy: only towards a view that is processed later (line3D.cc:1680)
-        if (pd.tgt > pd.src) {
-            const ViewDev& vt = views[pd.tgt];
-            if (orientation_ok(vt.C, vt.segx[s.tgt_seg], s.dq1, s.dq2, othr)) {
-                flags |= kSlotInvAlive;
-                atomicAdd(&cnt_all[seg_base[pd.tgt] + s.tgt_seg], 1u);
-                atomicAdd(&cnt_inv[seg_base[pd.tgt] + s.tgt_seg], 1u);
+    if ((uint64_t)blockIdx.x * blockDim.x >= n) return;   // whole block past the end
+    const uint32_t K = pd.K;
+    const uint32_t row = (uint32_t)(i / K);
+    bool alive = false;
+    if (i < n) {
+        uint32_t ipos = kEmpty;
+        Slot* sp = slots + pd.slot_off + i;
+        const Slot s = *sp;
+        if (s.tgt_seg != kEmpty) {
+            const ViewDev& vs = views[pd.src];
+            uint32_t flags = 0;
+            if (orientation_ok(vs.C, vs.segx[row], s.dp1, s.dp2, othr)) {
+                flags = kSlotAlive;
+                alive = true;
+                // inverse copy: only towards a view that is processed later (line3D.cc:1680)
+                if (pd.tgt > pd.src) {
+                    const ViewDev& vt = views[pd.tgt];
+                    if (orientation_ok(vt.C, vt.segx[s.tgt_seg], s.dq1, s.dq2, othr)) {
+                        flags |= kSlotInvAlive;
+                        // one 64-bit atomic: low word = list length, high word = number of inverse refs; the old
+                        // high word is this slot's position among the inverse refs of the target segment
+                        const unsigned long long old =
+                            atomicAdd(&cnt_pack[seg_base[pd.tgt] + s.tgt_seg], (1ull << 32) | 1ull);
+                        ipos = (uint32_t)(old >> 32);
+                    }
+                }
             }
+            sp->flags = flags;
+            sp->score3D = 0.0f;
         }
+        inv_pos[pd.slot_off + i] = ipos;
     }
-    sp->flags = flags;
-    sp->score3D = 0.0f;
+    // the K slots of a source row are neighbouring lanes: one atomic per (row, wave) instead of one per slot
+    const uint64_t m = __ballot(alive);
+    const uint32_t lane = lane_id();
+    const uint64_t base = i - lane, r0 = (uint64_t)row * K;
+    const uint32_t lo = (uint32_t)((r0 > base ? r0 : base) - base);
+    const uint64_t he = r0 + K < base + 64 ? r0 + K : base + 64;
+    const uint32_t hi = (uint32_t)(he - base);   // exclusive, <= 64
+    if (lane == lo && i < n) {
+        const uint64_t seg_mask = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+        const uint32_t c = (uint32_t)__popcll(m & seg_mask);
+        if (c) atomicAdd(&cnt_pack[seg_base[pd.src] + row], (unsigned long long)c);
+    }
+}
+
+__global__ void k_unpack_counts(uint32_t G, const unsigned long long* __restrict__ cnt_pack,
+                                uint32_t* __restrict__ cnt_all, uint32_t* __restrict__ cnt_inv) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const unsigned long long c = cnt_pack[g];
+    cnt_all[g] = (uint32_t)c;
+    cnt_inv[g] = (uint32_t)(c >> 32);
 }
 
 // transposed index of the potential inverse hypotheses: which slots point at global segment g
 __global__ void k_inv_fill(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ seg_base,
                            const Slot* __restrict__ slots, const uint32_t* __restrict__ inv_off,
-                           uint32_t* __restrict__ cur, InvRef* __restrict__ refs) {
+                           const uint32_t* __restrict__ inv_pos, InvRef* __restrict__ refs) {
     const PairDesc& pd = pairs[blockIdx.y];
     if (pd.tgt <= pd.src) return;
     const uint64_t n = (uint64_t)pd.Ms * pd.K;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Slot s = slots[pd.slot_off + i];
-    if (s.tgt_seg == kEmpty || !(s.flags & kSlotInvAlive)) return;
-    const uint32_t g = seg_base[pd.tgt] + s.tgt_seg;
+    const uint32_t ipos = inv_pos[pd.slot_off + i];
+    if (ipos == kEmpty) return;
+    const uint32_t g = seg_base[pd.tgt] + slots[pd.slot_off + i].tgt_seg;
     InvRef r;
     r.src_view = pd.src; r.src_row = (uint32_t)(i / pd.K); r.pair = blockIdx.y; r.j = (uint32_t)(i % pd.K);
-    refs[inv_off[g] + atomicAdd(&cur[g], 1u)] = r;
+    refs[inv_off[g] + ipos] = r;
 }
 
 // scoringCPU line3D.cc:1233-1248: unprojection + spatial regularisers of one hypothesis
@@ -690,18 +723,22 @@ hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* 
 
 // ---- launchers --------------------------------------------------------------------------------------
 hipError_t launch_orient_all(const ViewDev* views, const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots,
-                             const uint32_t* seg_base, Slot* slots, uint32_t* cnt_all, uint32_t* cnt_inv,
-                             double thr_lo, double thr_hi, hipStream_t st) {
-    if (!n_pairs || !max_slots) return hipSuccess;
-    hipLaunchKernelGGL(k_orient_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, views,
-                       pairs, seg_base, slots, cnt_all, cnt_inv, OrientThr{thr_lo, thr_hi});
+                             const uint32_t* seg_base, Slot* slots, uint32_t G, unsigned long long* cnt_pack,
+                             uint32_t* inv_pos, uint32_t* cnt_all, uint32_t* cnt_inv, double thr_lo, double thr_hi,
+                             hipStream_t st) {
+    if (n_pairs && max_slots)
+        hipLaunchKernelGGL(k_orient_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, views,
+                           pairs, seg_base, slots, cnt_pack, inv_pos, OrientThr{thr_lo, thr_hi});
+    if (!G) return hipGetLastError();
+    hipLaunchKernelGGL(k_unpack_counts, dim3((G + 255) / 256), dim3(256), 0, st, G, cnt_pack, cnt_all, cnt_inv);
     return hipGetLastError();
 }
 hipError_t launch_inv_fill(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
-                           const Slot* slots, const uint32_t* inv_off, uint32_t* cur, InvRef* refs, hipStream_t st) {
+                           const Slot* slots, const uint32_t* inv_off, const uint32_t* inv_pos, InvRef* refs,
+                           hipStream_t st) {
     if (!n_pairs || !max_slots) return hipSuccess;
     hipLaunchKernelGGL(k_inv_fill, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, pairs,
-                       seg_base, slots, inv_off, cur, refs);
+                       seg_base, slots, inv_off, inv_pos, refs);
     return hipGetLastError();
 }
 hipError_t launch_build_lists_all(uint32_t G, const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base,

@@ -18,10 +18,12 @@ void set_error(const std::string& s) { g_err = s; }
 // ---- prototypes of the launchers in k_views.hip / k_affinity.hip -------------------------------
 hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, uint32_t* total, hipStream_t);
 hipError_t launch_orient_all(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
-                             const uint32_t* seg_base, Slot*, uint32_t* cnt_all, uint32_t* cnt_inv, double thr_lo,
-                             double thr_hi, hipStream_t);
+                             const uint32_t* seg_base, Slot* slots, uint32_t G, unsigned long long* cnt_pack,
+                             uint32_t* inv_pos, uint32_t* cnt_all, uint32_t* cnt_inv, double thr_lo, double thr_hi,
+                             hipStream_t);
 hipError_t launch_inv_fill(const PairDesc*, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
-                           const Slot*, const uint32_t* inv_off, uint32_t* cur, InvRef*, hipStream_t);
+                           const Slot* slots, const uint32_t* inv_off, const uint32_t* inv_pos, InvRef* refs,
+                           hipStream_t);
 hipError_t launch_build_lists_all(uint32_t G, const ViewDev*, const PairDesc*, const uint32_t* seg_base,
                                   const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
                                   const uint32_t* off, const uint32_t* inv_off, const InvRef*, const Slot*, DEntry*,
@@ -101,14 +103,15 @@ struct l3d_ctx {
     // phase B (global over all views; G = sum of M)
     uint32_t G = 0, n_ents = 0, n_surv = 0, n_hyps = 0;
     std::vector<uint32_t> seg_base;                 // [V+1]
-    DevBuf<uint32_t> d_seg_base, d_gseg_view, d_cnt, d_off, d_cur, d_scan_tmp, d_scal, d_max_score;
+    DevBuf<uint32_t> d_seg_base, d_gseg_view, d_cnt, d_off, d_scan_tmp, d_scal, d_max_score;
     DevBuf<uint32_t> d_surv_cnt, d_has_best, d_best_pos, d_surv_off, d_hyp_off, d_surv_tg, d_surv_sg;
     DevBuf<InvRef> d_refs;
     DevBuf<uint64_t> d_bits;
     DevBuf<uint32_t> d_eref;
     DevBuf<uint8_t> d_positive;
     DevBuf<uint32_t> d_bits_len, d_boff;
-    DevBuf<uint32_t> d_cnt_inv, d_inv_off, d_vout_pairs, d_vout_off;
+    DevBuf<uint32_t> d_cnt_inv, d_inv_off, d_vout_pairs, d_vout_off, d_inv_pos;
+    DevBuf<unsigned long long> d_cnt_pack;
     std::vector<uint32_t> vout_off;
     DevBuf<DEntry> d_dents;
     DevBuf<Match> d_surv;
@@ -323,10 +326,11 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
     c->d_chunk_band.release(); c->d_tgt_sf.release(); c->d_tgt_band.release();
     c->d_row_counts.release();
-    c->d_seg_base.release(); c->d_gseg_view.release(); c->d_cnt.release(); c->d_off.release(); c->d_cur.release();
+    c->d_seg_base.release(); c->d_gseg_view.release(); c->d_cnt.release(); c->d_off.release();
     c->d_scan_tmp.release(); c->d_scal.release(); c->d_max_score.release(); c->d_surv_cnt.release();
     c->d_has_best.release(); c->d_best_pos.release(); c->d_surv_off.release(); c->d_hyp_off.release();
     c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_bits.release(); c->d_eref.release(); c->d_positive.release(); c->d_bits_len.release(); c->d_boff.release(); c->d_cnt_inv.release();
+    c->d_cnt_pack.release(); c->d_inv_pos.release();
     c->d_inv_off.release(); c->d_vout_pairs.release(); c->d_vout_off.release(); c->d_dents.release(); c->d_surv.release();
     c->d_hyp_of_seg.release(); c->d_depths.release(); c->d_medians.release(); c->d_hyps.release();
     c->d_vaff.release(); c->d_simv.release(); c->d_msdl.release(); c->d_ca.release(); c->d_cb.release();
@@ -587,7 +591,7 @@ int l3d_match_finish(l3d_ctx* c) {
     for (auto& pd : c->pairs) max_slots = std::max<uint64_t>(max_slots, (uint64_t)pd.Ms * pd.K);
     if (2 * c->n_slots >= (1ull << 32)) return fail(L3D_ERR_LIMIT, "more than 2^32 hypotheses");
     L3D_HIP_CHECK(c->d_seg_base.reserve(V + 1)); L3D_HIP_CHECK(c->d_gseg_view.reserve(G + 1));
-    L3D_HIP_CHECK(c->d_cnt.reserve(G + 1)); L3D_HIP_CHECK(c->d_off.reserve(G + 1)); L3D_HIP_CHECK(c->d_cur.reserve(G + 1));
+    L3D_HIP_CHECK(c->d_cnt.reserve(G + 1)); L3D_HIP_CHECK(c->d_off.reserve(G + 1));
     L3D_HIP_CHECK(c->d_scan_tmp.reserve(G / 4096 + 1024)); L3D_HIP_CHECK(c->d_scal.reserve(16));
     L3D_HIP_CHECK(c->d_max_score.reserve(V + 1));
     L3D_HIP_CHECK(c->d_surv_cnt.reserve(G + 1)); L3D_HIP_CHECK(c->d_has_best.reserve(G + 1));
@@ -611,14 +615,15 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_cnt_inv.reserve(G + 1)); L3D_HIP_CHECK(c->d_inv_off.reserve(G + 1));
     if (!vout.empty())
         L3D_HIP_CHECK(hipMemcpyAsync(c->d_vout_pairs.p, vout.data(), vout.size() * 4, hipMemcpyHostToDevice, st));
-    L3D_HIP_CHECK(hipMemsetAsync(c->d_cnt.p, 0, ((size_t)G + 1) * 4, st));
-    L3D_HIP_CHECK(hipMemsetAsync(c->d_cnt_inv.p, 0, ((size_t)G + 1) * 4, st));
-    L3D_HIP_CHECK(hipMemsetAsync(c->d_cur.p, 0, ((size_t)G + 1) * 4, st));
+    L3D_HIP_CHECK(c->d_cnt_pack.reserve(G + 1));
+    L3D_HIP_CHECK(c->d_inv_pos.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    L3D_HIP_CHECK(hipMemsetAsync(c->d_cnt_pack.p, 0, ((size_t)G + 1) * 8, st));
     L3D_HIP_CHECK(hipMemsetAsync(c->d_max_score.p, 0, ((size_t)V + 1) * 4, st));
     L3D_HIP_CHECK(hipMemsetAsync(c->d_scal.p, 0, 16 * 4, st));
     // ---- pre-pass: orientation flags, list offsets, transposed index of potential inverse matches ----
-    L3D_HIP_CHECK(launch_orient_all(c->d_views.p, c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p,
-                                    c->d_cnt.p, c->d_cnt_inv.p, c->orient_lo, c->orient_hi, st));
+    L3D_HIP_CHECK(launch_orient_all(c->d_views.p, c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, G,
+                                    c->d_cnt_pack.p, c->d_inv_pos.p, c->d_cnt.p, c->d_cnt_inv.p, c->orient_lo,
+                                    c->orient_hi, st));
     L3D_HIP_CHECK(launch_scan(c->d_cnt.p, G, c->d_off.p, c->d_scan_tmp.p, c->d_scal.p + 0, st));
     L3D_HIP_CHECK(launch_scan(c->d_cnt_inv.p, G, c->d_inv_off.p, c->d_scan_tmp.p, c->d_scal.p + 5, st));
     L3D_HIP_CHECK(c->d_bits_len.reserve(G + 1)); L3D_HIP_CHECK(c->d_boff.reserve(G + 1));
@@ -635,7 +640,7 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_positive.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(hipMemsetAsync(c->d_positive.p, 0, std::max<uint64_t>(c->n_slots, 1), st));
     L3D_HIP_CHECK(launch_inv_fill(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_inv_off.p,
-                                  c->d_cur.p, c->d_refs.p, st));
+                                  c->d_inv_pos.p, c->d_refs.p, st));
     L3D_HIP_CHECK(launch_build_lists_all(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p,
                                          c->d_vout_off.p, c->d_vout_pairs.p, c->d_off.p, c->d_inv_off.p, c->d_refs.p,
                                          c->d_slots.p, c->d_dents.p, c->d_eref.p, st));
