@@ -188,6 +188,8 @@ typedef struct l3d_timings {
     float match_kernel_ms; /* the pair-matching kernel alone */
     float cull_prepare_ms; /* ordering of rows/targets by epipolar band (part of match_pairs_ms) */
     uint32_t culled_pairs; /* directed pairs matched with epipolar-band culling in the last matchImages */
+    uint32_t list_entries; /* phase B: total length of the per-segment hypothesis lists (fresh + inverse) */
+    uint32_t support_words;/* phase B: 64-bit words of the support bitsets */
 } l3d_timings;
 int l3d_get_timings(l3d_ctx*, l3d_timings*);
 

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_build_lists_all(uint32_t G, const ViewD
                                                          const uint32_t* __restrict__ inv_off,
                                                          const InvRef* __restrict__ refs,
                                                          const Slot* __restrict__ slots, DEntry* __restrict__ dents,
-                                                         uint32_t* __restrict__ eref) {
+                                                         uint32_t* __restrict__ eref, uint32_t uniform_K) {
     __shared__ uint64_t s_key[4][kKeyCap];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t g = blockIdx.x * 4 + wave;
@@ -209,6 +209,31 @@ __global__ __launch_bounds__(256) void k_build_lists_all(uint32_t G, const ViewD
     }
     // ---- phase 1b: fresh hypotheses ----
     uint32_t pos = b + n_inv;
+    if (uniform_K) {
+        // bounded kNN: every pair has K slots per row -> lane = (outgoing pair, slot) packs 64 slots per step
+        // (still ascending (target view, slot) order, so the ballot prefix keeps the canonical order)
+        const uint32_t q0 = vout_off[vi], T = (vout_off[vi + 1] - q0) * uniform_K;
+        for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            bool alive = false;
+            Slot s;
+            uint64_t ref = 0; uint32_t pi = 0, tv = 0;
+            if (t < T) {
+                pi = vout_pairs[q0 + t / uniform_K];
+                const PairDesc& pd = pairs[pi];
+                tv = pd.tgt;
+                ref = pd.slot_off + (uint64_t)seg * uniform_K + t % uniform_K;
+                s = slots[ref];
+                alive = s.tgt_seg != kEmpty && (s.flags & kSlotAlive);
+            }
+            const uint64_t m = __ballot(alive);
+            if (alive) {
+                DEntry& d = dents[pos + (uint32_t)__popcll(m & lt_mask)];
+                d.ref = ref; d.dp1 = s.dp1; d.dp2 = s.dp2; d.tgt_view = tv; d.pair = pi; d.flags = 0;
+            }
+            pos += (uint32_t)__popcll(m);
+        }
+    } else
     for (uint32_t q = vout_off[vi]; q < vout_off[vi + 1]; ++q) {
         const uint32_t pi = vout_pairs[q];
         const PairDesc& pd = pairs[pi];
@@ -247,29 +272,39 @@ __global__ __launch_bounds__(256) void k_build_lists_all(uint32_t G, const ViewD
 // similarityForScoring (line3D.cc:1417-1446) for hypotheses a (the scored one) and b of the same 2D
 // segment.  Decisions are taken on the float quantities the reference compares; acos/exp are
 // evaluated in double and rounded to float (glibc's expf/acos differ from that by < 1 float ulp).
-struct SimConst {
-    float two_sigA_sqr;
-    float min_sim;     // L3D_DEF_MIN_SIMILARITY_3D
-};
-__device__ __forceinline__ float sim_scoring(const double* dira, bool zeroa, float adp1, float adp2, float reg1,
-                                             float reg2, const double* dirb, bool zerob, float bdp1, float bdp2,
-                                             const SimConst sc) {
-    if (zeroa || zerob) return 0.0f;
+// Decision form (k_support_all): "similarityForScoring > L3D_DEF_MIN_SIMILARITY_3D" without transcendentals.
+// sim = fmin(sim_a, fmin(e1, e2)) > 0.5 <=> every non-NaN component is > 0.5 (fmin skips NaNs; all NaN -> false).
+// expf and acos are monotone, so each component test is a comparison of its float argument with a threshold
+// the host found by bisection with the libm the reference itself would use (sim_thresholds, l3d_api.hip):
+//     expf(y) > 0.5f                      <=>  y > y_thr
+//     expf(-angle(x)^2 / two_sigA_sqr) > 0.5f  <=>  x >= x_hi || x <= x_lo     (x = clamped float dot product)
+__device__ __forceinline__ bool sim_decide(const d3 dira, bool zeroa, float adp1, float adp2, float reg1, float reg2,
+                                           const d3 dirb, bool zerob, float bdp1, float bdp2, const SimConst sc) {
+    if (zeroa || zerob) return false;
     const float d1 = adp1 - bdp1, d2 = adp2 - bdp2;
-    // expf(y) > 0.5 needs y = -d*d/reg > ln 0.5 = -0.693147...  Division-free early-out with a safety
-    // margin (d*d > 0.72*reg => y < -0.70 even after rounding); NaN/inf fall through to the exact path.
-    if (d1 * d1 > 0.72f * reg1 || d2 * d2 > 0.72f * reg2) return 0.0f;
     const float y1 = -d1 * d1 / reg1, y2 = -d2 * d2 / reg2;
-    if (y1 < -0.70f || y2 < -0.70f) return 0.0f;
-    const float dot_p = (float)dot(d3{dira[0], dira[1], dira[2]}, d3{dirb[0], dirb[1], dirb[2]});
+    // NaN components drop out of the fmin chain; the angular component is never NaN (x is clamped, sigma_a > 0)
+    if (y1 == y1 && !(y1 > sc.y_thr)) return false;
+    if (y2 == y2 && !(y2 > sc.y_thr)) return false;
+    const float dot_p = (float)dot(dira, dirb);
+    const float x = fmaxf(fminf(dot_p, 1.0f), -1.0f);
+    return x >= sc.x_hi || x <= sc.x_lo;
+}
+
+// Value form (k_score_all), for pairs sim_decide accepted: similarityForScoring (line3D.cc:1417-1446) without the
+// final threshold.  acos/exp are evaluated in double and rounded to float (glibc's expf/acos differ from that by
+// < 1 float ulp).
+__device__ __forceinline__ float sim_value(const d3 dira, float adp1, float adp2, float reg1, float reg2,
+                                           const d3 dirb, float bdp1, float bdp2, const SimConst sc) {
+    const float d1 = adp1 - bdp1, d2 = adp2 - bdp2;
+    const float y1 = -d1 * d1 / reg1, y2 = -d2 * d2 / reg2;
+    const float dot_p = (float)dot(dira, dirb);
     float angle = (float)(acos((double)fmaxf(fminf(dot_p, 1.0f), -1.0f)) / M_PI * 180.0f);
     if (angle > 90.0f) angle = 180.0f - angle;
     const float ya = -angle * angle / sc.two_sigA_sqr;
-    if (ya < -0.70f) return 0.0f;
     const float sim_a = (float)exp((double)ya);
     const float sim_p = fminf((float)exp((double)y1), (float)exp((double)y2));
-    const float sim = fminf(sim_a, sim_p);
-    return sim > sc.min_sim ? sim : 0.0f;
+    return fminf(sim_a, sim_p);
 }
 
 // ---- support bitsets (batched), presence propagation (the chain), scores (batched) ---------------------
@@ -291,7 +326,8 @@ __global__ void k_bits_len(uint32_t G, const uint32_t* __restrict__ off, uint32_
 // sim_scoring), so the hypotheses are rank-sorted by dp1 in LDS and hypothesis i evaluates only the
 // contiguous window of candidates inside that radius (found by binary search) instead of all L: O(L^2) cheap
 // compares for the sort + O(L * window) evaluations.  Lists longer than kSortCap take the all-pairs loop.
-constexpr uint32_t kSortCap = 1024;
+constexpr uint32_t kSortCap = 512;
+constexpr uint32_t kStageCap = 128;   // lists up to this length keep the fields the similarity reads in LDS
 __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t* __restrict__ off,
                                                      const uint32_t* __restrict__ boff,
                                                      const DEntry* __restrict__ dents, uint64_t* __restrict__ bits,
@@ -299,6 +335,9 @@ __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t*
     __shared__ float s_key[4][kSortCap];      // dp1 in canonical order, then reused: dp1 in sorted order
     __shared__ float s_sorted[4][kSortCap];
     __shared__ uint16_t s_sidx[4][kSortCap];  // canonical index of sorted position
+    __shared__ double s_dir[4][kStageCap][3];
+    __shared__ float s_dp2[4][kStageCap];
+    __shared__ uint32_t s_tvf[4][kStageCap];  // tgt_view | zero-length flag << 31
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t g = blockIdx.x * 4 + wave;
     if (g >= G) return;
@@ -307,8 +346,18 @@ __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t*
     const uint32_t W = (L + 63) / 64;
     uint64_t* rows = bits + boff[g];
     if (L <= kSortCap) {
+        const bool staged = L <= kStageCap;
         for (uint32_t m0 = 0; m0 < L; m0 += 64)
-            if (m0 + lane < L) s_key[wave][m0 + lane] = dents[b + m0 + lane].dp1;
+            if (m0 + lane < L) {
+                const DEntry& e = dents[b + m0 + lane];
+                s_key[wave][m0 + lane] = e.dp1;
+                if (staged) {
+                    s_dir[wave][m0 + lane][0] = e.dir[0]; s_dir[wave][m0 + lane][1] = e.dir[1];
+                    s_dir[wave][m0 + lane][2] = e.dir[2];
+                    s_dp2[wave][m0 + lane] = e.dp2;
+                    s_tvf[wave][m0 + lane] = e.tgt_view | ((e.flags & kDZeroLen) ? 0x80000000u : 0u);
+                }
+            }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -332,7 +381,8 @@ __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t*
             const uint32_t i = m0 + lane;
             if (i < L) {
                 const DEntry a = dents[b + i];
-                for (uint32_t w = 0; w < W; ++w) rows[(size_t)i * W + w] = 0ull;
+                const d3 ad{a.dir[0], a.dir[1], a.dir[2]};
+                if (!staged) for (uint32_t w = 0; w < W; ++w) rows[(size_t)i * W + w] = 0ull;
                 // window of candidates: |dp1_j - dp1_i| <= r  (r padded against float rounding)
                 float r = sqrtf(0.72f * a.reg1) * 1.0001f + 1e-30f;
                 uint32_t lo = 0, hi = L;
@@ -345,13 +395,30 @@ __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t*
                     while (x < y) { const uint32_t m = (x + y) >> 1; if (s_sorted[wave][m] <= kh) x = m + 1; else y = m; }
                     hi = x;
                 }
+                if (staged) {
+                    // W <= 2 words: the row is accumulated in registers and written once
+                    uint64_t r0 = 0, r1 = 0;
+                    for (uint32_t p = lo; p < hi; ++p) {
+                        const uint32_t j = s_sidx[wave][p];
+                        const uint32_t tvf = s_tvf[wave][j];
+                        if ((tvf & 0x7FFFFFFFu) == a.tgt_view) continue;
+                        const d3 od{s_dir[wave][j][0], s_dir[wave][j][1], s_dir[wave][j][2]};
+                        if (sim_decide(ad, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2, od,
+                                       (tvf >> 31) != 0, s_key[wave][j], s_dp2[wave][j], sc)) {
+                            if (j < 64) r0 |= 1ull << j; else r1 |= 1ull << (j - 64);
+                        }
+                    }
+                    rows[(size_t)i * W] = r0;
+                    if (W > 1) rows[(size_t)i * W + 1] = r1;
+                    continue;
+                }
                 for (uint32_t p = lo; p < hi; ++p) {
                     const uint32_t j = s_sidx[wave][p];
                     const DEntry& o = dents[b + j];
                     if (o.tgt_view == a.tgt_view) continue;
-                    const float sim = sim_scoring(a.dir, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
-                                                  o.dir, (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc);
-                    if (sim > 0.0f) rows[(size_t)i * W + (j >> 6)] |= 1ull << (j & 63);
+                    if (sim_decide(ad, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
+                                   d3{o.dir[0], o.dir[1], o.dir[2]}, (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc))
+                        rows[(size_t)i * W + (j >> 6)] |= 1ull << (j & 63);
                 }
             }
         }
@@ -362,15 +429,16 @@ __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t*
         const uint32_t i = m0 + lane;
         if (i < L) {
             const DEntry a = dents[b + i];
+            const d3 ad{a.dir[0], a.dir[1], a.dir[2]};
             for (uint32_t w = 0; w < W; ++w) {
                 uint64_t word = 0;
                 const uint32_t jn = min(64u, L - w * 64);
                 for (uint32_t jj = 0; jj < jn; ++jj) {
                     const DEntry& o = dents[b + w * 64 + jj];
                     if (o.tgt_view == a.tgt_view) continue;
-                    const float sim = sim_scoring(a.dir, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
-                                                  o.dir, (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc);
-                    word |= (uint64_t)(sim > 0.0f) << jj;
+                    word |= (uint64_t)sim_decide(ad, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
+                                                 d3{o.dir[0], o.dir[1], o.dir[2]}, (o.flags & kDZeroLen) != 0, o.dp1,
+                                                 o.dp2, sc) << jj;
                 }
                 rows[(size_t)i * W + w] = word;
             }
@@ -450,8 +518,8 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
                         const uint32_t j = w * 64 + (uint32_t)__ffsll((long long)m) - 1u;
                         m &= m - 1;
                         const DEntry& o = dents[b + j];
-                        const float sim = sim_scoring(a.dir, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
-                                                      o.dir, (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc);
+                        const float sim = sim_value(d3{a.dir[0], a.dir[1], a.dir[2]}, a.dp1, a.dp2, a.reg1, a.reg2,
+                                                    d3{o.dir[0], o.dir[1], o.dir[2]}, o.dp1, o.dp2, sc);
                         if (o.tgt_view == cur_cam) {
                             if (sim > cur) { score3D -= cur; score3D += sim; cur = sim; }
                         } else {
@@ -744,10 +812,10 @@ hipError_t launch_inv_fill(const PairDesc* pairs, uint32_t n_pairs, uint64_t max
 hipError_t launch_build_lists_all(uint32_t G, const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base,
                                   const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
                                   const uint32_t* off, const uint32_t* inv_off, const InvRef* refs, const Slot* slots,
-                                  DEntry* dents, uint32_t* eref, hipStream_t st) {
+                                  DEntry* dents, uint32_t* eref, uint32_t uniform_K, hipStream_t st) {
     if (!G) return hipSuccess;
     hipLaunchKernelGGL(k_build_lists_all, dim3((G + 3) / 4), dim3(256), 0, st, G, views, pairs, seg_base, gseg_view,
-                       vout_off, vout_pairs, off, inv_off, refs, slots, dents, eref);
+                       vout_off, vout_pairs, off, inv_off, refs, slots, dents, eref, uniform_K);
     return hipGetLastError();
 }
 hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, hipStream_t st) {
@@ -756,9 +824,8 @@ hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, hipSt
     return hipGetLastError();
 }
 hipError_t launch_support_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry* dents,
-                              uint64_t* bits, float two_sigA_sqr, float min_sim, hipStream_t st) {
+                              uint64_t* bits, SimConst sc, hipStream_t st) {
     if (!G) return hipSuccess;
-    SimConst sc{two_sigA_sqr, min_sim};
     hipLaunchKernelGGL(k_support_all, dim3((G + 3) / 4), dim3(256), 0, st, G, off, boff, dents, bits, sc);
     return hipGetLastError();
 }
@@ -772,9 +839,8 @@ hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, co
 }
 hipError_t launch_score_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view,
                             DEntry* dents, const uint64_t* bits, Slot* slots, uint32_t* max_score_bits,
-                            float two_sigA_sqr, float min_sim, hipStream_t st) {
+                            SimConst sc, hipStream_t st) {
     if (!G) return hipSuccess;
-    SimConst sc{two_sigA_sqr, min_sim};
     hipLaunchKernelGGL(k_score_all, dim3((G + 3) / 4), dim3(256), 0, st, G, off, boff, gseg_view, dents, bits, slots,
                        max_score_bits, sc);
     return hipGetLastError();

@@ -27,16 +27,15 @@ hipError_t launch_inv_fill(const PairDesc*, uint32_t n_pairs, uint64_t max_slots
 hipError_t launch_build_lists_all(uint32_t G, const ViewDev*, const PairDesc*, const uint32_t* seg_base,
                                   const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
                                   const uint32_t* off, const uint32_t* inv_off, const InvRef*, const Slot*, DEntry*,
-                                  uint32_t* eref, hipStream_t);
+                                  uint32_t* eref, uint32_t uniform_K, hipStream_t);
 hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, hipStream_t);
 hipError_t launch_support_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry*, uint64_t* bits,
-                              float two_sigA_sqr, float min_sim, hipStream_t);
+                              SimConst, hipStream_t);
 hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff,
                                 const uint32_t* inv_off, const uint32_t* eref, uint64_t* bits, uint8_t* positive,
                                 hipStream_t);
 hipError_t launch_score_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view, DEntry*,
-                            const uint64_t* bits, Slot*, uint32_t* max_score_bits, float two_sigA_sqr, float min_sim,
-                            hipStream_t);
+                            const uint64_t* bits, Slot*, uint32_t* max_score_bits, SimConst, hipStream_t);
 hipError_t launch_filter_all(uint32_t G, const uint32_t* off, const uint32_t* gseg_view, DEntry*,
                              const uint32_t* max_score_bits, uint32_t* surv_cnt, uint32_t* has_best,
                              uint32_t* best_pos, hipStream_t);
@@ -287,6 +286,38 @@ void orientation_thresholds(double& lo, double& hi) {
     x = -1.0; y = 1.0;                        // pred(d) = acos(d) < a2 : false at -1, true at 1
     for (int it = 0; it < 200 && std::nextafter(x, y) < y; ++it) { const double m = 0.5 * (x + y); if (std::acos(m) < a2) y = m; else x = m; }
     lo = y;
+}
+
+// Thresholds of the decision form of similarityForScoring (k_views.hip sim_decide): the smallest/largest float
+// arguments for which the reference's own expressions (libm expf / acos as line3D.cc:1428,1438,1575 call them)
+// exceed L3D_DEF_MIN_SIMILARITY_3D.  Every expression is monotone in its argument, so bisection over floats
+// finds the exact switch points.
+template <class Pred>
+float first_true(float lo, float hi, Pred pred) {   // pred(lo) false, pred(hi) true, monotone; returns first true
+    for (int it = 0; it < 300; ++it) {
+        const float mid = lo + 0.5f * (hi - lo);
+        if (!(mid > lo && mid < hi)) break;
+        if (pred(mid)) hi = mid; else lo = mid;
+    }
+    return hi;
+}
+SimConst sim_thresholds(float two_sigA_sqr) {
+    SimConst sc;
+    sc.two_sigA_sqr = two_sigA_sqr;
+    const float min_sim = 0.5f;   // L3D_DEF_MIN_SIMILARITY_3D
+    auto pe = [&](float y) { return expf(y) > min_sim; };
+    // y_thr = largest y that fails
+    const float first = first_true(-2.0f, 0.0f, pe);
+    sc.y_thr = std::nextafterf(first, -INFINITY);
+    auto pa = [&](float x) {   // angleBetweenSeg3D(.., undirected) + sim_a, line3D.cc:1571-1583, 1428
+        float angle = (float)(std::acos(std::fmax(std::fmin((double)x, 1.0), -1.0)) / M_PI * 180.0f);
+        if (angle > 90.0f) angle = 180.0f - angle;
+        return expf(-angle * angle / two_sigA_sqr) > min_sim;
+    };
+    if (pa(0.0f)) { sc.x_hi = 0.0f; sc.x_lo = 0.0f; return sc; }   // every direction passes
+    sc.x_hi = first_true(0.0f, 1.0f, pa);
+    sc.x_lo = -first_true(0.0f, 1.0f, [&](float m) { return pa(-m); });
+    return sc;
 }
 
 float ev_ms(hipEvent_t a, hipEvent_t b) {
@@ -633,6 +664,7 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(hipMemcpyAsync(tot, c->d_scal.p, 7 * 4, hipMemcpyDeviceToHost, st));
     L3D_HIP_CHECK(hipStreamSynchronize(st));   // also covers the local `vout`
     const uint32_t n_ents = c->n_ents = tot[0], n_inv = tot[5], n_words = tot[6];
+    c->tm.list_entries = n_ents; c->tm.support_words = n_words;
     L3D_HIP_CHECK(c->d_dents.reserve(std::max<uint32_t>(n_ents, 1)));
     L3D_HIP_CHECK(c->d_refs.reserve(std::max<uint32_t>(n_inv, 1)));
     L3D_HIP_CHECK(c->d_bits.reserve(std::max<uint32_t>(n_words, 1)));
@@ -643,16 +675,17 @@ int l3d_match_finish(l3d_ctx* c) {
                                   c->d_inv_pos.p, c->d_refs.p, st));
     L3D_HIP_CHECK(launch_build_lists_all(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p,
                                          c->d_vout_off.p, c->d_vout_pairs.p, c->d_off.p, c->d_inv_off.p, c->d_refs.p,
-                                         c->d_slots.p, c->d_dents.p, c->d_eref.p, st));
+                                         c->d_slots.p, c->d_dents.p, c->d_eref.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, st));
+    const SimConst simc = sim_thresholds(c->two_sigA_sqr);
     // all L^2 similarity decisions of all segments (chain independent)
-    L3D_HIP_CHECK(launch_support_all(G, c->d_off.p, c->d_boff.p, c->d_dents.p, c->d_bits.p, c->two_sigA_sqr, 0.5f, st));
+    L3D_HIP_CHECK(launch_support_all(G, c->d_off.p, c->d_boff.p, c->d_dents.p, c->d_bits.p, simc, st));
     // ---- chain: one bit-propagation launch per view, ascending camID ----
     for (uint32_t vi = 0; vi < V; ++vi)
         L3D_HIP_CHECK(launch_presence_view(c->seg_base[vi], c->order[vi]->M, c->d_off.p, c->d_boff.p, c->d_inv_off.p,
                                            c->d_eref.p, c->d_bits.p, c->d_positive.p, st));
     // scores of all views
     L3D_HIP_CHECK(launch_score_all(G, c->d_off.p, c->d_boff.p, c->d_gseg_view.p, c->d_dents.p, c->d_bits.p,
-                                   c->d_slots.p, c->d_max_score.p, c->two_sigA_sqr, 0.5f, st));
+                                   c->d_slots.p, c->d_max_score.p, simc, st));
     // ---- post-pass: filterMatches for all views ----
     L3D_HIP_CHECK(launch_filter_all(G, c->d_off.p, c->d_gseg_view.p, c->d_dents.p, c->d_max_score.p, c->d_surv_cnt.p,
                                     c->d_has_best.p, c->d_best_pos.p, st));

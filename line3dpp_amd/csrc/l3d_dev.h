@@ -127,6 +127,13 @@ struct HypRec {
 };
 static_assert(sizeof(HypRec) == 128, "HypRec is 128 bytes");
 
+// constants of similarityForScoring (line3D.cc:1417-1446) and the thresholds of its decision form (k_views.hip)
+struct SimConst {
+    float two_sigA_sqr;
+    float y_thr;        // expf(y) > L3D_DEF_MIN_SIMILARITY_3D  <=>  y > y_thr
+    float x_hi, x_lo;   // angular component > L3D_DEF_MIN_SIMILARITY_3D  <=>  x >= x_hi || x <= x_lo
+};
+
 // per-view scalars the affinity kernels read
 struct ViewAff {
     float k;              // View::k_
