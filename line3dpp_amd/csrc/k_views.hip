@@ -126,7 +126,7 @@ __global__ void k_inv_fill(const PairDesc* __restrict__ pairs, const uint32_t* _
 
 // scoringCPU line3D.cc:1233-1248: unprojection + spatial regularisers of one hypothesis
 __device__ __forceinline__ DEntry make_dentry(const ViewDev& v, const ViewDev& vt, const SegX& sx, float dp1,
-                                              float dp2, uint64_t ref, uint32_t tgt_view, uint32_t pair,
+                                              float dp2, uint32_t ref, uint32_t tgt_view, uint32_t pair,
                                               bool inverse) {
     const Seg3 s3 = unproject(v.C, sx.r1, sx.r2, dp1, dp2);
     const float k = v.k;
@@ -138,7 +138,6 @@ __device__ __forceinline__ DEntry make_dentry(const ViewDev& v, const ViewDev& v
     reg1 = 0.5f * (reg1 + 2.0f * sig1_t * sig1_t);
     reg2 = 0.5f * (reg2 + 2.0f * sig2_t * sig2_t);
     DEntry d;
-    d.dir[0] = s3.dir.x; d.dir[1] = s3.dir.y; d.dir[2] = s3.dir.z;
     d.ref = ref;
     d.dp1 = dp1; d.dp2 = dp2; d.reg1 = reg1; d.reg2 = reg2;
     d.score3D = 0.0f;
@@ -146,6 +145,11 @@ __device__ __forceinline__ DEntry make_dentry(const ViewDev& v, const ViewDev& v
     d.flags = (inverse ? kDInverse : 0u) | (s3.length < kEps ? kDZeroLen : 0u);
     d.pair = pair;
     return d;
+}
+
+// Segment3D::dir_ of a hypothesis of the segment with rays sx (view centre C): recomputed instead of stored
+__device__ __forceinline__ d3 entry_dir(const double* C, const SegX& sx, float dp1, float dp2) {
+    return unproject(C, sx.r1, sx.r2, dp1, dp2).dir;
 }
 
 // Batched list build, one wave per 2D segment of any view (global segment id g): writes the segment's
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256) void k_build_lists_all(uint32_t G, const ViewD
             const uint64_t ref = pd.slot_off + (uint64_t)r.src_row * pd.K + r.j;
             const Slot s = slots[ref];
             DEntry& d = dents[b + rank];
-            d.ref = ref; d.dp1 = s.dq1; d.dp2 = s.dq2; d.tgt_view = r.src_view; d.pair = r.pair; d.flags = kDInverse;
+            d.ref = (uint32_t)ref; d.dp1 = s.dq1; d.dp2 = s.dq2; d.tgt_view = r.src_view; d.pair = r.pair; d.flags = kDInverse;
         }
     }
     // ---- phase 1b: fresh hypotheses ----
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256) void k_build_lists_all(uint32_t G, const ViewD
             const uint64_t m = __ballot(alive);
             if (alive) {
                 DEntry& d = dents[pos + (uint32_t)__popcll(m & lt_mask)];
-                d.ref = ref; d.dp1 = s.dp1; d.dp2 = s.dp2; d.tgt_view = tv; d.pair = pi; d.flags = 0;
+                d.ref = (uint32_t)ref; d.dp1 = s.dp1; d.dp2 = s.dp2; d.tgt_view = tv; d.pair = pi; d.flags = 0;
             }
             pos += (uint32_t)__popcll(m);
         }
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256) void k_build_lists_all(uint32_t G, const ViewD
             const uint64_t m = __ballot(alive);
             if (alive) {
                 DEntry& d = dents[pos + (uint32_t)__popcll(m & lt_mask)];
-                d.ref = row0 + j0 + lane; d.dp1 = s.dp1; d.dp2 = s.dp2; d.tgt_view = pd.tgt; d.pair = pi; d.flags = 0;
+                d.ref = (uint32_t)(row0 + j0 + lane); d.dp1 = s.dp1; d.dp2 = s.dp2; d.tgt_view = pd.tgt; d.pair = pi; d.flags = 0;
             }
             pos += (uint32_t)__popcll(m);
         }
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void k_build_lists_all(uint32_t G, const ViewD
         if (m0 + lane < L) {
             DEntry& d = dents[b + m0 + lane];
             d = make_dentry(v, views[d.tgt_view], sx, d.dp1, d.dp2, d.ref, d.tgt_view, d.pair, (d.flags & kDInverse) != 0);
-            eref[b + m0 + lane] = (uint32_t)d.ref;   // slot index; the first n_inv entries of a list are the inverse ones
+            eref[b + m0 + lane] = d.ref;   // slot index; the first n_inv entries of a list are the inverse ones
         }
     }
 }
@@ -282,6 +286,9 @@ __device__ __forceinline__ bool sim_decide(const d3 dira, bool zeroa, float adp1
                                            const d3 dirb, bool zerob, float bdp1, float bdp2, const SimConst sc) {
     if (zeroa || zerob) return false;
     const float d1 = adp1 - bdp1, d2 = adp2 - bdp2;
+    // division-free early-out with a safety margin: d*d > 0.72*reg => y < -0.70 < y_thr even after rounding;
+    // NaN/inf fall through to the exact comparison
+    if (d1 * d1 > 0.72f * reg1 || d2 * d2 > 0.72f * reg2) return false;
     const float y1 = -d1 * d1 / reg1, y2 = -d2 * d2 / reg2;
     // NaN components drop out of the fmin chain; the angular component is never NaN (x is clamped, sigma_a > 0)
     if (y1 == y1 && !(y1 > sc.y_thr)) return false;
@@ -331,7 +338,9 @@ constexpr uint32_t kStageCap = 128;   // lists up to this length keep the fields
 __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t* __restrict__ off,
                                                      const uint32_t* __restrict__ boff,
                                                      const DEntry* __restrict__ dents, uint64_t* __restrict__ bits,
-                                                     SimConst sc) {
+                                                     const ViewDev* __restrict__ views,
+                                                     const uint32_t* __restrict__ seg_base,
+                                                     const uint32_t* __restrict__ gseg_view, SimConst sc) {
     __shared__ float s_key[4][kSortCap];      // dp1 in canonical order, then reused: dp1 in sorted order
     __shared__ float s_sorted[4][kSortCap];
     __shared__ uint16_t s_sidx[4][kSortCap];  // canonical index of sorted position
@@ -345,6 +354,9 @@ __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t*
     if (L == 0) return;
     const uint32_t W = (L + 63) / 64;
     uint64_t* rows = bits + boff[g];
+    const uint32_t vi = gseg_view[g];
+    const ViewDev& v = views[vi];
+    const SegX sx = v.segx[g - seg_base[vi]];
     if (L <= kSortCap) {
         const bool staged = L <= kStageCap;
         for (uint32_t m0 = 0; m0 < L; m0 += 64)
@@ -352,8 +364,9 @@ __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t*
                 const DEntry& e = dents[b + m0 + lane];
                 s_key[wave][m0 + lane] = e.dp1;
                 if (staged) {
-                    s_dir[wave][m0 + lane][0] = e.dir[0]; s_dir[wave][m0 + lane][1] = e.dir[1];
-                    s_dir[wave][m0 + lane][2] = e.dir[2];
+                    const d3 ed = entry_dir(v.C, sx, e.dp1, e.dp2);
+                    s_dir[wave][m0 + lane][0] = ed.x; s_dir[wave][m0 + lane][1] = ed.y;
+                    s_dir[wave][m0 + lane][2] = ed.z;
                     s_dp2[wave][m0 + lane] = e.dp2;
                     s_tvf[wave][m0 + lane] = e.tgt_view | ((e.flags & kDZeroLen) ? 0x80000000u : 0u);
                 }
@@ -381,7 +394,8 @@ __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t*
             const uint32_t i = m0 + lane;
             if (i < L) {
                 const DEntry a = dents[b + i];
-                const d3 ad{a.dir[0], a.dir[1], a.dir[2]};
+                const d3 ad = staged ? d3{s_dir[wave][i][0], s_dir[wave][i][1], s_dir[wave][i][2]}
+                                     : entry_dir(v.C, sx, a.dp1, a.dp2);
                 if (!staged) for (uint32_t w = 0; w < W; ++w) rows[(size_t)i * W + w] = 0ull;
                 // window of candidates: |dp1_j - dp1_i| <= r  (r padded against float rounding)
                 float r = sqrtf(0.72f * a.reg1) * 1.0001f + 1e-30f;
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t*
                     const DEntry& o = dents[b + j];
                     if (o.tgt_view == a.tgt_view) continue;
                     if (sim_decide(ad, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
-                                   d3{o.dir[0], o.dir[1], o.dir[2]}, (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc))
+                                   entry_dir(v.C, sx, o.dp1, o.dp2), (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc))
                         rows[(size_t)i * W + (j >> 6)] |= 1ull << (j & 63);
                 }
             }
@@ -429,7 +443,7 @@ __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t*
         const uint32_t i = m0 + lane;
         if (i < L) {
             const DEntry a = dents[b + i];
-            const d3 ad{a.dir[0], a.dir[1], a.dir[2]};
+            const d3 ad = entry_dir(v.C, sx, a.dp1, a.dp2);
             for (uint32_t w = 0; w < W; ++w) {
                 uint64_t word = 0;
                 const uint32_t jn = min(64u, L - w * 64);
@@ -437,7 +451,7 @@ __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t*
                     const DEntry& o = dents[b + w * 64 + jj];
                     if (o.tgt_view == a.tgt_view) continue;
                     word |= (uint64_t)sim_decide(ad, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
-                                                 d3{o.dir[0], o.dir[1], o.dir[2]}, (o.flags & kDZeroLen) != 0, o.dp1,
+                                                 entry_dir(v.C, sx, o.dp1, o.dp2), (o.flags & kDZeroLen) != 0, o.dp1,
                                                  o.dp2, sc) << jj;
                 }
                 rows[(size_t)i * W + w] = word;
@@ -494,7 +508,8 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
                                                    const uint32_t* __restrict__ gseg_view,
                                                    DEntry* __restrict__ dents, const uint64_t* __restrict__ bits,
                                                    Slot* __restrict__ slots, uint32_t* __restrict__ max_score_bits,
-                                                   SimConst sc) {
+                                                   const ViewDev* __restrict__ views,
+                                                   const uint32_t* __restrict__ seg_base, SimConst sc) {
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t g = blockIdx.x * 4 + wave;
     if (g >= G) return;
@@ -503,12 +518,16 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
     const uint32_t W = (L + 63) / 64;
     const uint64_t* rows = bits + boff[g];
     const uint64_t* P = rows + (size_t)L * W;
+    const uint32_t vi = gseg_view[g];
+    const ViewDev& v = views[vi];
+    const SegX sx = v.segx[g - seg_base[vi]];
     float vmax = 0.0f;
     for (uint32_t m0 = 0; m0 < L; m0 += 64) {
         const uint32_t i = m0 + lane;
         if (i < L) {
             const bool present = (P[i >> 6] >> (i & 63)) & 1ull;
             DEntry a = dents[b + i];
+            const d3 ad = entry_dir(v.C, sx, a.dp1, a.dp2);
             float score3D = 0.0f, cur = 0.0f;
             uint32_t cur_cam = kEmpty;
             if (present) {
@@ -518,8 +537,8 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
                         const uint32_t j = w * 64 + (uint32_t)__ffsll((long long)m) - 1u;
                         m &= m - 1;
                         const DEntry& o = dents[b + j];
-                        const float sim = sim_value(d3{a.dir[0], a.dir[1], a.dir[2]}, a.dp1, a.dp2, a.reg1, a.reg2,
-                                                    d3{o.dir[0], o.dir[1], o.dir[2]}, o.dp1, o.dp2, sc);
+                        const float sim = sim_value(ad, a.dp1, a.dp2, a.reg1, a.reg2,
+                                                    entry_dir(v.C, sx, o.dp1, o.dp2), o.dp1, o.dp2, sc);
                         if (o.tgt_view == cur_cam) {
                             if (sim > cur) { score3D -= cur; score3D += sim; cur = sim; }
                         } else {
@@ -538,7 +557,7 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
-    if (lane == 0 && vmax > 0.0f) atomicMax(&max_score_bits[gseg_view[g]], __float_as_uint(vmax));
+    if (lane == 0 && vmax > 0.0f) atomicMax(&max_score_bits[vi], __float_as_uint(vmax));
 }
 
 // ---- post-pass --------------------------------------------------------------------------------------
@@ -790,6 +809,18 @@ hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* 
 }
 
 // ---- launchers --------------------------------------------------------------------------------------
+// gseg_view[g] = view of global segment g: grid = (segment blocks, views)
+__global__ void k_fill_gseg_view(const uint32_t* __restrict__ seg_base, uint32_t* __restrict__ gseg_view) {
+    const uint32_t v = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = seg_base[v];
+    if (b + i < seg_base[v + 1]) gseg_view[b + i] = v;
+}
+hipError_t launch_fill_gseg_view(const uint32_t* seg_base, uint32_t V, uint32_t max_M, uint32_t* gseg_view,
+                                 hipStream_t st) {
+    if (!V || !max_M) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_gseg_view, dim3((max_M + 255) / 256, V), dim3(256), 0, st, seg_base, gseg_view);
+    return hipGetLastError();
+}
 hipError_t launch_orient_all(const ViewDev* views, const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots,
                              const uint32_t* seg_base, Slot* slots, uint32_t G, unsigned long long* cnt_pack,
                              uint32_t* inv_pos, uint32_t* cnt_all, uint32_t* cnt_inv, double thr_lo, double thr_hi,
@@ -824,9 +855,11 @@ hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, hipSt
     return hipGetLastError();
 }
 hipError_t launch_support_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry* dents,
-                              uint64_t* bits, SimConst sc, hipStream_t st) {
+                              uint64_t* bits, const ViewDev* views, const uint32_t* seg_base,
+                              const uint32_t* gseg_view, SimConst sc, hipStream_t st) {
     if (!G) return hipSuccess;
-    hipLaunchKernelGGL(k_support_all, dim3((G + 3) / 4), dim3(256), 0, st, G, off, boff, dents, bits, sc);
+    hipLaunchKernelGGL(k_support_all, dim3((G + 3) / 4), dim3(256), 0, st, G, off, boff, dents, bits, views, seg_base,
+                       gseg_view, sc);
     return hipGetLastError();
 }
 hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff,
@@ -839,10 +872,10 @@ hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, co
 }
 hipError_t launch_score_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view,
                             DEntry* dents, const uint64_t* bits, Slot* slots, uint32_t* max_score_bits,
-                            SimConst sc, hipStream_t st) {
+                            const ViewDev* views, const uint32_t* seg_base, SimConst sc, hipStream_t st) {
     if (!G) return hipSuccess;
     hipLaunchKernelGGL(k_score_all, dim3((G + 3) / 4), dim3(256), 0, st, G, off, boff, gseg_view, dents, bits, slots,
-                       max_score_bits, sc);
+                       max_score_bits, views, seg_base, sc);
     return hipGetLastError();
 }
 hipError_t launch_filter_all(uint32_t G, const uint32_t* off, const uint32_t* gseg_view, DEntry* dents,

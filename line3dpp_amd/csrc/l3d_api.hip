@@ -17,6 +17,7 @@ void set_error(const std::string& s) { g_err = s; }
 
 // ---- prototypes of the launchers in k_views.hip / k_affinity.hip -------------------------------
 hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, uint32_t* total, hipStream_t);
+hipError_t launch_fill_gseg_view(const uint32_t* seg_base, uint32_t V, uint32_t max_M, uint32_t* gseg_view, hipStream_t);
 hipError_t launch_orient_all(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
                              const uint32_t* seg_base, Slot* slots, uint32_t G, unsigned long long* cnt_pack,
                              uint32_t* inv_pos, uint32_t* cnt_all, uint32_t* cnt_inv, double thr_lo, double thr_hi,
@@ -30,12 +31,13 @@ hipError_t launch_build_lists_all(uint32_t G, const ViewDev*, const PairDesc*, c
                                   uint32_t* eref, uint32_t uniform_K, hipStream_t);
 hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, hipStream_t);
 hipError_t launch_support_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry*, uint64_t* bits,
-                              SimConst, hipStream_t);
+                              const ViewDev*, const uint32_t* seg_base, const uint32_t* gseg_view, SimConst, hipStream_t);
 hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff,
                                 const uint32_t* inv_off, const uint32_t* eref, uint64_t* bits, uint8_t* positive,
                                 hipStream_t);
 hipError_t launch_score_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view, DEntry*,
-                            const uint64_t* bits, Slot*, uint32_t* max_score_bits, SimConst, hipStream_t);
+                            const uint64_t* bits, Slot*, uint32_t* max_score_bits, const ViewDev*, const uint32_t* seg_base,
+                            SimConst, hipStream_t);
 hipError_t launch_filter_all(uint32_t G, const uint32_t* off, const uint32_t* gseg_view, DEntry*,
                              const uint32_t* max_score_bits, uint32_t* surv_cnt, uint32_t* has_best,
                              uint32_t* best_pos, hipStream_t);
@@ -66,7 +68,7 @@ using namespace l3d;
 struct l3d_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    std::mutex mu;                                  // view_mutex_/view_reserve_mutex_ stand-in
+    std::recursive_mutex mu;                                  // view_mutex_/view_reserve_mutex_ stand-in
     std::map<uint32_t, std::unique_ptr<HostView>> views;   // views_ (ascending camID)
     std::vector<HostView*> order;                   // view index -> view (ascending camID)
     std::vector<float> views_avg_depths;            // views_avg_depths_
@@ -98,6 +100,14 @@ struct l3d_ctx {
     DevBuf<float2> d_src_band, d_chunk_band, d_tgt_band;
     DevBuf<float4> d_tgt_sf;
     bool use_cull = true;
+    // pinned staging of the small host->device tables (reused across calls; every public call ends synchronised)
+    PinnedBuf<ViewDev> h_views;
+    PinnedBuf<PairDesc> h_pairs;
+    PinnedBuf<PairCull> h_cull;
+    PinnedBuf<WorkItem> h_work;
+    PinnedBuf<uint32_t> h_vout, h_small;
+    bool timing_pending = false;                    // phase-A events recorded but not read yet
+    uint32_t pending_launches = 0;
     DevBuf<uint32_t> d_row_counts;
     // phase B (global over all views; G = sum of M)
     uint32_t G = 0, n_ents = 0, n_surv = 0, n_hyps = 0;
@@ -131,7 +141,7 @@ struct l3d_ctx {
     std::vector<ReconLine> lines3D;                 // lines3D_ (original frame)
     bool lines_done = false;
     // timings
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[10] = {};
     l3d_timings tm{};
 };
 
@@ -257,7 +267,8 @@ void make_cull(const double F[9], double ws, double hs, double wt, double ht, Pa
 int upload_views(l3d_ctx& c) {
     const size_t V = c.order.size();
     L3D_HIP_CHECK(c.d_views.reserve(V));
-    std::vector<ViewDev> hv(V);
+    L3D_HIP_CHECK(c.h_views.reserve(V));
+    ViewDev* hv = c.h_views.p;
     uint32_t max_M = 0;
     for (size_t i = 0; i < V; ++i) {
         HostView& v = *c.order[i];
@@ -269,8 +280,7 @@ int upload_views(l3d_ctx& c) {
         d.cx = 0.5f * (float)v.width; d.cy = 0.5f * (float)v.height; d.pad = 0;
         max_M = std::max(max_M, v.M);
     }
-    L3D_HIP_CHECK(hipMemcpyAsync(c.d_views.p, hv.data(), V * sizeof(ViewDev), hipMemcpyHostToDevice, c.stream));
-    L3D_HIP_CHECK(hipStreamSynchronize(c.stream));  // host staging vector goes out of scope
+    L3D_HIP_CHECK(hipMemcpyAsync(c.d_views.p, hv, V * sizeof(ViewDev), hipMemcpyHostToDevice, c.stream));
     L3D_HIP_CHECK(launch_prep_views(c.d_views.p, (uint32_t)V, max_M, c.stream));
     return L3D_OK;
 }
@@ -354,6 +364,8 @@ void l3d_destroy(l3d_ctx* c) {
         v.d_seg4.release(); v.d_segf.release(); v.d_segx.release();
     }
     c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release();
+    c->h_views.release(); c->h_pairs.release(); c->h_cull.release(); c->h_work.release(); c->h_vout.release();
+    c->h_small.release();
     c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
     c->d_chunk_band.release(); c->d_tgt_sf.release(); c->d_tgt_band.release();
     c->d_row_counts.release();
@@ -388,7 +400,7 @@ int l3d_add_view(l3d_ctx* c, uint32_t camID, const float* segs4, uint32_t M, con
                  const double t[3], uint32_t width, uint32_t height, float median_depth, const uint32_t* neighbors,
                  uint32_t n_neighbors) {
     if (!c || !K || !R || !t) return fail(L3D_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (std::max(width, height) < 800) return fail(L3D_ERR_IMAGE_SMALL, "image is too small for reliable results");
     if (c->views.count(camID)) return fail(L3D_ERR_ID_IN_USE, "camera ID already in use");
     if (n_neighbors == 0 || !neighbors) return fail(L3D_ERR_NO_NEIGHBORS, "view has no visual neighbors");
@@ -417,7 +429,7 @@ int l3d_add_view(l3d_ctx* c, uint32_t camID, const float* segs4, uint32_t M, con
 
 int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
     if (!c || !p) return fail(L3D_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (c->views.empty()) return fail(L3D_ERR_NO_VIEWS, "no images to match");
     (void)hipSetDevice(c->device);
     // parameter clamps, line3D.cc:394-413
@@ -484,17 +496,26 @@ int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
             matched[v->cam].insert(tcam); matched[tcam].insert(v->cam);
         }
     c->n_slots = slot_off; c->n_rows_total = row_off;
+    if (c->n_slots >= (1ull << 32) || c->pairs.size() >= (1u << 24))
+        return fail(L3D_ERR_LIMIT, "slot buffer / pair list exceed the 32-bit slot and 24-bit pair indices of phase B");
     c->pair_done.assign(c->pairs.size(), 0);
     int rc = upload_views(*c);
     if (rc) return rc;
     L3D_HIP_CHECK(c->d_pairs.reserve(std::max<size_t>(c->pairs.size(), 1)));
-    if (!c->pairs.empty())
-        L3D_HIP_CHECK(hipMemcpy(c->d_pairs.p, c->pairs.data(), c->pairs.size() * sizeof(PairDesc),
-                                hipMemcpyHostToDevice));
+    if (!c->pairs.empty()) {
+        L3D_HIP_CHECK(c->h_pairs.reserve(c->pairs.size()));
+        std::memcpy(c->h_pairs.p, c->pairs.data(), c->pairs.size() * sizeof(PairDesc));
+        L3D_HIP_CHECK(hipMemcpyAsync(c->d_pairs.p, c->h_pairs.p, c->pairs.size() * sizeof(PairDesc),
+                                     hipMemcpyHostToDevice, c->stream));
+    }
     if (c->kNN > 0) L3D_HIP_CHECK(c->d_slots.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(c->d_cull.reserve(std::max<size_t>(c->cull.size(), 1)));
-    if (!c->cull.empty())
-        L3D_HIP_CHECK(hipMemcpy(c->d_cull.p, c->cull.data(), c->cull.size() * sizeof(PairCull), hipMemcpyHostToDevice));
+    if (!c->cull.empty()) {
+        L3D_HIP_CHECK(c->h_cull.reserve(c->cull.size()));
+        std::memcpy(c->h_cull.p, c->cull.data(), c->cull.size() * sizeof(PairCull));
+        L3D_HIP_CHECK(hipMemcpyAsync(c->d_cull.p, c->h_cull.p, c->cull.size() * sizeof(PairCull),
+                                     hipMemcpyHostToDevice, c->stream));
+    }
     L3D_HIP_CHECK(c->d_src_perm.reserve(std::max<uint64_t>(cs_off, 1)));
     L3D_HIP_CHECK(c->d_src_band.reserve(std::max<uint64_t>(cs_off, 1)));
     L3D_HIP_CHECK(c->d_tgt_perm.reserve(std::max<uint64_t>(ct_off, 1)));
@@ -523,42 +544,58 @@ int l3d_get_pairs(l3d_ctx* c, uint32_t* s, uint32_t* t, uint64_t* off) {
     return L3D_OK;
 }
 
+// reads the phase-A events of the last run_match_kernel (the stream must have passed ev[5])
+static void collect_match_timing(l3d_ctx* c) {
+    if (!c->timing_pending) return;
+    c->tm.match_kernel_ms += ev_ms(c->ev[4], c->ev[5]);
+    c->tm.cull_prepare_ms += ev_ms(c->ev[8], c->ev[4]);
+    c->tm.match_kernel_launches += c->pending_launches;
+    c->timing_pending = false; c->pending_launches = 0;
+}
+
+// enqueues (no host synchronisation) the cull set-up and the pair kernel for pairs [first, first+count)
 static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count) {
-    std::vector<WorkItem> work;
+    size_t n_work = 0;
     uint32_t maxK = 0, maxM = 0;
+    for (uint32_t p = first; p < first + count; ++p) n_work += (c->pairs[p].Ms + kMatchRows - 1) / kMatchRows;
+    if (!n_work) return L3D_OK;
+    L3D_HIP_CHECK(c->h_work.reserve(n_work));
+    WorkItem* work = c->h_work.p;
+    size_t w = 0;
     for (uint32_t p = first; p < first + count; ++p) {
         const PairDesc& pd = c->pairs[p];
         maxK = std::max(maxK, pd.K);
         if (c->cull[p].enabled) maxM = std::max(maxM, std::max(pd.Ms, pd.Mt));
-        for (uint32_t s0 = 0; s0 < pd.Ms; s0 += kMatchRows) work.push_back(WorkItem{p, s0});
+        for (uint32_t s0 = 0; s0 < pd.Ms; s0 += kMatchRows) work[w++] = WorkItem{p, s0};
     }
-    if (work.empty()) return L3D_OK;
     if (match_lds_bytes(mode, maxK) > 160 * 1024) return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
-    L3D_HIP_CHECK(c->d_work.reserve(work.size()));
-    L3D_HIP_CHECK(hipMemcpyAsync(c->d_work.p, work.data(), work.size() * sizeof(WorkItem), hipMemcpyHostToDevice,
-                                 c->stream));
-    L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
-    L3D_HIP_CHECK(hipEventRecord(c->ev[6], c->stream));
+    L3D_HIP_CHECK(c->d_work.reserve(n_work));
+    L3D_HIP_CHECK(hipMemcpyAsync(c->d_work.p, work, n_work * sizeof(WorkItem), hipMemcpyHostToDevice, c->stream));
+    L3D_HIP_CHECK(hipEventRecord(c->ev[8], c->stream));
     CullPools pools{c->d_cull.p, c->d_src_perm.p, c->d_src_band.p, c->d_tgt_perm.p, c->d_tgt_sf.p, c->d_tgt_band.p,
                     c->d_chunk_band.p};
     if (mode != 0 || c->brute || !maxM) pools.cull = nullptr;
     else L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
     L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
-    L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)work.size(),
+    L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work,
                                      maxK, c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, c->stream));
     L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));
-    L3D_HIP_CHECK(hipEventSynchronize(c->ev[5]));
-    c->tm.match_kernel_ms += ev_ms(c->ev[4], c->ev[5]);
-    c->tm.cull_prepare_ms += ev_ms(c->ev[6], c->ev[4]);
     if (pools.cull)
         for (uint32_t p = first; p < first + count; ++p) c->tm.culled_pairs += c->cull[p].enabled;
-    c->tm.match_kernel_launches += 1;
+    c->timing_pending = true; c->pending_launches += 1;
     return L3D_OK;
 }
 
+static int match_pairs_impl(l3d_ctx* c, uint32_t first, uint32_t count, bool sync);
+
 int l3d_match_pairs(l3d_ctx* c, uint32_t first, uint32_t count) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    return match_pairs_impl(c, first, count, true);
+}
+
+// sync = false (l3d_match_images): nothing waits for the GPU; the events are read at the end of l3d_match_finish
+static int match_pairs_impl(l3d_ctx* c, uint32_t first, uint32_t count, bool sync) {
     if (c->state != l3d_ctx::BEGUN) return fail(L3D_ERR_STATE, "l3d_match_begin must precede l3d_match_pairs");
     if ((uint64_t)first + count > c->pairs.size()) return fail(L3D_ERR_ARG, "pair range out of bounds");
     (void)hipSetDevice(c->device);
@@ -573,6 +610,8 @@ int l3d_match_pairs(l3d_ctx* c, uint32_t first, uint32_t count) {
         L3D_HIP_CHECK(c->d_row_counts.reserve(std::max<uint32_t>(c->n_rows_total, 1)));
         rc = run_match_kernel(c, 1, first, count);
         if (rc) return rc;
+        L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
+        collect_match_timing(c);
         std::vector<uint32_t> counts(c->n_rows_total);
         L3D_HIP_CHECK(hipMemcpy(counts.data(), c->d_row_counts.p, counts.size() * 4, hipMemcpyDeviceToHost));
         uint64_t slot_off = 0;
@@ -583,6 +622,8 @@ int l3d_match_pairs(l3d_ctx* c, uint32_t first, uint32_t count) {
             slot_off += (uint64_t)pd.Ms * k;
         }
         c->n_slots = slot_off;
+        if (c->n_slots >= (1ull << 32))
+            return fail(L3D_ERR_LIMIT, "slot buffer exceeds the 32-bit slot indices of phase B");
         L3D_HIP_CHECK(c->d_slots.reserve(std::max<uint64_t>(c->n_slots, 1)));
         L3D_HIP_CHECK(hipMemcpy(c->d_pairs.p, c->pairs.data(), c->pairs.size() * sizeof(PairDesc),
                                 hipMemcpyHostToDevice));
@@ -590,8 +631,11 @@ int l3d_match_pairs(l3d_ctx* c, uint32_t first, uint32_t count) {
     }
     if (rc) return rc;
     L3D_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
-    L3D_HIP_CHECK(hipEventSynchronize(c->ev[3]));
-    c->tm.match_pairs_ms += ev_ms(c->ev[2], c->ev[3]);
+    if (sync) {
+        L3D_HIP_CHECK(hipEventSynchronize(c->ev[3]));
+        collect_match_timing(c);
+        c->tm.match_pairs_ms += ev_ms(c->ev[2], c->ev[3]);
+    }
     for (uint32_t p = first; p < first + count; ++p) c->pair_done[p] = 1;
     return L3D_OK;
 }
@@ -606,7 +650,7 @@ int l3d_slot_buffer(l3d_ctx* c, void** dev_ptr, uint64_t* n_slots) {
 // phase B: line3D.cc:745-773 for every view in ascending camID order (k_views.hip)
 int l3d_match_finish(l3d_ctx* c) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (c->state != l3d_ctx::BEGUN) return fail(L3D_ERR_STATE, "l3d_match_begin must precede l3d_match_finish");
     (void)hipSetDevice(c->device);
     hipStream_t st = c->stream;
@@ -615,9 +659,6 @@ int l3d_match_finish(l3d_ctx* c) {
     c->seg_base.assign(V + 1, 0);
     for (uint32_t vi = 0; vi < V; ++vi) c->seg_base[vi + 1] = c->seg_base[vi] + c->order[vi]->M;
     const uint32_t G = c->G = c->seg_base[V];
-    std::vector<uint32_t> gseg_view(G);
-    for (uint32_t vi = 0; vi < V; ++vi)
-        std::fill(gseg_view.begin() + c->seg_base[vi], gseg_view.begin() + c->seg_base[vi + 1], vi);
     uint64_t max_slots = 0;
     for (auto& pd : c->pairs) max_slots = std::max<uint64_t>(max_slots, (uint64_t)pd.Ms * pd.K);
     if (2 * c->n_slots >= (1ull << 32)) return fail(L3D_ERR_LIMIT, "more than 2^32 hypotheses");
@@ -629,23 +670,33 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_best_pos.reserve(G + 1)); L3D_HIP_CHECK(c->d_surv_off.reserve(G + 1));
     L3D_HIP_CHECK(c->d_hyp_off.reserve(G + 1)); L3D_HIP_CHECK(c->d_hyp_of_seg.reserve(G + 1));
     L3D_HIP_CHECK(c->d_medians.reserve(V + 1));
-    L3D_HIP_CHECK(hipMemcpyAsync(c->d_seg_base.p, c->seg_base.data(), (V + 1) * 4, hipMemcpyHostToDevice, st));
-    L3D_HIP_CHECK(hipMemcpyAsync(c->d_gseg_view.p, gseg_view.data(), (size_t)G * 4, hipMemcpyHostToDevice, st));
-    L3D_HIP_CHECK(hipStreamSynchronize(st));   // gseg_view is a local
     L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
-    // outgoing pairs of every view (ascending target), for the fresh part of the lists
-    c->vout_off.assign(V + 1, 0);
-    std::vector<uint32_t> vout;
-    for (uint32_t vi = 0; vi < V; ++vi) {
-        for (uint32_t p : c->order[vi]->out_pairs) vout.push_back(p);
-        c->vout_off[vi + 1] = (uint32_t)vout.size();
+    L3D_HIP_CHECK(c->h_small.reserve(V + 1));
+    std::memcpy(c->h_small.p, c->seg_base.data(), ((size_t)V + 1) * 4);
+    L3D_HIP_CHECK(hipMemcpyAsync(c->d_seg_base.p, c->h_small.p, ((size_t)V + 1) * 4, hipMemcpyHostToDevice, st));
+    {
+        uint32_t max_M = 0;
+        for (auto* v : c->order) max_M = std::max(max_M, v->M);
+        L3D_HIP_CHECK(launch_fill_gseg_view(c->d_seg_base.p, V, max_M, c->d_gseg_view.p, st));
     }
-    L3D_HIP_CHECK(c->d_vout_pairs.reserve(vout.size() + 1));
-    L3D_HIP_CHECK(c->d_vout_off.reserve(V + 1));
-    L3D_HIP_CHECK(hipMemcpyAsync(c->d_vout_off.p, c->vout_off.data(), ((size_t)V + 1) * 4, hipMemcpyHostToDevice, st));
+    // outgoing pairs of every view (ascending target), for the fresh part of the lists
+    // staged as [vout_off (V+1) | vout_pairs (P)] in one pinned buffer
+    c->vout_off.assign(V + 1, 0);
+    L3D_HIP_CHECK(c->h_vout.reserve((size_t)V + 1 + P + 1));
+    {
+        uint32_t n = 0;
+        uint32_t* vp = c->h_vout.p + (V + 1);
+        for (uint32_t vi = 0; vi < V; ++vi) {
+            for (uint32_t p : c->order[vi]->out_pairs) vp[n++] = p;
+            c->vout_off[vi + 1] = n;
+        }
+        std::memcpy(c->h_vout.p, c->vout_off.data(), ((size_t)V + 1) * 4);
+        L3D_HIP_CHECK(c->d_vout_pairs.reserve((size_t)n + 1));
+        L3D_HIP_CHECK(c->d_vout_off.reserve(V + 1));
+        L3D_HIP_CHECK(hipMemcpyAsync(c->d_vout_off.p, c->h_vout.p, ((size_t)V + 1) * 4, hipMemcpyHostToDevice, st));
+        if (n) L3D_HIP_CHECK(hipMemcpyAsync(c->d_vout_pairs.p, vp, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    }
     L3D_HIP_CHECK(c->d_cnt_inv.reserve(G + 1)); L3D_HIP_CHECK(c->d_inv_off.reserve(G + 1));
-    if (!vout.empty())
-        L3D_HIP_CHECK(hipMemcpyAsync(c->d_vout_pairs.p, vout.data(), vout.size() * 4, hipMemcpyHostToDevice, st));
     L3D_HIP_CHECK(c->d_cnt_pack.reserve(G + 1));
     L3D_HIP_CHECK(c->d_inv_pos.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(hipMemsetAsync(c->d_cnt_pack.p, 0, ((size_t)G + 1) * 8, st));
@@ -662,7 +713,7 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(launch_scan(c->d_bits_len.p, G, c->d_boff.p, c->d_scan_tmp.p, c->d_scal.p + 6, st));
     uint32_t tot[7] = {0, 0, 0, 0, 0, 0, 0};
     L3D_HIP_CHECK(hipMemcpyAsync(tot, c->d_scal.p, 7 * 4, hipMemcpyDeviceToHost, st));
-    L3D_HIP_CHECK(hipStreamSynchronize(st));   // also covers the local `vout`
+    L3D_HIP_CHECK(hipStreamSynchronize(st));   // first point at which the host waits for the GPU in matchImages
     const uint32_t n_ents = c->n_ents = tot[0], n_inv = tot[5], n_words = tot[6];
     c->tm.list_entries = n_ents; c->tm.support_words = n_words;
     L3D_HIP_CHECK(c->d_dents.reserve(std::max<uint32_t>(n_ents, 1)));
@@ -678,14 +729,15 @@ int l3d_match_finish(l3d_ctx* c) {
                                          c->d_slots.p, c->d_dents.p, c->d_eref.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, st));
     const SimConst simc = sim_thresholds(c->two_sigA_sqr);
     // all L^2 similarity decisions of all segments (chain independent)
-    L3D_HIP_CHECK(launch_support_all(G, c->d_off.p, c->d_boff.p, c->d_dents.p, c->d_bits.p, simc, st));
+    L3D_HIP_CHECK(launch_support_all(G, c->d_off.p, c->d_boff.p, c->d_dents.p, c->d_bits.p, c->d_views.p, c->d_seg_base.p,
+                                     c->d_gseg_view.p, simc, st));
     // ---- chain: one bit-propagation launch per view, ascending camID ----
     for (uint32_t vi = 0; vi < V; ++vi)
         L3D_HIP_CHECK(launch_presence_view(c->seg_base[vi], c->order[vi]->M, c->d_off.p, c->d_boff.p, c->d_inv_off.p,
                                            c->d_eref.p, c->d_bits.p, c->d_positive.p, st));
     // scores of all views
     L3D_HIP_CHECK(launch_score_all(G, c->d_off.p, c->d_boff.p, c->d_gseg_view.p, c->d_dents.p, c->d_bits.p,
-                                   c->d_slots.p, c->d_max_score.p, simc, st));
+                                   c->d_slots.p, c->d_max_score.p, c->d_views.p, c->d_seg_base.p, simc, st));
     // ---- post-pass: filterMatches for all views ----
     L3D_HIP_CHECK(launch_filter_all(G, c->d_off.p, c->d_gseg_view.p, c->d_dents.p, c->d_max_score.p, c->d_surv_cnt.p,
                                     c->d_has_best.p, c->d_best_pos.p, st));
@@ -713,6 +765,10 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(hipStreamSynchronize(st));
     for (uint32_t vi = 0; vi < V; ++vi) c->order[vi]->median_depth = med[vi];
     c->host_offsets_valid = false;
+    if (c->timing_pending) {   // phase A ran unsynchronised (l3d_match_images)
+        collect_match_timing(c);
+        c->tm.match_pairs_ms += ev_ms(c->ev[2], c->ev[3]);
+    }
     c->tm.finish_ms = ev_ms(c->ev[6], c->ev[7]);
     c->tm.begin_ms = ev_ms(c->ev[0], c->ev[1]);
     untranslate(*c);   // line3D.cc:493
@@ -721,9 +777,12 @@ int l3d_match_finish(l3d_ctx* c) {
 }
 
 int l3d_match_images(l3d_ctx* c, const l3d_match_params* p) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     int rc = l3d_match_begin(c, p);
     if (rc) return rc;
-    rc = l3d_match_pairs(c, 0, (uint32_t)c->pairs.size());
+    // nothing between begin and the first sizing read-back of phase B waits for the GPU
+    rc = match_pairs_impl(c, 0, (uint32_t)c->pairs.size(), false);
     if (rc) return rc;
     return l3d_match_finish(c);
 }
@@ -794,7 +853,7 @@ static int affinity_core(l3d_ctx* c) {
 
 int l3d_compute_affinity(l3d_ctx* c) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (c->state != l3d_ctx::MATCHED) return fail(L3D_ERR_STATE, "matchImages must precede the affinity step");
     // translate()/untranslate() (line3D.cc:1749,1820) only move camera centres, which the affinity terms never
     // read; they are applied to keep the host state identical to the reference's.
@@ -809,7 +868,7 @@ int l3d_reconstruct_3d_lines(l3d_ctx* c, uint32_t visibility_t, int perform_diff
                              int use_CERES, uint32_t max_iter_CERES) {
     (void)max_iter_CERES;
     if (!c) return fail(L3D_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (c->state != l3d_ctx::MATCHED || c->n_hyps == 0)
         return fail(L3D_ERR_STATE, "no clusterable segments! forgot to match lines?");   // line3D.cc:1712-1718
     if (collinearity_t > 0.0f) return fail(L3D_ERR_LIMIT, "collinearity_t > 0 is not supported");

@@ -104,14 +104,16 @@ struct InvRef {
 };
 static_assert(sizeof(InvRef) == 16, "InvRef is 16 bytes");
 
-// the same hypothesis at its canonical position, with what scoring needs
+// the same hypothesis at its canonical position, with what scoring needs.  The unprojected 3D direction is NOT
+// stored: it is recomputed from the owning segment's rays and (dp1, dp2) where needed (entry_dir, k_views.hip)
 struct DEntry {
-    double dir[3];     // unprojected 3D direction (Segment3D::dir_)
-    uint64_t ref;
+    uint32_t ref;          // slot index (l3d_match_begin limits the slot buffer to 2^32 slots)
     float dp1, dp2, reg1, reg2, score3D;
-    uint32_t tgt_view, flags, pair;
+    uint32_t tgt_view;
+    uint32_t flags : 8;
+    uint32_t pair : 24;    // index of the directed pair the slot belongs to (< 2^24, checked by l3d_match_begin)
 };
-static_assert(sizeof(DEntry) == 64, "DEntry is 64 bytes");
+static_assert(sizeof(DEntry) == 32, "DEntry is 32 bytes");
 constexpr uint32_t kDInverse = 1u;   // inverse hypothesis (exists only if the source view scored it > 0)
 constexpr uint32_t kDZeroLen = 2u;   // unprojected segment shorter than L3D_EPS
 constexpr uint32_t kDPresent = 8u;   // took part in scoring

@@ -43,6 +43,22 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// pinned host staging: async H2D copies from it do not stall the stream (pageable sources are copied synchronously)
+template <class T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 // ---- host double 3x3 algebra (mirrors Eigen's fixed-size behaviour; see l3d_dev.h) -------------
 struct M3 { double m[9]; };
 inline M3 m3_mul(const M3& A, const M3& B) {
