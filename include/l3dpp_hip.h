@@ -205,6 +205,16 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
                     const double C_src[3], const double C_tgt[3], uint32_t width, uint32_t height,
                     float epi_overlap, int32_t kNN, l3d_slot* out_slots, uint64_t* num_matches);
 
+/* Replaces the body of Line3D::performRDD (line3D.cc:2026-2076): SparseMatrix(A_, n) +
+ * replicator_dynamics_diffusion_GPU (cudawrapper.h:74-75, cudawrapper.cu:708-766: row normalisation + 10
+ * diffusion steps P' = P o (P W)^T with the reference's lockstep row/column walk) + the min(w12, w21)
+ * symmetrisation.  Host pointers in and out; `edges` in any order with ids < n_rows; `out` receives n_edges
+ * CLEdges in (i, j) ascending order (the order performRDD rebuilds A_ in).  iterations = L3D_DEF_RDD_MAX_ITER (10)
+ * in the reference.  l3d_reconstruct_3d_lines(perform_diffusion != 0) runs the same kernels on the context's
+ * device-resident affinity matrix. */
+int l3d_diffuse_affinity(int device, const l3d_cledge* edges, uint32_t n_edges, uint32_t n_rows, uint32_t iterations,
+                         l3d_cledge* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,12 +98,12 @@ public:
     }
 
     // void Line3D::reconstruct3Dlines(...), line3D.h:162-166: affinity matrix, graph clustering, 3D line per
-    // cluster, collinear 3D segments (no diffusion / collinearity / Ceres, like a reference build without them)
+    // cluster, collinear 3D segments; perform_diffusion runs the replicator-dynamics diffusion (performRDD) on the
+    // GPU like a CUDA build of the reference; no Ceres (like a reference build without it)
     void reconstruct3Dlines(const unsigned int visibility_t = 3, const bool perform_diffusion = false,
                             const float collinearity_t = -1.0f, const bool use_CERES = false,
                             const unsigned int max_iter_CERES = 250) {
         std::cout << std::endl << prefix_ << "[3] RECONSTRUCTION ===============================" << std::endl;
-        if (perform_diffusion) std::cout << prefix_err_ << "diffusion not possible without CUDA! using graph clustering instead..." << std::endl;
         if (use_CERES) std::cout << prefix_err_ << "CERES was not found! no optimization will be performed..." << std::endl;
         const int rc = l3d_reconstruct_3d_lines(ctx_, visibility_t, perform_diffusion, collinearity_t, use_CERES, max_iter_CERES);
         if (rc != L3D_OK) std::cout << prefix_err_ << l3d_last_error() << std::endl;

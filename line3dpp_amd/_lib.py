@@ -45,7 +45,7 @@ EXPORTS = [
     "l3d_compute_affinity", "l3d_synchronize", "l3d_pair_tests", "l3d_get_matches", "l3d_get_pair_slots",
     "l3d_num_best", "l3d_get_best", "l3d_view_info", "l3d_translation", "l3d_num_affinity", "l3d_get_affinity",
     "l3d_get_sparse_matrix", "l3d_get_timings", "l3d_match_lines", "l3d_set_brute_force", "l3d_slots_exchanged",
-    "l3d_reconstruct_3d_lines", "l3d_num_3d_lines", "l3d_get_3d_lines",
+    "l3d_reconstruct_3d_lines", "l3d_num_3d_lines", "l3d_get_3d_lines", "l3d_diffuse_affinity",
 ]
 
 _lib = None
@@ -94,6 +94,7 @@ def load():
     L.l3d_reconstruct_3d_lines.argtypes = [vp, u32, i32, f32, i32, u32]
     L.l3d_num_3d_lines.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.l3d_get_3d_lines.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.l3d_diffuse_affinity.argtypes = [i32, vp, u32, u32, u32, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("l3d_last_error", "l3d_build_info", "l3d_create", "l3d_destroy"):

@@ -110,8 +110,6 @@ class Line3D:
     # Line3D::reconstruct3Dlines, line3D.h:162-166 (defaults commons.h:63-70)
     def reconstruct3Dlines(self, visibility_t=L3D_DEF_MIN_VISIBILITY_T, perform_diffusion=False, collinearity_t=-1.0,
                            use_CERES=False, max_iter_CERES=250):
-        if perform_diffusion:   # what a reference build without CUDA prints (line3D.cc:1733-1735)
-            print(f"{self.PREFIX}ERROR: diffusion not possible without CUDA! using graph clustering instead...")
         if use_CERES:           # line3D.cc:1741-1743
             print(f"{self.PREFIX}ERROR: CERES was not found! no optimization will be performed...")
         return self._check(self.L.l3d_reconstruct_3d_lines(self.h, int(visibility_t), int(perform_diffusion),
@@ -231,3 +229,16 @@ def match_lines(lines_src, lines_tgt, F, RtKinv_src, RtKinv_tgt, C_src, C_tgt, w
     if rc != 0:
         raise RuntimeError(f"l3d_match_lines failed [{rc}]: {_lib.last_error()}")
     return out, n.value
+
+
+def diffuse_affinity(edges, n_rows, iterations=10, device=0):
+    """Seam-level call replacing the body of Line3D::performRDD (line3D.cc:2026-2076): replicator-dynamics
+    diffusion of the affinity matrix + min-symmetrisation; returns the CLEdges in (i, j) order."""
+    from ._lib import CLEDGE_DTYPE
+    L = _lib.load()
+    e = np.ascontiguousarray(edges, CLEDGE_DTYPE)
+    out = np.zeros(len(e), CLEDGE_DTYPE)
+    rc = L.l3d_diffuse_affinity(device, ptr(e), len(e), int(n_rows), int(iterations), ptr(out))
+    if rc != 0:
+        raise RuntimeError(f"l3d_diffuse_affinity failed [{rc}]: {_lib.last_error()}")
+    return out

@@ -872,12 +872,25 @@ int l3d_reconstruct_3d_lines(l3d_ctx* c, uint32_t visibility_t, int perform_diff
     if (c->state != l3d_ctx::MATCHED || c->n_hyps == 0)
         return fail(L3D_ERR_STATE, "no clusterable segments! forgot to match lines?");   // line3D.cc:1712-1718
     if (collinearity_t > 0.0f) return fail(L3D_ERR_LIMIT, "collinearity_t > 0 is not supported");
-    if (perform_diffusion) set_error("diffusion not available, using graph clustering instead");   // :1733-1735
     if (use_CERES) set_error("CERES not available, no optimization will be performed");             // :1741-1743
     const unsigned vis = std::max<unsigned>(visibility_t, 3);
     c->lines3D.clear();
     translate(*c);
     int rc = affinity_core(c);
+    // matrix diffusion (performRDD, line3D.cc:1787-1791) on the device-resident A_
+    if (rc == L3D_OK && perform_diffusion && !c->edges.empty()) {
+        const uint32_t nnz = (uint32_t)c->edges.size(), n_rows = (uint32_t)c->l2g.size();
+        const size_t wb = rdd_workspace_bytes(nnz, n_rows);
+        DevBuf<char> ws; DevBuf<l3d_cledge> out;
+        hipError_t e = ws.reserve(wb);
+        if (e == hipSuccess) e = out.reserve(nnz);
+        if (e == hipSuccess) e = launch_rdd(c->d_edges.p, nnz, n_rows, 10 /* L3D_DEF_RDD_MAX_ITER */, out.p, ws.p, wb, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->d_edges.p, out.p, (size_t)nnz * sizeof(l3d_cledge), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->edges.data(), out.p, (size_t)nnz * sizeof(l3d_cledge), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        ws.release(); out.release();
+        if (e != hipSuccess) { untranslate(*c); return fail(L3D_ERR_HIP, std::string("matrix diffusion: ") + hipGetErrorString(e)); }
+    }
     if (rc == L3D_OK) {
         ReconInput in;
         in.visibility_t = vis;
@@ -1079,6 +1092,28 @@ int l3d_get_timings(l3d_ctx* c, l3d_timings* t) {
 }
 
 // seam layer: match_lines_GPU replacement (cudawrapper.h:54-63) with CPU-path semantics
+int l3d_diffuse_affinity(int device, const l3d_cledge* edges, uint32_t n_edges, uint32_t n_rows, uint32_t iterations,
+                         l3d_cledge* out) {
+    if ((!edges || !out) && n_edges) return fail(L3D_ERR_ARG, "null argument");
+    if (!n_edges || !n_rows) return L3D_OK;
+    for (uint32_t k = 0; k < n_edges; ++k)
+        if (edges[k].i_ < 0 || edges[k].j_ < 0 || (uint32_t)edges[k].i_ >= n_rows || (uint32_t)edges[k].j_ >= n_rows)
+            return fail(L3D_ERR_ARG, "edge index outside [0, n_rows)");
+    if (hipSetDevice(device) != hipSuccess) return fail(L3D_ERR_HIP, "hipSetDevice failed: no usable HIP device");
+    DevBuf<l3d_cledge> din, dout; DevBuf<char> ws;
+    const size_t wb = rdd_workspace_bytes(n_edges, n_rows);
+    hipError_t e = din.reserve(n_edges);
+    if (e == hipSuccess) e = dout.reserve(n_edges);
+    if (e == hipSuccess) e = ws.reserve(wb);
+    if (e == hipSuccess) e = hipMemcpy(din.p, edges, (size_t)n_edges * sizeof(l3d_cledge), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_rdd(din.p, n_edges, n_rows, iterations, dout.p, ws.p, wb, 0);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, dout.p, (size_t)n_edges * sizeof(l3d_cledge), hipMemcpyDeviceToHost);
+    din.release(); dout.release(); ws.release();
+    if (e != hipSuccess) return fail(L3D_ERR_HIP, std::string("l3d_diffuse_affinity: ") + hipGetErrorString(e));
+    return L3D_OK;
+}
+
 int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const float* lines_tgt4, uint32_t Mt,
                     const double F[9], const double RtKinv_src[9], const double RtKinv_tgt[9], const double C_src[3],
                     const double C_tgt[3], uint32_t width, uint32_t height, float epi_overlap, int32_t kNN,

@@ -2,6 +2,8 @@
 #pragma once
 #include "l3d_dev.h"
 
+struct l3d_cledge;
+
 namespace l3d {
 
 constexpr int kMatchRows = 64;   // source rows per work item of k_match_pairs (one wave64)
@@ -41,5 +43,10 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
                               const WorkItem* work, uint32_t nwork, uint32_t maxK, Slot* slots,
                               uint32_t* row_counts, float thr, CullPools pools, hipStream_t stream);
 hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, hipStream_t stream);
+
+// ---- k_rdd.hip ----
+size_t rdd_workspace_bytes(uint32_t nnz, uint32_t n_rows);
+hipError_t launch_rdd(const struct ::l3d_cledge* edges_in, uint32_t nnz, uint32_t n_rows, uint32_t iterations,
+                      struct ::l3d_cledge* edges_out, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace l3d

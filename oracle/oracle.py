@@ -80,6 +80,8 @@ def lib(reference=False):
         L.lo_num_edges.argtypes = [vp]; L.lo_num_edges.restype = u32
         L.lo_num_rows.argtypes = [vp]; L.lo_num_rows.restype = u32
         L.lo_get_affinity.argtypes = [vp, vp, vp]
+        if not reference:
+            L.lo_rdd.argtypes = [vp, u32, u32, u32, vp]; L.lo_rdd.restype = u32
         if reference:
             L.lo_reconstruct.argtypes = [vp, u32]
             L.lo_num_lines.argtypes = [vp, vp, vp, vp]
@@ -209,6 +211,16 @@ class Oracle:
         if ne:
             self.L.lo_get_affinity(self.h, _p(e), _p(l2g))
         return e[:ne], l2g[:nr]
+
+    @staticmethod
+    def rdd(edges, n_rows, iterations=10):
+        """Replicator-dynamics diffusion + symmetrisation of an affinity edge list (restatement of the reference's
+        CUDA-only performRDD; see l3d_oracle.cpp lo_rdd)."""
+        L = lib(False)
+        e = np.ascontiguousarray(edges, CLEDGE_DTYPE)
+        out = np.zeros(2 * max(len(e), 1), CLEDGE_DTYPE)
+        n = L.lo_rdd(_p(e), len(e), int(n_rows), int(iterations), _p(out))
+        return out[:n]
 
     # ---- reconstruction tail: only through the reference's own code (oracle/_ref) -------------------------
     def reconstruct(self, visibility_t=3):

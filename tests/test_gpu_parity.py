@@ -495,3 +495,45 @@ def test_final_3d_lines_vs_reference_own_code():
         # the affinity accessors still work after reconstruct3Dlines, and every residual has a hypothesis
         hyp = set(map(tuple, np.stack([g.best()[0]["cam"], g.best()[0]["seg"]], 1).tolist()))
         assert all(set(map(tuple, np.stack([L["residuals"]["cam"], L["residuals"]["seg"]], 1).tolist())) <= hyp for L in gl)
+
+
+def test_rdd_diffusion_matches_restatement():
+    """Replicator-dynamics diffusion: l3d_diffuse_affinity (seam) and
+    reconstruct3Dlines(perform_diffusion=True) against the CPU restatement of the reference's CUDA kernels.
+    The reference has no CPU path for this step, so parity is against the restatement at 1e-4 (unpinned)."""
+    from line3dpp_amd.api import diffuse_affinity
+    from oracle.oracle import Oracle
+    sc = make_scene(10, 400, n_neighbors=4, seed=51)
+    g = _gpu(sc)
+    assert g.matchImages() and g.computeAffinity()
+    e, l2g, _ = g.affinity()
+    assert len(e) > 200
+    ref = Oracle.rdd(e, len(l2g))
+    out = diffuse_affinity(e, len(l2g))
+    assert len(out) == len(ref) == len(e)
+    assert np.array_equal(out["i"], ref["i"]) and np.array_equal(out["j"], ref["j"])
+    assert np.max(np.abs(out["w"] - ref["w"]) / ref["w"]) < 1e-4
+    assert np.array_equal(out["w"], ref["w"])          # same float operations in the same order: bit-identical in practice
+    # (i, j) ascending, symmetric values
+    key = out["i"].astype(np.int64) * (1 << 32) + out["j"]
+    assert np.all(np.diff(key) > 0)
+    w = {(int(a), int(b)): float(c) for a, b, c in zip(out["i"], out["j"], out["w"])}
+    assert all(w[(j, i)] == v for (i, j), v in w.items())
+    # through the pipeline: A_ after reconstruct3Dlines(diffusion) is the diffused matrix, lines come out
+    assert g.reconstruct3Dlines(3, True)
+    e2, _, _ = g.affinity()
+    assert np.array_equal(e2["i"], ref["i"]) and np.array_equal(e2["w"], ref["w"])
+    lines_rdd = g.get3Dlines()
+    assert g.reconstruct3Dlines(3, False)
+    lines_plain = g.get3Dlines()
+    assert len(lines_rdd) > 0 and len(lines_plain) > 0
+    # random sparse symmetric-pattern matrix with uneven degrees (exercises the lockstep walk and empty rows)
+    rng = np.random.default_rng(5)
+    n = 300
+    pairs = {(int(a), int(b)) for a, b in rng.integers(0, n, (1500, 2)) if a != b}
+    pairs |= {(b, a) for a, b in pairs}
+    ee = np.array([(a, b, rng.uniform(0.05, 1.0)) for a, b in sorted(pairs)], dtype=e.dtype)
+    ee = ee[rng.permutation(len(ee))]
+    ref = Oracle.rdd(ee, n); out = diffuse_affinity(ee, n)
+    assert np.array_equal(out["i"], ref["i"]) and np.array_equal(out["j"], ref["j"])
+    assert np.max(np.abs(out["w"] - ref["w"]) / ref["w"]) < 1e-4

@@ -188,3 +188,32 @@ def test_golden_fixture():
         a, b = g[k], out[k]
         assert a.shape == b.shape, k
         assert np.array_equal(a, b), k   # same libm, same arithmetic: bit-identical
+
+
+def test_rdd_restatement_known_answers():
+    """Hand-checked replicator-dynamics diffusion (restatement of the reference's CUDA-only performRDD,
+    cudawrapper.cu:432-544, 708-766, line3D.cc:2026-2076)."""
+    from oracle.oracle import Oracle, CLEDGE_DTYPE
+    # two nodes, one symmetric edge: rownorm -> P = [[0,1],[1,0]]; step: P'[1,0] = P[0,1] * (P_row(1)[0] * W_col(0)[0])
+    # = 1 * (1 * w) = w; after the last iteration no normalisation -> both directions = w after 1 iteration
+    e = np.array([(0, 1, 0.8), (1, 0, 0.8)], CLEDGE_DTYPE)
+    out = Oracle.rdd(e, 2, iterations=1)
+    assert [(int(a["i"]), int(a["j"])) for a in out] == [(0, 1), (1, 0)]
+    assert np.allclose(out["w"], 0.8, rtol=1e-6)
+    # path 0-1-2 with weights a, b: the lockstep walk pairs the k-th entry of a row with the k-th of a column
+    a, b = np.float32(0.9), np.float32(0.6)
+    e = np.array([(0, 1, a), (1, 0, a), (1, 2, b), (2, 1, b)], CLEDGE_DTYPE)
+    out = Oracle.rdd(e, 3, iterations=1)
+    w = {(int(x["i"]), int(x["j"])): float(x["w"]) for x in out}
+    p10, p12 = a / (a + b), b / (a + b)            # normalised row 1; rows 0 and 2 normalise to 1
+    # entry (0,1): r=1, c=0: row 1 of P = [p10, p12], column 0 of W = [a]  -> mul = p10*a; times P[0,1]=1 -> stored at (1,0)
+    # entry (1,0): r=0, c=1: row 0 of P = [1], column 1 of W = [a, b]      -> mul = 1*a;   times P[1,0]=p10 -> stored at (0,1)
+    w01, w10 = p10 * a, p10 * a
+    assert np.isclose(w[(0, 1)], min(w01, w10), rtol=1e-6) and np.isclose(w[(1, 0)], w[(0, 1)], rtol=0)
+    # entry (1,2): r=2, c=1: row 2 of P = [1], column 1 of W = [a, b] -> mul = 1*a (lockstep: first entries!), times p12
+    # entry (2,1): r=1, c=2: row 1 of P = [p10, p12], column 2 of W = [b] -> mul = p10*b, times 1
+    assert np.isclose(w[(1, 2)], min(a * p12, p10 * b), rtol=1e-6)
+    # ten iterations keep every weight in (0, 1] and the matrix symmetric
+    out = Oracle.rdd(e, 3)
+    w = {(int(x["i"]), int(x["j"])): float(x["w"]) for x in out}
+    assert all(0.0 < v <= 1.0 for v in w.values()) and w[(0, 1)] == w[(1, 0)] and w[(1, 2)] == w[(2, 1)]
