@@ -80,10 +80,13 @@ def lib(reference=False):
         L.lo_num_edges.argtypes = [vp]; L.lo_num_edges.restype = u32
         L.lo_num_rows.argtypes = [vp]; L.lo_num_rows.restype = u32
         L.lo_get_affinity.argtypes = [vp, vp, vp]
+        L.lo_set_collinearity.argtypes = [vp, f32]
+        L.lo_get_collinear.argtypes = [vp, u32, vp, vp, u32]; L.lo_get_collinear.restype = u32
         if not reference:
             L.lo_rdd.argtypes = [vp, u32, u32, u32, vp]; L.lo_rdd.restype = u32
         if reference:
             L.lo_reconstruct.argtypes = [vp, u32]
+            L.lo_reconstruct_collin.argtypes = [vp, u32, f32]
             L.lo_num_lines.argtypes = [vp, vp, vp, vp]
             L.lo_get_lines.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         _libs[key] = L
@@ -156,6 +159,18 @@ class Oracle:
         self.L.lo_fundamental(self.h, src, tgt, _p(F))
         return F.reshape(3, 3)
 
+    def set_collinearity(self, t):
+        """collinearity_t_ of reconstruct3Dlines (line3D.cc:1725); > 0 adds the collinear-segment links"""
+        self.L.lo_set_collinearity(self.h, float(t))
+
+    def collinear(self, cam, M):
+        """View::collinearSegments for every segment of view `cam` as CSR (offsets[M+1], idx)"""
+        off = np.zeros(M + 1, np.uint32)
+        n = self.L.lo_get_collinear(self.h, int(cam), _p(off), None, 0)
+        idx = np.zeros(max(n, 1), np.uint32)
+        self.L.lo_get_collinear(self.h, int(cam), _p(off), _p(idx), n)
+        return off, idx[:n]
+
     def compute_affinity(self):
         self.L.lo_compute_affinity(self.h)
 
@@ -223,9 +238,12 @@ class Oracle:
         return out[:n]
 
     # ---- reconstruction tail: only through the reference's own code (oracle/_ref) -------------------------
-    def reconstruct(self, visibility_t=3):
+    def reconstruct(self, visibility_t=3, collinearity_t=-1.0):
         assert self.reference, "reconstruct3Dlines is run by the reference's own code only (oracle/_ref)"
-        self.L.lo_reconstruct(self.h, int(visibility_t))
+        if collinearity_t > 0:
+            self.L.lo_reconstruct_collin(self.h, int(visibility_t), float(collinearity_t))
+        else:
+            self.L.lo_reconstruct(self.h, int(visibility_t))
 
     def lines(self):
         """lines3D_ as a list of dicts: collinear3Dsegments [n,9] (P1,P2,dir), residuals [m,2], cluster_line [9],

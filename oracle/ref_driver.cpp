@@ -123,6 +123,30 @@ void lo_compute_affinity(void* p) {
     l->untranslate();
 }
 
+// collinearity_t_ as reconstruct3Dlines sets it (line3D.cc:1725-1726, 1752-1756): the per-view collinear lists
+// are (re)computed by the reference's own View::findCollinearSegments (CPU path)
+void lo_set_collinearity(void* p, float t) {
+    Quiet q;
+    L3DPP::Line3D* l = ((Ref*)p)->l3d;
+    l->collinearity_t_ = t;
+    if (t > L3D_EPS) l->findCollinearSegments();
+}
+uint32_t lo_get_collinear(void* p, uint32_t cam, uint32_t* offsets, uint32_t* idx, uint32_t cap) {
+    L3DPP::Line3D* l = ((Ref*)p)->l3d;
+    L3DPP::View* v = l->views_[cam];
+    uint32_t n = 0;
+    const uint32_t M = (uint32_t)v->num_lines();
+    for (uint32_t s = 0; s < M; ++s) {
+        if (offsets) offsets[s] = n;
+        if (l->collinearity_t_ > L3D_EPS) {
+            std::list<unsigned int> c = v->collinearSegments(s);
+            for (std::list<unsigned int>::const_iterator it = c.begin(); it != c.end(); ++it) { if (idx && n < cap) idx[n] = *it; ++n; }
+        }
+    }
+    if (offsets) offsets[M] = n;
+    return n;
+}
+
 // ---- accessors (same contracts as l3d_oracle.cpp) ----------------------------------------------------------
 uint64_t lo_get_matches(void* p, uint32_t cam, Match40* out, uint64_t cap, uint32_t* offsets) {
     L3DPP::Line3D* l = ((Ref*)p)->l3d;
@@ -206,6 +230,10 @@ uint64_t lo_pair_tests(void* p) {
 void lo_reconstruct(void* p, uint32_t visibility_t) {
     Quiet q;
     ((Ref*)p)->l3d->reconstruct3Dlines(visibility_t, false, -1.0f, false, 250);
+}
+void lo_reconstruct_collin(void* p, uint32_t visibility_t, float collinearity_t) {
+    Quiet q;
+    ((Ref*)p)->l3d->reconstruct3Dlines(visibility_t, false, collinearity_t, false, 250);
 }
 void lo_num_lines(void* p, uint32_t* n_lines, uint32_t* n_segments, uint32_t* n_residuals) {
     std::vector<L3DPP::FinalLine3D> r;

@@ -85,3 +85,14 @@ def affinity_map(edges, l2g, key=lambda r: (int(r[0]), int(r[1]))):
         assert kk not in out, "duplicate unordered pair in A_"
         out[kk] = float(e1["w"])
     return out
+
+
+def split_scene(sc, frac=0.5):
+    """Breaks the first `frac` of every view's segments into two collinear halves with a gap (same segment count):
+    the fragmented lines View::findCollinearSegments is meant for."""
+    for v in sc.views:
+        s = v.segs.astype(np.float64); n = int(len(s) * frac)
+        a = s[:n, :2]; b = s[:n, 2:]
+        h1 = np.concatenate([a, a + 0.45 * (b - a)], 1); h2 = np.concatenate([a + 0.55 * (b - a), b], 1)
+        v.segs = np.concatenate([h1, h2, s[n:len(s) - n]], 0).astype(np.float32)
+    return sc

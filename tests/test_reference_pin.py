@@ -81,3 +81,31 @@ def test_second_match_images_call_equals_reference_code():
     for x in (r, o):
         x.add_scene(sc); x.match_images(); x.match_images(kNN=5); x.compute_affinity()
     assert_identical(r, o, sc)
+
+
+@pytest.mark.parametrize("collin_t", [2.0, 6.0])
+def test_collinearity_links_equal_reference_code(collin_t):
+    """collinearity_t > 0: View::findCollinCPU lists and the extra affinity links of
+    computingAffinityMatrix (line3D.cc:1904-1974), restatement vs the reference's own code, byte for byte."""
+    from tests.helpers import split_scene
+    sc = split_scene(make_scene(8, 400, n_neighbors=4, seed=9))
+    out = []
+    for reference in (True, False):
+        o = O.Oracle(threads=1, reference=reference)
+        o.add_scene(sc)
+        o.match_images()
+        o.set_collinearity(collin_t)
+        o.compute_affinity()
+        out.append(o)
+    r, o = out
+    total = 0
+    for v in sc.views:
+        ro, ri = r.collinear(v.cam, len(v.segs)); oo, oi = o.collinear(v.cam, len(v.segs))
+        assert np.array_equal(ro, oo) and np.array_equal(ri, oi), f"collinear lists of view {v.cam}"
+        total += len(oi)
+    assert total > 1000
+    re_, rl = r.affinity(); oe, ol = o.affinity()
+    assert re_.tobytes() == oe.tobytes() and rl.tobytes() == ol.tobytes(), "A_ / local2global_ with collinear links"
+    # the links add edges
+    plain = run(sc, False)
+    assert len(oe) > len(plain.affinity()[0]) + 200
