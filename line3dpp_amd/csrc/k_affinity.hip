@@ -146,6 +146,103 @@ __global__ void k_aff_emit(uint32_t N, const uint32_t* __restrict__ flag, const 
     if (tb == 2u * k + 1u) local2global[id2] = Seg2D{hyps[hb].m.src_cam, hyps[hb].m.src_seg};
 }
 
+// ---- per-image collinearity ---------------------------------------------------------
+// View::findCollinCPU, view.cc:213-258: segment c is "collinear" to r (same view) if the two do not overlap along
+// their lines (pointOnSegment, view.cc:292-298) and all four point-to-line distances are below collin_t.
+// grid = (row blocks, views); pass 0 counts per row, pass 1 writes the ascending lists (CSR over global segments).
+__device__ __forceinline__ float dist_p2l_2d(const d3& line, double px, double py) {   // view.cc:260-264
+    const float den = sqrtf((float)(line.x * line.x + line.y * line.y));
+    return (float)fabs(((line.x * px + line.y * py) + line.z) / (double)den);
+}
+__device__ __forceinline__ bool on_seg_2d(double p1x, double p1y, double p2x, double p2y, double xx, double xy) {
+    return ((p1x - xx) * (p2x - xx) + (p1y - xy) * (p2y - xy)) < kEps;
+}
+template <int PASS>
+__global__ __launch_bounds__(256) void k_collin(const ViewDev* __restrict__ views, const uint32_t* __restrict__ seg_base,
+                                                float collin_t, uint32_t* __restrict__ cnt,
+                                                const uint32_t* __restrict__ coll_off, uint32_t* __restrict__ coll_idx) {
+    __shared__ float4 tile[256];
+    const ViewDev& v = views[blockIdx.y];
+    const uint32_t M = v.M;
+    if (blockIdx.x * blockDim.x >= M) return;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = r < M;
+    const float4 l1 = act ? v.seg4[r] : make_float4(0, 0, 0, 0);
+    const d3 p0{(double)l1.x, (double)l1.y, 1.0}, p1{(double)l1.z, (double)l1.w, 1.0};
+    const d3 line1 = cross(p0, p1);
+    uint32_t n = 0;
+    uint32_t* out = (PASS == 1 && act) ? coll_idx + coll_off[seg_base[blockIdx.y] + r] : nullptr;
+    for (uint32_t c0 = 0; c0 < M; c0 += 256) {
+        __syncthreads();
+        if (c0 + threadIdx.x < M) tile[threadIdx.x] = v.seg4[c0 + threadIdx.x];
+        __syncthreads();
+        const uint32_t ce = min(256u, M - c0);
+        if (!act) continue;
+        for (uint32_t k = 0; k < ce; ++k) {
+            const uint32_t c = c0 + k;
+            if (c == r) continue;
+            const float4 l2 = tile[k];
+            const d3 q0{(double)l2.x, (double)l2.y, 1.0}, q1{(double)l2.z, (double)l2.w, 1.0};
+            if (on_seg_2d(p0.x, p0.y, p1.x, p1.y, q0.x, q0.y) || on_seg_2d(p0.x, p0.y, p1.x, p1.y, q1.x, q1.y) ||
+                on_seg_2d(q0.x, q0.y, q1.x, q1.y, p0.x, p0.y) || on_seg_2d(q0.x, q0.y, q1.x, q1.y, p1.x, p1.y))
+                continue;
+            const d3 line2 = cross(q0, q1);
+            const float d1 = fmaxf(dist_p2l_2d(line1, q0.x, q0.y), dist_p2l_2d(line1, q1.x, q1.y));
+            const float d2 = fmaxf(dist_p2l_2d(line2, p0.x, p0.y), dist_p2l_2d(line2, p1.x, p1.y));
+            if (fmaxf(d1, d2) < collin_t) {
+                if (PASS == 1) out[n] = c;
+                ++n;
+            }
+        }
+    }
+    if (PASS == 0 && act) cnt[seg_base[blockIdx.y] + r] = n;
+}
+
+// similarity of a hypothesis with the hypotheses of a list of 2D segments (the collinear neighbours):
+//   MODE 0: children of primary candidate c (surviving match, passing the affinity threshold): collinear(tgt seg)
+//   MODE 1: own links of hypothesis h: collinear(src seg)
+// counts (per item) are produced by k_aff_coll_count, offsets by a scan.
+template <int MODE>
+__global__ void k_aff_coll_count(uint32_t n_items, const uint32_t* __restrict__ surv_tg, const float* __restrict__ simv,
+                                 const HypRec* __restrict__ hyps, const uint32_t* __restrict__ seg_base,
+                                 const uint32_t* __restrict__ coll_off, uint32_t* __restrict__ cnt) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_items) return;
+    uint32_t g;
+    if (MODE == 0) { if (!(simv[t] > kMinAffinity)) { cnt[t] = 0; return; } g = surv_tg[t]; }
+    else g = seg_base[hyps[t].view] + hyps[t].m.src_seg;
+    cnt[t] = coll_off[g + 1] - coll_off[g];
+}
+template <int MODE>
+__global__ void k_aff_coll_sim(uint32_t n_items, const uint32_t* __restrict__ surv_sg, const uint32_t* __restrict__ surv_tg,
+                               const int32_t* __restrict__ hyp_of_seg, const HypRec* __restrict__ hyps,
+                               const ViewDev* __restrict__ views, const uint32_t* __restrict__ seg_base,
+                               const uint32_t* __restrict__ gseg_view, const uint32_t* __restrict__ coll_off,
+                               const uint32_t* __restrict__ coll_idx, const uint32_t* __restrict__ item_off,
+                               const ViewAff* __restrict__ va, const float* __restrict__ medians,
+                               const float* __restrict__ msdl_ptr, float two_sigA_sqr, uint32_t* __restrict__ out_seg,
+                               float* __restrict__ out_sim) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_items) return;
+    const uint32_t ob = item_off[t], on = item_off[t + 1] - ob;
+    if (!on) return;
+    int32_t ha; uint32_t g;
+    if (MODE == 0) { ha = hyp_of_seg[surv_sg[t]]; g = surv_tg[t]; }
+    else { ha = (int32_t)t; g = seg_base[hyps[t].view] + hyps[t].m.src_seg; }
+    const uint32_t vi = gseg_view[g], base = seg_base[vi], cb = coll_off[g];
+    for (uint32_t k = 0; k < on; ++k) {
+        const uint32_t x = base + coll_idx[cb + k];
+        const int32_t hb = hyp_of_seg[x];
+        float sim = 0.0f;
+        if (ha >= 0 && hb >= 0) {
+            const uint32_t v1 = hyps[ha].view, v2 = hyps[hb].view;
+            sim = sim_affinity(hyps[ha], hyps[hb], va[v1].k, medians[v1], va[v2].k, medians[v2], *msdl_ptr, two_sigA_sqr);
+        }
+        out_seg[ob + k] = x;
+        out_sim[ob + k] = sim;
+    }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------
 static inline dim3 grid1(uint32_t n, uint32_t b = 256) { return dim3((n + b - 1) / b); }
 
@@ -189,4 +286,40 @@ hipError_t launch_aff_emit(uint32_t N, const uint32_t* flag, const uint32_t* epo
     return hipGetLastError();
 }
 
+}  // namespace l3d
+
+namespace l3d {
+hipError_t launch_collin(int pass, const ViewDev* views, uint32_t n_views, uint32_t max_M, const uint32_t* seg_base,
+                         float collin_t, uint32_t* cnt, const uint32_t* coll_off, uint32_t* coll_idx, hipStream_t st) {
+    if (!n_views || !max_M) return hipSuccess;
+    const dim3 g((max_M + 255) / 256, n_views);
+    if (pass == 0) hipLaunchKernelGGL((k_collin<0>), g, dim3(256), 0, st, views, seg_base, collin_t, cnt, coll_off, coll_idx);
+    else hipLaunchKernelGGL((k_collin<1>), g, dim3(256), 0, st, views, seg_base, collin_t, cnt, coll_off, coll_idx);
+    return hipGetLastError();
+}
+hipError_t launch_aff_coll_count(int mode, uint32_t n_items, const uint32_t* surv_tg, const float* simv,
+                                 const HypRec* hyps, const uint32_t* seg_base, const uint32_t* coll_off, uint32_t* cnt,
+                                 hipStream_t st) {
+    if (!n_items) return hipSuccess;
+    const dim3 g((n_items + 255) / 256);
+    if (mode == 0) hipLaunchKernelGGL((k_aff_coll_count<0>), g, dim3(256), 0, st, n_items, surv_tg, simv, hyps, seg_base, coll_off, cnt);
+    else hipLaunchKernelGGL((k_aff_coll_count<1>), g, dim3(256), 0, st, n_items, surv_tg, simv, hyps, seg_base, coll_off, cnt);
+    return hipGetLastError();
+}
+hipError_t launch_aff_coll_sim(int mode, uint32_t n_items, const uint32_t* surv_sg, const uint32_t* surv_tg,
+                               const int32_t* hyp_of_seg, const HypRec* hyps, const ViewDev* views,
+                               const uint32_t* seg_base, const uint32_t* gseg_view, const uint32_t* coll_off,
+                               const uint32_t* coll_idx, const uint32_t* item_off, const ViewAff* va,
+                               const float* medians, const float* msdl, float two_sigA_sqr, uint32_t* out_seg,
+                               float* out_sim, hipStream_t st) {
+    if (!n_items) return hipSuccess;
+    const dim3 g((n_items + 127) / 128);
+    if (mode == 0)
+        hipLaunchKernelGGL((k_aff_coll_sim<0>), g, dim3(128), 0, st, n_items, surv_sg, surv_tg, hyp_of_seg, hyps, views,
+                           seg_base, gseg_view, coll_off, coll_idx, item_off, va, medians, msdl, two_sigA_sqr, out_seg, out_sim);
+    else
+        hipLaunchKernelGGL((k_aff_coll_sim<1>), g, dim3(128), 0, st, n_items, surv_sg, surv_tg, hyp_of_seg, hyps, views,
+                           seg_base, gseg_view, coll_off, coll_idx, item_off, va, medians, msdl, two_sigA_sqr, out_seg, out_sim);
+    return hipGetLastError();
+}
 }  // namespace l3d

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <memory>
 #include <mutex>
+#include <unordered_set>
 
 #include "l3d_host.h"
 #include "l3d_recon.h"
@@ -17,6 +18,15 @@ void set_error(const std::string& s) { g_err = s; }
 
 // ---- prototypes of the launchers in k_views.hip / k_affinity.hip -------------------------------
 hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, uint32_t* total, hipStream_t);
+hipError_t launch_collin(int pass, const ViewDev* views, uint32_t n_views, uint32_t max_M, const uint32_t* seg_base,
+                         float collin_t, uint32_t* cnt, const uint32_t* coll_off, uint32_t* coll_idx, hipStream_t);
+hipError_t launch_aff_coll_count(int mode, uint32_t n_items, const uint32_t* surv_tg, const float* simv, const HypRec*,
+                                 const uint32_t* seg_base, const uint32_t* coll_off, uint32_t* cnt, hipStream_t);
+hipError_t launch_aff_coll_sim(int mode, uint32_t n_items, const uint32_t* surv_sg, const uint32_t* surv_tg,
+                               const int32_t* hyp_of_seg, const HypRec*, const ViewDev*, const uint32_t* seg_base,
+                               const uint32_t* gseg_view, const uint32_t* coll_off, const uint32_t* coll_idx,
+                               const uint32_t* item_off, const ViewAff*, const float* medians, const float* msdl,
+                               float two_sigA_sqr, uint32_t* out_seg, float* out_sim, hipStream_t);
 hipError_t launch_fill_gseg_view(const uint32_t* seg_base, uint32_t V, uint32_t max_M, uint32_t* gseg_view, hipStream_t);
 hipError_t launch_orient_all(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
                              const uint32_t* seg_base, Slot* slots, uint32_t G, unsigned long long* cnt_pack,
@@ -100,6 +110,9 @@ struct l3d_ctx {
     DevBuf<float2> d_src_band, d_chunk_band, d_tgt_band;
     DevBuf<float4> d_tgt_sf;
     bool use_cull = true;
+    float collinearity_t = -1.0f;                   // collinearity_t_ (reconstruct3Dlines); > 0: collinear links
+    DevBuf<uint32_t> d_coll_cnt, d_coll_off, d_coll_idx, d_item_cnt, d_item_off, d_item_seg;
+    DevBuf<float> d_item_sim;
     // pinned staging of the small host->device tables (reused across calls; every public call ends synchronised)
     PinnedBuf<ViewDev> h_views;
     PinnedBuf<PairDesc> h_pairs;
@@ -374,6 +387,8 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_has_best.release(); c->d_best_pos.release(); c->d_surv_off.release(); c->d_hyp_off.release();
     c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_bits.release(); c->d_eref.release(); c->d_positive.release(); c->d_bits_len.release(); c->d_boff.release(); c->d_cnt_inv.release();
     c->d_cnt_pack.release(); c->d_inv_pos.release();
+    c->d_coll_cnt.release(); c->d_coll_off.release(); c->d_coll_idx.release(); c->d_item_cnt.release();
+    c->d_item_off.release(); c->d_item_seg.release(); c->d_item_sim.release();
     c->d_inv_off.release(); c->d_vout_pairs.release(); c->d_vout_off.release(); c->d_dents.release(); c->d_surv.release();
     c->d_hyp_of_seg.release(); c->d_depths.release(); c->d_medians.release(); c->d_hyps.release();
     c->d_vaff.release(); c->d_simv.release(); c->d_msdl.release(); c->d_ca.release(); c->d_cb.release();
@@ -787,6 +802,118 @@ int l3d_match_images(l3d_ctx* c, const l3d_match_params* p) {
     return l3d_match_finish(c);
 }
 
+// computingAffinityMatrix with collinearity_t_ > 0 (line3D.cc:1852-1979 incl. the links to collinear segments,
+// :1904-1974).  The GPU does the arithmetic -- the per-view all-pairs collinearity tests (View::findCollinCPU)
+// and the similarity of every potential link -- and hands the host three candidate streams (primary =
+// surviving matches, children = collinear segments of a passing primary's target, own = collinear segments of
+// the hypothesis' segment).  The bookkeeping that is sequential BY DEFINITION in the reference (used_ claims a
+// pair for whoever comes first, a child is only visited when its parent was accepted, row ids in first-touch
+// order) is one linear pass over those streams in the reference's single-thread order.  d_simv is ready.
+static int affinity_collinear(l3d_ctx* c) {
+    hipStream_t st = c->stream;
+    const uint32_t V = (uint32_t)c->order.size(), G = c->G, N = c->n_surv, H = c->n_hyps;
+    uint32_t max_M = 0;
+    for (auto* v : c->order) max_M = std::max(max_M, v->M);
+    // ---- per-view collinear lists (CSR over global segments) ----
+    L3D_HIP_CHECK(c->d_coll_cnt.reserve(G + 1)); L3D_HIP_CHECK(c->d_coll_off.reserve(G + 1));
+    L3D_HIP_CHECK(launch_collin(0, c->d_views.p, V, max_M, c->d_seg_base.p, c->collinearity_t, c->d_coll_cnt.p, nullptr,
+                                nullptr, st));
+    L3D_HIP_CHECK(launch_scan(c->d_coll_cnt.p, G, c->d_coll_off.p, c->d_scan_tmp.p, c->d_scal.p + 9, st));
+    uint32_t n_coll = 0;
+    L3D_HIP_CHECK(hipMemcpyAsync(&n_coll, c->d_scal.p + 9, 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipStreamSynchronize(st));
+    L3D_HIP_CHECK(c->d_coll_idx.reserve(std::max<uint32_t>(n_coll, 1)));
+    L3D_HIP_CHECK(launch_collin(1, c->d_views.p, V, max_M, c->d_seg_base.p, c->collinearity_t, nullptr, c->d_coll_off.p,
+                                c->d_coll_idx.p, st));
+    // ---- similarities of the child and own candidates ----
+    std::vector<uint32_t> off[2], seg[2];
+    std::vector<float> sim[2];
+    const uint32_t n_items[2] = {N, H};
+    for (int mode = 0; mode < 2; ++mode) {
+        const uint32_t n = n_items[mode];
+        L3D_HIP_CHECK(c->d_item_cnt.reserve(n + 1)); L3D_HIP_CHECK(c->d_item_off.reserve(n + 1));
+        L3D_HIP_CHECK(c->d_scan_tmp.reserve((size_t)n / 4096 + 1024));
+        L3D_HIP_CHECK(launch_aff_coll_count(mode, n, c->d_surv_tg.p, c->d_simv.p, c->d_hyps.p, c->d_seg_base.p,
+                                            c->d_coll_off.p, c->d_item_cnt.p, st));
+        L3D_HIP_CHECK(launch_scan(c->d_item_cnt.p, n, c->d_item_off.p, c->d_scan_tmp.p, c->d_scal.p + 10, st));
+        uint32_t total = 0;
+        L3D_HIP_CHECK(hipMemcpyAsync(&total, c->d_scal.p + 10, 4, hipMemcpyDeviceToHost, st));
+        L3D_HIP_CHECK(hipStreamSynchronize(st));
+        L3D_HIP_CHECK(c->d_item_seg.reserve(std::max<uint32_t>(total, 1)));
+        L3D_HIP_CHECK(c->d_item_sim.reserve(std::max<uint32_t>(total, 1)));
+        L3D_HIP_CHECK(launch_aff_coll_sim(mode, n, c->d_surv_sg.p, c->d_surv_tg.p, c->d_hyp_of_seg.p, c->d_hyps.p,
+                                          c->d_views.p, c->d_seg_base.p, c->d_gseg_view.p, c->d_coll_off.p,
+                                          c->d_coll_idx.p, c->d_item_off.p, c->d_vaff.p, c->d_medians.p, c->d_msdl.p,
+                                          c->two_sigA_sqr, c->d_item_seg.p, c->d_item_sim.p, st));
+        off[mode].resize((size_t)n + 1); seg[mode].resize(total); sim[mode].resize(total);
+        L3D_HIP_CHECK(hipMemcpyAsync(off[mode].data(), c->d_item_off.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, st));
+        if (total) {
+            L3D_HIP_CHECK(hipMemcpyAsync(seg[mode].data(), c->d_item_seg.p, (size_t)total * 4, hipMemcpyDeviceToHost, st));
+            L3D_HIP_CHECK(hipMemcpyAsync(sim[mode].data(), c->d_item_sim.p, (size_t)total * 4, hipMemcpyDeviceToHost, st));
+        }
+        L3D_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    // ---- primary stream + hypothesis -> segment map ----
+    std::vector<uint32_t> surv_off((size_t)G + 1), surv_tg(N);
+    std::vector<float> simv(N);
+    std::vector<int32_t> hyp_of_seg(G);
+    L3D_HIP_CHECK(hipMemcpyAsync(surv_off.data(), c->d_surv_off.p, ((size_t)G + 1) * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipMemcpyAsync(surv_tg.data(), c->d_surv_tg.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipMemcpyAsync(simv.data(), c->d_simv.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipMemcpyAsync(hyp_of_seg.data(), c->d_hyp_of_seg.p, (size_t)G * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<uint32_t> seg_of_hyp(H, kEmpty);
+    for (uint32_t g = 0; g < G; ++g) if (hyp_of_seg[g] >= 0) seg_of_hyp[(uint32_t)hyp_of_seg[g]] = g;
+    // ---- the sequential pass: unused() (line3D.cc:1982-2002), getLocalID() (:2005-2023) ----
+    std::unordered_set<uint64_t> used;
+    std::vector<int32_t> local_id(G, -1);
+    std::vector<uint32_t> row_seg;
+    auto unused = [&](uint32_t a, uint32_t b) {
+        const uint64_t key = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+        return used.insert(key).second;
+    };
+    auto get_id = [&](uint32_t g) {
+        if (local_id[g] < 0) { local_id[g] = (int32_t)row_seg.size(); row_seg.push_back(g); }
+        return local_id[g];
+    };
+    c->edges.clear();
+    auto push = [&](int32_t i, int32_t j, float w) {
+        c->edges.push_back(l3d_cledge{i, j, w}); c->edges.push_back(l3d_cledge{j, i, w});
+    };
+    for (uint32_t h = 0; h < H; ++h) {
+        const uint32_t a = seg_of_hyp[h];
+        if (a == kEmpty) continue;
+        int32_t id1 = -1;
+        bool found_aff = false;
+        for (uint32_t p = surv_off[a]; p < surv_off[a + 1]; ++p) {
+            const uint32_t b = surv_tg[p];
+            if (simv[p] > kMinAffinity && unused(a, b)) {
+                if (id1 < 0) id1 = get_id(a);
+                const int32_t id2 = get_id(b);
+                push(id1, id2, simv[p]);
+                found_aff = true;
+                for (uint32_t k = off[0][p]; k < off[0][p + 1]; ++k)
+                    if (sim[0][k] > kMinAffinity && unused(a, seg[0][k])) push(id1, get_id(seg[0][k]), sim[0][k]);
+            }
+        }
+        if (found_aff && id1 >= 0)
+            for (uint32_t k = off[1][h]; k < off[1][h + 1]; ++k)
+                if (sim[1][k] > kMinAffinity && unused(a, seg[1][k])) push(id1, get_id(seg[1][k]), sim[1][k]);
+    }
+    c->l2g.resize(row_seg.size());
+    for (size_t r = 0; r < row_seg.size(); ++r) {
+        const uint32_t g = row_seg[r];
+        const uint32_t vi = (uint32_t)(std::upper_bound(c->seg_base.begin(), c->seg_base.end(), g) - c->seg_base.begin()) - 1;
+        c->l2g[r].camID_ = c->order[vi]->cam; c->l2g[r].segID_ = g - c->seg_base[vi];
+    }
+    // A_ stays device resident as well (matrix diffusion reads it there)
+    L3D_HIP_CHECK(c->d_edges.reserve(std::max<size_t>(c->edges.size(), 1)));
+    if (!c->edges.empty())
+        L3D_HIP_CHECK(hipMemcpyAsync(c->d_edges.p, c->edges.data(), c->edges.size() * sizeof(l3d_cledge),
+                                     hipMemcpyHostToDevice, st));
+    return L3D_OK;
+}
+
 // med_scene_depth_lines_ + computingAffinityMatrix (line3D.cc:1759-1778) in the CURRENT (translated) frame
 static int affinity_core(l3d_ctx* c) {
     (void)hipSetDevice(c->device);
@@ -813,6 +940,15 @@ static int affinity_core(l3d_ctx* c) {
         L3D_HIP_CHECK(launch_aff_sim(N, c->d_surv_sg.p, c->d_surv_tg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_vaff.p,
                                      c->d_medians.p, c->d_msdl.p, c->two_sigA_sqr, c->d_simv.p, c->d_ca.p, c->d_cb.p,
                                      st));
+        if (c->collinearity_t > (float)kEps) {
+            const int rc = affinity_collinear(c);
+            if (rc) return rc;
+            L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
+            L3D_HIP_CHECK(hipStreamSynchronize(st));
+            c->tm.affinity_ms = ev_ms(c->ev[6], c->ev[7]);
+            c->affinity_done = true;
+            return L3D_OK;
+        }
         L3D_HIP_CHECK(launch_aff_flag(N, c->d_surv_off.p, c->d_surv_sg.p, c->d_surv_tg.p, c->d_simv.p, c->d_ca.p,
                                       c->d_cb.p, c->d_flag.p, st));
         L3D_HIP_CHECK(launch_scan(c->d_flag.p, N, c->d_epos.p, c->d_scan_tmp.p, c->d_scal.p + 3, st));
@@ -871,7 +1007,7 @@ int l3d_reconstruct_3d_lines(l3d_ctx* c, uint32_t visibility_t, int perform_diff
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (c->state != l3d_ctx::MATCHED || c->n_hyps == 0)
         return fail(L3D_ERR_STATE, "no clusterable segments! forgot to match lines?");   // line3D.cc:1712-1718
-    if (collinearity_t > 0.0f) return fail(L3D_ERR_LIMIT, "collinearity_t > 0 is not supported");
+    c->collinearity_t = collinearity_t;                                                          // :1725-1726
     if (use_CERES) set_error("CERES not available, no optimization will be performed");             // :1741-1743
     const unsigned vis = std::max<unsigned>(visibility_t, 3);
     c->lines3D.clear();

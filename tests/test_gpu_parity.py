@@ -537,3 +537,36 @@ def test_rdd_diffusion_matches_restatement():
     ref = Oracle.rdd(ee, n); out = diffuse_affinity(ee, n)
     assert np.array_equal(out["i"], ref["i"]) and np.array_equal(out["j"], ref["j"])
     assert np.max(np.abs(out["w"] - ref["w"]) / ref["w"]) < 1e-4
+
+
+def test_collinearity_links_and_lines():
+    """collinearity_t > 0: per-view collinear lists + the extra affinity links, against the
+    restatement (A_ ids/order identical, weights within tolerance) and, for the final 3D lines, against the
+    reference's own code (oracle/_ref)."""
+    from oracle import oracle as O
+    sc = H.split_scene(make_scene(8, 400, n_neighbors=4, seed=9))
+    collin_t = 2.0
+    g = _gpu(sc)
+    assert g.matchImages() and g.reconstruct3Dlines(3, False, collin_t)
+    ge, gl, _ = g.affinity()
+    o = _oracle(sc, threads=1)
+    o.match_images(); o.set_collinearity(collin_t); o.compute_affinity()
+    oe, ol = o.affinity()
+    o2 = _oracle(sc, threads=1); o2.match_images(); o2.compute_affinity()
+    assert len(oe) > len(o2.affinity()[0]) + 200          # the links add edges
+    assert len(ge) == len(oe) and len(gl) == len(ol)
+    assert np.array_equal(ge["i"], oe["i"]) and np.array_equal(ge["j"], oe["j"])
+    assert np.array_equal(np.stack([gl["cam"], gl["seg"]], 1), ol)
+    assert np.max(np.abs(ge["w"] - oe["w"]) / oe["w"]) < H.REL_TOL
+    lines = g.get3Dlines()
+    assert len(lines) > 10
+    if O.have_reference():
+        r = O.Oracle(threads=1, reference=True)
+        r.add_scene(sc); r.match_images(); r.reconstruct(3, collin_t)
+        rl = r.lines()
+        key = lambda res: tuple(sorted(map(tuple, np.asarray(res).reshape(-1, 2).tolist())))
+        assert len(lines) == len(rl)
+        assert {key(np.stack([L["residuals"]["cam"], L["residuals"]["seg"]], 1)) for L in lines} == {key(L["residuals"]) for L in rl}
+    # switching it off again restores the plain matrix
+    assert g.reconstruct3Dlines(3, False, -1.0)
+    assert len(g.affinity()[0]) == len(o2.affinity()[0])
