@@ -330,61 +330,71 @@ __global__ void k_bits_len(uint32_t G, const uint32_t* __restrict__ off, uint32_
 
 // One wave per 2D segment (any view): the similarity decisions of the segment's hypotheses.
 // similarityForScoring(i, j) can only exceed 0.5 if |dp1_i - dp1_j| <= sqrt(0.72 * reg1_i) (first early-out of
-// sim_scoring), so the hypotheses are rank-sorted by dp1 in LDS and hypothesis i evaluates only the
-// contiguous window of candidates inside that radius (found by binary search) instead of all L: O(L^2) cheap
-// compares for the sort + O(L * window) evaluations.  Lists longer than kSortCap take the all-pairs loop.
-constexpr uint32_t kSortCap = 512;
-constexpr uint32_t kStageCap = 128;   // lists up to this length keep the fields the similarity reads in LDS
-__global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t* __restrict__ off,
+// sim_decide), so the hypotheses are rank-sorted by dp1 in LDS and hypothesis i evaluates only the contiguous
+// window of candidates inside that radius (found by binary search) instead of all L: O(L^2) cheap compares for
+// the sort + O(L * window) evaluations.
+//   L <= kStageCap: everything the decision reads is staged in LDS IN SORTED ORDER (the window walk reads
+//                   consecutive positions: no dependent index load), directions as fp32 -- the angular test is
+//                   decided in fp32 when it is at least kDirSlack away from both thresholds and re-done in fp64
+//                   (directions recomputed from the depths) otherwise, so the result is the fp64 one;
+//   L <= kSortCap:  only the sort lives in LDS (same pool), candidates are read from global memory;
+//   longer lists:   all-pairs loop.
+constexpr uint32_t kStageCap = 192;
+constexpr uint32_t kPoolFloats = 1440;                    // per-wave LDS pool: 7.5 floats per staged hypothesis
+constexpr uint32_t kSortCap = kPoolFloats * 2 / 5;        // 2.5 floats per hypothesis when only the sort is kept
+constexpr float kDirSlack = 2e-6f;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_support_all(uint32_t G, const uint32_t* __restrict__ off,
                                                      const uint32_t* __restrict__ boff,
                                                      const DEntry* __restrict__ dents, uint64_t* __restrict__ bits,
                                                      const ViewDev* __restrict__ views,
                                                      const uint32_t* __restrict__ seg_base,
                                                      const uint32_t* __restrict__ gseg_view, SimConst sc) {
-    __shared__ float s_key[4][kSortCap];      // dp1 in canonical order, then reused: dp1 in sorted order
-    __shared__ float s_sorted[4][kSortCap];
-    __shared__ uint16_t s_sidx[4][kSortCap];  // canonical index of sorted position
-    __shared__ double s_dir[4][kStageCap][3];
-    __shared__ float s_dp2[4][kStageCap];
-    __shared__ uint32_t s_tvf[4][kStageCap];  // tgt_view | zero-length flag << 31
+    __shared__ float s_pool[4][kPoolFloats];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t g = blockIdx.x * 4 + wave;
     if (g >= G) return;
     const uint32_t b = off[g], L = off[g + 1] - b;
     if (L == 0) return;
+#ifdef L3D_EXP_SHORTONLY
+    if (L > 128) return;
+#endif
     const uint32_t W = (L + 63) / 64;
     uint64_t* rows = bits + boff[g];
     const uint32_t vi = gseg_view[g];
     const ViewDev& v = views[vi];
-    const SegX sx = v.segx[g - seg_base[vi]];
+    const SegX sx = views[0].segx[g];   // global array (upload_views): views[0].segx is its base
     if (L <= kSortCap) {
         const bool staged = L <= kStageCap;
+        const uint32_t cap = staged ? kStageCap : kSortCap;
+        float* s_key = s_pool[wave];                       // dp1, canonical order
+        float* s_sorted = s_key + cap;                     // dp1, sorted
+        uint16_t* s_sidx = (uint16_t*)(s_sorted + cap);    // canonical index of a sorted position
+        float* s_dp2 = (float*)(s_sidx + cap);             // staged only, sorted order
+        uint32_t* s_tvf = (uint32_t*)(s_dp2 + cap);        // tgt_view | zero-length flag << 31
+        float* s_dir = (float*)(s_tvf + cap);              // 3 floats per hypothesis
         for (uint32_t m0 = 0; m0 < L; m0 += 64)
-            if (m0 + lane < L) {
-                const DEntry& e = dents[b + m0 + lane];
-                s_key[wave][m0 + lane] = e.dp1;
-                if (staged) {
-                    const d3 ed = entry_dir(v.C, sx, e.dp1, e.dp2);
-                    s_dir[wave][m0 + lane][0] = ed.x; s_dir[wave][m0 + lane][1] = ed.y;
-                    s_dir[wave][m0 + lane][2] = ed.z;
-                    s_dp2[wave][m0 + lane] = e.dp2;
-                    s_tvf[wave][m0 + lane] = e.tgt_view | ((e.flags & kDZeroLen) ? 0x80000000u : 0u);
-                }
-            }
+            if (m0 + lane < L) s_key[m0 + lane] = dents[b + m0 + lane].dp1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         for (uint32_t m0 = 0; m0 < L; m0 += 64) {
             const uint32_t i = m0 + lane;
             if (i < L) {
-                const float k = s_key[wave][i];
+                const float k = s_key[i];
                 uint32_t rank = 0;
                 for (uint32_t j = 0; j < L; ++j) {
-                    const float o = s_key[wave][j];
+                    const float o = s_key[j];
                     rank += (o < k || (o == k && j < i)) ? 1u : 0u;
                 }
-                s_sorted[wave][rank] = k;
-                s_sidx[wave][rank] = (uint16_t)i;
+                s_sorted[rank] = k;
+                s_sidx[rank] = (uint16_t)i;
+                if (staged) {
+                    const DEntry e = dents[b + i];
+                    const d3 ed = entry_dir(v.C, sx, e.dp1, e.dp2);
+                    s_dp2[rank] = e.dp2;
+                    s_tvf[rank] = e.tgt_view | ((e.flags & kDZeroLen) ? 0x80000000u : 0u);
+                    s_dir[3 * rank] = (float)ed.x; s_dir[3 * rank + 1] = (float)ed.y; s_dir[3 * rank + 2] = (float)ed.z;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -394,44 +404,60 @@ __global__ __launch_bounds__(256) void k_support_all(uint32_t G, const uint32_t*
             const uint32_t i = m0 + lane;
             if (i < L) {
                 const DEntry a = dents[b + i];
-                const d3 ad = staged ? d3{s_dir[wave][i][0], s_dir[wave][i][1], s_dir[wave][i][2]}
-                                     : entry_dir(v.C, sx, a.dp1, a.dp2);
-                if (!staged) for (uint32_t w = 0; w < W; ++w) rows[(size_t)i * W + w] = 0ull;
+                const d3 ad = entry_dir(v.C, sx, a.dp1, a.dp2);
+                const bool azero = (a.flags & kDZeroLen) != 0;
                 // window of candidates: |dp1_j - dp1_i| <= r  (r padded against float rounding)
                 float r = sqrtf(0.72f * a.reg1) * 1.0001f + 1e-30f;
                 uint32_t lo = 0, hi = L;
                 if (r < 1e30f) {   // also false for NaN: then the whole list is the window
                     const float kl = a.dp1 - r, kh = a.dp1 + r;
                     uint32_t x = 0, y = L;          // first position with key >= kl
-                    while (x < y) { const uint32_t m = (x + y) >> 1; if (s_sorted[wave][m] < kl) x = m + 1; else y = m; }
+                    while (x < y) { const uint32_t m = (x + y) >> 1; if (s_sorted[m] < kl) x = m + 1; else y = m; }
                     lo = x;
                     y = L;                          // first position with key > kh
-                    while (x < y) { const uint32_t m = (x + y) >> 1; if (s_sorted[wave][m] <= kh) x = m + 1; else y = m; }
+                    while (x < y) { const uint32_t m = (x + y) >> 1; if (s_sorted[m] <= kh) x = m + 1; else y = m; }
                     hi = x;
                 }
                 if (staged) {
-                    // W <= 2 words: the row is accumulated in registers and written once
-                    uint64_t r0 = 0, r1 = 0;
+                    // W <= 5 words: the row is accumulated in registers and written once
+                    uint64_t rw[(kStageCap + 63) / 64] = {};
+                    const float adx = (float)ad.x, ady = (float)ad.y, adz = (float)ad.z;
                     for (uint32_t p = lo; p < hi; ++p) {
-                        const uint32_t j = s_sidx[wave][p];
-                        const uint32_t tvf = s_tvf[wave][j];
-                        if ((tvf & 0x7FFFFFFFu) == a.tgt_view) continue;
-                        const d3 od{s_dir[wave][j][0], s_dir[wave][j][1], s_dir[wave][j][2]};
-                        if (sim_decide(ad, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2, od,
-                                       (tvf >> 31) != 0, s_key[wave][j], s_dp2[wave][j], sc)) {
-                            if (j < 64) r0 |= 1ull << j; else r1 |= 1ull << (j - 64);
+                        const uint32_t tvf = s_tvf[p];
+                        if ((tvf & 0x7FFFFFFFu) == a.tgt_view || azero || (tvf >> 31)) continue;
+                        const float odp1 = s_sorted[p], odp2 = s_dp2[p];
+                        const float d1 = a.dp1 - odp1, d2 = a.dp2 - odp2;
+                        if (d1 * d1 > 0.72f * a.reg1 || d2 * d2 > 0.72f * a.reg2) continue;   // see sim_decide
+                        const float y1 = -d1 * d1 / a.reg1, y2 = -d2 * d2 / a.reg2;
+                        if (y1 == y1 && !(y1 > sc.y_thr)) continue;
+                        if (y2 == y2 && !(y2 > sc.y_thr)) continue;
+                        // angular part: fp32 dot product, exact fp64 redo when it is near a threshold
+                        const float xf = fmaxf(fminf(adx * s_dir[3 * p] + ady * s_dir[3 * p + 1] + adz * s_dir[3 * p + 2], 1.0f), -1.0f);
+                        bool ok;
+                        if (fabsf(xf - sc.x_hi) > kDirSlack && fabsf(xf - sc.x_lo) > kDirSlack) {
+                            ok = xf >= sc.x_hi || xf <= sc.x_lo;
+                        } else {
+                            const float dot_p = (float)dot(ad, entry_dir(v.C, sx, odp1, odp2));
+                            const float x = fmaxf(fminf(dot_p, 1.0f), -1.0f);
+                            ok = x >= sc.x_hi || x <= sc.x_lo;
+                        }
+                        if (ok) {
+                            const uint32_t j = s_sidx[p];
+#pragma unroll
+                            for (uint32_t w = 0; w < (kStageCap + 63) / 64; ++w) rw[w] |= (w == (j >> 6)) ? (1ull << (j & 63)) : 0ull;
                         }
                     }
-                    rows[(size_t)i * W] = r0;
-                    if (W > 1) rows[(size_t)i * W + 1] = r1;
+#pragma unroll
+                    for (uint32_t w = 0; w < (kStageCap + 63) / 64; ++w) if (w < W) rows[(size_t)i * W + w] = rw[w];
                     continue;
                 }
+                for (uint32_t w = 0; w < W; ++w) rows[(size_t)i * W + w] = 0ull;
                 for (uint32_t p = lo; p < hi; ++p) {
-                    const uint32_t j = s_sidx[wave][p];
+                    const uint32_t j = s_sidx[p];
                     const DEntry& o = dents[b + j];
                     if (o.tgt_view == a.tgt_view) continue;
-                    if (sim_decide(ad, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
-                                   entry_dir(v.C, sx, o.dp1, o.dp2), (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc))
+                    if (sim_decide(ad, azero, a.dp1, a.dp2, a.reg1, a.reg2, entry_dir(v.C, sx, o.dp1, o.dp2),
+                                   (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc))
                         rows[(size_t)i * W + (j >> 6)] |= 1ull << (j & 63);
                 }
             }
@@ -500,6 +526,7 @@ __global__ __launch_bounds__(256) void k_presence_view(uint32_t g0, uint32_t M, 
     }
 }
 
+constexpr uint32_t kScoreCap = 256;
 // scores of all views (batched): for every existing hypothesis i walk the existing supporters (S_i & P) in
 // canonical order with the reference's per-camera replace/subtract accumulation (line3D.cc:1255-1274); a zero
 // similarity never changes that accumulation, so visiting only the supporters gives the same float result.
@@ -515,12 +542,30 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
     if (g >= G) return;
     const uint32_t b = off[g], L = off[g + 1] - b;
     if (L == 0) return;
+#ifdef L3D_EXP_SHORTONLY
+    if (L > 128) return;
+#endif
     const uint32_t W = (L + 63) / 64;
     const uint64_t* rows = bits + boff[g];
     const uint64_t* P = rows + (size_t)L * W;
     const uint32_t vi = gseg_view[g];
     const ViewDev& v = views[vi];
-    const SegX sx = v.segx[g - seg_base[vi]];
+    const SegX sx = views[0].segx[g];   // global array (upload_views): views[0].segx is its base
+    // the supporters' depths and cameras are read from LDS (one coalesced pass) instead of one dependent global
+    // load per set bit
+    __shared__ float s_d1[4][kScoreCap], s_d2[4][kScoreCap];
+    __shared__ uint32_t s_tv[4][kScoreCap];
+    const bool staged = L <= kScoreCap;
+    if (staged) {
+        for (uint32_t m0 = 0; m0 < L; m0 += 64)
+            if (m0 + lane < L) {
+                const DEntry& e = dents[b + m0 + lane];
+                s_d1[wave][m0 + lane] = e.dp1; s_d2[wave][m0 + lane] = e.dp2; s_tv[wave][m0 + lane] = e.tgt_view;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     float vmax = 0.0f;
     for (uint32_t m0 = 0; m0 < L; m0 += 64) {
         const uint32_t i = m0 + lane;
@@ -536,13 +581,15 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
                     while (m) {
                         const uint32_t j = w * 64 + (uint32_t)__ffsll((long long)m) - 1u;
                         m &= m - 1;
-                        const DEntry& o = dents[b + j];
+                        float odp1, odp2; uint32_t otv;
+                        if (staged) { odp1 = s_d1[wave][j]; odp2 = s_d2[wave][j]; otv = s_tv[wave][j]; }
+                        else { const DEntry& o = dents[b + j]; odp1 = o.dp1; odp2 = o.dp2; otv = o.tgt_view; }
                         const float sim = sim_value(ad, a.dp1, a.dp2, a.reg1, a.reg2,
-                                                    entry_dir(v.C, sx, o.dp1, o.dp2), o.dp1, o.dp2, sc);
-                        if (o.tgt_view == cur_cam) {
+                                                    entry_dir(v.C, sx, odp1, odp2), odp1, odp2, sc);
+                        if (otv == cur_cam) {
                             if (sim > cur) { score3D -= cur; score3D += sim; cur = sim; }
                         } else {
-                            score3D += sim; cur = sim; cur_cam = o.tgt_view;
+                            score3D += sim; cur = sim; cur_cam = otv;
                         }
                     }
                 }

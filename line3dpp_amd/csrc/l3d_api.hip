@@ -110,6 +110,7 @@ struct l3d_ctx {
     DevBuf<float2> d_src_band, d_chunk_band, d_tgt_band;
     DevBuf<float4> d_tgt_sf;
     bool use_cull = true;
+    DevBuf<SegX> d_gsegx;                           // SegX of every segment, global segment order
     float collinearity_t = -1.0f;                   // collinearity_t_ (reconstruct3Dlines); > 0: collinear links
     DevBuf<uint32_t> d_coll_cnt, d_coll_off, d_coll_idx, d_item_cnt, d_item_off, d_item_seg;
     DevBuf<float> d_item_sim;
@@ -283,12 +284,19 @@ int upload_views(l3d_ctx& c) {
     L3D_HIP_CHECK(c.h_views.reserve(V));
     ViewDev* hv = c.h_views.p;
     uint32_t max_M = 0;
+    // the per-segment invariants of all views live in ONE array indexed by the global segment id, so that the
+    // phase-B kernels reach them with one load (gsegx[g]) instead of g -> view -> pointer -> record
+    size_t Gtot = 0;
+    for (size_t i = 0; i < V; ++i) Gtot += c.order[i]->M;
+    L3D_HIP_CHECK(c.d_gsegx.reserve(std::max<size_t>(Gtot, 1)));
+    size_t gbase = 0;
     for (size_t i = 0; i < V; ++i) {
         HostView& v = *c.order[i];
         ViewDev& d = hv[i];
         d.C[0] = v.C.x; d.C[1] = v.C.y; d.C[2] = v.C.z;
         std::memcpy(d.RtKinv, v.RtKinv.m, 72);
-        d.seg4 = v.d_seg4.p; d.segf = v.d_segf.p; d.segx = v.d_segx.p;
+        d.seg4 = v.d_seg4.p; d.segf = v.d_segf.p; d.segx = c.d_gsegx.p + gbase;
+        gbase += v.M;
         d.M = v.M; d.cam = v.cam; d.k = v.k;
         d.cx = 0.5f * (float)v.width; d.cy = 0.5f * (float)v.height; d.pad = 0;
         max_M = std::max(max_M, v.M);
@@ -374,7 +382,7 @@ void l3d_destroy(l3d_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->views) {
         HostView& v = *kv.second;
-        v.d_seg4.release(); v.d_segf.release(); v.d_segx.release();
+        v.d_seg4.release(); v.d_segf.release();
     }
     c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release();
     c->h_views.release(); c->h_pairs.release(); c->h_cull.release(); c->h_work.release(); c->h_vout.release();
@@ -386,7 +394,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_scan_tmp.release(); c->d_scal.release(); c->d_max_score.release(); c->d_surv_cnt.release();
     c->d_has_best.release(); c->d_best_pos.release(); c->d_surv_off.release(); c->d_hyp_off.release();
     c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_bits.release(); c->d_eref.release(); c->d_positive.release(); c->d_bits_len.release(); c->d_boff.release(); c->d_cnt_inv.release();
-    c->d_cnt_pack.release(); c->d_inv_pos.release();
+    c->d_cnt_pack.release(); c->d_inv_pos.release(); c->d_gsegx.release();
     c->d_coll_cnt.release(); c->d_coll_off.release(); c->d_coll_idx.release(); c->d_item_cnt.release();
     c->d_item_off.release(); c->d_item_seg.release(); c->d_item_sim.release();
     c->d_inv_off.release(); c->d_vout_pairs.release(); c->d_vout_off.release(); c->d_dents.release(); c->d_surv.release();
@@ -431,7 +439,6 @@ int l3d_add_view(l3d_ctx* c, uint32_t camID, const float* segs4, uint32_t M, con
     v->fixed_nbrs.assign(neighbors, neighbors + n_neighbors);
     L3D_HIP_CHECK(v->d_seg4.reserve(M));
     L3D_HIP_CHECK(v->d_segf.reserve(M));
-    L3D_HIP_CHECK(v->d_segx.reserve(M));
     L3D_HIP_CHECK(hipMemcpy(v->d_seg4.p, v->segs.data(), (size_t)M * 16, hipMemcpyHostToDevice));
     c->views_avg_depths.push_back((float)std::fmax(median_depth, kEps));
     c->views[camID] = std::move(v);

@@ -96,7 +96,6 @@ struct HostView {
     // device
     DevBuf<float4> d_seg4;
     DevBuf<SegF> d_segf;
-    DevBuf<SegX> d_segx;
     // pairs touching this view (indices into Ctx::pairs)
     std::vector<uint32_t> out_pairs;    // this view is src, ascending tgt
     std::vector<uint32_t> in_pairs;     // this view is tgt and src < this (inverse matches), ascending src
