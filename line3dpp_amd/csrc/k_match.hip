@@ -356,9 +356,7 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
         for (uint32_t i = 0; i < c; ++i) rank += better(ov[i], ix[i], oj, xj) ? 1u : 0u;
         PairResult res{};
         const SegX tx = vt.segx[xj];
-#ifndef L3D_EXP_NOEPI
         exact_depths(sx, tx, vs.C, vt.C, res);
-#endif
         Slot o;
         o.tgt_seg = xj; o.overlap = oj;
         o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;

@@ -348,16 +348,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                      const DEntry* __restrict__ dents, uint64_t* __restrict__ bits,
                                                      const ViewDev* __restrict__ views,
                                                      const uint32_t* __restrict__ seg_base,
-                                                     const uint32_t* __restrict__ gseg_view, SimConst sc) {
+                                                     const uint32_t* __restrict__ gseg_view, SimConst sc,
+                                                     uint32_t g0) {
     __shared__ float s_pool[4][kPoolFloats];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t g = blockIdx.x * 4 + wave;
+    const uint32_t g = g0 + blockIdx.x * 4 + wave;
     if (g >= G) return;
     const uint32_t b = off[g], L = off[g + 1] - b;
     if (L == 0) return;
-#ifdef L3D_EXP_SHORTONLY
-    if (L > 128) return;
-#endif
     const uint32_t W = (L + 63) / 64;
     uint64_t* rows = bits + boff[g];
     const uint32_t vi = gseg_view[g];
@@ -536,15 +534,13 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
                                                    DEntry* __restrict__ dents, const uint64_t* __restrict__ bits,
                                                    Slot* __restrict__ slots, uint32_t* __restrict__ max_score_bits,
                                                    const ViewDev* __restrict__ views,
-                                                   const uint32_t* __restrict__ seg_base, SimConst sc) {
+                                                   const uint32_t* __restrict__ seg_base, SimConst sc,
+                                                   uint32_t g0) {
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t g = blockIdx.x * 4 + wave;
+    const uint32_t g = g0 + blockIdx.x * 4 + wave;
     if (g >= G) return;
     const uint32_t b = off[g], L = off[g + 1] - b;
     if (L == 0) return;
-#ifdef L3D_EXP_SHORTONLY
-    if (L > 128) return;
-#endif
     const uint32_t W = (L + 63) / 64;
     const uint64_t* rows = bits + boff[g];
     const uint64_t* P = rows + (size_t)L * W;
@@ -901,12 +897,12 @@ hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, hipSt
     hipLaunchKernelGGL(k_bits_len, dim3((G + 255) / 256), dim3(256), 0, st, G, off, len);
     return hipGetLastError();
 }
-hipError_t launch_support_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry* dents,
+hipError_t launch_support_all(uint32_t g0, uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry* dents,
                               uint64_t* bits, const ViewDev* views, const uint32_t* seg_base,
                               const uint32_t* gseg_view, SimConst sc, hipStream_t st) {
-    if (!G) return hipSuccess;
-    hipLaunchKernelGGL(k_support_all, dim3((G + 3) / 4), dim3(256), 0, st, G, off, boff, dents, bits, views, seg_base,
-                       gseg_view, sc);
+    if (G <= g0) return hipSuccess;
+    hipLaunchKernelGGL(k_support_all, dim3((G - g0 + 3) / 4), dim3(256), 0, st, G, off, boff, dents, bits, views,
+                       seg_base, gseg_view, sc, g0);
     return hipGetLastError();
 }
 hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff,
@@ -917,12 +913,12 @@ hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, co
                        positive);
     return hipGetLastError();
 }
-hipError_t launch_score_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view,
+hipError_t launch_score_all(uint32_t g0, uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view,
                             DEntry* dents, const uint64_t* bits, Slot* slots, uint32_t* max_score_bits,
                             const ViewDev* views, const uint32_t* seg_base, SimConst sc, hipStream_t st) {
-    if (!G) return hipSuccess;
-    hipLaunchKernelGGL(k_score_all, dim3((G + 3) / 4), dim3(256), 0, st, G, off, boff, gseg_view, dents, bits, slots,
-                       max_score_bits, views, seg_base, sc);
+    if (G <= g0) return hipSuccess;
+    hipLaunchKernelGGL(k_score_all, dim3((G - g0 + 3) / 4), dim3(256), 0, st, G, off, boff, gseg_view, dents, bits,
+                       slots, max_score_bits, views, seg_base, sc, g0);
     return hipGetLastError();
 }
 hipError_t launch_filter_all(uint32_t G, const uint32_t* off, const uint32_t* gseg_view, DEntry* dents,

@@ -40,12 +40,12 @@ hipError_t launch_build_lists_all(uint32_t G, const ViewDev*, const PairDesc*, c
                                   const uint32_t* off, const uint32_t* inv_off, const InvRef*, const Slot*, DEntry*,
                                   uint32_t* eref, uint32_t uniform_K, hipStream_t);
 hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, hipStream_t);
-hipError_t launch_support_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry*, uint64_t* bits,
+hipError_t launch_support_all(uint32_t g0, uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry*, uint64_t* bits,
                               const ViewDev*, const uint32_t* seg_base, const uint32_t* gseg_view, SimConst, hipStream_t);
 hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff,
                                 const uint32_t* inv_off, const uint32_t* eref, uint64_t* bits, uint8_t* positive,
                                 hipStream_t);
-hipError_t launch_score_all(uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view, DEntry*,
+hipError_t launch_score_all(uint32_t g0, uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view, DEntry*,
                             const uint64_t* bits, Slot*, uint32_t* max_score_bits, const ViewDev*, const uint32_t* seg_base,
                             SimConst, hipStream_t);
 hipError_t launch_filter_all(uint32_t G, const uint32_t* off, const uint32_t* gseg_view, DEntry*,
@@ -110,6 +110,8 @@ struct l3d_ctx {
     DevBuf<float2> d_src_band, d_chunk_band, d_tgt_band;
     DevBuf<float4> d_tgt_sf;
     bool use_cull = true;
+    hipStream_t aux[2] = {nullptr, nullptr};        // phase-B pipeline streams (chain, scores)
+    std::vector<hipEvent_t> pipe_ev;
     DevBuf<SegX> d_gsegx;                           // SegX of every segment, global segment order
     float collinearity_t = -1.0f;                   // collinearity_t_ (reconstruct3Dlines); > 0: collinear links
     DevBuf<uint32_t> d_coll_cnt, d_coll_off, d_coll_idx, d_item_cnt, d_item_off, d_item_seg;
@@ -403,6 +405,8 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_flag.release(); c->d_epos.release(); c->d_first_touch.release(); c->d_touch_flag.release();
     c->d_touch_rank.release(); c->d_edges.release(); c->d_l2g.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->pipe_ev) (void)hipEventDestroy(e);
+    for (auto& s2 : c->aux) if (s2) (void)hipStreamDestroy(s2);
     delete c;
 }
 
@@ -750,16 +754,50 @@ int l3d_match_finish(l3d_ctx* c) {
                                          c->d_vout_off.p, c->d_vout_pairs.p, c->d_off.p, c->d_inv_off.p, c->d_refs.p,
                                          c->d_slots.p, c->d_dents.p, c->d_eref.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, st));
     const SimConst simc = sim_thresholds(c->two_sigA_sqr);
-    // all L^2 similarity decisions of all segments (chain independent)
-    L3D_HIP_CHECK(launch_support_all(G, c->d_off.p, c->d_boff.p, c->d_dents.p, c->d_bits.p, c->d_views.p, c->d_seg_base.p,
-                                     c->d_gseg_view.p, simc, st));
-    // ---- chain: one bit-propagation launch per view, ascending camID ----
-    for (uint32_t vi = 0; vi < V; ++vi)
-        L3D_HIP_CHECK(launch_presence_view(c->seg_base[vi], c->order[vi]->M, c->d_off.p, c->d_boff.p, c->d_inv_off.p,
-                                           c->d_eref.p, c->d_bits.p, c->d_positive.p, st));
-    // scores of all views
-    L3D_HIP_CHECK(launch_score_all(G, c->d_off.p, c->d_boff.p, c->d_gseg_view.p, c->d_dents.p, c->d_bits.p,
-                                   c->d_slots.p, c->d_max_score.p, c->d_views.p, c->d_seg_base.p, simc, st));
+    // Three-stage software pipeline over chunks of views on three streams:
+    //   A (the context's stream)  support bitsets of chunk k          (chain independent, heavy)
+    //   B                         THE CHAIN: one tiny bit-propagation launch per view, ascending camID; view v only
+    //                             needs the support rows of its own chunk and the chain state of the views before it
+    //   C                         scores of chunk k (needs the presence masks of chunk k)
+    // so the launch-latency-bound chain (V dependent launches that keep < 5 % of the GPU busy) hides behind the
+    // support / score kernels of the neighbouring chunks.
+    {
+        const uint32_t n_chunks = std::min<uint32_t>(std::max<uint32_t>((V + 7) / 8, 1), 64);
+        const uint32_t per = (V + n_chunks - 1) / n_chunks;
+        while (c->pipe_ev.size() < 2 * (size_t)n_chunks + 2) {
+            hipEvent_t e;
+            L3D_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->pipe_ev.push_back(e);
+        }
+        if (!c->aux[0]) {   // the chain stream gets the highest priority: its tiny kernels must not queue behind
+            int lo_p = 0, hi_p = 0;   // thousands of support/score workgroups
+            L3D_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+            L3D_HIP_CHECK(hipStreamCreateWithPriority(&c->aux[0], hipStreamNonBlocking, hi_p));
+        }
+        if (!c->aux[1]) L3D_HIP_CHECK(hipStreamCreateWithFlags(&c->aux[1], hipStreamNonBlocking));
+        hipStream_t sB = c->aux[0], sC = c->aux[1];
+        hipEvent_t ev_start = c->pipe_ev[2 * n_chunks], ev_done = c->pipe_ev[2 * n_chunks + 1];
+        L3D_HIP_CHECK(hipEventRecord(ev_start, st));
+        L3D_HIP_CHECK(hipStreamWaitEvent(sB, ev_start, 0));
+        L3D_HIP_CHECK(hipStreamWaitEvent(sC, ev_start, 0));
+        for (uint32_t k = 0; k < n_chunks; ++k) {
+            const uint32_t v0 = std::min(V, k * per), v1 = std::min(V, v0 + per);
+            const uint32_t g0 = c->seg_base[v0], g1 = c->seg_base[v1];
+            L3D_HIP_CHECK(launch_support_all(g0, g1, c->d_off.p, c->d_boff.p, c->d_dents.p, c->d_bits.p, c->d_views.p,
+                                             c->d_seg_base.p, c->d_gseg_view.p, simc, st));
+            L3D_HIP_CHECK(hipEventRecord(c->pipe_ev[2 * k], st));
+            L3D_HIP_CHECK(hipStreamWaitEvent(sB, c->pipe_ev[2 * k], 0));
+            for (uint32_t vi = v0; vi < v1; ++vi)
+                L3D_HIP_CHECK(launch_presence_view(c->seg_base[vi], c->order[vi]->M, c->d_off.p, c->d_boff.p,
+                                                   c->d_inv_off.p, c->d_eref.p, c->d_bits.p, c->d_positive.p, sB));
+            L3D_HIP_CHECK(hipEventRecord(c->pipe_ev[2 * k + 1], sB));
+            L3D_HIP_CHECK(hipStreamWaitEvent(sC, c->pipe_ev[2 * k + 1], 0));
+            L3D_HIP_CHECK(launch_score_all(g0, g1, c->d_off.p, c->d_boff.p, c->d_gseg_view.p, c->d_dents.p, c->d_bits.p,
+                                           c->d_slots.p, c->d_max_score.p, c->d_views.p, c->d_seg_base.p, simc, sC));
+        }
+        L3D_HIP_CHECK(hipEventRecord(ev_done, sC));
+        L3D_HIP_CHECK(hipStreamWaitEvent(st, ev_done, 0));
+    }
     // ---- post-pass: filterMatches for all views ----
     L3D_HIP_CHECK(launch_filter_all(G, c->d_off.p, c->d_gseg_view.p, c->d_dents.p, c->d_max_score.p, c->d_surv_cnt.p,
                                     c->d_has_best.p, c->d_best_pos.p, st));
