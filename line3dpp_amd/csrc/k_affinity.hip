@@ -39,7 +39,7 @@ __device__ __forceinline__ float sim_affinity(const HypRec& h1, const HypRec& h2
     const float dot_p = (float)dot(d3{h1.dir[0], h1.dir[1], h1.dir[2]}, d3{h2.dir[0], h2.dir[1], h2.dir[2]});
     float angle = (float)(acos((double)fmaxf(fminf(dot_p, 1.0f), -1.0f)) / M_PI * 180.0f);
     if (angle > 90.0f) angle = 180.0f - angle;
-    const float sim_a = expf_ref(-angle * angle / two_sigA_sqr);
+    const float y_a = -angle * angle / two_sigA_sqr;
     float cutoff1 = md1, cutoff2 = md2;
     if (med_scene_depth_lines > kEps) {
         cutoff1 = fminf(cutoff1, med_scene_depth_lines);
@@ -53,9 +53,10 @@ __device__ __forceinline__ float sim_affinity(const HypRec& h1, const HypRec& h2
     const float sig21 = (h2.m.dp1 > cutoff2) ? cutoff2 * k2 : h2.m.dp1 * k2;
     const float sig22 = (h2.m.dp2 > cutoff2) ? cutoff2 * k2 : h2.m.dp2 * k2;
     const float reg21 = 2.0f * sig21 * sig21, reg22 = 2.0f * sig22 * sig22;
-    const float sim_p1 = fminf(expf_ref(-d11 * d11 / reg11), expf_ref(-d12 * d12 / reg12));
-    const float sim_p2 = fminf(expf_ref(-d21 * d21 / reg21), expf_ref(-d22 * d22 / reg22));
-    return fminf(sim_a, fminf(sim_p1, sim_p2));
+    // fmin over five expf values == expf of the fmin of their arguments (monotone, NaNs skipped alike)
+    const float y_p1 = fminf(-d11 * d11 / reg11, -d12 * d12 / reg12);
+    const float y_p2 = fminf(-d21 * d21 / reg21, -d22 * d22 / reg22);
+    return expf_ref(fminf(y_a, fminf(y_p1, y_p2)));
 }
 
 }  // namespace

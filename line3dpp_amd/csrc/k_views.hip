@@ -309,9 +309,9 @@ __device__ __forceinline__ float sim_value(const d3 dira, float adp1, float adp2
     float angle = (float)(acos((double)fmaxf(fminf(dot_p, 1.0f), -1.0f)) / M_PI * 180.0f);
     if (angle > 90.0f) angle = 180.0f - angle;
     const float ya = -angle * angle / sc.two_sigA_sqr;
-    const float sim_a = (float)exp((double)ya);
-    const float sim_p = fminf((float)exp((double)y1), (float)exp((double)y2));
-    return fminf(sim_a, sim_p);
+    // fmin(expf(ya), fmin(expf(y1), expf(y2))) == expf(fmin(ya, fmin(y1, y2))): expf is monotone and fmin skips
+    // NaNs on both sides alike -- one exponential instead of three
+    return (float)exp((double)fminf(ya, fminf(y1, y2)));
 }
 
 // ---- support bitsets (batched), presence propagation (the chain), scores (batched) ---------------------

@@ -3,6 +3,8 @@
 // (line3D.cc:112-227, 375-497, 702-778, 1749-1778, 1852-1979).  No CPU fallback exists: every
 // compute step is a HIP kernel launch; without a usable device the calls fail with L3D_ERR_HIP.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <memory>
 #include <mutex>
@@ -353,6 +355,18 @@ SimConst sim_thresholds(float two_sigA_sqr) {
     return sc;
 }
 
+// L3D_TRACE=1: host-side wall-clock checkpoints of matchImages on stderr (diagnostics)
+struct HostTrace {
+    bool on = std::getenv("L3D_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char* what) {
+        if (!on) return;
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        std::fprintf(stderr, "[l3d trace] %9.1f us  %s\n", us, what);
+    }
+};
+static HostTrace g_trace;
+
 float ev_ms(hipEvent_t a, hipEvent_t b) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, a, b);
@@ -698,6 +712,7 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_medians.reserve(V + 1));
     L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
     L3D_HIP_CHECK(c->h_small.reserve(V + 1));
+    g_trace.mark("finish: reserves done");
     std::memcpy(c->h_small.p, c->seg_base.data(), ((size_t)V + 1) * 4);
     L3D_HIP_CHECK(hipMemcpyAsync(c->d_seg_base.p, c->h_small.p, ((size_t)V + 1) * 4, hipMemcpyHostToDevice, st));
     {
@@ -705,6 +720,7 @@ int l3d_match_finish(l3d_ctx* c) {
         for (auto* v : c->order) max_M = std::max(max_M, v->M);
         L3D_HIP_CHECK(launch_fill_gseg_view(c->d_seg_base.p, V, max_M, c->d_gseg_view.p, st));
     }
+    g_trace.mark("finish: seg_base + gseg enqueued");
     // outgoing pairs of every view (ascending target), for the fresh part of the lists
     // staged as [vout_off (V+1) | vout_pairs (P)] in one pinned buffer
     c->vout_off.assign(V + 1, 0);
@@ -728,6 +744,7 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(hipMemsetAsync(c->d_cnt_pack.p, 0, ((size_t)G + 1) * 8, st));
     L3D_HIP_CHECK(hipMemsetAsync(c->d_max_score.p, 0, ((size_t)V + 1) * 4, st));
     L3D_HIP_CHECK(hipMemsetAsync(c->d_scal.p, 0, 16 * 4, st));
+    g_trace.mark("finish: memsets enqueued");
     // ---- pre-pass: orientation flags, list offsets, transposed index of potential inverse matches ----
     L3D_HIP_CHECK(launch_orient_all(c->d_views.p, c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, G,
                                     c->d_cnt_pack.p, c->d_inv_pos.p, c->d_cnt.p, c->d_cnt_inv.p, c->orient_lo,
@@ -739,7 +756,9 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(launch_scan(c->d_bits_len.p, G, c->d_boff.p, c->d_scan_tmp.p, c->d_scal.p + 6, st));
     uint32_t tot[7] = {0, 0, 0, 0, 0, 0, 0};
     L3D_HIP_CHECK(hipMemcpyAsync(tot, c->d_scal.p, 7 * 4, hipMemcpyDeviceToHost, st));
+    g_trace.mark("pre-pass enqueued, waiting for sizes");
     L3D_HIP_CHECK(hipStreamSynchronize(st));   // first point at which the host waits for the GPU in matchImages
+    g_trace.mark("sizes known");
     const uint32_t n_ents = c->n_ents = tot[0], n_inv = tot[5], n_words = tot[6];
     c->tm.list_entries = n_ents; c->tm.support_words = n_words;
     L3D_HIP_CHECK(c->d_dents.reserve(std::max<uint32_t>(n_ents, 1)));
@@ -805,7 +824,9 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(launch_scan(c->d_has_best.p, G, c->d_hyp_off.p, c->d_scan_tmp.p, c->d_scal.p + 2, st));
     uint32_t nh[2] = {0, 0};
     L3D_HIP_CHECK(hipMemcpyAsync(nh, c->d_scal.p + 1, 8, hipMemcpyDeviceToHost, st));
+    g_trace.mark("lists/support/chain/scores/filter enqueued, waiting for counts");
     L3D_HIP_CHECK(hipStreamSynchronize(st));
+    g_trace.mark("counts known");
     c->n_surv = nh[0]; c->n_hyps = nh[1];
     L3D_HIP_CHECK(c->d_surv.reserve(std::max<uint32_t>(c->n_surv, 1)));
     L3D_HIP_CHECK(c->d_surv_tg.reserve(std::max<uint32_t>(c->n_surv, 1)));
@@ -839,12 +860,18 @@ int l3d_match_finish(l3d_ctx* c) {
 int l3d_match_images(l3d_ctx* c, const l3d_match_params* p) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
+    g_trace.t0 = std::chrono::steady_clock::now();
+    g_trace.mark("matchImages enter");
     int rc = l3d_match_begin(c, p);
+    g_trace.mark("begin enqueued");
     if (rc) return rc;
     // nothing between begin and the first sizing read-back of phase B waits for the GPU
     rc = match_pairs_impl(c, 0, (uint32_t)c->pairs.size(), false);
+    g_trace.mark("phase A enqueued");
     if (rc) return rc;
-    return l3d_match_finish(c);
+    rc = l3d_match_finish(c);
+    g_trace.mark("matchImages done");
+    return rc;
 }
 
 // computingAffinityMatrix with collinearity_t_ > 0 (line3D.cc:1852-1979 incl. the links to collinear segments,

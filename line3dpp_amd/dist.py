@@ -83,6 +83,8 @@ def device_tensor(ptr, nbytes, device):
 def match_images_sharded(l3d, rank, world_size, device=None, group=None, **params):
     """matchImages with phase A sharded over `world_size` ranks.  `l3d` is a line3dpp_amd.Line3D that
     already holds all views (every rank adds the same views)."""
+    if world_size == 1:
+        return l3d.matchImages(**params)   # one call: nothing waits for the GPU between the phases
     if not l3d.matchBegin(**params):
         return False
     pairs, slot_off = l3d.pairs()
