@@ -340,8 +340,8 @@ __global__ void k_bits_len(uint32_t G, const uint32_t* __restrict__ off, uint32_
 //   L <= kSortCap:  only the sort lives in LDS (same pool), candidates are read from global memory;
 //   longer lists:   all-pairs loop.
 constexpr uint32_t kStageCap = 192;
-constexpr uint32_t kPoolFloats = 1440;                    // per-wave LDS pool: 7.5 floats per staged hypothesis
-constexpr uint32_t kSortCap = kPoolFloats * 2 / 5;        // 2.5 floats per hypothesis when only the sort is kept
+constexpr uint32_t kPoolFloats = 1632;                    // per-wave LDS pool: 8.5 floats per staged hypothesis
+constexpr uint32_t kSortCap = kPoolFloats * 2 / 7;        // 3.5 floats per hypothesis when only the sort is kept
 constexpr float kDirSlack = 2e-6f;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_support_all(uint32_t G, const uint32_t* __restrict__ off,
                                                      const uint32_t* __restrict__ boff,
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                      const uint32_t* __restrict__ seg_base,
                                                      const uint32_t* __restrict__ gseg_view, SimConst sc,
                                                      uint32_t g0) {
-    __shared__ float s_pool[4][kPoolFloats];
+    __shared__ __attribute__((aligned(16))) float s_pool[4][kPoolFloats];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t g = g0 + blockIdx.x * 4 + wave;
     if (g >= G) return;
@@ -364,27 +364,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     if (L <= kSortCap) {
         const bool staged = L <= kStageCap;
         const uint32_t cap = staged ? kStageCap : kSortCap;
-        float* s_key = s_pool[wave];                       // dp1, canonical order
-        float* s_sorted = s_key + cap;                     // dp1, sorted
+        // sort key of hypothesis i: order-preserving bits of dp1 in the high word, i in the low word -- one 64-bit
+        // compare per pair gives the rank with the (dp1, index) tie-break
+        uint64_t* s_key = (uint64_t*)s_pool[wave];         // canonical order
+        float* s_sorted = (float*)(s_key + cap);           // dp1, sorted
         uint16_t* s_sidx = (uint16_t*)(s_sorted + cap);    // canonical index of a sorted position
         float* s_dp2 = (float*)(s_sidx + cap);             // staged only, sorted order
         uint32_t* s_tvf = (uint32_t*)(s_dp2 + cap);        // tgt_view | zero-length flag << 31
         float* s_dir = (float*)(s_tvf + cap);              // 3 floats per hypothesis
         for (uint32_t m0 = 0; m0 < L; m0 += 64)
-            if (m0 + lane < L) s_key[m0 + lane] = dents[b + m0 + lane].dp1;
+            if (m0 + lane < L) {
+                const uint32_t u = __float_as_uint(dents[b + m0 + lane].dp1);
+                const uint32_t o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                s_key[m0 + lane] = ((uint64_t)o << 32) | (m0 + lane);
+            }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         for (uint32_t m0 = 0; m0 < L; m0 += 64) {
             const uint32_t i = m0 + lane;
             if (i < L) {
-                const float k = s_key[i];
+                const uint64_t k = s_key[i];
                 uint32_t rank = 0;
-                for (uint32_t j = 0; j < L; ++j) {
-                    const float o = s_key[j];
-                    rank += (o < k || (o == k && j < i)) ? 1u : 0u;
-                }
-                s_sorted[rank] = k;
+                for (uint32_t j = 0; j < L; ++j) rank += (s_key[j] < k) ? 1u : 0u;
+                const uint32_t ko = (uint32_t)(k >> 32);
+                s_sorted[rank] = __uint_as_float((ko & 0x80000000u) ? (ko & 0x7FFFFFFFu) : ~ko);
                 s_sidx[rank] = (uint16_t)i;
                 if (staged) {
                     const DEntry e = dents[b + i];
