@@ -112,6 +112,10 @@ struct l3d_ctx {
     DevBuf<float2> d_src_band, d_chunk_band, d_tgt_band;
     DevBuf<float4> d_tgt_sf;
     bool use_cull = true;
+    // A_ / local2global_ stay on the device; the host copies (edges, l2g) are fetched on first use
+    uint32_t aff_n_edges = 0, aff_n_rows = 0;
+    bool aff_host_valid = true;
+    PinnedBuf<uint32_t> h_cnt;
     hipStream_t aux[2] = {nullptr, nullptr};        // phase-B pipeline streams (chain, scores)
     std::vector<hipEvent_t> pipe_ev;
     DevBuf<SegX> d_gsegx;                           // SegX of every segment, global segment order
@@ -402,7 +406,7 @@ void l3d_destroy(l3d_ctx* c) {
     }
     c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release();
     c->h_views.release(); c->h_pairs.release(); c->h_cull.release(); c->h_work.release(); c->h_vout.release();
-    c->h_small.release();
+    c->h_small.release(); c->h_cnt.release();
     c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
     c->d_chunk_band.release(); c->d_tgt_sf.release(); c->d_tgt_band.release();
     c->d_row_counts.release();
@@ -978,6 +982,7 @@ static int affinity_collinear(l3d_ctx* c) {
         const uint32_t vi = (uint32_t)(std::upper_bound(c->seg_base.begin(), c->seg_base.end(), g) - c->seg_base.begin()) - 1;
         c->l2g[r].camID_ = c->order[vi]->cam; c->l2g[r].segID_ = g - c->seg_base[vi];
     }
+    c->aff_n_edges = (uint32_t)c->edges.size(); c->aff_n_rows = (uint32_t)c->l2g.size(); c->aff_host_valid = true;
     // A_ stays device resident as well (matrix diffusion reads it there)
     L3D_HIP_CHECK(c->d_edges.reserve(std::max<size_t>(c->edges.size(), 1)));
     if (!c->edges.empty())
@@ -992,6 +997,8 @@ static int affinity_core(l3d_ctx* c) {
     hipStream_t st = c->stream;
     const uint32_t V = (uint32_t)c->order.size();
     c->edges.clear(); c->l2g.clear();
+    c->aff_n_edges = 0; c->aff_n_rows = 0; c->aff_host_valid = true;
+    bool counts_pending = false;
     // med_scene_depth_lines_, line3D.cc:1759-1774
     std::vector<float> sd;
     for (auto* v : c->order) if (v->median_depth > kEps) sd.push_back(v->median_depth);
@@ -1024,40 +1031,48 @@ static int affinity_core(l3d_ctx* c) {
         L3D_HIP_CHECK(launch_aff_flag(N, c->d_surv_off.p, c->d_surv_sg.p, c->d_surv_tg.p, c->d_simv.p, c->d_ca.p,
                                       c->d_cb.p, c->d_flag.p, st));
         L3D_HIP_CHECK(launch_scan(c->d_flag.p, N, c->d_epos.p, c->d_scan_tmp.p, c->d_scal.p + 3, st));
-        uint32_t E = 0;
-        L3D_HIP_CHECK(hipMemcpyAsync(&E, c->d_scal.p + 3, 4, hipMemcpyDeviceToHost, st));
-        L3D_HIP_CHECK(hipStreamSynchronize(st));
-        if (E > 0) {
-            L3D_HIP_CHECK(c->d_touch_flag.reserve(2 * (size_t)E + 1));
-            L3D_HIP_CHECK(c->d_touch_rank.reserve(2 * (size_t)E + 1));
-            L3D_HIP_CHECK(c->d_edges.reserve(2 * (size_t)E));
+        // no read-back of the edge count: everything downstream is sized by its upper bound N (flags beyond the
+        // 2E touched positions stay zero), the two counts are read once at the end
+        {
+            L3D_HIP_CHECK(c->d_touch_flag.reserve(2 * (size_t)N + 1));
+            L3D_HIP_CHECK(c->d_touch_rank.reserve(2 * (size_t)N + 1));
+            L3D_HIP_CHECK(c->d_edges.reserve(2 * (size_t)N));
             L3D_HIP_CHECK(c->d_l2g.reserve(H));
             L3D_HIP_CHECK(launch_fill_u32(c->d_first_touch.p, H, kEmpty, st));
-            L3D_HIP_CHECK(hipMemsetAsync(c->d_touch_flag.p, 0, (2 * (size_t)E + 1) * 4, st));
+            L3D_HIP_CHECK(hipMemsetAsync(c->d_touch_flag.p, 0, (2 * (size_t)N + 1) * 4, st));
             L3D_HIP_CHECK(launch_aff_touch(N, c->d_flag.p, c->d_epos.p, c->d_ca.p, c->d_cb.p, c->d_first_touch.p, st));
             L3D_HIP_CHECK(launch_aff_mark(H, c->d_first_touch.p, c->d_touch_flag.p, st));
-            L3D_HIP_CHECK(launch_scan(c->d_touch_flag.p, 2 * E, c->d_touch_rank.p, c->d_scan_tmp.p, c->d_scal.p + 4, st));
+            L3D_HIP_CHECK(launch_scan(c->d_touch_flag.p, 2 * N, c->d_touch_rank.p, c->d_scan_tmp.p, c->d_scal.p + 4, st));
             L3D_HIP_CHECK(launch_aff_emit(N, c->d_flag.p, c->d_epos.p, c->d_ca.p, c->d_cb.p, c->d_simv.p,
                                           c->d_first_touch.p, c->d_touch_rank.p, c->d_hyps.p, c->d_edges.p,
                                           c->d_l2g.p, st));
-            uint32_t rows = 0;
-            L3D_HIP_CHECK(hipMemcpyAsync(&rows, c->d_scal.p + 4, 4, hipMemcpyDeviceToHost, st));
-            L3D_HIP_CHECK(hipStreamSynchronize(st));
-            c->edges.resize(2 * (size_t)E);
-            c->l2g.resize(rows);
-            L3D_HIP_CHECK(hipMemcpyAsync(c->edges.data(), c->d_edges.p, c->edges.size() * sizeof(l3d_cledge),
-                                         hipMemcpyDeviceToHost, st));
-            L3D_HIP_CHECK(hipMemcpyAsync(c->l2g.data(), c->d_l2g.p, rows * sizeof(l3d_segment2d),
-                                         hipMemcpyDeviceToHost, st));
+            L3D_HIP_CHECK(c->h_cnt.reserve(4));
+            L3D_HIP_CHECK(hipMemcpyAsync(c->h_cnt.p, c->d_scal.p + 3, 8, hipMemcpyDeviceToHost, st));
+            counts_pending = true;
         }
     }
     L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
     L3D_HIP_CHECK(hipStreamSynchronize(st));
+    if (counts_pending) { c->aff_n_edges = 2 * c->h_cnt.p[0]; c->aff_n_rows = c->h_cnt.p[1]; c->aff_host_valid = false; }
     c->tm.affinity_ms = ev_ms(c->ev[6], c->ev[7]);
     c->affinity_done = true;
     return L3D_OK;
 }
 
+// host copies of A_ / local2global_ (fetched on first use)
+static int ensure_affinity_host(l3d_ctx* c) {
+    if (c->aff_host_valid) return L3D_OK;
+    (void)hipSetDevice(c->device);
+    c->edges.resize(c->aff_n_edges);
+    c->l2g.resize(c->aff_n_rows);
+    L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->aff_n_edges)
+        L3D_HIP_CHECK(hipMemcpy(c->edges.data(), c->d_edges.p, (size_t)c->aff_n_edges * sizeof(l3d_cledge), hipMemcpyDeviceToHost));
+    if (c->aff_n_rows)
+        L3D_HIP_CHECK(hipMemcpy(c->l2g.data(), c->d_l2g.p, (size_t)c->aff_n_rows * sizeof(l3d_segment2d), hipMemcpyDeviceToHost));
+    c->aff_host_valid = true;
+    return L3D_OK;
+}
 
 int l3d_compute_affinity(l3d_ctx* c) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
@@ -1086,19 +1101,23 @@ int l3d_reconstruct_3d_lines(l3d_ctx* c, uint32_t visibility_t, int perform_diff
     translate(*c);
     int rc = affinity_core(c);
     // matrix diffusion (performRDD, line3D.cc:1787-1791) on the device-resident A_
-    if (rc == L3D_OK && perform_diffusion && !c->edges.empty()) {
-        const uint32_t nnz = (uint32_t)c->edges.size(), n_rows = (uint32_t)c->l2g.size();
+    if (rc == L3D_OK && perform_diffusion && c->aff_n_edges) {
+        const uint32_t nnz = c->aff_n_edges, n_rows = c->aff_n_rows;
+        rc = ensure_affinity_host(c);       // l2g; the edge list is replaced below
+        if (rc) { untranslate(*c); return rc; }
         const size_t wb = rdd_workspace_bytes(nnz, n_rows);
         DevBuf<char> ws; DevBuf<l3d_cledge> out;
         hipError_t e = ws.reserve(wb);
         if (e == hipSuccess) e = out.reserve(nnz);
         if (e == hipSuccess) e = launch_rdd(c->d_edges.p, nnz, n_rows, 10 /* L3D_DEF_RDD_MAX_ITER */, out.p, ws.p, wb, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->d_edges.p, out.p, (size_t)nnz * sizeof(l3d_cledge), hipMemcpyDeviceToDevice, c->stream);
+        c->edges.resize(nnz);
         if (e == hipSuccess) e = hipMemcpyAsync(c->edges.data(), out.p, (size_t)nnz * sizeof(l3d_cledge), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         ws.release(); out.release();
         if (e != hipSuccess) { untranslate(*c); return fail(L3D_ERR_HIP, std::string("matrix diffusion: ") + hipGetErrorString(e)); }
     }
+    if (rc == L3D_OK) rc = ensure_affinity_host(c);
     if (rc == L3D_OK) {
         ReconInput in;
         in.visibility_t = vis;
@@ -1257,14 +1276,15 @@ int l3d_translation(l3d_ctx* c, double t[3]) {
 int l3d_num_affinity(l3d_ctx* c, uint32_t* n_edges, uint32_t* n_rows) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
     if (!c->affinity_done) return fail(L3D_ERR_STATE, "l3d_compute_affinity has not run");
-    if (n_edges) *n_edges = (uint32_t)c->edges.size();
-    if (n_rows) *n_rows = (uint32_t)c->l2g.size();
+    if (n_edges) *n_edges = c->aff_n_edges;
+    if (n_rows) *n_rows = c->aff_n_rows;
     return L3D_OK;
 }
 
 int l3d_get_affinity(l3d_ctx* c, l3d_cledge* edges, l3d_segment2d* l2g, float* msdl) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
     if (!c->affinity_done) return fail(L3D_ERR_STATE, "l3d_compute_affinity has not run");
+    { std::lock_guard<std::recursive_mutex> lk(c->mu); const int rc = ensure_affinity_host(c); if (rc) return rc; }
     if (edges && !c->edges.empty()) std::memcpy(edges, c->edges.data(), c->edges.size() * sizeof(l3d_cledge));
     if (l2g && !c->l2g.empty()) std::memcpy(l2g, c->l2g.data(), c->l2g.size() * sizeof(l3d_segment2d));
     if (msdl) *msdl = c->med_scene_depth_lines;
@@ -1276,6 +1296,7 @@ int l3d_get_affinity(l3d_ctx* c, l3d_cledge* edges, l3d_segment2d* l2g, float* m
 int l3d_get_sparse_matrix(l3d_ctx* c, int sort_by_row, l3d_float4* entries, int32_t* start_indices) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
     if (!c->affinity_done) return fail(L3D_ERR_STATE, "l3d_compute_affinity has not run");
+    { std::lock_guard<std::recursive_mutex> lk(c->mu); const int rc = ensure_affinity_host(c); if (rc) return rc; }
     std::vector<l3d_cledge> e = c->edges;
     if (sort_by_row)
         std::stable_sort(e.begin(), e.end(), [](const l3d_cledge& a, const l3d_cledge& b) {
