@@ -4,7 +4,7 @@
 // triangulationDepths (:1168-1193) and the reference's K_match_lines/host-heap pipeline
 // (cudawrapper.cu:186-253, 549-658) with a design that never materialises the Ms x Mt matrix:
 //
-//   workgroup  = (directed pair, block of 256 source segments), 4 wave64
+//   workgroup  = (directed pair, 64 source segments in epipolar-band order), one wave64
 //   lane       = one source segment; its two epipolar lines live in VGPRs (fp32, unit normal,
 //                image-centre origin)
 //   target view streams through LDS tiles of 16-byte SegF records; every lane reads the same
@@ -394,7 +394,7 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
 // ---- epipolar-band culling: order the source rows and the target segments of each pair by tau ------------
 namespace {
 
-constexpr int kCullBlock = 1024;
+constexpr int kCullBlock = 512;
 constexpr double kCullMinDen = 0.05;   // B.x of a usable point (B.centre == 1): the pencil line is not near-parallel
                                        // to the transversal
 
@@ -480,36 +480,43 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
     const ViewDev& vs = views[pd.src];
     const ViewDev& vt = views[pd.tgt];
     const uint32_t Ms = pd.Ms, Mt = pd.Mt;
+    const bool tgt_side = blockIdx.y != 0;       // grid.y = 2: the two sorts of a pair run in different workgroups
     uint32_t n2 = 64;
-    while (n2 < max(Ms, Mt)) n2 <<= 1;
+    while (n2 < (tgt_side ? Mt : Ms)) n2 <<= 1;
     uint64_t* keys = (uint64_t*)smem;
     uint32_t* cb = (uint32_t*)(keys + n2);       // [2 * n2/64] chunk bands, orderable floats
     __shared__ uint32_t span[2];
     const uint32_t tid = threadIdx.x;
 
-    // ---- source rows: key = (class, lo, row) ----
-    if (tid == 0) { span[0] = 0xFFFFFFFFu; span[1] = 0u; }
-    __syncthreads();
-    for (uint32_t i = tid; i < n2; i += kCullBlock) {
-        uint64_t key = ~0ull;
-        if (i < Ms) {
-            const Band b = src_band(pc, vs.seg4[i]);
-            key = ((uint64_t)b.cls << 56) | ((uint64_t)f2ord(b.lo) << 24) | i;
-            if (b.cls) { atomicMin(&span[0], f2ord(b.lo)); atomicMax(&span[1], f2ord(b.hi)); }
+    if (!tgt_side) {
+        // ---- source rows: key = (class, lo, row) ----
+        for (uint32_t i = tid; i < n2; i += kCullBlock) {
+            uint64_t key = ~0ull;
+            if (i < Ms) {
+                const Band b = src_band(pc, vs.seg4[i]);
+                key = ((uint64_t)b.cls << 56) | ((uint64_t)f2ord(b.lo) << 24) | i;
+            }
+            keys[i] = key;
         }
-        keys[i] = key;
-    }
-    lds_sort(keys, n2);
-    for (uint32_t i = tid; i < Ms; i += kCullBlock) {
-        const uint32_t row = (uint32_t)(keys[i] & 0xFFFFFFu);
-        const Band b = src_band(pc, vs.seg4[row]);
-        cp.src_perm[pc.s_off + i] = row;
-        cp.src_band[pc.s_off + i] = make_float2(b.lo, b.hi);
+        lds_sort(keys, n2);
+        for (uint32_t i = tid; i < Ms; i += kCullBlock) {
+            const uint32_t row = (uint32_t)(keys[i] & 0xFFFFFFu);
+            const Band b = src_band(pc, vs.seg4[row]);
+            cp.src_perm[pc.s_off + i] = row;
+            cp.src_band[pc.s_off + i] = make_float2(b.lo, b.hi);
+        }
+        return;
     }
     // span of all bounded source wedges (empty: no bounded row -> nothing can be widened, nothing is culled
     // either because every row band is unbounded)
-    const float slo = ord2f(span[0]), shi = ord2f(span[1]);
+    if (tid == 0) { span[0] = 0xFFFFFFFFu; span[1] = 0u; }
     __syncthreads();
+    for (uint32_t i = tid; i < Ms; i += kCullBlock) {
+        const Band b = src_band(pc, vs.seg4[i]);
+        if (b.cls) { atomicMin(&span[0], f2ord(b.lo)); atomicMax(&span[1], f2ord(b.hi)); }
+    }
+    __syncthreads();
+    const float slo = ord2f(span[0]), shi = ord2f(span[1]);
 
     // ---- target segments ----
     const uint32_t nchunk = (Mt + 63) / 64;
@@ -545,7 +552,7 @@ hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint
     const size_t lds = (size_t)n2 * 8 + (size_t)(n2 / 64) * 8;
     hipError_t e = hipFuncSetAttribute((const void*)k_cull_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_cull_prepare, dim3(count), dim3(kCullBlock), lds, stream, views, pairs, first, pools);
+    hipLaunchKernelGGL(k_cull_prepare, dim3(count, 2), dim3(kCullBlock), lds, stream, views, pairs, first, pools);
     return hipGetLastError();
 }
 
