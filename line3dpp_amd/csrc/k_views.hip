@@ -320,170 +320,182 @@ __device__ __forceinline__ float sim_value(const d3 dira, float adp1, float adp2
 // Layout per global segment g: bits[boff[g] + i*W + w], i in [0, L]; row L is the presence mask P.
 
 
-// words per segment: (L+1) * ceil(L/64)
-__global__ void k_bits_len(uint32_t G, const uint32_t* __restrict__ off, uint32_t* __restrict__ len) {
+
+// The similarity decisions of the hypotheses of one 2D segment (any view) -> support bitset rows.
+// similarityForScoring(i, j) can only exceed 0.5 if |dp1_i - dp1_j| <= sqrt(0.72 * reg1_i) (first early-out of
+// sim_decide), so the hypotheses are rank-sorted by dp1 in LDS and hypothesis i evaluates only the contiguous
+// window of candidates inside that radius (found by binary search) instead of all L: O(L^2) cheap compares for
+// the sort + O(L * window) evaluations.  Everything the decision reads is staged in LDS IN SORTED ORDER (the
+// window walk reads consecutive positions: no dependent index load), directions as fp32 -- the angular test is
+// decided in fp32 when it is at least kDirSlack away from both thresholds and re-done in fp64 (directions
+// recomputed from the depths) otherwise, so the result is the fp64 one.
+//   WPL = 1: one wave per list, lists up to kStageCap (the common case; a 4-wave workgroup handles 4 lists)
+//   WPL = 4: one 4-wave workgroup per list for the long lists (compacted by k_bits_len): the same code with a
+//            4x LDS pool (staged up to 4*kStageCap, sort-only beyond that, all-pairs for the rest) and
+//            __syncthreads instead of wave barriers
+constexpr uint32_t kStageCap = 192;
+constexpr uint32_t kPoolFloats = 1632;                    // per-wave LDS pool: 8.5 floats per staged hypothesis
+constexpr float kDirSlack = 2e-6f;
+
+// words per segment: (L+1) * ceil(L/64); lists longer than kStageCap are appended to long_list
+__global__ void k_bits_len(uint32_t G, const uint32_t* __restrict__ off, uint32_t* __restrict__ len,
+                           uint32_t* __restrict__ long_list, uint32_t* __restrict__ n_long) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     const uint32_t L = off[g + 1] - off[g];
     len[g] = L ? (L + 1) * ((L + 63) / 64) : 0u;
+    if (L > kStageCap) long_list[atomicAdd(n_long, 1u)] = g;
 }
 
-// One wave per 2D segment (any view): the similarity decisions of the segment's hypotheses.
-// similarityForScoring(i, j) can only exceed 0.5 if |dp1_i - dp1_j| <= sqrt(0.72 * reg1_i) (first early-out of
-// sim_decide), so the hypotheses are rank-sorted by dp1 in LDS and hypothesis i evaluates only the contiguous
-// window of candidates inside that radius (found by binary search) instead of all L: O(L^2) cheap compares for
-// the sort + O(L * window) evaluations.
-//   L <= kStageCap: everything the decision reads is staged in LDS IN SORTED ORDER (the window walk reads
-//                   consecutive positions: no dependent index load), directions as fp32 -- the angular test is
-//                   decided in fp32 when it is at least kDirSlack away from both thresholds and re-done in fp64
-//                   (directions recomputed from the depths) otherwise, so the result is the fp64 one;
-//   L <= kSortCap:  only the sort lives in LDS (same pool), candidates are read from global memory;
-//   longer lists:   all-pairs loop.
-constexpr uint32_t kStageCap = 192;
-constexpr uint32_t kPoolFloats = 1632;                    // per-wave LDS pool: 8.5 floats per staged hypothesis
-constexpr uint32_t kSortCap = kPoolFloats * 2 / 7;        // 3.5 floats per hypothesis when only the sort is kept
-constexpr float kDirSlack = 2e-6f;
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_support_all(uint32_t G, const uint32_t* __restrict__ off,
-                                                     const uint32_t* __restrict__ boff,
-                                                     const DEntry* __restrict__ dents, uint64_t* __restrict__ bits,
-                                                     const ViewDev* __restrict__ views,
-                                                     const uint32_t* __restrict__ seg_base,
-                                                     const uint32_t* __restrict__ gseg_view, SimConst sc,
-                                                     uint32_t g0) {
-    __shared__ __attribute__((aligned(16))) float s_pool[4][kPoolFloats];
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t g = g0 + blockIdx.x * 4 + wave;
-    if (g >= G) return;
+template <int WPL>
+__device__ __forceinline__ void group_barrier() {
+    if (WPL == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int WPL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
+void k_support(uint32_t G, const uint32_t* __restrict__ off, const uint32_t* __restrict__ boff,
+               const DEntry* __restrict__ dents, uint64_t* __restrict__ bits, const ViewDev* __restrict__ views,
+               const uint32_t* __restrict__ gseg_view, SimConst sc, uint32_t g0,
+               const uint32_t* __restrict__ long_list) {
+    __shared__ __attribute__((aligned(16))) float s_pool[4 * kPoolFloats];
+    constexpr uint32_t GS = 64 * WPL;                                   // threads per list
+    constexpr uint32_t kStage = kStageCap * WPL;                        // staged capacity of the group's pool
+    constexpr uint32_t kSort = (kPoolFloats * WPL * 2 / 7) & ~1u;       // sort-only capacity (3.5 floats per entry)
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t t = WPL == 1 ? lane_id() : threadIdx.x;              // thread index within the group
+    uint32_t g;
+    if (WPL == 1) { g = g0 + blockIdx.x * 4 + wave; if (g >= G) return; }
+    else g = long_list[blockIdx.x];
     const uint32_t b = off[g], L = off[g + 1] - b;
     if (L == 0) return;
+    if (WPL == 1 && L > kStageCap) return;                              // long list: k_support<4>
     const uint32_t W = (L + 63) / 64;
     uint64_t* rows = bits + boff[g];
-    const uint32_t vi = gseg_view[g];
-    const ViewDev& v = views[vi];
+    const ViewDev& v = views[gseg_view[g]];
     const SegX sx = views[0].segx[g];   // global array (upload_views): views[0].segx is its base
-    if (L <= kSortCap) {
-        const bool staged = L <= kStageCap;
-        const uint32_t cap = staged ? kStageCap : kSortCap;
+    if (L <= kSort) {
+        const bool staged = L <= kStage;
+        const uint32_t cap = staged ? kStage : kSort;
+        float* pool = s_pool + (WPL == 1 ? wave * kPoolFloats : 0);
         // sort key of hypothesis i: order-preserving bits of dp1 in the high word, i in the low word -- one 64-bit
         // compare per pair gives the rank with the (dp1, index) tie-break
-        uint64_t* s_key = (uint64_t*)s_pool[wave];         // canonical order
+        uint64_t* s_key = (uint64_t*)pool;                 // canonical order
         float* s_sorted = (float*)(s_key + cap);           // dp1, sorted
         uint16_t* s_sidx = (uint16_t*)(s_sorted + cap);    // canonical index of a sorted position
         float* s_dp2 = (float*)(s_sidx + cap);             // staged only, sorted order
         uint32_t* s_tvf = (uint32_t*)(s_dp2 + cap);        // tgt_view | zero-length flag << 31
         float* s_dir = (float*)(s_tvf + cap);              // 3 floats per hypothesis
-        for (uint32_t m0 = 0; m0 < L; m0 += 64)
-            if (m0 + lane < L) {
-                const uint32_t u = __float_as_uint(dents[b + m0 + lane].dp1);
-                const uint32_t o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-                s_key[m0 + lane] = ((uint64_t)o << 32) | (m0 + lane);
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (uint32_t m0 = 0; m0 < L; m0 += 64) {
-            const uint32_t i = m0 + lane;
-            if (i < L) {
-                const uint64_t k = s_key[i];
-                uint32_t rank = 0;
-                for (uint32_t j = 0; j < L; ++j) rank += (s_key[j] < k) ? 1u : 0u;
-                const uint32_t ko = (uint32_t)(k >> 32);
-                s_sorted[rank] = __uint_as_float((ko & 0x80000000u) ? (ko & 0x7FFFFFFFu) : ~ko);
-                s_sidx[rank] = (uint16_t)i;
-                if (staged) {
-                    const DEntry e = dents[b + i];
-                    const d3 ed = entry_dir(v.C, sx, e.dp1, e.dp2);
-                    s_dp2[rank] = e.dp2;
-                    s_tvf[rank] = e.tgt_view | ((e.flags & kDZeroLen) ? 0x80000000u : 0u);
-                    s_dir[3 * rank] = (float)ed.x; s_dir[3 * rank + 1] = (float)ed.y; s_dir[3 * rank + 2] = (float)ed.z;
-                }
+        for (uint32_t i = t; i < L; i += GS) {
+            const uint32_t u = __float_as_uint(dents[b + i].dp1);
+            const uint32_t o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            s_key[i] = ((uint64_t)o << 32) | i;
+        }
+        group_barrier<WPL>();
+        for (uint32_t i = t; i < L; i += GS) {
+            const uint64_t k = s_key[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < L; ++j) rank += (s_key[j] < k) ? 1u : 0u;
+            const uint32_t ko = (uint32_t)(k >> 32);
+            s_sorted[rank] = __uint_as_float((ko & 0x80000000u) ? (ko & 0x7FFFFFFFu) : ~ko);
+            s_sidx[rank] = (uint16_t)i;
+            if (staged) {
+                const DEntry e = dents[b + i];
+                const d3 ed = entry_dir(v.C, sx, e.dp1, e.dp2);
+                s_dp2[rank] = e.dp2;
+                s_tvf[rank] = e.tgt_view | ((e.flags & kDZeroLen) ? 0x80000000u : 0u);
+                s_dir[3 * rank] = (float)ed.x; s_dir[3 * rank + 1] = (float)ed.y; s_dir[3 * rank + 2] = (float)ed.z;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (uint32_t m0 = 0; m0 < L; m0 += 64) {
-            const uint32_t i = m0 + lane;
-            if (i < L) {
-                const DEntry a = dents[b + i];
-                const d3 ad = entry_dir(v.C, sx, a.dp1, a.dp2);
-                const bool azero = (a.flags & kDZeroLen) != 0;
-                // window of candidates: |dp1_j - dp1_i| <= r  (r padded against float rounding)
-                float r = sqrtf(0.72f * a.reg1) * 1.0001f + 1e-30f;
-                uint32_t lo = 0, hi = L;
-                if (r < 1e30f) {   // also false for NaN: then the whole list is the window
-                    const float kl = a.dp1 - r, kh = a.dp1 + r;
-                    uint32_t x = 0, y = L;          // first position with key >= kl
-                    while (x < y) { const uint32_t m = (x + y) >> 1; if (s_sorted[m] < kl) x = m + 1; else y = m; }
-                    lo = x;
-                    y = L;                          // first position with key > kh
-                    while (x < y) { const uint32_t m = (x + y) >> 1; if (s_sorted[m] <= kh) x = m + 1; else y = m; }
-                    hi = x;
-                }
+        group_barrier<WPL>();
+        for (uint32_t i = t; i < L; i += GS) {
+            const DEntry a = dents[b + i];
+            const d3 ad = entry_dir(v.C, sx, a.dp1, a.dp2);
+            const bool azero = (a.flags & kDZeroLen) != 0;
+            // window of candidates: |dp1_j - dp1_i| <= r  (r padded against float rounding)
+            float r = sqrtf(0.72f * a.reg1) * 1.0001f + 1e-30f;
+            uint32_t lo = 0, hi = L;
+            if (r < 1e30f) {   // also false for NaN: then the whole list is the window
+                const float kl = a.dp1 - r, kh = a.dp1 + r;
+                uint32_t x = 0, y = L;          // first position with key >= kl
+                while (x < y) { const uint32_t m = (x + y) >> 1; if (s_sorted[m] < kl) x = m + 1; else y = m; }
+                lo = x;
+                y = L;                          // first position with key > kh
+                while (x < y) { const uint32_t m = (x + y) >> 1; if (s_sorted[m] <= kh) x = m + 1; else y = m; }
+                hi = x;
+            }
+            // the row is accumulated in registers (up to kRowRegs words) or OR-ed into the zeroed global row
+            constexpr uint32_t kRowRegs = (kStageCap + 63) / 64;
+            const bool in_regs = WPL == 1;
+            uint64_t rw[kRowRegs] = {};
+            if (!in_regs) for (uint32_t w = 0; w < W; ++w) rows[(size_t)i * W + w] = 0ull;
+            const float adx = (float)ad.x, ady = (float)ad.y, adz = (float)ad.z;
+            for (uint32_t p = lo; p < hi; ++p) {
+                bool ok;
+                uint32_t j;
                 if (staged) {
-                    // W <= 5 words: the row is accumulated in registers and written once
-                    uint64_t rw[(kStageCap + 63) / 64] = {};
-                    const float adx = (float)ad.x, ady = (float)ad.y, adz = (float)ad.z;
-                    for (uint32_t p = lo; p < hi; ++p) {
-                        const uint32_t tvf = s_tvf[p];
-                        if ((tvf & 0x7FFFFFFFu) == a.tgt_view || azero || (tvf >> 31)) continue;
-                        const float odp1 = s_sorted[p], odp2 = s_dp2[p];
-                        const float d1 = a.dp1 - odp1, d2 = a.dp2 - odp2;
-                        if (d1 * d1 > 0.72f * a.reg1 || d2 * d2 > 0.72f * a.reg2) continue;   // see sim_decide
-                        const float y1 = -d1 * d1 / a.reg1, y2 = -d2 * d2 / a.reg2;
-                        if (y1 == y1 && !(y1 > sc.y_thr)) continue;
-                        if (y2 == y2 && !(y2 > sc.y_thr)) continue;
-                        // angular part: fp32 dot product, exact fp64 redo when it is near a threshold
-                        const float xf = fmaxf(fminf(adx * s_dir[3 * p] + ady * s_dir[3 * p + 1] + adz * s_dir[3 * p + 2], 1.0f), -1.0f);
-                        bool ok;
-                        if (fabsf(xf - sc.x_hi) > kDirSlack && fabsf(xf - sc.x_lo) > kDirSlack) {
-                            ok = xf >= sc.x_hi || xf <= sc.x_lo;
-                        } else {
-                            const float dot_p = (float)dot(ad, entry_dir(v.C, sx, odp1, odp2));
-                            const float x = fmaxf(fminf(dot_p, 1.0f), -1.0f);
-                            ok = x >= sc.x_hi || x <= sc.x_lo;
-                        }
-                        if (ok) {
-                            const uint32_t j = s_sidx[p];
-#pragma unroll
-                            for (uint32_t w = 0; w < (kStageCap + 63) / 64; ++w) rw[w] |= (w == (j >> 6)) ? (1ull << (j & 63)) : 0ull;
-                        }
+                    const uint32_t tvf = s_tvf[p];
+                    if ((tvf & 0x7FFFFFFFu) == a.tgt_view || azero || (tvf >> 31)) continue;
+                    const float odp1 = s_sorted[p], odp2 = s_dp2[p];
+                    const float d1 = a.dp1 - odp1, d2 = a.dp2 - odp2;
+                    if (d1 * d1 > 0.72f * a.reg1 || d2 * d2 > 0.72f * a.reg2) continue;   // see sim_decide
+                    const float y1 = -d1 * d1 / a.reg1, y2 = -d2 * d2 / a.reg2;
+                    if (y1 == y1 && !(y1 > sc.y_thr)) continue;
+                    if (y2 == y2 && !(y2 > sc.y_thr)) continue;
+                    // angular part: fp32 dot product, exact fp64 redo when it is near a threshold
+                    const float xf = fmaxf(fminf(adx * s_dir[3 * p] + ady * s_dir[3 * p + 1] + adz * s_dir[3 * p + 2], 1.0f), -1.0f);
+                    if (fabsf(xf - sc.x_hi) > kDirSlack && fabsf(xf - sc.x_lo) > kDirSlack) {
+                        ok = xf >= sc.x_hi || xf <= sc.x_lo;
+                    } else {
+                        const float dot_p = (float)dot(ad, entry_dir(v.C, sx, odp1, odp2));
+                        const float x = fmaxf(fminf(dot_p, 1.0f), -1.0f);
+                        ok = x >= sc.x_hi || x <= sc.x_lo;
                     }
-#pragma unroll
-                    for (uint32_t w = 0; w < (kStageCap + 63) / 64; ++w) if (w < W) rows[(size_t)i * W + w] = rw[w];
-                    continue;
-                }
-                for (uint32_t w = 0; w < W; ++w) rows[(size_t)i * W + w] = 0ull;
-                for (uint32_t p = lo; p < hi; ++p) {
-                    const uint32_t j = s_sidx[p];
+                    j = s_sidx[p];
+                } else {
+                    j = s_sidx[p];
                     const DEntry& o = dents[b + j];
                     if (o.tgt_view == a.tgt_view) continue;
-                    if (sim_decide(ad, azero, a.dp1, a.dp2, a.reg1, a.reg2, entry_dir(v.C, sx, o.dp1, o.dp2),
-                                   (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc))
-                        rows[(size_t)i * W + (j >> 6)] |= 1ull << (j & 63);
+                    ok = sim_decide(ad, azero, a.dp1, a.dp2, a.reg1, a.reg2, entry_dir(v.C, sx, o.dp1, o.dp2),
+                                    (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc);
                 }
+                if (ok) {
+                    if (in_regs) {
+#pragma unroll
+                        for (uint32_t w = 0; w < kRowRegs; ++w) rw[w] |= (w == (j >> 6)) ? (1ull << (j & 63)) : 0ull;
+                    } else {
+                        rows[(size_t)i * W + (j >> 6)] |= 1ull << (j & 63);
+                    }
+                }
+            }
+            if (in_regs) {
+#pragma unroll
+                for (uint32_t w = 0; w < kRowRegs; ++w) if (w < W) rows[(size_t)i * W + w] = rw[w];
             }
         }
         return;
     }
-    // ---- all-pairs loop for very long lists ----
-    for (uint32_t m0 = 0; m0 < L; m0 += 64) {
-        const uint32_t i = m0 + lane;
-        if (i < L) {
-            const DEntry a = dents[b + i];
-            const d3 ad = entry_dir(v.C, sx, a.dp1, a.dp2);
-            for (uint32_t w = 0; w < W; ++w) {
-                uint64_t word = 0;
-                const uint32_t jn = min(64u, L - w * 64);
-                for (uint32_t jj = 0; jj < jn; ++jj) {
-                    const DEntry& o = dents[b + w * 64 + jj];
-                    if (o.tgt_view == a.tgt_view) continue;
-                    word |= (uint64_t)sim_decide(ad, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
-                                                 entry_dir(v.C, sx, o.dp1, o.dp2), (o.flags & kDZeroLen) != 0, o.dp1,
-                                                 o.dp2, sc) << jj;
-                }
-                rows[(size_t)i * W + w] = word;
+    // ---- all-pairs loop for lists beyond the sort capacity ----
+    for (uint32_t i = t; i < L; i += GS) {
+        const DEntry a = dents[b + i];
+        const d3 ad = entry_dir(v.C, sx, a.dp1, a.dp2);
+        for (uint32_t w = 0; w < W; ++w) {
+            uint64_t word = 0;
+            const uint32_t jn = min(64u, L - w * 64);
+            for (uint32_t jj = 0; jj < jn; ++jj) {
+                const DEntry& o = dents[b + w * 64 + jj];
+                if (o.tgt_view == a.tgt_view) continue;
+                word |= (uint64_t)sim_decide(ad, (a.flags & kDZeroLen) != 0, a.dp1, a.dp2, a.reg1, a.reg2,
+                                             entry_dir(v.C, sx, o.dp1, o.dp2), (o.flags & kDZeroLen) != 0, o.dp1,
+                                             o.dp2, sc) << jj;
             }
+            rows[(size_t)i * W + w] = word;
         }
     }
 }
@@ -896,17 +908,28 @@ hipError_t launch_build_lists_all(uint32_t G, const ViewDev* views, const PairDe
                        vout_off, vout_pairs, off, inv_off, refs, slots, dents, eref, uniform_K);
     return hipGetLastError();
 }
-hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, hipStream_t st) {
+hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, uint32_t* long_list, uint32_t* n_long,
+                           hipStream_t st) {
     if (!G) return hipSuccess;
-    hipLaunchKernelGGL(k_bits_len, dim3((G + 255) / 256), dim3(256), 0, st, G, off, len);
+    hipLaunchKernelGGL(k_bits_len, dim3((G + 255) / 256), dim3(256), 0, st, G, off, len, long_list, n_long);
     return hipGetLastError();
 }
 hipError_t launch_support_all(uint32_t g0, uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry* dents,
                               uint64_t* bits, const ViewDev* views, const uint32_t* seg_base,
                               const uint32_t* gseg_view, SimConst sc, hipStream_t st) {
+    (void)seg_base;
     if (G <= g0) return hipSuccess;
-    hipLaunchKernelGGL(k_support_all, dim3((G - g0 + 3) / 4), dim3(256), 0, st, G, off, boff, dents, bits, views,
-                       seg_base, gseg_view, sc, g0);
+    hipLaunchKernelGGL((k_support<1>), dim3((G - g0 + 3) / 4), dim3(256), 0, st, G, off, boff, dents, bits, views,
+                       gseg_view, sc, g0, (const uint32_t*)nullptr);
+    return hipGetLastError();
+}
+// the lists longer than one wave's staging capacity (long_list from k_bits_len), one workgroup each
+hipError_t launch_support_long(uint32_t n_long, const uint32_t* long_list, const uint32_t* off, const uint32_t* boff,
+                               const DEntry* dents, uint64_t* bits, const ViewDev* views, const uint32_t* gseg_view,
+                               SimConst sc, hipStream_t st) {
+    if (!n_long) return hipSuccess;
+    hipLaunchKernelGGL((k_support<4>), dim3(n_long), dim3(256), 0, st, 0u, off, boff, dents, bits, views, gseg_view,
+                       sc, 0u, long_list);
     return hipGetLastError();
 }
 hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff,

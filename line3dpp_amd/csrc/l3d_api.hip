@@ -41,7 +41,11 @@ hipError_t launch_build_lists_all(uint32_t G, const ViewDev*, const PairDesc*, c
                                   const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
                                   const uint32_t* off, const uint32_t* inv_off, const InvRef*, const Slot*, DEntry*,
                                   uint32_t* eref, uint32_t uniform_K, hipStream_t);
-hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, hipStream_t);
+hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, uint32_t* long_list, uint32_t* n_long,
+                           hipStream_t);
+hipError_t launch_support_long(uint32_t n_long, const uint32_t* long_list, const uint32_t* off, const uint32_t* boff,
+                               const DEntry*, uint64_t* bits, const ViewDev*, const uint32_t* gseg_view, SimConst,
+                               hipStream_t);
 hipError_t launch_support_all(uint32_t g0, uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry*, uint64_t* bits,
                               const ViewDev*, const uint32_t* seg_base, const uint32_t* gseg_view, SimConst, hipStream_t);
 hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff,
@@ -140,7 +144,7 @@ struct l3d_ctx {
     DevBuf<uint64_t> d_bits;
     DevBuf<uint32_t> d_eref;
     DevBuf<uint8_t> d_positive;
-    DevBuf<uint32_t> d_bits_len, d_boff;
+    DevBuf<uint32_t> d_bits_len, d_boff, d_long_list;
     DevBuf<uint32_t> d_cnt_inv, d_inv_off, d_vout_pairs, d_vout_off, d_inv_pos;
     DevBuf<unsigned long long> d_cnt_pack;
     std::vector<uint32_t> vout_off;
@@ -413,7 +417,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_seg_base.release(); c->d_gseg_view.release(); c->d_cnt.release(); c->d_off.release();
     c->d_scan_tmp.release(); c->d_scal.release(); c->d_max_score.release(); c->d_surv_cnt.release();
     c->d_has_best.release(); c->d_best_pos.release(); c->d_surv_off.release(); c->d_hyp_off.release();
-    c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_bits.release(); c->d_eref.release(); c->d_positive.release(); c->d_bits_len.release(); c->d_boff.release(); c->d_cnt_inv.release();
+    c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_bits.release(); c->d_eref.release(); c->d_positive.release(); c->d_bits_len.release(); c->d_boff.release(); c->d_cnt_inv.release(); c->d_long_list.release();
     c->d_cnt_pack.release(); c->d_inv_pos.release(); c->d_gsegx.release();
     c->d_coll_cnt.release(); c->d_coll_off.release(); c->d_coll_idx.release(); c->d_item_cnt.release();
     c->d_item_off.release(); c->d_item_seg.release(); c->d_item_sim.release();
@@ -756,10 +760,11 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(launch_scan(c->d_cnt.p, G, c->d_off.p, c->d_scan_tmp.p, c->d_scal.p + 0, st));
     L3D_HIP_CHECK(launch_scan(c->d_cnt_inv.p, G, c->d_inv_off.p, c->d_scan_tmp.p, c->d_scal.p + 5, st));
     L3D_HIP_CHECK(c->d_bits_len.reserve(G + 1)); L3D_HIP_CHECK(c->d_boff.reserve(G + 1));
-    L3D_HIP_CHECK(launch_bits_len(G, c->d_off.p, c->d_bits_len.p, st));
+    L3D_HIP_CHECK(c->d_long_list.reserve(G + 1));
+    L3D_HIP_CHECK(launch_bits_len(G, c->d_off.p, c->d_bits_len.p, c->d_long_list.p, c->d_scal.p + 7, st));
     L3D_HIP_CHECK(launch_scan(c->d_bits_len.p, G, c->d_boff.p, c->d_scan_tmp.p, c->d_scal.p + 6, st));
-    uint32_t tot[7] = {0, 0, 0, 0, 0, 0, 0};
-    L3D_HIP_CHECK(hipMemcpyAsync(tot, c->d_scal.p, 7 * 4, hipMemcpyDeviceToHost, st));
+    uint32_t tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    L3D_HIP_CHECK(hipMemcpyAsync(tot, c->d_scal.p, 8 * 4, hipMemcpyDeviceToHost, st));
     g_trace.mark("pre-pass enqueued, waiting for sizes");
     L3D_HIP_CHECK(hipStreamSynchronize(st));   // first point at which the host waits for the GPU in matchImages
     g_trace.mark("sizes known");
@@ -777,6 +782,9 @@ int l3d_match_finish(l3d_ctx* c) {
                                          c->d_vout_off.p, c->d_vout_pairs.p, c->d_off.p, c->d_inv_off.p, c->d_refs.p,
                                          c->d_slots.p, c->d_dents.p, c->d_eref.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, st));
     const SimConst simc = sim_thresholds(c->two_sigA_sqr);
+    // lists too long for one wave's LDS staging: one workgroup each, before the pipeline (chain independent)
+    L3D_HIP_CHECK(launch_support_long(tot[7], c->d_long_list.p, c->d_off.p, c->d_boff.p, c->d_dents.p, c->d_bits.p,
+                                      c->d_views.p, c->d_gseg_view.p, simc, st));
     // Three-stage software pipeline over chunks of views on three streams:
     //   A (the context's stream)  support bitsets of chunk k          (chain independent, heavy)
     //   B                         THE CHAIN: one tiny bit-propagation launch per view, ascending camID; view v only
