@@ -891,6 +891,20 @@ hipError_t launch_orient_all(const ViewDev* views, const PairDesc* pairs, uint32
     hipLaunchKernelGGL(k_unpack_counts, dim3((G + 255) / 256), dim3(256), 0, st, G, cnt_pack, cnt_all, cnt_inv);
     return hipGetLastError();
 }
+hipError_t launch_orient_pairs(const ViewDev* views, const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots,
+                               const uint32_t* seg_base, Slot* slots, unsigned long long* cnt_pack, uint32_t* inv_pos,
+                               double thr_lo, double thr_hi, hipStream_t st) {
+    if (!n_pairs || !max_slots) return hipSuccess;
+    hipLaunchKernelGGL(k_orient_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, views,
+                       pairs, seg_base, slots, cnt_pack, inv_pos, OrientThr{thr_lo, thr_hi});
+    return hipGetLastError();
+}
+hipError_t launch_unpack_counts(uint32_t G, const unsigned long long* cnt_pack, uint32_t* cnt_all, uint32_t* cnt_inv,
+                                hipStream_t st) {
+    if (!G) return hipSuccess;
+    hipLaunchKernelGGL(k_unpack_counts, dim3((G + 255) / 256), dim3(256), 0, st, G, cnt_pack, cnt_all, cnt_inv);
+    return hipGetLastError();
+}
 hipError_t launch_inv_fill(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
                            const Slot* slots, const uint32_t* inv_off, const uint32_t* inv_pos, InvRef* refs,
                            hipStream_t st) {

@@ -34,6 +34,11 @@ hipError_t launch_orient_all(const ViewDev*, const PairDesc*, uint32_t n_pairs, 
                              const uint32_t* seg_base, Slot* slots, uint32_t G, unsigned long long* cnt_pack,
                              uint32_t* inv_pos, uint32_t* cnt_all, uint32_t* cnt_inv, double thr_lo, double thr_hi,
                              hipStream_t);
+hipError_t launch_orient_pairs(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
+                               const uint32_t* seg_base, Slot* slots, unsigned long long* cnt_pack, uint32_t* inv_pos,
+                               double thr_lo, double thr_hi, hipStream_t);
+hipError_t launch_unpack_counts(uint32_t G, const unsigned long long* cnt_pack, uint32_t* cnt_all, uint32_t* cnt_inv,
+                                hipStream_t);
 hipError_t launch_inv_fill(const PairDesc*, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
                            const Slot* slots, const uint32_t* inv_off, const uint32_t* inv_pos, InvRef* refs,
                            hipStream_t);
@@ -120,8 +125,13 @@ struct l3d_ctx {
     uint32_t aff_n_edges = 0, aff_n_rows = 0;
     bool aff_host_valid = true;
     PinnedBuf<uint32_t> h_cnt;
-    hipStream_t aux[2] = {nullptr, nullptr};        // phase-B pipeline streams (chain, scores)
+    hipStream_t aux[2] = {nullptr, nullptr};        // aux[0] high priority (phase-A first half, the chain), aux[1]
     std::vector<hipEvent_t> pipe_ev;
+    // phase A split over two streams (single-call path): pairs [0, split_pair) run on aux[0] with priority, the rest
+    // on aux[1]; the orientation pass of the first half then overlaps the tail of the second (l3d_match_finish)
+    bool split_active = false;
+    uint32_t split_pair = 0;
+    hipEvent_t sev[5] = {};                         // prepared, half A done, half B done, memsets done, orient A done
     DevBuf<SegX> d_gsegx;                           // SegX of every segment, global segment order
     float collinearity_t = -1.0f;                   // collinearity_t_ (reconstruct3Dlines); > 0: collinear links
     DevBuf<uint32_t> d_coll_cnt, d_coll_off, d_coll_idx, d_item_cnt, d_item_off, d_item_seg;
@@ -428,6 +438,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_touch_rank.release(); c->d_edges.release(); c->d_l2g.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->pipe_ev) (void)hipEventDestroy(e);
+    for (auto& e : c->sev) if (e) (void)hipEventDestroy(e);
     for (auto& s2 : c->aux) if (s2) (void)hipStreamDestroy(s2);
     delete c;
 }
@@ -592,6 +603,17 @@ int l3d_get_pairs(l3d_ctx* c, uint32_t* s, uint32_t* t, uint64_t* off) {
     return L3D_OK;
 }
 
+static int ensure_aux(l3d_ctx* c) {
+    if (!c->aux[0]) {   // highest priority: its kernels must not queue behind thousands of other workgroups
+        int lo_p = 0, hi_p = 0;
+        L3D_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+        L3D_HIP_CHECK(hipStreamCreateWithPriority(&c->aux[0], hipStreamNonBlocking, hi_p));
+    }
+    if (!c->aux[1]) L3D_HIP_CHECK(hipStreamCreateWithFlags(&c->aux[1], hipStreamNonBlocking));
+    for (auto& e : c->sev) if (!e) L3D_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return L3D_OK;
+}
+
 // reads the phase-A events of the last run_match_kernel (the stream must have passed ev[5])
 static void collect_match_timing(l3d_ctx* c) {
     if (!c->timing_pending) return;
@@ -602,7 +624,7 @@ static void collect_match_timing(l3d_ctx* c) {
 }
 
 // enqueues (no host synchronisation) the cull set-up and the pair kernel for pairs [first, first+count)
-static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count) {
+static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count, bool allow_split = false) {
     size_t n_work = 0;
     uint32_t maxK = 0, maxM = 0;
     for (uint32_t p = first; p < first + count; ++p) n_work += (c->pairs[p].Ms + kMatchRows - 1) / kMatchRows;
@@ -625,9 +647,35 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     if (mode != 0 || c->brute || !maxM) pools.cull = nullptr;
     else L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
     L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
-    L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work,
-                                     maxK, c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, c->stream));
-    L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));
+    c->split_active = false;
+    if (allow_split && mode == 0 && count >= 2 && std::getenv("L3D_NO_SPLIT") == nullptr) {
+        // two halves by cost on two streams; ev[5] / ev[3] are recorded by l3d_match_finish once both are done
+        uint64_t total = 0, acc = 0;
+        for (uint32_t p = first; p < first + count; ++p) total += (uint64_t)c->pairs[p].Ms * c->pairs[p].Mt;
+        uint32_t ps = first; size_t n_work1 = 0;
+        while (ps < first + count - 1 && 2 * acc < total) {
+            acc += (uint64_t)c->pairs[ps].Ms * c->pairs[ps].Mt;
+            n_work1 += (c->pairs[ps].Ms + kMatchRows - 1) / kMatchRows;
+            ++ps;
+        }
+        const int rc = ensure_aux(c);
+        if (rc) return rc;
+        L3D_HIP_CHECK(hipEventRecord(c->sev[0], c->stream));
+        L3D_HIP_CHECK(hipStreamWaitEvent(c->aux[0], c->sev[0], 0));
+        L3D_HIP_CHECK(hipStreamWaitEvent(c->aux[1], c->sev[0], 0));
+        L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work1,
+                                         maxK, c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, c->aux[0]));
+        L3D_HIP_CHECK(hipEventRecord(c->sev[1], c->aux[0]));
+        L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p + n_work1,
+                                         (uint32_t)(n_work - n_work1), maxK, c->d_slots.p, c->d_row_counts.p,
+                                         c->epipolar_overlap, pools, c->aux[1]));
+        L3D_HIP_CHECK(hipEventRecord(c->sev[2], c->aux[1]));
+        c->split_active = true; c->split_pair = ps;
+    } else {
+        L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work,
+                                         maxK, c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, c->stream));
+        L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));
+    }
     if (pools.cull)
         for (uint32_t p = first; p < first + count; ++p) c->tm.culled_pairs += c->cull[p].enabled;
     c->timing_pending = true; c->pending_launches += 1;
@@ -650,7 +698,7 @@ static int match_pairs_impl(l3d_ctx* c, uint32_t first, uint32_t count, bool syn
     L3D_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
     int rc = L3D_OK;
     if (c->kNN > 0) {
-        rc = run_match_kernel(c, 0, first, count);
+        rc = run_match_kernel(c, 0, first, count, /*allow_split=*/!sync && first == 0 && count == c->pairs.size());
     } else {
         // kNN <= 0: keep every accepted match (line3D.cc:987-992): count, size the rows, fill
         if (first != 0 || count != c->pairs.size())
@@ -678,7 +726,7 @@ static int match_pairs_impl(l3d_ctx* c, uint32_t first, uint32_t count, bool syn
         rc = run_match_kernel(c, 2, first, count);
     }
     if (rc) return rc;
-    L3D_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    if (!c->split_active) L3D_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
     if (sync) {
         L3D_HIP_CHECK(hipEventSynchronize(c->ev[3]));
         collect_match_timing(c);
@@ -718,7 +766,7 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_best_pos.reserve(G + 1)); L3D_HIP_CHECK(c->d_surv_off.reserve(G + 1));
     L3D_HIP_CHECK(c->d_hyp_off.reserve(G + 1)); L3D_HIP_CHECK(c->d_hyp_of_seg.reserve(G + 1));
     L3D_HIP_CHECK(c->d_medians.reserve(V + 1));
-    L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
+    if (!c->split_active) L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));   // (split: recorded once phase A is done)
     L3D_HIP_CHECK(c->h_small.reserve(V + 1));
     g_trace.mark("finish: reserves done");
     std::memcpy(c->h_small.p, c->seg_base.data(), ((size_t)V + 1) * 4);
@@ -754,9 +802,30 @@ int l3d_match_finish(l3d_ctx* c) {
     L3D_HIP_CHECK(hipMemsetAsync(c->d_scal.p, 0, 16 * 4, st));
     g_trace.mark("finish: memsets enqueued");
     // ---- pre-pass: orientation flags, list offsets, transposed index of potential inverse matches ----
-    L3D_HIP_CHECK(launch_orient_all(c->d_views.p, c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, G,
-                                    c->d_cnt_pack.p, c->d_inv_pos.p, c->d_cnt.p, c->d_cnt_inv.p, c->orient_lo,
-                                    c->orient_hi, st));
+    if (c->split_active) {
+        // phase A still runs on the two auxiliary streams: the first half's orientation pass follows its match
+        // kernel on the priority stream and overlaps the tail of the second half
+        const uint32_t ps = c->split_pair;
+        L3D_HIP_CHECK(hipEventRecord(c->sev[3], st));                       // counters zeroed
+        L3D_HIP_CHECK(hipStreamWaitEvent(c->aux[0], c->sev[3], 0));
+        L3D_HIP_CHECK(launch_orient_pairs(c->d_views.p, c->d_pairs.p, ps, max_slots, c->d_seg_base.p, c->d_slots.p,
+                                          c->d_cnt_pack.p, c->d_inv_pos.p, c->orient_lo, c->orient_hi, c->aux[0]));
+        L3D_HIP_CHECK(hipEventRecord(c->sev[4], c->aux[0]));
+        L3D_HIP_CHECK(hipStreamWaitEvent(st, c->sev[1], 0));
+        L3D_HIP_CHECK(hipStreamWaitEvent(st, c->sev[2], 0));
+        L3D_HIP_CHECK(hipEventRecord(c->ev[5], st));                        // both match kernels done
+        L3D_HIP_CHECK(hipEventRecord(c->ev[3], st));
+        L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
+        L3D_HIP_CHECK(launch_orient_pairs(c->d_views.p, c->d_pairs.p + ps, P - ps, max_slots, c->d_seg_base.p,
+                                          c->d_slots.p, c->d_cnt_pack.p, c->d_inv_pos.p, c->orient_lo, c->orient_hi, st));
+        L3D_HIP_CHECK(hipStreamWaitEvent(st, c->sev[4], 0));
+        L3D_HIP_CHECK(launch_unpack_counts(G, c->d_cnt_pack.p, c->d_cnt.p, c->d_cnt_inv.p, st));
+        c->split_active = false;
+    } else {
+        L3D_HIP_CHECK(launch_orient_all(c->d_views.p, c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, G,
+                                        c->d_cnt_pack.p, c->d_inv_pos.p, c->d_cnt.p, c->d_cnt_inv.p, c->orient_lo,
+                                        c->orient_hi, st));
+    }
     L3D_HIP_CHECK(launch_scan(c->d_cnt.p, G, c->d_off.p, c->d_scan_tmp.p, c->d_scal.p + 0, st));
     L3D_HIP_CHECK(launch_scan(c->d_cnt_inv.p, G, c->d_inv_off.p, c->d_scan_tmp.p, c->d_scal.p + 5, st));
     L3D_HIP_CHECK(c->d_bits_len.reserve(G + 1)); L3D_HIP_CHECK(c->d_boff.reserve(G + 1));
@@ -800,12 +869,7 @@ int l3d_match_finish(l3d_ctx* c) {
             L3D_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             c->pipe_ev.push_back(e);
         }
-        if (!c->aux[0]) {   // the chain stream gets the highest priority: its tiny kernels must not queue behind
-            int lo_p = 0, hi_p = 0;   // thousands of support/score workgroups
-            L3D_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-            L3D_HIP_CHECK(hipStreamCreateWithPriority(&c->aux[0], hipStreamNonBlocking, hi_p));
-        }
-        if (!c->aux[1]) L3D_HIP_CHECK(hipStreamCreateWithFlags(&c->aux[1], hipStreamNonBlocking));
+        { const int rc2 = ensure_aux(c); if (rc2) return rc2; }
         hipStream_t sB = c->aux[0], sC = c->aux[1];
         hipEvent_t ev_start = c->pipe_ev[2 * n_chunks], ev_done = c->pipe_ev[2 * n_chunks + 1];
         L3D_HIP_CHECK(hipEventRecord(ev_start, st));
