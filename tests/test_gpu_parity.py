@@ -570,3 +570,27 @@ def test_collinearity_links_and_lines():
     # switching it off again restores the plain matrix
     assert g.reconstruct3Dlines(3, False, -1.0)
     assert len(g.affinity()[0]) == len(o2.affinity()[0])
+
+
+@pytest.mark.parametrize("n_views,n_segs,nn,kNN,epi,seed,rf,min_avg", [
+    (18, 300, 16, 30, 0.1, 71, 0.5, 50),       # ~200 lists beyond one wave's staging (192), longest ~360
+    (12, 1100, 11, 80, 0.05, 73, 0.9, 200),    # thousands of long lists, some beyond 768 (sort-only path)
+])
+def test_long_hypothesis_lists_parity(n_views, n_segs, nn, kNN, epi, seed, rf, min_avg):
+    """Many neighbours / large kNN make per-segment hypothesis lists longer than one wave's LDS staging (192):
+    the workgroup-per-list support kernel (staged up to 768, sort-only beyond) against the oracle, full pipeline."""
+    sc = make_scene(n_views, n_segs, n_neighbors=nn, seed=seed, real_fraction=rf)
+    g = _gpu(sc)
+    assert g.matchImages(kNN=kNN, epipolar_overlap=epi) and g.computeAffinity()
+    tm = g.timings()
+    assert tm["list_entries"] / (n_views * n_segs) > min_avg
+    o = _oracle(sc, threads=16)
+    o.match_images(kNN=kNN, epi_overlap=epi); o.compute_affinity()
+    worst = 0.0
+    for v in sc.views:
+        r = H.compare_matches(g.matches(v.cam)[0], o.matches(v.cam)[0])
+        assert not r["missing"] and not r["extra"], (v.cam, r["missing"][:3], r["extra"][:3])
+        worst = max(worst, r["max_rel"])
+    assert worst < H.REL_TOL
+    ge, gl, _ = g.affinity(); oe, ol = o.affinity()
+    assert len(ge) == len(oe) and np.array_equal(ge["i"], oe["i"]) and np.array_equal(ge["j"], oe["j"])
