@@ -7,8 +7,10 @@
 //   workgroup  = (directed pair, 64 source segments in epipolar-band order), one wave64
 //   lane       = one source segment; its two epipolar lines live in VGPRs (fp32, unit normal,
 //                image-centre origin)
-//   target view streams through LDS tiles of 16-byte SegF records; every lane reads the same
-//                record (LDS broadcast, conflict free)
+//   k_cull_prepare orders rows and targets of the pair by epipolar band (tau); the wave visits only the
+//                64-target chunks, and inside them only the targets, whose band meets its rows' bands
+//                (exact culling); lane l loads record l of a visited chunk and the wave walks
+//                the chunk by broadcasting one 16-byte SegF record at a time through SGPRs (v_readlane)
 //   fp32 pre-filter (conservative) -> __ballot -> popcount-prefix compaction of
 //                the few survivors into a per-wave LDS ring
 //   ring holds >= 64 candidates -> the wave drains 64 of them, one per lane, through the EXACT

@@ -11,20 +11,20 @@
 //                       hypothesis counts
 //     scans + k_inv_fill  CSR offsets of every 2D segment's hypothesis list and a compact transposed index
 //                       (16-byte refs) of the slots that point at it as potential inverse matches
-//   chain (one launch per view, ascending camID)
+//   lists (all views at once, chain independent)
 //     k_build_lists_all every 2D segment's list of potential hypotheses in canonical (= reference
 //                       single-thread) order -- inverse refs rank-sorted, fresh rows by ballot prefix, no
-//                       atomics -- with the unprojected 3D direction and the spatial regularisers scoring
-//                       needs (scoringCPU :1233-1248)
-//     k_support_all     one wave per 2D segment: all L^2 similarityForScoring decisions -> support bitsets
+//                       atomics -- with the spatial regularisers scoring needs (scoringCPU :1233-1248); the
+//                       unprojected 3D direction is recomputed where needed (32-byte entries)
+//     k_support<WPL>    one wave (long lists: one workgroup) per 2D segment: the similarityForScoring decisions
+//                       inside each hypothesis' depth window -> support bitsets
 //   chain (one launch per view, ascending camID)
 //     k_presence_view   one wave per 2D segment: which inverse hypotheses exist, which fresh ones are
 //                       supported -- pure bit operations on the support bitsets
-//   scores (all views at once)
+//   scores (per chunk of views, pipelined with the chain)
 //     k_score_all       O(#supporters) similarityForScoring (:1417-1446) with the
-//                       reference's per-camera replace/subtract accumulation (:1255-1274); an inverse
-//                       hypothesis takes part only if its source view's kernel (an earlier launch on the
-//                       same stream) wrote score3D > 0 into the shared slot
+//                       reference's per-camera replace/subtract accumulation (:1255-1274) over the hypotheses
+//                       the chain marked present
 //   post-pass (all views at once)
 //     k_filter_all / scans / k_filter_write_all / k_median_all
 //                       filterMatches (:1586-1669): 10 % of the view's best score, first strict maximum,
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_build_lists_all(uint32_t G, const ViewD
 // similarityForScoring (line3D.cc:1417-1446) for hypotheses a (the scored one) and b of the same 2D
 // segment.  Decisions are taken on the float quantities the reference compares; acos/exp are
 // evaluated in double and rounded to float (glibc's expf/acos differ from that by < 1 float ulp).
-// Decision form (k_support_all): "similarityForScoring > L3D_DEF_MIN_SIMILARITY_3D" without transcendentals.
+// Decision form (k_support): "similarityForScoring > L3D_DEF_MIN_SIMILARITY_3D" without transcendentals.
 // sim = fmin(sim_a, fmin(e1, e2)) > 0.5 <=> every non-NaN component is > 0.5 (fmin skips NaNs; all NaN -> false).
 // expf and acos are monotone, so each component test is a comparison of its float argument with a threshold
 // the host found by bisection with the libm the reference itself would use (sim_thresholds, l3d_api.hip):
