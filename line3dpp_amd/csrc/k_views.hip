@@ -414,11 +414,65 @@ void k_support(uint32_t G, const uint32_t* __restrict__ off, const uint32_t* __r
             }
         }
         group_barrier<WPL>();
+        constexpr uint32_t kRowRegs = (kStageCap + 63) / 64;
+        if (staged) {
+            // each thread takes a SORTED position p0: everything about its hypothesis except the two regularisers is
+            // already in LDS, and its candidates are its neighbours in the sorted order -- walk outwards from p0 in
+            // both directions while |dp1 - dp1_p0| <= r (no binary search, no second pass over the entries)
+            for (uint32_t p0 = t; p0 < L; p0 += GS) {
+                const uint32_t i = s_sidx[p0];
+                const float a_reg1 = dents[b + i].reg1, a_reg2 = dents[b + i].reg2;
+                const float a_dp1 = s_sorted[p0], a_dp2 = s_dp2[p0];
+                const uint32_t a_tvf = s_tvf[p0];
+                const float adx = s_dir[3 * p0], ady = s_dir[3 * p0 + 1], adz = s_dir[3 * p0 + 2];
+                float r = sqrtf(0.72f * a_reg1) * 1.0001f + 1e-30f;   // padded against float rounding
+                if (!(r < 1e30f)) r = __builtin_inff();               // NaN / huge: the whole list is the window
+                const float kl = a_dp1 - r, kh = a_dp1 + r;
+                uint64_t rw[kRowRegs] = {};
+                const bool in_regs = WPL == 1;
+                if (!in_regs) for (uint32_t w = 0; w < W; ++w) rows[(size_t)i * W + w] = 0ull;
+                auto visit = [&](uint32_t p) {
+                    const uint32_t tvf = s_tvf[p];
+                    if (((tvf ^ a_tvf) & 0x7FFFFFFFu) == 0 || ((tvf | a_tvf) >> 31)) return;   // same camera / zero length
+                    const float odp1 = s_sorted[p], odp2 = s_dp2[p];
+                    const float d1 = a_dp1 - odp1, d2 = a_dp2 - odp2;
+                    if (d1 * d1 > 0.72f * a_reg1 || d2 * d2 > 0.72f * a_reg2) return;   // see sim_decide
+                    const float y1 = -d1 * d1 / a_reg1, y2 = -d2 * d2 / a_reg2;
+                    if (y1 == y1 && !(y1 > sc.y_thr)) return;
+                    if (y2 == y2 && !(y2 > sc.y_thr)) return;
+                    // angular part: fp32 dot product, exact fp64 redo when it is near a threshold
+                    const float xf = fmaxf(fminf(adx * s_dir[3 * p] + ady * s_dir[3 * p + 1] + adz * s_dir[3 * p + 2], 1.0f), -1.0f);
+                    bool ok;
+                    if (fabsf(xf - sc.x_hi) > kDirSlack && fabsf(xf - sc.x_lo) > kDirSlack) {
+                        ok = xf >= sc.x_hi || xf <= sc.x_lo;
+                    } else {
+                        const float dot_p = (float)dot(entry_dir(v.C, sx, a_dp1, a_dp2), entry_dir(v.C, sx, odp1, odp2));
+                        const float x = fmaxf(fminf(dot_p, 1.0f), -1.0f);
+                        ok = x >= sc.x_hi || x <= sc.x_lo;
+                    }
+                    if (!ok) return;
+                    const uint32_t j = s_sidx[p];
+                    if (in_regs) {
+#pragma unroll
+                        for (uint32_t w = 0; w < kRowRegs; ++w) rw[w] |= (w == (j >> 6)) ? (1ull << (j & 63)) : 0ull;
+                    } else {
+                        rows[(size_t)i * W + (j >> 6)] |= 1ull << (j & 63);
+                    }
+                };
+                for (uint32_t p = p0; p-- > 0;) { if (!(s_sorted[p] >= kl)) break; visit(p); }
+                for (uint32_t p = p0 + 1; p < L; ++p) { if (!(s_sorted[p] <= kh)) break; visit(p); }
+                if (in_regs) {
+#pragma unroll
+                    for (uint32_t w = 0; w < kRowRegs; ++w) if (w < W) rows[(size_t)i * W + w] = rw[w];
+                }
+            }
+            return;
+        }
+        // sort-only lists: candidates are read from global memory
         for (uint32_t i = t; i < L; i += GS) {
             const DEntry a = dents[b + i];
             const d3 ad = entry_dir(v.C, sx, a.dp1, a.dp2);
             const bool azero = (a.flags & kDZeroLen) != 0;
-            // window of candidates: |dp1_j - dp1_i| <= r  (r padded against float rounding)
             float r = sqrtf(0.72f * a.reg1) * 1.0001f + 1e-30f;
             uint32_t lo = 0, hi = L;
             if (r < 1e30f) {   // also false for NaN: then the whole list is the window
@@ -430,53 +484,14 @@ void k_support(uint32_t G, const uint32_t* __restrict__ off, const uint32_t* __r
                 while (x < y) { const uint32_t m = (x + y) >> 1; if (s_sorted[m] <= kh) x = m + 1; else y = m; }
                 hi = x;
             }
-            // the row is accumulated in registers (up to kRowRegs words) or OR-ed into the zeroed global row
-            constexpr uint32_t kRowRegs = (kStageCap + 63) / 64;
-            const bool in_regs = WPL == 1;
-            uint64_t rw[kRowRegs] = {};
-            if (!in_regs) for (uint32_t w = 0; w < W; ++w) rows[(size_t)i * W + w] = 0ull;
-            const float adx = (float)ad.x, ady = (float)ad.y, adz = (float)ad.z;
+            for (uint32_t w = 0; w < W; ++w) rows[(size_t)i * W + w] = 0ull;
             for (uint32_t p = lo; p < hi; ++p) {
-                bool ok;
-                uint32_t j;
-                if (staged) {
-                    const uint32_t tvf = s_tvf[p];
-                    if ((tvf & 0x7FFFFFFFu) == a.tgt_view || azero || (tvf >> 31)) continue;
-                    const float odp1 = s_sorted[p], odp2 = s_dp2[p];
-                    const float d1 = a.dp1 - odp1, d2 = a.dp2 - odp2;
-                    if (d1 * d1 > 0.72f * a.reg1 || d2 * d2 > 0.72f * a.reg2) continue;   // see sim_decide
-                    const float y1 = -d1 * d1 / a.reg1, y2 = -d2 * d2 / a.reg2;
-                    if (y1 == y1 && !(y1 > sc.y_thr)) continue;
-                    if (y2 == y2 && !(y2 > sc.y_thr)) continue;
-                    // angular part: fp32 dot product, exact fp64 redo when it is near a threshold
-                    const float xf = fmaxf(fminf(adx * s_dir[3 * p] + ady * s_dir[3 * p + 1] + adz * s_dir[3 * p + 2], 1.0f), -1.0f);
-                    if (fabsf(xf - sc.x_hi) > kDirSlack && fabsf(xf - sc.x_lo) > kDirSlack) {
-                        ok = xf >= sc.x_hi || xf <= sc.x_lo;
-                    } else {
-                        const float dot_p = (float)dot(ad, entry_dir(v.C, sx, odp1, odp2));
-                        const float x = fmaxf(fminf(dot_p, 1.0f), -1.0f);
-                        ok = x >= sc.x_hi || x <= sc.x_lo;
-                    }
-                    j = s_sidx[p];
-                } else {
-                    j = s_sidx[p];
-                    const DEntry& o = dents[b + j];
-                    if (o.tgt_view == a.tgt_view) continue;
-                    ok = sim_decide(ad, azero, a.dp1, a.dp2, a.reg1, a.reg2, entry_dir(v.C, sx, o.dp1, o.dp2),
-                                    (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc);
-                }
-                if (ok) {
-                    if (in_regs) {
-#pragma unroll
-                        for (uint32_t w = 0; w < kRowRegs; ++w) rw[w] |= (w == (j >> 6)) ? (1ull << (j & 63)) : 0ull;
-                    } else {
-                        rows[(size_t)i * W + (j >> 6)] |= 1ull << (j & 63);
-                    }
-                }
-            }
-            if (in_regs) {
-#pragma unroll
-                for (uint32_t w = 0; w < kRowRegs; ++w) if (w < W) rows[(size_t)i * W + w] = rw[w];
+                const uint32_t j = s_sidx[p];
+                const DEntry& o = dents[b + j];
+                if (o.tgt_view == a.tgt_view) continue;
+                if (sim_decide(ad, azero, a.dp1, a.dp2, a.reg1, a.reg2, entry_dir(v.C, sx, o.dp1, o.dp2),
+                               (o.flags & kDZeroLen) != 0, o.dp1, o.dp2, sc))
+                    rows[(size_t)i * W + (j >> 6)] |= 1ull << (j & 63);
             }
         }
         return;
