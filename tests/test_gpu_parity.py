@@ -594,3 +594,41 @@ def test_long_hypothesis_lists_parity(n_views, n_segs, nn, kNN, epi, seed, rf, m
     assert worst < H.REL_TOL
     ge, gl, _ = g.affinity(); oe, ol = o.affinity()
     assert len(ge) == len(oe) and np.array_equal(ge["i"], oe["i"]) and np.array_equal(ge["j"], oe["j"])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_phase_a_emulated_on_one_gpu(world):
+    """The N>1 path without RCCL: `world` contexts on one GPU each match their range of the pair list
+    (l3d_match_pairs(first, count)), the slot slices are copied device-to-device exactly where the all-gather would
+    put them, and every context finishes phase B on its own -- all must equal the single-context result."""
+    import torch
+    from line3dpp_amd import dist
+    sc = make_scene(9, 350, n_neighbors=4, seed=81)
+    ref = _gpu(sc)
+    assert ref.matchImages() and ref.computeAffinity()
+    ctxs = [_gpu(sc) for _ in range(world)]
+    for g in ctxs:
+        assert g.matchBegin()
+    pairs, slot_off = ctxs[0].pairs()
+    M = {v.cam: len(v.segs) for v in sc.views}
+    ranges = dist.pair_ranges([M[int(s)] * M[int(t)] for s, t in pairs], world)
+    for r, g in enumerate(ctxs):
+        first, count = ranges[r]
+        if count:
+            assert g.matchPairs(first, count)
+    ptr0, n_slots = ctxs[0].slot_buffer()
+    bufs = [dist.device_tensor(g.slot_buffer()[0], n_slots * 32, torch.device("cuda", 0)) for g in ctxs]
+    byte_ranges = dist.slot_byte_ranges(ranges, slot_off, n_slots)
+    for r, (lo, hi) in enumerate(byte_ranges):       # "all-gather": rank r's slice to everybody else
+        for q in range(world):
+            if q != r and hi > lo:
+                bufs[q][lo:hi].copy_(bufs[r][lo:hi])
+    torch.cuda.synchronize()
+    for g in ctxs:
+        g.L.l3d_slots_exchanged(g.h)
+        assert g.matchFinish() and g.computeAffinity()
+        for v in sc.views:
+            a, ao = g.matches(v.cam); b, bo = ref.matches(v.cam)
+            assert np.array_equal(ao, bo) and a.tobytes() == b.tobytes()
+        ge, gl, _ = g.affinity(); re_, rl, _ = ref.affinity()
+        assert ge.tobytes() == re_.tobytes() and gl.tobytes() == rl.tobytes()
