@@ -1,0 +1,34 @@
+"""Randomised full-pipeline stress (run on the GPU box: python tools/stress_pipeline.py [n]): matchImages + affinity
+of the HIP path against the CPU oracle on random ring geometries / parameters: surviving-match sets, best
+hypotheses and affinity edges must be identical, float values within 1e-4."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from line3dpp_amd.api import Line3D
+from line3dpp_amd.scene import make_scene
+from oracle.oracle import Oracle
+from tests import helpers as H
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(321)
+bad = 0
+for it in range(n):
+    nv = int(rng.integers(3, 16)); ns = int(rng.integers(40, 700)); nn = int(rng.integers(2, min(nv, 12)))
+    knn = int(rng.choice([1, 5, 10, 25])); epi = float(rng.choice([0.1, 0.25, 0.5])); sa = float(rng.choice([5.0, 10.0, 20.0]))
+    sp = float(rng.choice([1.0, 2.5, 5.0])); radius = float(rng.uniform(10, 50))
+    sc = make_scene(nv, ns, n_neighbors=nn, seed=int(rng.integers(1, 1 << 30)), radius=radius, noise_px=float(rng.uniform(0, 1.5)),
+                    real_fraction=float(rng.uniform(0.3, 0.9)))
+    g = Line3D(); g.add_scene(sc)
+    assert g.matchImages(sigma_position=sp, sigma_angle=sa, kNN=knn, epipolar_overlap=epi) and g.computeAffinity()
+    o = Oracle(threads=16); o.add_scene(sc)
+    o.match_images(sigma_p=sp, sigma_a=sa, kNN=knn, epi_overlap=epi); o.compute_affinity()
+    ok = True; worst = 0.0
+    for v in sc.views:
+        r = H.compare_matches(g.matches(v.cam)[0], o.matches(v.cam)[0])
+        ok &= not r["missing"] and not r["extra"]; worst = max(worst, r["max_rel"])
+    ge, gl, _ = g.affinity(); oe, ol = o.affinity()
+    ok &= len(ge) == len(oe) and np.array_equal(ge["i"], oe["i"]) and np.array_equal(ge["j"], oe["j"])
+    if len(ge) == len(oe) and len(ge): worst = max(worst, float(np.max(np.abs(ge["w"] - oe["w"]) / oe["w"])))
+    ok &= worst < 1e-4
+    bad += not ok
+    print(it, nv, ns, nn, knn, epi, sa, sp, "entries", g.timings()["list_entries"], "edges", len(ge), "max_rel %.2e" % worst, "OK" if ok else "MISMATCH", flush=True)
+print("RESULT mismatching scenes:", bad, "of", n)
