@@ -744,11 +744,29 @@ int l3d_slot_buffer(l3d_ctx* c, void** dev_ptr, uint64_t* n_slots) {
 }
 
 // phase B: line3D.cc:745-773 for every view in ascending camID order (k_views.hip)
+static int match_finish_impl(l3d_ctx* c);
+
 int l3d_match_finish(l3d_ctx* c) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (c->state != l3d_ctx::BEGUN) return fail(L3D_ERR_STATE, "l3d_match_begin must precede l3d_match_finish");
     (void)hipSetDevice(c->device);
+    const int rc = match_finish_impl(c);
+    if (rc != L3D_OK) {
+        // leave a defined state behind: drain every stream this call may have used, restore the views
+        // (matchImages translates them, line3D.cc:436/493) and require a new l3d_match_begin
+        const std::string why = l3d_last_error();
+        (void)hipStreamSynchronize(c->stream);
+        for (auto& s2 : c->aux) if (s2) (void)hipStreamSynchronize(s2);
+        untranslate(*c);
+        c->split_active = false; c->timing_pending = false; c->pending_launches = 0;
+        c->state = l3d_ctx::IDLE;
+        set_error(why);
+    }
+    return rc;
+}
+
+static int match_finish_impl(l3d_ctx* c) {
     hipStream_t st = c->stream;
     const uint32_t V = (uint32_t)c->order.size(), P = (uint32_t)c->pairs.size();
     // global segment ids
