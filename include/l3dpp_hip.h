@@ -205,6 +205,13 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
                     const double C_src[3], const double C_tgt[3], uint32_t width, uint32_t height,
                     float epi_overlap, int32_t kNN, l3d_slot* out_slots, uint64_t* num_matches);
 
+/* Line3D::createOutputFilename (line3D.cc:2853-2893): "Line3D++__W_FULL__N_10__sigmaP_2.5__..._vis_3" from the
+ * parameters of the last matchImages / reconstruct3Dlines.  max_image_width <= 0 -> "W_FULL". */
+int l3d_output_filename(l3d_ctx*, int max_image_width, char* buf, uint32_t cap);
+/* Line3D::save3DLinesAsTXT (line3D.cc:2631-2688): <output_folder>/<output filename>.txt, one line per 3D line:
+ * n_segments (P1 P2)* n_residuals (camID segID x1 y1 x2 y2)*, the format of the .txt files under testdata/Line3D++_ref. */
+int l3d_save_3d_lines_txt(l3d_ctx*, const char* output_folder, int max_image_width);
+
 /* Replaces the body of Line3D::performRDD (line3D.cc:2026-2076): SparseMatrix(A_, n) +
  * replicator_dynamics_diffusion_GPU (cudawrapper.h:74-75, cudawrapper.cu:708-766: row normalisation + 10
  * diffusion steps P' = P o (P W)^T with the reference's lockstep row/column walk) + the min(w12, w21)

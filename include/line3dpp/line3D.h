@@ -45,7 +45,8 @@ public:
            const unsigned int max_line_segments = 3000, const bool neighbors_by_worldpoints = false,
            const bool use_GPU = true, const int device = 0, void* hip_stream = nullptr)
         : prefix_("[L3D++] "), prefix_err_("[L3D++] ERROR: ") {
-        (void)output_folder; (void)load_segments; (void)max_img_width; (void)max_line_segments; (void)use_GPU;
+        (void)output_folder; (void)load_segments; (void)max_line_segments; (void)use_GPU;
+        max_img_width_ = max_img_width;
         if (neighbors_by_worldpoints)
             std::cout << prefix_err_ << "worldpoint-derived neighbours are outside the accelerated path; "
                          "pass explicit neighbour lists" << std::endl;
@@ -133,6 +134,12 @@ public:
         }
     }
 
+    // void Line3D::save3DLinesAsTXT(const std::string& output_folder), line3D.h:176
+    void save3DLinesAsTXT(const std::string& output_folder) {
+        if (l3d_save_3d_lines_txt(ctx_, output_folder.c_str(), max_img_width_) != L3D_OK)
+            std::cout << prefix_ << "WARNING: " << l3d_last_error() << std::endl;
+    }
+
     size_t numImages() const { return num_lines_.size(); }
 
     // matches_[camID] rebuilt in the reference's container type (line3D.h:348)
@@ -178,6 +185,7 @@ public:
 
 private:
     l3d_ctx* ctx_ = nullptr;
+    int max_img_width_ = -1;
     std::map<unsigned int, uint32_t> num_lines_;
     std::string prefix_, prefix_err_;
 };

@@ -116,6 +116,18 @@ class Line3D:
                                                            float(collinearity_t), int(use_CERES), int(max_iter_CERES)),
                            "reconstruct3Dlines")
 
+    # Line3D::createOutputFilename (private in the reference; line3D.cc:2853-2893)
+    def outputFilename(self, max_image_width=-1):
+        buf = C.create_string_buffer(512)
+        if not self._check(self.L.l3d_output_filename(self.h, int(max_image_width), buf, 512), "outputFilename"):
+            return None
+        return buf.value.decode()
+
+    # Line3D::save3DLinesAsTXT, line3D.h:176 -- <output_folder>/<outputFilename()>.txt
+    def save3DLinesAsTXT(self, output_folder, max_image_width=-1):
+        return self._check(self.L.l3d_save_3d_lines_txt(self.h, str(output_folder).encode(), int(max_image_width)),
+                           "save3DLinesAsTXT")
+
     # Line3D::get3Dlines, line3D.h:173: list of FinalLine3D as dicts
     def get3Dlines(self):
         nl = C.c_uint32(); ns = C.c_uint32(); nr = C.c_uint32()

@@ -3,6 +3,8 @@
 // (line3D.cc:112-227, 375-497, 702-778, 1749-1778, 1852-1979).  No CPU fallback exists: every
 // compute step is a HIP kernel launch; without a usable device the calls fail with L3D_ERR_HIP.
 #include <algorithm>
+#include <fstream>
+#include <sstream>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -121,6 +123,8 @@ struct l3d_ctx {
     DevBuf<float2> d_src_band, d_chunk_band, d_tgt_band;
     DevBuf<float4> d_tgt_sf;
     bool use_cull = true;
+    unsigned visibility_t = 3;                      // visibility_t_ / perform_RDD_ of the last reconstruct3Dlines
+    bool perform_rdd = false;
     // A_ / local2global_ stay on the device; the host copies (edges, l2g) are fetched on first use
     uint32_t aff_n_edges = 0, aff_n_rows = 0;
     bool aff_host_valid = true;
@@ -1187,6 +1191,7 @@ int l3d_reconstruct_3d_lines(l3d_ctx* c, uint32_t visibility_t, int perform_diff
     c->collinearity_t = collinearity_t;                                                          // :1725-1726
     if (use_CERES) set_error("CERES not available, no optimization will be performed");             // :1741-1743
     const unsigned vis = std::max<unsigned>(visibility_t, 3);
+    c->visibility_t = vis; c->perform_rdd = perform_diffusion != 0;
     c->lines3D.clear();
     translate(*c);
     int rc = affinity_core(c);
@@ -1230,6 +1235,68 @@ int l3d_reconstruct_3d_lines(l3d_ctx* c, uint32_t visibility_t, int perform_diff
     }
     untranslate(*c);
     return rc;
+}
+
+// Line3D::createOutputFilename, line3D.cc:2853-2893 (stream formatting of the float parameters as there)
+static std::string output_filename(l3d_ctx* c, int max_image_width) {
+    std::stringstream str;
+    str << "Line3D++__";
+    if (max_image_width > 0) str << "W_" << max_image_width << "__";
+    else str << "W_FULL__";
+    str << "N_" << c->num_neighbors << "__";
+    str << "sigmaP_" << c->sigma_p << "__";
+    str << "sigmaA_" << c->sigma_a << "__";
+    str << "epiOverlap_" << c->epipolar_overlap << "__";
+    if (c->kNN > 0) str << "kNN_" << c->kNN << "__";
+    if (c->collinearity_t > (float)kEps) str << "COLLIN_" << c->collinearity_t << "__";
+    if (c->fixed3Dregularizer) {
+        str << "FXD_SIGMA_P__";
+        if (c->const_regularization_depth > 0.0f) str << "REG_DEPTH_" << c->const_regularization_depth << "__";
+    }
+    if (c->perform_rdd) str << "DIFFUSION__";
+    str << "vis_" << c->visibility_t;     // (no "OPTIMIZED__": Ceres is not part of this library)
+    return str.str();
+}
+
+int l3d_output_filename(l3d_ctx* c, int max_image_width, char* buf, uint32_t cap) {
+    if (!c || !buf || !cap) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    const std::string n = output_filename(c, max_image_width);
+    if (n.size() + 1 > cap) return fail(L3D_ERR_ARG, "buffer too small for the output file name");
+    std::memcpy(buf, n.c_str(), n.size() + 1);
+    return L3D_OK;
+}
+
+// Line3D::save3DLinesAsTXT, line3D.cc:2631-2688: one text line per 3D line --
+//   #segments  (P1.x P1.y P1.z P2.x P2.y P2.z)*  #residuals  (camID segID x1 y1 x2 y2)*
+// written with the stream defaults the reference uses (6 significant digits), so files can be diffed
+int l3d_save_3d_lines_txt(l3d_ctx* c, const char* output_folder, int max_image_width) {
+    if (!c || !output_folder) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (!c->lines_done || c->lines3D.empty()) return fail(L3D_ERR_STATE, "no 3D lines to save!");   // :2636-2642
+    const std::string filename = std::string(output_folder) + "/" + output_filename(c, max_image_width) + ".txt";
+    std::ofstream file(filename.c_str());
+    if (!file) return fail(L3D_ERR_ARG, "cannot open " + filename);
+    for (const ReconLine& L : c->lines3D) {
+        if (L.collinear.empty()) continue;
+        file << L.collinear.size() << " ";
+        for (const ReconSeg3D& sg : L.collinear) {
+            file << sg.P1.x << " " << sg.P1.y << " " << sg.P1.z << " ";
+            file << sg.P2.x << " " << sg.P2.y << " " << sg.P2.z << " ";
+        }
+        file << L.residuals.size() << " ";
+        for (const auto& r : L.residuals) {
+            file << r.first << " " << r.second << " ";
+            float co[4] = {0, 0, 0, 0};                                   // getSegmentCoords2D, line3D.cc:2608-2628
+            auto f = c->views.find(r.first);
+            if (f != c->views.end() && r.second < f->second->M)
+                for (int k = 0; k < 4; ++k) co[k] = f->second->segs[4 * (size_t)r.second + k];
+            file << co[0] << " " << co[1] << " " << co[2] << " " << co[3] << " ";
+        }
+        file << std::endl;
+    }
+    file.close();
+    return file.fail() ? fail(L3D_ERR_ARG, "writing " + filename + " failed") : L3D_OK;
 }
 
 int l3d_num_3d_lines(l3d_ctx* c, uint32_t* n_lines, uint32_t* n_segments, uint32_t* n_residuals) {

@@ -87,6 +87,7 @@ def lib(reference=False):
         if reference:
             L.lo_reconstruct.argtypes = [vp, u32]
             L.lo_reconstruct_collin.argtypes = [vp, u32, f32]
+            L.lo_save_txt.argtypes = [vp, C.c_char_p]
             L.lo_num_lines.argtypes = [vp, vp, vp, vp]
             L.lo_get_lines.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         _libs[key] = L
@@ -244,6 +245,11 @@ class Oracle:
             self.L.lo_reconstruct_collin(self.h, int(visibility_t), float(collinearity_t))
         else:
             self.L.lo_reconstruct(self.h, int(visibility_t))
+
+    def save_txt(self, folder):
+        """the reference's own Line3D::save3DLinesAsTXT into `folder`"""
+        assert self.reference
+        self.L.lo_save_txt(self.h, str(folder).encode())
 
     def lines(self):
         """lines3D_ as a list of dicts: collinear3Dsegments [n,9] (P1,P2,dir), residuals [m,2], cluster_line [9],

@@ -235,6 +235,11 @@ void lo_reconstruct_collin(void* p, uint32_t visibility_t, float collinearity_t)
     Quiet q;
     ((Ref*)p)->l3d->reconstruct3Dlines(visibility_t, false, collinearity_t, false, 250);
 }
+// the reference's own writer (Line3D::save3DLinesAsTXT): <folder>/<createOutputFilename()>.txt
+void lo_save_txt(void* p, const char* folder) {
+    Quiet q;
+    ((Ref*)p)->l3d->save3DLinesAsTXT(std::string(folder));
+}
 void lo_num_lines(void* p, uint32_t* n_lines, uint32_t* n_segments, uint32_t* n_residuals) {
     std::vector<L3DPP::FinalLine3D> r;
     ((Ref*)p)->l3d->get3Dlines(r);

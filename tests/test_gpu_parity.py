@@ -632,3 +632,43 @@ def test_sharded_phase_a_emulated_on_one_gpu(world):
             assert np.array_equal(ao, bo) and a.tobytes() == b.tobytes()
         ge, gl, _ = g.affinity(); re_, rl, _ = ref.affinity()
         assert ge.tobytes() == re_.tobytes() and gl.tobytes() == rl.tobytes()
+
+
+def test_txt_writer_matches_accessor_and_reference_writer(tmp_path):
+    """l3d_save_3d_lines_txt (Line3D::save3DLinesAsTXT): file name and content against get3Dlines() and against
+    the file the reference's own writer produces for the same scene (oracle/_ref)."""
+    from line3dpp_amd.io import read_3d_lines_txt
+    from oracle import oracle as O
+    sc = make_scene(12, 500, n_neighbors=6, seed=61)
+    g = _gpu(sc)
+    assert g.matchImages() and g.reconstruct3Dlines(3)
+    name = g.outputFilename()
+    assert name == "Line3D++__W_FULL__N_10__sigmaP_2.5__sigmaA_10__epiOverlap_0.25__kNN_10__vis_3"
+    assert g.save3DLinesAsTXT(tmp_path)
+    mine = read_3d_lines_txt(tmp_path / (name + ".txt"))
+    acc = g.get3Dlines()
+    assert len(mine) == len(acc) > 10
+    segs = {v.cam: v.segs for v in sc.views}
+    for a, b in zip(mine, acc):
+        ref = np.concatenate([b["collinear3Dsegments"]["P1"], b["collinear3Dsegments"]["P2"]], 1)
+        assert np.allclose(a["segments"], ref, rtol=1e-5, atol=1e-6)          # 6 significant digits in the file
+        assert np.array_equal(a["residuals"], np.stack([b["residuals"]["cam"], b["residuals"]["seg"]], 1))
+        for (cam, seg), co in zip(a["residuals"], a["coords2D"]):
+            assert np.allclose(co, segs[int(cam)][int(seg)], rtol=1e-5)
+    if O.have_reference():
+        r = O.Oracle(threads=1, reference=True)
+        r.add_scene(sc); r.match_images(); r.reconstruct(3)
+        d = tmp_path / "ref"; d.mkdir()
+        r.save_txt(d)
+        files = list(d.iterdir())
+        assert [f.name for f in files] == [name + ".txt"]                     # createOutputFilename
+        theirs = read_3d_lines_txt(files[0])
+        key = lambda L: tuple(sorted(map(tuple, L["residuals"].tolist())))
+        tm = {key(L): L for L in theirs}
+        assert len(theirs) == len(mine) and set(tm) == {key(L) for L in mine}
+        for L in mine:
+            R = tm[key(L)]
+            assert len(L["segments"]) == len(R["segments"])
+            for p, q in zip(L["segments"], R["segments"]):
+                qs = np.concatenate([q[3:], q[:3]])
+                assert min(np.abs(p - q).max(), np.abs(p - qs).max()) <= 30.0 * H.REL_TOL

@@ -93,3 +93,19 @@ def test_slot_byte_ranges():
     off = [0, 100, 250]
     br = dist.slot_byte_ranges(ranges, off, 400)
     assert br == [(0, 250 * 32), (250 * 32, 400 * 32), (400 * 32, 400 * 32)]
+
+
+def test_reference_txt_result_format_round_trip():
+    """The TXT result format of Line3D::save3DLinesAsTXT (line3D.cc:2631-2688): an excerpt of the reference's own
+    fixture testdata/Line3D++_ref/...kNN_10__vis_3.txt (first 40 lines, tools/make_golden.py --txt-excerpt) is
+    parsed and re-created byte for byte."""
+    import os
+    from line3dpp_amd.io import read_3d_lines_txt, format_3d_lines_txt
+    path = os.path.join(os.path.dirname(__file__), "golden", "ref_lines3d_excerpt.txt")
+    lines = read_3d_lines_txt(path)
+    assert len(lines) == 40
+    assert all(len(L["segments"]) >= 1 and len(L["residuals"]) >= 3 for L in lines)   # visibility_t = 3
+    assert format_3d_lines_txt(lines) == open(path).read()
+    # the first record of the fixture
+    assert np.allclose(lines[0]["segments"][0], [4.71643, -1.30196, 1.86753, 4.80419, -1.30583, 1.8841])
+    assert lines[0]["residuals"].tolist() == [[19, 273], [17, 313], [24, 301]]

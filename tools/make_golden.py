@@ -4,6 +4,8 @@ place from /root/reference against oracle/ref_shim; see oracle/Makefile).  /root
 the GPU box, so the vectors are committed; the oracle restatement and the HIP path are both tested against
 this file.  Regenerate (in the container that has /root/reference):
     python tools/make_golden.py
+`python tools/make_golden.py --txt-excerpt` re-creates tests/golden/ref_lines3d_excerpt.txt: the first 40 records of
+the reference's own result fixture testdata/Line3D++_ref/...kNN_10__vis_3.txt (Line3D::save3DLinesAsTXT format).
 """
 import os
 import sys
@@ -47,7 +49,18 @@ def run_oracle(scene, reference=False):
                 ks=np.array([o.view_info(c)["k"] for c in cams], np.float64))
 
 
+REF_TXT = ("/root/reference/testdata/Line3D++_ref/"
+           "Line3D++__W_FULL__N_10__sigmaP_2.5__sigmaA_10__epiOverlap_0.25__kNN_10__vis_3.txt")
+
+
 if __name__ == "__main__":
+    if "--txt-excerpt" in sys.argv:
+        with open(REF_TXT) as f:
+            head = [next(f) for _ in range(40)]
+        path = os.path.join(ROOT, "tests", "golden", "ref_lines3d_excerpt.txt")
+        open(path, "w").write("".join(head))
+        print("wrote", path)
+        sys.exit(0)
     from oracle.oracle import have_reference
     assert have_reference(), "oracle/_ref is not built: run `make -C oracle` where /root/reference exists"
     out = run_oracle(golden_scene(), reference=True)
