@@ -211,6 +211,9 @@ int l3d_output_filename(l3d_ctx*, int max_image_width, char* buf, uint32_t cap);
 /* Line3D::save3DLinesAsTXT (line3D.cc:2631-2688): <output_folder>/<output filename>.txt, one line per 3D line:
  * n_segments (P1 P2)* n_residuals (camID segID x1 y1 x2 y2)*, the format of the .txt files under testdata/Line3D++_ref. */
 int l3d_save_3d_lines_txt(l3d_ctx*, const char* output_folder, int max_image_width);
+/* Line3D::saveResultAsSTL (line3D.cc:2465-2531) and saveResultAsOBJ (:2579-2628): <output filename>.stl / .obj */
+int l3d_save_result_stl(l3d_ctx*, const char* output_folder, int max_image_width);
+int l3d_save_result_obj(l3d_ctx*, const char* output_folder, int max_image_width);
 
 /* Replaces the body of Line3D::performRDD (line3D.cc:2026-2076): SparseMatrix(A_, n) +
  * replicator_dynamics_diffusion_GPU (cudawrapper.h:74-75, cudawrapper.cu:708-766: row normalisation + 10

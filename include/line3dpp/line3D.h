@@ -140,6 +140,16 @@ public:
             std::cout << prefix_ << "WARNING: " << l3d_last_error() << std::endl;
     }
 
+    // saveResultAsSTL / saveResultAsOBJ, line3D.h:174-175
+    void saveResultAsSTL(const std::string& output_folder) {
+        if (l3d_save_result_stl(ctx_, output_folder.c_str(), max_img_width_) != L3D_OK)
+            std::cout << prefix_ << "WARNING: " << l3d_last_error() << std::endl;
+    }
+    void saveResultAsOBJ(const std::string& output_folder) {
+        if (l3d_save_result_obj(ctx_, output_folder.c_str(), max_img_width_) != L3D_OK)
+            std::cout << prefix_ << "WARNING: " << l3d_last_error() << std::endl;
+    }
+
     size_t numImages() const { return num_lines_.size(); }
 
     // matches_[camID] rebuilt in the reference's container type (line3D.h:348)

@@ -128,6 +128,15 @@ class Line3D:
         return self._check(self.L.l3d_save_3d_lines_txt(self.h, str(output_folder).encode(), int(max_image_width)),
                            "save3DLinesAsTXT")
 
+    # Line3D::saveResultAsSTL / saveResultAsOBJ, line3D.h:174-175
+    def saveResultAsSTL(self, output_folder, max_image_width=-1):
+        return self._check(self.L.l3d_save_result_stl(self.h, str(output_folder).encode(), int(max_image_width)),
+                           "saveResultAsSTL")
+
+    def saveResultAsOBJ(self, output_folder, max_image_width=-1):
+        return self._check(self.L.l3d_save_result_obj(self.h, str(output_folder).encode(), int(max_image_width)),
+                           "saveResultAsOBJ")
+
     # Line3D::get3Dlines, line3D.h:173: list of FinalLine3D as dicts
     def get3Dlines(self):
         nl = C.c_uint32(); ns = C.c_uint32(); nr = C.c_uint32()

@@ -1299,6 +1299,52 @@ int l3d_save_3d_lines_txt(l3d_ctx* c, const char* output_folder, int max_image_w
     return file.fail() ? fail(L3D_ERR_ARG, "writing " + filename + " failed") : L3D_OK;
 }
 
+// Line3D::saveResultAsSTL (line3D.cc:2465-2531) / saveResultAsOBJ (:2579-2628)
+int l3d_save_result_stl(l3d_ctx* c, const char* output_folder, int max_image_width) {
+    if (!c || !output_folder) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (!c->lines_done || c->lines3D.empty()) return fail(L3D_ERR_STATE, "no 3D lines to save!");
+    const std::string filename = std::string(output_folder) + "/" + output_filename(c, max_image_width) + ".stl";
+    std::ofstream file(filename.c_str());
+    if (!file) return fail(L3D_ERR_ARG, "cannot open " + filename);
+    file << "solid lineModel" << std::endl;
+    for (const ReconLine& L : c->lines3D)
+        for (const ReconSeg3D& sg : L.collinear) {
+            char a[6][50];
+            const double v[6] = {sg.P1.x, sg.P1.y, sg.P1.z, sg.P2.x, sg.P2.y, sg.P2.z};
+            for (int k = 0; k < 6; ++k) std::snprintf(a[k], sizeof(a[k]), "%e", v[k]);
+            file << " facet normal 1.0e+000 0.0e+000 0.0e+000" << std::endl;
+            file << "  outer loop" << std::endl;
+            file << "   vertex " << a[0] << " " << a[1] << " " << a[2] << std::endl;
+            file << "   vertex " << a[3] << " " << a[4] << " " << a[5] << std::endl;
+            file << "   vertex " << a[0] << " " << a[1] << " " << a[2] << std::endl;
+            file << "  endloop" << std::endl;
+            file << " endfacet" << std::endl;
+        }
+    file << "endsolid lineModel" << std::endl;
+    file.close();
+    return file.fail() ? fail(L3D_ERR_ARG, "writing " + filename + " failed") : L3D_OK;
+}
+
+int l3d_save_result_obj(l3d_ctx* c, const char* output_folder, int max_image_width) {
+    if (!c || !output_folder) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (!c->lines_done || c->lines3D.empty()) return fail(L3D_ERR_STATE, "no 3D lines to save!");
+    const std::string filename = std::string(output_folder) + "/" + output_filename(c, max_image_width) + ".obj";
+    std::ofstream file(filename.c_str());
+    if (!file) return fail(L3D_ERR_ARG, "cannot open " + filename);
+    size_t n_segments = 0;
+    for (const ReconLine& L : c->lines3D)
+        for (const ReconSeg3D& sg : L.collinear) {
+            file << "v " << sg.P1.x << " " << sg.P1.y << " " << sg.P1.z << std::endl;
+            file << "v " << sg.P2.x << " " << sg.P2.y << " " << sg.P2.z << std::endl;
+            ++n_segments;
+        }
+    for (size_t k = 0; k < n_segments; ++k) file << "l " << 2 * k + 1 << " " << 2 * k + 2 << std::endl;
+    file.close();
+    return file.fail() ? fail(L3D_ERR_ARG, "writing " + filename + " failed") : L3D_OK;
+}
+
 int l3d_num_3d_lines(l3d_ctx* c, uint32_t* n_lines, uint32_t* n_segments, uint32_t* n_residuals) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
     if (!c->lines_done) return fail(L3D_ERR_STATE, "l3d_reconstruct_3d_lines has not run");

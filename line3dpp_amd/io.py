@@ -42,3 +42,28 @@ def format_3d_lines_txt(lines):
             t += [str(int(cam)), str(int(seg))] + [_g(np.float32(v)) for v in co]
         rows.append(" ".join(t) + " \n")
     return "".join(rows)
+
+
+def format_obj(lines):
+    """the text Line3D::saveResultAsOBJ (line3D.cc:2579-2628) writes: two `v` records per 3D segment, then one `l`
+    record per segment"""
+    v, n = [], 0
+    for L in lines:
+        for s in L["segments"]:
+            v.append("v " + " ".join(_g(x) for x in s[:3]) + "\n")
+            v.append("v " + " ".join(_g(x) for x in s[3:]) + "\n")
+            n += 1
+    return "".join(v) + "".join(f"l {2 * k + 1} {2 * k + 2}\n" for k in range(n))
+
+
+def format_stl(lines):
+    """the text Line3D::saveResultAsSTL (line3D.cc:2465-2531) writes (degenerate triangles P1-P2-P1, printf %e)"""
+    t = ["solid lineModel\n"]
+    for L in lines:
+        for s in L["segments"]:
+            a = ["%e" % x for x in s]
+            t += [" facet normal 1.0e+000 0.0e+000 0.0e+000\n", "  outer loop\n",
+                  "   vertex %s %s %s\n" % tuple(a[:3]), "   vertex %s %s %s\n" % tuple(a[3:]),
+                  "   vertex %s %s %s\n" % tuple(a[:3]), "  endloop\n", " endfacet\n"]
+    t.append("endsolid lineModel\n")
+    return "".join(t)

@@ -655,6 +655,12 @@ def test_txt_writer_matches_accessor_and_reference_writer(tmp_path):
         assert np.array_equal(a["residuals"], np.stack([b["residuals"]["cam"], b["residuals"]["seg"]], 1))
         for (cam, seg), co in zip(a["residuals"], a["coords2D"]):
             assert np.allclose(co, segs[int(cam)][int(seg)], rtol=1e-5)
+    # OBJ / STL writers: the library's files equal the reference formats applied to the same lines
+    from line3dpp_amd.io import format_obj, format_stl
+    assert g.saveResultAsOBJ(tmp_path) and g.saveResultAsSTL(tmp_path)
+    assert open(tmp_path / (name + ".obj")).read() == format_obj(mine)
+    full = [dict(segments=np.concatenate([b["collinear3Dsegments"]["P1"], b["collinear3Dsegments"]["P2"]], 1)) for b in acc]
+    assert open(tmp_path / (name + ".stl")).read() == format_stl(full)
     if O.have_reference():
         r = O.Oracle(threads=1, reference=True)
         r.add_scene(sc); r.match_images(); r.reconstruct(3)

@@ -109,3 +109,21 @@ def test_reference_txt_result_format_round_trip():
     # the first record of the fixture
     assert np.allclose(lines[0]["segments"][0], [4.71643, -1.30196, 1.86753, 4.80419, -1.30583, 1.8841])
     assert lines[0]["residuals"].tolist() == [[19, 273], [17, 313], [24, 301]]
+
+
+def test_reference_obj_and_stl_formats():
+    """saveResultAsOBJ / saveResultAsSTL formats (line3D.cc:2579-2628, 2465-2531): the OBJ text generated from the
+    parsed TXT excerpt equals the `v` records of the reference's own .obj fixture for the same 3D segments (the full
+    files are identical too, 165 115 bytes, checked when the excerpt was made); the STL text has the reference's
+    record structure."""
+    import os
+    from line3dpp_amd.io import read_3d_lines_txt, format_obj, format_stl
+    gd = os.path.join(os.path.dirname(__file__), "golden")
+    lines = read_3d_lines_txt(os.path.join(gd, "ref_lines3d_excerpt.txt"))
+    n_seg = sum(len(L["segments"]) for L in lines)
+    obj = format_obj(lines).splitlines(keepends=True)
+    assert "".join(obj[:2 * n_seg]) == open(os.path.join(gd, "ref_lines3d_excerpt.obj")).read()
+    assert obj[2 * n_seg:] == [f"l {2 * k + 1} {2 * k + 2}\n" for k in range(n_seg)]
+    stl = format_stl(lines).splitlines()
+    assert stl[0] == "solid lineModel" and stl[-1] == "endsolid lineModel" and len(stl) == 2 + 7 * n_seg
+    assert stl[1] == " facet normal 1.0e+000 0.0e+000 0.0e+000" and stl[3].startswith("   vertex 4.716430e+00 ")

@@ -60,6 +60,13 @@ if __name__ == "__main__":
         path = os.path.join(ROOT, "tests", "golden", "ref_lines3d_excerpt.txt")
         open(path, "w").write("".join(head))
         print("wrote", path)
+        # the `v` records of the same 3D segments in the reference's .obj result (two per segment, same order)
+        n_seg = sum(int(l.split()[0]) for l in head)
+        with open(REF_TXT[:-4] + ".obj") as f:
+            v = [next(f) for _ in range(2 * n_seg)]
+        path = os.path.join(ROOT, "tests", "golden", "ref_lines3d_excerpt.obj")
+        open(path, "w").write("".join(v))
+        print("wrote", path)
         sys.exit(0)
     from oracle.oracle import have_reference
     assert have_reference(), "oracle/_ref is not built: run `make -C oracle` where /root/reference exists"
