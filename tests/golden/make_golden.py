@@ -3,8 +3,8 @@ deterministic scene, produced by THE REFERENCE'S OWN CODE (oracle/_ref = line3D.
 place from /root/reference against oracle/ref_shim; see oracle/Makefile).  /root/reference does not exist on
 the GPU box, so the vectors are committed; the oracle restatement and the HIP path are both tested against
 this file.  Regenerate (in the container that has /root/reference):
-    python tools/make_golden.py
-`python tools/make_golden.py --txt-excerpt` re-creates tests/golden/ref_lines3d_excerpt.txt: the first 40 records of
+    python tests/golden/make_golden.py
+`python tests/golden/make_golden.py --txt-excerpt` re-creates tests/golden/ref_lines3d_excerpt.txt: the first 40 records of
 the reference's own result fixture testdata/Line3D++_ref/...kNN_10__vis_3.txt (Line3D::save3DLinesAsTXT format).
 """
 import os
@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from line3dpp_amd.scene import make_scene  # noqa: E402
 

@@ -1,7 +1,7 @@
 """Verbose GPU-vs-oracle comparison on one synthetic scene (run on the GPU box):
-   python tools/gpu_check.py [n_views n_segs n_neighbors kNN seed]"""
+   python tests/stress/gpu_check.py [n_views n_segs n_neighbors kNN seed]"""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from line3dpp_amd.scene import make_scene
 from line3dpp_amd.api import Line3D

@@ -1,8 +1,8 @@
-"""Randomised stress (run on the GPU box: python tools/stress_culling.py): phase A with epipolar-band culling + fp32
+"""Randomised stress (run on the GPU box: python tests/stress/stress_culling.py): phase A with epipolar-band culling + fp32
 pre-filter against the brute-force path (every pair through the exact test) on random ring geometries, image
 scalings, kNN and overlap thresholds.  Round 1: 40 scenes, 614 directed pairs, 3.4 M matches, 0 differences."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from line3dpp_amd.api import Line3D
 from line3dpp_amd.scene import make_scene

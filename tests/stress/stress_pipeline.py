@@ -1,9 +1,9 @@
-"""Randomised full-pipeline stress (run on the GPU box: python tools/stress_pipeline.py [n]): matchImages + affinity
+"""Randomised full-pipeline stress (run on the GPU box: python tests/stress/stress_pipeline.py [n]): matchImages + affinity
 of the HIP path against the CPU oracle on random ring geometries / parameters: surviving-match sets, best
 hypotheses and affinity edges must be identical, float values within 1e-4 (incl. metric regulariser, keep-all kNN,
 ragged views, asymmetric neighbour lists).  Round 1: 30 scenes, 0 mismatches."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from line3dpp_amd.api import Line3D
 from line3dpp_amd.scene import make_scene

@@ -240,7 +240,7 @@ def test_asymmetric_neighbours_and_sparse_cam_ids():
 
 
 def test_golden_fixture_gpu():
-    from tools.make_golden import PARAMS, flat_matches, golden_scene
+    from tests.golden.make_golden import PARAMS, flat_matches, golden_scene
     gold = np.load(GOLDEN)
     sc = golden_scene()
     g = _gpu(sc)

@@ -97,7 +97,7 @@ def test_slot_byte_ranges():
 
 def test_reference_txt_result_format_round_trip():
     """The TXT result format of Line3D::save3DLinesAsTXT (line3D.cc:2631-2688): an excerpt of the reference's own
-    fixture testdata/Line3D++_ref/...kNN_10__vis_3.txt (first 40 lines, tools/make_golden.py --txt-excerpt) is
+    fixture testdata/Line3D++_ref/...kNN_10__vis_3.txt (first 40 lines, tests/golden/make_golden.py --txt-excerpt) is
     parsed and re-created byte for byte."""
     import os
     from line3dpp_amd.io import read_3d_lines_txt, format_3d_lines_txt

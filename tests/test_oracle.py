@@ -177,11 +177,11 @@ def test_param_clamps_and_errors():
 
 def test_golden_fixture():
     """tests/golden/small_scene.npz holds the output of the REFERENCE'S OWN CODE (oracle/_ref) on a small
-    scene (tools/make_golden.py); the restatement must reproduce it, and the HIP path is checked against the
+    scene (tests/golden/make_golden.py); the restatement must reproduce it, and the HIP path is checked against the
     same file in test_gpu_parity."""
-    assert os.path.exists(GOLDEN), "run python tools/make_golden.py"
+    assert os.path.exists(GOLDEN), "run python tests/golden/make_golden.py"
     g = np.load(GOLDEN)
-    from tools.make_golden import golden_scene, run_oracle
+    from tests.golden.make_golden import golden_scene, run_oracle
     out = run_oracle(golden_scene())
     assert "reference" in str(g["generator"])
     for k in ("matches", "best_keys", "best_geo", "edges", "l2g", "medians", "ks"):
