@@ -211,6 +211,8 @@ int l3d_output_filename(l3d_ctx*, int max_image_width, char* buf, uint32_t cap);
 /* Line3D::save3DLinesAsTXT (line3D.cc:2631-2688): <output_folder>/<output filename>.txt, one line per 3D line:
  * n_segments (P1 P2)* n_residuals (camID segID x1 y1 x2 y2)*, the format of the .txt files under testdata/Line3D++_ref. */
 int l3d_save_3d_lines_txt(l3d_ctx*, const char* output_folder, int max_image_width);
+/* Line3D::getSegmentCoords2D (line3D.cc:2757-2772): (x1,y1,x2,y2) of a 2D segment, zeros if unknown */
+int l3d_get_segment_coords2d(l3d_ctx*, uint32_t camID, uint32_t segID, float coords[4]);
 /* Line3D::saveResultAsSTL (line3D.cc:2465-2531) and saveResultAsOBJ (:2579-2628): <output filename>.stl / .obj */
 int l3d_save_result_stl(l3d_ctx*, const char* output_folder, int max_image_width);
 int l3d_save_result_obj(l3d_ctx*, const char* output_folder, int max_image_width);

@@ -140,6 +140,19 @@ public:
             std::cout << prefix_ << "WARNING: " << l3d_last_error() << std::endl;
     }
 
+    // std::string Line3D::createOutputFilename(), line3D.h:226
+    std::string createOutputFilename() {
+        char buf[512];
+        return l3d_output_filename(ctx_, max_img_width_, buf, sizeof(buf)) == L3D_OK ? std::string(buf) : std::string();
+    }
+    // getSegmentCoords2D(camID, segID), line3D.h:195-197: (x1, y1, x2, y2)
+    struct Coords2D { float v[4]; float operator()(int i) const { return v[i]; } };
+    Coords2D getSegmentCoords2D(const unsigned int camID, const unsigned int segID) {
+        Coords2D c{};
+        l3d_get_segment_coords2d(ctx_, camID, segID, c.v);
+        return c;
+    }
+
     // saveResultAsSTL / saveResultAsOBJ, line3D.h:174-175
     void saveResultAsSTL(const std::string& output_folder) {
         if (l3d_save_result_stl(ctx_, output_folder.c_str(), max_img_width_) != L3D_OK)

@@ -128,6 +128,12 @@ class Line3D:
         return self._check(self.L.l3d_save_3d_lines_txt(self.h, str(output_folder).encode(), int(max_image_width)),
                            "save3DLinesAsTXT")
 
+    # Line3D::getSegmentCoords2D, line3D.h:195-197
+    def getSegmentCoords2D(self, camID, segID):
+        out = np.zeros(4, np.float32)
+        self._check(self.L.l3d_get_segment_coords2d(self.h, int(camID), int(segID), ptr(out)), "getSegmentCoords2D")
+        return out
+
     # Line3D::saveResultAsSTL / saveResultAsOBJ, line3D.h:174-175
     def saveResultAsSTL(self, output_folder, max_image_width=-1):
         return self._check(self.L.l3d_save_result_stl(self.h, str(output_folder).encode(), int(max_image_width)),

@@ -1299,6 +1299,17 @@ int l3d_save_3d_lines_txt(l3d_ctx* c, const char* output_folder, int max_image_w
     return file.fail() ? fail(L3D_ERR_ARG, "writing " + filename + " failed") : L3D_OK;
 }
 
+// Line3D::getSegmentCoords2D, line3D.cc:2757-2772: (0,0,0,0) for an unknown camera / segment
+int l3d_get_segment_coords2d(l3d_ctx* c, uint32_t camID, uint32_t segID, float coords[4]) {
+    if (!c || !coords) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    for (int k = 0; k < 4; ++k) coords[k] = 0.0f;
+    auto f = c->views.find(camID);
+    if (f != c->views.end() && segID < f->second->M)
+        for (int k = 0; k < 4; ++k) coords[k] = f->second->segs[4 * (size_t)segID + k];
+    return L3D_OK;
+}
+
 // Line3D::saveResultAsSTL (line3D.cc:2465-2531) / saveResultAsOBJ (:2579-2628)
 int l3d_save_result_stl(l3d_ctx* c, const char* output_folder, int max_image_width) {
     if (!c || !output_folder) return fail(L3D_ERR_ARG, "null argument");

@@ -655,6 +655,8 @@ def test_txt_writer_matches_accessor_and_reference_writer(tmp_path):
         assert np.array_equal(a["residuals"], np.stack([b["residuals"]["cam"], b["residuals"]["seg"]], 1))
         for (cam, seg), co in zip(a["residuals"], a["coords2D"]):
             assert np.allclose(co, segs[int(cam)][int(seg)], rtol=1e-5)
+    assert np.array_equal(g.getSegmentCoords2D(3, 17), sc.views[3].segs[17])
+    assert np.array_equal(g.getSegmentCoords2D(999, 0), np.zeros(4, np.float32))     # unknown camera -> zeros
     # OBJ / STL writers: the library's files equal the reference formats applied to the same lines
     from line3dpp_amd.io import format_obj, format_stl
     assert g.saveResultAsOBJ(tmp_path) and g.saveResultAsSTL(tmp_path)
