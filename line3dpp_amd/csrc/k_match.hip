@@ -50,25 +50,34 @@ __device__ unsigned long long g_cycles[1 << 16][2];   // per work item: start, d
 #define L3D_STAT(i, n) ((void)0)
 #endif
 typedef float v4f __attribute__((ext_vector_type(4)));
+// IX16: target indices, row counts and slot positions fit 16 bits (every Mt and K below 65536 -- always true when
+// the pair is culled, kCullMaxSegs = 16384): 6.5 KiB of LDS per wave at K = 10 instead of 8 KiB, i.e. 24 resident
+// waves per CU (6 per SIMD) instead of 20
+template <bool IX16> struct IdxT { typedef uint32_t type; };
+template <> struct IdxT<true> { typedef uint16_t type; };
+template <bool IX16>
 struct Lds {
+    typedef typename IdxT<IX16>::type idx_t;
     L3D_LDS volatile uint32_t* ring;   // [kRing]
-    L3D_LDS volatile uint32_t* cnt;    // [kBlock]
     L3D_LDS volatile float* minov;     // [kBlock]
     L3D_LDS volatile uint32_t* claim;  // [kBlock]
-    L3D_LDS volatile uint32_t* minpos; // [kBlock] slot of the worst entry of a full row
     L3D_LDS volatile float* top_ov;    // [kBlock*K]
-    L3D_LDS volatile uint32_t* top_ix; // [kBlock*K]
+    L3D_LDS volatile idx_t* cnt;       // [kBlock]
+    L3D_LDS volatile idx_t* minpos;    // [kBlock] slot of the worst entry of a full row
+    L3D_LDS volatile idx_t* top_ix;    // [kBlock*K]
 };
 
-__device__ __forceinline__ Lds carve(L3D_LDS char* base, uint32_t K) {
-    Lds l;
+template <bool IX16>
+__device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K) {
+    typedef typename IdxT<IX16>::type idx_t;
+    Lds<IX16> l;
     l.ring = (L3D_LDS volatile uint32_t*)base; base += kRing * sizeof(uint32_t);
-    l.cnt = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
     l.minov = (L3D_LDS volatile float*)base; base += kBlock * 4;
     l.claim = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
-    l.minpos = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
     l.top_ov = (L3D_LDS volatile float*)base; base += (size_t)kBlock * K * 4;
-    l.top_ix = (L3D_LDS volatile uint32_t*)base;
+    l.cnt = (L3D_LDS volatile idx_t*)base; base += kBlock * sizeof(idx_t);
+    l.minpos = (L3D_LDS volatile idx_t*)base; base += kBlock * sizeof(idx_t);
+    l.top_ix = (L3D_LDS volatile idx_t*)base;
     return l;
 }
 
@@ -101,7 +110,7 @@ __device__ __forceinline__ bool prefilter(float e1x, float e1y, float e1z, float
 // MODE 2: write every accepted match in ascending target order (kNN <= 0, pass 2)
 // BRUTE: skip the pre-filter (every pair goes through the exact test) -- on-GPU check that the
 //        pre-filter never loses a match.
-template <int MODE, bool BRUTE>
+template <int MODE, bool BRUTE, bool IX16>
 __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restrict__ views,
                                                            const PairDesc* __restrict__ pairs,
                                                            const WorkItem* __restrict__ work, uint32_t nwork,
@@ -122,7 +131,8 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
     const ViewDev& vs = views[pd.src];
     const ViewDev& vt = views[pd.tgt];
     const uint32_t K = pd.K, Ms = pd.Ms, Mt = pd.Mt;
-    Lds L = carve((L3D_LDS char*)smem, MODE == 0 ? K : 0);
+    typedef typename IdxT<IX16>::type idx_t;
+    Lds<IX16> L = carve<IX16>((L3D_LDS char*)smem, MODE == 0 ? K : 0);
     const uint32_t tid = threadIdx.x, lane = tid;
     L3D_LDS volatile uint32_t* ring = L.ring;
     // epipolar-band culling (kNN mode only: the keep-all rows must be filled in ascending target order)
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
     // worst entry of a full row under (overlap desc, tgt asc): pipelined (non-volatile) LDS reads
     auto rescan_worst = [&](uint32_t sl) {
         L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)sl * K;
-        L3D_LDS const uint32_t* ix = (L3D_LDS const uint32_t*)L.top_ix + (size_t)sl * K;
+        L3D_LDS const idx_t* ix = (L3D_LDS const idx_t*)L.top_ix + (size_t)sl * K;
         uint32_t wj = 0; float wo = ov[0]; uint32_t wx = ix[0];
         for (uint32_t j = 1; j < K; ++j) {
             const float o = ov[j]; const uint32_t x = ix[j];
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
                     L.cnt[sl] = c + 1;
                 } else {
                     L3D_LDS volatile float* ov = L.top_ov + (size_t)sl * K;
-                    L3D_LDS volatile uint32_t* ix = L.top_ix + (size_t)sl * K;
+                    L3D_LDS volatile idx_t* ix = L.top_ix + (size_t)sl * K;
                     if (c < K) {
                         ov[c] = res.overlap; ix[c] = tg;
                         L.cnt[sl] = c + 1;
@@ -350,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
     // rank the winners by (overlap desc, tgt asc); the overlaps are in LDS, the depths are recomputed
     // (identical arithmetic to the acceptance test, so identical values)
     L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)tid * K;
-    L3D_LDS const uint32_t* ix = (L3D_LDS const uint32_t*)L.top_ix + (size_t)tid * K;
+    L3D_LDS const idx_t* ix = (L3D_LDS const idx_t*)L.top_ix + (size_t)tid * K;
     const SegX sx = vs.segx[src];
     for (uint32_t j = 0; j < c; ++j) {
         const float oj = ov[j]; const uint32_t xj = ix[j];
@@ -368,27 +378,29 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
     for (uint32_t j = c; j < K; ++j) row[j] = empty;
 }
 
-size_t match_lds_bytes(int mode, uint32_t K) {
-    return kRing * 4 + 4 * kBlock * 4 + (mode == 0 ? (size_t)kBlock * K * 8 : 0);
+size_t match_lds_bytes(int mode, uint32_t K, bool ix16) {
+    const size_t ib = ix16 ? 2 : 4;
+    return kRing * 4 + 2 * kBlock * 4 + 2 * kBlock * ib + (mode == 0 ? (size_t)kBlock * K * (4 + ib) : 0);
 }
 
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,
                               const WorkItem* work, uint32_t nwork, uint32_t maxK, Slot* slots,
-                              uint32_t* row_counts, float thr, CullPools pools, hipStream_t stream) {
+                              uint32_t* row_counts, float thr, CullPools pools, bool ix16, hipStream_t stream) {
     if (nwork == 0) return hipSuccess;
     const uint32_t grid = ((nwork + 7) / 8) * 8;
-    const size_t lds = match_lds_bytes(mode, maxK);
-#define L3D_LAUNCH(M, B)                                                                                  \
+    if (!(mode == 0 && !brute)) ix16 = false;       // the compact layout is only instantiated for the hot variant
+    const size_t lds = match_lds_bytes(mode, maxK, ix16);
+#define L3D_LAUNCH(M, B, X)                                                                               \
     do {                                                                                                  \
-        hipError_t e = hipFuncSetAttribute((const void*)k_match_pairs<M, B>,                              \
+        hipError_t e = hipFuncSetAttribute((const void*)k_match_pairs<M, B, X>,                           \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
         if (e != hipSuccess) return e;                                                                    \
-        hipLaunchKernelGGL((k_match_pairs<M, B>), dim3(grid), dim3(kBlock), lds, stream, views, pairs,    \
-                           work, nwork, slots, row_counts, thr, pools);                                        \
+        hipLaunchKernelGGL((k_match_pairs<M, B, X>), dim3(grid), dim3(kBlock), lds, stream, views, pairs, \
+                           work, nwork, slots, row_counts, thr, pools);                                   \
     } while (0)
-    if (mode == 0) { if (brute) L3D_LAUNCH(0, true); else L3D_LAUNCH(0, false); }
-    else if (mode == 1) { if (brute) L3D_LAUNCH(1, true); else L3D_LAUNCH(1, false); }
-    else { if (brute) L3D_LAUNCH(2, true); else L3D_LAUNCH(2, false); }
+    if (mode == 0) { if (brute) L3D_LAUNCH(0, true, false); else if (ix16) L3D_LAUNCH(0, false, true); else L3D_LAUNCH(0, false, false); }
+    else if (mode == 1) { if (brute) L3D_LAUNCH(1, true, false); else L3D_LAUNCH(1, false, false); }
+    else { if (brute) L3D_LAUNCH(2, true, false); else L3D_LAUNCH(2, false, false); }
 #undef L3D_LAUNCH
     return hipGetLastError();
 }

@@ -630,7 +630,7 @@ static void collect_match_timing(l3d_ctx* c) {
 // enqueues (no host synchronisation) the cull set-up and the pair kernel for pairs [first, first+count)
 static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count, bool allow_split = false) {
     size_t n_work = 0;
-    uint32_t maxK = 0, maxM = 0;
+    uint32_t maxK = 0, maxM = 0, maxMt = 0;
     for (uint32_t p = first; p < first + count; ++p) n_work += (c->pairs[p].Ms + kMatchRows - 1) / kMatchRows;
     if (!n_work) return L3D_OK;
     L3D_HIP_CHECK(c->h_work.reserve(n_work));
@@ -640,6 +640,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         const PairDesc& pd = c->pairs[p];
         maxK = std::max(maxK, pd.K);
         if (c->cull[p].enabled) maxM = std::max(maxM, std::max(pd.Ms, pd.Mt));
+        maxMt = std::max(maxMt, pd.Mt);
         for (uint32_t s0 = 0; s0 < pd.Ms; s0 += kMatchRows) work[w++] = WorkItem{p, s0};
     }
     if (match_lds_bytes(mode, maxK) > 160 * 1024) return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
@@ -651,6 +652,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     if (mode != 0 || c->brute || !maxM) pools.cull = nullptr;
     else L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
     L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
+    const bool ix16 = maxMt < 65536u && maxK < 65536u;   // 16-bit indices in the kernel's LDS tables
     c->split_active = false;
     if (allow_split && mode == 0 && count >= 2 && std::getenv("L3D_NO_SPLIT") == nullptr) {
         // two halves by cost on two streams; ev[5] / ev[3] are recorded by l3d_match_finish once both are done
@@ -668,16 +670,16 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         L3D_HIP_CHECK(hipStreamWaitEvent(c->aux[0], c->sev[0], 0));
         L3D_HIP_CHECK(hipStreamWaitEvent(c->aux[1], c->sev[0], 0));
         L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work1,
-                                         maxK, c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, c->aux[0]));
+                                         maxK, c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, ix16, c->aux[0]));
         L3D_HIP_CHECK(hipEventRecord(c->sev[1], c->aux[0]));
         L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p + n_work1,
                                          (uint32_t)(n_work - n_work1), maxK, c->d_slots.p, c->d_row_counts.p,
-                                         c->epipolar_overlap, pools, c->aux[1]));
+                                         c->epipolar_overlap, pools, ix16, c->aux[1]));
         L3D_HIP_CHECK(hipEventRecord(c->sev[2], c->aux[1]));
         c->split_active = true; c->split_pair = ps;
     } else {
         L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work,
-                                         maxK, c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, c->stream));
+                                         maxK, c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, ix16, c->stream));
         L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));
     }
     if (pools.cull)
@@ -1618,7 +1620,7 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
             L3D_HIP_CHECK(launch_cull_prepare(dv.p, dp.p, 0, 1, std::max(Ms, Mt), pools, 0));
         }
         L3D_HIP_CHECK(launch_match_pairs(0, false, dv.p, dp.p, dw.p, (uint32_t)work.size(), pd.K, ds.p, nullptr, thr,
-                                         pools, 0));
+                                         pools, Mt < 65536u && pd.K < 65536u, 0));
         L3D_HIP_CHECK(hipDeviceSynchronize());
         L3D_HIP_CHECK(hipMemcpy(out_slots, ds.p, (size_t)Ms * pd.K * sizeof(Slot), hipMemcpyDeviceToHost));
         return L3D_OK;

@@ -36,12 +36,12 @@ struct CullPools {
 constexpr uint32_t kCullMaxSegs = 16384;   // LDS sort capacity of k_cull_prepare
 
 // ---- k_match.hip ----
-size_t match_lds_bytes(int mode, uint32_t K);
+size_t match_lds_bytes(int mode, uint32_t K, bool ix16 = false);
 hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
                                uint32_t max_M, CullPools pools, hipStream_t stream);
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,
                               const WorkItem* work, uint32_t nwork, uint32_t maxK, Slot* slots,
-                              uint32_t* row_counts, float thr, CullPools pools, hipStream_t stream);
+                              uint32_t* row_counts, float thr, CullPools pools, bool ix16, hipStream_t stream);
 hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, hipStream_t stream);
 
 // ---- k_rdd.hip ----
