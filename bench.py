@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C1", help="BASELINE config: C1 | C2 | C3 | C4")
+    ap.add_argument("--config", default="C1", help="BASELINE config: C0 | C1 | C2 | C3 | C4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
     args = ap.parse_args()
@@ -172,8 +172,11 @@ def main():
             "metric": "M segment-pair scores/sec", "value": round(value, 2), "unit": "M segment-pair scores/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"{args.config}: synthetic {cfg['n_views']} views x {cfg['n_segs']} segments/view, "
+            "data": "synthetic" if args.config != "C0" else "reference testdata (recovered cameras)",
+            "config": {"workload": (f"{args.config}: synthetic {cfg['n_views']} views x {cfg['n_segs']} segments/view, "
+                                    if args.config != "C0" else
+                                    "C0: the reference's bundled testdata (26 images, cameras recovered from its result "
+                                    "fixture, the 406-919 LSD segments per view that occur in it), ") +
                                    f"{cfg['n_neighbors']} visual neighbours, kNN=10, sigma_p=2.5px, sigma_a=10deg, "
                                    f"epipolar_overlap=0.25; matchImages + affinity fill",
                        "pair_tests_per_step": pair_tests, "directed_pairs": len(pairs),

@@ -13,6 +13,8 @@ within 10 deg of vertical, ~11 % within 10 deg of horizontal).
 """
 from dataclasses import dataclass, field
 
+import os
+
 import numpy as np
 
 WIDTH, HEIGHT, FOCAL = 3072, 2304, 2400.0
@@ -176,8 +178,12 @@ def make_scene(n_views, n_segs, n_neighbors=10, seed=0x4C334450, real_fraction=0
     return Scene(views, name or f"ring{n_views}x{n_segs}n{n_neighbors}")
 
 
-# BASELINE.json configs (C0 is blocked: testdata/vsfm_result.nvm is missing from the reference)
+# BASELINE.json configs.  C0 = the reference's bundled testdata (26 images): its SfM input vsfm_result.nvm is not
+# part of the reference checkout, so the cameras were recovered from the reference's own result fixture by line-based
+# resection and the 2D segments are those that occur in that result (tests/golden/make_real_scene.py).
+C0_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "real_scene_c0.npz")
 CONFIGS = {
+    "C0": dict(n_views=26, n_segs=670, n_neighbors=10),   # n_segs: average; 406-919 per view
     "C1": dict(n_views=64, n_segs=2000, n_neighbors=10),
     "C2": dict(n_views=256, n_segs=4096, n_neighbors=20),
     "C3": dict(n_views=1024, n_segs=1000, n_neighbors=10, rings=2, radius=22.0),
@@ -185,6 +191,20 @@ CONFIGS = {
 }
 
 
+def load_scene_npz(path, name=""):
+    """scene stored by tests/golden/make_real_scene.py: cameras, per-view segments, neighbours, median depths"""
+    d = np.load(path)
+    views = []
+    for i, cam in enumerate(d["cam"]):
+        a, b = int(d["seg_off"][i]), int(d["seg_off"][i + 1])
+        nb = [int(x) for x in d["nb"][int(d["nb_off"][i]):int(d["nb_off"][i + 1])]]
+        views.append(ViewData(int(cam), d["segs"][a:b].astype(np.float32), d["K"][i].copy(), d["R"][i].copy(), d["t"][i].copy(),
+                              int(d["width"]), int(d["height"]), float(d["median_depth"][i]), nb))
+    return Scene(views, name or os.path.basename(path))
+
+
 def make_config(name, seed=None):
-    idx = list(CONFIGS).index(name) + 1
+    if name == "C0":
+        return load_scene_npz(C0_FILE, "C0")
+    idx = list(CONFIGS).index(name)
     return make_scene(seed=(0x4C334450 + idx) if seed is None else seed, name=name, **CONFIGS[name])

@@ -680,3 +680,48 @@ def test_txt_writer_matches_accessor_and_reference_writer(tmp_path):
             for p, q in zip(L["segments"], R["segments"]):
                 qs = np.concatenate([q[3:], q[:3]])
                 assert min(np.abs(p - q).max(), np.abs(p - qs).max()) <= 30.0 * H.REL_TOL
+
+
+def test_real_testdata_c0_parity_and_fixture_plausibility():
+    """BASELINE config C0 (the reference's bundled testdata; cameras recovered from its result fixture,
+    tests/golden/make_real_scene.py): full pipeline of the HIP path against the oracle on real LSD segments and
+    real geometry; final 3D lines against the reference's own code; most of the fixture's published lines re-found."""
+    from line3dpp_amd.scene import make_config, C0_FILE
+    from oracle import oracle as O
+    sc = make_config("C0")
+    g = _gpu(sc)
+    assert g.matchImages() and g.reconstruct3Dlines(3)
+    assert g.timings()["culled_pairs"] > 0.8 * len(g.pairs()[0])
+    o = _oracle(sc, threads=16)
+    o.match_images(); o.compute_affinity()
+    worst, n = 0.0, 0
+    for v in sc.views:
+        r = H.compare_matches(g.matches(v.cam)[0], o.matches(v.cam)[0])
+        assert not r["missing"] and not r["extra"], (v.cam, r["missing"][:3], r["extra"][:3])
+        worst = max(worst, r["max_rel"]); n += r["n_cpu"]
+    assert n > 50000 and worst < H.REL_TOL
+    ge, gl, _ = g.affinity(); oe, ol = o.affinity()
+    assert len(ge) == len(oe) > 20000 and np.array_equal(ge["i"], oe["i"]) and np.array_equal(ge["j"], oe["j"])
+    assert np.max(np.abs(ge["w"] - oe["w"]) / oe["w"]) < H.REL_TOL
+    lines = g.get3Dlines()
+    mine = [frozenset(map(tuple, np.stack([L["residuals"]["cam"], L["residuals"]["seg"]], 1).tolist())) for L in lines]
+    if O.have_reference():
+        r = O.Oracle(threads=1, reference=True)
+        r.add_scene(sc); r.match_images(); r.reconstruct(3)
+        theirs = [frozenset(map(tuple, np.asarray(L["residuals"]).reshape(-1, 2).tolist())) for L in r.lines()]
+        assert set(mine) == set(theirs) and len(mine) == len(theirs)
+    d = np.load(C0_FILE)
+    inv = {}
+    for i, m in enumerate(mine):
+        for x in m:
+            inv.setdefault(x, set()).add(i)
+    off, res = d["fixture_res_off"], d["fixture_res"]
+    found = 0
+    for k in range(len(off) - 1):
+        f = [tuple(x) for x in res[off[k]:off[k + 1]].tolist()]
+        cnt = {}
+        for x in f:
+            for i in inv.get(x, ()):
+                cnt[i] = cnt.get(i, 0) + 1
+        found += bool(cnt) and max(cnt.values()) >= 0.6 * len(f)
+    assert len(lines) > 1500 and found > 0.6 * (len(off) - 1), (len(lines), found)
