@@ -736,3 +736,33 @@ def test_real_testdata_c0_parity_and_fixture_plausibility():
             dist.append(min(np.abs(p - f).max(), np.abs(p - np.concatenate([f[3:], f[:3]])).max()))
     # scene extent ~5 units: a median of 3e-4 is 6e-5 relative -- with cameras that were themselves estimated
     assert len(dist) > 900 and np.median(dist) < 1e-3 and np.percentile(dist, 90) < 5e-3, (len(dist), np.median(dist))
+
+
+def test_real_testdata_c0_collinearity_and_diffusion():
+    """The widened rows on real data (BASELINE C0): collinear links (collinearity_t = 2 px, real fragmented LSD
+    segments) against the reference's own code, matrix diffusion against the restatement."""
+    from line3dpp_amd.api import diffuse_affinity
+    from line3dpp_amd.scene import make_config
+    from oracle import oracle as O
+    sc = make_config("C0")
+    g = _gpu(sc)
+    assert g.matchImages() and g.computeAffinity()
+    e0, l0, _ = g.affinity()
+    ref = O.Oracle.rdd(e0, len(l0))
+    out = diffuse_affinity(e0, len(l0))
+    assert np.array_equal(out["i"], ref["i"]) and np.array_equal(out["j"], ref["j"])
+    assert np.max(np.abs(out["w"] - ref["w"]) / ref["w"]) < H.REL_TOL
+    assert g.reconstruct3Dlines(3, False, 2.0)
+    ge, gl, _ = g.affinity()
+    assert len(ge) > len(e0)                                   # real collinear fragments add links
+    o = _oracle(sc, threads=1)
+    o.match_images(); o.set_collinearity(2.0); o.compute_affinity()
+    oe, ol = o.affinity()
+    assert len(ge) == len(oe) and np.array_equal(ge["i"], oe["i"]) and np.array_equal(ge["j"], oe["j"])
+    assert np.array_equal(np.stack([gl["cam"], gl["seg"]], 1), ol)
+    if O.have_reference():
+        r = O.Oracle(threads=1, reference=True)
+        r.add_scene(sc); r.match_images(); r.reconstruct(3, 2.0)
+        key = lambda res: frozenset(map(tuple, np.asarray(res).reshape(-1, 2).tolist()))
+        mine = {key(np.stack([L["residuals"]["cam"], L["residuals"]["seg"]], 1)) for L in g.get3Dlines()}
+        assert mine == {key(L["residuals"]) for L in r.lines()}
