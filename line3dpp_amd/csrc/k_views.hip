@@ -159,6 +159,7 @@ __device__ __forceinline__ d3 entry_dir(const double* C, const SegX& sx, float d
 //           descriptor fields of each DEntry are written;
 //   phase 2 (fp64 work, full lanes): unprojection + regularisers of every hypothesis.
 constexpr uint32_t kKeyCap = 512;   // per-wave LDS copy of the inverse sort keys
+constexpr uint32_t kDescCap = 192;  // fast path: whole list staged in LDS (keys + 20-byte descriptors)
 __global__ __launch_bounds__(256) void k_build_lists_all(uint32_t G, const ViewDev* __restrict__ views,
                                                          const PairDesc* __restrict__ pairs,
                                                          const uint32_t* __restrict__ seg_base,
@@ -170,16 +171,102 @@ __global__ __launch_bounds__(256) void k_build_lists_all(uint32_t G, const ViewD
                                                          const InvRef* __restrict__ refs,
                                                          const Slot* __restrict__ slots, DEntry* __restrict__ dents,
                                                          uint32_t* __restrict__ eref, uint32_t uniform_K) {
-    __shared__ uint64_t s_key[4][kKeyCap];
+    // per wave: kKeyCap sort keys (general path) or kDescCap keys + kDescCap 20-byte descriptors (fast path)
+    constexpr uint32_t kWaveWords = (kDescCap * 28 + 7) / 8 > kKeyCap ? (kDescCap * 28 + 7) / 8 : kKeyCap;
+    __shared__ uint64_t s_mem[4][kWaveWords];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    uint64_t (&s_key)[4][kWaveWords] = s_mem;
     const uint32_t g = blockIdx.x * 4 + wave;
     if (g >= G) return;
     const uint32_t b = off[g], L = off[g + 1] - b;
     if (L == 0) return;
     const uint32_t vi = gseg_view[g], seg = g - seg_base[vi];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    // ---- phase 1a: inverse hypotheses ----
     const uint32_t ib = inv_off[g], n_inv = inv_off[g + 1] - ib;
+    // ---- fast path (bounded kNN, list fits LDS, at most 128 own slots): the two gather chains (inverse refs ->
+    // pair -> slot, outgoing pair -> slot) are issued back to back, the descriptors go through LDS instead of a
+    // global write + read-back, and every entry is written to global memory exactly once (coalesced) ----
+    if (uniform_K && L <= kDescCap) {
+        const uint32_t q0 = vout_off[vi], T = (vout_off[vi + 1] - q0) * uniform_K;
+        if (T <= 128) {
+            uint64_t* keys = s_mem[wave];
+            uint32_t* d_ref = (uint32_t*)(keys + kDescCap);
+            float* d_dp1 = (float*)(d_ref + kDescCap);
+            float* d_dp2 = d_dp1 + kDescCap;
+            uint32_t* d_tv = (uint32_t*)(d_dp2 + kDescCap);
+            uint32_t* d_pf = d_tv + kDescCap;                 // pair | inverse << 31
+            // own slots: loads first (up to two per lane)
+            Slot sA{}, sB{};
+            uint32_t piA = 0, tvA = 0, piB = 0, tvB = 0, refA = 0, refB = 0;
+            bool aA = false, aB = false;
+            if (lane < T) {
+                piA = vout_pairs[q0 + lane / uniform_K];
+                const PairDesc& pd = pairs[piA];
+                tvA = pd.tgt; refA = (uint32_t)(pd.slot_off + (uint64_t)seg * uniform_K + lane % uniform_K);
+                sA = slots[refA];
+                aA = sA.tgt_seg != kEmpty && (sA.flags & kSlotAlive);
+            }
+            if (64 + lane < T) {
+                piB = vout_pairs[q0 + (64 + lane) / uniform_K];
+                const PairDesc& pd = pairs[piB];
+                tvB = pd.tgt; refB = (uint32_t)(pd.slot_off + (uint64_t)seg * uniform_K + (64 + lane) % uniform_K);
+                sB = slots[refB];
+                aB = sB.tgt_seg != kEmpty && (sB.flags & kSlotAlive);
+            }
+            // inverse refs: keys to LDS, rank = canonical position
+            for (uint32_t m0 = 0; m0 < n_inv; m0 += 64)
+                if (m0 + lane < n_inv) {
+                    const InvRef r = refs[ib + m0 + lane];
+                    keys[m0 + lane] = ((uint64_t)r.src_view << 32) | r.src_row;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (uint32_t m0 = 0; m0 < n_inv; m0 += 64)
+                if (m0 + lane < n_inv) {
+                    const InvRef r = refs[ib + m0 + lane];
+                    const uint64_t key = ((uint64_t)r.src_view << 32) | r.src_row;
+                    uint32_t rank = 0;
+                    for (uint32_t j = 0; j < n_inv; ++j) rank += (keys[j] < key) ? 1u : 0u;
+                    const PairDesc& pd = pairs[r.pair];
+                    const uint32_t ref = (uint32_t)(pd.slot_off + (uint64_t)r.src_row * pd.K + r.j);
+                    const Slot s = slots[ref];
+                    d_ref[rank] = ref; d_dp1[rank] = s.dq1; d_dp2[rank] = s.dq2; d_tv[rank] = r.src_view;
+                    d_pf[rank] = r.pair | 0x80000000u;
+                }
+            // own slots: compaction by ballot prefix (ascending (target view, slot) order)
+            uint32_t pos = n_inv;
+            {
+                const uint64_t m = __ballot(aA);
+                if (aA) {
+                    const uint32_t k = pos + (uint32_t)__popcll(m & lt_mask);
+                    d_ref[k] = refA; d_dp1[k] = sA.dp1; d_dp2[k] = sA.dp2; d_tv[k] = tvA; d_pf[k] = piA;
+                }
+                pos += (uint32_t)__popcll(m);
+                const uint64_t m2 = __ballot(aB);
+                if (aB) {
+                    const uint32_t k = pos + (uint32_t)__popcll(m2 & lt_mask);
+                    d_ref[k] = refB; d_dp1[k] = sB.dp1; d_dp2[k] = sB.dp2; d_tv[k] = tvB; d_pf[k] = piB;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const ViewDev& v = views[vi];
+            const SegX sx = v.segx[seg];
+            for (uint32_t m0 = 0; m0 < L; m0 += 64) {
+                const uint32_t i = m0 + lane;
+                if (i < L) {
+                    const uint32_t pf = d_pf[i], tv = d_tv[i];
+                    dents[b + i] = make_dentry(v, views[tv], sx, d_dp1[i], d_dp2[i], d_ref[i], tv, pf & 0x7FFFFFFFu,
+                                               (pf >> 31) != 0);
+                    eref[b + i] = d_ref[i];
+                }
+            }
+            return;
+        }
+    }
+    // ---- phase 1a: inverse hypotheses ----
     const bool keys_in_lds = n_inv <= kKeyCap;
     if (keys_in_lds) {
         for (uint32_t m0 = 0; m0 < n_inv; m0 += 64)
