@@ -858,22 +858,42 @@ static int match_finish_impl(l3d_ctx* c) {
     L3D_HIP_CHECK(launch_scan(c->d_bits_len.p, G, c->d_boff.p, c->d_scan_tmp.p, c->d_scal.p + 6, st));
     uint32_t tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     L3D_HIP_CHECK(hipMemcpyAsync(tot, c->d_scal.p, 8 * 4, hipMemcpyDeviceToHost, st));
-    g_trace.mark("pre-pass enqueued, waiting for sizes");
+    // The list kernels only need buffers sized by bounds the host already knows (every slot yields at most one own
+    // and one inverse hypothesis), so they are enqueued BEFORE the totals are read back: the host round trip that
+    // sizes the support bitsets hides behind them.  (If the bound-sized buffers cannot be had, read first.)
+    L3D_HIP_CHECK(c->d_positive.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    L3D_HIP_CHECK(hipMemsetAsync(c->d_positive.p, 0, std::max<uint64_t>(c->n_slots, 1), st));
+    const uint64_t ents_bound = std::max<uint64_t>(2 * c->n_slots, 1), inv_bound = std::max<uint64_t>(c->n_slots, 1);
+    bool lists_enqueued = false;
+    auto enqueue_lists = [&]() -> int {
+        L3D_HIP_CHECK(launch_inv_fill(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_inv_off.p,
+                                      c->d_inv_pos.p, c->d_refs.p, st));
+        L3D_HIP_CHECK(launch_build_lists_all(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p,
+                                             c->d_vout_off.p, c->d_vout_pairs.p, c->d_off.p, c->d_inv_off.p, c->d_refs.p,
+                                             c->d_slots.p, c->d_dents.p, c->d_eref.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, st));
+        return L3D_OK;
+    };
+    if (c->d_dents.reserve(ents_bound) == hipSuccess && c->d_eref.reserve(ents_bound) == hipSuccess &&
+        c->d_refs.reserve(inv_bound) == hipSuccess) {
+        const int rc = enqueue_lists();
+        if (rc) return rc;
+        lists_enqueued = true;
+    } else {
+        (void)hipGetLastError();
+    }
+    g_trace.mark("pre-pass + lists enqueued, waiting for sizes");
     L3D_HIP_CHECK(hipStreamSynchronize(st));   // first point at which the host waits for the GPU in matchImages
     g_trace.mark("sizes known");
     const uint32_t n_ents = c->n_ents = tot[0], n_inv = tot[5], n_words = tot[6];
     c->tm.list_entries = n_ents; c->tm.support_words = n_words;
-    L3D_HIP_CHECK(c->d_dents.reserve(std::max<uint32_t>(n_ents, 1)));
-    L3D_HIP_CHECK(c->d_refs.reserve(std::max<uint32_t>(n_inv, 1)));
     L3D_HIP_CHECK(c->d_bits.reserve(std::max<uint32_t>(n_words, 1)));
-    L3D_HIP_CHECK(c->d_eref.reserve(std::max<uint32_t>(n_ents, 1)));
-    L3D_HIP_CHECK(c->d_positive.reserve(std::max<uint64_t>(c->n_slots, 1)));
-    L3D_HIP_CHECK(hipMemsetAsync(c->d_positive.p, 0, std::max<uint64_t>(c->n_slots, 1), st));
-    L3D_HIP_CHECK(launch_inv_fill(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_inv_off.p,
-                                  c->d_inv_pos.p, c->d_refs.p, st));
-    L3D_HIP_CHECK(launch_build_lists_all(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p,
-                                         c->d_vout_off.p, c->d_vout_pairs.p, c->d_off.p, c->d_inv_off.p, c->d_refs.p,
-                                         c->d_slots.p, c->d_dents.p, c->d_eref.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, st));
+    if (!lists_enqueued) {
+        L3D_HIP_CHECK(c->d_dents.reserve(std::max<uint32_t>(n_ents, 1)));
+        L3D_HIP_CHECK(c->d_refs.reserve(std::max<uint32_t>(n_inv, 1)));
+        L3D_HIP_CHECK(c->d_eref.reserve(std::max<uint32_t>(n_ents, 1)));
+        const int rc = enqueue_lists();
+        if (rc) return rc;
+    }
     const SimConst simc = sim_thresholds(c->two_sigA_sqr);
     // lists too long for one wave's LDS staging: one workgroup each, before the pipeline (chain independent)
     L3D_HIP_CHECK(launch_support_long(tot[7], c->d_long_list.p, c->d_off.p, c->d_boff.p, c->d_dents.p, c->d_bits.p,
