@@ -217,6 +217,12 @@ int l3d_get_segment_coords2d(l3d_ctx*, uint32_t camID, uint32_t segID, float coo
 int l3d_save_result_stl(l3d_ctx*, const char* output_folder, int max_image_width);
 int l3d_save_result_obj(l3d_ctx*, const char* output_folder, int max_image_width);
 
+/* Replaces the body of View::findCollinGPU (view.cc:173-209; find_collinear_segments_GPU, cudawrapper.h:66-68) with
+ * the semantics of View::findCollinCPU (view.cc:213-258).  Host pointers.  CSR output: offsets[M+1] and, if
+ * cap >= *n, idx[*n] (ascending lists; call with idx = NULL first to learn *n). */
+int l3d_find_collinear_segments(int device, const float* lines4, uint32_t M, float dist_t, uint32_t* offsets,
+                                uint32_t* idx, uint64_t cap, uint64_t* n);
+
 /* Replaces the body of Line3D::performRDD (line3D.cc:2026-2076): SparseMatrix(A_, n) +
  * replicator_dynamics_diffusion_GPU (cudawrapper.h:74-75, cudawrapper.cu:708-766: row normalisation + 10
  * diffusion steps P' = P o (P W)^T with the reference's lockstep row/column walk) + the min(w12, w21)

@@ -269,3 +269,19 @@ def diffuse_affinity(edges, n_rows, iterations=10, device=0):
     if rc != 0:
         raise RuntimeError(f"l3d_diffuse_affinity failed [{rc}]: {_lib.last_error()}")
     return out
+
+
+def find_collinear_segments(lines, dist_t, device=0):
+    """Seam-level call replacing View::findCollinGPU / find_collinear_segments_GPU (view.cc:173-209) with the
+    semantics of View::findCollinCPU: CSR (offsets[M+1], idx) of the collinear segments of every segment."""
+    L = _lib.load()
+    a = np.ascontiguousarray(lines, np.float32).reshape(-1, 4)
+    off = np.zeros(len(a) + 1, np.uint32)
+    n = C.c_uint64()
+    rc = L.l3d_find_collinear_segments(device, ptr(a), len(a), float(dist_t), ptr(off), None, 0, C.byref(n))
+    idx = np.zeros(max(n.value, 1), np.uint32)
+    if rc == 0 and n.value:
+        rc = L.l3d_find_collinear_segments(device, ptr(a), len(a), float(dist_t), ptr(off), ptr(idx), n.value, C.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"l3d_find_collinear_segments failed [{rc}]: {_lib.last_error()}")
+    return off, idx[:n.value]

@@ -1579,6 +1579,48 @@ int l3d_diffuse_affinity(int device, const l3d_cledge* edges, uint32_t n_edges, 
     return L3D_OK;
 }
 
+// Replaces the body of View::findCollinGPU (view.cc:173-209) / find_collinear_segments_GPU (cudawrapper.h:66-68) with
+// the semantics of View::findCollinCPU (view.cc:213-258): for every segment the ascending list of the segments of
+// the same image that are collinear to it (no overlap along the line, all four point-to-line distances < dist_t).
+// CSR output: offsets[M+1]; idx receives the lists if cap >= *n (call once with idx = nullptr to size it).
+int l3d_find_collinear_segments(int device, const float* lines4, uint32_t M, float dist_t, uint32_t* offsets,
+                                uint32_t* idx, uint64_t cap, uint64_t* n) {
+    if ((!lines4 && M) || !offsets || !n) return fail(L3D_ERR_ARG, "null argument");
+    *n = 0;
+    for (uint32_t i = 0; i <= M; ++i) offsets[i] = 0;
+    if (!M || !(dist_t > (float)kEps)) return L3D_OK;                       // view.cc:158: nothing to do
+    if (hipSetDevice(device) != hipSuccess) return fail(L3D_ERR_HIP, "hipSetDevice failed: no usable HIP device");
+    DevBuf<float4> seg4; DevBuf<ViewDev> dv; DevBuf<uint32_t> base, cnt, off, tmp, tot, lists;
+    auto cleanup = [&]() { seg4.release(); dv.release(); base.release(); cnt.release(); off.release(); tmp.release();
+                           tot.release(); lists.release(); };
+    const int rc = [&]() -> int {
+        L3D_HIP_CHECK(seg4.reserve(M)); L3D_HIP_CHECK(dv.reserve(1)); L3D_HIP_CHECK(base.reserve(2));
+        L3D_HIP_CHECK(cnt.reserve(M + 1)); L3D_HIP_CHECK(off.reserve(M + 1)); L3D_HIP_CHECK(tmp.reserve(M / 4096 + 1024));
+        L3D_HIP_CHECK(tot.reserve(1));
+        L3D_HIP_CHECK(hipMemcpy(seg4.p, lines4, (size_t)M * 16, hipMemcpyHostToDevice));
+        ViewDev hv{};
+        hv.seg4 = seg4.p; hv.M = M;
+        const uint32_t hb[2] = {0, M};
+        L3D_HIP_CHECK(hipMemcpy(dv.p, &hv, sizeof(hv), hipMemcpyHostToDevice));
+        L3D_HIP_CHECK(hipMemcpy(base.p, hb, sizeof(hb), hipMemcpyHostToDevice));
+        L3D_HIP_CHECK(launch_collin(0, dv.p, 1, M, base.p, dist_t, cnt.p, nullptr, nullptr, 0));
+        L3D_HIP_CHECK(launch_scan(cnt.p, M, off.p, tmp.p, tot.p, 0));
+        uint32_t total = 0;
+        L3D_HIP_CHECK(hipMemcpy(&total, tot.p, 4, hipMemcpyDeviceToHost));
+        L3D_HIP_CHECK(hipMemcpy(offsets, off.p, ((size_t)M + 1) * 4, hipMemcpyDeviceToHost));
+        *n = total;
+        if (idx && cap >= total && total) {
+            L3D_HIP_CHECK(lists.reserve(total));
+            L3D_HIP_CHECK(launch_collin(1, dv.p, 1, M, base.p, dist_t, nullptr, off.p, lists.p, 0));
+            L3D_HIP_CHECK(hipDeviceSynchronize());
+            L3D_HIP_CHECK(hipMemcpy(idx, lists.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+        }
+        return L3D_OK;
+    }();
+    cleanup();
+    return rc;
+}
+
 int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const float* lines_tgt4, uint32_t Mt,
                     const double F[9], const double RtKinv_src[9], const double RtKinv_tgt[9], const double C_src[3],
                     const double C_tgt[3], uint32_t width, uint32_t height, float epi_overlap, int32_t kNN,

@@ -738,6 +738,25 @@ def test_real_testdata_c0_parity_and_fixture_plausibility():
     assert len(dist) > 900 and np.median(dist) < 1e-3 and np.percentile(dist, 90) < 5e-3, (len(dist), np.median(dist))
 
 
+def test_seam_level_find_collinear_segments():
+    """l3d_find_collinear_segments (replaces View::findCollinGPU, view.cc:173-209) against View::findCollinCPU of
+    the oracle, on real LSD segments (BASELINE C0) and on a split synthetic view."""
+    from line3dpp_amd.api import find_collinear_segments
+    from line3dpp_amd.scene import make_config
+    for sc, t in ((make_config("C0"), 2.0), (H.split_scene(make_scene(3, 500, n_neighbors=2, seed=91)), 6.0)):
+        o = _oracle(sc, threads=8)
+        o.match_images(); o.set_collinearity(t); o.compute_affinity()
+        total = 0
+        for v in sc.views[:4]:
+            off, idx = find_collinear_segments(v.segs, t)
+            ooff, oidx = o.collinear(v.cam, len(v.segs))
+            assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+            total += len(idx)
+        assert total > 20
+    off, idx = find_collinear_segments(sc.views[0].segs, -1.0)      # disabled: empty lists
+    assert not off.any() and len(idx) == 0
+
+
 def test_real_testdata_c0_collinearity_and_diffusion():
     """The widened rows on real data (BASELINE C0): collinear links (collinearity_t = 2 px, real fragmented LSD
     segments) against the reference's own code, matrix diffusion against the restatement."""
