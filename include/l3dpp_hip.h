@@ -217,6 +217,15 @@ int l3d_get_segment_coords2d(l3d_ctx*, uint32_t camID, uint32_t segID, float coo
 int l3d_save_result_stl(l3d_ctx*, const char* output_folder, int max_image_width);
 int l3d_save_result_obj(l3d_ctx*, const char* output_folder, int max_image_width);
 
+/* Replaces score_matches_GPU (cudawrapper.h:70-73; caller Line3D::scoringGPU, line3D.cc:1297-1414) with the
+ * semantics of Line3D::scoringCPU (line3D.cc:1208-1294): score3D of every match of one view.  Host pointers,
+ * arrays as scoringGPU marshals them: matches4[n] = (src segment, target camera, depth_p1, depth_p2), grouped per
+ * segment and by target camera inside a segment (sortMatches); ranges2[M] = (first, last) inclusive, (-1,-1) if
+ * none; reg_tgt2[n] = View::regularizerFrom3Dpoint of the two 3D end points in the target view; k = View::k(). */
+int l3d_score_matches(int device, const float* lines4, uint32_t M, const float* matches4, const int32_t* ranges2,
+                      const float* reg_tgt2, uint32_t n, const double RtKinv[9], const double C[3], float two_sigA_sqr,
+                      float k, float* scores);
+
 /* Replaces the body of View::findCollinGPU (view.cc:173-209; find_collinear_segments_GPU, cudawrapper.h:66-68) with
  * the semantics of View::findCollinCPU (view.cc:213-258).  Host pointers.  CSR output: offsets[M+1] and, if
  * cap >= *n, idx[*n] (ascending lists; call with idx = NULL first to learn *n). */

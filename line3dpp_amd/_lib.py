@@ -47,7 +47,7 @@ EXPORTS = [
     "l3d_get_sparse_matrix", "l3d_get_timings", "l3d_match_lines", "l3d_set_brute_force", "l3d_slots_exchanged",
     "l3d_reconstruct_3d_lines", "l3d_num_3d_lines", "l3d_get_3d_lines", "l3d_diffuse_affinity",
     "l3d_output_filename", "l3d_save_3d_lines_txt", "l3d_save_result_stl", "l3d_save_result_obj",
-    "l3d_get_segment_coords2d", "l3d_find_collinear_segments",
+    "l3d_get_segment_coords2d", "l3d_find_collinear_segments", "l3d_score_matches",
 ]
 
 _lib = None
@@ -103,6 +103,7 @@ def load():
     L.l3d_save_result_obj.argtypes = [vp, C.c_char_p, i32]
     L.l3d_get_segment_coords2d.argtypes = [vp, u32, u32, vp]
     L.l3d_find_collinear_segments.argtypes = [i32, vp, u32, f32, vp, vp, u64, vp]
+    L.l3d_score_matches.argtypes = [i32, vp, u32, vp, vp, vp, u32, vp, vp, f32, f32, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("l3d_last_error", "l3d_build_info", "l3d_create", "l3d_destroy"):

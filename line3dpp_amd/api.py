@@ -285,3 +285,20 @@ def find_collinear_segments(lines, dist_t, device=0):
     if rc != 0:
         raise RuntimeError(f"l3d_find_collinear_segments failed [{rc}]: {_lib.last_error()}")
     return off, idx[:n.value]
+
+
+def score_matches(lines, matches4, ranges2, reg_tgt2, RtKinv, C_, two_sigA_sqr, k, device=0):
+    """Seam-level call replacing score_matches_GPU (cudawrapper.h:70-73) with the semantics of Line3D::scoringCPU;
+    arrays as Line3D::scoringGPU marshals them (see include/l3dpp_hip.h)."""
+    L = _lib.load()
+    a = np.ascontiguousarray(lines, np.float32).reshape(-1, 4)
+    m = np.ascontiguousarray(matches4, np.float32).reshape(-1, 4)
+    r = np.ascontiguousarray(ranges2, np.int32).reshape(-1, 2)
+    g = np.ascontiguousarray(reg_tgt2, np.float32).reshape(-1, 2)
+    A = np.ascontiguousarray(RtKinv, np.float64); Cc = np.ascontiguousarray(C_, np.float64)
+    out = np.zeros(len(m), np.float32)
+    rc = L.l3d_score_matches(device, ptr(a), len(a), ptr(m), ptr(r), ptr(g), len(m), ptr(A), ptr(Cc),
+                             float(two_sigA_sqr), float(k), ptr(out))
+    if rc != 0:
+        raise RuntimeError(f"l3d_score_matches failed [{rc}]: {_lib.last_error()}")
+    return out

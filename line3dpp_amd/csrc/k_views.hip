@@ -1048,6 +1048,61 @@ hipError_t launch_support_long(uint32_t n_long, const uint32_t* long_list, const
                        sc, 0u, long_list);
     return hipGetLastError();
 }
+// ---- seam-level scoring (l3d_score_matches): one view, every match present -----------------------------
+// list entries from the marshalled arrays of Line3D::scoringGPU (line3D.cc:1330-1352): matches4 = (src segment,
+// target camera, depth_p1, depth_p2), reg_tgt2 = View::regularizerFrom3Dpoint of the two 3D end points in the
+// target view; regularisers as scoringCPU combines them (line3D.cc:1233-1248)
+__global__ void k_seam_entries(uint32_t n, const float4* __restrict__ m4, const float2* __restrict__ rt,
+                               const ViewDev* __restrict__ views, float k, DEntry* __restrict__ dents) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 m = m4[i];
+    const float2 r = rt[i];
+    const uint32_t seg = (uint32_t)m.x;
+    const ViewDev& v = views[0];
+    const Seg3 s3 = unproject(v.C, v.segx[seg].r1, v.segx[seg].r2, m.z, m.w);
+    const float sig1 = m.z * k, sig2 = m.w * k;
+    DEntry d;
+    d.ref = i; d.dp1 = m.z; d.dp2 = m.w;
+    d.reg1 = 0.5f * (2.0f * sig1 * sig1 + 2.0f * r.x * r.x);
+    d.reg2 = 0.5f * (2.0f * sig2 * sig2 + 2.0f * r.y * r.y);
+    d.score3D = 0.0f;
+    d.tgt_view = (uint32_t)m.y;
+    d.flags = kDInverse | (s3.length < kEps ? kDZeroLen : 0u);   // kDInverse: k_score_all must not touch a slot buffer
+    d.pair = 0;
+    dents[i] = d;
+}
+// presence mask = every hypothesis of the list
+__global__ void k_seam_all_present(uint32_t G, const uint32_t* __restrict__ off, const uint32_t* __restrict__ boff,
+                                   uint64_t* __restrict__ bits) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const uint32_t L = off[g + 1] - off[g];
+    if (!L) return;
+    const uint32_t W = (L + 63) / 64;
+    uint64_t* P = bits + boff[g] + (size_t)L * W;
+    for (uint32_t w = 0; w < W; ++w) P[w] = (w + 1 < W || (L & 63u) == 0) ? ~0ull : ((1ull << (L & 63u)) - 1ull);
+}
+__global__ void k_seam_scores_out(uint32_t n, const DEntry* __restrict__ dents, float* __restrict__ scores) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) scores[i] = dents[i].score3D;
+}
+hipError_t launch_seam_entries(uint32_t n, const float4* m4, const float2* rt, const ViewDev* views, float k,
+                               DEntry* dents, hipStream_t st) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_seam_entries, dim3((n + 255) / 256), dim3(256), 0, st, n, m4, rt, views, k, dents);
+    return hipGetLastError();
+}
+hipError_t launch_seam_all_present(uint32_t G, const uint32_t* off, const uint32_t* boff, uint64_t* bits, hipStream_t st) {
+    if (!G) return hipSuccess;
+    hipLaunchKernelGGL(k_seam_all_present, dim3((G + 255) / 256), dim3(256), 0, st, G, off, boff, bits);
+    return hipGetLastError();
+}
+hipError_t launch_seam_scores_out(uint32_t n, const DEntry* dents, float* scores, hipStream_t st) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_seam_scores_out, dim3((n + 255) / 256), dim3(256), 0, st, n, dents, scores);
+    return hipGetLastError();
+}
 hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff,
                                 const uint32_t* inv_off, const uint32_t* eref, uint64_t* bits, uint8_t* positive,
                                 hipStream_t st) {

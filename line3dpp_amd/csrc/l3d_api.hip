@@ -31,6 +31,9 @@ hipError_t launch_aff_coll_sim(int mode, uint32_t n_items, const uint32_t* surv_
                                const uint32_t* gseg_view, const uint32_t* coll_off, const uint32_t* coll_idx,
                                const uint32_t* item_off, const ViewAff*, const float* medians, const float* msdl,
                                float two_sigA_sqr, uint32_t* out_seg, float* out_sim, hipStream_t);
+hipError_t launch_seam_entries(uint32_t n, const float4* m4, const float2* rt, const ViewDev*, float k, DEntry*, hipStream_t);
+hipError_t launch_seam_all_present(uint32_t G, const uint32_t* off, const uint32_t* boff, uint64_t* bits, hipStream_t);
+hipError_t launch_seam_scores_out(uint32_t n, const DEntry*, float* scores, hipStream_t);
 hipError_t launch_fill_gseg_view(const uint32_t* seg_base, uint32_t V, uint32_t max_M, uint32_t* gseg_view, hipStream_t);
 hipError_t launch_orient_all(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
                              const uint32_t* seg_base, Slot* slots, uint32_t G, unsigned long long* cnt_pack,
@@ -1615,6 +1618,77 @@ int l3d_find_collinear_segments(int device, const float* lines4, uint32_t M, flo
             L3D_HIP_CHECK(hipDeviceSynchronize());
             L3D_HIP_CHECK(hipMemcpy(idx, lists.p, (size_t)total * 4, hipMemcpyDeviceToHost));
         }
+        return L3D_OK;
+    }();
+    cleanup();
+    return rc;
+}
+
+// Replaces score_matches_GPU (cudawrapper.h:70-73; caller Line3D::scoringGPU, line3D.cc:1297-1414) with the
+// semantics of Line3D::scoringCPU (line3D.cc:1208-1294): score3D of every match of ONE view.  Inputs as scoringGPU
+// marshals them: lines4[M]; matches4[n] = (src segment, target camera, depth_p1, depth_p2) grouped per segment
+// and, inside a segment, by target camera (sortMatches); ranges2[M] = (first, last) inclusive or (-1, -1);
+// reg_tgt2[n] = the two View::regularizerFrom3Dpoint values; RtKinv / C of the view in double (translated frame).
+int l3d_score_matches(int device, const float* lines4, uint32_t M, const float* matches4, const int32_t* ranges2,
+                      const float* reg_tgt2, uint32_t n, const double RtKinv[9], const double C[3], float two_sigA_sqr,
+                      float k, float* scores) {
+    if ((!lines4 && M) || ((!matches4 || !reg_tgt2 || !scores) && n) || (!ranges2 && M) || !RtKinv || !C)
+        return fail(L3D_ERR_ARG, "null argument");
+    if (!M || !n) return L3D_OK;
+    std::vector<uint32_t> off((size_t)M + 1);
+    {
+        uint32_t next = 0;
+        for (uint32_t i = 0; i < M; ++i) {
+            const int32_t a = ranges2[2 * i], b = ranges2[2 * i + 1];
+            if (a >= 0) {
+                if ((uint32_t)a != next || b < a || (uint32_t)b >= n) return fail(L3D_ERR_ARG, "ranges are not a partition of the matches");
+                off[i] = (uint32_t)a; next = (uint32_t)b + 1;
+            } else off[i] = next;
+        }
+        off[M] = next;
+        if (next != n) return fail(L3D_ERR_ARG, "ranges do not cover the matches");
+    }
+    if (hipSetDevice(device) != hipSuccess) return fail(L3D_ERR_HIP, "hipSetDevice failed: no usable HIP device");
+    DevBuf<float4> seg4, m4; DevBuf<float2> rt; DevBuf<SegF> segf; DevBuf<SegX> segx; DevBuf<ViewDev> dv;
+    DevBuf<uint32_t> d_off, d_boff, d_len, d_tmp, d_scal, d_gv, d_long, d_max; DevBuf<DEntry> dents; DevBuf<uint64_t> bits;
+    DevBuf<float> d_scores;
+    auto cleanup = [&]() { seg4.release(); m4.release(); rt.release(); segf.release(); segx.release(); dv.release();
+                           d_off.release(); d_boff.release(); d_len.release(); d_tmp.release(); d_scal.release();
+                           d_gv.release(); d_long.release(); d_max.release(); dents.release(); bits.release();
+                           d_scores.release(); };
+    const int rc = [&]() -> int {
+        L3D_HIP_CHECK(seg4.reserve(M)); L3D_HIP_CHECK(segf.reserve(M)); L3D_HIP_CHECK(segx.reserve(M));
+        L3D_HIP_CHECK(m4.reserve(n)); L3D_HIP_CHECK(rt.reserve(n)); L3D_HIP_CHECK(dv.reserve(1));
+        L3D_HIP_CHECK(d_off.reserve(M + 1)); L3D_HIP_CHECK(d_boff.reserve(M + 1)); L3D_HIP_CHECK(d_len.reserve(M + 1));
+        L3D_HIP_CHECK(d_tmp.reserve(M / 4096 + 1024)); L3D_HIP_CHECK(d_scal.reserve(4)); L3D_HIP_CHECK(d_gv.reserve(M + 1));
+        L3D_HIP_CHECK(d_long.reserve(M + 1)); L3D_HIP_CHECK(d_max.reserve(2)); L3D_HIP_CHECK(dents.reserve(n));
+        L3D_HIP_CHECK(d_scores.reserve(n));
+        L3D_HIP_CHECK(hipMemcpy(seg4.p, lines4, (size_t)M * 16, hipMemcpyHostToDevice));
+        L3D_HIP_CHECK(hipMemcpy(m4.p, matches4, (size_t)n * 16, hipMemcpyHostToDevice));
+        L3D_HIP_CHECK(hipMemcpy(rt.p, reg_tgt2, (size_t)n * 8, hipMemcpyHostToDevice));
+        L3D_HIP_CHECK(hipMemcpy(d_off.p, off.data(), ((size_t)M + 1) * 4, hipMemcpyHostToDevice));
+        L3D_HIP_CHECK(hipMemset(d_gv.p, 0, ((size_t)M + 1) * 4));
+        L3D_HIP_CHECK(hipMemset(d_scal.p, 0, 16)); L3D_HIP_CHECK(hipMemset(d_max.p, 0, 8));
+        ViewDev hv{};
+        std::memcpy(hv.C, C, 24); std::memcpy(hv.RtKinv, RtKinv, 72);
+        hv.seg4 = seg4.p; hv.segf = segf.p; hv.segx = segx.p; hv.M = M; hv.k = k;
+        L3D_HIP_CHECK(hipMemcpy(dv.p, &hv, sizeof(hv), hipMemcpyHostToDevice));
+        L3D_HIP_CHECK(launch_prep_views(dv.p, 1, M, 0));
+        L3D_HIP_CHECK(launch_seam_entries(n, m4.p, rt.p, dv.p, k, dents.p, 0));
+        L3D_HIP_CHECK(launch_bits_len(M, d_off.p, d_len.p, d_long.p, d_scal.p + 1, 0));
+        L3D_HIP_CHECK(launch_scan(d_len.p, M, d_boff.p, d_tmp.p, d_scal.p + 0, 0));
+        uint32_t tot[2] = {0, 0};
+        L3D_HIP_CHECK(hipMemcpy(tot, d_scal.p, 8, hipMemcpyDeviceToHost));
+        L3D_HIP_CHECK(bits.reserve(std::max<uint32_t>(tot[0], 1)));
+        const SimConst simc = sim_thresholds(two_sigA_sqr);
+        L3D_HIP_CHECK(launch_support_long(tot[1], d_long.p, d_off.p, d_boff.p, dents.p, bits.p, dv.p, d_gv.p, simc, 0));
+        L3D_HIP_CHECK(launch_support_all(0, M, d_off.p, d_boff.p, dents.p, bits.p, dv.p, nullptr, d_gv.p, simc, 0));
+        L3D_HIP_CHECK(launch_seam_all_present(M, d_off.p, d_boff.p, bits.p, 0));
+        L3D_HIP_CHECK(launch_score_all(0, M, d_off.p, d_boff.p, d_gv.p, dents.p, bits.p, nullptr, d_max.p, dv.p, nullptr,
+                                       simc, 0));
+        L3D_HIP_CHECK(launch_seam_scores_out(n, dents.p, d_scores.p, 0));
+        L3D_HIP_CHECK(hipDeviceSynchronize());
+        L3D_HIP_CHECK(hipMemcpy(scores, d_scores.p, (size_t)n * 4, hipMemcpyDeviceToHost));
         return L3D_OK;
     }();
     cleanup();

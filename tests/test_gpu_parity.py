@@ -738,6 +738,42 @@ def test_real_testdata_c0_parity_and_fixture_plausibility():
     assert len(dist) > 900 and np.median(dist) < 1e-3 and np.percentile(dist, 90) < 5e-3, (len(dist), np.median(dist))
 
 
+def test_seam_level_score_matches():
+    """l3d_score_matches (replaces score_matches_GPU / Line3D::scoringGPU's kernel, line3D.cc:1297-1414) against the
+    scores Line3D::scoringCPU gives the same lists in the oracle (scored lists = fresh + inverse matches of a view)."""
+    from line3dpp_amd.api import score_matches
+    sc = make_scene(8, 300, n_neighbors=4, seed=95)
+    o = _oracle(sc, record_scored=True)
+    o.match_images()
+    ks = {v.cam: o.view_info(v.cam)["k"] for v in sc.views}
+    Cs = {v.cam: -v.R.T @ v.t for v in sc.views}
+    checked = total = 0
+    for v in sc.views[1:]:                        # views with inverse matches in their lists
+        m, off = o.scored(v.cam)
+        A = v.R.T @ np.linalg.inv(v.K)
+        rows, ranges, regs, want = [], [], [], []
+        for s_ in range(len(v.segs)):
+            seg = m[off[s_]:off[s_ + 1]]
+            seg = seg[np.argsort(seg["tgt_cam"], kind="stable")]          # sortMatches: grouped by target camera
+            ranges.append((len(rows), len(rows) + len(seg) - 1) if len(seg) else (-1, -1))
+            for r in seg:
+                p1 = np.array([v.segs[s_][0], v.segs[s_][1], 1.0]); p2 = np.array([v.segs[s_][2], v.segs[s_][3], 1.0])
+                r1 = A @ p1; r1 /= np.linalg.norm(r1); r2 = A @ p2; r2 /= np.linalg.norm(r2)
+                P1 = Cs[v.cam] + r1 * float(r["d_p1"]); P2 = Cs[v.cam] + r2 * float(r["d_p2"])
+                t = int(r["tgt_cam"])
+                regs.append((np.float32(np.linalg.norm(P1 - Cs[t]) * float(ks[t])), np.float32(np.linalg.norm(P2 - Cs[t]) * float(ks[t]))))
+                rows.append((s_, t, r["d_p1"], r["d_p2"])); want.append(r["score3D"])
+        got = score_matches(v.segs, rows, ranges, regs, A, Cs[v.cam], 200.0, ks[v.cam])
+        want = np.array(want, np.float32)
+        assert len(got) == len(want)
+        total += len(got)
+        assert np.array_equal(got > 0, want > 0)
+        nz = want > 0
+        assert np.max(np.abs(got[nz] - want[nz]) / want[nz]) < 1e-3       # reg_tgt recomputed in numpy (float32 inputs)
+        checked += int(nz.sum())
+    assert checked > 200 and total > 5000
+
+
 def test_seam_level_find_collinear_segments():
     """l3d_find_collinear_segments (replaces View::findCollinGPU, view.cc:173-209) against View::findCollinCPU of
     the oracle, on real LSD segments (BASELINE C0) and on a split synthetic view."""
