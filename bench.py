@@ -160,8 +160,7 @@ def main():
                 "frac": round(achieved / 8000.0, 6), "traffic": traffic, "algorithmic_bytes": algo_bytes,
                 "kernel": "k_match_pairs<0,false>", "kernel_ms": round(avg_ms, 4),
                 "kernel_pair_tests_per_s": round(my_tests / (avg_ms * 1e-3), 1) if avg_ms > 0 else 0.0,
-                "note": "VALU/latency bound by design (<0.2 B per pair test), see DESIGN.md roofline; at 1 GPU phase A runs as "
-                        "two concurrent half launches and kernel_ms is the span of that region", "valu": valu}
+                "note": "VALU/latency bound by design (<0.2 B per pair test), see DESIGN.md roofline", "valu": valu}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

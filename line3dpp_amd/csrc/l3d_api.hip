@@ -657,8 +657,11 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
     const bool ix16 = maxMt < 65536u && maxK < 65536u;   // 16-bit indices in the kernel's LDS tables
     c->split_active = false;
-    if (allow_split && mode == 0 && count >= 2 && std::getenv("L3D_NO_SPLIT") == nullptr) {
-        // two halves by cost on two streams; ev[5] / ev[3] are recorded by l3d_match_finish once both are done
+    if (allow_split && mode == 0 && count >= 2 && std::getenv("L3D_SPLIT_PHASE_A") != nullptr) {
+        // opt-in (L3D_SPLIT_PHASE_A=1): two halves by cost on two streams, the first with priority, so that its
+        // orientation pass overlaps the tail of the second (-2 % step time on C1).  Off by default so that one
+        // launch covers all pairs and its event-timed duration is directly comparable with a rocprofv3 trace.
+        // ev[5] / ev[3] are recorded by l3d_match_finish once both halves are done
         uint64_t total = 0, acc = 0;
         for (uint32_t p = first; p < first + count; ++p) total += (uint64_t)c->pairs[p].Ms * c->pairs[p].Mt;
         uint32_t ps = first; size_t n_work1 = 0;
