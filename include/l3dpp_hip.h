@@ -124,6 +124,17 @@ int l3d_match_pairs(l3d_ctx*, uint32_t first, uint32_t count);
 int l3d_slot_buffer(l3d_ctx*, void** dev_ptr, uint64_t* n_slots);
 /* tell the context that the caller's exchange has filled in the slots of all other pairs */
 int l3d_slots_exchanged(l3d_ctx*);
+/* Compact form of the same exchange (kNN > 0): only the target index of every slot travels (4 B instead of 32);
+ * overlap and depths are functions of (pair, source row, target index) and are re-derived on the receiving rank by
+ * the match kernel's own device functions, bit-identically.
+ *   l3d_pack_slot_indices    slots of the rank's own pairs [first, first+count) -> index buffer (returns when done)
+ *   (all-gather of the u32 index buffer l3d_slot_index_buffer() returns, by the caller)
+ *   l3d_expand_slot_indices  index buffer -> slots of the foreign pairs [first, first+count); marks them matched
+ * Replaces the host-side gather of per-view match lists a multi-GPU run of the reference would need between
+ * matchingCPU and the per-view chain (line3D.cc:728-773). */
+int l3d_slot_index_buffer(l3d_ctx*, void** dev_ptr, uint64_t* n_slots);
+int l3d_pack_slot_indices(l3d_ctx*, uint32_t first, uint32_t count);
+int l3d_expand_slot_indices(l3d_ctx*, uint32_t first, uint32_t count);
 int l3d_match_finish(l3d_ctx*);
 
 /* The affinity part of Line3D::reconstruct3Dlines: translate(), med_scene_depth_lines_,

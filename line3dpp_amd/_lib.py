@@ -48,6 +48,7 @@ EXPORTS = [
     "l3d_reconstruct_3d_lines", "l3d_num_3d_lines", "l3d_get_3d_lines", "l3d_diffuse_affinity",
     "l3d_output_filename", "l3d_save_3d_lines_txt", "l3d_save_result_stl", "l3d_save_result_obj",
     "l3d_get_segment_coords2d", "l3d_find_collinear_segments", "l3d_score_matches",
+    "l3d_slot_index_buffer", "l3d_pack_slot_indices", "l3d_expand_slot_indices",
 ]
 
 _lib = None
@@ -93,6 +94,9 @@ def load():
                                   C.POINTER(u64)]
     L.l3d_set_brute_force.argtypes = [vp, i32]
     L.l3d_slots_exchanged.argtypes = [vp]
+    L.l3d_slot_index_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.l3d_pack_slot_indices.argtypes = [vp, u32, u32]
+    L.l3d_expand_slot_indices.argtypes = [vp, u32, u32]
     L.l3d_reconstruct_3d_lines.argtypes = [vp, u32, i32, f32, i32, u32]
     L.l3d_num_3d_lines.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.l3d_get_3d_lines.argtypes = [vp, vp, vp, vp, vp, vp, vp]

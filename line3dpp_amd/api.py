@@ -174,6 +174,19 @@ class Line3D:
         self.L.l3d_slot_buffer(self.h, C.byref(p), C.byref(n))
         return p.value, n.value
 
+    def slot_index_buffer(self):
+        """device pointer of the compact exchange buffer (uint32 target index per slot) and its length"""
+        p = C.c_void_p(); n = C.c_uint64()
+        if not self._check(self.L.l3d_slot_index_buffer(self.h, C.byref(p), C.byref(n)), "slot_index_buffer"):
+            return None, 0
+        return p.value, n.value
+
+    def packSlotIndices(self, first, count):
+        return self._check(self.L.l3d_pack_slot_indices(self.h, int(first), int(count)), "packSlotIndices")
+
+    def expandSlotIndices(self, first, count):
+        return self._check(self.L.l3d_expand_slot_indices(self.h, int(first), int(count)), "expandSlotIndices")
+
     def pair_tests(self):
         n = C.c_uint64()
         self.L.l3d_pair_tests(self.h, C.byref(n))

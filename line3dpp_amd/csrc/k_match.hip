@@ -405,6 +405,64 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
     return hipGetLastError();
 }
 
+// ---- compact slot exchange (N > 1 ranks) ---------------------------------------------------------------------
+// Between ranks only the target index of every slot travels (4 B instead of the 32-byte record): overlap and
+// depths are functions of (pair, source row, target index) alone, so the receiving rank re-derives them with the
+// device functions the match kernel itself uses (exact_overlap / exact_depths, l3d_dev.h).
+__global__ __launch_bounds__(256) void k_pack_slot_idx(const Slot* __restrict__ slots, uint32_t* __restrict__ idx,
+                                                       uint64_t lo, uint64_t hi) {
+    const uint64_t i = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < hi) idx[i] = slots[i].tgt_seg;
+}
+
+// grid (ceil(max Ms*K / 256), pairs): one thread per slot of pair first + blockIdx.y
+__global__ __launch_bounds__(256) void k_expand_slot_idx(const ViewDev* __restrict__ views,
+                                                         const PairDesc* __restrict__ pairs, uint32_t first,
+                                                         const uint32_t* __restrict__ idx, Slot* __restrict__ slots) {
+    const PairDesc& pd = pairs[first + blockIdx.y];
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= pd.Ms * pd.K) return;
+    const uint32_t row = s / pd.K;
+    const uint64_t at = pd.slot_off + s;
+    const uint32_t tg = idx[at];
+    Slot o;
+    o.tgt_seg = tg; o.overlap = 0; o.dp1 = o.dp2 = o.dq1 = o.dq2 = 0; o.score3D = 0.0f; o.flags = 0;
+    if (tg != kEmpty && tg < pd.Mt) {
+        const ViewDev& vs = views[pd.src];
+        const ViewDev& vt = views[pd.tgt];
+        double F[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) F[i] = pd.F[i];
+        const float4 s4 = vs.seg4[row], t4 = vt.seg4[tg];
+        o.overlap = exact_overlap(F, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w);
+        PairResult res{};
+        exact_depths(vs.segx[row], vt.segx[tg], vs.C, vt.C, res);
+        o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
+    } else {
+        o.tgt_seg = kEmpty;
+    }
+    slots[at] = o;
+}
+
+hipError_t launch_pack_slot_idx(const Slot* slots, uint32_t* idx, uint64_t lo, uint64_t hi, hipStream_t stream) {
+    if (hi <= lo) return hipSuccess;
+    const uint64_t blocks = (hi - lo + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pack_slot_idx, dim3((uint32_t)blocks), dim3(256), 0, stream, slots, idx, lo, hi);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_slot_idx(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
+                                  uint32_t max_row_slots, const uint32_t* idx, Slot* slots, hipStream_t stream) {
+    if (!max_row_slots) return hipSuccess;
+    for (uint32_t p0 = 0; p0 < count; p0 += 65535u) {
+        const uint32_t n = count - p0 < 65535u ? count - p0 : 65535u;
+        hipLaunchKernelGGL(k_expand_slot_idx, dim3((max_row_slots + 255) / 256, n), dim3(256), 0, stream, views, pairs,
+                           first + p0, idx, slots);
+    }
+    return hipGetLastError();
+}
+
 // ---- epipolar-band culling: order the source rows and the target segments of each pair by tau ------------
 namespace {
 

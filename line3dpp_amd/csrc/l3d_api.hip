@@ -119,6 +119,7 @@ struct l3d_ctx {
     DevBuf<PairDesc> d_pairs;
     DevBuf<WorkItem> d_work;
     DevBuf<Slot> d_slots;
+    DevBuf<uint32_t> d_slot_idx;   // compact exchange form of d_slots (N > 1 ranks): target index per slot
     // epipolar-band culling pools (l3d_kernels.h)
     std::vector<PairCull> cull;
     DevBuf<PairCull> d_cull;
@@ -425,7 +426,7 @@ void l3d_destroy(l3d_ctx* c) {
         HostView& v = *kv.second;
         v.d_seg4.release(); v.d_segf.release();
     }
-    c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release();
+    c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release(); c->d_slot_idx.release();
     c->h_views.release(); c->h_pairs.release(); c->h_cull.release(); c->h_work.release(); c->h_vout.release();
     c->h_small.release(); c->h_cnt.release();
     c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
@@ -752,6 +753,65 @@ int l3d_slot_buffer(l3d_ctx* c, void** dev_ptr, uint64_t* n_slots) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
     if (dev_ptr) *dev_ptr = c->d_slots.p;
     if (n_slots) *n_slots = c->n_slots;
+    return L3D_OK;
+}
+
+// ---- compact exchange (N > 1 ranks): 4 B per slot travel instead of 32 --------------------------------------------
+int l3d_slot_index_buffer(l3d_ctx* c, void** dev_ptr, uint64_t* n_slots) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (c->state != l3d_ctx::BEGUN) return fail(L3D_ERR_STATE, "l3d_match_begin must precede l3d_slot_index_buffer");
+    if (c->kNN <= 0) return fail(L3D_ERR_LIMIT, "the compact exchange needs kNN > 0 (fixed rows)");
+    (void)hipSetDevice(c->device);
+    L3D_HIP_CHECK(c->d_slot_idx.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    if (dev_ptr) *dev_ptr = c->d_slot_idx.p;
+    if (n_slots) *n_slots = c->n_slots;
+    return L3D_OK;
+}
+
+static int check_exchange_range(l3d_ctx* c, uint32_t first, uint32_t count, const char* who) {
+    if (c->state != l3d_ctx::BEGUN) return fail(L3D_ERR_STATE, std::string("l3d_match_begin must precede ") + who);
+    if (c->kNN <= 0) return fail(L3D_ERR_LIMIT, "the compact exchange needs kNN > 0 (fixed rows)");
+    if ((uint64_t)first + count > c->pairs.size()) return fail(L3D_ERR_ARG, "pair range out of bounds");
+    return L3D_OK;
+}
+
+// target indices of the slots of pairs [first, first+count) -> index buffer; returns when they are there, so that
+// a collective on another stream (RCCL runs on its own) may read them
+int l3d_pack_slot_indices(l3d_ctx* c, uint32_t first, uint32_t count) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    int rc = check_exchange_range(c, first, count, "l3d_pack_slot_indices");
+    if (rc) return rc;
+    for (uint32_t p = first; p < first + count; ++p)
+        if (!c->pair_done[p]) return fail(L3D_ERR_STATE, "l3d_pack_slot_indices: pair not matched on this rank");
+    (void)hipSetDevice(c->device);
+    L3D_HIP_CHECK(c->d_slot_idx.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    if (!count) return L3D_OK;
+    const uint64_t lo = c->pairs[first].slot_off;
+    const PairDesc& last = c->pairs[first + count - 1];
+    const uint64_t hi = last.slot_off + (uint64_t)last.Ms * last.K;
+    L3D_HIP_CHECK(launch_pack_slot_idx(c->d_slots.p, c->d_slot_idx.p, lo, hi, c->stream));
+    L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return L3D_OK;
+}
+
+// index buffer -> full slot records for pairs [first, first+count) (received from their owning ranks); the pairs
+// then count as matched.  Enqueued on the context's stream: l3d_match_finish follows in order.
+int l3d_expand_slot_indices(l3d_ctx* c, uint32_t first, uint32_t count) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    int rc = check_exchange_range(c, first, count, "l3d_expand_slot_indices");
+    if (rc) return rc;
+    if (!c->d_slot_idx.p) return fail(L3D_ERR_STATE, "l3d_expand_slot_indices: no index buffer");
+    if (!count) return L3D_OK;
+    (void)hipSetDevice(c->device);
+    uint32_t max_row_slots = 0;
+    for (uint32_t p = first; p < first + count; ++p)
+        max_row_slots = std::max<uint64_t>(max_row_slots, (uint64_t)c->pairs[p].Ms * c->pairs[p].K);
+    L3D_HIP_CHECK(launch_expand_slot_idx(c->d_views.p, c->d_pairs.p, first, count, max_row_slots, c->d_slot_idx.p,
+                                         c->d_slots.p, c->stream));
+    for (uint32_t p = first; p < first + count; ++p) c->pair_done[p] = 1;
     return L3D_OK;
 }
 

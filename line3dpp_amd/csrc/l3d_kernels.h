@@ -42,6 +42,10 @@ hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,
                               const WorkItem* work, uint32_t nwork, uint32_t maxK, Slot* slots,
                               uint32_t* row_counts, float thr, CullPools pools, bool ix16, hipStream_t stream);
+// compact exchange of slots between ranks: target indices out, full records back (bit-identical re-derivation)
+hipError_t launch_pack_slot_idx(const Slot* slots, uint32_t* idx, uint64_t lo, uint64_t hi, hipStream_t stream);
+hipError_t launch_expand_slot_idx(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
+                                  uint32_t max_row_slots, const uint32_t* idx, Slot* slots, hipStream_t stream);
 hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, hipStream_t stream);
 
 // ---- k_rdd.hip ----

@@ -3,14 +3,18 @@
 Phase A (Line3D::matchingCPU per directed view pair, line3D.cc:728-735) reads only static per-view
 arrays, so the directed pairs are independent units: every rank holds all views (<= 34 MB even for
 the largest BASELINE config), matches a contiguous, cost-balanced range of the pair list, and the
-ranks then exchange their slices of the fixed-layout slot buffer (32-byte l3d_slot records) with an
-all-gather over RCCL/xGMI.  Phase B (the per-view chain, line3D.cc:745-773) is order dependent in
+ranks then exchange their slices of the fixed-layout slot buffer with an all-gather over RCCL/xGMI -- in
+compact form: only the uint32 target index of every slot travels (4 B instead of the 32-byte l3d_slot
+record), the receiving rank re-derives overlap and depths with the match kernel's own device functions
+(l3d_pack_slot_indices / l3d_expand_slot_indices; L3D_EXCHANGE_FULL=1 sends the full records instead).  Phase B (the per-view chain, line3D.cc:745-773) is order dependent in
 ascending camID and is replicated on every rank after the exchange (SURVEY.md §8e option 1).
 
 The exchange is written as one in-place broadcast per owning rank: slices are uneven, and
 `ncclBroadcast` of a slice of the one shared buffer is the all-gather(v) primitive RCCL offers.
 Works with backend "nccl" (= RCCL, device buffers) and "gloo" (CPU tensors, used by the tests).
 """
+import os
+
 import numpy as np
 
 
@@ -80,6 +84,13 @@ def device_tensor(ptr, nbytes, device):
     return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
 
 
+def _wait_for_exchange(buf, device):
+    """the collective runs on the backend's own stream: the library's stream must not touch `buf` before it is done"""
+    if buf.is_cuda:
+        import torch
+        torch.cuda.synchronize(device)
+
+
 def match_images_sharded(l3d, rank, world_size, device=None, group=None, **params):
     """matchImages with phase A sharded over `world_size` ranks.  `l3d` is a line3dpp_amd.Line3D that
     already holds all views (every rank adds the same views)."""
@@ -94,13 +105,29 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, **param
     first, count = ranges[rank]
     if count and not l3d.matchPairs(first, count):
         return False
-    if world_size > 1:
+    n_pairs = len(pairs)
+    if params.get("kNN", 10) > 0 and os.environ.get("L3D_EXCHANGE_FULL") is None:
+        # compact exchange: 4 B per slot (the target index) travel; the rest of a slot is re-derived on arrival
+        if count and not l3d.packSlotIndices(first, count):
+            return False
+        ptr, n_slots = l3d.slot_index_buffer()
+        if ptr is None:
+            return False
+        if n_slots:
+            buf = device_tensor(ptr, n_slots * 4, device)
+            exchange_slots(buf, slot_byte_ranges(ranges, slot_off, n_slots, slot_bytes=4), group)
+            _wait_for_exchange(buf, device)
+        ok = (first == 0 or l3d.expandSlotIndices(0, first)) and \
+             (first + count == n_pairs or l3d.expandSlotIndices(first + count, n_pairs - first - count))
+        if not ok:
+            return False
+    else:
+        # full records (L3D_EXCHANGE_FULL=1; always for the keep-all mode kNN <= 0)
         ptr, n_slots = l3d.slot_buffer()
         if n_slots:
             buf = device_tensor(ptr, n_slots * 32, device)
             exchange_slots(buf, slot_byte_ranges(ranges, slot_off, n_slots), group)
-            import torch
-            torch.cuda.synchronize(device)
+            _wait_for_exchange(buf, device)
         # every pair is now present on this rank
         l3d.L.l3d_slots_exchanged(l3d.h)
     return l3d.matchFinish()

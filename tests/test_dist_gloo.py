@@ -1,5 +1,5 @@
 """world_size-2 (and 3) gloo test of the N>1 path's host logic: pair sharding + in-place all-gather(v)
-of slot-buffer slices (line3dpp_amd/dist.py).  The slot contents come from the oracle (tests may use
+of slot-buffer slices, as full 32-byte records and in the compact 4-byte form (line3dpp_amd/dist.py).  The slot contents come from the oracle (tests may use
 it): each rank fills only the slices of its own pairs, the exchange must reproduce the buffer a single
 process would have produced."""
 import os
@@ -42,6 +42,68 @@ def _slots_from_oracle(scene, kNN):
     return full, offs, n, pairs, M
 
 
+class _StubLine3D:
+    """stands in for line3dpp_amd.Line3D (no GPU here): records what match_images_sharded asks of it and keeps the
+    compact index buffer in host memory"""
+
+    def __init__(self, pairs, offs, n_slots, M, idx_full):
+        self.pairs_, self.offs, self.n_slots, self._M = np.asarray(pairs), np.asarray(offs, np.uint64), n_slots, M
+        self.truth = idx_full.view(np.uint32)
+        self.idx = np.zeros(n_slots, np.uint32)
+        self.done = np.zeros(len(pairs), bool)
+        self.matched, self.log = [], []
+        self.L, self.h = self, None
+
+    def matchBegin(self, **kw):
+        self.log.append("begin"); return True
+
+    def pairs(self):
+        return self.pairs_, self.offs
+
+    def _span(self, first, count):
+        end = list(map(int, self.offs)) + [self.n_slots]
+        return end[first], end[first + count]
+
+    def matchPairs(self, first, count):
+        self.matched.append((first, count)); self.done[first:first + count] = True; return True
+
+    def packSlotIndices(self, first, count):
+        if not self.done[first:first + count].all():
+            return False
+        lo, hi = self._span(first, count)
+        self.idx[lo:hi] = self.truth[lo:hi]
+        return True
+
+    def slot_index_buffer(self):
+        return self.idx, self.n_slots
+
+    def expandSlotIndices(self, first, count):
+        lo, hi = self._span(first, count)
+        if not np.array_equal(self.idx[lo:hi], self.truth[lo:hi]):
+            return False
+        self.done[first:first + count] = True
+        return True
+
+    def matchFinish(self):
+        self.log.append("finish")
+        return bool(self.done.all())
+
+
+def _sharded_control_flow(dist, rank, world, pairs, offs, n_slots, M, idx_full):
+    """match_images_sharded end to end over gloo with the stub: own range matched and packed, every foreign pair
+    expanded from what the exchange delivered, finish only after that"""
+    stub = _StubLine3D(pairs, offs, n_slots, M, idx_full)
+    real = dist.device_tensor
+    dist.device_tensor = lambda arr, nbytes, device: torch.from_numpy(arr.view(np.uint8))[:nbytes]
+    try:
+        ok = dist.match_images_sharded(stub, rank, world, device=None, kNN=5)
+    finally:
+        dist.device_tensor = real
+    ranges = dist.pair_ranges([M[s] * M[t] for s, t in pairs], world)
+    return bool(ok) and stub.matched == [ranges[rank]] and stub.log == ["begin", "finish"] and \
+        np.array_equal(stub.idx, stub.truth)
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     from line3dpp_amd import dist
@@ -65,6 +127,18 @@ def _worker(rank, world, port, q):
         how = dist.exchange_slots(buf, br)
         ok = bool(np.array_equal(buf.numpy(), full)) and how == ("all_gather" if world == 2 else "broadcast")
         covered = sum(h - l for l, h in br) == len(full)
+        # the compact form the product exchanges by default: the uint32 target index of every slot
+        from line3dpp_amd._lib import SLOT_DTYPE
+        idx_full = np.ascontiguousarray(full.view(SLOT_DTYPE)["tgt_seg"]).view(np.uint8)
+        br4 = dist.slot_byte_ranges(ranges, offs, n_slots, slot_bytes=4)
+        mine4 = np.zeros_like(idx_full)
+        lo, hi = br4[rank]
+        mine4[lo:hi] = idx_full[lo:hi]
+        buf4 = torch.from_numpy(mine4)
+        how4 = dist.exchange_slots(buf4, br4)
+        ok = ok and bool(np.array_equal(buf4.numpy(), idx_full)) and how4 == how
+        covered = covered and sum(h - l for l, h in br4) == len(idx_full) == 4 * n_slots
+        ok = ok and _sharded_control_flow(dist, rank, world, pairs, offs, n_slots, M, idx_full)
         q.put((rank, ok, covered, [c for _, c in ranges]))
     finally:
         dist_t.destroy_process_group()

@@ -634,6 +634,61 @@ def test_sharded_phase_a_emulated_on_one_gpu(world):
         assert ge.tobytes() == re_.tobytes() and gl.tobytes() == rl.tobytes()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_compact_exchange_emulated_on_one_gpu(world):
+    """The default N>1 exchange (line3dpp_amd/dist.py): only the uint32 target index of every slot travels and the
+    receiving context re-derives the 32-byte records (l3d_pack_slot_indices / l3d_expand_slot_indices).  `world`
+    contexts on one GPU; the index slices are copied where the all-gather would put them.  The expanded slot buffer
+    must equal, byte for byte, the one a single context produces, and so must the final matches and affinities."""
+    import torch
+    from line3dpp_amd import dist
+    sc = H.split_scene(make_scene(9, 350, n_neighbors=4, seed=83))
+    for i, v in enumerate(sc.views):                 # ragged views: uneven slices
+        v.segs = v.segs[:len(v.segs) - 11 * i].copy()
+    ref = _gpu(sc)
+    assert ref.matchBegin()
+    pairs, slot_off = ref.pairs()
+    assert ref.matchPairs(0, len(pairs))
+    ptr, n_slots = ref.slot_buffer()
+    dev = torch.device("cuda", 0)
+    want = dist.device_tensor(ptr, n_slots * 32, dev).clone()
+    assert ref.matchFinish() and ref.computeAffinity()
+    ctxs = [_gpu(sc) for _ in range(world)]
+    for g in ctxs:
+        assert g.matchBegin()
+    M = {v.cam: len(v.segs) for v in sc.views}
+    ranges = dist.pair_ranges([M[int(s)] * M[int(t)] for s, t in pairs], world)
+    for r, g in enumerate(ctxs):
+        first, count = ranges[r]
+        if count:
+            assert g.matchPairs(first, count)
+        assert g.packSlotIndices(first, count)
+    bufs = [dist.device_tensor(g.slot_index_buffer()[0], n_slots * 4, dev) for g in ctxs]
+    byte_ranges = dist.slot_byte_ranges(ranges, slot_off, n_slots, slot_bytes=4)
+    assert sum(hi - lo for lo, hi in byte_ranges) == n_slots * 4
+    for r, (lo, hi) in enumerate(byte_ranges):
+        for q in range(world):
+            if q != r and hi > lo:
+                bufs[q][lo:hi].copy_(bufs[r][lo:hi])
+    torch.cuda.synchronize()
+    for r, g in enumerate(ctxs):
+        first, count = ranges[r]
+        assert g.expandSlotIndices(0, first) and g.expandSlotIndices(first + count, len(pairs) - first - count)
+        g.L.l3d_synchronize(g.h)
+        got = dist.device_tensor(g.slot_buffer()[0], n_slots * 32, dev)
+        assert torch.equal(got, want), "expanded slots differ from the match kernel's"
+        assert g.matchFinish() and g.computeAffinity()
+        for v in sc.views:
+            a, ao = g.matches(v.cam); b, bo = ref.matches(v.cam)
+            assert np.array_equal(ao, bo) and a.tobytes() == b.tobytes()
+        ge, gl, _ = g.affinity(); re_, rl, _ = ref.affinity()
+        assert ge.tobytes() == re_.tobytes() and gl.tobytes() == rl.tobytes()
+    # misuse: packing a pair this context has not matched
+    g = _gpu(sc)
+    assert g.matchBegin() and not g.packSlotIndices(0, 1)
+    assert g.matchPairs(0, len(pairs)) and g.matchFinish()
+
+
 def test_txt_writer_matches_accessor_and_reference_writer(tmp_path):
     """l3d_save_3d_lines_txt (Line3D::save3DLinesAsTXT): file name and content against get3Dlines() and against
     the file the reference's own writer produces for the same scene (oracle/_ref)."""
