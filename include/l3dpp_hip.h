@@ -60,7 +60,8 @@ typedef struct l3d_slot {
     float overlap;
     float depth_p1, depth_p2, depth_q1, depth_q2;
     float score3D;      /* written when the src view is processed (scoringCPU) */
-    uint32_t flags;     /* bit0: survived the src view's orientation filter */
+    uint32_t flags;     /* bit0: survived the src view's orientation filter (checkMatchOrientation); bit1: so did
+                         * its inverse copy in the tgt view.  Set by phase A itself when kNN > 0. */
 } l3d_slot;
 
 typedef enum l3d_status {

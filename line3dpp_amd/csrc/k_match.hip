@@ -31,7 +31,7 @@ namespace l3d {
 namespace {
 
 constexpr int kBlock = kMatchRows;  // one wave64 per workgroup: waves never wait for each other
-constexpr int kRing = 512;          // candidate ring (entries); >= 63 + 4*64
+constexpr int kRing = 256;          // candidate ring (entries); >= 63 + 2*64 (drained after every two pushes)
 constexpr float kKappa = 1.0e-2f;  // pre-filter slack, px: margin = kKappa * max|1/d| + kKappa0
 constexpr float kKappa0 = 2.0e-4f;
 
@@ -104,6 +104,28 @@ __device__ __forceinline__ bool prefilter(float e1x, float e1y, float e1z, float
     return !(u <= 0.0f);
 }
 
+// an inverse-alive slot takes its position among the inverse refs of its target segment (global id g_tgt) from the
+// packed counter (low word: list length, high word: inverse refs), exactly as k_orient_all does
+__device__ __forceinline__ uint32_t take_inverse_position(const OrientFuse& of, uint32_t g_tgt) {
+    const unsigned long long old = atomicAdd(&of.cnt_pack[g_tgt], (1ull << 32) | 1ull);
+    return (uint32_t)(old >> 32);
+}
+
+// checkMatchOrientation (line3D.cc:811-858) of one freshly computed slot, in its source frame and -- for a pair that
+// hands inverse matches to its target (tgt processed later, :1680) -- in the target frame.  Returns the slot flags.
+__device__ __forceinline__ uint32_t fuse_orientation(const OrientFuse& of, const double* Cs, const double* Ct,
+                                                     const SegX& sx, const SegX& tx, const PairResult& res,
+                                                     bool hands_inverse, uint32_t g_tgt, uint32_t& ipos) {
+    ipos = kEmpty;
+    if (!orientation_ok(Cs, sx, res.dp1, res.dp2, of.thr)) return 0u;
+    uint32_t flags = kSlotAlive;
+    if (hands_inverse && orientation_ok(Ct, tx, res.dq1, res.dq2, of.thr)) {
+        flags |= kSlotInvAlive;
+        ipos = take_inverse_position(of, g_tgt);
+    }
+    return flags;
+}
+
 }  // namespace
 
 // MODE 0: bounded kNN (top-K rows)   MODE 1: count accepted matches per row (kNN <= 0, pass 1)
@@ -116,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
                                                            const WorkItem* __restrict__ work, uint32_t nwork,
                                                            Slot* __restrict__ slots,
                                                            uint32_t* __restrict__ row_counts, float thr,
-                                                           const CullPools cp) {
+                                                           const CullPools cp, const OrientFuse of) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware order: consecutive work items (same pair => same target view) go to one XCD
     // (block b runs on XCD b % 8, MI355X_MICROARCH.md), so the target view stays in that XCD's L2.
@@ -328,11 +350,18 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
                 const uint64_t m0 = __ballot(c0b), m1 = __ballot(c1b), m2 = __ballot(c2b), m3 = __ballot(c3b);
                 if (lane == 0) L3D_STAT(0, 64 * (1 + v1 + v2 + v3));
                 if (m0 | m1 | m2 | m3) {
-                    if (m0) { if (c0b) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | (tb + j0); tail += __popcll(m0); }
-                    if (m1) { if (c1b) ring[(tail + prefix(m1)) & (kRing - 1)] = ent_hi | (tb + j1); tail += __popcll(m1); }
-                    if (m2) { if (c2b) ring[(tail + prefix(m2)) & (kRing - 1)] = ent_hi | (tb + j2); tail += __popcll(m2); }
-                    if (m3) { if (c3b) ring[(tail + prefix(m3)) & (kRing - 1)] = ent_hi | (tb + j3); tail += __popcll(m3); }
-                    while (tail - head >= 64) drain();
+                    // two pushes, then drain: the ring never holds more than 63 + 2*64 candidates (kRing = 256,
+                    // which is what lets a seventh wave per SIMD fit the LDS).  One loop body for both halves keeps
+                    // a single copy of drain() in the instruction stream.
+#pragma nounroll
+                    for (uint32_t h = 0; h < 2; ++h) {
+                        const uint64_t ma = h ? m2 : m0, mb = h ? m3 : m1;
+                        const bool ca = h ? c2b : c0b, cb = h ? c3b : c1b;
+                        const uint32_t ja = h ? j2 : j0, jb = h ? j3 : j1;
+                        if (ma) { if (ca) ring[(tail + prefix(ma)) & (kRing - 1)] = ent_hi | (tb + ja); tail += __popcll(ma); }
+                        if (mb) { if (cb) ring[(tail + prefix(mb)) & (kRing - 1)] = ent_hi | (tb + jb); tail += __popcll(mb); }
+                        while (tail - head >= 64) drain();
+                    }
                 }
             }
         }
@@ -359,23 +388,47 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
     }
     // rank the winners by (overlap desc, tgt asc); the overlaps are in LDS, the depths are recomputed
     // (identical arithmetic to the acceptance test, so identical values)
+    // The orientation filter of phase B (checkMatchOrientation, line3D.cc:811-858) is a function of the slot alone
+    // and everything it needs is in registers here: its flags are written with the slot and the hypothesis counters
+    // of phase B are fed from here (fuse_orientation), instead of a separate pass that re-reads every slot.
     L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)tid * K;
     L3D_LDS const idx_t* ix = (L3D_LDS const idx_t*)L.top_ix + (size_t)tid * K;
-    const SegX sx = vs.segx[src];
+    const uint32_t gs = (uint32_t)(vs.segx - views[0].segx), gt = (uint32_t)(vt.segx - views[0].segx);
+    uint32_t* ipos_row = of.inv_pos + pd.slot_off + (uint64_t)src * K;
+    const bool hands_inverse = pd.tgt > pd.src;   // inverse copy only towards a view processed later (:1680)
+    uint32_t n_alive = 0;
     for (uint32_t j = 0; j < c; ++j) {
         const float oj = ov[j]; const uint32_t xj = ix[j];
         uint32_t rank = 0;
         for (uint32_t i = 0; i < c; ++i) rank += better(ov[i], ix[i], oj, xj) ? 1u : 0u;
+        // Three short stages that each fetch only the invariants they use (depths: rays + plane; orientation: rays +
+        // mid ray).  The pointers are laundered between the stages so that the compiler does not keep both 104-byte
+        // records live across them: that would cost the kernel a wave of occupancy for the sake of its epilogue.
+        const SegX* psx = vs.segx + src;
+        const SegX* ptx = vt.segx + xj;
+        asm volatile("" : "+v"(psx), "+v"(ptx));
         PairResult res{};
-        const SegX tx = vt.segx[xj];
-        exact_depths(sx, tx, vs.C, vt.C, res);
+        exact_depths(*psx, *ptx, vs.C, vt.C, res);
         Slot o;
         o.tgt_seg = xj; o.overlap = oj;
         o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
         o.score3D = 0.0f; o.flags = 0;
+        uint32_t ipos = kEmpty;
+        asm volatile("" : "+v"(psx));
+        if (orientation_ok(vs.C, *psx, res.dp1, res.dp2, of.thr)) {
+            o.flags = kSlotAlive;
+            ++n_alive;
+            asm volatile("" : "+v"(ptx));
+            if (hands_inverse && orientation_ok(vt.C, *ptx, res.dq1, res.dq2, of.thr)) {
+                o.flags |= kSlotInvAlive;
+                ipos = take_inverse_position(of, gt + xj);
+            }
+        }
         row[rank] = o;
+        ipos_row[rank] = ipos;
     }
-    for (uint32_t j = c; j < K; ++j) row[j] = empty;
+    for (uint32_t j = c; j < K; ++j) { row[j] = empty; ipos_row[j] = kEmpty; }
+    if (n_alive) atomicAdd(&of.cnt_pack[gs + src], (unsigned long long)n_alive);
 }
 
 size_t match_lds_bytes(int mode, uint32_t K, bool ix16) {
@@ -385,8 +438,10 @@ size_t match_lds_bytes(int mode, uint32_t K, bool ix16) {
 
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,
                               const WorkItem* work, uint32_t nwork, uint32_t maxK, Slot* slots,
-                              uint32_t* row_counts, float thr, CullPools pools, bool ix16, hipStream_t stream) {
+                              uint32_t* row_counts, float thr, CullPools pools, OrientFuse of, bool ix16,
+                              hipStream_t stream) {
     if (nwork == 0) return hipSuccess;
+    if (mode == 0 && (!of.cnt_pack || !of.inv_pos)) return hipErrorInvalidValue;   // MODE 0 always fuses
     const uint32_t grid = ((nwork + 7) / 8) * 8;
     if (!(mode == 0 && !brute)) ix16 = false;       // the compact layout is only instantiated for the hot variant
     const size_t lds = match_lds_bytes(mode, maxK, ix16);
@@ -396,7 +451,7 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
         if (e != hipSuccess) return e;                                                                    \
         hipLaunchKernelGGL((k_match_pairs<M, B, X>), dim3(grid), dim3(kBlock), lds, stream, views, pairs, \
-                           work, nwork, slots, row_counts, thr, pools);                                   \
+                           work, nwork, slots, row_counts, thr, pools, of);                               \
     } while (0)
     if (mode == 0) { if (brute) L3D_LAUNCH(0, true, false); else if (ix16) L3D_LAUNCH(0, false, true); else L3D_LAUNCH(0, false, false); }
     else if (mode == 1) { if (brute) L3D_LAUNCH(1, true, false); else L3D_LAUNCH(1, false, false); }
@@ -418,15 +473,18 @@ __global__ __launch_bounds__(256) void k_pack_slot_idx(const Slot* __restrict__ 
 // grid (ceil(max Ms*K / 256), pairs): one thread per slot of pair first + blockIdx.y
 __global__ __launch_bounds__(256) void k_expand_slot_idx(const ViewDev* __restrict__ views,
                                                          const PairDesc* __restrict__ pairs, uint32_t first,
-                                                         const uint32_t* __restrict__ idx, Slot* __restrict__ slots) {
+                                                         const uint32_t* __restrict__ idx, Slot* __restrict__ slots,
+                                                         const OrientFuse of) {
     const PairDesc& pd = pairs[first + blockIdx.y];
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= pd.Ms * pd.K) return;
-    const uint32_t row = s / pd.K;
+    const uint32_t n = pd.Ms * pd.K;
+    if (blockIdx.x * blockDim.x >= n) return;   // whole block past the end
+    const uint32_t K = pd.K, row = s / K;
     const uint64_t at = pd.slot_off + s;
-    const uint32_t tg = idx[at];
+    const uint32_t tg = s < n ? idx[at] : kEmpty;
     Slot o;
     o.tgt_seg = tg; o.overlap = 0; o.dp1 = o.dp2 = o.dq1 = o.dq2 = 0; o.score3D = 0.0f; o.flags = 0;
+    uint32_t ipos = kEmpty;
     if (tg != kEmpty && tg < pd.Mt) {
         const ViewDev& vs = views[pd.src];
         const ViewDev& vt = views[pd.tgt];
@@ -436,12 +494,28 @@ __global__ __launch_bounds__(256) void k_expand_slot_idx(const ViewDev* __restri
         const float4 s4 = vs.seg4[row], t4 = vt.seg4[tg];
         o.overlap = exact_overlap(F, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w);
         PairResult res{};
-        exact_depths(vs.segx[row], vt.segx[tg], vs.C, vt.C, res);
+        const SegX sx = vs.segx[row], tx = vt.segx[tg];
+        exact_depths(sx, tx, vs.C, vt.C, res);
         o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
+        o.flags = fuse_orientation(of, vs.C, vt.C, sx, tx, res, pd.tgt > pd.src,
+                                   (uint32_t)(vt.segx - views[0].segx) + tg, ipos);
     } else {
         o.tgt_seg = kEmpty;
     }
-    slots[at] = o;
+    const bool alive = (o.flags & kSlotAlive) != 0;
+    if (s < n) { slots[at] = o; of.inv_pos[at] = ipos; }
+    // the K slots of a source row are neighbouring lanes: one counter update per (row, wave), as in k_orient_all
+    const uint64_t m = __ballot(alive);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t base = s - lane, r0 = row * K;
+    const uint32_t lo = (r0 > base ? r0 : base) - base;
+    const uint32_t he = r0 + K < base + 64 ? r0 + K : base + 64;
+    const uint32_t hi = he - base;   // exclusive, <= 64
+    if (lane == lo && s < n) {
+        const uint64_t seg_mask = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+        const uint32_t cnt = (uint32_t)__popcll(m & seg_mask);
+        if (cnt) atomicAdd(&of.cnt_pack[(uint32_t)(views[pd.src].segx - views[0].segx) + row], (unsigned long long)cnt);
+    }
 }
 
 hipError_t launch_pack_slot_idx(const Slot* slots, uint32_t* idx, uint64_t lo, uint64_t hi, hipStream_t stream) {
@@ -453,12 +527,14 @@ hipError_t launch_pack_slot_idx(const Slot* slots, uint32_t* idx, uint64_t lo, u
 }
 
 hipError_t launch_expand_slot_idx(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
-                                  uint32_t max_row_slots, const uint32_t* idx, Slot* slots, hipStream_t stream) {
+                                  uint32_t max_row_slots, const uint32_t* idx, Slot* slots, OrientFuse of,
+                                  hipStream_t stream) {
     if (!max_row_slots) return hipSuccess;
+    if (!of.cnt_pack || !of.inv_pos) return hipErrorInvalidValue;
     for (uint32_t p0 = 0; p0 < count; p0 += 65535u) {
         const uint32_t n = count - p0 < 65535u ? count - p0 : 65535u;
         hipLaunchKernelGGL(k_expand_slot_idx, dim3((max_row_slots + 255) / 256, n), dim3(256), 0, stream, views, pairs,
-                           first + p0, idx, slots);
+                           first + p0, idx, slots, of);
     }
     return hipGetLastError();
 }

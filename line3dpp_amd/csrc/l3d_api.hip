@@ -135,10 +135,7 @@ struct l3d_ctx {
     PinnedBuf<uint32_t> h_cnt;
     hipStream_t aux[2] = {nullptr, nullptr};        // aux[0] high priority (phase-A first half, the chain), aux[1]
     std::vector<hipEvent_t> pipe_ev;
-    // phase A split over two streams (single-call path): pairs [0, split_pair) run on aux[0] with priority, the rest
-    // on aux[1]; the orientation pass of the first half then overlaps the tail of the second (l3d_match_finish)
-    bool split_active = false;
-    uint32_t split_pair = 0;
+    std::vector<uint8_t> pair_counted;   // the pair's slots carry orientation flags and are in the phase-B counters
     hipEvent_t sev[5] = {};                         // prepared, half A done, half B done, memsets done, orient A done
     DevBuf<SegX> d_gsegx;                           // SegX of every segment, global segment order
     float collinearity_t = -1.0f;                   // collinearity_t_ (reconstruct3Dlines); > 0: collinear links
@@ -385,10 +382,14 @@ SimConst sim_thresholds(float two_sigA_sqr) {
 struct HostTrace {
     bool on = std::getenv("L3D_TRACE") != nullptr;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::vector<std::pair<double, const char*>> marks;   // printed by flush(): printing inside the timeline distorts it
     void mark(const char* what) {
         if (!on) return;
-        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        std::fprintf(stderr, "[l3d trace] %9.1f us  %s\n", us, what);
+        marks.emplace_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what);
+    }
+    void flush() {
+        for (auto& m : marks) std::fprintf(stderr, "[l3d trace] %9.1f us  %s\n", m.first, m.second);
+        marks.clear();
     }
 };
 static HostTrace g_trace;
@@ -566,8 +567,16 @@ int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
     if (c->n_slots >= (1ull << 32) || c->pairs.size() >= (1u << 24))
         return fail(L3D_ERR_LIMIT, "slot buffer / pair list exceed the 32-bit slot and 24-bit pair indices of phase B");
     c->pair_done.assign(c->pairs.size(), 0);
+    c->pair_counted.assign(c->pairs.size(), 0);
     int rc = upload_views(*c);
     if (rc) return rc;
+    {   // packed hypothesis counters of phase B: fed by the match epilogue (bounded kNN) or by k_orient_all
+        uint64_t G = 0;
+        for (auto* v : c->order) G += v->M;
+        L3D_HIP_CHECK(c->d_cnt_pack.reserve(G + 1));
+        L3D_HIP_CHECK(hipMemsetAsync(c->d_cnt_pack.p, 0, (G + 1) * 8, c->stream));
+        if (c->kNN > 0) L3D_HIP_CHECK(c->d_inv_pos.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    }
     L3D_HIP_CHECK(c->d_pairs.reserve(std::max<size_t>(c->pairs.size(), 1)));
     if (!c->pairs.empty()) {
         L3D_HIP_CHECK(c->h_pairs.reserve(c->pairs.size()));
@@ -632,7 +641,7 @@ static void collect_match_timing(l3d_ctx* c) {
 }
 
 // enqueues (no host synchronisation) the cull set-up and the pair kernel for pairs [first, first+count)
-static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count, bool allow_split = false) {
+static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count) {
     size_t n_work = 0;
     uint32_t maxK = 0, maxM = 0, maxMt = 0;
     for (uint32_t p = first; p < first + count; ++p) n_work += (c->pairs[p].Ms + kMatchRows - 1) / kMatchRows;
@@ -657,38 +666,14 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     else L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
     L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
     const bool ix16 = maxMt < 65536u && maxK < 65536u;   // 16-bit indices in the kernel's LDS tables
-    c->split_active = false;
-    if (allow_split && mode == 0 && count >= 2 && std::getenv("L3D_SPLIT_PHASE_A") != nullptr) {
-        // opt-in (L3D_SPLIT_PHASE_A=1): two halves by cost on two streams, the first with priority, so that its
-        // orientation pass overlaps the tail of the second (-2 % step time on C1).  Off by default so that one
-        // launch covers all pairs and its event-timed duration is directly comparable with a rocprofv3 trace.
-        // ev[5] / ev[3] are recorded by l3d_match_finish once both halves are done
-        uint64_t total = 0, acc = 0;
-        for (uint32_t p = first; p < first + count; ++p) total += (uint64_t)c->pairs[p].Ms * c->pairs[p].Mt;
-        uint32_t ps = first; size_t n_work1 = 0;
-        while (ps < first + count - 1 && 2 * acc < total) {
-            acc += (uint64_t)c->pairs[ps].Ms * c->pairs[ps].Mt;
-            n_work1 += (c->pairs[ps].Ms + kMatchRows - 1) / kMatchRows;
-            ++ps;
-        }
-        const int rc = ensure_aux(c);
-        if (rc) return rc;
-        L3D_HIP_CHECK(hipEventRecord(c->sev[0], c->stream));
-        L3D_HIP_CHECK(hipStreamWaitEvent(c->aux[0], c->sev[0], 0));
-        L3D_HIP_CHECK(hipStreamWaitEvent(c->aux[1], c->sev[0], 0));
-        L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work1,
-                                         maxK, c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, ix16, c->aux[0]));
-        L3D_HIP_CHECK(hipEventRecord(c->sev[1], c->aux[0]));
-        L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p + n_work1,
-                                         (uint32_t)(n_work - n_work1), maxK, c->d_slots.p, c->d_row_counts.p,
-                                         c->epipolar_overlap, pools, ix16, c->aux[1]));
-        L3D_HIP_CHECK(hipEventRecord(c->sev[2], c->aux[1]));
-        c->split_active = true; c->split_pair = ps;
-    } else {
-        L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work,
-                                         maxK, c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, ix16, c->stream));
-        L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));
-    }
+    // bounded kNN: the orientation filter and the hypothesis counters of phase B are fused into the epilogue
+    const OrientFuse of{mode == 0 ? c->d_cnt_pack.p : nullptr, mode == 0 ? c->d_inv_pos.p : nullptr,
+                        OrientThr{c->orient_lo, c->orient_hi}};
+    L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work, maxK,
+                                     c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, of, ix16, c->stream));
+    L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));
+    if (mode == 0)
+        for (uint32_t p = first; p < first + count; ++p) c->pair_counted[p] = 1;
     if (pools.cull)
         for (uint32_t p = first; p < first + count; ++p) c->tm.culled_pairs += c->cull[p].enabled;
     c->timing_pending = true; c->pending_launches += 1;
@@ -707,11 +692,13 @@ int l3d_match_pairs(l3d_ctx* c, uint32_t first, uint32_t count) {
 static int match_pairs_impl(l3d_ctx* c, uint32_t first, uint32_t count, bool sync) {
     if (c->state != l3d_ctx::BEGUN) return fail(L3D_ERR_STATE, "l3d_match_begin must precede l3d_match_pairs");
     if ((uint64_t)first + count > c->pairs.size()) return fail(L3D_ERR_ARG, "pair range out of bounds");
+    for (uint32_t p = first; p < first + count; ++p)
+        if (c->pair_done[p]) return fail(L3D_ERR_STATE, "l3d_match_pairs: pair already matched since l3d_match_begin");
     (void)hipSetDevice(c->device);
     L3D_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
     int rc = L3D_OK;
     if (c->kNN > 0) {
-        rc = run_match_kernel(c, 0, first, count, /*allow_split=*/!sync && first == 0 && count == c->pairs.size());
+        rc = run_match_kernel(c, 0, first, count);
     } else {
         // kNN <= 0: keep every accepted match (line3D.cc:987-992): count, size the rows, fill
         if (first != 0 || count != c->pairs.size())
@@ -739,7 +726,7 @@ static int match_pairs_impl(l3d_ctx* c, uint32_t first, uint32_t count, bool syn
         rc = run_match_kernel(c, 2, first, count);
     }
     if (rc) return rc;
-    if (!c->split_active) L3D_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    L3D_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
     if (sync) {
         L3D_HIP_CHECK(hipEventSynchronize(c->ev[3]));
         collect_match_timing(c);
@@ -809,9 +796,12 @@ int l3d_expand_slot_indices(l3d_ctx* c, uint32_t first, uint32_t count) {
     uint32_t max_row_slots = 0;
     for (uint32_t p = first; p < first + count; ++p)
         max_row_slots = std::max<uint64_t>(max_row_slots, (uint64_t)c->pairs[p].Ms * c->pairs[p].K);
+    for (uint32_t p = first; p < first + count; ++p)
+        if (c->pair_done[p]) return fail(L3D_ERR_STATE, "l3d_expand_slot_indices: pair already present on this rank");
+    const OrientFuse of{c->d_cnt_pack.p, c->d_inv_pos.p, OrientThr{c->orient_lo, c->orient_hi}};
     L3D_HIP_CHECK(launch_expand_slot_idx(c->d_views.p, c->d_pairs.p, first, count, max_row_slots, c->d_slot_idx.p,
-                                         c->d_slots.p, c->stream));
-    for (uint32_t p = first; p < first + count; ++p) c->pair_done[p] = 1;
+                                         c->d_slots.p, of, c->stream));
+    for (uint32_t p = first; p < first + count; ++p) c->pair_done[p] = c->pair_counted[p] = 1;
     return L3D_OK;
 }
 
@@ -831,7 +821,7 @@ int l3d_match_finish(l3d_ctx* c) {
         (void)hipStreamSynchronize(c->stream);
         for (auto& s2 : c->aux) if (s2) (void)hipStreamSynchronize(s2);
         untranslate(*c);
-        c->split_active = false; c->timing_pending = false; c->pending_launches = 0;
+        c->timing_pending = false; c->pending_launches = 0;
         c->state = l3d_ctx::IDLE;
         set_error(why);
     }
@@ -856,7 +846,7 @@ static int match_finish_impl(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_best_pos.reserve(G + 1)); L3D_HIP_CHECK(c->d_surv_off.reserve(G + 1));
     L3D_HIP_CHECK(c->d_hyp_off.reserve(G + 1)); L3D_HIP_CHECK(c->d_hyp_of_seg.reserve(G + 1));
     L3D_HIP_CHECK(c->d_medians.reserve(V + 1));
-    if (!c->split_active) L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));   // (split: recorded once phase A is done)
+    L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
     L3D_HIP_CHECK(c->h_small.reserve(V + 1));
     g_trace.mark("finish: reserves done");
     std::memcpy(c->h_small.p, c->seg_base.data(), ((size_t)V + 1) * 4);
@@ -885,37 +875,24 @@ static int match_finish_impl(l3d_ctx* c) {
         if (n) L3D_HIP_CHECK(hipMemcpyAsync(c->d_vout_pairs.p, vp, (size_t)n * 4, hipMemcpyHostToDevice, st));
     }
     L3D_HIP_CHECK(c->d_cnt_inv.reserve(G + 1)); L3D_HIP_CHECK(c->d_inv_off.reserve(G + 1));
-    L3D_HIP_CHECK(c->d_cnt_pack.reserve(G + 1));
+    // (d_cnt_pack was zeroed by l3d_match_begin: the match epilogue already counts into it)
     L3D_HIP_CHECK(c->d_inv_pos.reserve(std::max<uint64_t>(c->n_slots, 1)));
-    L3D_HIP_CHECK(hipMemsetAsync(c->d_cnt_pack.p, 0, ((size_t)G + 1) * 8, st));
     L3D_HIP_CHECK(hipMemsetAsync(c->d_max_score.p, 0, ((size_t)V + 1) * 4, st));
     L3D_HIP_CHECK(hipMemsetAsync(c->d_scal.p, 0, 16 * 4, st));
     g_trace.mark("finish: memsets enqueued");
     // ---- pre-pass: orientation flags, list offsets, transposed index of potential inverse matches ----
-    if (c->split_active) {
-        // phase A still runs on the two auxiliary streams: the first half's orientation pass follows its match
-        // kernel on the priority stream and overlaps the tail of the second half
-        const uint32_t ps = c->split_pair;
-        L3D_HIP_CHECK(hipEventRecord(c->sev[3], st));                       // counters zeroed
-        L3D_HIP_CHECK(hipStreamWaitEvent(c->aux[0], c->sev[3], 0));
-        L3D_HIP_CHECK(launch_orient_pairs(c->d_views.p, c->d_pairs.p, ps, max_slots, c->d_seg_base.p, c->d_slots.p,
-                                          c->d_cnt_pack.p, c->d_inv_pos.p, c->orient_lo, c->orient_hi, c->aux[0]));
-        L3D_HIP_CHECK(hipEventRecord(c->sev[4], c->aux[0]));
-        L3D_HIP_CHECK(hipStreamWaitEvent(st, c->sev[1], 0));
-        L3D_HIP_CHECK(hipStreamWaitEvent(st, c->sev[2], 0));
-        L3D_HIP_CHECK(hipEventRecord(c->ev[5], st));                        // both match kernels done
-        L3D_HIP_CHECK(hipEventRecord(c->ev[3], st));
-        L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
-        L3D_HIP_CHECK(launch_orient_pairs(c->d_views.p, c->d_pairs.p + ps, P - ps, max_slots, c->d_seg_base.p,
+    // (bounded kNN: already done by the match epilogue / the exchange expansion; what is left are the pairs of the
+    // keep-all mode and pairs whose full records arrived through l3d_slots_exchanged)
+    for (uint32_t p0 = 0; p0 < P;) {
+        if (c->pair_counted[p0]) { ++p0; continue; }
+        uint32_t p1 = p0;
+        while (p1 < P && !c->pair_counted[p1]) ++p1;
+        L3D_HIP_CHECK(launch_orient_pairs(c->d_views.p, c->d_pairs.p + p0, p1 - p0, max_slots, c->d_seg_base.p,
                                           c->d_slots.p, c->d_cnt_pack.p, c->d_inv_pos.p, c->orient_lo, c->orient_hi, st));
-        L3D_HIP_CHECK(hipStreamWaitEvent(st, c->sev[4], 0));
-        L3D_HIP_CHECK(launch_unpack_counts(G, c->d_cnt_pack.p, c->d_cnt.p, c->d_cnt_inv.p, st));
-        c->split_active = false;
-    } else {
-        L3D_HIP_CHECK(launch_orient_all(c->d_views.p, c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, G,
-                                        c->d_cnt_pack.p, c->d_inv_pos.p, c->d_cnt.p, c->d_cnt_inv.p, c->orient_lo,
-                                        c->orient_hi, st));
+        for (uint32_t p = p0; p < p1; ++p) c->pair_counted[p] = 1;
+        p0 = p1;
     }
+    L3D_HIP_CHECK(launch_unpack_counts(G, c->d_cnt_pack.p, c->d_cnt.p, c->d_cnt_inv.p, st));
     L3D_HIP_CHECK(launch_scan(c->d_cnt.p, G, c->d_off.p, c->d_scan_tmp.p, c->d_scal.p + 0, st));
     L3D_HIP_CHECK(launch_scan(c->d_cnt_inv.p, G, c->d_inv_off.p, c->d_scan_tmp.p, c->d_scal.p + 5, st));
     L3D_HIP_CHECK(c->d_bits_len.reserve(G + 1)); L3D_HIP_CHECK(c->d_boff.reserve(G + 1));
@@ -992,9 +969,11 @@ static int match_finish_impl(l3d_ctx* c) {
                                              c->d_seg_base.p, c->d_gseg_view.p, simc, st));
             L3D_HIP_CHECK(hipEventRecord(c->pipe_ev[2 * k], st));
             L3D_HIP_CHECK(hipStreamWaitEvent(sB, c->pipe_ev[2 * k], 0));
+            g_trace.mark("  chunk: support enqueued");
             for (uint32_t vi = v0; vi < v1; ++vi)
                 L3D_HIP_CHECK(launch_presence_view(c->seg_base[vi], c->order[vi]->M, c->d_off.p, c->d_boff.p,
                                                    c->d_inv_off.p, c->d_eref.p, c->d_bits.p, c->d_positive.p, sB));
+            g_trace.mark("  chunk: chain launches enqueued");
             L3D_HIP_CHECK(hipEventRecord(c->pipe_ev[2 * k + 1], sB));
             L3D_HIP_CHECK(hipStreamWaitEvent(sC, c->pipe_ev[2 * k + 1], 0));
             L3D_HIP_CHECK(launch_score_all(g0, g1, c->d_off.p, c->d_boff.p, c->d_gseg_view.p, c->d_dents.p, c->d_bits.p,
@@ -1057,6 +1036,7 @@ int l3d_match_images(l3d_ctx* c, const l3d_match_params* p) {
     if (rc) return rc;
     rc = l3d_match_finish(c);
     g_trace.mark("matchImages done");
+    g_trace.flush();
     return rc;
 }
 
@@ -1771,11 +1751,15 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
     const float* lines[2] = {lines_src4, lines_tgt4};
     const double* A[2] = {RtKinv_src, RtKinv_tgt};
     const double* Cc[2] = {C_src, C_tgt};
-    DevBuf<float4> seg4[2]; DevBuf<SegF> segf[2]; DevBuf<SegX> segx[2];
+    DevBuf<float4> seg4[2]; DevBuf<SegF> segf[2];
+    DevBuf<SegX> segx;   // one array for both views (source first), like the context's global array: the match kernel
+                         // derives global segment ids from it for the phase-B counters it feeds
+    DevBuf<unsigned long long> cnt_pack; DevBuf<uint32_t> inv_pos;
     DevBuf<double> consts; DevBuf<ViewDev> dv; DevBuf<PairDesc> dp; DevBuf<WorkItem> dw; DevBuf<Slot> ds;
     DevBuf<PairCull> dc; DevBuf<uint32_t> sperm, tperm; DevBuf<float2> sband, tband, cband; DevBuf<float4> tsf;
     auto cleanup = [&]() {
-        for (int i = 0; i < 2; ++i) { seg4[i].release(); segf[i].release(); segx[i].release(); }
+        for (int i = 0; i < 2; ++i) { seg4[i].release(); segf[i].release(); }
+        segx.release(); cnt_pack.release(); inv_pos.release();
         consts.release(); dv.release(); dp.release(); dw.release(); ds.release();
         dc.release(); sperm.release(); tperm.release(); sband.release(); tband.release(); cband.release(); tsf.release();
     };
@@ -1783,12 +1767,13 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         ViewDev hv[2];
         double hc[24];
         L3D_HIP_CHECK(consts.reserve(24));
+        L3D_HIP_CHECK(segx.reserve((size_t)Ms + Mt));
         for (int i = 0; i < 2; ++i) {
-            L3D_HIP_CHECK(seg4[i].reserve(M[i])); L3D_HIP_CHECK(segf[i].reserve(M[i])); L3D_HIP_CHECK(segx[i].reserve(M[i]));
+            L3D_HIP_CHECK(seg4[i].reserve(M[i])); L3D_HIP_CHECK(segf[i].reserve(M[i]));
             L3D_HIP_CHECK(hipMemcpy(seg4[i].p, lines[i], (size_t)M[i] * 16, hipMemcpyHostToDevice));
             std::memcpy(hc + 12 * i, A[i], 72); std::memcpy(hc + 12 * i + 9, Cc[i], 24);
             std::memcpy(hv[i].C, Cc[i], 24); std::memcpy(hv[i].RtKinv, A[i], 72);
-            hv[i].seg4 = seg4[i].p; hv[i].segf = segf[i].p; hv[i].segx = segx[i].p;
+            hv[i].seg4 = seg4[i].p; hv[i].segf = segf[i].p; hv[i].segx = segx.p + (i ? Ms : 0u);
             hv[i].M = M[i]; hv[i].cam = (uint32_t)i; hv[i].k = 0;
             hv[i].cx = 0.5f * (float)width; hv[i].cy = 0.5f * (float)height; hv[i].pad = 0;
         }
@@ -1818,8 +1803,13 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
             pools = CullPools{dc.p, sperm.p, sband.p, tperm.p, tsf.p, tband.p, cband.p};
             L3D_HIP_CHECK(launch_cull_prepare(dv.p, dp.p, 0, 1, std::max(Ms, Mt), pools, 0));
         }
+        // the kernel also applies the orientation filter (slot flags) and feeds the phase-B counters: scratch here
+        L3D_HIP_CHECK(cnt_pack.reserve((size_t)Ms + Mt + 1)); L3D_HIP_CHECK(inv_pos.reserve((size_t)Ms * pd.K));
+        L3D_HIP_CHECK(hipMemset(cnt_pack.p, 0, ((size_t)Ms + Mt + 1) * 8));
+        OrientFuse of{cnt_pack.p, inv_pos.p, OrientThr{-1.0, 1.0}};
+        orientation_thresholds(of.thr.lo, of.thr.hi);
         L3D_HIP_CHECK(launch_match_pairs(0, false, dv.p, dp.p, dw.p, (uint32_t)work.size(), pd.K, ds.p, nullptr, thr,
-                                         pools, Mt < 65536u && pd.K < 65536u, 0));
+                                         pools, of, Mt < 65536u && pd.K < 65536u, 0));
         L3D_HIP_CHECK(hipDeviceSynchronize());
         L3D_HIP_CHECK(hipMemcpy(out_slots, ds.p, (size_t)Ms * pd.K * sizeof(Slot), hipMemcpyDeviceToHost));
         return L3D_OK;

@@ -35,17 +35,26 @@ struct CullPools {
 };
 constexpr uint32_t kCullMaxSegs = 16384;   // LDS sort capacity of k_cull_prepare
 
+// the orientation filter of phase B fused into whatever produces a slot (match epilogue, exchange expansion)
+struct OrientFuse {
+    unsigned long long* cnt_pack;   // [G] packed hypothesis counters of the global segments (k_orient_all)
+    uint32_t* inv_pos;              // [n_slots] position of a slot among the inverse refs of its target segment
+    OrientThr thr;
+};
+
 // ---- k_match.hip ----
 size_t match_lds_bytes(int mode, uint32_t K, bool ix16 = false);
 hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
                                uint32_t max_M, CullPools pools, hipStream_t stream);
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,
                               const WorkItem* work, uint32_t nwork, uint32_t maxK, Slot* slots,
-                              uint32_t* row_counts, float thr, CullPools pools, bool ix16, hipStream_t stream);
+                              uint32_t* row_counts, float thr, CullPools pools, OrientFuse of, bool ix16,
+                              hipStream_t stream);
 // compact exchange of slots between ranks: target indices out, full records back (bit-identical re-derivation)
 hipError_t launch_pack_slot_idx(const Slot* slots, uint32_t* idx, uint64_t lo, uint64_t hi, hipStream_t stream);
 hipError_t launch_expand_slot_idx(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
-                                  uint32_t max_row_slots, const uint32_t* idx, Slot* slots, hipStream_t stream);
+                                  uint32_t max_row_slots, const uint32_t* idx, Slot* slots, OrientFuse of,
+                                  hipStream_t stream);
 hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, hipStream_t stream);
 
 // ---- k_rdd.hip ----
