@@ -372,63 +372,89 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
 #endif
 
     // ---- epilogue ----
-    if (!active) return;
-    const uint32_t c = L.cnt[tid];
-    if (MODE == 1) {
-        row_counts[pd.row_off + src] = c;
-        return;
-    }
-    Slot* row = slots + pd.slot_off + (uint64_t)src * K;
-    Slot empty;
-    empty.tgt_seg = kEmpty; empty.overlap = 0; empty.dp1 = empty.dp2 = empty.dq1 = empty.dq2 = 0;
-    empty.score3D = 0; empty.flags = 0;
-    if (MODE == 2) {
+    if (MODE != 0) {
+        if (!active) return;
+        const uint32_t c = L.cnt[tid];
+        if (MODE == 1) {
+            row_counts[pd.row_off + src] = c;
+            return;
+        }
+        Slot* row = slots + pd.slot_off + (uint64_t)src * K;
+        Slot empty;
+        empty.tgt_seg = kEmpty; empty.overlap = 0; empty.dp1 = empty.dp2 = empty.dq1 = empty.dq2 = 0;
+        empty.score3D = 0; empty.flags = 0;
         for (uint32_t j = min(c, K); j < K; ++j) row[j] = empty;
         return;
     }
-    // rank the winners by (overlap desc, tgt asc); the overlaps are in LDS, the depths are recomputed
-    // (identical arithmetic to the acceptance test, so identical values)
-    // The orientation filter of phase B (checkMatchOrientation, line3D.cc:811-858) is a function of the slot alone
-    // and everything it needs is in registers here: its flags are written with the slot and the hypothesis counters
-    // of phase B are fed from here (fuse_orientation), instead of a separate pass that re-reads every slot.
-    L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)tid * K;
-    L3D_LDS const idx_t* ix = (L3D_LDS const idx_t*)L.top_ix + (size_t)tid * K;
+    // MODE 0.  The wave writes its rows TOGETHER: item = (row, entry), one item per lane and pass, so that the K
+    // 32-byte slots of a row (K*32 B contiguous, 64-byte aligned for even K) leave in one store instruction as whole
+    // cache lines -- a lane writing its own row slot by slot leaves every line partially written between two stores.
+    // Per item: rank among the row's winners by (overlap desc, tgt asc) (the overlaps are in LDS), depths recomputed
+    // with the arithmetic of the acceptance test (identical values), and the orientation filter of phase B
+    // (checkMatchOrientation, line3D.cc:811-858), which is a function of the slot alone: its flags are written with
+    // the slot and the hypothesis counters of phase B are fed from here instead of by a pass that re-reads every slot.
+    L3D_LDS volatile uint32_t* row_src = ring;          // the ring is idle now: source segment of each row
+    row_src[tid] = src;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t n_rows = min((uint32_t)kBlock, Ms - wi.src0);
     const uint32_t gs = (uint32_t)(vs.segx - views[0].segx), gt = (uint32_t)(vt.segx - views[0].segx);
-    uint32_t* ipos_row = of.inv_pos + pd.slot_off + (uint64_t)src * K;
     const bool hands_inverse = pd.tgt > pd.src;   // inverse copy only towards a view processed later (:1680)
-    uint32_t n_alive = 0;
-    for (uint32_t j = 0; j < c; ++j) {
-        const float oj = ov[j]; const uint32_t xj = ix[j];
-        uint32_t rank = 0;
-        for (uint32_t i = 0; i < c; ++i) rank += better(ov[i], ix[i], oj, xj) ? 1u : 0u;
-        // Three short stages that each fetch only the invariants they use (depths: rays + plane; orientation: rays +
-        // mid ray).  The pointers are laundered between the stages so that the compiler does not keep both 104-byte
-        // records live across them: that would cost the kernel a wave of occupancy for the sake of its epilogue.
-        const SegX* psx = vs.segx + src;
-        const SegX* ptx = vt.segx + xj;
-        asm volatile("" : "+v"(psx), "+v"(ptx));
-        PairResult res{};
-        exact_depths(*psx, *ptx, vs.C, vt.C, res);
+    const uint32_t n_items = n_rows * K;
+    for (uint32_t base = 0; base < n_items; base += 64) {
+        const uint32_t it = base + lane;
+        const bool in = it < n_items;
+        const uint32_t r = in ? it / K : 0u, j = it - r * K;
+        const uint32_t rsrc = row_src[r];
+        const uint32_t c = in ? (uint32_t)L.cnt[r] : 0u;
         Slot o;
-        o.tgt_seg = xj; o.overlap = oj;
-        o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
-        o.score3D = 0.0f; o.flags = 0;
-        uint32_t ipos = kEmpty;
-        asm volatile("" : "+v"(psx));
-        if (orientation_ok(vs.C, *psx, res.dp1, res.dp2, of.thr)) {
-            o.flags = kSlotAlive;
-            ++n_alive;
-            asm volatile("" : "+v"(ptx));
-            if (hands_inverse && orientation_ok(vt.C, *ptx, res.dq1, res.dq2, of.thr)) {
-                o.flags |= kSlotInvAlive;
-                ipos = take_inverse_position(of, gt + xj);
+        o.tgt_seg = kEmpty; o.overlap = 0; o.dp1 = o.dp2 = o.dq1 = o.dq2 = 0; o.score3D = 0.0f; o.flags = 0;
+        uint32_t ipos = kEmpty, dst = j;
+        if (j < c) {
+            L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)r * K;
+            L3D_LDS const idx_t* ix = (L3D_LDS const idx_t*)L.top_ix + (size_t)r * K;
+            const float oj = ov[j]; const uint32_t xj = ix[j];
+            uint32_t rank = 0;
+            for (uint32_t i = 0; i < c; ++i) rank += better(ov[i], ix[i], oj, xj) ? 1u : 0u;
+            dst = rank;
+            // Three short stages that each fetch only the invariants they use (depths: rays + plane; orientation:
+            // rays + mid ray).  The pointers are laundered between the stages so that the compiler does not keep both
+            // 104-byte records live across them: that would cost the kernel a wave of occupancy for its epilogue.
+            const SegX* psx = vs.segx + rsrc;
+            const SegX* ptx = vt.segx + xj;
+            asm volatile("" : "+v"(psx), "+v"(ptx));
+            PairResult res{};
+            exact_depths(*psx, *ptx, vs.C, vt.C, res);
+            o.tgt_seg = xj; o.overlap = oj;
+            o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
+            asm volatile("" : "+v"(psx));
+            if (orientation_ok(vs.C, *psx, res.dp1, res.dp2, of.thr)) {
+                o.flags = kSlotAlive;
+                asm volatile("" : "+v"(ptx));
+                if (hands_inverse && orientation_ok(vt.C, *ptx, res.dq1, res.dq2, of.thr)) {
+                    o.flags |= kSlotInvAlive;
+                    ipos = take_inverse_position(of, gt + xj);
+                }
             }
         }
-        row[rank] = o;
-        ipos_row[rank] = ipos;
+        if (in) {
+            const uint64_t at = pd.slot_off + (uint64_t)rsrc * K + dst;
+            slots[at] = o;
+            of.inv_pos[at] = ipos;
+        }
+        // fresh alive hypotheses of the row: its items are neighbouring lanes, one counter update per (row, pass)
+        const uint64_t m = __ballot((o.flags & kSlotAlive) != 0);
+        const uint32_t r0 = r * K;
+        const uint32_t lo = (r0 > base ? r0 : base) - base;
+        const uint32_t he = r0 + K < base + 64 ? r0 + K : base + 64;
+        const uint32_t hi = he - base;   // exclusive, <= 64
+        if (in && lane == lo) {
+            const uint64_t seg_mask = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+            const uint32_t n_alive = (uint32_t)__popcll(m & seg_mask);
+            if (n_alive) atomicAdd(&of.cnt_pack[gs + rsrc], (unsigned long long)n_alive);
+        }
     }
-    for (uint32_t j = c; j < K; ++j) { row[j] = empty; ipos_row[j] = kEmpty; }
-    if (n_alive) atomicAdd(&of.cnt_pack[gs + src], (unsigned long long)n_alive);
 }
 
 size_t match_lds_bytes(int mode, uint32_t K, bool ix16) {
