@@ -624,6 +624,24 @@ __global__ __launch_bounds__(256) void k_presence_view(uint32_t g0, uint32_t M, 
     const uint32_t n_inv = inv_off[g + 1] - inv_off[g];   // the inverse hypotheses come first in canonical order
     uint64_t* rows = bits + boff[g];
     uint64_t* P = rows + (size_t)L * W;
+    if (W <= 2) {
+        // Short lists (the common case): every load that does not depend on the chain state -- the inverse refs, this
+        // lane's support rows, the slots it may mark -- is issued up front, so that the launch is two dependent memory
+        // round trips deep (header -> refs/rows -> positive[]) instead of five; the presence words stay in registers.
+        const uint32_t j1 = 64 + lane, i0 = n_inv + lane, i1 = i0 + 64;
+        const uint32_t e0 = lane < n_inv ? eref[b + lane] : 0u, e1 = j1 < n_inv ? eref[b + j1] : 0u;
+        uint64_t r00 = 0, r01 = 0, r10 = 0, r11 = 0;
+        uint32_t w0 = 0, w1 = 0;
+        if (i0 < L) { r00 = rows[(size_t)i0 * W]; if (W == 2) r01 = rows[(size_t)i0 * W + 1]; w0 = eref[b + i0]; }
+        if (i1 < L) { r10 = rows[(size_t)i1 * W]; if (W == 2) r11 = rows[(size_t)i1 * W + 1]; w1 = eref[b + i1]; }
+        const bool p0 = lane < L && (lane >= n_inv || positive[e0] != 0);
+        const bool p1 = j1 < L && (j1 >= n_inv || positive[e1] != 0);
+        const uint64_t P0 = __ballot(p0), P1 = __ballot(p1);
+        if (lane == 0) { P[0] = P0; if (W == 2) P[1] = P1; }
+        if (i0 < L && ((r00 & P0) | (r01 & P1))) positive[w0] = 1;
+        if (i1 < L && ((r10 & P0) | (r11 & P1))) positive[w1] = 1;
+        return;
+    }
     const bool in_lds = W <= kPCap;
     for (uint32_t w = 0; w < W; ++w) {
         const uint32_t j = w * 64 + lane;

@@ -949,7 +949,10 @@ static int match_finish_impl(l3d_ctx* c) {
     // so the launch-latency-bound chain (V dependent launches that keep < 5 % of the GPU busy) hides behind the
     // support / score kernels of the neighbouring chunks.
     {
-        const uint32_t n_chunks = std::min<uint32_t>(std::max<uint32_t>((V + 7) / 8, 1), 64);
+        // 4 views per chunk (at most 64 chunks): measured best on C1 among 1/2/4/8/16 and ramped schedules -- the
+        // chain cannot start before the first chunk's support rows exist and the last chunk's scores cannot start
+        // before the chain ends, while very small chunks leave the support / score launches too small to fill the GPU
+        const uint32_t n_chunks = std::min<uint32_t>(std::max<uint32_t>((V + 3) / 4, 1), 64);
         const uint32_t per = (V + n_chunks - 1) / n_chunks;
         while (c->pipe_ev.size() < 2 * (size_t)n_chunks + 2) {
             hipEvent_t e;
