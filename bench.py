@@ -139,8 +139,9 @@ def main():
     f, c = ranges[rank]
     my_pairs = pairs[f:f + c]
     # algorithmic bytes per launch (SURVEY.md §8d / DESIGN.md): per directed pair 16*(Ms+Mt) B of segment
-    # records read + 32*kNN*Ms B of result slots written
-    algo_bytes = sum(16 * (M[s] + M[t]) + 32 * kNN * M[s] for s, t in my_pairs)
+    # records read + (32 + 4)*kNN*Ms B written: the result slots and, since the orientation filter is fused into
+    # the kernel, the 4-byte inverse-list position of every slot (SURVEY's bound is 40*kNN*Ms)
+    algo_bytes = sum(16 * (M[s] + M[t]) + 36 * kNN * M[s] for s, t in my_pairs)
     my_tests = sum(M[s] * M[t] for s, t in my_pairs)
     avg_ms = kern_ms / max(kern_launches, 1)
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
