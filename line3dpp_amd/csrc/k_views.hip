@@ -6,9 +6,11 @@
 // everything else is geometry.  So the work is split in three:
 //
 //   pre-pass (all views at once, chain independent)
-//     k_orient_all      checkMatchOrientation (:811-858) of every slot in its source frame and, for pairs
-//                       that will hand inverse matches to their target, in the target frame; per-segment
-//                       hypothesis counts
+//     (bounded kNN: checkMatchOrientation (:811-858) and the per-segment hypothesis counts come out of the match
+//                       kernel's epilogue / the exchange expansion, k_match.hip)
+//     k_orient_all      the same for slots that did not: keep-all mode, full records received from another rank --
+//                       orientation of every slot in its source frame and, for pairs that hand inverse matches to
+//                       their target, in the target frame; per-segment hypothesis counts
 //     scans + k_inv_fill  CSR offsets of every 2D segment's hypothesis list and a compact transposed index
 //                       (16-byte refs) of the slots that point at it as potential inverse matches
 //   lists (all views at once, chain independent)
@@ -998,17 +1000,6 @@ hipError_t launch_fill_gseg_view(const uint32_t* seg_base, uint32_t V, uint32_t 
                                  hipStream_t st) {
     if (!V || !max_M) return hipSuccess;
     hipLaunchKernelGGL(k_fill_gseg_view, dim3((max_M + 255) / 256, V), dim3(256), 0, st, seg_base, gseg_view);
-    return hipGetLastError();
-}
-hipError_t launch_orient_all(const ViewDev* views, const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots,
-                             const uint32_t* seg_base, Slot* slots, uint32_t G, unsigned long long* cnt_pack,
-                             uint32_t* inv_pos, uint32_t* cnt_all, uint32_t* cnt_inv, double thr_lo, double thr_hi,
-                             hipStream_t st) {
-    if (n_pairs && max_slots)
-        hipLaunchKernelGGL(k_orient_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, views,
-                           pairs, seg_base, slots, cnt_pack, inv_pos, OrientThr{thr_lo, thr_hi});
-    if (!G) return hipGetLastError();
-    hipLaunchKernelGGL(k_unpack_counts, dim3((G + 255) / 256), dim3(256), 0, st, G, cnt_pack, cnt_all, cnt_inv);
     return hipGetLastError();
 }
 hipError_t launch_orient_pairs(const ViewDev* views, const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots,

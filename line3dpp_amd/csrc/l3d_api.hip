@@ -35,10 +35,6 @@ hipError_t launch_seam_entries(uint32_t n, const float4* m4, const float2* rt, c
 hipError_t launch_seam_all_present(uint32_t G, const uint32_t* off, const uint32_t* boff, uint64_t* bits, hipStream_t);
 hipError_t launch_seam_scores_out(uint32_t n, const DEntry*, float* scores, hipStream_t);
 hipError_t launch_fill_gseg_view(const uint32_t* seg_base, uint32_t V, uint32_t max_M, uint32_t* gseg_view, hipStream_t);
-hipError_t launch_orient_all(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
-                             const uint32_t* seg_base, Slot* slots, uint32_t G, unsigned long long* cnt_pack,
-                             uint32_t* inv_pos, uint32_t* cnt_all, uint32_t* cnt_inv, double thr_lo, double thr_hi,
-                             hipStream_t);
 hipError_t launch_orient_pairs(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
                                const uint32_t* seg_base, Slot* slots, unsigned long long* cnt_pack, uint32_t* inv_pos,
                                double thr_lo, double thr_hi, hipStream_t);

@@ -50,7 +50,7 @@ def exchange_slots(buf, byte_ranges, group=None):
     """In-place all-gather(v): after the call every rank's `buf` (flat uint8 torch tensor) holds every
     rank's slice.  byte_ranges[r] = (lo, hi) owned by rank r.
 
-    Equal, contiguous slices (the usual case: BASELINE configs have uniform pairs) go through ONE in-place
+    Equal, contiguous slices (the usual case: BASELINE configs have uniform pairs) go through ONE
     all_gather_into_tensor -- a ring all-gather drives all xGMI links at once, whereas N successive
     broadcasts serialise them.  Uneven slices fall back to one broadcast per owning rank."""
     import torch.distributed as dist
@@ -62,7 +62,8 @@ def exchange_slots(buf, byte_ranges, group=None):
         lo0, hi_last = byte_ranges[0][0], byte_ranges[-1][1]
         lo, hi = byte_ranges[rank]
         try:
-            dist.all_gather_into_tensor(buf[lo0:hi_last], buf[lo:hi], group=group)
+            # the send side is a copy of the rank's slice (a few MB), so that input and output never alias
+            dist.all_gather_into_tensor(buf[lo0:hi_last], buf[lo:hi].clone(), group=group)
             return "all_gather"
         except (RuntimeError, NotImplementedError):
             pass   # backend without all_gather_into_tensor: use the broadcasts
