@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void k_presence_view(uint32_t g0, uint32_t M, 
     }
 }
 
-constexpr uint32_t kScoreCap = 256;
+constexpr uint32_t kScoreCap = 192;   // per-wave LDS staging of a list: 36 B per hypothesis (27 KiB per workgroup)
 // scores of all views (batched): for every existing hypothesis i walk the existing supporters (S_i & P) in
 // canonical order with the reference's per-camera replace/subtract accumulation (line3D.cc:1255-1274); a zero
 // similarity never changes that accumulation, so visiting only the supporters gives the same float result.
@@ -685,16 +685,20 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
     const uint32_t vi = gseg_view[g];
     const ViewDev& v = views[vi];
     const SegX sx = views[0].segx[g];   // global array (upload_views): views[0].segx is its base
-    // the supporters' depths and cameras are read from LDS (one coalesced pass) instead of one dependent global
-    // load per set bit
+    // the supporters' depths, cameras and unprojected 3D directions are read from LDS: one coalesced pass over the
+    // list and ONE unprojection (fp64 sqrt + 3 divisions) per hypothesis, instead of one dependent global load and
+    // one unprojection per (hypothesis, supporter) pair
     __shared__ float s_d1[4][kScoreCap], s_d2[4][kScoreCap];
     __shared__ uint32_t s_tv[4][kScoreCap];
+    __shared__ double s_dir[4][kScoreCap][3];
     const bool staged = L <= kScoreCap;
     if (staged) {
         for (uint32_t m0 = 0; m0 < L; m0 += 64)
             if (m0 + lane < L) {
                 const DEntry& e = dents[b + m0 + lane];
                 s_d1[wave][m0 + lane] = e.dp1; s_d2[wave][m0 + lane] = e.dp2; s_tv[wave][m0 + lane] = e.tgt_view;
+                const d3 dir = entry_dir(v.C, sx, e.dp1, e.dp2);
+                s_dir[wave][m0 + lane][0] = dir.x; s_dir[wave][m0 + lane][1] = dir.y; s_dir[wave][m0 + lane][2] = dir.z;
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -706,7 +710,8 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
         if (i < L) {
             const bool present = (P[i >> 6] >> (i & 63)) & 1ull;
             DEntry a = dents[b + i];
-            const d3 ad = entry_dir(v.C, sx, a.dp1, a.dp2);
+            const d3 ad = staged ? d3{s_dir[wave][i][0], s_dir[wave][i][1], s_dir[wave][i][2]}
+                                 : entry_dir(v.C, sx, a.dp1, a.dp2);
             float score3D = 0.0f, cur = 0.0f;
             uint32_t cur_cam = kEmpty;
             if (present) {
@@ -715,11 +720,15 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
                     while (m) {
                         const uint32_t j = w * 64 + (uint32_t)__ffsll((long long)m) - 1u;
                         m &= m - 1;
-                        float odp1, odp2; uint32_t otv;
-                        if (staged) { odp1 = s_d1[wave][j]; odp2 = s_d2[wave][j]; otv = s_tv[wave][j]; }
-                        else { const DEntry& o = dents[b + j]; odp1 = o.dp1; odp2 = o.dp2; otv = o.tgt_view; }
-                        const float sim = sim_value(ad, a.dp1, a.dp2, a.reg1, a.reg2,
-                                                    entry_dir(v.C, sx, odp1, odp2), odp1, odp2, sc);
+                        float odp1, odp2; uint32_t otv; d3 od;
+                        if (staged) {
+                            odp1 = s_d1[wave][j]; odp2 = s_d2[wave][j]; otv = s_tv[wave][j];
+                            od = d3{s_dir[wave][j][0], s_dir[wave][j][1], s_dir[wave][j][2]};
+                        } else {
+                            const DEntry& o = dents[b + j]; odp1 = o.dp1; odp2 = o.dp2; otv = o.tgt_view;
+                            od = entry_dir(v.C, sx, odp1, odp2);
+                        }
+                        const float sim = sim_value(ad, a.dp1, a.dp2, a.reg1, a.reg2, od, odp1, odp2, sc);
                         if (otv == cur_cam) {
                             if (sim > cur) { score3D -= cur; score3D += sim; cur = sim; }
                         } else {
