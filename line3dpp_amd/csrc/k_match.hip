@@ -23,6 +23,8 @@
 // Roofline: compulsory HBM traffic per directed pair is 16*(Ms+Mt) B read + 32*K*Ms B written;
 // per pair test that is < 0.2 B against ~30 fp32 VALU issues, so the kernel is VALU-issue bound
 // (DESIGN.md §roofline).  No MFMA: there is no contraction here.
+#include <cstdlib>
+
 #include "l3d_dev.h"
 #include "l3d_kernels.h"
 
@@ -58,7 +60,8 @@ template <> struct IdxT<true> { typedef uint16_t type; };
 template <bool IX16>
 struct Lds {
     typedef typename IdxT<IX16>::type idx_t;
-    L3D_LDS volatile uint32_t* ring;   // [kRing]
+    L3D_LDS volatile uint32_t* ring;   // [waves][kRing]
+    L3D_LDS volatile uint32_t* row_src;  // [kBlock] source segment of each row (epilogue)
     L3D_LDS volatile float* minov;     // [kBlock]
     L3D_LDS volatile uint32_t* claim;  // [kBlock]
     L3D_LDS volatile float* top_ov;    // [kBlock*K]
@@ -68,10 +71,11 @@ struct Lds {
 };
 
 template <bool IX16>
-__device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K) {
+__device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K, uint32_t waves) {
     typedef typename IdxT<IX16>::type idx_t;
     Lds<IX16> l;
-    l.ring = (L3D_LDS volatile uint32_t*)base; base += kRing * sizeof(uint32_t);
+    l.ring = (L3D_LDS volatile uint32_t*)base; base += waves * kRing * sizeof(uint32_t);
+    l.row_src = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
     l.minov = (L3D_LDS volatile float*)base; base += kBlock * 4;
     l.claim = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
     l.top_ov = (L3D_LDS volatile float*)base; base += (size_t)kBlock * K * 4;
@@ -132,8 +136,13 @@ __device__ __forceinline__ uint32_t fuse_orientation(const OrientFuse& of, const
 // MODE 2: write every accepted match in ascending target order (kNN <= 0, pass 2)
 // BRUTE: skip the pre-filter (every pair goes through the exact test) -- on-GPU check that the
 //        pre-filter never loses a match.
-template <int MODE, bool BRUTE, bool IX16>
-__global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restrict__ views,
+// WPG: waves per workgroup (1 or 2).  Both waves of a workgroup hold the SAME 64 source rows and share their top-K
+//      tables in LDS; wave q visits the target chunks with index = q (mod 2).  A work item is then half as long, which
+//      shortens the ramp-down tail of the launch (waves cannot migrate: at the end some SIMDs still hold a full set of
+//      long items while others are empty).  The waves meet at two barriers only (tables initialised / all candidates
+//      inserted); a row's table is guarded by a compare-and-swap lock in LDS.
+template <int MODE, bool BRUTE, bool IX16, int WPG>
+__global__ __launch_bounds__(kBlock * WPG) void k_match_pairs(const ViewDev* __restrict__ views,
                                                            const PairDesc* __restrict__ pairs,
                                                            const WorkItem* __restrict__ work, uint32_t nwork,
                                                            Slot* __restrict__ slots,
@@ -154,9 +163,10 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
     const ViewDev& vt = views[pd.tgt];
     const uint32_t K = pd.K, Ms = pd.Ms, Mt = pd.Mt;
     typedef typename IdxT<IX16>::type idx_t;
-    Lds<IX16> L = carve<IX16>((L3D_LDS char*)smem, MODE == 0 ? K : 0);
-    const uint32_t tid = threadIdx.x, lane = tid;
-    L3D_LDS volatile uint32_t* ring = L.ring;
+    Lds<IX16> L = carve<IX16>((L3D_LDS char*)smem, MODE == 0 ? K : 0, WPG);
+    const uint32_t q = WPG > 1 ? threadIdx.x >> 6 : 0u;          // wave of the workgroup
+    const uint32_t tid = threadIdx.x & 63u, lane = tid;          // row of the work item = lane
+    L3D_LDS volatile uint32_t* ring = L.ring + q * kRing;
     // epipolar-band culling (kNN mode only: the keep-all rows must be filled in ascending target order)
     const PairCull* pc = (MODE == 0 && !BRUTE && cp.cull && cp.cull[wi.pair].enabled) ? &cp.cull[wi.pair] : nullptr;
     const bool cull = pc != nullptr;
@@ -193,9 +203,13 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
             live = true;
         }
     }
-    L.cnt[tid] = 0;
-    L.minov[tid] = thr;
-    L.claim[tid] = kEmpty;
+    if (q == 0) {
+        L.cnt[tid] = 0;
+        L.minov[tid] = thr;
+        L.claim[tid] = kEmpty;
+        L.row_src[tid] = src;
+    }
+    if (WPG > 1) __syncthreads();
     uint32_t head = 0, tail = 0;   // wave-uniform ring cursors
     // tau band of the wave (hull of the live lanes), kept in SGPRs
     float wlo = live ? blo : __builtin_inff(), whi = live ? bhi : -__builtin_inff();
@@ -243,11 +257,11 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
             const float4 s4 = vs.seg4[sg], t4 = vt.seg4[tg];
             const float ov = exact_overlap(F, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w);
             // a full row only admits overlaps that beat its K-th best under (overlap desc, tgt asc); minov == thr
-            // while the row is not full.  Without culling the candidates of a row arrive in ascending target
-            // order and a tie always loses; with culling the order is arbitrary and the comparator at the
-            // insertion decides a tie.
+            // while the row is not full.  Without culling (and with one wave per row group) the candidates of a row
+            // arrive in ascending target order and a tie always loses; otherwise the order is arbitrary and the
+            // comparator at the insertion decides a tie.
             const float need = (MODE == 0) ? L.minov[sl] : thr;
-            if (ov > need || (cull && ov == need && ov > thr)) {
+            if (ov > need || ((cull || WPG > 1) && ov == need && ov > thr)) {
                 res.overlap = ov;
                 L3D_STAT(2, 1);
                 pending = exact_depths(vs.segx[sg], vt.segx[tg], vs.C, vt.C, res);
@@ -256,11 +270,24 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
         }
         // several candidates of one drain may belong to the same row: one at a time, lowest lane first (without
         // culling a row therefore sees its candidates in ascending target order, which MODE 2 relies on)
+        // With several waves per row group the row's table is a critical section: compare-and-swap lock (a wave's
+        // own contenders are serialised by the LDS atomic unit just the same), released after the update.
         while (__ballot(pending)) {
-            if (pending) __hip_atomic_fetch_min((L3D_LDS uint32_t*)&L.claim[sl], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const bool win = pending && (L.claim[sl] == lane);
+            bool win;
+            if (WPG > 1) {
+                win = false;
+                if (pending) {
+                    uint32_t expect = kEmpty;
+                    win = __hip_atomic_compare_exchange_strong((L3D_LDS uint32_t*)&L.claim[sl], &expect, threadIdx.x,
+                                                               __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
+                if (pending) __hip_atomic_fetch_min((L3D_LDS uint32_t*)&L.claim[sl], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                win = pending && (L.claim[sl] == lane);
+            }
             if (win) {
-                L.claim[sl] = kEmpty;
+                if (WPG == 1) L.claim[sl] = kEmpty;
                 pending = false;
                 const uint32_t c = L.cnt[sl];
                 if (MODE == 1) {
@@ -287,6 +314,9 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
                         }
                     }
                 }
+                if (WPG > 1)
+                    __hip_atomic_store((L3D_LDS uint32_t*)&L.claim[sl], kEmpty, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         // feed the K-th best overlap back into the owning lane's pre-filter threshold
@@ -322,6 +352,7 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
         } else {
             wm = (nch - g0 >= 32) ? 0xFFFFFFFFu : ((1u << (nch - g0)) - 1u);
         }
+        if (WPG > 1) wm &= 0x55555555u << q;   // this wave's chunks: index = q (mod 2)
         while (wm) {
             const uint32_t tb = (g0 + (uint32_t)__builtin_ctz(wm)) * 64;
             wm &= wm - 1;
@@ -393,16 +424,14 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
     // with the arithmetic of the acceptance test (identical values), and the orientation filter of phase B
     // (checkMatchOrientation, line3D.cc:811-858), which is a function of the slot alone: its flags are written with
     // the slot and the hypothesis counters of phase B are fed from here instead of by a pass that re-reads every slot.
-    L3D_LDS volatile uint32_t* row_src = ring;          // the ring is idle now: source segment of each row
-    row_src[tid] = src;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (WPG > 1) __syncthreads();                       // every wave's candidates are in the tables
+    L3D_LDS volatile uint32_t* row_src = L.row_src;
     const uint32_t n_rows = min((uint32_t)kBlock, Ms - wi.src0);
     const uint32_t gs = (uint32_t)(vs.segx - views[0].segx), gt = (uint32_t)(vt.segx - views[0].segx);
     const bool hands_inverse = pd.tgt > pd.src;   // inverse copy only towards a view processed later (:1680)
     const uint32_t n_items = n_rows * K;
-    for (uint32_t base = 0; base < n_items; base += 64) {
+    for (uint32_t base0 = 0; base0 < n_items; base0 += 64 * WPG) {
+        const uint32_t base = base0 + q * 64;           // first item of this wave in this pass
         const uint32_t it = base + lane;
         const bool in = it < n_items;
         const uint32_t r = in ? it / K : 0u, j = it - r * K;
@@ -457,9 +486,20 @@ __global__ __launch_bounds__(kBlock) void k_match_pairs(const ViewDev* __restric
     }
 }
 
-size_t match_lds_bytes(int mode, uint32_t K, bool ix16) {
+size_t match_lds_bytes(int mode, uint32_t K, bool ix16, uint32_t waves) {
     const size_t ib = ix16 ? 2 : 4;
-    return kRing * 4 + 2 * kBlock * 4 + 2 * kBlock * ib + (mode == 0 ? (size_t)kBlock * K * (4 + ib) : 0);
+    return (size_t)waves * kRing * 4 + 3 * kBlock * 4 + 2 * kBlock * ib + (mode == 0 ? (size_t)kBlock * K * (4 + ib) : 0);
+}
+
+// Two waves per work item pay off while the launch has few items for the machine (C0: kernel 0.34 -> 0.24 ms, C1 with
+// 1.4 items per wave slot: -2 %); with many rounds of items the duplicated per-wave work costs more than the shorter
+// tail gains (C4: +4 %; four waves per item were slower everywhere: each wave drains its own ring, so the K-th-best
+// feedback arrives later and more candidates reach the exact test).
+uint32_t match_waves_per_group(int mode, bool brute, uint32_t nwork) {
+    if (mode != 0 || brute) return 1;   // keep-all rows need ascending target order; the brute path is a test hook
+    static const int forced = [] { const char* e = std::getenv("L3D_MATCH_WPG"); return e ? std::atoi(e) : 0; }();
+    if (forced == 1 || forced == 2) return (uint32_t)forced;
+    return nwork <= 16384u ? 2u : 1u;
 }
 
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,
@@ -470,18 +510,23 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
     if (mode == 0 && (!of.cnt_pack || !of.inv_pos)) return hipErrorInvalidValue;   // MODE 0 always fuses
     const uint32_t grid = ((nwork + 7) / 8) * 8;
     if (!(mode == 0 && !brute)) ix16 = false;       // the compact layout is only instantiated for the hot variant
-    const size_t lds = match_lds_bytes(mode, maxK, ix16);
-#define L3D_LAUNCH(M, B, X)                                                                               \
-    do {                                                                                                  \
-        hipError_t e = hipFuncSetAttribute((const void*)k_match_pairs<M, B, X>,                           \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-        if (e != hipSuccess) return e;                                                                    \
-        hipLaunchKernelGGL((k_match_pairs<M, B, X>), dim3(grid), dim3(kBlock), lds, stream, views, pairs, \
-                           work, nwork, slots, row_counts, thr, pools, of);                               \
+    const uint32_t wpg = match_waves_per_group(mode, brute, nwork);
+    const size_t lds = match_lds_bytes(mode, maxK, ix16, wpg);
+#define L3D_LAUNCH(M, B, X, W)                                                                                \
+    do {                                                                                                      \
+        hipError_t e = hipFuncSetAttribute((const void*)k_match_pairs<M, B, X, W>,                            \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+        if (e != hipSuccess) return e;                                                                        \
+        hipLaunchKernelGGL((k_match_pairs<M, B, X, W>), dim3(grid), dim3(kBlock * W), lds, stream, views,     \
+                           pairs, work, nwork, slots, row_counts, thr, pools, of);                            \
     } while (0)
-    if (mode == 0) { if (brute) L3D_LAUNCH(0, true, false); else if (ix16) L3D_LAUNCH(0, false, true); else L3D_LAUNCH(0, false, false); }
-    else if (mode == 1) { if (brute) L3D_LAUNCH(1, true, false); else L3D_LAUNCH(1, false, false); }
-    else { if (brute) L3D_LAUNCH(2, true, false); else L3D_LAUNCH(2, false, false); }
+    if (mode == 0) {
+        if (brute) L3D_LAUNCH(0, true, false, 1);
+        else if (ix16) { if (wpg == 2) L3D_LAUNCH(0, false, true, 2); else L3D_LAUNCH(0, false, true, 1); }
+        else { if (wpg == 2) L3D_LAUNCH(0, false, false, 2); else L3D_LAUNCH(0, false, false, 1); }
+    }
+    else if (mode == 1) { if (brute) L3D_LAUNCH(1, true, false, 1); else L3D_LAUNCH(1, false, false, 1); }
+    else { if (brute) L3D_LAUNCH(2, true, false, 1); else L3D_LAUNCH(2, false, false, 1); }
 #undef L3D_LAUNCH
     return hipGetLastError();
 }

@@ -652,7 +652,8 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         maxMt = std::max(maxMt, pd.Mt);
         for (uint32_t s0 = 0; s0 < pd.Ms; s0 += kMatchRows) work[w++] = WorkItem{p, s0};
     }
-    if (match_lds_bytes(mode, maxK) > 160 * 1024) return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
+    if (match_lds_bytes(mode, maxK, false, match_waves_per_group(mode, c->brute, (uint32_t)n_work)) > 160 * 1024)
+        return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
     L3D_HIP_CHECK(c->d_work.reserve(n_work));
     L3D_HIP_CHECK(hipMemcpyAsync(c->d_work.p, work, n_work * sizeof(WorkItem), hipMemcpyHostToDevice, c->stream));
     L3D_HIP_CHECK(hipEventRecord(c->ev[8], c->stream));
@@ -1781,7 +1782,8 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         pd.src = 0; pd.tgt = 1; pd.Ms = Ms; pd.Mt = Mt; pd.K = (uint32_t)kNN; pd.row_off = 0; pd.slot_off = 0;
         std::vector<WorkItem> work;
         for (uint32_t s0 = 0; s0 < Ms; s0 += kMatchRows) work.push_back(WorkItem{0, s0});
-        if (match_lds_bytes(0, pd.K) > 160 * 1024) return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
+        if (match_lds_bytes(0, pd.K, false, match_waves_per_group(0, false, (uint32_t)work.size())) > 160 * 1024)
+            return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
         L3D_HIP_CHECK(dv.reserve(2)); L3D_HIP_CHECK(dp.reserve(1)); L3D_HIP_CHECK(dw.reserve(work.size()));
         L3D_HIP_CHECK(ds.reserve((size_t)Ms * pd.K));
         L3D_HIP_CHECK(hipMemcpy(dv.p, hv, sizeof(hv), hipMemcpyHostToDevice));

@@ -43,7 +43,8 @@ struct OrientFuse {
 };
 
 // ---- k_match.hip ----
-size_t match_lds_bytes(int mode, uint32_t K, bool ix16 = false);
+size_t match_lds_bytes(int mode, uint32_t K, bool ix16 = false, uint32_t waves = 1);
+uint32_t match_waves_per_group(int mode, bool brute, uint32_t nwork);   // waves that share one 64-row work item of k_match_pairs
 hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
                                uint32_t max_M, CullPools pools, hipStream_t stream);
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,

@@ -683,10 +683,15 @@ def test_compact_exchange_emulated_on_one_gpu(world):
             assert np.array_equal(ao, bo) and a.tobytes() == b.tobytes()
         ge, gl, _ = g.affinity(); re_, rl, _ = ref.affinity()
         assert ge.tobytes() == re_.tobytes() and gl.tobytes() == rl.tobytes()
-    # misuse: packing a pair this context has not matched
+    # misuse: packing a pair this context has not matched; matching or expanding a pair twice (its slots already
+    # feed the phase-B counters) -- refused, and the call sequence still completes
     g = _gpu(sc)
     assert g.matchBegin() and not g.packSlotIndices(0, 1)
-    assert g.matchPairs(0, len(pairs)) and g.matchFinish()
+    assert g.matchPairs(0, len(pairs))
+    assert not g.matchPairs(0, 1) and not g.expandSlotIndices(0, 1)
+    assert g.matchFinish() and g.computeAffinity()
+    ge, gl, _ = g.affinity(); re_, rl, _ = ref.affinity()
+    assert ge.tobytes() == re_.tobytes()
 
 
 def test_txt_writer_matches_accessor_and_reference_writer(tmp_path):
