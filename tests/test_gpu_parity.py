@@ -430,6 +430,29 @@ def test_large_views_tile_loop_parity():
     assert not r["missing"] and not r["extra"] and r["bit_exact"] and r["n_cpu"] > 100000
 
 
+@pytest.mark.parametrize("n_segs", [5000, 9000])
+def test_width_classes_of_large_views_vs_brute_force(n_segs):
+    """From 4096 segments per view on, k_cull_prepare groups source rows with wide epipolar bands apart (one class,
+    two from 8192 on).  The row order must not change the result: culled + pre-filtered path against the brute-force
+    path (every pair through the exact test) of the same library, slot for slot."""
+    sc = make_scene(16, n_segs, n_neighbors=2, seed=57)     # neighbouring views of a 16-view ring: epipoles far outside
+    sc.views = sc.views[:3]
+    for v in sc.views:
+        v.neighbors = [c for c in (0, 1, 2) if c != v.cam]
+    out = []
+    for brute in (0, 1):
+        g = _gpu(sc); g.set_brute_force(brute)
+        assert g.matchBegin(kNN=10) and g.matchPairs(0, len(g.pairs()[0]))
+        if not brute:
+            assert g.timings()["culled_pairs"] == len(g.pairs()[0])
+        out.append([g.pair_slots(pi) for pi in range(len(g.pairs()[0]))])
+    n = 0
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+        n += int((b["tgt_seg"] != EMPTY).sum())
+    assert n > 10 * n_segs
+
+
 def test_many_views_chain_properties():
     """BASELINE C3-like: a long chain (256 views x 250 segments, two rings): full parity with the oracle."""
     sc = make_scene(256, 250, n_neighbors=6, seed=53, rings=2, radius=22.0)
