@@ -4,7 +4,8 @@
 // triangulationDepths (:1168-1193) and the reference's K_match_lines/host-heap pipeline
 // (cudawrapper.cu:186-253, 549-658) with a design that never materialises the Ms x Mt matrix:
 //
-//   workgroup  = (directed pair, 64 source segments in epipolar-band order), one wave64
+//   workgroup  = (directed pair, 64 source segments in epipolar-band order), one wave64 -- or two that split the
+//                target chunks and share the rows' top-K tables (template parameter WPG)
 //   lane       = one source segment; its two epipolar lines live in VGPRs (fp32, unit normal,
 //                image-centre origin)
 //   k_cull_prepare orders rows and targets of the pair by epipolar band (tau); the wave visits only the
@@ -32,7 +33,7 @@ namespace l3d {
 
 namespace {
 
-constexpr int kBlock = kMatchRows;  // one wave64 per workgroup: waves never wait for each other
+constexpr int kBlock = kMatchRows;  // rows per work item = lanes of a wave64; a workgroup is WPG (1 or 2) such waves
 constexpr int kRing = 256;          // candidate ring (entries); >= 63 + 2*64 (drained after every two pushes)
 constexpr float kKappa = 1.0e-2f;  // pre-filter slack, px: margin = kKappa * max|1/d| + kKappa0
 constexpr float kKappa0 = 2.0e-4f;
