@@ -129,15 +129,17 @@ def _scene_lines(rng, S, half=10.0):
 
 
 def make_scene(n_views, n_segs, n_neighbors=10, seed=0x4C334450, real_fraction=0.5, radius=25.0,
-               noise_px=0.5, rings=1, name=""):
-    """Ring-of-cameras scene: `n_views` views x exactly `n_segs` segments, ring neighbours +-n/2."""
+               noise_px=0.5, rings=1, name="", max_views=None):
+    """Ring-of-cameras scene: `n_views` views x exactly `n_segs` segments, ring neighbours +-n/2.
+    max_views: stop after the first `max_views` views (they are identical to the first views of the full scene: the
+    random stream is consumed view by view) -- for tests that need a slice of a large configuration."""
     rng = np.random.default_rng(seed)
     S = max(int(6 * n_segs * real_fraction), 64)
     P, Q, N = _scene_lines(rng, S)
     K = np.array([[FOCAL, 0, WIDTH / 2], [0, FOCAL, HEIGHT / 2], [0, 0, 1.0]])
     views = []
     per_ring = n_views // rings
-    for i in range(n_views):
+    for i in range(n_views if max_views is None else min(n_views, max_views)):
         ring, j = divmod(i, per_ring) if rings > 1 else (0, i)
         nr = per_ring if rings > 1 else n_views
         phi = 2 * np.pi * (j + 0.37 * ring) / nr
@@ -203,8 +205,8 @@ def load_scene_npz(path, name=""):
     return Scene(views, name or os.path.basename(path))
 
 
-def make_config(name, seed=None):
+def make_config(name, seed=None, max_views=None):
     if name == "C0":
         return load_scene_npz(C0_FILE, "C0")
     idx = list(CONFIGS).index(name)
-    return make_scene(seed=(0x4C334450 + idx) if seed is None else seed, name=name, **CONFIGS[name])
+    return make_scene(seed=(0x4C334450 + idx) if seed is None else seed, name=name, max_views=max_views, **CONFIGS[name])

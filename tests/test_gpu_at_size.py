@@ -1,0 +1,107 @@
+"""GPU parity at the BASELINE sizes (pytest -m gpu): the HIP path against the reference's own CPU code (oracle/_ref;
+the restatement when _ref is absent) on
+
+  C1  full (64 views x 2000 segments, 10 neighbours) -- the configuration bench.py's headline number is quoted on
+  C3  full (1024 views x 1000 segments, two rings)
+  C2  a 24-view slice at the configured 4096 segments x 20 neighbours (the views in the middle of the slice have their
+      full neighbour sets: the configured list lengths), all views through phase B + 32 directed pairs of phase A
+  C4  an 11-view slice at 16384 segments x 10 neighbours, likewise
+
+Everything is compared: surviving match lists (sets, order inside every list, overlap and depths bit-exact, score3D
+within 1e-4), best hypotheses (same choice, 3D end points within 1e-4), A_ as a map with weights within 1e-4.  kNN rows
+whose order differs from the reference's must be exact-overlap ties (libstdc++ priority_queue pop order of equal keys).
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from line3dpp_amd.scene import make_config
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+THREADS = min(16, len(os.sched_getaffinity(0)))   # the reference's per-row containers stop scaling beyond 16 threads
+
+
+def _context(scene):
+    from line3dpp_amd.api import Line3D
+    g = Line3D()
+    g.add_scene(scene)
+    assert g.matchImages() and g.computeAffinity()
+    return g
+
+
+def _reference(scene):
+    from oracle import oracle as O
+    o = O.Oracle(threads=THREADS, reference=O.have_reference())
+    o.add_scene(scene)
+    t0 = time.perf_counter()
+    o.match_images(); o.compute_affinity()
+    return o, time.perf_counter() - t0
+
+
+def _assert_clean(r, min_surviving, min_edges):
+    assert r["ok"], r
+    assert r["set_diff"] == 0 and r["best_set_diff"] == 0 and r["affinity_set_diff"] == 0
+    assert r["inexact_phase_a_fields"] == 0 and r["best_choice_diff"] == 0
+    assert r["order_rows"] == r["tie_rows"], "list order differs from the reference outside exact-overlap ties"
+    assert r["surviving"] >= min_surviving and r["affinity_entries"] >= min_edges, r
+    assert max(r["max_rel_score3D"], r["max_rel_endpoints"], r["max_rel_affinity"]) <= H.REL_TOL
+
+
+def _phase_a_sample(g, scene, n_pairs, seed=0):
+    """phase-A slots of `n_pairs` sampled directed pairs against the restatement's matchingCPU, bit for bit"""
+    from oracle import oracle as O
+    o = O.Oracle(threads=THREADS)
+    o.add_scene(scene)
+    o.begin_match()
+    pairs, _ = g.pairs()
+    rng = np.random.default_rng(seed)
+    total = ties = 0
+    for pi in rng.choice(len(pairs), min(n_pairs, len(pairs)), replace=False):
+        om, _ = o.match_pair(int(pairs[pi][0]), int(pairs[pi][1]))
+        r = H.compare_pair_fast(g.pair_slots(int(pi)), om)
+        assert r["set_diff"] == 0 and r["inexact_fields"] == 0, (int(pi), r)
+        assert r["order_rows"] == r["tie_rows"], (int(pi), r)
+        total += r["n_cpu"]; ties += r["tie_rows"]
+    o.end_match()
+    return total, ties
+
+
+def test_full_c1_against_the_reference():
+    sc = make_config("C1")
+    g = _context(sc)
+    assert g.pair_tests() == 1_280_000_000
+    o, secs = _reference(sc)
+    r = H.full_result_diff(g, o, sc)
+    print("C1", r, f"reference CPU path {secs:.1f} s on {THREADS} threads")
+    _assert_clean(r, 1_000_000, 100_000)
+    n, ties = _phase_a_sample(g, sc, 32)
+    assert n > 400_000
+
+
+def test_full_c3_against_the_reference():
+    sc = make_config("C3")
+    g = _context(sc)
+    o, secs = _reference(sc)
+    r = H.full_result_diff(g, o, sc)
+    print("C3", r, f"reference CPU path {secs:.1f} s on {THREADS} threads")
+    _assert_clean(r, 100_000, 10_000)
+    assert r["views"] == 1024
+    _phase_a_sample(g, sc, 32)
+
+
+@pytest.mark.parametrize("config,count,mid", [("C2", 24, 12), ("C4", 11, 5)])
+def test_slice_of_c2_c4_at_configured_size(config, count, mid):
+    full_nb = {"C2": 20, "C4": 10}[config]
+    sc = H.ring_slice(make_config(config, max_views=count), 0, count)
+    assert len(sc.views[mid].neighbors) == full_nb and len(sc.views[mid].segs) == {"C2": 4096, "C4": 16384}[config]
+    g = _context(sc)
+    o, secs = _reference(sc)
+    r = H.full_result_diff(g, o, sc)
+    print(config, "slice", r, f"reference CPU path {secs:.1f} s on {THREADS} threads")
+    _assert_clean(r, 100_000, 10_000)
+    n, ties = _phase_a_sample(g, sc, 32)
+    assert n > 1_000_000
