@@ -1,0 +1,200 @@
+// l3d_ctx.h -- the context behind the C-ABI (include/l3dpp_hip.h): the slice of class L3DPP::Line3D that drives the
+// hot path (line3D.h:61-424), shared by the translation units of the host side:
+//   l3d_api.hip            context layer: addImage / matchImages (begin, pairs, exchange, finish)
+//   l3d_affinity_host.hip  the affinity part of reconstruct3Dlines, collinear links, diffusion, reconstruction tail
+//   l3d_access.hip         accessors (matches_, estimated_position3D_, A_, SparseMatrix, timings)
+//   l3d_output.hip         get3Dlines and the result writers (TXT / OBJ / STL)
+//   l3d_seam.hip           the accelerator-seam entries (cudawrapper.h:54-80) with CPU-path semantics
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <unordered_set>
+
+#include "l3d_host.h"
+#include "l3d_recon.h"
+
+struct l3d_ctx;
+
+namespace l3d {
+
+// ---- prototypes of the launchers in k_views.hip / k_affinity.hip -------------------------------
+hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, uint32_t* total, hipStream_t);
+hipError_t launch_collin(int pass, const ViewDev* views, uint32_t n_views, uint32_t max_M, const uint32_t* seg_base,
+                         float collin_t, uint32_t* cnt, const uint32_t* coll_off, uint32_t* coll_idx, hipStream_t);
+hipError_t launch_aff_coll_count(int mode, uint32_t n_items, const uint32_t* surv_tg, const float* simv, const HypRec*,
+                                 const uint32_t* seg_base, const uint32_t* coll_off, uint32_t* cnt, hipStream_t);
+hipError_t launch_aff_coll_sim(int mode, uint32_t n_items, const uint32_t* surv_sg, const uint32_t* surv_tg,
+                               const int32_t* hyp_of_seg, const HypRec*, const ViewDev*, const uint32_t* seg_base,
+                               const uint32_t* gseg_view, const uint32_t* coll_off, const uint32_t* coll_idx,
+                               const uint32_t* item_off, const ViewAff*, const float* medians, const float* msdl,
+                               float two_sigA_sqr, uint32_t* out_seg, float* out_sim, hipStream_t);
+hipError_t launch_seam_entries(uint32_t n, const float4* m4, const float2* rt, const ViewDev*, float k, DEntry*, hipStream_t);
+hipError_t launch_seam_all_present(uint32_t G, const uint32_t* off, const uint32_t* boff, uint64_t* bits, hipStream_t);
+hipError_t launch_seam_scores_out(uint32_t n, const DEntry*, float* scores, hipStream_t);
+hipError_t launch_fill_gseg_view(const uint32_t* seg_base, uint32_t V, uint32_t max_M, uint32_t* gseg_view, hipStream_t);
+hipError_t launch_orient_pairs(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
+                               const uint32_t* seg_base, Slot* slots, unsigned long long* cnt_pack, uint32_t* inv_pos,
+                               double thr_lo, double thr_hi, hipStream_t);
+hipError_t launch_unpack_counts(uint32_t G, const unsigned long long* cnt_pack, uint32_t* cnt_all, uint32_t* cnt_inv,
+                                hipStream_t);
+hipError_t launch_inv_fill(const PairDesc*, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
+                           const Slot* slots, const uint32_t* inv_off, const uint32_t* inv_pos, InvRef* refs,
+                           hipStream_t);
+hipError_t launch_build_lists_all(uint32_t G, const ViewDev*, const PairDesc*, const uint32_t* seg_base,
+                                  const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
+                                  const uint32_t* off, const uint32_t* inv_off, const InvRef*, const Slot*, DEntry*,
+                                  uint32_t* eref, uint32_t uniform_K, hipStream_t);
+hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, uint32_t* long_list, uint32_t* n_long,
+                           hipStream_t);
+hipError_t launch_support_long(uint32_t n_long, const uint32_t* long_list, const uint32_t* off, const uint32_t* boff,
+                               const DEntry*, uint64_t* bits, const ViewDev*, const uint32_t* gseg_view, SimConst,
+                               hipStream_t);
+hipError_t launch_support_all(uint32_t g0, uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry*, uint64_t* bits,
+                              const ViewDev*, const uint32_t* seg_base, const uint32_t* gseg_view, SimConst, hipStream_t);
+hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff,
+                                const uint32_t* inv_off, const uint32_t* eref, uint64_t* bits, uint8_t* positive,
+                                hipStream_t);
+hipError_t launch_score_all(uint32_t g0, uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view, DEntry*,
+                            const uint64_t* bits, Slot*, uint32_t* max_score_bits, const ViewDev*, const uint32_t* seg_base,
+                            SimConst, hipStream_t);
+hipError_t launch_filter_all(uint32_t G, const uint32_t* off, const uint32_t* gseg_view, DEntry*,
+                             const uint32_t* max_score_bits, uint32_t* surv_cnt, uint32_t* has_best,
+                             uint32_t* best_pos, hipStream_t);
+hipError_t launch_filter_write_all(const ViewDev*, const PairDesc*, const uint32_t* seg_base, uint32_t G,
+                                   const uint32_t* gseg_view, const uint32_t* off, const DEntry*, const Slot*,
+                                   const uint32_t* surv_off, const uint32_t* hyp_off, const uint32_t* best_pos,
+                                   Match* surv, uint32_t* surv_tg, uint32_t* surv_sg, int32_t* hyp_of_seg, HypRec*,
+                                   float* depths, hipStream_t);
+hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base,
+                             float* out, hipStream_t);
+hipError_t launch_aff_sim(uint32_t N, const uint32_t* surv_sg, const uint32_t* surv_tg, const int32_t* hyp_of_seg,
+                          const HypRec*, const ViewAff*, const float* medians, const float* msdl, float two_sigA_sqr,
+                          float* simv, int32_t* ca, int32_t* cb, hipStream_t);
+hipError_t launch_aff_flag(uint32_t N, const uint32_t* surv_off, const uint32_t* surv_sg, const uint32_t* surv_tg,
+                           const float* simv, const int32_t* ca, const int32_t* cb, uint32_t* flag, hipStream_t);
+hipError_t launch_fill_u32(uint32_t*, uint32_t n, uint32_t val, hipStream_t);
+hipError_t launch_aff_touch(uint32_t N, const uint32_t* flag, const uint32_t* epos, const int32_t* ca,
+                            const int32_t* cb, uint32_t* first_touch, hipStream_t);
+hipError_t launch_aff_mark(uint32_t H, const uint32_t* first_touch, uint32_t* touch_flag, hipStream_t);
+hipError_t launch_aff_emit(uint32_t N, const uint32_t* flag, const uint32_t* epos, const int32_t* ca,
+                           const int32_t* cb, const float* simv, const uint32_t* first_touch,
+                           const uint32_t* touch_rank, const HypRec*, void* edges, void* local2global, hipStream_t);
+
+// ---- host helpers shared by the translation units (defined in l3d_api.hip) ----
+int fail(int code, const std::string& msg);
+const char* last_error_cstr();
+void translate(::l3d_ctx& c);      // Line3D::translate, line3D.cc:500-536
+void untranslate(::l3d_ctx& c);    // line3D.cc:539-545
+void make_cull(const double F[9], double ws, double hs, double wt, double ht, PairCull& pc);
+void orientation_thresholds(double& lo, double& hi);
+SimConst sim_thresholds(float two_sigA_sqr);
+float ev_ms(hipEvent_t a, hipEvent_t b);
+int affinity_core(::l3d_ctx* c);           // l3d_affinity_host.hip
+int ensure_affinity_host(::l3d_ctx* c);    // l3d_affinity_host.hip
+std::string output_filename(::l3d_ctx* c, int max_image_width);   // l3d_output.hip
+
+}  // namespace l3d
+
+using namespace l3d;   // host-side translation units of this library only (never included by users of the C-ABI)
+
+// (global namespace: the C-ABI's opaque handle type; its members are l3d:: types)
+struct l3d_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::recursive_mutex mu;                                  // view_mutex_/view_reserve_mutex_ stand-in
+    std::map<uint32_t, std::unique_ptr<HostView>> views;   // views_ (ascending camID)
+    std::vector<HostView*> order;                   // view index -> view (ascending camID)
+    std::vector<float> views_avg_depths;            // views_avg_depths_
+    // params (matchImages)
+    float sigma_p = 2.5f, sigma_a = 10.0f, two_sigA_sqr = 200.0f, epipolar_overlap = 0.25f;
+    float const_regularization_depth = -1.0f, med_scene_depth = (float)kEps, med_scene_depth_lines = 0.0f;
+    int kNN = 10, num_neighbors = 10;
+    bool fixed3Dregularizer = false;
+    bool brute = false;                             // test hook: disable the fp32 pre-filter
+    double orient_lo = -1.0, orient_hi = 1.0;       // dp window equivalent to acos(dp) in (PI/32, 31PI/32)
+    d3 translation{0, 0, 0};
+    // state
+    enum { IDLE, BEGUN, MATCHED } state = IDLE;
+    bool affinity_done = false;
+    std::vector<PairDesc> pairs;
+    std::vector<uint32_t> pair_src_cam, pair_tgt_cam;
+    std::vector<char> pair_done;
+    uint64_t n_slots = 0, pair_tests = 0;
+    uint32_t n_rows_total = 0;
+    // device
+    DevBuf<ViewDev> d_views;
+    DevBuf<PairDesc> d_pairs;
+    DevBuf<WorkItem> d_work;
+    DevBuf<Slot> d_slots;
+    DevBuf<uint32_t> d_slot_idx;   // compact exchange form of d_slots (N > 1 ranks): target index per slot
+    // epipolar-band culling pools (l3d_kernels.h)
+    std::vector<PairCull> cull;
+    DevBuf<PairCull> d_cull;
+    DevBuf<uint32_t> d_src_perm, d_tgt_perm;
+    DevBuf<float2> d_src_band, d_chunk_band, d_tgt_band;
+    DevBuf<float4> d_tgt_sf;
+    bool use_cull = true;
+    unsigned visibility_t = 3;                      // visibility_t_ / perform_RDD_ of the last reconstruct3Dlines
+    bool perform_rdd = false;
+    // A_ / local2global_ stay on the device; the host copies (edges, l2g) are fetched on first use
+    uint32_t aff_n_edges = 0, aff_n_rows = 0;
+    bool aff_host_valid = true;
+    PinnedBuf<uint32_t> h_cnt;
+    hipStream_t aux[2] = {nullptr, nullptr};        // aux[0] high priority (phase-A first half, the chain), aux[1]
+    std::vector<hipEvent_t> pipe_ev;
+    std::vector<uint8_t> pair_counted;   // the pair's slots carry orientation flags and are in the phase-B counters
+    hipEvent_t sev[5] = {};                         // prepared, half A done, half B done, memsets done, orient A done
+    DevBuf<SegX> d_gsegx;                           // SegX of every segment, global segment order
+    float collinearity_t = -1.0f;                   // collinearity_t_ (reconstruct3Dlines); > 0: collinear links
+    DevBuf<uint32_t> d_coll_cnt, d_coll_off, d_coll_idx, d_item_cnt, d_item_off, d_item_seg;
+    DevBuf<float> d_item_sim;
+    // pinned staging of the small host->device tables (reused across calls; every public call ends synchronised)
+    PinnedBuf<ViewDev> h_views;
+    PinnedBuf<PairDesc> h_pairs;
+    PinnedBuf<PairCull> h_cull;
+    PinnedBuf<WorkItem> h_work;
+    PinnedBuf<uint32_t> h_vout, h_small;
+    bool timing_pending = false;                    // phase-A events recorded but not read yet
+    uint32_t pending_launches = 0;
+    DevBuf<uint32_t> d_row_counts;
+    // phase B (global over all views; G = sum of M)
+    uint32_t G = 0, n_ents = 0, n_surv = 0, n_hyps = 0;
+    std::vector<uint32_t> seg_base;                 // [V+1]
+    DevBuf<uint32_t> d_seg_base, d_gseg_view, d_cnt, d_off, d_scan_tmp, d_scal, d_max_score;
+    DevBuf<uint32_t> d_surv_cnt, d_has_best, d_best_pos, d_surv_off, d_hyp_off, d_surv_tg, d_surv_sg;
+    DevBuf<InvRef> d_refs;
+    DevBuf<uint64_t> d_bits;
+    DevBuf<uint32_t> d_eref;
+    DevBuf<uint8_t> d_positive;
+    DevBuf<uint32_t> d_bits_len, d_boff, d_long_list;
+    DevBuf<uint32_t> d_cnt_inv, d_inv_off, d_vout_pairs, d_vout_off, d_inv_pos;
+    DevBuf<unsigned long long> d_cnt_pack;
+    std::vector<uint32_t> vout_off;
+    DevBuf<DEntry> d_dents;
+    DevBuf<Match> d_surv;
+    DevBuf<int32_t> d_hyp_of_seg;
+    DevBuf<float> d_depths, d_medians;              // d_medians[V]
+    DevBuf<HypRec> d_hyps;
+    std::vector<uint32_t> h_surv_off, h_hyp_off;    // lazily fetched for the accessors
+    bool host_offsets_valid = false;
+    // affinity
+    DevBuf<ViewAff> d_vaff;
+    DevBuf<float> d_simv, d_msdl;
+    DevBuf<int32_t> d_ca, d_cb;
+    DevBuf<uint32_t> d_flag, d_epos, d_first_touch, d_touch_flag, d_touch_rank;
+    DevBuf<l3d_cledge> d_edges;
+    DevBuf<l3d_segment2d> d_l2g;
+    std::vector<l3d_cledge> edges;
+    std::vector<l3d_segment2d> l2g;
+    std::vector<ReconLine> lines3D;                 // lines3D_ (original frame)
+    bool lines_done = false;
+    // timings
+    hipEvent_t ev[10] = {};
+    l3d_timings tm{};
+};

@@ -203,7 +203,8 @@ def ring_slice(scene, first, count):
     out.views = []
     for i in range(count):
         w = copy.copy(scene.views[(first + i) % scene.n_views])
-        w.neighbors = [n for n in w.neighbors if n in keep]
+        w.neighbors = [n for n in w.neighbors if n in keep] or \
+            [scene.views[(first + (i + 1) % count) % scene.n_views].cam]   # never empty (line3D.cc:154 rejects the view)
         out.views.append(w)
     out.views.sort(key=lambda v: v.cam)
     out.name = f"{scene.name}[{first}:{first + count}]"

@@ -77,7 +77,7 @@ def test_full_c1_against_the_reference():
     o, secs = _reference(sc)
     r = H.full_result_diff(g, o, sc)
     print("C1", r, f"reference CPU path {secs:.1f} s on {THREADS} threads")
-    _assert_clean(r, 1_000_000, 100_000)
+    _assert_clean(r, 100_000, 100_000)
     n, ties = _phase_a_sample(g, sc, 32)
     assert n > 400_000
 
@@ -88,7 +88,7 @@ def test_full_c3_against_the_reference():
     o, secs = _reference(sc)
     r = H.full_result_diff(g, o, sc)
     print("C3", r, f"reference CPU path {secs:.1f} s on {THREADS} threads")
-    _assert_clean(r, 100_000, 10_000)
+    _assert_clean(r, 10_000, 1_000)
     assert r["views"] == 1024
     _phase_a_sample(g, sc, 32)
 
@@ -102,6 +102,6 @@ def test_slice_of_c2_c4_at_configured_size(config, count, mid):
     o, secs = _reference(sc)
     r = H.full_result_diff(g, o, sc)
     print(config, "slice", r, f"reference CPU path {secs:.1f} s on {THREADS} threads")
-    _assert_clean(r, 100_000, 10_000)
+    _assert_clean(r, 10_000, 1_000)
     n, ties = _phase_a_sample(g, sc, 32)
     assert n > 1_000_000
