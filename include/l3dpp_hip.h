@@ -137,6 +137,11 @@ int l3d_slot_index_buffer(l3d_ctx*, void** dev_ptr, uint64_t* n_slots);
 int l3d_pack_slot_indices(l3d_ctx*, uint32_t first, uint32_t count);
 int l3d_expand_slot_indices(l3d_ctx*, uint32_t first, uint32_t count);
 int l3d_match_finish(l3d_ctx*);
+/* Leaves an open l3d_match_begin without results: everything queued is drained, the views are moved back
+ * (matchImages translates them for its duration, line3D.cc:436/493), the context is idle again.  A no-op when no
+ * begin is open.  Every failing l3d_match_begin / l3d_match_images / l3d_match_finish does this itself; callers that
+ * give up between the split calls (e.g. a failed exchange in a multi-GPU run) call it explicitly. */
+int l3d_match_abort(l3d_ctx*);
 
 /* The affinity part of Line3D::reconstruct3Dlines: translate(), med_scene_depth_lines_,
  * computingAffinityMatrix(), untranslate() (line3D.cc:1749-1778, 1852-2023; collinearity off). */
@@ -144,8 +149,10 @@ int l3d_compute_affinity(l3d_ctx*);
 
 /* Line3D::reconstruct3Dlines (line3D.cc:1702-1824) up to the final 3D segments: translate(), affinity matrix
  * (as l3d_compute_affinity), graph clustering (clustering.cc), 3D line per cluster, collinear 3D segments,
- * filterTinySegments, untranslate().  Like a reference build without CUDA/Ceres, perform_diffusion and
- * use_CERES are reported and ignored (line3D.cc:1733-1744); collinearity_t > 0 is not supported.
+ * filterTinySegments, untranslate().  perform_diffusion != 0 runs the replicator-dynamics diffusion of A_
+ * (performRDD, line3D.cc:2026-2076) on the device-resident matrix; collinearity_t > 0 adds the per-image collinearity
+ * tests (View::findCollinearSegments, view.cc:150-258) and the collinear affinity links (line3D.cc:1904-1974).
+ * use_CERES is reported and ignored like in a reference build without Ceres (line3D.cc:1741-1743).
  * The clustering / reconstruction tail is small sequential host work in the reference and runs on the host
  * here as well. */
 int l3d_reconstruct_3d_lines(l3d_ctx*, uint32_t visibility_t, int perform_diffusion, float collinearity_t,

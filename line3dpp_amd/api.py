@@ -103,6 +103,10 @@ class Line3D:
     def matchFinish(self):
         return self._check(self.L.l3d_match_finish(self.h), "matchFinish")
 
+    def matchAbort(self):
+        """closes an open matchBegin without results (views untranslated, context idle); no-op otherwise"""
+        return self.L.l3d_match_abort(self.h) == 0
+
     # the affinity part of Line3D::reconstruct3Dlines, line3D.h:162-166 / line3D.cc:1749-1778
     def computeAffinity(self):
         return self._check(self.L.l3d_compute_affinity(self.h), "computeAffinity")

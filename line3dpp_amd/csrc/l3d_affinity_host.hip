@@ -173,14 +173,14 @@ int affinity_core(l3d_ctx* c) {
             L3D_HIP_CHECK(launch_aff_emit(N, c->d_flag.p, c->d_epos.p, c->d_ca.p, c->d_cb.p, c->d_simv.p,
                                           c->d_first_touch.p, c->d_touch_rank.p, c->d_hyps.p, c->d_edges.p,
                                           c->d_l2g.p, st));
-            L3D_HIP_CHECK(c->h_cnt.reserve(4));
-            L3D_HIP_CHECK(hipMemcpyAsync(c->h_cnt.p, c->d_scal.p + 3, 8, hipMemcpyDeviceToHost, st));
+            L3D_HIP_CHECK(c->h_cnt.reserve(16));
+            L3D_HIP_CHECK(hipMemcpyAsync(c->h_cnt.p + 12, c->d_scal.p + 3, 8, hipMemcpyDeviceToHost, st));
             counts_pending = true;
         }
     }
     L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
     L3D_HIP_CHECK(hipStreamSynchronize(st));
-    if (counts_pending) { c->aff_n_edges = 2 * c->h_cnt.p[0]; c->aff_n_rows = c->h_cnt.p[1]; c->aff_host_valid = false; }
+    if (counts_pending) { c->aff_n_edges = 2 * c->h_cnt.p[12]; c->aff_n_rows = c->h_cnt.p[13]; c->aff_host_valid = false; }
     c->tm.affinity_ms = ev_ms(c->ev[6], c->ev[7]);
     c->affinity_done = true;
     return L3D_OK;

@@ -252,7 +252,7 @@ void l3d_destroy(l3d_ctx* c) {
     }
     c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release(); c->d_slot_idx.release();
     c->h_views.release(); c->h_pairs.release(); c->h_cull.release(); c->h_work.release(); c->h_vout.release();
-    c->h_small.release(); c->h_cnt.release();
+    c->h_small.release(); c->h_cnt.release(); c->h_med.release();
     c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
     c->d_chunk_band.release(); c->d_tgt_sf.release(); c->d_tgt_band.release();
     c->d_row_counts.release();
@@ -318,11 +318,36 @@ int l3d_add_view(l3d_ctx* c, uint32_t camID, const float* segs4, uint32_t M, con
     return L3D_OK;
 }
 
+// leaves the BEGUN state without results: everything queued is drained, the views are moved back
+// (matchImages translates them, line3D.cc:436/493) and a new l3d_match_begin is required
+static void abort_match(l3d_ctx* c) {
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& s2 : c->aux) if (s2) (void)hipStreamSynchronize(s2);
+    untranslate(*c);
+    c->timing_pending = false; c->pending_launches = 0;
+    c->state = l3d_ctx::IDLE;
+}
+
+int l3d_match_abort(l3d_ctx* c) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    (void)hipSetDevice(c->device);
+    if (c->state == l3d_ctx::BEGUN) abort_match(c);
+    return L3D_OK;
+}
+
+static int match_begin_body(l3d_ctx* c);
+
+// Failure behaviour: the views are translated for the duration BEGUN only.  Every exit of this function that is not
+// L3D_OK -- limits, HIP errors -- leaves them untranslated and the context IDLE; a call while a previous begin is
+// still open closes that one first (its views are moved back before the new translation is computed).
 int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
     if (!c || !p) return fail(L3D_ERR_ARG, "null argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (c->views.empty()) return fail(L3D_ERR_NO_VIEWS, "no images to match");
     (void)hipSetDevice(c->device);
+    if (c->state == l3d_ctx::BEGUN) abort_match(c);
+    if (p->kNN > 4096) return fail(L3D_ERR_LIMIT, "kNN > 4096");
     // parameter clamps, line3D.cc:394-413
     c->num_neighbors = std::max(int(p->num_neighbors), 2);
     c->sigma_p = p->sigma_position;
@@ -333,7 +358,6 @@ int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
     c->const_regularization_depth = p->const_regularization_depth;
     if (c->sigma_p < 0.0f) { c->fixed3Dregularizer = true; c->sigma_p = std::fabs(c->sigma_p); }
     else { c->fixed3Dregularizer = false; c->sigma_p = std::fmax(0.1f, c->sigma_p); }
-    if (c->kNN > 4096) return fail(L3D_ERR_LIMIT, "kNN > 4096");
     c->affinity_done = false;
     c->lines_done = false;
     c->n_hyps = 0;
@@ -343,8 +367,19 @@ int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
         std::sort(c->views_avg_depths.begin(), c->views_avg_depths.end());
         c->med_scene_depth = c->views_avg_depths[c->views_avg_depths.size() / 2];
     }
-    L3D_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
+    c->state = l3d_ctx::IDLE;
     translate(*c);
+    const int rc = match_begin_body(c);
+    if (rc != L3D_OK) {
+        const std::string why = l3d_last_error();
+        abort_match(c);
+        set_error(why);
+    }
+    return rc;
+}
+
+static int match_begin_body(l3d_ctx* c) {
+    L3D_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
     for (auto* v : c->order) {
         if (!c->fixed3Dregularizer) v->k = spatial_reg(*v, c->sigma_p);      // computeSpatialRegularizer
         else v->k = c->sigma_p / c->med_scene_depth;                          // update_k, view.h:124-127
@@ -389,6 +424,19 @@ int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
     c->n_slots = slot_off; c->n_rows_total = row_off;
     if (c->n_slots >= (1ull << 32) || c->pairs.size() >= (1u << 24))
         return fail(L3D_ERR_LIMIT, "slot buffer / pair list exceed the 32-bit slot and 24-bit pair indices of phase B");
+    if (c->kNN > 0 && !c->pairs.empty()) {
+        // bounded kNN keeps the per-row top-K tables of 64 rows in LDS (k_match.hip): the real limit of this build
+        size_t n_work = 0; uint32_t maxMt = 0;
+        for (auto& pd : c->pairs) { n_work += (pd.Ms + kMatchRows - 1) / kMatchRows; maxMt = std::max(maxMt, pd.Mt); }
+        const uint32_t wpg = match_waves_per_group(0, c->brute, (uint32_t)std::min<size_t>(n_work, 0xFFFFFFFFu));
+        auto fits = [&](uint32_t K) { return match_lds_bytes(0, K, maxMt < 65536u && K < 65536u && !c->brute, wpg) <= 160 * 1024; };
+        if (!fits((uint32_t)c->kNN)) {
+            uint32_t lo = 1, hi = (uint32_t)c->kNN;           // largest K that fits
+            while (lo + 1 < hi) { const uint32_t m = (lo + hi) / 2; if (fits(m)) lo = m; else hi = m; }
+            return fail(L3D_ERR_LIMIT, "kNN = " + std::to_string(c->kNN) + " exceeds the per-row top-K table in LDS: the "
+                        "largest bounded kNN of this build is " + std::to_string(lo) + " (kNN <= 0 keeps every match)");
+        }
+    }
     c->pair_done.assign(c->pairs.size(), 0);
     c->pair_counted.assign(c->pairs.size(), 0);
     int rc = upload_views(*c);
@@ -642,11 +690,7 @@ int l3d_match_finish(l3d_ctx* c) {
         // leave a defined state behind: drain every stream this call may have used, restore the views
         // (matchImages translates them, line3D.cc:436/493) and require a new l3d_match_begin
         const std::string why = l3d_last_error();
-        (void)hipStreamSynchronize(c->stream);
-        for (auto& s2 : c->aux) if (s2) (void)hipStreamSynchronize(s2);
-        untranslate(*c);
-        c->timing_pending = false; c->pending_launches = 0;
-        c->state = l3d_ctx::IDLE;
+        abort_match(c);
         set_error(why);
     }
     return rc;
@@ -723,7 +767,8 @@ static int match_finish_impl(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_long_list.reserve(G + 1));
     L3D_HIP_CHECK(launch_bits_len(G, c->d_off.p, c->d_bits_len.p, c->d_long_list.p, c->d_scal.p + 7, st));
     L3D_HIP_CHECK(launch_scan(c->d_bits_len.p, G, c->d_boff.p, c->d_scan_tmp.p, c->d_scal.p + 6, st));
-    uint32_t tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    L3D_HIP_CHECK(c->h_cnt.reserve(16));   // pinned: an early return below must not leave a copy in flight to a dead frame
+    uint32_t* tot = c->h_cnt.p;
     L3D_HIP_CHECK(hipMemcpyAsync(tot, c->d_scal.p, 8 * 4, hipMemcpyDeviceToHost, st));
     // The list kernels only need buffers sized by bounds the host already knows (every slot yields at most one own
     // and one inverse hypothesis), so they are enqueued BEFORE the totals are read back: the host round trip that
@@ -814,7 +859,7 @@ static int match_finish_impl(l3d_ctx* c) {
                                     c->d_has_best.p, c->d_best_pos.p, st));
     L3D_HIP_CHECK(launch_scan(c->d_surv_cnt.p, G, c->d_surv_off.p, c->d_scan_tmp.p, c->d_scal.p + 1, st));
     L3D_HIP_CHECK(launch_scan(c->d_has_best.p, G, c->d_hyp_off.p, c->d_scan_tmp.p, c->d_scal.p + 2, st));
-    uint32_t nh[2] = {0, 0};
+    uint32_t* nh = c->h_cnt.p + 8;
     L3D_HIP_CHECK(hipMemcpyAsync(nh, c->d_scal.p + 1, 8, hipMemcpyDeviceToHost, st));
     g_trace.mark("lists/support/chain/scores/filter enqueued, waiting for counts");
     L3D_HIP_CHECK(hipStreamSynchronize(st));
@@ -832,8 +877,9 @@ static int match_finish_impl(l3d_ctx* c) {
     L3D_HIP_CHECK(launch_median_all(V, c->d_depths.p, c->d_hyp_off.p, c->d_seg_base.p, c->d_medians.p, st));
     // View::update_median_depth for every view (line3D.cc:1665-1668); in fixed-regulariser mode k is
     // re-set to the same sigma_p/med_scene_depth value, so k is unchanged either way
-    std::vector<float> med(V);
-    L3D_HIP_CHECK(hipMemcpyAsync(med.data(), c->d_medians.p, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(c->h_med.reserve(V));
+    float* med = c->h_med.p;
+    L3D_HIP_CHECK(hipMemcpyAsync(med, c->d_medians.p, (size_t)V * 4, hipMemcpyDeviceToHost, st));
     L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
     L3D_HIP_CHECK(hipStreamSynchronize(st));
     for (uint32_t vi = 0; vi < V; ++vi) c->order[vi]->median_depth = med[vi];
@@ -860,7 +906,12 @@ int l3d_match_images(l3d_ctx* c, const l3d_match_params* p) {
     // nothing between begin and the first sizing read-back of phase B waits for the GPU
     rc = match_pairs_impl(c, 0, (uint32_t)c->pairs.size(), false);
     g_trace.mark("phase A enqueued");
-    if (rc) return rc;
+    if (rc) {
+        const std::string why = l3d_last_error();
+        abort_match(c);
+        set_error(why);
+        return rc;
+    }
     rc = l3d_match_finish(c);
     g_trace.mark("matchImages done");
     g_trace.flush();

@@ -146,6 +146,7 @@ struct l3d_ctx {
     uint32_t aff_n_edges = 0, aff_n_rows = 0;
     bool aff_host_valid = true;
     PinnedBuf<uint32_t> h_cnt;
+    PinnedBuf<float> h_med;
     hipStream_t aux[2] = {nullptr, nullptr};        // aux[0] high priority (phase-A first half, the chain), aux[1]
     std::vector<hipEvent_t> pipe_ev;
     std::vector<uint8_t> pair_counted;   // the pair's slots carry orientation flags and are in the phase-B counters

@@ -6,7 +6,8 @@ the largest BASELINE config), matches a contiguous, cost-balanced range of the p
 ranks then exchange their slices of the fixed-layout slot buffer with an all-gather over RCCL/xGMI -- in
 compact form: only the uint32 target index of every slot travels (4 B instead of the 32-byte l3d_slot
 record), the receiving rank re-derives overlap and depths with the match kernel's own device functions
-(l3d_pack_slot_indices / l3d_expand_slot_indices; L3D_EXCHANGE_FULL=1 sends the full records instead).  Phase B (the per-view chain, line3D.cc:745-773) is order dependent in
+(l3d_pack_slot_indices / l3d_expand_slot_indices; L3D_EXCHANGE_FULL=1 sends the full records instead; the
+keep-all mode kNN <= 0 has no fixed slot layout and runs unsharded on every rank).  Phase B (the per-view chain, line3D.cc:745-773) is order dependent in
 ascending camID and is replicated on every rank after the exchange (SURVEY.md §8e option 1).
 
 The exchange is written as one in-place broadcast per owning rank: slices are uneven, and
@@ -52,7 +53,10 @@ def exchange_slots(buf, byte_ranges, group=None):
 
     Equal, contiguous slices (the usual case: BASELINE configs have uniform pairs) go through ONE
     all_gather_into_tensor -- a ring all-gather drives all xGMI links at once, whereas N successive
-    broadcasts serialise them.  Uneven slices fall back to one broadcast per owning rank."""
+    broadcasts serialise them.  Uneven slices take one broadcast per owning rank.  Which of the two runs is a
+    function of byte_ranges alone -- identical on every rank, so the ranks can never issue different collectives --
+    and an error of the chosen collective propagates to the caller (RCCL and gloo both implement
+    all_gather_into_tensor)."""
     import torch.distributed as dist
     world = len(byte_ranges)
     rank = dist.get_rank(group)
@@ -61,12 +65,9 @@ def exchange_slots(buf, byte_ranges, group=None):
     if world > 1 and contiguous and len(set(sizes)) == 1 and sizes[0] > 0:
         lo0, hi_last = byte_ranges[0][0], byte_ranges[-1][1]
         lo, hi = byte_ranges[rank]
-        try:
-            # the send side is a copy of the rank's slice (a few MB), so that input and output never alias
-            dist.all_gather_into_tensor(buf[lo0:hi_last], buf[lo:hi].clone(), group=group)
-            return "all_gather"
-        except (RuntimeError, NotImplementedError):
-            pass   # backend without all_gather_into_tensor: use the broadcasts
+        # the send side is a copy of the rank's slice (1/N of a few MB), so that input and output never alias
+        dist.all_gather_into_tensor(buf[lo0:hi_last], buf[lo:hi].clone(), group=group)
+        return "all_gather"
     for r, (lo, hi) in enumerate(byte_ranges):
         if hi > lo:
             dist.broadcast(buf[lo:hi], src=r if group is None else dist.get_global_rank(group, r), group=group)
@@ -94,10 +95,21 @@ def _wait_for_exchange(buf, device):
 
 def match_images_sharded(l3d, rank, world_size, device=None, group=None, **params):
     """matchImages with phase A sharded over `world_size` ranks.  `l3d` is a line3dpp_amd.Line3D that
-    already holds all views (every rank adds the same views)."""
-    if world_size == 1:
+    already holds all views (every rank adds the same views).
+
+    Keep-all mode (kNN <= 0, line3D.cc:987-992): a row's slot count is only known after the count pass over ALL
+    pairs, so there is no fixed slot layout to shard; every rank then runs the whole call itself (replicas, no
+    exchange) -- correct by construction, just not faster.
+
+    Failure behaviour: whenever this function returns False after matchBegin succeeded, the context has been
+    closed with matchAbort (views untranslated, idle), so the next call starts from a clean state."""
+    if world_size == 1 or params.get("kNN", 10) <= 0:
         return l3d.matchImages(**params)   # one call: nothing waits for the GPU between the phases
     if not l3d.matchBegin(**params):
+        return False                       # a failing matchBegin restores the context itself
+
+    def give_up():
+        l3d.matchAbort()
         return False
     pairs, slot_off = l3d.pairs()
     M = l3d._M
@@ -105,15 +117,15 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, **param
     ranges = pair_ranges(costs, world_size)
     first, count = ranges[rank]
     if count and not l3d.matchPairs(first, count):
-        return False
+        return give_up()
     n_pairs = len(pairs)
-    if params.get("kNN", 10) > 0 and os.environ.get("L3D_EXCHANGE_FULL") is None:
+    if os.environ.get("L3D_EXCHANGE_FULL") is None:
         # compact exchange: 4 B per slot (the target index) travel; the rest of a slot is re-derived on arrival
         if count and not l3d.packSlotIndices(first, count):
-            return False
+            return give_up()
         ptr, n_slots = l3d.slot_index_buffer()
         if ptr is None:
-            return False
+            return give_up()
         if n_slots:
             buf = device_tensor(ptr, n_slots * 4, device)
             exchange_slots(buf, slot_byte_ranges(ranges, slot_off, n_slots, slot_bytes=4), group)
@@ -121,9 +133,9 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, **param
         ok = (first == 0 or l3d.expandSlotIndices(0, first)) and \
              (first + count == n_pairs or l3d.expandSlotIndices(first + count, n_pairs - first - count))
         if not ok:
-            return False
+            return give_up()
     else:
-        # full records (L3D_EXCHANGE_FULL=1; always for the keep-all mode kNN <= 0)
+        # full 32-byte records (L3D_EXCHANGE_FULL=1)
         ptr, n_slots = l3d.slot_buffer()
         if n_slots:
             buf = device_tensor(ptr, n_slots * 32, device)
@@ -131,4 +143,4 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, **param
             _wait_for_exchange(buf, device)
         # every pair is now present on this rank
         l3d.L.l3d_slots_exchanged(l3d.h)
-    return l3d.matchFinish()
+    return l3d.matchFinish()               # a failing matchFinish restores the context itself

@@ -54,8 +54,16 @@ class _StubLine3D:
         self.matched, self.log = [], []
         self.L, self.h = self, None
 
+    fail_pack = False
+
     def matchBegin(self, **kw):
         self.log.append("begin"); return True
+
+    def matchImages(self, **kw):
+        self.log.append("images"); return True
+
+    def matchAbort(self):
+        self.log.append("abort"); return True
 
     def pairs(self):
         return self.pairs_, self.offs
@@ -68,7 +76,7 @@ class _StubLine3D:
         self.matched.append((first, count)); self.done[first:first + count] = True; return True
 
     def packSlotIndices(self, first, count):
-        if not self.done[first:first + count].all():
+        if self.fail_pack or not self.done[first:first + count].all():
             return False
         lo, hi = self._span(first, count)
         self.idx[lo:hi] = self.truth[lo:hi]
@@ -100,8 +108,16 @@ def _sharded_control_flow(dist, rank, world, pairs, offs, n_slots, M, idx_full):
     finally:
         dist.device_tensor = real
     ranges = dist.pair_ranges([M[s] * M[t] for s, t in pairs], world)
-    return bool(ok) and stub.matched == [ranges[rank]] and stub.log == ["begin", "finish"] and \
+    ok = bool(ok) and stub.matched == [ranges[rank]] and stub.log == ["begin", "finish"] and \
         np.array_equal(stub.idx, stub.truth)
+    # keep-all mode (kNN <= 0) has no fixed slot layout: every rank runs the whole call, nothing is begun or exchanged
+    keep_all = _StubLine3D(pairs, offs, n_slots, M, idx_full)
+    ok = ok and dist.match_images_sharded(keep_all, rank, world, device=None, kNN=0) and keep_all.log == ["images"]
+    # a failure between begin and finish closes the context (views untranslated, idle) before False is returned
+    broken = _StubLine3D(pairs, offs, n_slots, M, idx_full); broken.fail_pack = True
+    ok = ok and dist.match_images_sharded(broken, rank, world, device=None, kNN=5) is False and \
+        broken.log == ["begin", "abort"]
+    return ok
 
 
 def _worker(rank, world, port, q):

@@ -1,0 +1,102 @@
+"""GPU tests (pytest -m gpu) of the parameter modes and the failure paths of the context layer THROUGH the HIP
+library's own clamp / state code (l3d_match_begin, l3d_api.hip), against the reference's own code (oracle/_ref):
+
+  * clamped arguments (epipolar_overlap = -1.7, sigma_angle = -200, num_neighbors = 0), line3D.cc:394-413
+  * fixed 3D regulariser (sigma_p < 0) with and without const_regularization_depth, line3D.cc:426-433, view.h:124-127
+  * a second matchImages with different parameters on the same context
+  * failing calls (kNN beyond the LDS table, an abandoned matchBegin) leave the views untranslated and the context
+    usable: the next matchImages gives the results of a fresh context
+"""
+import numpy as np
+import pytest
+
+from line3dpp_amd.scene import make_scene
+from oracle import oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu(scene):
+    from line3dpp_amd.api import Line3D
+    g = Line3D()
+    g.add_scene(scene)
+    return g
+
+
+def _ref(scene, calls):
+    o = O.Oracle(threads=1, reference=O.have_reference())
+    o.add_scene(scene)
+    for kw in calls:
+        o.match_images(**kw)
+    o.compute_affinity()
+    return o
+
+
+_O2G = dict(sigma_p="sigma_position", sigma_a="sigma_angle", num_neighbors="num_neighbors", epi_overlap="epipolar_overlap",
+            kNN="kNN", const_reg_depth="const_regularization_depth")
+
+
+def _g(kw):
+    return {_O2G[k]: v for k, v in kw.items()}
+
+
+def _assert_same(g, o, sc):
+    r = H.full_result_diff(g, o, sc)
+    assert r["ok"] and r["order_rows"] == 0, r
+    # single-threaded reference: A_ ids and order, estimated_position3D_ order are deterministic -> identical
+    ge, gl, _ = g.affinity(); oe, ol = o.affinity()
+    assert np.array_equal(ge["i"], oe["i"]) and np.array_equal(ge["j"], oe["j"])
+    assert np.array_equal(np.stack([gl["cam"], gl["seg"]], 1), ol)
+    assert np.allclose(g.translation(), o.translation(), rtol=0, atol=0)
+    return r
+
+
+@pytest.mark.parametrize("params", [dict(epi_overlap=-1.7, sigma_a=-200.0, num_neighbors=0),
+                                    dict(sigma_p=-0.05), dict(sigma_p=-0.05, const_reg_depth=20.0),
+                                    dict(sigma_a=5.0, sigma_p=1.0), dict(kNN=3, epi_overlap=0.5),
+                                    dict(sigma_p=0.01)])
+def test_parameter_modes_through_the_hip_path(params):
+    sc = make_scene(7, 260, n_neighbors=4, seed=11)
+    g = _gpu(sc)
+    assert g.matchImages(**_g(params)) and g.computeAffinity()
+    r = _assert_same(g, _ref(sc, [params]), sc)
+    assert r["surviving"] > 0 or params.get("epi_overlap", 0) < 0     # overlap > 0.99 leaves next to nothing
+
+
+def test_second_match_images_with_other_parameters():
+    sc = make_scene(6, 200, n_neighbors=4, seed=7)
+    g = _gpu(sc)
+    calls = [dict(), dict(kNN=5, sigma_a=7.0, epi_overlap=0.4)]
+    for kw in calls:
+        assert g.matchImages(**_g(kw))
+    assert g.computeAffinity()
+    _assert_same(g, _ref(sc, calls), sc)
+
+
+def test_failed_and_abandoned_calls_leave_a_clean_context():
+    sc = make_scene(6, 240, n_neighbors=4, seed=23)
+    fresh = _gpu(sc)
+    assert fresh.matchImages() and fresh.computeAffinity()
+    g = _gpu(sc)
+    # (1) kNN beyond the per-row top-K table in LDS: refused with the real maximum in the message, nothing moved
+    assert not g.matchImages(kNN=3000) and g.last_status == -9
+    from line3dpp_amd import _lib
+    assert "largest bounded kNN" in _lib.last_error()
+    # (2) a begin that is never finished, then another begin on top of it
+    assert g.matchBegin()
+    assert g.matchBegin(kNN=4)
+    assert g.matchAbort() and g.matchAbort()          # idempotent
+    assert not g.matchPairs(0, 1) and g.last_status == -7
+    # (3) after all that the context behaves like a fresh one -- a view left translated would shift its camera
+    # centre, the next translation would come out near zero and every 3D end point would move
+    assert g.matchImages() and g.computeAffinity()
+    assert np.array_equal(g.translation(), fresh.translation())
+    a, b = g.best(), fresh.best()
+    for x, y in zip(a, b):
+        assert x.tobytes() == y.tobytes()
+    ea, la, _ = g.affinity(); eb, lb, _ = fresh.affinity()
+    assert ea.tobytes() == eb.tobytes() and la.tobytes() == lb.tobytes()
+    assert g.reconstruct3Dlines() and fresh.reconstruct3Dlines()
+    for x, y in zip(g.get3Dlines(), fresh.get3Dlines()):
+        assert x["collinear3Dsegments"].tobytes() == y["collinear3Dsegments"].tobytes()
