@@ -209,6 +209,7 @@ typedef struct l3d_timings {
     uint32_t culled_pairs; /* directed pairs matched with epipolar-band culling in the last matchImages */
     uint32_t list_entries; /* phase B: total length of the per-segment hypothesis lists (fresh + inverse) */
     uint32_t support_words;/* phase B: 64-bit words of the support bitsets */
+    uint32_t tied_rows;    /* phase A: source rows with equal overlaps, replayed in the reference's priority_queue order */
 } l3d_timings;
 int l3d_get_timings(l3d_ctx*, l3d_timings*);
 
@@ -217,7 +218,8 @@ int l3d_get_timings(l3d_ctx*, l3d_timings*);
 /* Replaces match_lines_GPU (cudawrapper.h:54-63; caller Line3D::matchingGPU line3D.cc:1040-1074)
  * with CPU-path semantics (Line3D::matchingCPU line3D.cc:900-1015).  Host pointers in and out.
  * F, RtKinv_* are row-major 3x3 doubles, C_* camera centres (already translated, line3D.cc:436).
- * kNN must be > 0 here.  out_slots: Ms x kNN slots, rows sorted by (overlap desc, tgt_seg asc).
+ * kNN must be > 0 here.  out_slots: Ms x kNN slots, every row in the order Line3D::matchingCPU appends it to
+ * matches_[src][r] (descending overlap; equal overlaps in the pop order of its std::priority_queue).
  * Returns the number of matches in *num_matches. */
 int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const float* lines_tgt4, uint32_t Mt,
                     const double F[9], const double RtKinv_src[9], const double RtKinv_tgt[9],

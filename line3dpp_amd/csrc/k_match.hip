@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include "l3d_dev.h"
+#include "l3d_heap.h"
 #include "l3d_kernels.h"
 
 namespace l3d {
@@ -69,6 +70,7 @@ struct Lds {
     L3D_LDS volatile idx_t* cnt;       // [kBlock]
     L3D_LDS volatile idx_t* minpos;    // [kBlock] slot of the worst entry of a full row
     L3D_LDS volatile idx_t* top_ix;    // [kBlock*K]
+    L3D_LDS volatile uint8_t* tie;     // [kBlock] row saw equal overlaps where the reference's heap order decides
 };
 
 template <bool IX16>
@@ -82,7 +84,8 @@ __device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K, uint3
     l.top_ov = (L3D_LDS volatile float*)base; base += (size_t)kBlock * K * 4;
     l.cnt = (L3D_LDS volatile idx_t*)base; base += kBlock * sizeof(idx_t);
     l.minpos = (L3D_LDS volatile idx_t*)base; base += kBlock * sizeof(idx_t);
-    l.top_ix = (L3D_LDS volatile idx_t*)base;
+    l.top_ix = (L3D_LDS volatile idx_t*)base; base += (size_t)kBlock * K * sizeof(idx_t);
+    l.tie = (L3D_LDS volatile uint8_t*)base;
     return l;
 }
 
@@ -211,6 +214,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
         L.minov[tid] = thr;
         L.claim[tid] = kEmpty;
         L.row_src[tid] = src;
+        L.tie[tid] = 0;
     }
     if (WPG > 1) __syncthreads();
     uint32_t head = 0, tail = 0;   // wave-uniform ring cursors
@@ -259,12 +263,12 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
             if (cull) tg = tperm[tg];
             const float4 s4 = vs.seg4[sg], t4 = vt.seg4[tg];
             const float ov = exact_overlap(F, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w);
-            // a full row only admits overlaps that beat its K-th best under (overlap desc, tgt asc); minov == thr
-            // while the row is not full.  Without culling (and with one wave per row group) the candidates of a row
-            // arrive in ascending target order and a tie always loses; otherwise the order is arbitrary and the
-            // comparator at the insertion decides a tie.
+            // a full row only admits overlaps that reach its K-th best; minov == thr while the row is not full.  An
+            // overlap EQUAL to the K-th best goes on to the insertion as well: whether it wins or loses there under
+            // (overlap desc, tgt asc), it is a tie at the kNN-th place, which the reference resolves by the pop order
+            // of its priority_queue -- the row is flagged and replayed exactly by k_match_tied_rows.
             const float need = (MODE == 0) ? L.minov[sl] : thr;
-            if (ov > need || ((cull || WPG > 1) && ov == need && ov > thr)) {
+            if (ov > thr && ov >= need) {
                 res.overlap = ov;
                 L3D_STAT(2, 1);
                 pending = exact_depths(vs.segx[sg], vt.segx[tg], vs.C, vt.C, res);
@@ -311,9 +315,13 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
                         if (c + 1 == K) rescan_worst(sl);
                     } else {
                         const uint32_t wj = L.minpos[sl];
-                        if (better(res.overlap, tg, L.minov[sl], ix[wj])) {
+                        const float mo = L.minov[sl];
+                        if (better(res.overlap, tg, mo, ix[wj])) {
                             ov[wj] = res.overlap; ix[wj] = tg;
                             rescan_worst(sl);
+                            if (L.minov[sl] == mo) L.tie[sl] = 1;   // the evicted entry ties with the new K-th best
+                        } else if (res.overlap == mo) {
+                            L.tie[sl] = 1;                          // loses a tie at the K-th place
                         }
                     }
                 }
@@ -428,6 +436,20 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     // (checkMatchOrientation, line3D.cc:811-858), which is a function of the slot alone: its flags are written with
     // the slot and the hypothesis counters of phase B are fed from here instead of by a pass that re-reads every slot.
     if (WPG > 1) __syncthreads();                       // every wave's candidates are in the tables
+    {   // equal overlaps INSIDE a row's table: their order is the reference's heap order as well (every wave of the
+        // group checks all 64 rows itself: same flags, no further barrier)
+        const uint32_t c = min((uint32_t)L.cnt[tid], K);
+        L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)tid * K;
+        bool t = false;
+        for (uint32_t i = 1; i < c; ++i) {
+            const float oi = ov[i];
+            for (uint32_t j = 0; j < i; ++j) t |= ov[j] == oi;
+        }
+        if (t) L.tie[tid] = 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     L3D_LDS volatile uint32_t* row_src = L.row_src;
     const uint32_t n_rows = min((uint32_t)kBlock, Ms - wi.src0);
     const uint32_t gs = (uint32_t)(vs.segx - views[0].segx), gt = (uint32_t)(vt.segx - views[0].segx);
@@ -439,7 +461,13 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
         const bool in = it < n_items;
         const uint32_t r = in ? it / K : 0u, j = it - r * K;
         const uint32_t rsrc = row_src[r];
-        const uint32_t c = in ? (uint32_t)L.cnt[r] : 0u;
+        // a flagged row is left to k_match_tied_rows entirely (slots, orientation flags, counters)
+        const bool tied = in && L.tie[r] != 0;
+        if (tied && j == 0) {
+            const uint32_t pos = atomicAdd(of.tie_count, 1u);
+            if (pos < of.tie_cap) of.tie_list[pos] = make_uint2(wi.pair, rsrc);
+        }
+        const uint32_t c = (in && !tied) ? (uint32_t)L.cnt[r] : 0u;
         Slot o;
         o.tgt_seg = kEmpty; o.overlap = 0; o.dp1 = o.dp2 = o.dq1 = o.dq2 = 0; o.score3D = 0.0f; o.flags = 0;
         uint32_t ipos = kEmpty, dst = j;
@@ -470,7 +498,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
                 }
             }
         }
-        if (in) {
+        if (in && !tied) {
             const uint64_t at = pd.slot_off + (uint64_t)rsrc * K + dst;
             slots[at] = o;
             of.inv_pos[at] = ipos;
@@ -491,7 +519,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
 
 size_t match_lds_bytes(int mode, uint32_t K, bool ix16, uint32_t waves) {
     const size_t ib = ix16 ? 2 : 4;
-    return (size_t)waves * kRing * 4 + 3 * kBlock * 4 + 2 * kBlock * ib + (mode == 0 ? (size_t)kBlock * K * (4 + ib) : 0);
+    return (size_t)waves * kRing * 4 + 3 * kBlock * 4 + 2 * kBlock * ib + (mode == 0 ? (size_t)kBlock * K * (4 + ib) : 0) + kBlock;
 }
 
 // Two waves per work item pay off while the launch has few items for the machine (C0: kernel 0.34 -> 0.24 ms, C1 with
@@ -510,7 +538,7 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
                               uint32_t* row_counts, float thr, CullPools pools, OrientFuse of, bool ix16,
                               hipStream_t stream) {
     if (nwork == 0) return hipSuccess;
-    if (mode == 0 && (!of.cnt_pack || !of.inv_pos)) return hipErrorInvalidValue;   // MODE 0 always fuses
+    if (mode == 0 && (!of.cnt_pack || !of.inv_pos || !of.tie_count || !of.tie_list)) return hipErrorInvalidValue;   // MODE 0 always fuses
     const uint32_t grid = ((nwork + 7) / 8) * 8;
     if (!(mode == 0 && !brute)) ix16 = false;       // the compact layout is only instantiated for the hot variant
     const uint32_t wpg = match_waves_per_group(mode, brute, nwork);
@@ -531,6 +559,128 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
     else if (mode == 1) { if (brute) L3D_LAUNCH(1, true, false, 1); else L3D_LAUNCH(1, false, false, 1); }
     else { if (brute) L3D_LAUNCH(2, true, false, 1); else L3D_LAUNCH(2, false, false, 1); }
 #undef L3D_LAUNCH
+    return hipGetLastError();
+}
+
+// ---- rows with equal overlaps: the reference's kNN order, replayed ------------------------------------------------
+// Line3D::matchingCPU keeps a row's accepted matches in a std::priority_queue keyed by the overlap alone and pops
+// kNN of them (line3D.cc:982-1007): with equal overlaps, which entries come out and in which order is the pop order
+// of libstdc++'s binary heap.  k_match_pairs selects by (overlap desc, target asc), which is the same thing for
+// distinct overlaps, and hands every row in which it saw equal overlaps -- inside the table or at the kNN-th place --
+// to this kernel (one wave per row): all Mt targets through the exact test in ascending target order, accepted ones
+// pushed into the very heap the reference builds (l3d_heap.h), kNN pops, then the same slot / orientation / counter
+// work as the match epilogue.  Such rows are rare (C1: none, C4: a few per 10^5 rows), duplicated segments make many.
+constexpr uint32_t kTieLdsHeap = 4096;   // heap entries kept in LDS; larger heaps move to the block's global scratch
+
+__global__ __launch_bounds__(64) void k_match_tied_rows(const ViewDev* __restrict__ views,
+                                                        const PairDesc* __restrict__ pairs, Slot* __restrict__ slots,
+                                                        float thr, const OrientFuse of, float* __restrict__ scratch_ov,
+                                                        uint32_t* __restrict__ scratch_ix, uint32_t scratch_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float s_hov[kTieLdsHeap];
+    __shared__ uint32_t s_hix[kTieLdsHeap];
+    __shared__ float s_stage[64];
+    __shared__ uint32_t s_nwin;
+    float* win_ov = (float*)smem;                 // [K] dynamic
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_tied = min(*of.tie_count, of.tie_cap);
+    for (uint32_t t = blockIdx.x; t < n_tied; t += gridDim.x) {
+        const uint2 item = of.tie_list[t];
+        const PairDesc& pd = pairs[item.x];
+        const uint32_t src = item.y, K = pd.K, Mt = pd.Mt;
+        uint32_t* win_ix = (uint32_t*)(win_ov + K);
+        const ViewDev& vs = views[pd.src];
+        const ViewDev& vt = views[pd.tgt];
+        double F[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) F[i] = pd.F[i];
+        const float4 s4 = vs.seg4[src];
+        const SegX sx = vs.segx[src];
+        float* hov = s_hov; uint32_t* hix = s_hix;    // generic pointers: LDS first, global scratch if the heap outgrows it
+        uint32_t n = 0;
+        for (uint32_t c0 = 0; c0 < Mt; c0 += 64) {
+            const uint32_t cc = c0 + lane;
+            bool acc = false;
+            if (cc < Mt) {
+                PairResult res{};
+                acc = exact_pair(F, s4, vt.seg4[cc], sx, vt.segx[cc], vs.C, vt.C, thr, res);
+                s_stage[lane] = res.overlap;
+            }
+            uint64_t m = __ballot(acc);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane == 0) {
+                while (m) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(m); m &= m - 1;
+                    if (n == kTieLdsHeap && hov == s_hov) {   // outgrown: continue in this block's global scratch
+                        float* gov = scratch_ov + (size_t)blockIdx.x * scratch_stride;
+                        uint32_t* gix = scratch_ix + (size_t)blockIdx.x * scratch_stride;
+                        for (uint32_t i = 0; i < n; ++i) { gov[i] = s_hov[i]; gix[i] = s_hix[i]; }
+                        hov = gov; hix = gix;
+                    }
+                    heap_push(hov, hix, n, s_stage[b], c0 + b);
+                    ++n;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        if (lane == 0) {
+            uint32_t w = 0;
+            while (w < K && n > 0) {
+                float v; uint32_t x;
+                heap_pop(hov, hix, n, v, x);
+                --n;
+                win_ov[w] = v; win_ix[w] = x; ++w;
+            }
+            s_nwin = w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t n_win = s_nwin;
+        const uint32_t gs = (uint32_t)(vs.segx - views[0].segx), gt = (uint32_t)(vt.segx - views[0].segx);
+        const bool hands_inverse = pd.tgt > pd.src;
+        uint32_t n_alive = 0;
+        for (uint32_t j0 = 0; j0 < K; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            Slot o;
+            o.tgt_seg = kEmpty; o.overlap = 0; o.dp1 = o.dp2 = o.dq1 = o.dq2 = 0; o.score3D = 0.0f; o.flags = 0;
+            uint32_t ipos = kEmpty;
+            if (j < n_win) {
+                const uint32_t xj = win_ix[j];
+                const SegX tx = vt.segx[xj];
+                PairResult res{};
+                exact_depths(sx, tx, vs.C, vt.C, res);
+                res.overlap = win_ov[j];
+                o.tgt_seg = xj; o.overlap = res.overlap;
+                o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
+                o.flags = fuse_orientation(of, vs.C, vt.C, sx, tx, res, hands_inverse, gt + xj, ipos);
+            }
+            if (j < K) {
+                const uint64_t at = pd.slot_off + (uint64_t)src * K + j;
+                slots[at] = o;
+                of.inv_pos[at] = ipos;
+            }
+            n_alive += (uint32_t)__popcll(__ballot((o.flags & kSlotAlive) != 0));
+        }
+        if (lane == 0 && n_alive) atomicAdd(&of.cnt_pack[gs + src], (unsigned long long)n_alive);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+uint32_t match_tied_grid() { return 256; }
+
+hipError_t launch_match_tied_rows(const ViewDev* views, const PairDesc* pairs, Slot* slots, uint32_t maxK, float thr,
+                                  OrientFuse of, float* scratch_ov, uint32_t* scratch_ix, uint32_t scratch_stride,
+                                  hipStream_t stream) {
+    if (!of.tie_count || !of.tie_list || !scratch_ov || !scratch_ix) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_match_tied_rows, dim3(match_tied_grid()), dim3(64), (size_t)maxK * 8, stream, views, pairs, slots,
+                       thr, of, scratch_ov, scratch_ix, scratch_stride);
     return hipGetLastError();
 }
 

@@ -261,6 +261,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_has_best.release(); c->d_best_pos.release(); c->d_surv_off.release(); c->d_hyp_off.release();
     c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_bits.release(); c->d_eref.release(); c->d_positive.release(); c->d_bits_len.release(); c->d_boff.release(); c->d_cnt_inv.release(); c->d_long_list.release();
     c->d_cnt_pack.release(); c->d_inv_pos.release(); c->d_gsegx.release();
+    c->d_tie_count.release(); c->d_tie_list.release(); c->d_tie_ov.release(); c->d_tie_ix.release();
     c->d_coll_cnt.release(); c->d_coll_off.release(); c->d_coll_idx.release(); c->d_item_cnt.release();
     c->d_item_off.release(); c->d_item_seg.release(); c->d_item_sim.release();
     c->d_inv_off.release(); c->d_vout_pairs.release(); c->d_vout_off.release(); c->d_dents.release(); c->d_surv.release();
@@ -508,6 +509,7 @@ static void collect_match_timing(l3d_ctx* c) {
     c->tm.match_kernel_ms += ev_ms(c->ev[4], c->ev[5]);
     c->tm.cull_prepare_ms += ev_ms(c->ev[8], c->ev[4]);
     c->tm.match_kernel_launches += c->pending_launches;
+    if (c->tie_count_pending) { c->tm.tied_rows += c->h_cnt.p[14]; c->tie_count_pending = false; }
     c->timing_pending = false; c->pending_launches = 0;
 }
 
@@ -539,13 +541,31 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
     const bool ix16 = maxMt < 65536u && maxK < 65536u;   // 16-bit indices in the kernel's LDS tables
     // bounded kNN: the orientation filter and the hypothesis counters of phase B are fused into the epilogue
-    const OrientFuse of{mode == 0 ? c->d_cnt_pack.p : nullptr, mode == 0 ? c->d_inv_pos.p : nullptr,
-                        OrientThr{c->orient_lo, c->orient_hi}};
+    OrientFuse of{mode == 0 ? c->d_cnt_pack.p : nullptr, mode == 0 ? c->d_inv_pos.p : nullptr,
+                  OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u};
+    uint32_t tie_stride = 0;
+    if (mode == 0) {   // rows with equal overlaps are collected here and replayed in the reference's heap order
+        uint32_t mt = 0;
+        for (auto& pd : c->pairs) mt = std::max(mt, pd.Mt);
+        tie_stride = std::max(mt, 1u);
+        L3D_HIP_CHECK(c->d_tie_count.reserve(4));
+        L3D_HIP_CHECK(c->d_tie_list.reserve(std::max<uint32_t>(c->n_rows_total, 1)));
+        L3D_HIP_CHECK(c->d_tie_ov.reserve((size_t)match_tied_grid() * tie_stride));
+        L3D_HIP_CHECK(c->d_tie_ix.reserve((size_t)match_tied_grid() * tie_stride));
+        L3D_HIP_CHECK(hipMemsetAsync(c->d_tie_count.p, 0, 16, c->stream));
+        of.tie_count = c->d_tie_count.p; of.tie_list = c->d_tie_list.p; of.tie_cap = c->n_rows_total;
+    }
     L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work, maxK,
                                      c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, of, ix16, c->stream));
     L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));
-    if (mode == 0)
+    if (mode == 0) {
+        L3D_HIP_CHECK(launch_match_tied_rows(c->d_views.p, c->d_pairs.p, c->d_slots.p, maxK, c->epipolar_overlap, of,
+                                             c->d_tie_ov.p, c->d_tie_ix.p, tie_stride, c->stream));
+        L3D_HIP_CHECK(c->h_cnt.reserve(16));
+        L3D_HIP_CHECK(hipMemcpyAsync(c->h_cnt.p + 14, c->d_tie_count.p, 4, hipMemcpyDeviceToHost, c->stream));
+        c->tie_count_pending = true;
         for (uint32_t p = first; p < first + count; ++p) c->pair_counted[p] = 1;
+    }
     if (pools.cull)
         for (uint32_t p = first; p < first + count; ++p) c->tm.culled_pairs += c->cull[p].enabled;
     c->timing_pending = true; c->pending_launches += 1;
@@ -670,7 +690,7 @@ int l3d_expand_slot_indices(l3d_ctx* c, uint32_t first, uint32_t count) {
         max_row_slots = std::max<uint64_t>(max_row_slots, (uint64_t)c->pairs[p].Ms * c->pairs[p].K);
     for (uint32_t p = first; p < first + count; ++p)
         if (c->pair_done[p]) return fail(L3D_ERR_STATE, "l3d_expand_slot_indices: pair already present on this rank");
-    const OrientFuse of{c->d_cnt_pack.p, c->d_inv_pos.p, OrientThr{c->orient_lo, c->orient_hi}};
+    const OrientFuse of{c->d_cnt_pack.p, c->d_inv_pos.p, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u};
     L3D_HIP_CHECK(launch_expand_slot_idx(c->d_views.p, c->d_pairs.p, first, count, max_row_slots, c->d_slot_idx.p,
                                          c->d_slots.p, of, c->stream));
     for (uint32_t p = first; p < first + count; ++p) c->pair_done[p] = c->pair_counted[p] = 1;

@@ -281,7 +281,8 @@ L3D_HD bool orientation_ok(const double* C, const SegX& sx, float d1, float d2, 
     return dp >= t.lo && dp <= t.hi;
 }
 
-// (overlap desc, tgt asc) total order used for the kNN selection
+// (overlap desc, tgt asc) total order used for the kNN selection of rows WITHOUT equal overlaps; rows with equal
+// overlaps are replayed in the reference's priority_queue order (l3d_heap.h, k_match_tied_rows)
 L3D_HD bool better(float ova, uint32_t ia, float ovb, uint32_t ib) {
     return ova > ovb || (ova == ovb && ia < ib);
 }

@@ -40,6 +40,11 @@ struct OrientFuse {
     unsigned long long* cnt_pack;   // [G] packed hypothesis counters of the global segments (k_orient_all)
     uint32_t* inv_pos;              // [n_slots] position of a slot among the inverse refs of its target segment
     OrientThr thr;
+    // rows in which the match kernel saw equal overlaps (the reference's heap order decides there): (pair, source row),
+    // replayed by k_match_tied_rows
+    uint32_t* tie_count;
+    uint2* tie_list;
+    uint32_t tie_cap;
 };
 
 // ---- k_match.hip ----
@@ -51,6 +56,12 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
                               const WorkItem* work, uint32_t nwork, uint32_t maxK, Slot* slots,
                               uint32_t* row_counts, float thr, CullPools pools, OrientFuse of, bool ix16,
                               hipStream_t stream);
+// rows flagged by the match kernel (equal overlaps): the reference's priority_queue order, replayed; scratch = one
+// region of scratch_stride (>= max Mt) entries per workgroup of match_tied_grid()
+uint32_t match_tied_grid();
+hipError_t launch_match_tied_rows(const ViewDev* views, const PairDesc* pairs, Slot* slots, uint32_t maxK, float thr,
+                                  OrientFuse of, float* scratch_ov, uint32_t* scratch_ix, uint32_t scratch_stride,
+                                  hipStream_t stream);
 // compact exchange of slots between ranks: target indices out, full records back (bit-identical re-derivation)
 hipError_t launch_pack_slot_idx(const Slot* slots, uint32_t* idx, uint64_t lo, uint64_t hi, hipStream_t stream);
 hipError_t launch_expand_slot_idx(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,

@@ -45,6 +45,7 @@ def _check_phase_a(g, scene, kNN, epi=0.25, allow_tie_order=True):
         r = H.compare_pair(g.pair_slots(pi), om)
         assert not r["missing"] and not r["extra"], (pi, r["missing"][:3], r["extra"][:3])
         assert r["bit_exact"], f"pair {pi}: overlap/depths differ from the oracle (max rel {r['max_rel']})"
+        assert r["order_mismatch"] == 0, f"pair {pi}: rows ordered differently from the reference's priority_queue"
         total += r["n_cpu"]
     o.end_match()
     return total
@@ -64,6 +65,34 @@ def test_phase_a_bit_exact(n_views, n_segs, nn, kNN, seed):
     total = _check_phase_a(g, sc, kNN)
     assert total > 0 or n_segs == 1
     assert g.matchFinish()
+
+
+@pytest.mark.parametrize("kNN", [10, 3, 1])
+def test_equal_overlaps_follow_the_reference_heap_order(kNN):
+    """Every segment occurs twice in its view, so nearly every source row sees pairs of EQUAL overlaps -- inside its
+    top-kNN and at the kNN-th place.  The reference resolves them by the pop order of its std::priority_queue
+    (line3D.cc:982-1007, commons.h:217-231); the HIP path replays exactly that (k_match_tied_rows, l3d_heap.h): same
+    slots in the same order, and the whole pipeline stays identical."""
+    sc = make_scene(5, 300, n_neighbors=4, seed=41)
+    for v in sc.views:
+        v.segs[1::2] = v.segs[0::2]
+    g = _gpu(sc)
+    assert g.matchBegin(kNN=kNN) and g.matchPairs(0, len(g.pairs()[0]))
+    o = _oracle(sc, threads=2)
+    o.begin_match(kNN=kNN)
+    pairs, _ = g.pairs()
+    total = 0
+    for pi, (s, t) in enumerate(pairs):
+        om, _ = o.match_pair(int(s), int(t))
+        r = H.compare_pair_fast(g.pair_slots(pi), om)
+        assert r["set_diff"] == 0 and r["order_rows"] == 0 and r["inexact_fields"] == 0, (pi, r)
+        total += r["n_cpu"]
+    o.end_match()
+    assert total > 1000
+    assert g.matchFinish() and g.computeAffinity()
+    assert g.timings()["tied_rows"] > 200
+    o1 = _oracle(sc, threads=1); o1.match_images(kNN=kNN); o1.compute_affinity()
+    _compare_final(g, o1, sc)
 
 
 def test_phase_a_views_of_different_size_and_overlap_threshold():
