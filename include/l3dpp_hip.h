@@ -209,7 +209,8 @@ typedef struct l3d_timings {
     uint32_t culled_pairs; /* directed pairs matched with epipolar-band culling in the last matchImages */
     uint32_t list_entries; /* phase B: total length of the per-segment hypothesis lists (fresh + inverse) */
     uint32_t support_words;/* phase B: 64-bit words of the support bitsets */
-    uint32_t tied_rows;    /* phase A: source rows with equal overlaps, replayed in the reference's priority_queue order */
+    uint32_t tied_rows;    /* phase A: source rows with equal overlaps, replayed in the reference's priority_queue order
+                            * (cumulative since l3d_create) */
 } l3d_timings;
 int l3d_get_timings(l3d_ctx*, l3d_timings*);
 
@@ -232,6 +233,10 @@ int l3d_output_filename(l3d_ctx*, int max_image_width, char* buf, uint32_t cap);
 /* Line3D::save3DLinesAsTXT (line3D.cc:2631-2688): <output_folder>/<output filename>.txt, one line per 3D line:
  * n_segments (P1 P2)* n_residuals (camID segID x1 y1 x2 y2)*, the format of the .txt files under testdata/Line3D++_ref. */
 int l3d_save_3d_lines_txt(l3d_ctx*, const char* output_folder, int max_image_width);
+/* Line3D::save3DLinesAsBIN (line3D.cc:2690-2711): <output filename>.bin = boost::archive::binary_oarchive of
+ * std::vector<FinalLine3D> (serialization.h:38-45, segment3D.h:99-178), written without Boost in the byte layout of
+ * the reference's own fixtures testdata/Line3D++_ref/\*vis_3.bin (doubles: the only result file that keeps full precision). */
+int l3d_save_3d_lines_bin(l3d_ctx*, const char* output_folder, int max_image_width);
 /* Line3D::getSegmentCoords2D (line3D.cc:2757-2772): (x1,y1,x2,y2) of a 2D segment, zeros if unknown */
 int l3d_get_segment_coords2d(l3d_ctx*, uint32_t camID, uint32_t segID, float coords[4]);
 /* Line3D::saveResultAsSTL (line3D.cc:2465-2531) and saveResultAsOBJ (:2579-2628): <output filename>.stl / .obj */

@@ -140,6 +140,12 @@ public:
             std::cout << prefix_ << "WARNING: " << l3d_last_error() << std::endl;
     }
 
+    // void Line3D::save3DLinesAsBIN(const std::string& output_folder), line3D.h:185
+    void save3DLinesAsBIN(const std::string& output_folder) {
+        if (l3d_save_3d_lines_bin(ctx_, output_folder.c_str(), max_img_width_) != L3D_OK)
+            std::cout << prefix_ << "WARNING: " << l3d_last_error() << std::endl;
+    }
+
     // std::string Line3D::createOutputFilename(), line3D.h:226
     std::string createOutputFilename() {
         char buf[512];

@@ -48,7 +48,7 @@ EXPORTS = [
     "l3d_reconstruct_3d_lines", "l3d_num_3d_lines", "l3d_get_3d_lines", "l3d_diffuse_affinity",
     "l3d_output_filename", "l3d_save_3d_lines_txt", "l3d_save_result_stl", "l3d_save_result_obj",
     "l3d_get_segment_coords2d", "l3d_find_collinear_segments", "l3d_score_matches",
-    "l3d_slot_index_buffer", "l3d_pack_slot_indices", "l3d_expand_slot_indices", "l3d_match_abort",
+    "l3d_slot_index_buffer", "l3d_pack_slot_indices", "l3d_expand_slot_indices", "l3d_match_abort", "l3d_save_3d_lines_bin",
 ]
 
 _lib = None
@@ -105,6 +105,7 @@ def load():
     L.l3d_output_filename.argtypes = [vp, i32, C.c_char_p, u32]
     L.l3d_save_3d_lines_txt.argtypes = [vp, C.c_char_p, i32]
     L.l3d_save_result_stl.argtypes = [vp, C.c_char_p, i32]
+    L.l3d_save_3d_lines_bin.argtypes = [vp, C.c_char_p, i32]
     L.l3d_save_result_obj.argtypes = [vp, C.c_char_p, i32]
     L.l3d_get_segment_coords2d.argtypes = [vp, u32, u32, vp]
     L.l3d_find_collinear_segments.argtypes = [i32, vp, u32, f32, vp, vp, u64, vp]

@@ -132,6 +132,11 @@ class Line3D:
         return self._check(self.L.l3d_save_3d_lines_txt(self.h, str(output_folder).encode(), int(max_image_width)),
                            "save3DLinesAsTXT")
 
+    # Line3D::save3DLinesAsBIN, line3D.h:177 -- <output_folder>/<outputFilename()>.bin (boost binary archive layout)
+    def save3DLinesAsBIN(self, output_folder, max_image_width=-1):
+        return self._check(self.L.l3d_save_3d_lines_bin(self.h, str(output_folder).encode(), int(max_image_width)),
+                           "save3DLinesAsBIN")
+
     # Line3D::getSegmentCoords2D, line3D.h:195-197
     def getSegmentCoords2D(self, camID, segID):
         out = np.zeros(4, np.float32)

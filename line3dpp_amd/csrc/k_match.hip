@@ -570,20 +570,26 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
 // to this kernel (one wave per row): all Mt targets through the exact test in ascending target order, accepted ones
 // pushed into the very heap the reference builds (l3d_heap.h), kNN pops, then the same slot / orientation / counter
 // work as the match epilogue.  Such rows are rare (C1: none, C4: a few per 10^5 rows), duplicated segments make many.
-constexpr uint32_t kTieLdsHeap = 4096;   // heap entries kept in LDS; larger heaps move to the block's global scratch
+constexpr uint32_t kTieBlock = 512;       // threads per tied row (all Mt exact tests in Mt/512 steps)
+constexpr uint32_t kTieLdsHeap = 7168;    // accepted (overlap, target) pairs kept in LDS (56 KiB); more: global scratch
 
-__global__ __launch_bounds__(64) void k_match_tied_rows(const ViewDev* __restrict__ views,
-                                                        const PairDesc* __restrict__ pairs, Slot* __restrict__ slots,
-                                                        float thr, const OrientFuse of, float* __restrict__ scratch_ov,
-                                                        uint32_t* __restrict__ scratch_ix, uint32_t scratch_stride) {
+// tie_count[0] = rows queued by the match kernel, [1] = blocks done (the last one resets [0] for the next launch),
+// [2] = rows replayed since the context was created (diagnostics)
+__global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __restrict__ views,
+                                                               const PairDesc* __restrict__ pairs,
+                                                               Slot* __restrict__ slots, float thr, const OrientFuse of,
+                                                               float* __restrict__ scratch_ov,
+                                                               uint32_t* __restrict__ scratch_ix, uint32_t scratch_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float s_hov[kTieLdsHeap];
     __shared__ uint32_t s_hix[kTieLdsHeap];
-    __shared__ float s_stage[64];
+    __shared__ uint32_t s_wcnt[kTieBlock / 64];
     __shared__ uint32_t s_nwin;
     float* win_ov = (float*)smem;                 // [K] dynamic
-    const uint32_t lane = threadIdx.x;
-    const uint32_t n_tied = min(*of.tie_count, of.tie_cap);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_tied = min(of.tie_count[0], of.tie_cap);
+    float* gov = scratch_ov + (size_t)blockIdx.x * scratch_stride;
+    uint32_t* gix = scratch_ix + (size_t)blockIdx.x * scratch_stride;
     for (uint32_t t = blockIdx.x; t < n_tied; t += gridDim.x) {
         const uint2 item = of.tie_list[t];
         const PairDesc& pd = pairs[item.x];
@@ -596,56 +602,53 @@ __global__ __launch_bounds__(64) void k_match_tied_rows(const ViewDev* __restric
         for (int i = 0; i < 9; ++i) F[i] = pd.F[i];
         const float4 s4 = vs.seg4[src];
         const SegX sx = vs.segx[src];
-        float* hov = s_hov; uint32_t* hix = s_hix;    // generic pointers: LDS first, global scratch if the heap outgrows it
-        uint32_t n = 0;
-        for (uint32_t c0 = 0; c0 < Mt; c0 += 64) {
-            const uint32_t cc = c0 + lane;
+        // ---- every target through the acceptance test; accepted ones in ascending target order ----
+        uint32_t n = 0;                           // accepted so far (block-uniform)
+        for (uint32_t c0 = 0; c0 < Mt; c0 += kTieBlock) {
+            const uint32_t cc = c0 + tid;
             bool acc = false;
-            if (cc < Mt) {
-                PairResult res{};
-                acc = exact_pair(F, s4, vt.seg4[cc], sx, vt.segx[cc], vs.C, vt.C, thr, res);
-                s_stage[lane] = res.overlap;
+            PairResult res{};
+            if (cc < Mt) acc = exact_pair(F, s4, vt.seg4[cc], sx, vt.segx[cc], vs.C, vt.C, thr, res);
+            const uint64_t m = __ballot(acc);
+            if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kTieBlock / 64; ++w) { const uint32_t x = s_wcnt[w]; before += w < wave ? x : 0u; total += x; }
+            if (acc) {
+                const uint32_t k = n + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (k < kTieLdsHeap) { s_hov[k] = res.overlap; s_hix[k] = cc; }
+                else { gov[k] = res.overlap; gix[k] = cc; }
             }
-            uint64_t m = __ballot(acc);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (lane == 0) {
-                while (m) {
-                    const uint32_t b = (uint32_t)__builtin_ctzll(m); m &= m - 1;
-                    if (n == kTieLdsHeap && hov == s_hov) {   // outgrown: continue in this block's global scratch
-                        float* gov = scratch_ov + (size_t)blockIdx.x * scratch_stride;
-                        uint32_t* gix = scratch_ix + (size_t)blockIdx.x * scratch_stride;
-                        for (uint32_t i = 0; i < n; ++i) { gov[i] = s_hov[i]; gix[i] = s_hix[i]; }
-                        hov = gov; hix = gix;
-                    }
-                    heap_push(hov, hix, n, s_stage[b], c0 + b);
-                    ++n;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            n += total;
+            __syncthreads();
         }
-        if (lane == 0) {
-            uint32_t w = 0;
-            while (w < K && n > 0) {
+        // ---- the reference's heap: push all in order, pop K (one thread; n is a few dozen to a few hundred) ----
+        if (n > kTieLdsHeap) {   // outgrown the LDS list: continue in this block's global scratch
+            for (uint32_t i = tid; i < kTieLdsHeap; i += kTieBlock) { gov[i] = s_hov[i]; gix[i] = s_hix[i]; }
+            __threadfence_block();
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float* hov = n > kTieLdsHeap ? gov : s_hov;       // generic pointers
+            uint32_t* hix = n > kTieLdsHeap ? gix : s_hix;
+            for (uint32_t i = 1; i < n; ++i) heap_push(hov, hix, i, hov[i], hix[i]);   // in place: the heap is the prefix
+            uint32_t w = 0, left = n;
+            while (w < K && left > 0) {
                 float v; uint32_t x;
-                heap_pop(hov, hix, n, v, x);
-                --n;
+                heap_pop(hov, hix, left, v, x);
+                --left;
                 win_ov[w] = v; win_ix[w] = x; ++w;
             }
             s_nwin = w;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __syncthreads();
         const uint32_t n_win = s_nwin;
         const uint32_t gs = (uint32_t)(vs.segx - views[0].segx), gt = (uint32_t)(vt.segx - views[0].segx);
         const bool hands_inverse = pd.tgt > pd.src;
-        uint32_t n_alive = 0;
-        for (uint32_t j0 = 0; j0 < K; j0 += 64) {
-            const uint32_t j = j0 + lane;
+        // ---- the row's K slots: depths, orientation filter, phase-B counters (as the match epilogue) ----
+        for (uint32_t j0 = 0; j0 < K; j0 += kTieBlock) {
+            const uint32_t j = j0 + tid;
             Slot o;
             o.tgt_seg = kEmpty; o.overlap = 0; o.dp1 = o.dp2 = o.dq1 = o.dq2 = 0; o.score3D = 0.0f; o.flags = 0;
             uint32_t ipos = kEmpty;
@@ -664,23 +667,30 @@ __global__ __launch_bounds__(64) void k_match_tied_rows(const ViewDev* __restric
                 slots[at] = o;
                 of.inv_pos[at] = ipos;
             }
-            n_alive += (uint32_t)__popcll(__ballot((o.flags & kSlotAlive) != 0));
+            const uint32_t n_alive = (uint32_t)__popcll(__ballot((o.flags & kSlotAlive) != 0));
+            if (lane == 0 && n_alive) atomicAdd(&of.cnt_pack[gs + src], (unsigned long long)n_alive);
         }
-        if (lane == 0 && n_alive) atomicAdd(&of.cnt_pack[gs + src], (unsigned long long)n_alive);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __syncthreads();
+    }
+    // the last block to finish re-arms the queue for the next match launch
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&of.tie_count[1], 1u) == gridDim.x - 1) {
+            of.tie_count[2] += n_tied;
+            of.tie_count[0] = 0; of.tie_count[1] = 0;
+            __threadfence();
+        }
     }
 }
 
-uint32_t match_tied_grid() { return 256; }
+uint32_t match_tied_grid() { return 128; }
 
 hipError_t launch_match_tied_rows(const ViewDev* views, const PairDesc* pairs, Slot* slots, uint32_t maxK, float thr,
                                   OrientFuse of, float* scratch_ov, uint32_t* scratch_ix, uint32_t scratch_stride,
                                   hipStream_t stream) {
     if (!of.tie_count || !of.tie_list || !scratch_ov || !scratch_ix) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_match_tied_rows, dim3(match_tied_grid()), dim3(64), (size_t)maxK * 8, stream, views, pairs, slots,
-                       thr, of, scratch_ov, scratch_ix, scratch_stride);
+    hipLaunchKernelGGL(k_match_tied_rows, dim3(match_tied_grid()), dim3(kTieBlock), (size_t)maxK * 8, stream, views, pairs,
+                       slots, thr, of, scratch_ov, scratch_ix, scratch_stride);
     return hipGetLastError();
 }
 

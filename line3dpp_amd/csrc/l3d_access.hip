@@ -148,6 +148,13 @@ int l3d_get_sparse_matrix(l3d_ctx* c, int sort_by_row, l3d_float4* entries, int3
 int l3d_get_timings(l3d_ctx* c, l3d_timings* t) {
     if (!c || !t) return fail(L3D_ERR_ARG, "null argument");
     *t = c->tm;
+    if (c->d_tie_count.p) {   // rows replayed in the reference's priority_queue order, cumulative (diagnostics: read on demand)
+        uint32_t v[4] = {0, 0, 0, 0};
+        (void)hipSetDevice(c->device);
+        L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
+        L3D_HIP_CHECK(hipMemcpy(v, c->d_tie_count.p, 16, hipMemcpyDeviceToHost));
+        t->tied_rows = v[2];
+    }
     return L3D_OK;
 }
 

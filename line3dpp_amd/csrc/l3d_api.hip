@@ -509,7 +509,6 @@ static void collect_match_timing(l3d_ctx* c) {
     c->tm.match_kernel_ms += ev_ms(c->ev[4], c->ev[5]);
     c->tm.cull_prepare_ms += ev_ms(c->ev[8], c->ev[4]);
     c->tm.match_kernel_launches += c->pending_launches;
-    if (c->tie_count_pending) { c->tm.tied_rows += c->h_cnt.p[14]; c->tie_count_pending = false; }
     c->timing_pending = false; c->pending_launches = 0;
 }
 
@@ -548,11 +547,13 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         uint32_t mt = 0;
         for (auto& pd : c->pairs) mt = std::max(mt, pd.Mt);
         tie_stride = std::max(mt, 1u);
-        L3D_HIP_CHECK(c->d_tie_count.reserve(4));
+        if (!c->d_tie_count.p) {   // zeroed once: the replay kernel re-arms the queue itself after every launch
+            L3D_HIP_CHECK(c->d_tie_count.reserve(4));
+            L3D_HIP_CHECK(hipMemsetAsync(c->d_tie_count.p, 0, 16, c->stream));
+        }
         L3D_HIP_CHECK(c->d_tie_list.reserve(std::max<uint32_t>(c->n_rows_total, 1)));
         L3D_HIP_CHECK(c->d_tie_ov.reserve((size_t)match_tied_grid() * tie_stride));
         L3D_HIP_CHECK(c->d_tie_ix.reserve((size_t)match_tied_grid() * tie_stride));
-        L3D_HIP_CHECK(hipMemsetAsync(c->d_tie_count.p, 0, 16, c->stream));
         of.tie_count = c->d_tie_count.p; of.tie_list = c->d_tie_list.p; of.tie_cap = c->n_rows_total;
     }
     L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work, maxK,
@@ -561,9 +562,6 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     if (mode == 0) {
         L3D_HIP_CHECK(launch_match_tied_rows(c->d_views.p, c->d_pairs.p, c->d_slots.p, maxK, c->epipolar_overlap, of,
                                              c->d_tie_ov.p, c->d_tie_ix.p, tie_stride, c->stream));
-        L3D_HIP_CHECK(c->h_cnt.reserve(16));
-        L3D_HIP_CHECK(hipMemcpyAsync(c->h_cnt.p + 14, c->d_tie_count.p, 4, hipMemcpyDeviceToHost, c->stream));
-        c->tie_count_pending = true;
         for (uint32_t p = first; p < first + count; ++p) c->pair_counted[p] = 1;
     }
     if (pools.cull)

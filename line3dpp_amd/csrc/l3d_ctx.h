@@ -168,7 +168,6 @@ struct l3d_ctx {
     DevBuf<uint32_t> d_tie_count, d_tie_ix;
     DevBuf<uint2> d_tie_list;
     DevBuf<float> d_tie_ov;
-    bool tie_count_pending = false;
     // phase B (global over all views; G = sum of M)
     uint32_t G = 0, n_ents = 0, n_surv = 0, n_hyps = 0;
     std::vector<uint32_t> seg_base;                 // [V+1]

@@ -1,6 +1,6 @@
 // l3d_output.hip -- output layer of the C-ABI: Line3D::get3Dlines (line3D.cc:2455-2463), createOutputFilename
 // (:2853-2893), getSegmentCoords2D (:2757-2772) and the result writers save3DLinesAsTXT (:2631-2688),
-// saveResultAsSTL (:2465-2531), saveResultAsOBJ (:2579-2628).
+// save3DLinesAsBIN (:2690-2711), saveResultAsSTL (:2465-2531), saveResultAsOBJ (:2579-2628).
 #include "l3d_ctx.h"
 
 namespace l3d {
@@ -71,6 +71,50 @@ int l3d_save_3d_lines_txt(l3d_ctx* c, const char* output_folder, int max_image_w
     }
     file.close();
     return file.fail() ? fail(L3D_ERR_ARG, "writing " + filename + " failed") : L3D_OK;
+}
+
+// Line3D::save3DLinesAsBIN, line3D.cc:2690-2711: serializeToFile(filename, lines3D_) (serialization.h:38-45) =
+// boost::archive::binary_oarchive of std::vector<FinalLine3D>.  Written here without Boost, byte for byte as the
+// Boost behind the reference's own fixtures does (archive library version 10; layout in line3dpp_amd/io.py, which
+// re-creates testdata/Line3D++_ref/*vis_3.bin bit-identically -- tests/test_bin_format.py): every class writes its
+// 5-byte header (tracking 0, version 0) at its first occurrence only; collections write u64 count + u32 item_version.
+int l3d_save_3d_lines_bin(l3d_ctx* c, const char* output_folder, int max_image_width) {
+    if (!c || !output_folder) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (!c->lines_done || c->lines3D.empty()) return fail(L3D_ERR_STATE, "no 3D lines to save!");   // :2695-2701
+    const std::string filename = std::string(output_folder) + "/" + output_filename(c, max_image_width) + ".bin";
+    std::ofstream os(filename.c_str(), std::ios::binary);
+    if (!os) return fail(L3D_ERR_ARG, "cannot open " + filename);
+    auto put = [&](const void* p, size_t n) { os.write((const char*)p, (std::streamsize)n); };
+    auto u64 = [&](uint64_t v) { put(&v, 8); };
+    auto u32 = [&](uint32_t v) { put(&v, 4); };
+    bool seen[7] = {};
+    enum { VEC, FINAL, LIST3, SEG3, CLUSTER, LIST2, SEG2 };
+    auto hdr = [&](int cls) { if (!seen[cls]) { seen[cls] = true; const char z[5] = {0, 0, 0, 0, 0}; put(z, 5); } };
+    auto seg3 = [&](const ReconSeg3D& sg) {               // Segment3D::serialize, segment3D.h:99-115
+        hdr(SEG3);
+        const float len = sg.length; const uint8_t valid = sg.valid ? 1 : 0;
+        put(&len, 4); put(&valid, 1);
+        const double g[9] = {sg.P1.x, sg.P1.y, sg.P1.z, sg.P2.x, sg.P2.y, sg.P2.z, sg.dir.x, sg.dir.y, sg.dir.z};
+        put(g, 72);
+    };
+    const char sig[] = "serialization::archive";
+    u64(22); put(sig, 22);
+    const uint16_t lib_version = 10; put(&lib_version, 2);
+    const uint8_t sizes[4] = {4, 8, 4, 8}; put(sizes, 4); u32(1);
+    hdr(VEC); u64(c->lines3D.size()); u32(0);
+    for (const ReconLine& L : c->lines3D) {
+        hdr(FINAL);                                        // FinalLine3D::serialize, segment3D.h:165-178
+        hdr(LIST3); u64(L.collinear.size()); u32(0);
+        for (const ReconSeg3D& sg : L.collinear) seg3(sg);
+        hdr(CLUSTER);                                      // LineCluster3D::serialize, segment3D.h:152-160
+        seg3(L.cluster_seg);
+        hdr(LIST2); u64(L.residuals.size()); u32(0);
+        for (const auto& r : L.residuals) { hdr(SEG2); u32(r.first); u32(r.second); }   // commons.h:123-130
+        u32(L.reference_view);
+    }
+    os.close();
+    return os.fail() ? fail(L3D_ERR_ARG, "writing " + filename + " failed") : L3D_OK;
 }
 
 // Line3D::getSegmentCoords2D, line3D.cc:2757-2772: (0,0,0,0) for an unknown camera / segment

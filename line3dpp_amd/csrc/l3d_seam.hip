@@ -214,7 +214,7 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         L3D_HIP_CHECK(cnt_pack.reserve((size_t)Ms + Mt + 1)); L3D_HIP_CHECK(inv_pos.reserve((size_t)Ms * pd.K));
         L3D_HIP_CHECK(hipMemset(cnt_pack.p, 0, ((size_t)Ms + Mt + 1) * 8));
         L3D_HIP_CHECK(tie_count.reserve(4)); L3D_HIP_CHECK(tie_list.reserve(Ms));
-        L3D_HIP_CHECK(tie_ov.reserve((size_t)match_tied_grid() * Mt)); L3D_HIP_CHECK(tie_ix.reserve((size_t)match_tied_grid() * Mt));
+        L3D_HIP_CHECK(tie_ov.reserve((size_t)match_tied_grid() * Mt)); L3D_HIP_CHECK(tie_ix.reserve((size_t)match_tied_grid() * Mt));   // (l3d_kernels.h: one scratch region per workgroup)
         L3D_HIP_CHECK(hipMemset(tie_count.p, 0, 16));
         OrientFuse of{cnt_pack.p, inv_pos.p, OrientThr{-1.0, 1.0}, tie_count.p, tie_list.p, Ms};
         orientation_thresholds(of.thr.lo, of.thr.hi);

@@ -67,3 +67,117 @@ def format_stl(lines):
                   "   vertex %s %s %s\n" % tuple(a[:3]), "  endloop\n", " endfacet\n"]
     t.append("endsolid lineModel\n")
     return "".join(t)
+
+
+# ---- BIN result format (Line3D::save3DLinesAsBIN, line3D.cc:2690-2711) ------------------------------------------
+# boost::archive::binary_oarchive of std::vector<FinalLine3D> (serialization.h:38-45), little endian, as written by
+# the Boost version behind the reference's fixtures (archive library version 10).  Layout, verified byte for byte
+# against testdata/Line3D++_ref/*vis_3.bin (tests/test_bin_format.py):
+#   u64 22, "serialization::archive", u16 library version, sizeof(int, long, float, double) as 4 bytes, u32 1 (endian)
+#   every class writes a 5-byte header (u8 tracking = 0, u32 version = 0) at its FIRST occurrence in the archive only
+#   collections: u64 count, u32 item_version
+#   vector<FinalLine3D>   = [hdr] count item_version FinalLine3D*
+#   FinalLine3D           = [hdr] list<Segment3D> LineCluster3D                       (segment3D.h:165-178)
+#   list<Segment3D>       = [hdr] count item_version Segment3D*
+#   Segment3D             = [hdr] f32 length_, u8 valid_, 9 x f64 (P1, P2, dir)       (segment3D.h:99-115)
+#   LineCluster3D         = [hdr] Segment3D list<Segment2D> u32 reference_view_        (segment3D.h:152-160)
+#   list<Segment2D>       = [hdr] count item_version Segment2D*
+#   Segment2D             = [hdr] u32 camID_, u32 segID_                               (commons.h:123-130)
+_BIN_SIG = b"serialization::archive"
+_CLASS_HDR = b"\x00" * 5
+
+
+class _Reader:
+    def __init__(self, buf):
+        self.b, self.p, self.seen = buf, 0, set()
+
+    def take(self, fmt):
+        import struct
+        v = struct.unpack_from("<" + fmt, self.b, self.p)
+        self.p += struct.calcsize("<" + fmt)
+        return v if len(v) > 1 else v[0]
+
+    def hdr(self, cls):
+        if cls not in self.seen:
+            self.seen.add(cls)
+            if self.b[self.p:self.p + 5] != _CLASS_HDR:
+                raise ValueError(f"unexpected class header for {cls} at byte {self.p}")
+            self.p += 5
+
+    def seg3d(self):
+        self.hdr("Segment3D")
+        length, valid = self.take("fB")
+        geo = np.array(self.take("9d"))
+        return length, valid, geo
+
+
+def read_3d_lines_bin(path):
+    """-> (lines, library_version); lines = list of dicts: segments [n,9] float64 (P1, P2, dir), seg_length [n] float32,
+    seg_valid [n] uint8, cluster_line [9] float64, cluster_length, cluster_valid, residuals [m,2] uint32 (camID, segID),
+    reference_view"""
+    r = _Reader(open(path, "rb").read())
+    if r.take("Q") != len(_BIN_SIG) or r.b[r.p:r.p + len(_BIN_SIG)] != _BIN_SIG:
+        raise ValueError(f"{path}: not a boost binary archive")
+    r.p += len(_BIN_SIG)
+    lib_version = r.take("H")
+    if bytes(r.b[r.p:r.p + 8]) != bytes([4, 8, 4, 8, 1, 0, 0, 0]):
+        raise ValueError(f"{path}: written on a platform with other type sizes / endianness")
+    r.p += 8
+    r.hdr("vector<FinalLine3D>")
+    n, _ = r.take("QI")
+    lines = []
+    for _ in range(n):
+        r.hdr("FinalLine3D")
+        r.hdr("list<Segment3D>")
+        ns, _ = r.take("QI")
+        segs = [r.seg3d() for _ in range(ns)]
+        r.hdr("LineCluster3D")
+        cl_len, cl_valid, cl_geo = r.seg3d()
+        r.hdr("list<Segment2D>")
+        nr, _ = r.take("QI")
+        res = np.zeros((nr, 2), np.uint32)
+        for k in range(nr):
+            r.hdr("Segment2D")
+            res[k] = r.take("II")
+        ref_view = r.take("I")
+        lines.append(dict(segments=np.array([s[2] for s in segs]).reshape(-1, 9),
+                          seg_length=np.array([s[0] for s in segs], np.float32),
+                          seg_valid=np.array([s[1] for s in segs], np.uint8),
+                          cluster_line=cl_geo, cluster_length=np.float32(cl_len), cluster_valid=int(cl_valid),
+                          residuals=res, reference_view=int(ref_view)))
+    if r.p != len(r.b):
+        raise ValueError(f"{path}: {len(r.b) - r.p} trailing bytes")
+    return lines, lib_version
+
+
+def format_3d_lines_bin(lines, lib_version=10):
+    """inverse of read_3d_lines_bin: the exact bytes Line3D::save3DLinesAsBIN writes for these lines"""
+    import struct
+    out = [struct.pack("<Q", len(_BIN_SIG)), _BIN_SIG, struct.pack("<H", lib_version), bytes([4, 8, 4, 8, 1, 0, 0, 0])]
+    seen = set()
+
+    def hdr(cls):
+        if cls not in seen:
+            seen.add(cls)
+            out.append(_CLASS_HDR)
+
+    def seg3d(length, valid, geo):
+        hdr("Segment3D")
+        out.append(struct.pack("<fB9d", float(length), int(valid), *[float(x) for x in geo]))
+    hdr("vector<FinalLine3D>")
+    out.append(struct.pack("<QI", len(lines), 0))
+    for L in lines:
+        hdr("FinalLine3D")
+        hdr("list<Segment3D>")
+        out.append(struct.pack("<QI", len(L["segments"]), 0))
+        for g, ln, va in zip(L["segments"], L["seg_length"], L["seg_valid"]):
+            seg3d(ln, va, g)
+        hdr("LineCluster3D")
+        seg3d(L["cluster_length"], L["cluster_valid"], L["cluster_line"])
+        hdr("list<Segment2D>")
+        out.append(struct.pack("<QI", len(L["residuals"]), 0))
+        for cam, seg in L["residuals"]:
+            hdr("Segment2D")
+            out.append(struct.pack("<II", int(cam), int(seg)))
+        out.append(struct.pack("<I", int(L["reference_view"])))
+    return b"".join(out)

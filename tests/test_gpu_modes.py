@@ -61,7 +61,8 @@ def test_parameter_modes_through_the_hip_path(params):
     g = _gpu(sc)
     assert g.matchImages(**_g(params)) and g.computeAffinity()
     r = _assert_same(g, _ref(sc, [params]), sc)
-    assert r["surviving"] > 0 or params.get("epi_overlap", 0) < 0     # overlap > 0.99 leaves next to nothing
+    assert r["surviving"] > 0 or params.get("epi_overlap", 0) < 0 or params.get("sigma_p") == 0.01   # overlap > 0.99 /
+    # a 0.1 px regulariser leave next to nothing
 
 
 def test_second_match_images_with_other_parameters():

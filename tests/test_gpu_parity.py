@@ -775,6 +775,21 @@ def test_txt_writer_matches_accessor_and_reference_writer(tmp_path):
     assert open(tmp_path / (name + ".obj")).read() == format_obj(mine)
     full = [dict(segments=np.concatenate([b["collinear3Dsegments"]["P1"], b["collinear3Dsegments"]["P2"]], 1)) for b in acc]
     assert open(tmp_path / (name + ".stl")).read() == format_stl(full)
+    # BIN writer (Line3D::save3DLinesAsBIN, boost binary archive layout): lossless -- the parsed file equals
+    # get3Dlines() bit for bit, cluster line, residuals and reference view included, and re-serialises identically
+    from line3dpp_amd.io import format_3d_lines_bin, read_3d_lines_bin
+    assert g.save3DLinesAsBIN(tmp_path)
+    binl, version = read_3d_lines_bin(tmp_path / (name + ".bin"))
+    assert version == 10 and len(binl) == len(acc)
+    for a, b in zip(binl, acc):
+        cs = b["collinear3Dsegments"]
+        assert np.array_equal(a["segments"], np.concatenate([cs["P1"], cs["P2"], cs["dir"]], 1))
+        assert np.array_equal(a["seg_length"], cs["length"]) and np.array_equal(a["seg_valid"], cs["valid"].astype(np.uint8))
+        cl = b["cluster_line"]
+        assert np.array_equal(a["cluster_line"], np.concatenate([cl["P1"], cl["P2"], cl["dir"]]))
+        assert a["cluster_length"] == cl["length"] and a["reference_view"] == b["reference_view"]
+        assert np.array_equal(a["residuals"], np.stack([b["residuals"]["cam"], b["residuals"]["seg"]], 1))
+    assert format_3d_lines_bin(binl, version) == open(tmp_path / (name + ".bin"), "rb").read()
     if O.have_reference():
         r = O.Oracle(threads=1, reference=True)
         r.add_scene(sc); r.match_images(); r.reconstruct(3)
