@@ -208,9 +208,10 @@ typedef struct l3d_timings {
     float cull_prepare_ms; /* ordering of rows/targets by epipolar band (part of match_pairs_ms) */
     uint32_t culled_pairs; /* directed pairs matched with epipolar-band culling in the last matchImages */
     uint32_t list_entries; /* phase B: total length of the per-segment hypothesis lists (fresh + inverse) */
-    uint32_t support_words;/* phase B: 64-bit words of the support bitsets */
+    uint32_t support_words;/* phase B: supporting (hypothesis, supporter) pairs = edges of the sparse form */
     uint32_t tied_rows;    /* phase A: source rows with equal overlaps, replayed in the reference's priority_queue order
                             * (cumulative since l3d_create) */
+    uint32_t chain_extra_rounds; /* phase B: extra rounds of chain sweeps beyond the ones enqueued blindly (0 normally) */
 } l3d_timings;
 int l3d_get_timings(l3d_ctx*, l3d_timings*);
 

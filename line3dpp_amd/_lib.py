@@ -10,6 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libl3dpp_hip.so")
+# L3D_LIB=<path>: load another build of the same library (diagnostic builds with -DL3D_STATS / -DL3D_CYCLES)
+SO_PATH = os.environ.get("L3D_LIB", SO_PATH)
 
 # reference PODs (include/l3dpp_hip.h)
 MATCH_DTYPE = np.dtype([
@@ -36,7 +38,7 @@ class Timings(C.Structure):
     _fields_ = [("begin_ms", C.c_float), ("match_pairs_ms", C.c_float), ("finish_ms", C.c_float),
                 ("affinity_ms", C.c_float), ("match_kernel_launches", C.c_uint32), ("match_kernel_ms", C.c_float),
                 ("cull_prepare_ms", C.c_float), ("culled_pairs", C.c_uint32),
-                ("list_entries", C.c_uint32), ("support_words", C.c_uint32), ("tied_rows", C.c_uint32)]
+                ("list_entries", C.c_uint32), ("support_words", C.c_uint32), ("tied_rows", C.c_uint32), ("chain_extra_rounds", C.c_uint32)]
 
 
 EXPORTS = [

@@ -1,0 +1,946 @@
+// k_lists.hip -- phase B, sparse form: the per-view part of Line3D::computeMatches (line3D.cc:745-773) =
+// scoringCPU (:1208-1294) + storeInverseMatches (:1672-1699) + filterMatches (:1586-1669) for ALL views.
+//
+//   k_inv_records   transposed index of the potential inverse hypotheses (24-byte records, CSR over segments)
+//   k_lists<WPL>    THE dense pass, one wave (long lists: one 4-wave workgroup) per 2D segment: gathers the segment's
+//                   hypotheses in canonical (= reference single-thread) order, sorts them by depth, finds the pairs
+//                   (i, j) with similarityForScoring(i, j) > 0.5 inside each hypothesis' depth window (conservative
+//                   window from slot data alone, then the reference's exact decision on the few candidates, full
+//                   lanes), evaluates their similarity and emits EDGES + one HEADER per supported hypothesis
+//                   (l3d_lists.h).  98 % of the hypotheses have no supporter and leave no trace.
+//   k_lists_huge    the same for lists beyond the LDS capacity of k_lists<4> (global-memory staging, all pairs)
+//   k_chain_sweep   the reference's chain (view v sees the inverse matches of views u < v whose score was > 0,
+//                   :1680) as a monotone fixed point over the headers: positive[slot] only ever gains bits and the
+//                   dependency graph is acyclic (u < v), so sweeping until nothing changes gives the sequential
+//                   result; a sweep is one pass over ~10^5 headers
+//   k_hyp_scores    score3D of every header from its edges (per-camera replace/subtract accumulation, :1255-1274)
+//   k_hyp_filter / k_seg_filter / k_seg_write   filterMatches: 10 % of the view's best score, first strict maximum,
+//                   0.75 gate; surviving matches_ lists, estimated_position3D_ entries, depths for the view medians
+#include "l3d_dev.h"
+#include "l3d_kernels.h"
+#include "l3d_lists.h"
+
+namespace l3d {
+
+namespace {
+
+#define L3D_LDS __attribute__((address_space(3)))
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+template <int WPL>
+__device__ __forceinline__ void group_barrier() {
+    if (WPL == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __syncthreads();
+    }
+}
+
+// exclusive prefix sum of v over the group's threads (thread order) and the group total.  red: >= 8 words of LDS
+template <int WPL>
+__device__ __forceinline__ uint32_t group_scan(uint32_t v, uint32_t& total, uint32_t* red) {
+    const uint32_t lane = lane_id();
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= (uint32_t)d) x += y; }
+    if (WPL == 1) {
+        total = __shfl(x, 63);
+        return x - v;
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    __syncthreads();                       // red may still be read from a previous call
+    if (lane == 63) red[wave] = x;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < (uint32_t)WPL; ++w) { const uint32_t c = red[w]; before += w < wave ? c : 0u; tot += c; }
+    total = tot;
+    return before + x - v;
+}
+
+template <int WPL>
+__device__ __forceinline__ uint32_t group_max(uint32_t v, uint32_t* red) {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x = max(x, (uint32_t)__shfl_xor(x, d));
+    if (WPL == 1) return x;
+    const uint32_t wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane_id() == 0) red[wave] = x;
+    __syncthreads();
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < (uint32_t)WPL; ++w) m = max(m, red[w]);
+    return m;
+}
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+
+// ---- similarityForScoring (line3D.cc:1417-1446) for hypotheses a (the scored one) and b of the same 2D segment ----
+// Decision form: "similarityForScoring > L3D_DEF_MIN_SIMILARITY_3D" without transcendentals.
+// sim = fmin(sim_a, fmin(e1, e2)) > 0.5 <=> every non-NaN component is > 0.5 (fmin skips NaNs; all NaN -> false).
+// expf and acos are monotone, so each component test is a comparison of its float argument with a threshold the host
+// found by bisection with the libm the reference itself would use (sim_thresholds, l3d_api.hip):
+//     expf(y) > 0.5f                           <=>  y > y_thr
+//     expf(-angle(x)^2 / two_sigA_sqr) > 0.5f  <=>  x >= x_hi || x <= x_lo     (x = clamped float dot product)
+__device__ __forceinline__ bool sim_decide(const d3 dira, bool zeroa, float adp1, float adp2, float reg1, float reg2,
+                                           const d3 dirb, bool zerob, float bdp1, float bdp2, const SimConst sc) {
+    if (zeroa || zerob) return false;
+    const float d1 = adp1 - bdp1, d2 = adp2 - bdp2;
+    const float y1 = -d1 * d1 / reg1, y2 = -d2 * d2 / reg2;
+    // NaN components drop out of the fmin chain; the angular component is never NaN (x is clamped, sigma_a > 0)
+    if (y1 == y1 && !(y1 > sc.y_thr)) return false;
+    if (y2 == y2 && !(y2 > sc.y_thr)) return false;
+    const float dot_p = (float)dot(dira, dirb);
+    const float x = fmaxf(fminf(dot_p, 1.0f), -1.0f);
+    return x >= sc.x_hi || x <= sc.x_lo;
+}
+
+// Value form, for pairs sim_decide accepted.  acos/exp are evaluated in double and rounded to float (glibc's
+// expf/acos differ from that by < 1 float ulp).  fmin(expf(ya), fmin(expf(y1), expf(y2))) == expf(fmin(ya, fmin(y1,
+// y2))): expf is monotone and fmin skips NaNs on both sides alike -- one exponential instead of three.
+__device__ __forceinline__ float sim_value(const d3 dira, float adp1, float adp2, float reg1, float reg2,
+                                           const d3 dirb, float bdp1, float bdp2, const SimConst sc) {
+    const float d1 = adp1 - bdp1, d2 = adp2 - bdp2;
+    const float y1 = -d1 * d1 / reg1, y2 = -d2 * d2 / reg2;
+    const float dot_p = (float)dot(dira, dirb);
+    float angle = (float)(acos((double)fmaxf(fminf(dot_p, 1.0f), -1.0f)) / M_PI * 180.0f);
+    if (angle > 90.0f) angle = 180.0f - angle;
+    const float ya = -angle * angle / sc.two_sigA_sqr;
+    return (float)exp((double)fminf(ya, fminf(y1, y2)));
+}
+
+// the exact test of one ordered pair (i scored, j supporter) of the segment with invariants sx in view v:
+// scoringCPU's unprojection + spatial regularisers of i (line3D.cc:1233-1248) and similarityForScoring(i, j)
+__device__ __forceinline__ bool exact_support(const ViewDev& v, const ViewDev* __restrict__ views, const SegX& sx,
+                                              float a1, float a2, uint32_t tvi, float b1, float b2, const SimConst sc,
+                                              float& sim) {
+    const Seg3 si = unproject(v.C, sx.r1, sx.r2, a1, a2);
+    const Seg3 sj = unproject(v.C, sx.r1, sx.r2, b1, b2);
+    const ViewDev& vt = views[tvi];
+    const float k = v.k;
+    const float sig1 = a1 * k, sig2 = a2 * k;
+    float reg1 = 2.0f * sig1 * sig1, reg2 = 2.0f * sig2 * sig2;
+    const d3 ct{vt.C[0], vt.C[1], vt.C[2]};
+    const float sig1_t = (float)(norm(si.P1 - ct) * (double)vt.k);   // View::regularizerFrom3Dpoint
+    const float sig2_t = (float)(norm(si.P2 - ct) * (double)vt.k);
+    reg1 = 0.5f * (reg1 + 2.0f * sig1_t * sig1_t);
+    reg2 = 0.5f * (reg2 + 2.0f * sig2_t * sig2_t);
+    if (!sim_decide(si.dir, si.length < kEps, a1, a2, reg1, reg2, sj.dir, sj.length < kEps, b1, b2, sc)) return false;
+    sim = sim_value(si.dir, a1, a2, reg1, reg2, sj.dir, b1, b2, sc);
+    return true;
+}
+
+// Conservative squared depth windows of hypothesis i, from slot data alone: similarityForScoring(i, .) > 0.5 needs
+// d^2 < 0.6932 * reg (expf(-d^2/reg) > 0.5), and reg = (dp k)^2 + (|P - C_t| k_t)^2 with |P - C_t| <= dp + |C - C_t|
+// (P = C + ray * dp, unit ray): no unprojection is needed to bound it.  0.72 * 1.001 covers every float rounding.
+__device__ __forceinline__ float window_sq(float dp, float k, float kt, float cc_dist) {
+    const float a = dp * k, b = (dp + cc_dist) * kt;
+    const float r = 0.72f * 1.001f * (a * a + b * b) + 1e-37f;
+    return (r < 1e30f) ? r : __builtin_inff();     // NaN / huge: the whole list is the window
+}
+
+template <int WPL>
+struct ListCfg {
+    static constexpr uint32_t GS = 64 * WPL;      // threads per list
+    static constexpr uint32_t CAP = 192 * WPL;    // hypotheses staged in LDS
+    static constexpr uint32_t NKEY = 256 * WPL;   // sort keys (power of two >= CAP)
+    static constexpr uint32_t BYTES = CAP * 20 + NKEY * 8 + CAP * 2 + 64;   // LDS per list
+};
+
+// One list: its candidate pairs.  Returns 0 (done / nothing to do) or 1 (needs a larger kernel: nothing was written).
+// Group-uniform control flow.
+template <int WPL>
+__device__ __forceinline__ int process_list(uint32_t g, L3D_LDS char* lds, const ViewDev* __restrict__ views,
+                                            const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ seg_base,
+                                            const uint32_t* __restrict__ gseg_view,
+                                            const uint32_t* __restrict__ vout_off,
+                                            const uint32_t* __restrict__ vout_pairs,
+                                            const unsigned long long* __restrict__ off64,
+                                            const InvRec* __restrict__ inv, const Slot* __restrict__ slots,
+                                            uint32_t uniform_K, const ListPools lp) {
+    typedef ListCfg<WPL> Cfg;
+    constexpr uint32_t GS = Cfg::GS, CAP = Cfg::CAP, NKEY = Cfg::NKEY;
+    const uint32_t t = WPL == 1 ? lane_id() : threadIdx.x;
+    const uint32_t L = (uint32_t)(off64[g + 1] - off64[g]);             // low words: list offsets
+    if (L < 2) return 0;
+    if (L > CAP) return 1;
+    L3D_LDS float* e_d1 = (L3D_LDS float*)lds;
+    L3D_LDS float* e_d2 = e_d1 + CAP;
+    L3D_LDS uint32_t* e_tv = (L3D_LDS uint32_t*)(e_d2 + CAP);
+    L3D_LDS uint32_t* e_ref = e_tv + CAP;
+    L3D_LDS uint32_t* e_pf = e_ref + CAP;
+    L3D_LDS uint64_t* keys = (L3D_LDS uint64_t*)(e_pf + CAP);
+    L3D_LDS uint16_t* pos_of = (L3D_LDS uint16_t*)(keys + NKEY);        // sorted position of hypothesis i
+    uint32_t* red = (uint32_t*)(pos_of + CAP);                          // 16 words (generic pointer into LDS)
+    const uint32_t vi = gseg_view[g], seg = g - seg_base[vi];
+    const ViewDev& v = views[vi];
+    const uint32_t ib = (uint32_t)(off64[g] >> 32), n_inv = (uint32_t)(off64[g + 1] >> 32) - ib;
+    // ---- inverse hypotheses, placed at their canonical rank: (source view, source segment) ascending ----
+    for (uint32_t x = t; x < n_inv; x += GS) {
+        const InvRec r = inv[ib + x];
+        keys[x] = ((uint64_t)r.src_view << 32) | r.src_row;
+    }
+    group_barrier<WPL>();
+    for (uint32_t x = t; x < n_inv; x += GS) {
+        const InvRec r = inv[ib + x];
+        const uint64_t key = ((uint64_t)r.src_view << 32) | r.src_row;
+        uint32_t rank = 0;
+        for (uint32_t y = 0; y < n_inv; ++y) rank += (keys[y] < key) ? 1u : 0u;
+        e_d1[rank] = r.dq1; e_d2[rank] = r.dq2; e_tv[rank] = r.src_view; e_ref[rank] = r.ref; e_pf[rank] = r.pair | kHypInv;
+    }
+    // ---- fresh hypotheses: the alive slots of the view's outgoing pairs, ascending (target view, slot) ----
+    uint32_t pos = n_inv;
+    {
+        const uint32_t q0 = vout_off[vi], nq = vout_off[vi + 1] - q0;
+        if (uniform_K) {
+            const uint32_t T = nq * uniform_K;
+            for (uint32_t t0 = 0; t0 < T; t0 += GS) {
+                const uint32_t x = t0 + t;
+                bool alive = false;
+                Slot s; uint32_t ref = 0, pi = 0, tv = 0;
+                if (x < T) {
+                    pi = vout_pairs[q0 + x / uniform_K];
+                    const PairDesc& pd = pairs[pi];
+                    tv = pd.tgt;
+                    ref = (uint32_t)(pd.slot_off + (uint64_t)seg * uniform_K + x % uniform_K);
+                    s = slots[ref];
+                    alive = s.tgt_seg != kEmpty && (s.flags & kSlotAlive);
+                }
+                uint32_t total;
+                const uint32_t at = pos + group_scan<WPL>(alive ? 1u : 0u, total, red);
+                if (alive && at < CAP) { e_d1[at] = s.dp1; e_d2[at] = s.dp2; e_tv[at] = tv; e_ref[at] = ref; e_pf[at] = pi; }
+                pos += total;
+            }
+        } else {
+            for (uint32_t q = q0; q < q0 + nq; ++q) {
+                const uint32_t pi = vout_pairs[q];
+                const PairDesc& pd = pairs[pi];
+                const uint64_t row0 = pd.slot_off + (uint64_t)seg * pd.K;
+                for (uint32_t j0 = 0; j0 < pd.K; j0 += GS) {
+                    bool alive = false;
+                    Slot s;
+                    if (j0 + t < pd.K) {
+                        s = slots[row0 + j0 + t];
+                        alive = s.tgt_seg != kEmpty && (s.flags & kSlotAlive);
+                    }
+                    uint32_t total;
+                    const uint32_t at = pos + group_scan<WPL>(alive ? 1u : 0u, total, red);
+                    if (alive && at < CAP) { e_d1[at] = s.dp1; e_d2[at] = s.dp2; e_tv[at] = pd.tgt; e_ref[at] = (uint32_t)(row0 + j0 + t); e_pf[at] = pi; }
+                    pos += total;
+                }
+            }
+        }
+    }
+    group_barrier<WPL>();
+    if (pos != L) { if (t == 0) atomicOr(&lp.flags[3], 1u); return 0; }   // counters and slots disagree: reported by the host
+    // ---- sort by the first depth: key = (order-preserving bits of dp1, canonical index) ----
+    uint32_t N = 2;
+    while (N < L) N <<= 1;
+    for (uint32_t x = t; x < N; x += GS) keys[x] = x < L ? (((uint64_t)f2ord(e_d1[x]) << 32) | x) : ~0ull;
+    for (uint32_t k = 2; k <= N; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            group_barrier<WPL>();
+            for (uint32_t px = t; px < N / 2; px += GS) {
+                const uint32_t lo = ((px & ~(j - 1)) << 1) | (px & (j - 1)), hi = lo | j;
+                const uint64_t a = keys[lo], b = keys[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+        }
+    group_barrier<WPL>();
+    for (uint32_t p = t; p < L; p += GS) pos_of[(uint32_t)keys[p] & 0xFFFFu] = (uint16_t)p;
+    group_barrier<WPL>();
+    // ---- candidate pairs: every hypothesis walks outwards from its sorted position while the first depths differ by
+    // no more than its window; a candidate also has another camera and its second depth inside the second window.
+    // Threads take the hypotheses in CANONICAL order, so the records come out grouped by i in canonical order.
+    // Two passes: count (-> one reservation for the whole list), then write the records ----
+    constexpr uint32_t kPer = (CAP + GS - 1) / GS;                      // hypotheses per thread
+    uint32_t my_cnt[kPer], my_total = 0;
+    auto walk = [&](uint32_t i, auto&& emit) {
+        const uint32_t p = pos_of[i];
+        const float a1 = e_d1[i], a2 = e_d2[i];
+        const uint32_t tvi = e_tv[i];
+        const float kt = views[tvi].k, D = pairs[e_pf[i] & 0x7FFFFFFFu].cc_dist;
+        const float R1 = window_sq(a1, v.k, kt, D), R2 = window_sq(a2, v.k, kt, D);
+        for (uint32_t q = p; q-- > 0;) {
+            const uint64_t kq = keys[q];
+            const float d = a1 - ord2f((uint32_t)(kq >> 32));
+            if (!(d * d <= R1)) break;
+            const uint32_t j = (uint32_t)kq & 0xFFFFu;
+            const float d2 = a2 - e_d2[j];
+            if (e_tv[j] != tvi && d2 * d2 <= R2) emit(j);
+        }
+        for (uint32_t q = p + 1; q < L; ++q) {
+            const uint64_t kq = keys[q];
+            const float d = a1 - ord2f((uint32_t)(kq >> 32));
+            if (!(d * d <= R1)) break;
+            const uint32_t j = (uint32_t)kq & 0xFFFFu;
+            const float d2 = a2 - e_d2[j];
+            if (e_tv[j] != tvi && d2 * d2 <= R2) emit(j);
+        }
+    };
+    // hypothesis i = c * GS + t: canonical order = ascending (c, t), so the offsets are one group scan per c
+    uint32_t H = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < kPer; ++c) {
+        const uint32_t i = c * GS + t;
+        uint32_t cnt = 0;
+        if (c * GS < L) {
+            if (i < L) walk(i, [&](uint32_t) { ++cnt; });
+            uint32_t total;
+            my_cnt[c] = H + group_scan<WPL>(cnt, total, red);          // offset of my records within the list
+            H += total;
+        }
+        my_total += cnt;
+    }
+    if (H == 0) return 0;
+    const uint32_t pool = blockIdx.x % kListPools;
+    if (t == 0) {
+        red[8] = atomicAdd(&lp.cnt[pool * 16 + 3], H);
+        red[9] = atomicAdd(&lp.cnt[pool * 16 + 4], 1u);
+    }
+    group_barrier<WPL>();
+    const uint32_t cb = red[8], hb = red[9];
+    if (cb + H > lp.ccap || hb + 1 > lp.scap) {
+        if (t == 0) atomicOr(&lp.flags[0], 1u);
+        return 0;
+    }
+    const uint32_t c0 = pool * lp.ccap + cb;
+    if (my_total) {
+#pragma unroll
+        for (uint32_t c = 0; c < kPer; ++c) {
+            const uint32_t i = c * GS + t;
+            if (i < L) {
+                uint32_t w = c0 + my_cnt[c];
+                walk(i, [&](uint32_t j) {
+                    CandRec r;
+                    r.ij = (i << 16) | j; r.ref_i = e_ref[i]; r.ref_j = e_ref[j]; r.pf_i = e_pf[i];
+                    r.tvj = e_tv[j] | (e_pf[j] & kHypInv);
+                    r.a1 = e_d1[i]; r.a2 = e_d2[i]; r.b1 = e_d1[j]; r.b2 = e_d2[j]; r.sim = -1.0f;
+                    lp.cands[w++] = r;
+                });
+            }
+        }
+    }
+    if (t == 0) lp.chdrs[pool * lp.scap + hb] = CandHdr{g, c0, H, 0u};
+    return 0;
+}
+
+}  // namespace
+
+// ---- transposed index of the potential inverse hypotheses -------------------------------------------------------
+// grid = (slot blocks, pairs); one thread per slot; off64[g] high word = first record of segment g
+__global__ void k_inv_records(const PairDesc* __restrict__ pairs, uint32_t first_pair,
+                              const uint32_t* __restrict__ seg_base, const Slot* __restrict__ slots,
+                              const unsigned long long* __restrict__ off64, const uint32_t* __restrict__ inv_pos,
+                              InvRec* __restrict__ recs) {
+    const uint32_t pi = first_pair + blockIdx.y;
+    const PairDesc& pd = pairs[pi];
+    if (pd.tgt <= pd.src) return;
+    const uint64_t n = (uint64_t)pd.Ms * pd.K;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ipos = inv_pos[pd.slot_off + i];
+    if (ipos == kEmpty) return;
+    const Slot s = slots[pd.slot_off + i];
+    const uint32_t g = seg_base[pd.tgt] + s.tgt_seg;
+    InvRec r;
+    r.ref = (uint32_t)(pd.slot_off + i); r.pair = pi; r.src_view = pd.src; r.src_row = (uint32_t)(i / pd.K);
+    r.dq1 = s.dq1; r.dq2 = s.dq2;
+    recs[(uint32_t)(off64[g] >> 32) + ipos] = r;
+}
+
+template <int WPL>
+__global__ __launch_bounds__(256) void k_lists(uint32_t G, const ViewDev* __restrict__ views,
+                                               const PairDesc* __restrict__ pairs,
+                                               const uint32_t* __restrict__ seg_base,
+                                               const uint32_t* __restrict__ gseg_view,
+                                               const uint32_t* __restrict__ vout_off,
+                                               const uint32_t* __restrict__ vout_pairs,
+                                               const unsigned long long* __restrict__ off64,
+                                               const InvRec* __restrict__ inv, const Slot* __restrict__ slots,
+                                               uint32_t uniform_K, const ListPools lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef ListCfg<WPL> Cfg;
+    if (WPL == 1) {
+        const uint32_t wave = threadIdx.x >> 6;
+        const uint32_t g = blockIdx.x * 4 + wave;
+        if (g >= G) return;
+        const int rc = process_list<1>(g, (L3D_LDS char*)smem + wave * Cfg::BYTES, views, pairs, seg_base, gseg_view,
+                                       vout_off, vout_pairs, off64, inv, slots, uniform_K, lp);
+        if (rc && lane_id() == 0) {
+            const uint32_t L = (uint32_t)(off64[g + 1] - off64[g]);
+            if (L > 65535u) atomicOr(&lp.flags[1], 1u);
+            else if (L > ListCfg<4>::CAP) lp.listH[atomicAdd(&lp.flags[5], 1u)] = g;
+            else lp.list4[atomicAdd(&lp.flags[4], 1u)] = g;
+        }
+    } else {
+        const uint32_t n4 = lp.flags[4];
+        for (uint32_t idx = blockIdx.x; idx < n4; idx += gridDim.x) {
+            const uint32_t g = lp.list4[idx];
+            (void)process_list<WPL>(g, (L3D_LDS char*)smem, views, pairs, seg_base, gseg_view, vout_off, vout_pairs,
+                                    off64, inv, slots, uniform_K, lp);
+            __syncthreads();
+        }
+    }
+}
+
+// ---- lists beyond the LDS capacity: one workgroup per list, hypotheses staged in global scratch, every ordered pair
+// through the conservative window test (no sort), two passes (count, then write the candidate records) -------------
+struct HugeScratch {
+    float* d1; float* d2; uint32_t* tv; uint32_t* ref; uint32_t* pf; uint64_t* key;   // [cap] each
+    uint32_t cap;
+};
+__global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+                                                    const uint32_t* __restrict__ seg_base,
+                                                    const uint32_t* __restrict__ gseg_view,
+                                                    const uint32_t* __restrict__ vout_off,
+                                                    const uint32_t* __restrict__ vout_pairs,
+                                                    const unsigned long long* __restrict__ off64,
+                                                    const InvRec* __restrict__ inv, const Slot* __restrict__ slots,
+                                                    const ListPools lp, const HugeScratch hs) {
+    __shared__ uint32_t red[16];
+    __shared__ uint32_t s_base;
+    const uint32_t t = threadIdx.x;
+    const uint32_t nH = lp.flags[5];
+    for (uint32_t idx = blockIdx.x; idx < nH; idx += gridDim.x) {
+        const uint32_t g = lp.listH[idx];
+        const uint32_t L = (uint32_t)(off64[g + 1] - off64[g]);
+        __syncthreads();
+        if (t == 0) s_base = atomicAdd(&lp.flags[6], L);
+        __syncthreads();
+        const uint32_t base = s_base;
+        if ((uint64_t)base + L > hs.cap) { if (t == 0) atomicOr(&lp.flags[2], 1u); continue; }
+        float* e_d1 = hs.d1 + base; float* e_d2 = hs.d2 + base;
+        uint32_t* e_tv = hs.tv + base; uint32_t* e_ref = hs.ref + base; uint32_t* e_pf = hs.pf + base;
+        uint64_t* keys = hs.key + base;
+        const uint32_t vi = gseg_view[g], seg = g - seg_base[vi];
+        const ViewDev& v = views[vi];
+        const uint32_t ib = (uint32_t)(off64[g] >> 32), n_inv = (uint32_t)(off64[g + 1] >> 32) - ib;
+        for (uint32_t x = t; x < n_inv; x += 256) { const InvRec r = inv[ib + x]; keys[x] = ((uint64_t)r.src_view << 32) | r.src_row; }
+        __threadfence_block();
+        __syncthreads();
+        for (uint32_t x = t; x < n_inv; x += 256) {
+            const InvRec r = inv[ib + x];
+            const uint64_t key = ((uint64_t)r.src_view << 32) | r.src_row;
+            uint32_t rank = 0;
+            for (uint32_t y = 0; y < n_inv; ++y) rank += (keys[y] < key) ? 1u : 0u;
+            e_d1[rank] = r.dq1; e_d2[rank] = r.dq2; e_tv[rank] = r.src_view; e_ref[rank] = r.ref; e_pf[rank] = r.pair | kHypInv;
+        }
+        uint32_t pos = n_inv;
+        for (uint32_t q = vout_off[vi]; q < vout_off[vi + 1]; ++q) {
+            const uint32_t pi = vout_pairs[q];
+            const PairDesc& pd = pairs[pi];
+            const uint64_t row0 = pd.slot_off + (uint64_t)seg * pd.K;
+            for (uint32_t j0 = 0; j0 < pd.K; j0 += 256) {
+                bool alive = false;
+                Slot s;
+                if (j0 + t < pd.K) { s = slots[row0 + j0 + t]; alive = s.tgt_seg != kEmpty && (s.flags & kSlotAlive); }
+                uint32_t total;
+                const uint32_t at = pos + group_scan<4>(alive ? 1u : 0u, total, red);
+                if (alive && at < L) { e_d1[at] = s.dp1; e_d2[at] = s.dp2; e_tv[at] = pd.tgt; e_ref[at] = (uint32_t)(row0 + j0 + t); e_pf[at] = pi; }
+                pos += total;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (pos != L) { if (t == 0) atomicOr(&lp.flags[3], 1u); continue; }
+        auto for_candidates = [&](uint32_t i, auto&& emit) {
+            const float a1 = e_d1[i], a2 = e_d2[i];
+            const uint32_t tvi = e_tv[i];
+            const float kt = views[tvi].k, D = pairs[e_pf[i] & 0x7FFFFFFFu].cc_dist;
+            const float R1 = window_sq(a1, v.k, kt, D), R2 = window_sq(a2, v.k, kt, D);
+            for (uint32_t j = 0; j < L; ++j) {
+                if (j == i || e_tv[j] == tvi) continue;
+                const float d1 = a1 - e_d1[j], d2 = a2 - e_d2[j];
+                if ((d1 * d1 <= R1) && (d2 * d2 <= R2)) emit(j);
+            }
+        };
+        uint32_t mine = 0;
+        for (uint32_t i = t; i < L; i += 256) {
+            uint32_t c = 0;
+            for_candidates(i, [&](uint32_t) { ++c; });
+            keys[i] = c;
+            mine += c;
+        }
+        uint32_t H;
+        (void)group_scan<4>(mine, H, red);
+        __threadfence_block();
+        __syncthreads();
+        if (H == 0) continue;
+        const uint32_t pool = blockIdx.x % kListPools;
+        if (t == 0) {
+            red[8] = atomicAdd(&lp.cnt[pool * 16 + 3], H);
+            red[9] = atomicAdd(&lp.cnt[pool * 16 + 4], 1u);
+        }
+        __syncthreads();
+        const uint32_t cb = red[8], hb = red[9];
+        if (cb + H > lp.ccap || hb + 1 > lp.scap) { if (t == 0) atomicOr(&lp.flags[0], 1u); continue; }
+        const uint32_t c0 = pool * lp.ccap + cb;
+        for (uint32_t i = t; i < L; i += 256) {
+            if (!keys[i]) continue;
+            uint32_t w = c0;
+            for (uint32_t y = 0; y < i; ++y) w += (uint32_t)keys[y];
+            for_candidates(i, [&](uint32_t j) {
+                CandRec r;
+                r.ij = (i << 16) | j; r.ref_i = e_ref[i]; r.ref_j = e_ref[j]; r.pf_i = e_pf[i];
+                r.tvj = e_tv[j] | (e_pf[j] & kHypInv);
+                r.a1 = e_d1[i]; r.a2 = e_d2[i]; r.b1 = e_d1[j]; r.b2 = e_d2[j]; r.sim = -1.0f;
+                lp.cands[w++] = r;
+            });
+        }
+        if (t == 0) lp.chdrs[pool * lp.scap + hb] = CandHdr{g, c0, H, 0u};
+    }
+}
+
+// ---- candidates -> edges: one wave per segment with candidates.  The reference's decision and value for every
+// candidate (one per lane, full lanes: this is where the fp64 unprojections, acos and exp live), then the accepted
+// ones as EDGES in (i, j) order with one HEADER per hypothesis i that has any.  The candidates arrive grouped by i
+// in canonical order (one contiguous run per i, j in walk order), so the order only has to be fixed inside a run.
+__global__ __launch_bounds__(256) void k_edges(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+                                               const uint32_t* __restrict__ gseg_view, const SimConst sc,
+                                               const ListPools lp, uint32_t* __restrict__ seg_of_g) {
+    const uint32_t pool = blockIdx.y, wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t k = blockIdx.x * 4 + wave;
+    if (k >= min(lp.cnt[pool * 16 + 4], lp.scap)) return;
+    const CandHdr ch = lp.chdrs[pool * lp.scap + k];
+    const uint32_t g = ch.g, n = ch.cnt;
+    CandRec* cand = lp.cands + ch.begin;
+    const ViewDev& v = views[gseg_view[g]];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    auto sync_wave = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    };
+    // (ij, sim) of the list's candidates live in LDS for the order fixing below (lists beyond kEdgeLds entries walk
+    // global memory instead: correct, slow, rare)
+    constexpr uint32_t kEdgeLds = 512;
+    __shared__ uint32_t s_ij[4][kEdgeLds];
+    __shared__ float s_sim[4][kEdgeLds];
+    const bool in_lds = n <= kEdgeLds;
+    // pass 1: the exact test
+    uint32_t n_acc = 0;
+    for (uint32_t x0 = 0; x0 < n; x0 += 64) {
+        const uint32_t x = x0 + lane;
+        bool ok = false;
+        if (x < n) {
+            const CandRec r = cand[x];
+            const PairDesc& pd = pairs[r.pf_i & 0x7FFFFFFFu];
+            const uint32_t tvi = (r.pf_i & kHypInv) ? pd.src : pd.tgt;
+            float sim = -1.0f;
+            ok = exact_support(v, views, views[0].segx[g], r.a1, r.a2, tvi, r.b1, r.b2, sc, sim);
+            if (!ok) sim = -1.0f;
+            if (in_lds) { s_ij[wave][x] = r.ij; s_sim[wave][x] = sim; }
+            else if (ok) cand[x].sim = sim;
+        }
+        n_acc += (uint32_t)__popcll(__ballot(ok));
+    }
+    if (n_acc == 0) return;
+    if (in_lds) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        sync_wave();
+    }
+    auto ij_of = [&](uint32_t y) -> uint32_t { return in_lds ? s_ij[wave][y] : cand[y].ij; };
+    auto sim_of = [&](uint32_t y) -> float { return in_lds ? s_sim[wave][y] : cand[y].sim; };
+    // inside its run: rank of an accepted pair by j, accepted pairs before it (0: it writes the header), run total
+    auto in_run = [&](uint32_t x, uint32_t& rank, uint32_t& earlier, uint32_t& mine) {
+        const uint32_t ij = ij_of(x), i = ij >> 16;
+        rank = 0; earlier = 0; mine = 1;
+        for (uint32_t y = x; y-- > 0;) {
+            const uint32_t o = ij_of(y);
+            if ((o >> 16) != i) break;
+            if (sim_of(y) >= 0.0f) { ++earlier; ++mine; rank += o < ij ? 1u : 0u; }
+        }
+        for (uint32_t y = x + 1; y < n; ++y) {
+            const uint32_t o = ij_of(y);
+            if ((o >> 16) != i) break;
+            if (sim_of(y) >= 0.0f) { ++mine; rank += o < ij ? 1u : 0u; }
+        }
+    };
+    // pass 2: headers = runs with an accepted pair
+    uint32_t n_h = 0;
+    for (uint32_t x0 = 0; x0 < n; x0 += 64) {
+        const uint32_t x = x0 + lane;
+        bool first = false;
+        if (x < n && sim_of(x) >= 0.0f) {
+            const uint32_t i = ij_of(x) >> 16;
+            first = true;
+            for (uint32_t y = x; y-- > 0;) {
+                if ((ij_of(y) >> 16) != i) break;
+                if (sim_of(y) >= 0.0f) { first = false; break; }
+            }
+        }
+        n_h += (uint32_t)__popcll(__ballot(first));
+    }
+    const uint32_t opool = blockIdx.x % kListPools;           // spread the reservations independently of the input pool
+    uint32_t eb = 0, hb = 0, sb = 0;
+    if (lane == 0) {
+        eb = atomicAdd(&lp.cnt[opool * 16 + 0], n_acc);
+        hb = atomicAdd(&lp.cnt[opool * 16 + 1], n_h);
+        sb = atomicAdd(&lp.cnt[opool * 16 + 2], 1u);
+    }
+    eb = __shfl(eb, 0); hb = __shfl(hb, 0); sb = __shfl(sb, 0);
+    if (eb + n_acc > lp.ecap || hb + n_h > lp.hcap || sb + 1 > lp.scap) {
+        if (lane == 0) atomicOr(&lp.flags[0], 1u);
+        return;
+    }
+    const uint32_t e0 = opool * lp.ecap + eb, h0 = opool * lp.hcap + hb;
+    // pass 3: write.  accepted pairs before mine - earlier ones of my run = first edge of my run
+    uint32_t acc_before = 0, first_before = 0;
+    for (uint32_t x0 = 0; x0 < n; x0 += 64) {
+        const uint32_t x = x0 + lane;
+        bool acc = false, first = false;
+        uint32_t rank = 0, earlier = 0, mine = 0;
+        float sim = -1.0f;
+        if (x < n) {
+            sim = sim_of(x);
+            acc = sim >= 0.0f;
+            if (acc) { in_run(x, rank, earlier, mine); first = earlier == 0; }
+        }
+        const uint64_t ma = __ballot(acc), mf = __ballot(first);
+        if (acc) {
+            const CandRec r = cand[x];
+            const uint32_t run0 = acc_before + (uint32_t)__popcll(ma & lt_mask) - earlier;
+            EdgeRec e;
+            e.ref_j = r.ref_j; e.sim = sim;
+            e.j_cam = (r.ij & 0xFFFFu) | ((r.tvj & kHypInv) ? kEdgeInv : 0u);
+            e.tv_j = r.tvj & 0x7FFFFFFFu;
+            lp.edges[e0 + run0 + rank] = e;
+            if (first) {
+                HypHdr hdr;
+                hdr.g = g; hdr.ref = r.ref_i; hdr.pair_flags = r.pf_i; hdr.canon = r.ij >> 16;
+                hdr.dp1 = r.a1; hdr.dp2 = r.a2;
+                hdr.edge_begin = e0 + run0; hdr.edge_cnt = mine; hdr.score3D = 0.0f; hdr.state = 0;
+                hdr.pad[0] = hdr.pad[1] = 0;
+                lp.hyps[h0 + first_before + (uint32_t)__popcll(mf & lt_mask)] = hdr;
+            }
+        }
+        acc_before += (uint32_t)__popcll(ma); first_before += (uint32_t)__popcll(mf);
+    }
+    if (lane == 0) {
+        const uint32_t si = opool * lp.scap + sb;
+        lp.segs[si] = SegHdr{g, h0, n_h, 0u};
+        seg_of_g[g] = si;
+    }
+}
+
+// ---- the chain as a monotone fixed point ------------------------------------------------------------------------
+// grid (header blocks, pools).  Sweep s runs only if sweep s-1 changed something (changed[] is zeroed by the host).
+__global__ void k_chain_sweep(const ListPools lp, uint8_t* __restrict__ positive, uint32_t* __restrict__ changed,
+                              uint32_t sweep) {
+    if (sweep && !changed[sweep - 1]) return;
+    const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= min(lp.cnt[pool * 16 + 1], lp.hcap)) return;
+    const HypHdr& h = lp.hyps[pool * lp.hcap + k];
+    if ((h.pair_flags & kHypInv) || positive[h.ref]) return;   // an inverse hypothesis exists iff its SOURCE is positive
+    for (uint32_t e = 0; e < h.edge_cnt; ++e) {
+        const EdgeRec& ed = lp.edges[h.edge_begin + e];
+        if (!(ed.j_cam & kEdgeInv) || positive[ed.ref_j]) {   // a fresh supporter always exists (line3D.cc:1680)
+            positive[h.ref] = 1;
+            changed[sweep] = 1;
+            return;
+        }
+    }
+}
+
+// score3D of every header: the existing supporters in canonical order with the reference's per-camera
+// replace/subtract accumulation (line3D.cc:1255-1274); the view's maximum for filterMatches
+__global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ positive,
+                             const uint32_t* __restrict__ gseg_view, Slot* __restrict__ slots,
+                             uint32_t* __restrict__ max_score_bits) {
+    const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= min(lp.cnt[pool * 16 + 1], lp.hcap)) return;
+    HypHdr& h = lp.hyps[pool * lp.hcap + k];
+    const bool inv = (h.pair_flags & kHypInv) != 0;
+    const bool exists = !inv || positive[h.ref] != 0;
+    float score3D = 0.0f, cur = 0.0f;
+    uint32_t cur_cam = kEmpty;
+    if (exists)
+        for (uint32_t e = 0; e < h.edge_cnt; ++e) {
+            const EdgeRec ed = lp.edges[h.edge_begin + e];
+            if ((ed.j_cam & kEdgeInv) && !positive[ed.ref_j]) continue;
+            if (ed.tv_j == cur_cam) {
+                if (ed.sim > cur) { score3D -= cur; score3D += ed.sim; cur = ed.sim; }
+            } else {
+                score3D += ed.sim; cur = ed.sim; cur_cam = ed.tv_j;
+            }
+        }
+    h.score3D = score3D;
+    h.state = exists ? kHypExists : 0u;
+    if (exists) {
+        if (!inv) slots[h.ref].score3D = score3D;
+        // (most threads see a maximum that already exceeds theirs: the plain read skips the contended atomic)
+        if (score3D > 0.0f) {
+            uint32_t* mx = &max_score_bits[gseg_view[h.g]];
+            if (__float_as_uint(score3D) > *(volatile uint32_t*)mx) atomicMax(mx, __float_as_uint(score3D));
+        }
+    }
+}
+
+// filterMatches, line3D.cc:1602-1653, per header: kept iff score3D > 0 and > 10 % of the view's best; the segment's
+// best = first strict maximum among the kept ones = largest (score, -canonical index)
+__global__ void k_hyp_filter(const ListPools lp, const uint32_t* __restrict__ gseg_view,
+                             const uint32_t* __restrict__ max_score_bits, uint32_t* __restrict__ kept_cnt,
+                             unsigned long long* __restrict__ best_pack) {
+    const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= min(lp.cnt[pool * 16 + 1], lp.hcap)) return;
+    HypHdr& h = lp.hyps[pool * lp.hcap + k];
+    const float lim = kMinBestScorePerc * __uint_as_float(max_score_bits[gseg_view[h.g]]);
+    const float s = h.score3D;
+    if ((h.state & kHypExists) && s > 0.0f && s > lim) {
+        h.state |= kHypKeep;
+        atomicAdd(&kept_cnt[h.g], 1u);
+        atomicMax(&best_pack[h.g], ((unsigned long long)__float_as_uint(s) << 32) | (0xFFFFFFFFu - h.canon));
+    }
+}
+
+// per segment: the 0.75 gate; cnt64[g] = surviving matches (low word) | has a best hypothesis (high word)
+__global__ void k_seg_filter(uint32_t G, const uint32_t* __restrict__ kept_cnt,
+                             const unsigned long long* __restrict__ best_pack, unsigned long long* __restrict__ cnt64) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const bool ok = __uint_as_float((uint32_t)(best_pack[g] >> 32)) > kMinBestScore3D;
+    cnt64[g] = ok ? ((1ull << 32) | kept_cnt[g]) : 0ull;
+}
+
+__device__ __forceinline__ void make_match(const ViewDev* views, const PairDesc* pairs, uint32_t view, uint32_t seg,
+                                           const HypHdr& h, const Slot& s, Match& m, uint32_t& tgt_view,
+                                           uint32_t& tgt_seg) {
+    // a fresh hypothesis reads its slot as is; an inverse one swaps the roles (line3D.cc:1682-1692)
+    const bool inv = (h.pair_flags & kHypInv) != 0;
+    const PairDesc& pd = pairs[h.pair_flags & 0x7FFFFFFFu];
+    tgt_view = inv ? pd.src : pd.tgt;
+    tgt_seg = inv ? (uint32_t)((h.ref - pd.slot_off) / pd.K) : s.tgt_seg;
+    m.src_cam = views[view].cam; m.src_seg = seg;
+    m.tgt_cam = views[tgt_view].cam; m.tgt_seg = tgt_seg;
+    m.overlap = s.overlap; m.score3D = h.score3D;
+    m.dp1 = h.dp1; m.dp2 = h.dp2;
+    m.dq1 = inv ? s.dp1 : s.dq1; m.dq2 = inv ? s.dp2 : s.dq2;
+}
+
+// offsets of all segments + the outputs of the segments that keep a best hypothesis: surviving matches (reference
+// Match layout, canonical order), the estimated_position3D_ entry, the two depths for the view's median
+__global__ void k_seg_write(uint32_t G, const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+                            const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ gseg_view,
+                            const unsigned long long* __restrict__ off64s, const unsigned long long* __restrict__ best_pack,
+                            const uint32_t* __restrict__ seg_of_g, const ListPools lp, const Slot* __restrict__ slots,
+                            uint32_t* __restrict__ surv_off, uint32_t* __restrict__ hyp_off, Match* __restrict__ surv,
+                            uint32_t* __restrict__ surv_tg, uint32_t* __restrict__ surv_sg,
+                            int32_t* __restrict__ hyp_of_seg, HypRec* __restrict__ hyps, float* __restrict__ depths) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > G) return;
+    const unsigned long long o = off64s[g];
+    surv_off[g] = (uint32_t)o; hyp_off[g] = (uint32_t)(o >> 32);
+    if (g == G) return;
+    const bool ok = (off64s[g + 1] >> 32) != (o >> 32);
+    if (!ok) { hyp_of_seg[g] = -1; return; }
+    const uint32_t view = gseg_view[g], seg = g - seg_base[view];
+    const ViewDev& v = views[view];
+    const SegHdr sh = lp.segs[seg_of_g[g]];
+    const uint32_t best_canon = 0xFFFFFFFFu - (uint32_t)best_pack[g];
+    uint32_t w = (uint32_t)o;
+    const uint32_t hx = (uint32_t)(o >> 32);
+    for (uint32_t k = 0; k < sh.hyp_cnt; ++k) {
+        const HypHdr& h = lp.hyps[sh.hyp_begin + k];
+        if (!(h.state & kHypKeep)) continue;
+        const Slot s = slots[h.ref];
+        Match m; uint32_t tv, tseg;
+        make_match(views, pairs, view, seg, h, s, m, tv, tseg);
+        surv_tg[w] = seg_base[tv] + tseg;
+        surv_sg[w] = g;
+        surv[w++] = m;
+        if (h.canon == best_canon) {
+            HypRec r;
+            const SegX& sx = v.segx[seg];
+            const Seg3 s3 = unproject(v.C, sx.r1, sx.r2, h.dp1, h.dp2);   // unprojectMatch(best,true), :1638
+            r.P1[0] = s3.P1.x; r.P1[1] = s3.P1.y; r.P1[2] = s3.P1.z;
+            r.P2[0] = s3.P2.x; r.P2[1] = s3.P2.y; r.P2[2] = s3.P2.z;
+            r.dir[0] = s3.dir.x; r.dir[1] = s3.dir.y; r.dir[2] = s3.dir.z;
+            r.length = s3.length;
+            r.valid = s3.length > 0.0f ? 1u : 0u;
+            r.m = m;
+            r.view = view; r.pad = 0;
+            hyps[hx] = r;
+            depths[2 * hx] = h.dp1;
+            depths[2 * hx + 1] = h.dp2;
+        }
+    }
+    hyp_of_seg[g] = (int32_t)hx;
+}
+
+// ---- 64-bit exclusive scan (two 32-bit counters per word are summed at once: low and high words never carry into
+// each other for totals below 2^32) ---------------------------------------------------------------------------------
+namespace {
+constexpr uint32_t kS64Block = 1024, kS64Items = 4, kS64Tile = kS64Block * kS64Items;
+__device__ __forceinline__ unsigned long long block_scan64(unsigned long long v, unsigned long long* wsum /*[17]*/,
+                                                           unsigned long long& block_total) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned long long x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long acc = 0;
+        for (uint32_t w = 0; w < kS64Block / 64; ++w) { const unsigned long long t = wsum[w]; wsum[w] = acc; acc += t; }
+        wsum[16] = acc;
+    }
+    __syncthreads();
+    block_total = wsum[16];
+    const unsigned long long r = wsum[wave] + x - v;
+    __syncthreads();
+    return r;
+}
+}  // namespace
+
+__global__ __launch_bounds__(kS64Block) void k_scan64_sums(const unsigned long long* __restrict__ in, uint32_t n,
+                                                           unsigned long long* __restrict__ sums) {
+    __shared__ unsigned long long wsum[17];
+    const uint32_t base = blockIdx.x * kS64Tile + threadIdx.x * kS64Items;
+    unsigned long long v = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kS64Items; ++k) v += (base + k < n) ? in[base + k] : 0ull;
+    unsigned long long total;
+    (void)block_scan64(v, wsum, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kS64Block) void k_scan64_top(unsigned long long* __restrict__ sums, uint32_t nb,
+                                                          unsigned long long* __restrict__ total_out) {
+    __shared__ unsigned long long wsum[17];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nb; b0 += kS64Block) {
+        const uint32_t i = b0 + threadIdx.x;
+        const unsigned long long v = i < nb ? sums[i] : 0ull;
+        unsigned long long total;
+        const unsigned long long ex = block_scan64(v, wsum, total);
+        const unsigned long long c = carry;
+        if (i < nb) sums[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+__global__ __launch_bounds__(kS64Block) void k_scan64_down(const unsigned long long* __restrict__ in, uint32_t n,
+                                                           const unsigned long long* __restrict__ sums,
+                                                           unsigned long long* __restrict__ out,
+                                                           const unsigned long long* total) {
+    __shared__ unsigned long long wsum[17];
+    const uint32_t base = blockIdx.x * kS64Tile + threadIdx.x * kS64Items;
+    unsigned long long a[kS64Items];
+    unsigned long long v = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kS64Items; ++k) { a[k] = (base + k < n) ? in[base + k] : 0ull; v += a[k]; }
+    unsigned long long tot;
+    unsigned long long ex = block_scan64(v, wsum, tot) + sums[blockIdx.x];
+#pragma unroll
+    for (uint32_t k = 0; k < kS64Items; ++k) {
+        if (base + k < n) out[base + k] = ex;
+        ex += a[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+}
+
+// out[0..n] = exclusive scan of in[0..n) (out[n] = total, also stored to *total).  tmp: >= n/4096 + 2 words.
+// in and out may be the same array.
+hipError_t launch_scan64(const unsigned long long* in, uint32_t n, unsigned long long* out, unsigned long long* tmp,
+                         unsigned long long* total, hipStream_t st) {
+    const uint32_t nb = (n + kS64Tile - 1) / kS64Tile;
+    if (nb == 0) {
+        hipLaunchKernelGGL(k_scan64_top, dim3(1), dim3(kS64Block), 0, st, tmp, 0u, total);
+        hipLaunchKernelGGL(k_scan64_down, dim3(1), dim3(kS64Block), 0, st, in, 0u, tmp, out, total);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_scan64_sums, dim3(nb), dim3(kS64Block), 0, st, in, n, tmp);
+    hipLaunchKernelGGL(k_scan64_top, dim3(1), dim3(kS64Block), 0, st, tmp, nb, total);
+    hipLaunchKernelGGL(k_scan64_down, dim3(nb), dim3(kS64Block), 0, st, in, n, tmp, out, total);
+    return hipGetLastError();
+}
+
+// ---- launchers --------------------------------------------------------------------------------------------------
+hipError_t launch_inv_records(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
+                              const Slot* slots, const unsigned long long* off64, const uint32_t* inv_pos, InvRec* recs,
+                              hipStream_t st) {
+    if (!n_pairs || !max_slots) return hipSuccess;
+    for (uint32_t p0 = 0; p0 < n_pairs; p0 += 65535u) {
+        const uint32_t n = n_pairs - p0 < 65535u ? n_pairs - p0 : 65535u;
+        hipLaunchKernelGGL(k_inv_records, dim3((uint32_t)((max_slots + 255) / 256), n), dim3(256), 0, st, pairs, p0,
+                           seg_base, slots, off64, inv_pos, recs);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_lists(uint32_t G, const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base,
+                        const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
+                        const unsigned long long* off64, const InvRec* inv, const Slot* slots, uint32_t uniform_K,
+                        SimConst sc, ListPools lp, uint32_t* seg_of_g, HugeScratchArgs hsa, hipStream_t st) {
+    if (!G) return hipSuccess;
+    const size_t lds1 = 4 * (size_t)ListCfg<1>::BYTES, lds4 = ListCfg<4>::BYTES;
+    hipError_t e = hipFuncSetAttribute((const void*)k_lists<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_lists<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_lists<1>), dim3((G + 3) / 4), dim3(256), lds1, st, G, views, pairs, seg_base, gseg_view, vout_off,
+                       vout_pairs, off64, inv, slots, uniform_K, lp);
+    hipLaunchKernelGGL((k_lists<4>), dim3(2048), dim3(256), lds4, st, G, views, pairs, seg_base, gseg_view, vout_off,
+                       vout_pairs, off64, inv, slots, uniform_K, lp);
+    HugeScratch hs;
+    hs.d1 = hsa.f32; hs.d2 = hsa.f32 + hsa.cap;
+    hs.tv = hsa.u32; hs.ref = hsa.u32 + hsa.cap; hs.pf = hsa.u32 + 2 * (size_t)hsa.cap;
+    hs.key = hsa.u64; hs.cap = hsa.cap;
+    hipLaunchKernelGGL(k_lists_huge, dim3(256), dim3(256), 0, st, views, pairs, seg_base, gseg_view, vout_off, vout_pairs,
+                       off64, inv, slots, lp, hs);
+    hipLaunchKernelGGL(k_edges, dim3((lp.scap + 3) / 4, kListPools), dim3(256), 0, st, views, pairs, gseg_view, sc, lp,
+                       seg_of_g);
+    return hipGetLastError();
+}
+
+static dim3 hyp_grid(const ListPools& lp) { return dim3((lp.hcap + 255) / 256, kListPools); }
+
+hipError_t launch_chain_sweep(ListPools lp, uint8_t* positive, uint32_t* changed, uint32_t sweep, hipStream_t st) {
+    hipLaunchKernelGGL(k_chain_sweep, hyp_grid(lp), dim3(256), 0, st, lp, positive, changed, sweep);
+    return hipGetLastError();
+}
+hipError_t launch_hyp_scores(ListPools lp, const uint8_t* positive, const uint32_t* gseg_view, Slot* slots,
+                             uint32_t* max_score_bits, hipStream_t st) {
+    hipLaunchKernelGGL(k_hyp_scores, hyp_grid(lp), dim3(256), 0, st, lp, positive, gseg_view, slots, max_score_bits);
+    return hipGetLastError();
+}
+hipError_t launch_hyp_filter(ListPools lp, uint32_t G, const uint32_t* gseg_view, const uint32_t* max_score_bits,
+                             uint32_t* kept_cnt, unsigned long long* best_pack, unsigned long long* cnt64,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(k_hyp_filter, hyp_grid(lp), dim3(256), 0, st, lp, gseg_view, max_score_bits, kept_cnt, best_pack);
+    if (G) hipLaunchKernelGGL(k_seg_filter, dim3((G + 255) / 256), dim3(256), 0, st, G, kept_cnt, best_pack, cnt64);
+    return hipGetLastError();
+}
+hipError_t launch_seg_write(uint32_t G, const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base,
+                            const uint32_t* gseg_view, const unsigned long long* off64s,
+                            const unsigned long long* best_pack, const uint32_t* seg_of_g, ListPools lp,
+                            const Slot* slots, uint32_t* surv_off, uint32_t* hyp_off, Match* surv, uint32_t* surv_tg,
+                            uint32_t* surv_sg, int32_t* hyp_of_seg, HypRec* hyps, float* depths, hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_write, dim3((G + 1 + 127) / 128), dim3(128), 0, st, G, views, pairs, seg_base, gseg_view,
+                       off64s, best_pack, seg_of_g, lp, slots, surv_off, hyp_off, surv, surv_tg, surv_sg, hyp_of_seg,
+                       hyps, depths);
+    return hipGetLastError();
+}
+
+}  // namespace l3d

@@ -42,6 +42,18 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
 }  // namespace
 
+// diagnostics build only (-DL3D_STATS): 0 lists scored, 1 hypotheses, 2 present hypotheses, 3 present (hypothesis,
+// supporter) pairs, 4 hypotheses with at least one present supporter, 5 longest pair sequence of a list, 6 set bits of
+// all support rows
+#ifdef L3D_STATS
+__device__ unsigned long long g_bstats[8];
+#define L3D_BSTAT(i, n) atomicAdd(&g_bstats[i], (unsigned long long)(n))
+#define L3D_BSTAT_MAX(i, n) atomicMax(&g_bstats[i], (unsigned long long)(n))
+#else
+#define L3D_BSTAT(i, n) ((void)0)
+#define L3D_BSTAT_MAX(i, n) ((void)0)
+#endif
+
 // ---- pre-pass ---------------------------------------------------------------------------------------
 // grid = (slot blocks, pairs).  One thread per slot: orientation flags + list lengths.
 //   cnt_pack[g] low word:  hypotheses of global segment g (fresh alive + potential inverse) -> CSR of the lists
@@ -662,10 +674,16 @@ __global__ __launch_bounds__(256) void k_presence_view(uint32_t g0, uint32_t M, 
     }
 }
 
-constexpr uint32_t kScoreCap = 192;   // per-wave LDS staging of a list: 36 B per hypothesis (27 KiB per workgroup)
+constexpr uint32_t kScoreCap = 192;   // per-wave LDS staging of a list: 50 B per hypothesis
 // scores of all views (batched): for every existing hypothesis i walk the existing supporters (S_i & P) in
 // canonical order with the reference's per-camera replace/subtract accumulation (line3D.cc:1255-1274); a zero
 // similarity never changes that accumulation, so visiting only the supporters gives the same float result.
+//
+// The similarity VALUES (fp64 acos + exp) are the expensive part and the supporters are spread very unevenly over the
+// hypotheses of a list (the few hypotheses of a true 3D line support each other, clutter has none).  So a staged list
+// is processed as a flat sequence of (hypothesis, supporter) pairs, 64 per round with one pair per lane (full lanes
+// instead of "every lane walks its own supporters and the wave waits for the longest walk"); the per-camera
+// accumulation, which is sequential per hypothesis by definition, then only adds up the values of the round.
 __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* __restrict__ off,
                                                    const uint32_t* __restrict__ boff,
                                                    const uint32_t* __restrict__ gseg_view,
@@ -685,63 +703,162 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
     const uint32_t vi = gseg_view[g];
     const ViewDev& v = views[vi];
     const SegX sx = views[0].segx[g];   // global array (upload_views): views[0].segx is its base
-    // the supporters' depths, cameras and unprojected 3D directions are read from LDS: one coalesced pass over the
-    // list and ONE unprojection (fp64 sqrt + 3 divisions) per hypothesis, instead of one dependent global load and
-    // one unprojection per (hypothesis, supporter) pair
     __shared__ float s_d1[4][kScoreCap], s_d2[4][kScoreCap];
     __shared__ uint32_t s_tv[4][kScoreCap];
     __shared__ double s_dir[4][kScoreCap][3];
+    __shared__ uint16_t s_start[4][kScoreCap + 2];              // first pair of every hypothesis (exclusive scan)
+    __shared__ float s_acc[4][kScoreCap], s_cur[4][kScoreCap];  // running score / current camera's best (:1255-1274)
+    __shared__ uint32_t s_cam[4][kScoreCap];
+    __shared__ float r_sim[4][64];                              // the round's similarities and supporter cameras
+    __shared__ uint32_t r_tv[4][64];
     const bool staged = L <= kScoreCap;
-    if (staged) {
-        for (uint32_t m0 = 0; m0 < L; m0 += 64)
-            if (m0 + lane < L) {
-                const DEntry& e = dents[b + m0 + lane];
-                s_d1[wave][m0 + lane] = e.dp1; s_d2[wave][m0 + lane] = e.dp2; s_tv[wave][m0 + lane] = e.tgt_view;
-                const d3 dir = entry_dir(v.C, sx, e.dp1, e.dp2);
-                s_dir[wave][m0 + lane][0] = dir.x; s_dir[wave][m0 + lane][1] = dir.y; s_dir[wave][m0 + lane][2] = dir.z;
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
     float vmax = 0.0f;
-    for (uint32_t m0 = 0; m0 < L; m0 += 64) {
-        const uint32_t i = m0 + lane;
-        if (i < L) {
-            const bool present = (P[i >> 6] >> (i & 63)) & 1ull;
-            DEntry a = dents[b + i];
-            const d3 ad = staged ? d3{s_dir[wave][i][0], s_dir[wave][i][1], s_dir[wave][i][2]}
-                                 : entry_dir(v.C, sx, a.dp1, a.dp2);
-            float score3D = 0.0f, cur = 0.0f;
-            uint32_t cur_cam = kEmpty;
-            if (present) {
+    if (staged) {
+        // ---- stage: depths, cameras, ONE unprojection (fp64 sqrt + 3 divisions) per hypothesis; pair counts ----
+        for (uint32_t m0 = 0; m0 < L; m0 += 64) {
+            const uint32_t i = m0 + lane;
+            uint32_t cnt = 0;
+            if (i < L) {
+                const DEntry& e = dents[b + i];
+                s_d1[wave][i] = e.dp1; s_d2[wave][i] = e.dp2; s_tv[wave][i] = e.tgt_view;
+                const d3 dir = entry_dir(v.C, sx, e.dp1, e.dp2);
+                s_dir[wave][i][0] = dir.x; s_dir[wave][i][1] = dir.y; s_dir[wave][i][2] = dir.z;
+                s_acc[wave][i] = 0.0f; s_cur[wave][i] = 0.0f; s_cam[wave][i] = kEmpty;
+                if ((P[i >> 6] >> (i & 63)) & 1ull)
+                    for (uint32_t w = 0; w < W; ++w) cnt += (uint32_t)__popcll(rows[(size_t)i * W + w] & P[w]);
+            }
+            // exclusive scan of the counts over the list (wave scan per 64 + carry)
+            uint32_t x = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= (uint32_t)d) x += y; }
+            const uint32_t carry = m0 ? (uint32_t)s_start[wave][m0] : 0u;
+            if (i < L) s_start[wave][i + 1] = (uint16_t)(carry + x);      // <= 192 * 191 < 65536
+            if (m0 == 0 && lane == 0) s_start[wave][0] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        const uint32_t T = s_start[wave][L];
+#ifdef L3D_STATS
+        if (lane == 0) { L3D_BSTAT(0, 1); L3D_BSTAT(1, L); L3D_BSTAT(3, T); L3D_BSTAT_MAX(5, T); }
+        for (uint32_t i = lane; i < L; i += 64) {
+            const bool pr = (P[i >> 6] >> (i & 63)) & 1ull;
+            uint32_t all = 0;
+            for (uint32_t w = 0; w < W; ++w) all += (uint32_t)__popcll(rows[(size_t)i * W + w]);
+            L3D_BSTAT(6, all);
+            if (pr) { L3D_BSTAT(2, 1); if (s_start[wave][i + 1] > s_start[wave][i]) L3D_BSTAT(4, 1); }
+        }
+#endif
+        // ---- rounds of 64 (hypothesis, supporter) pairs in canonical order ----
+        for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            uint32_t i = 0;
+            if (t < T) {
+                uint32_t lo = 0, hi = L;                       // last i with start[i] <= t
+                while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (s_start[wave][m] <= t) lo = m; else hi = m; }
+                i = lo;
+                uint32_t k = t - s_start[wave][i];             // the k-th supporter of i
+                uint32_t j = 0;
                 for (uint32_t w = 0; w < W; ++w) {
                     uint64_t m = rows[(size_t)i * W + w] & P[w];
-                    while (m) {
-                        const uint32_t j = w * 64 + (uint32_t)__ffsll((long long)m) - 1u;
-                        m &= m - 1;
-                        float odp1, odp2; uint32_t otv; d3 od;
-                        if (staged) {
-                            odp1 = s_d1[wave][j]; odp2 = s_d2[wave][j]; otv = s_tv[wave][j];
-                            od = d3{s_dir[wave][j][0], s_dir[wave][j][1], s_dir[wave][j][2]};
-                        } else {
-                            const DEntry& o = dents[b + j]; odp1 = o.dp1; odp2 = o.dp2; otv = o.tgt_view;
-                            od = entry_dir(v.C, sx, odp1, odp2);
+                    const uint32_t c = (uint32_t)__popcll(m);
+                    if (k < c) {
+                        // k-th set bit of m: binary search on the popcount of the low part
+                        uint32_t pos = 0;
+#pragma unroll
+                        for (int sh = 32; sh > 0; sh >>= 1) {
+                            const uint32_t cl = (uint32_t)__popcll(m & ((1ull << sh) - 1ull));
+                            if (k >= cl) { k -= cl; m >>= sh; pos += sh; }
                         }
-                        const float sim = sim_value(ad, a.dp1, a.dp2, a.reg1, a.reg2, od, odp1, odp2, sc);
+                        j = w * 64 + pos;
+                        break;
+                    }
+                    k -= c;
+                }
+                const DEntry& a = dents[b + i];
+                const d3 ad{s_dir[wave][i][0], s_dir[wave][i][1], s_dir[wave][i][2]};
+                const d3 od{s_dir[wave][j][0], s_dir[wave][j][1], s_dir[wave][j][2]};
+                r_sim[wave][lane] = sim_value(ad, s_d1[wave][i], s_d2[wave][i], a.reg1, a.reg2, od, s_d1[wave][j],
+                                              s_d2[wave][j], sc);
+                r_tv[wave][lane] = s_tv[wave][j];
+            }
+            const uint32_t i_prev = __shfl_up(i, 1);
+            const bool head = t < T && (lane == 0 || i != i_prev);   // first pair of a hypothesis within this round
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // the pairs of one hypothesis are consecutive lanes: its first lane adds them up, in order
+            {
+                const uint32_t e = i;
+                if (head) {
+                    const uint32_t p0 = lane;
+                    const uint32_t p1 = min((uint32_t)s_start[wave][e + 1], t0 + 64) - t0;
+                    float score3D = s_acc[wave][e], cur = s_cur[wave][e];
+                    uint32_t cur_cam = s_cam[wave][e];
+                    for (uint32_t p = p0; p < p1; ++p) {
+                        const float sim = r_sim[wave][p];
+                        const uint32_t otv = r_tv[wave][p];
                         if (otv == cur_cam) {
                             if (sim > cur) { score3D -= cur; score3D += sim; cur = sim; }
                         } else {
                             score3D += sim; cur = sim; cur_cam = otv;
                         }
                     }
+                    s_acc[wave][e] = score3D; s_cur[wave][e] = cur; s_cam[wave][e] = cur_cam;
                 }
             }
-            dents[b + i].score3D = score3D;
-            dents[b + i].flags = present ? (a.flags | kDPresent) : (a.flags & ~kDPresent);
-            if (present) {
-                if (!(a.flags & kDInverse)) slots[a.ref].score3D = score3D;
-                vmax = fmaxf(vmax, score3D);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        for (uint32_t m0 = 0; m0 < L; m0 += 64) {
+            const uint32_t i = m0 + lane;
+            if (i < L) {
+                const bool present = (P[i >> 6] >> (i & 63)) & 1ull;
+                const float score3D = present ? s_acc[wave][i] : 0.0f;
+                const uint32_t fl = dents[b + i].flags;
+                dents[b + i].score3D = score3D;
+                dents[b + i].flags = present ? (fl | kDPresent) : (fl & ~kDPresent);
+                if (present) {
+                    if (!(fl & kDInverse)) slots[dents[b + i].ref].score3D = score3D;
+                    vmax = fmaxf(vmax, score3D);
+                }
+            }
+        }
+    } else {
+        // lists beyond the staging capacity: every lane walks the supporters of its own hypotheses
+        for (uint32_t m0 = 0; m0 < L; m0 += 64) {
+            const uint32_t i = m0 + lane;
+            if (i < L) {
+                const bool present = (P[i >> 6] >> (i & 63)) & 1ull;
+                DEntry a = dents[b + i];
+                const d3 ad = entry_dir(v.C, sx, a.dp1, a.dp2);
+                float score3D = 0.0f, cur = 0.0f;
+                uint32_t cur_cam = kEmpty;
+                if (present) {
+                    for (uint32_t w = 0; w < W; ++w) {
+                        uint64_t m = rows[(size_t)i * W + w] & P[w];
+                        while (m) {
+                            const uint32_t j = w * 64 + (uint32_t)__ffsll((long long)m) - 1u;
+                            m &= m - 1;
+                            const DEntry& o = dents[b + j];
+                            const float odp1 = o.dp1, odp2 = o.dp2; const uint32_t otv = o.tgt_view;
+                            const d3 od = entry_dir(v.C, sx, odp1, odp2);
+                            const float sim = sim_value(ad, a.dp1, a.dp2, a.reg1, a.reg2, od, odp1, odp2, sc);
+                            if (otv == cur_cam) {
+                                if (sim > cur) { score3D -= cur; score3D += sim; cur = sim; }
+                            } else {
+                                score3D += sim; cur = sim; cur_cam = otv;
+                            }
+                        }
+                    }
+                }
+                dents[b + i].score3D = score3D;
+                dents[b + i].flags = present ? (a.flags | kDPresent) : (a.flags & ~kDPresent);
+                if (present) {
+                    if (!(a.flags & kDInverse)) slots[a.ref].score3D = score3D;
+                    vmax = fmaxf(vmax, score3D);
+                }
             }
         }
     }
@@ -1165,3 +1282,10 @@ hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hy
 }
 
 }  // namespace l3d
+
+#ifdef L3D_STATS
+extern "C" void l3d_debug_bstats(unsigned long long* out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(l3d::g_bstats), sizeof(l3d::g_bstats));
+    if (reset) { unsigned long long z[8] = {}; hipMemcpyToSymbol(HIP_SYMBOL(l3d::g_bstats), z, sizeof(z)); }
+}
+#endif

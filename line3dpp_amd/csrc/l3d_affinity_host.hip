@@ -134,6 +134,8 @@ int affinity_core(l3d_ctx* c) {
     std::vector<ViewAff> va(V);
     for (uint32_t vi = 0; vi < V; ++vi) { va[vi].k = c->order[vi]->k; va[vi].pad = 0; }
     const uint32_t N = c->n_surv, H = c->n_hyps;
+    L3D_HIP_CHECK(c->d_scal.reserve(16));
+    L3D_HIP_CHECK(c->d_scan_tmp.reserve(((size_t)c->G + 2 * (size_t)N) / 4096 + 1024));
     L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
     if (N > 0 && H > 0) {
         L3D_HIP_CHECK(c->d_vaff.reserve(V)); L3D_HIP_CHECK(c->d_msdl.reserve(1));

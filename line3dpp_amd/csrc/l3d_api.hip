@@ -252,7 +252,11 @@ void l3d_destroy(l3d_ctx* c) {
     }
     c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release(); c->d_slot_idx.release();
     c->h_views.release(); c->h_pairs.release(); c->h_cull.release(); c->h_work.release(); c->h_vout.release();
-    c->h_small.release(); c->h_cnt.release(); c->h_med.release();
+    c->h_small.release(); c->h_cnt.release(); c->h_med.release(); c->h_fin.release();
+    c->d_off64.release(); c->d_cnt64.release(); c->d_off64s.release(); c->d_scan64_tmp.release(); c->d_tot64.release();
+    c->d_huge_u64.release(); c->d_inv_recs.release(); c->d_lzero.release(); c->d_list4.release(); c->d_listH.release();
+    c->d_seg_of_g.release(); c->d_huge_u32.release(); c->d_huge_f32.release(); c->d_ledges.release(); c->d_lhyps.release();
+    c->d_lsegs.release(); c->d_lcands.release(); c->d_lchdrs.release();
     c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
     c->d_chunk_band.release(); c->d_tgt_sf.release(); c->d_tgt_band.release();
     c->d_row_counts.release();
@@ -407,6 +411,10 @@ static int match_begin_body(l3d_ctx* c) {
             pd.src = v->index; pd.tgt = t->index; pd.Ms = v->M; pd.Mt = t->M;
             pd.K = c->kNN > 0 ? (uint32_t)c->kNN : 0u;
             pd.row_off = row_off; pd.slot_off = slot_off;
+            {   // |C_src - C_tgt|, rounded up (k_lists.hip: window_sq)
+                const double d = norm(v->C - t->C);
+                pd.cc_dist = std::nextafterf((float)(d * (1.0 + 1e-6)), INFINITY); pd.pad = 0;
+            }
             slot_off += (uint64_t)pd.Ms * pd.K; row_off += pd.Ms;
             const uint32_t pi = (uint32_t)c->pairs.size();
             v->out_pairs.push_back(pi);
@@ -714,6 +722,75 @@ int l3d_match_finish(l3d_ctx* c) {
     return rc;
 }
 
+// One pass of the sparse phase B from the zeroed work arrays to the view medians (k_lists.hip): the list pass (only
+// when `with_lists`), the chain sweeps, scores, filterMatches, outputs.  Everything is enqueued; the results of the
+// run (totals, overflow / convergence flags, pool fill, medians) are copied to pinned memory for the caller's sync.
+static constexpr uint32_t kChainSweeps = 12;   // sweeps enqueued blindly (each one is a no-op once nothing changes)
+
+static ListPools list_pools(l3d_ctx* c) {
+    ListPools lp;
+    lp.cnt = c->d_lzero.p; lp.edges = c->d_ledges.p; lp.hyps = c->d_lhyps.p; lp.segs = c->d_lsegs.p;
+    lp.cands = c->d_lcands.p; lp.chdrs = c->d_lchdrs.p;
+    lp.ecap = c->lp_ecap; lp.hcap = c->lp_hcap; lp.scap = c->lp_scap; lp.ccap = c->lp_ccap;
+    lp.flags = c->d_lzero.p + kListPools * 16;
+    lp.list4 = c->d_list4.p; lp.listH = c->d_listH.p;
+    return lp;
+}
+
+// layout of the zero block d_lzero (one memset per pass): pool counters | flags (32) | changed (64) | max_score (V+1)
+// | kept_cnt (G) | best_pack (G x u64, 8-byte aligned)
+struct ZeroLayout { size_t flags, changed, max_score, kept, best, words; };
+static ZeroLayout zero_layout(uint32_t V, uint32_t G) {
+    ZeroLayout z;
+    z.flags = (size_t)kListPools * 16; z.changed = z.flags + 32; z.max_score = z.changed + 64;
+    z.kept = z.max_score + V + 1;
+    z.best = (z.kept + G + 1) & ~(size_t)1;
+    z.words = z.best + 2 * (size_t)G + 2;
+    return z;
+}
+
+static int finish_pass(l3d_ctx* c, bool with_lists, bool more_sweeps) {
+    hipStream_t st = c->stream;
+    const uint32_t V = (uint32_t)c->order.size(), P = (uint32_t)c->pairs.size(), G = c->G;
+    const ZeroLayout z = zero_layout(V, G);
+    const ListPools lp = list_pools(c);
+    uint32_t* changed = c->d_lzero.p + z.changed;
+    uint32_t* max_score = c->d_lzero.p + z.max_score;
+    uint32_t* kept = c->d_lzero.p + z.kept;
+    unsigned long long* best = (unsigned long long*)(c->d_lzero.p + z.best);
+    const SimConst simc = sim_thresholds(c->two_sigA_sqr);
+    (void)P;
+    if (with_lists) {
+        L3D_HIP_CHECK(hipMemsetAsync(c->d_lzero.p, 0, z.words * 4, st));
+        L3D_HIP_CHECK(hipMemsetAsync(c->d_positive.p, 0, std::max<uint64_t>(c->n_slots, 1), st));
+        L3D_HIP_CHECK(hipMemsetAsync(c->d_seg_of_g.p, 0xFF, ((size_t)G + 1) * 4, st));
+        const HugeScratchArgs hsa{c->d_huge_f32.p, c->d_huge_u32.p, (uint64_t*)c->d_huge_u64.p, c->huge_cap};
+        L3D_HIP_CHECK(launch_lists(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p, c->d_vout_off.p,
+                                   c->d_vout_pairs.p, c->d_off64.p, c->d_inv_recs.p, c->d_slots.p,
+                                   c->kNN > 0 ? (uint32_t)c->kNN : 0u, simc, lp, c->d_seg_of_g.p, hsa, st));
+    } else {
+        // keep the records of the list pass and what the sweeps have found; reset what the later stages accumulate
+        L3D_HIP_CHECK(hipMemsetAsync(changed, 0, (z.words - z.changed) * 4, st));
+    }
+    for (uint32_t s2 = 0; s2 < kChainSweeps; ++s2)
+        L3D_HIP_CHECK(launch_chain_sweep(lp, c->d_positive.p, changed, s2, st));
+    (void)more_sweeps;
+    L3D_HIP_CHECK(launch_hyp_scores(lp, c->d_positive.p, c->d_gseg_view.p, c->d_slots.p, max_score, st));
+    L3D_HIP_CHECK(launch_hyp_filter(lp, G, c->d_gseg_view.p, max_score, kept, best, c->d_cnt64.p, st));
+    L3D_HIP_CHECK(launch_scan64(c->d_cnt64.p, G, c->d_off64s.p, c->d_scan64_tmp.p, c->d_tot64.p + 1, st));
+    L3D_HIP_CHECK(launch_seg_write(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p, c->d_off64s.p, best,
+                                   c->d_seg_of_g.p, lp, c->d_slots.p, c->d_surv_off.p, c->d_hyp_off.p, c->d_surv.p,
+                                   c->d_surv_tg.p, c->d_surv_sg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_depths.p, st));
+    L3D_HIP_CHECK(launch_median_all(V, c->d_depths.p, c->d_hyp_off.p, c->d_seg_base.p, c->d_medians.p, st));
+    // read-backs (pinned): [0..3] two 64-bit totals, [4..35] flags, [36..99] changed, [128..] pool counters
+    uint32_t* h = c->h_fin.p;
+    L3D_HIP_CHECK(hipMemcpyAsync(h, c->d_tot64.p, 16, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipMemcpyAsync(h + 4, c->d_lzero.p + z.flags, (32 + 64) * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipMemcpyAsync(h + 128, c->d_lzero.p, (size_t)kListPools * 16 * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipMemcpyAsync(c->h_med.p, c->d_medians.p, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+    return L3D_OK;
+}
+
 static int match_finish_impl(l3d_ctx* c) {
     hipStream_t st = c->stream;
     const uint32_t V = (uint32_t)c->order.size(), P = (uint32_t)c->pairs.size();
@@ -725,15 +802,18 @@ static int match_finish_impl(l3d_ctx* c) {
     for (auto& pd : c->pairs) max_slots = std::max<uint64_t>(max_slots, (uint64_t)pd.Ms * pd.K);
     if (2 * c->n_slots >= (1ull << 32)) return fail(L3D_ERR_LIMIT, "more than 2^32 hypotheses");
     L3D_HIP_CHECK(c->d_seg_base.reserve(V + 1)); L3D_HIP_CHECK(c->d_gseg_view.reserve(G + 1));
-    L3D_HIP_CHECK(c->d_cnt.reserve(G + 1)); L3D_HIP_CHECK(c->d_off.reserve(G + 1));
-    L3D_HIP_CHECK(c->d_scan_tmp.reserve(G / 4096 + 1024)); L3D_HIP_CHECK(c->d_scal.reserve(16));
-    L3D_HIP_CHECK(c->d_max_score.reserve(V + 1));
-    L3D_HIP_CHECK(c->d_surv_cnt.reserve(G + 1)); L3D_HIP_CHECK(c->d_has_best.reserve(G + 1));
-    L3D_HIP_CHECK(c->d_best_pos.reserve(G + 1)); L3D_HIP_CHECK(c->d_surv_off.reserve(G + 1));
-    L3D_HIP_CHECK(c->d_hyp_off.reserve(G + 1)); L3D_HIP_CHECK(c->d_hyp_of_seg.reserve(G + 1));
-    L3D_HIP_CHECK(c->d_medians.reserve(V + 1));
-    L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
+    L3D_HIP_CHECK(c->d_surv_off.reserve(G + 2)); L3D_HIP_CHECK(c->d_hyp_off.reserve(G + 2));
+    L3D_HIP_CHECK(c->d_hyp_of_seg.reserve(G + 1)); L3D_HIP_CHECK(c->d_medians.reserve(V + 1));
+    L3D_HIP_CHECK(c->d_off64.reserve(G + 2)); L3D_HIP_CHECK(c->d_cnt64.reserve(G + 2)); L3D_HIP_CHECK(c->d_off64s.reserve(G + 2));
+    L3D_HIP_CHECK(c->d_scan64_tmp.reserve(G / 4096 + 1024)); L3D_HIP_CHECK(c->d_tot64.reserve(4));
+    L3D_HIP_CHECK(c->d_seg_of_g.reserve(G + 1)); L3D_HIP_CHECK(c->d_list4.reserve(G + 1)); L3D_HIP_CHECK(c->d_listH.reserve(G + 1));
+    L3D_HIP_CHECK(c->d_hyps.reserve(std::max<uint32_t>(G, 1))); L3D_HIP_CHECK(c->d_depths.reserve(2 * (size_t)G + 2));
+    L3D_HIP_CHECK(c->d_positive.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    L3D_HIP_CHECK(c->d_inv_recs.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    L3D_HIP_CHECK(c->d_inv_pos.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    L3D_HIP_CHECK(c->h_fin.reserve(128 + kListPools * 16)); L3D_HIP_CHECK(c->h_med.reserve(V + 1));
     L3D_HIP_CHECK(c->h_small.reserve(V + 1));
+    L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
     g_trace.mark("finish: reserves done");
     std::memcpy(c->h_small.p, c->seg_base.data(), ((size_t)V + 1) * 4);
     L3D_HIP_CHECK(hipMemcpyAsync(c->d_seg_base.p, c->h_small.p, ((size_t)V + 1) * 4, hipMemcpyHostToDevice, st));
@@ -742,7 +822,6 @@ static int match_finish_impl(l3d_ctx* c) {
         for (auto* v : c->order) max_M = std::max(max_M, v->M);
         L3D_HIP_CHECK(launch_fill_gseg_view(c->d_seg_base.p, V, max_M, c->d_gseg_view.p, st));
     }
-    g_trace.mark("finish: seg_base + gseg enqueued");
     // outgoing pairs of every view (ascending target), for the fresh part of the lists
     // staged as [vout_off (V+1) | vout_pairs (P)] in one pinned buffer
     c->vout_off.assign(V + 1, 0);
@@ -760,15 +839,9 @@ static int match_finish_impl(l3d_ctx* c) {
         L3D_HIP_CHECK(hipMemcpyAsync(c->d_vout_off.p, c->h_vout.p, ((size_t)V + 1) * 4, hipMemcpyHostToDevice, st));
         if (n) L3D_HIP_CHECK(hipMemcpyAsync(c->d_vout_pairs.p, vp, (size_t)n * 4, hipMemcpyHostToDevice, st));
     }
-    L3D_HIP_CHECK(c->d_cnt_inv.reserve(G + 1)); L3D_HIP_CHECK(c->d_inv_off.reserve(G + 1));
-    // (d_cnt_pack was zeroed by l3d_match_begin: the match epilogue already counts into it)
-    L3D_HIP_CHECK(c->d_inv_pos.reserve(std::max<uint64_t>(c->n_slots, 1)));
-    L3D_HIP_CHECK(hipMemsetAsync(c->d_max_score.p, 0, ((size_t)V + 1) * 4, st));
-    L3D_HIP_CHECK(hipMemsetAsync(c->d_scal.p, 0, 16 * 4, st));
-    g_trace.mark("finish: memsets enqueued");
-    // ---- pre-pass: orientation flags, list offsets, transposed index of potential inverse matches ----
-    // (bounded kNN: already done by the match epilogue / the exchange expansion; what is left are the pairs of the
-    // keep-all mode and pairs whose full records arrived through l3d_slots_exchanged)
+    // ---- pre-pass: orientation flags and hypothesis counters of the pairs that do not carry them yet ----
+    // (bounded kNN: done by the match epilogue / the exchange expansion; what is left are the pairs of the keep-all
+    // mode and pairs whose full records arrived through l3d_slots_exchanged; d_cnt_pack was zeroed by l3d_match_begin)
     for (uint32_t p0 = 0; p0 < P;) {
         if (c->pair_counted[p0]) { ++p0; continue; }
         uint32_t p1 = p0;
@@ -778,129 +851,84 @@ static int match_finish_impl(l3d_ctx* c) {
         for (uint32_t p = p0; p < p1; ++p) c->pair_counted[p] = 1;
         p0 = p1;
     }
-    L3D_HIP_CHECK(launch_unpack_counts(G, c->d_cnt_pack.p, c->d_cnt.p, c->d_cnt_inv.p, st));
-    L3D_HIP_CHECK(launch_scan(c->d_cnt.p, G, c->d_off.p, c->d_scan_tmp.p, c->d_scal.p + 0, st));
-    L3D_HIP_CHECK(launch_scan(c->d_cnt_inv.p, G, c->d_inv_off.p, c->d_scan_tmp.p, c->d_scal.p + 5, st));
-    L3D_HIP_CHECK(c->d_bits_len.reserve(G + 1)); L3D_HIP_CHECK(c->d_boff.reserve(G + 1));
-    L3D_HIP_CHECK(c->d_long_list.reserve(G + 1));
-    L3D_HIP_CHECK(launch_bits_len(G, c->d_off.p, c->d_bits_len.p, c->d_long_list.p, c->d_scal.p + 7, st));
-    L3D_HIP_CHECK(launch_scan(c->d_bits_len.p, G, c->d_boff.p, c->d_scan_tmp.p, c->d_scal.p + 6, st));
-    L3D_HIP_CHECK(c->h_cnt.reserve(16));   // pinned: an early return below must not leave a copy in flight to a dead frame
-    uint32_t* tot = c->h_cnt.p;
-    L3D_HIP_CHECK(hipMemcpyAsync(tot, c->d_scal.p, 8 * 4, hipMemcpyDeviceToHost, st));
-    // The list kernels only need buffers sized by bounds the host already knows (every slot yields at most one own
-    // and one inverse hypothesis), so they are enqueued BEFORE the totals are read back: the host round trip that
-    // sizes the support bitsets hides behind them.  (If the bound-sized buffers cannot be had, read first.)
-    L3D_HIP_CHECK(c->d_positive.reserve(std::max<uint64_t>(c->n_slots, 1)));
-    L3D_HIP_CHECK(hipMemsetAsync(c->d_positive.p, 0, std::max<uint64_t>(c->n_slots, 1), st));
-    const uint64_t ents_bound = std::max<uint64_t>(2 * c->n_slots, 1), inv_bound = std::max<uint64_t>(c->n_slots, 1);
-    bool lists_enqueued = false;
-    auto enqueue_lists = [&]() -> int {
-        L3D_HIP_CHECK(launch_inv_fill(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_inv_off.p,
-                                      c->d_inv_pos.p, c->d_refs.p, st));
-        L3D_HIP_CHECK(launch_build_lists_all(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p,
-                                             c->d_vout_off.p, c->d_vout_pairs.p, c->d_off.p, c->d_inv_off.p, c->d_refs.p,
-                                             c->d_slots.p, c->d_dents.p, c->d_eref.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, st));
-        return L3D_OK;
-    };
-    if (c->d_dents.reserve(ents_bound) == hipSuccess && c->d_eref.reserve(ents_bound) == hipSuccess &&
-        c->d_refs.reserve(inv_bound) == hipSuccess) {
-        const int rc = enqueue_lists();
-        if (rc) return rc;
-        lists_enqueued = true;
-    } else {
-        (void)hipGetLastError();
+    // list offsets (low words) and offsets of the inverse records (high words) in ONE scan of the packed counters
+    L3D_HIP_CHECK(launch_scan64(c->d_cnt_pack.p, G, c->d_off64.p, c->d_scan64_tmp.p, c->d_tot64.p, st));
+    L3D_HIP_CHECK(launch_inv_records(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_off64.p,
+                                     c->d_inv_pos.p, c->d_inv_recs.p, st));
+    // ---- the sparse phase B with optimistic sizes: the pools are sized from the slot count (or from what an earlier
+    // call needed); a pass that outgrows them says so and is repeated with larger ones -- no sizing read-back sits in
+    // the common path, the one host synchronisation of matchImages is the one at its end ----
+    if (!c->lp_ecap) {
+        c->lp_ecap = (uint32_t)std::max<uint64_t>(c->n_slots / 4 / kListPools, 512);
+        c->lp_hcap = (uint32_t)std::max<uint64_t>(c->n_slots / 8 / kListPools, 256);
+        c->lp_ccap = (uint32_t)std::max<uint64_t>(c->n_slots / 2 / kListPools, 1024);
     }
-    g_trace.mark("pre-pass + lists enqueued, waiting for sizes");
-    L3D_HIP_CHECK(hipStreamSynchronize(st));   // first point at which the host waits for the GPU in matchImages
-    g_trace.mark("sizes known");
-    const uint32_t n_ents = c->n_ents = tot[0], n_inv = tot[5], n_words = tot[6];
-    c->tm.list_entries = n_ents; c->tm.support_words = n_words;
-    L3D_HIP_CHECK(c->d_bits.reserve(std::max<uint32_t>(n_words, 1)));
-    if (!lists_enqueued) {
-        L3D_HIP_CHECK(c->d_dents.reserve(std::max<uint32_t>(n_ents, 1)));
-        L3D_HIP_CHECK(c->d_refs.reserve(std::max<uint32_t>(n_inv, 1)));
-        L3D_HIP_CHECK(c->d_eref.reserve(std::max<uint32_t>(n_ents, 1)));
-        const int rc = enqueue_lists();
+    c->lp_scap = std::max<uint32_t>(c->lp_scap, 2 * (G / kListPools) + 64);
+    if (!c->huge_cap) c->huge_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->n_slots / 16, 1u << 20), 1u << 30);
+    const ZeroLayout z = zero_layout(V, G);
+    for (int attempt = 0;; ++attempt) {
+        L3D_HIP_CHECK(c->d_lzero.reserve(z.words + 2));
+        L3D_HIP_CHECK(c->d_ledges.reserve((size_t)kListPools * c->lp_ecap));
+        L3D_HIP_CHECK(c->d_lhyps.reserve((size_t)kListPools * c->lp_hcap));
+        L3D_HIP_CHECK(c->d_lsegs.reserve((size_t)kListPools * c->lp_scap));
+        L3D_HIP_CHECK(c->d_lchdrs.reserve((size_t)kListPools * c->lp_scap));
+        L3D_HIP_CHECK(c->d_lcands.reserve((size_t)kListPools * c->lp_ccap));
+        L3D_HIP_CHECK(c->d_huge_f32.reserve(2 * (size_t)c->huge_cap)); L3D_HIP_CHECK(c->d_huge_u32.reserve(3 * (size_t)c->huge_cap));
+        L3D_HIP_CHECK(c->d_huge_u64.reserve(c->huge_cap));
+        // n_surv <= number of headers: the outputs are sized by that bound
+        const size_t surv_cap = (size_t)kListPools * c->lp_hcap;
+        L3D_HIP_CHECK(c->d_surv.reserve(surv_cap)); L3D_HIP_CHECK(c->d_surv_tg.reserve(surv_cap));
+        L3D_HIP_CHECK(c->d_surv_sg.reserve(surv_cap));
+        int rc = finish_pass(c, true, false);
         if (rc) return rc;
+        L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
+        g_trace.mark("phase B enqueued, waiting");
+        L3D_HIP_CHECK(hipStreamSynchronize(st));   // the one point at which matchImages waits for the GPU
+        g_trace.mark("phase B done");
+        const uint32_t* h = c->h_fin.p;
+        const uint32_t* fl = h + 4;
+        if (fl[1]) return fail(L3D_ERR_LIMIT, "a 2D segment has more than 65535 match hypotheses");
+        if (fl[3]) return fail(L3D_ERR_HIP, "internal error: hypothesis counters and slot flags disagree");
+        if (fl[0] || fl[2]) {
+            if (attempt >= 6) return fail(L3D_ERR_LIMIT, "phase-B pools keep overflowing");
+            if (fl[0]) {   // size from what this pass asked for, with head room
+                // (a pass that ran out of candidate space never reached the edges: those pools double)
+                uint32_t me = 0, mh = 0, ms = 0, mc = 0;
+                for (uint32_t q = 0; q < kListPools; ++q) {
+                    me = std::max(me, h[128 + q * 16]); mh = std::max(mh, h[128 + q * 16 + 1]);
+                    ms = std::max(ms, std::max(h[128 + q * 16 + 2], h[128 + q * 16 + 4])); mc = std::max(mc, h[128 + q * 16 + 3]);
+                }
+                const bool cands_over = mc > c->lp_ccap || ms > c->lp_scap;
+                c->lp_ccap = std::max(c->lp_ccap, mc + mc / 2 + 64); c->lp_scap = std::max(c->lp_scap, ms + ms / 2 + 64);
+                c->lp_ecap = std::max(cands_over ? 2 * c->lp_ecap : c->lp_ecap, me + me / 2 + 64);
+                c->lp_hcap = std::max(cands_over ? 2 * c->lp_hcap : c->lp_hcap, mh + mh / 2 + 64);
+            }
+            if (fl[2]) c->huge_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * c->huge_cap, fl[6] + 1024ull), 1u << 31);
+            continue;
+        }
+        // the chain: not converged within the blind sweeps -> keep sweeping (exact for any chain depth), then redo
+        // the stages that follow it
+        while (h[36 + kChainSweeps - 1]) {
+            rc = finish_pass(c, false, true);
+            if (rc) return rc;
+            L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
+            L3D_HIP_CHECK(hipStreamSynchronize(st));
+            ++c->tm.chain_extra_rounds;
+        }
+        break;
     }
-    const SimConst simc = sim_thresholds(c->two_sigA_sqr);
-    // lists too long for one wave's LDS staging: one workgroup each, before the pipeline (chain independent)
-    L3D_HIP_CHECK(launch_support_long(tot[7], c->d_long_list.p, c->d_off.p, c->d_boff.p, c->d_dents.p, c->d_bits.p,
-                                      c->d_views.p, c->d_gseg_view.p, simc, st));
-    // Three-stage software pipeline over chunks of views on three streams:
-    //   A (the context's stream)  support bitsets of chunk k          (chain independent, heavy)
-    //   B                         THE CHAIN: one tiny bit-propagation launch per view, ascending camID; view v only
-    //                             needs the support rows of its own chunk and the chain state of the views before it
-    //   C                         scores of chunk k (needs the presence masks of chunk k)
-    // so the launch-latency-bound chain (V dependent launches that keep < 5 % of the GPU busy) hides behind the
-    // support / score kernels of the neighbouring chunks.
+    const uint32_t* h = c->h_fin.p;
+    c->n_ents = h[0];
+    c->n_surv = h[2]; c->n_hyps = h[3];
+    c->tm.list_entries = h[0];
     {
-        // 4 views per chunk (at most 64 chunks): measured best on C1 among 1/2/4/8/16 and ramped schedules -- the
-        // chain cannot start before the first chunk's support rows exist and the last chunk's scores cannot start
-        // before the chain ends, while very small chunks leave the support / score launches too small to fill the GPU
-        const uint32_t n_chunks = std::min<uint32_t>(std::max<uint32_t>((V + 3) / 4, 1), 64);
-        const uint32_t per = (V + n_chunks - 1) / n_chunks;
-        while (c->pipe_ev.size() < 2 * (size_t)n_chunks + 2) {
-            hipEvent_t e;
-            L3D_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            c->pipe_ev.push_back(e);
-        }
-        { const int rc2 = ensure_aux(c); if (rc2) return rc2; }
-        hipStream_t sB = c->aux[0], sC = c->aux[1];
-        hipEvent_t ev_start = c->pipe_ev[2 * n_chunks], ev_done = c->pipe_ev[2 * n_chunks + 1];
-        L3D_HIP_CHECK(hipEventRecord(ev_start, st));
-        L3D_HIP_CHECK(hipStreamWaitEvent(sB, ev_start, 0));
-        L3D_HIP_CHECK(hipStreamWaitEvent(sC, ev_start, 0));
-        for (uint32_t k = 0; k < n_chunks; ++k) {
-            const uint32_t v0 = std::min(V, k * per), v1 = std::min(V, v0 + per);
-            const uint32_t g0 = c->seg_base[v0], g1 = c->seg_base[v1];
-            L3D_HIP_CHECK(launch_support_all(g0, g1, c->d_off.p, c->d_boff.p, c->d_dents.p, c->d_bits.p, c->d_views.p,
-                                             c->d_seg_base.p, c->d_gseg_view.p, simc, st));
-            L3D_HIP_CHECK(hipEventRecord(c->pipe_ev[2 * k], st));
-            L3D_HIP_CHECK(hipStreamWaitEvent(sB, c->pipe_ev[2 * k], 0));
-            g_trace.mark("  chunk: support enqueued");
-            for (uint32_t vi = v0; vi < v1; ++vi)
-                L3D_HIP_CHECK(launch_presence_view(c->seg_base[vi], c->order[vi]->M, c->d_off.p, c->d_boff.p,
-                                                   c->d_inv_off.p, c->d_eref.p, c->d_bits.p, c->d_positive.p, sB));
-            g_trace.mark("  chunk: chain launches enqueued");
-            L3D_HIP_CHECK(hipEventRecord(c->pipe_ev[2 * k + 1], sB));
-            L3D_HIP_CHECK(hipStreamWaitEvent(sC, c->pipe_ev[2 * k + 1], 0));
-            L3D_HIP_CHECK(launch_score_all(g0, g1, c->d_off.p, c->d_boff.p, c->d_gseg_view.p, c->d_dents.p, c->d_bits.p,
-                                           c->d_slots.p, c->d_max_score.p, c->d_views.p, c->d_seg_base.p, simc, sC));
-        }
-        L3D_HIP_CHECK(hipEventRecord(ev_done, sC));
-        L3D_HIP_CHECK(hipStreamWaitEvent(st, ev_done, 0));
+        uint64_t ne = 0;
+        for (uint32_t q = 0; q < kListPools; ++q) ne += h[128 + q * 16];
+        c->tm.support_words = (uint32_t)ne;    // supporting (hypothesis, supporter) pairs
     }
-    // ---- post-pass: filterMatches for all views ----
-    L3D_HIP_CHECK(launch_filter_all(G, c->d_off.p, c->d_gseg_view.p, c->d_dents.p, c->d_max_score.p, c->d_surv_cnt.p,
-                                    c->d_has_best.p, c->d_best_pos.p, st));
-    L3D_HIP_CHECK(launch_scan(c->d_surv_cnt.p, G, c->d_surv_off.p, c->d_scan_tmp.p, c->d_scal.p + 1, st));
-    L3D_HIP_CHECK(launch_scan(c->d_has_best.p, G, c->d_hyp_off.p, c->d_scan_tmp.p, c->d_scal.p + 2, st));
-    uint32_t* nh = c->h_cnt.p + 8;
-    L3D_HIP_CHECK(hipMemcpyAsync(nh, c->d_scal.p + 1, 8, hipMemcpyDeviceToHost, st));
-    g_trace.mark("lists/support/chain/scores/filter enqueued, waiting for counts");
-    L3D_HIP_CHECK(hipStreamSynchronize(st));
-    g_trace.mark("counts known");
-    c->n_surv = nh[0]; c->n_hyps = nh[1];
-    L3D_HIP_CHECK(c->d_surv.reserve(std::max<uint32_t>(c->n_surv, 1)));
-    L3D_HIP_CHECK(c->d_surv_tg.reserve(std::max<uint32_t>(c->n_surv, 1)));
-    L3D_HIP_CHECK(c->d_surv_sg.reserve(std::max<uint32_t>(c->n_surv, 1)));
-    L3D_HIP_CHECK(c->d_hyps.reserve(std::max<uint32_t>(c->n_hyps, 1)));
-    L3D_HIP_CHECK(c->d_depths.reserve(2 * (size_t)c->n_hyps + 2));
-    L3D_HIP_CHECK(launch_filter_write_all(c->d_views.p, c->d_pairs.p, c->d_seg_base.p, G, c->d_gseg_view.p,
-                                          c->d_off.p, c->d_dents.p, c->d_slots.p, c->d_surv_off.p, c->d_hyp_off.p,
-                                          c->d_best_pos.p, c->d_surv.p, c->d_surv_tg.p, c->d_surv_sg.p,
-                                          c->d_hyp_of_seg.p, c->d_hyps.p, c->d_depths.p, st));
-    L3D_HIP_CHECK(launch_median_all(V, c->d_depths.p, c->d_hyp_off.p, c->d_seg_base.p, c->d_medians.p, st));
     // View::update_median_depth for every view (line3D.cc:1665-1668); in fixed-regulariser mode k is
     // re-set to the same sigma_p/med_scene_depth value, so k is unchanged either way
-    L3D_HIP_CHECK(c->h_med.reserve(V));
-    float* med = c->h_med.p;
-    L3D_HIP_CHECK(hipMemcpyAsync(med, c->d_medians.p, (size_t)V * 4, hipMemcpyDeviceToHost, st));
-    L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
-    L3D_HIP_CHECK(hipStreamSynchronize(st));
-    for (uint32_t vi = 0; vi < V; ++vi) c->order[vi]->median_depth = med[vi];
+    for (uint32_t vi = 0; vi < V; ++vi) c->order[vi]->median_depth = c->h_med.p[vi];
     c->host_offsets_valid = false;
     if (c->timing_pending) {   // phase A ran unsynchronised (l3d_match_images)
         collect_match_timing(c);

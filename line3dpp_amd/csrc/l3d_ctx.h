@@ -17,6 +17,7 @@
 #include <unordered_set>
 
 #include "l3d_host.h"
+#include "l3d_lists.h"
 #include "l3d_recon.h"
 
 struct l3d_ctx;
@@ -186,6 +187,18 @@ struct l3d_ctx {
     DevBuf<int32_t> d_hyp_of_seg;
     DevBuf<float> d_depths, d_medians;              // d_medians[V]
     DevBuf<HypRec> d_hyps;
+    // sparse phase B (k_lists.hip, l3d_lists.h)
+    DevBuf<unsigned long long> d_off64, d_cnt64, d_off64s, d_scan64_tmp, d_tot64, d_huge_u64;
+    DevBuf<InvRec> d_inv_recs;
+    DevBuf<uint32_t> d_lzero, d_list4, d_listH, d_seg_of_g, d_huge_u32;
+    DevBuf<float> d_huge_f32;
+    DevBuf<EdgeRec> d_ledges;
+    DevBuf<HypHdr> d_lhyps;
+    DevBuf<SegHdr> d_lsegs;
+    DevBuf<CandRec> d_lcands;
+    DevBuf<CandHdr> d_lchdrs;
+    uint32_t lp_ecap = 0, lp_hcap = 0, lp_scap = 0, lp_ccap = 0, huge_cap = 0;   // per-pool capacities (grow on overflow, kept across calls)
+    PinnedBuf<uint32_t> h_fin;
     std::vector<uint32_t> h_surv_off, h_hyp_off;    // lazily fetched for the accessors
     bool host_offsets_valid = false;
     // affinity

@@ -95,6 +95,8 @@ struct PairDesc {
     uint32_t K;         // slots per src segment
     uint32_t row_off;   // first row of this pair in the per-row count array (kNN <= 0 mode)
     uint64_t slot_off;  // first slot of this pair in the slot buffer
+    float cc_dist;      // |C_src - C_tgt| rounded up: bounds |P - C_other| of a hypothesis from its depth (k_lists.hip)
+    uint32_t pad;
 };
 
 // ---- phase-B records ------------------------------------------------------------------------

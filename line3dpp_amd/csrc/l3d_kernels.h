@@ -69,6 +69,30 @@ hipError_t launch_expand_slot_idx(const ViewDev* views, const PairDesc* pairs, u
                                   hipStream_t stream);
 hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, hipStream_t stream);
 
+// ---- k_lists.hip: the sparse phase B (l3d_lists.h) ----
+struct InvRec; struct ListPools;
+struct HugeScratchArgs { float* f32; uint32_t* u32; uint64_t* u64; uint32_t cap; };   // [2 cap] [3 cap] [cap]
+hipError_t launch_scan64(const unsigned long long* in, uint32_t n, unsigned long long* out, unsigned long long* tmp,
+                         unsigned long long* total, hipStream_t st);
+hipError_t launch_inv_records(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
+                              const Slot* slots, const unsigned long long* off64, const uint32_t* inv_pos, InvRec* recs,
+                              hipStream_t st);
+hipError_t launch_lists(uint32_t G, const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base,
+                        const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
+                        const unsigned long long* off64, const InvRec* inv, const Slot* slots, uint32_t uniform_K,
+                        SimConst sc, ListPools lp, uint32_t* seg_of_g, HugeScratchArgs hsa, hipStream_t st);
+hipError_t launch_chain_sweep(ListPools lp, uint8_t* positive, uint32_t* changed, uint32_t sweep, hipStream_t st);
+hipError_t launch_hyp_scores(ListPools lp, const uint8_t* positive, const uint32_t* gseg_view, Slot* slots,
+                             uint32_t* max_score_bits, hipStream_t st);
+hipError_t launch_hyp_filter(ListPools lp, uint32_t G, const uint32_t* gseg_view, const uint32_t* max_score_bits,
+                             uint32_t* kept_cnt, unsigned long long* best_pack, unsigned long long* cnt64,
+                             hipStream_t st);
+hipError_t launch_seg_write(uint32_t G, const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base,
+                            const uint32_t* gseg_view, const unsigned long long* off64s,
+                            const unsigned long long* best_pack, const uint32_t* seg_of_g, ListPools lp,
+                            const Slot* slots, uint32_t* surv_off, uint32_t* hyp_off, Match* surv, uint32_t* surv_tg,
+                            uint32_t* surv_sg, int32_t* hyp_of_seg, HypRec* hyps, float* depths, hipStream_t st);
+
 // ---- k_rdd.hip ----
 size_t rdd_workspace_bytes(uint32_t nnz, uint32_t n_rows);
 hipError_t launch_rdd(const struct ::l3d_cledge* edges_in, uint32_t nnz, uint32_t n_rows, uint32_t iterations,

@@ -1,0 +1,96 @@
+// l3d_lists.h -- records of the sparse phase B (k_lists.hip).
+//
+// A 2D segment of view v owns a list of L hypotheses (fresh matches of v's outgoing pairs + inverse matches handed
+// over by earlier views, line3D.cc:745-773).  scoringCPU (line3D.cc:1208-1294) compares every hypothesis with every
+// other one of the list, but similarityForScoring exceeds L3D_DEF_MIN_SIMILARITY_3D only for hypotheses that agree in
+// depth within a fraction of a percent: on the BASELINE scenes 10^7 hypotheses have 5*10^5 supporting pairs and 98 %
+// of the hypotheses have none.  Phase B therefore keeps nothing per hypothesis: one dense pass over the lists
+// (k_lists) finds the supporting pairs and emits them -- EDGES, with their similarity -- together with a HEADER per
+// hypothesis that has at least one; the chain of the reference (which inverse hypotheses exist), the scores, the
+// filter and the outputs are all functions of those few records.
+#pragma once
+#include "l3d_dev.h"
+
+namespace l3d {
+
+// slot (pair, src_row, j) as a potential inverse hypothesis of its target segment, with what the list pass needs
+// (the slot itself is only read again if the hypothesis survives): 24 bytes, CSR over global segments (inv_off)
+struct InvRec {
+    uint32_t ref;        // slot index
+    uint32_t pair;       // directed pair the slot belongs to
+    uint32_t src_view;   // canonical order of the inverse hypotheses: (source view, source segment) ascending
+    uint32_t src_row;
+    float dq1, dq2;      // depths of the target segment's end points = this hypothesis' own depths
+};
+static_assert(sizeof(InvRec) == 24, "InvRec is 24 bytes");
+
+// hypothesis i of a list is supported by hypothesis j (other camera, similarityForScoring > 0.5): sim is the value
+struct EdgeRec {
+    uint32_t ref_j;      // slot of the supporter (its existence bit lives in positive[ref_j] when it is inverse)
+    float sim;
+    uint32_t j_cam;      // canonical index of j in the list (low 16 bits) | j inverse << 16 ; cam in hyp-local order
+    uint32_t tv_j;       // camera (view index) of the supporter: the per-camera maximum of scoringCPU (:1255-1274)
+};
+static_assert(sizeof(EdgeRec) == 16, "EdgeRec is 16 bytes");
+constexpr uint32_t kEdgeInv = 1u << 16;
+
+// a hypothesis with at least one edge.  The headers of one segment are contiguous and in canonical order, and so
+// are the edges of one header (ascending j).
+struct HypHdr {
+    uint32_t g;          // global segment id
+    uint32_t ref;        // its slot
+    uint32_t pair_flags; // pair | inverse << 31
+    uint32_t canon;      // canonical index in the list
+    float dp1, dp2;      // its depths in this view
+    uint32_t edge_begin; // global edge index
+    uint32_t edge_cnt;
+    float score3D;       // k_hyp_scores
+    uint32_t state;      // bit0 exists (fresh, or inverse with positive source), bit1 kept by filterMatches
+    uint32_t pad[2];
+};
+static_assert(sizeof(HypHdr) == 48, "HypHdr is 48 bytes");
+constexpr uint32_t kHypInv = 1u << 31;
+constexpr uint32_t kHypExists = 1u, kHypKeep = 2u;
+
+// a segment with at least one header
+struct SegHdr {
+    uint32_t g, hyp_begin, hyp_cnt, pad;
+};
+
+// candidate pair of the list pass: hypothesis i might be supported by hypothesis j (other camera, both depths inside
+// i's conservative windows).  Carries what the exact test and the records above need, so that nothing is gathered
+// twice.  The candidates of one segment are contiguous.
+struct CandRec {
+    uint32_t ij;         // canonical indices i << 16 | j
+    uint32_t ref_i, ref_j;
+    uint32_t pf_i;       // pair | inverse << 31 of i
+    uint32_t tvj;        // camera (view index) of j | j inverse << 31
+    float a1, a2, b1, b2;   // depths of i and of j
+    float sim;           // k_edges: similarity if the pair passed the exact test, else -1
+};
+static_assert(sizeof(CandRec) == 40, "CandRec is 40 bytes");
+struct CandHdr {
+    uint32_t g, begin, cnt, pad;
+};
+
+// The records are allocated from kListPools independent pools (a workgroup uses pool blockIdx % kListPools): one
+// hot atomic counter would serialise 10^5 reservations per call.  cnt[pool * 16 + k] = records reserved in that pool,
+// k = 0 edges, 1 headers, 2 segments, 3 candidates, 4 candidate headers (may exceed the capacity: then `overflow` is
+// set, the call is repeated with larger pools, and consumers clamp).
+constexpr uint32_t kListPools = 256;
+struct ListPools {
+    uint32_t* cnt;         // [kListPools * 16]
+    EdgeRec* edges;        // [kListPools * ecap]
+    HypHdr* hyps;          // [kListPools * hcap]
+    SegHdr* segs;          // [kListPools * scap]
+    CandRec* cands;        // [kListPools * ccap]
+    CandHdr* chdrs;        // [kListPools * scap]
+    uint32_t ecap, hcap, scap, ccap;
+    uint32_t* flags;       // [0] pool overflow, [1] list longer than 65535 hypotheses, [2] scratch overflow,
+                           // [3] counters and slots disagree (internal error), [4] lists handed to the 4-wave kernel,
+                           // [5] lists handed to the global-memory kernel, [6] scratch cursor of the latter
+    uint32_t* list4;       // [G] segments for the 4-wave kernel
+    uint32_t* listH;       // [G] segments for the global-memory kernel
+};
+
+}  // namespace l3d

@@ -2,6 +2,8 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  -- first: torch brings its own HIP runtime, which must be initialised before libl3dpp_hip.so
+#                       loads the system one (otherwise torch.cuda reports "No HIP GPUs are available" later on)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
