@@ -211,6 +211,7 @@ typedef struct l3d_timings {
     uint32_t support_words;/* phase B: supporting (hypothesis, supporter) pairs = edges of the sparse form */
     uint32_t tied_rows;    /* phase A: source rows with equal overlaps, replayed in the reference's priority_queue order
                             * (cumulative since l3d_create) */
+    uint32_t chain_sweeps; /* phase B: sweeps of the chain fixed point that still changed something (last round) */
     uint32_t chain_extra_rounds; /* phase B: extra rounds of chain sweeps beyond the ones enqueued blindly (0 normally) */
 } l3d_timings;
 int l3d_get_timings(l3d_ctx*, l3d_timings*);

@@ -31,12 +31,26 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 template <int WPL>
 __device__ __forceinline__ void group_barrier() {
     if (WPL == 1) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // one wave: the LDS executes a wave's instructions in order, so only the compiler has to be held back
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     } else {
         __syncthreads();
     }
+}
+
+// exclusive prefix count of a flag over the group's threads and the group total
+template <int WPL>
+__device__ __forceinline__ uint32_t group_scan(uint32_t v, uint32_t& total, uint32_t* red);
+template <int WPL>
+__device__ __forceinline__ uint32_t group_count(bool f, uint32_t& total, uint32_t* red) {
+    if (WPL == 1) {
+        const uint64_t m = __ballot(f);
+        total = (uint32_t)__popcll(m);
+        return (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+    }
+    return group_scan<WPL>(f ? 1u : 0u, total, red);
 }
 
 // exclusive prefix sum of v over the group's threads (thread order) and the group total.  red: >= 8 words of LDS
@@ -160,18 +174,19 @@ struct ListCfg {
 // One list: its candidate pairs.  Returns 0 (done / nothing to do) or 1 (needs a larger kernel: nothing was written).
 // Group-uniform control flow.
 template <int WPL>
-__device__ __forceinline__ int process_list(uint32_t g, L3D_LDS char* lds, const ViewDev* __restrict__ views,
-                                            const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ seg_base,
-                                            const uint32_t* __restrict__ gseg_view,
-                                            const uint32_t* __restrict__ vout_off,
-                                            const uint32_t* __restrict__ vout_pairs,
+__device__ __forceinline__ int process_list(uint32_t vi, uint32_t seg, uint32_t pool, L3D_LDS char* lds,
+                                            const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+                                            const ListView* __restrict__ lviews, const OutPair* __restrict__ opairs,
                                             const unsigned long long* __restrict__ off64,
                                             const InvRec* __restrict__ inv, const Slot* __restrict__ slots,
                                             uint32_t uniform_K, const ListPools lp) {
     typedef ListCfg<WPL> Cfg;
     constexpr uint32_t GS = Cfg::GS, CAP = Cfg::CAP, NKEY = Cfg::NKEY;
     const uint32_t t = WPL == 1 ? lane_id() : threadIdx.x;
-    const uint32_t L = (uint32_t)(off64[g + 1] - off64[g]);             // low words: list offsets
+    const ListView lv = lviews[vi];
+    const uint32_t g = lv.seg_base + seg;
+    const unsigned long long o0 = off64[g], o1 = off64[g + 1];
+    const uint32_t L = (uint32_t)(o1 - o0);                             // low words: list offsets
     if (L < 2) return 0;
     if (L > CAP) return 1;
     L3D_LDS float* e_d1 = (L3D_LDS float*)lds;
@@ -182,26 +197,37 @@ __device__ __forceinline__ int process_list(uint32_t g, L3D_LDS char* lds, const
     L3D_LDS uint64_t* keys = (L3D_LDS uint64_t*)(e_pf + CAP);
     L3D_LDS uint16_t* pos_of = (L3D_LDS uint16_t*)(keys + NKEY);        // sorted position of hypothesis i
     uint32_t* red = (uint32_t*)(pos_of + CAP);                          // 16 words (generic pointer into LDS)
-    const uint32_t vi = gseg_view[g], seg = g - seg_base[vi];
-    const ViewDev& v = views[vi];
-    const uint32_t ib = (uint32_t)(off64[g] >> 32), n_inv = (uint32_t)(off64[g + 1] >> 32) - ib;
+    const float vk = lv.k;
+    const uint32_t ib = (uint32_t)(o0 >> 32), n_inv = (uint32_t)(o1 >> 32) - ib;
     // ---- inverse hypotheses, placed at their canonical rank: (source view, source segment) ascending ----
-    for (uint32_t x = t; x < n_inv; x += GS) {
-        const InvRec r = inv[ib + x];
-        keys[x] = ((uint64_t)r.src_view << 32) | r.src_row;
-    }
-    group_barrier<WPL>();
-    for (uint32_t x = t; x < n_inv; x += GS) {
-        const InvRec r = inv[ib + x];
-        const uint64_t key = ((uint64_t)r.src_view << 32) | r.src_row;
-        uint32_t rank = 0;
-        for (uint32_t y = 0; y < n_inv; ++y) rank += (keys[y] < key) ? 1u : 0u;
-        e_d1[rank] = r.dq1; e_d2[rank] = r.dq2; e_tv[rank] = r.src_view; e_ref[rank] = r.ref; e_pf[rank] = r.pair | kHypInv;
+    {
+        constexpr uint32_t kInvPer = (CAP + GS - 1) / GS;               // records per thread (n_inv <= L <= CAP)
+        InvRec mine[kInvPer];
+#pragma unroll
+        for (uint32_t c = 0; c < kInvPer; ++c) {
+            const uint32_t x = c * GS + t;
+            if (x < n_inv) {
+                mine[c] = inv[ib + x];
+                keys[x] = ((uint64_t)mine[c].src_view << 32) | mine[c].src_row;
+            }
+        }
+        group_barrier<WPL>();
+#pragma unroll
+        for (uint32_t c = 0; c < kInvPer; ++c) {
+            const uint32_t x = c * GS + t;
+            if (x < n_inv) {
+                const InvRec& r = mine[c];
+                const uint64_t key = ((uint64_t)r.src_view << 32) | r.src_row;
+                uint32_t rank = 0;
+                for (uint32_t y = 0; y < n_inv; ++y) rank += (keys[y] < key) ? 1u : 0u;
+                e_d1[rank] = r.dq1; e_d2[rank] = r.dq2; e_tv[rank] = r.src_view; e_ref[rank] = r.ref; e_pf[rank] = r.pair | kHypInv;
+            }
+        }
     }
     // ---- fresh hypotheses: the alive slots of the view's outgoing pairs, ascending (target view, slot) ----
     uint32_t pos = n_inv;
     {
-        const uint32_t q0 = vout_off[vi], nq = vout_off[vi + 1] - q0;
+        const uint32_t q0 = lv.q0, nq = lv.nq;
         if (uniform_K) {
             const uint32_t T = nq * uniform_K;
             for (uint32_t t0 = 0; t0 < T; t0 += GS) {
@@ -209,33 +235,31 @@ __device__ __forceinline__ int process_list(uint32_t g, L3D_LDS char* lds, const
                 bool alive = false;
                 Slot s; uint32_t ref = 0, pi = 0, tv = 0;
                 if (x < T) {
-                    pi = vout_pairs[q0 + x / uniform_K];
-                    const PairDesc& pd = pairs[pi];
-                    tv = pd.tgt;
-                    ref = (uint32_t)(pd.slot_off + (uint64_t)seg * uniform_K + x % uniform_K);
+                    const OutPair op = opairs[q0 + x / uniform_K];
+                    pi = op.pair; tv = op.tgt;
+                    ref = (uint32_t)(op.slot_off + (uint64_t)seg * uniform_K + x % uniform_K);
                     s = slots[ref];
                     alive = s.tgt_seg != kEmpty && (s.flags & kSlotAlive);
                 }
                 uint32_t total;
-                const uint32_t at = pos + group_scan<WPL>(alive ? 1u : 0u, total, red);
+                const uint32_t at = pos + group_count<WPL>(alive, total, red);
                 if (alive && at < CAP) { e_d1[at] = s.dp1; e_d2[at] = s.dp2; e_tv[at] = tv; e_ref[at] = ref; e_pf[at] = pi; }
                 pos += total;
             }
         } else {
             for (uint32_t q = q0; q < q0 + nq; ++q) {
-                const uint32_t pi = vout_pairs[q];
-                const PairDesc& pd = pairs[pi];
-                const uint64_t row0 = pd.slot_off + (uint64_t)seg * pd.K;
-                for (uint32_t j0 = 0; j0 < pd.K; j0 += GS) {
+                const OutPair op = opairs[q];
+                const uint64_t row0 = op.slot_off + (uint64_t)seg * op.K;
+                for (uint32_t j0 = 0; j0 < op.K; j0 += GS) {
                     bool alive = false;
                     Slot s;
-                    if (j0 + t < pd.K) {
+                    if (j0 + t < op.K) {
                         s = slots[row0 + j0 + t];
                         alive = s.tgt_seg != kEmpty && (s.flags & kSlotAlive);
                     }
                     uint32_t total;
-                    const uint32_t at = pos + group_scan<WPL>(alive ? 1u : 0u, total, red);
-                    if (alive && at < CAP) { e_d1[at] = s.dp1; e_d2[at] = s.dp2; e_tv[at] = pd.tgt; e_ref[at] = (uint32_t)(row0 + j0 + t); e_pf[at] = pi; }
+                    const uint32_t at = pos + group_count<WPL>(alive, total, red);
+                    if (alive && at < CAP) { e_d1[at] = s.dp1; e_d2[at] = s.dp2; e_tv[at] = op.tgt; e_ref[at] = (uint32_t)(row0 + j0 + t); e_pf[at] = op.pair; }
                     pos += total;
                 }
             }
@@ -246,6 +270,17 @@ __device__ __forceinline__ int process_list(uint32_t g, L3D_LDS char* lds, const
     // ---- sort by the first depth: key = (order-preserving bits of dp1, canonical index) ----
     uint32_t N = 2;
     while (N < L) N <<= 1;
+    if (WPL == 1 && N <= 64) {
+        // one key per lane: the bitonic network runs on lane exchanges, no LDS round trip per stage
+        uint64_t key = t < L ? (((uint64_t)f2ord(e_d1[t]) << 32) | t) : ~0ull;
+        for (uint32_t k = 2; k <= 64; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                const uint64_t other = __shfl_xor(key, (int)j);
+                const bool keep_min = ((t & j) == 0) == ((t & k) == 0);
+                key = keep_min ? (key < other ? key : other) : (key > other ? key : other);
+            }
+        keys[t] = key;
+    } else {
     for (uint32_t x = t; x < N; x += GS) keys[x] = x < L ? (((uint64_t)f2ord(e_d1[x]) << 32) | x) : ~0ull;
     for (uint32_t k = 2; k <= N; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -257,6 +292,7 @@ __device__ __forceinline__ int process_list(uint32_t g, L3D_LDS char* lds, const
                 if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
             }
         }
+    }
     group_barrier<WPL>();
     for (uint32_t p = t; p < L; p += GS) pos_of[(uint32_t)keys[p] & 0xFFFFu] = (uint16_t)p;
     group_barrier<WPL>();
@@ -266,12 +302,11 @@ __device__ __forceinline__ int process_list(uint32_t g, L3D_LDS char* lds, const
     // Two passes: count (-> one reservation for the whole list), then write the records ----
     constexpr uint32_t kPer = (CAP + GS - 1) / GS;                      // hypotheses per thread
     uint32_t my_cnt[kPer], my_total = 0;
-    auto walk = [&](uint32_t i, auto&& emit) {
+    float my_R1[kPer], my_R2[kPer];                                      // squared windows of my hypotheses
+    auto walk = [&](uint32_t i, float R1, float R2, auto&& emit) {
         const uint32_t p = pos_of[i];
         const float a1 = e_d1[i], a2 = e_d2[i];
         const uint32_t tvi = e_tv[i];
-        const float kt = views[tvi].k, D = pairs[e_pf[i] & 0x7FFFFFFFu].cc_dist;
-        const float R1 = window_sq(a1, v.k, kt, D), R2 = window_sq(a2, v.k, kt, D);
         for (uint32_t q = p; q-- > 0;) {
             const uint64_t kq = keys[q];
             const float d = a1 - ord2f((uint32_t)(kq >> 32));
@@ -295,8 +330,13 @@ __device__ __forceinline__ int process_list(uint32_t g, L3D_LDS char* lds, const
     for (uint32_t c = 0; c < kPer; ++c) {
         const uint32_t i = c * GS + t;
         uint32_t cnt = 0;
+        my_R1[c] = my_R2[c] = -1.0f;
         if (c * GS < L) {
-            if (i < L) walk(i, [&](uint32_t) { ++cnt; });
+            if (i < L) {
+                const float kt = views[e_tv[i]].k, D = pairs[e_pf[i] & 0x7FFFFFFFu].cc_dist;
+                my_R1[c] = window_sq(e_d1[i], vk, kt, D); my_R2[c] = window_sq(e_d2[i], vk, kt, D);
+                walk(i, my_R1[c], my_R2[c], [&](uint32_t) { ++cnt; });
+            }
             uint32_t total;
             my_cnt[c] = H + group_scan<WPL>(cnt, total, red);          // offset of my records within the list
             H += total;
@@ -304,7 +344,6 @@ __device__ __forceinline__ int process_list(uint32_t g, L3D_LDS char* lds, const
         my_total += cnt;
     }
     if (H == 0) return 0;
-    const uint32_t pool = blockIdx.x % kListPools;
     if (t == 0) {
         red[8] = atomicAdd(&lp.cnt[pool * 16 + 3], H);
         red[9] = atomicAdd(&lp.cnt[pool * 16 + 4], 1u);
@@ -322,7 +361,7 @@ __device__ __forceinline__ int process_list(uint32_t g, L3D_LDS char* lds, const
             const uint32_t i = c * GS + t;
             if (i < L) {
                 uint32_t w = c0 + my_cnt[c];
-                walk(i, [&](uint32_t j) {
+                walk(i, my_R1[c], my_R2[c], [&](uint32_t j) {
                     CandRec r;
                     r.ij = (i << 16) | j; r.ref_i = e_ref[i]; r.ref_j = e_ref[j]; r.pf_i = e_pf[i];
                     r.tvj = e_tv[j] | (e_pf[j] & kHypInv);
@@ -360,13 +399,11 @@ __global__ void k_inv_records(const PairDesc* __restrict__ pairs, uint32_t first
     recs[(uint32_t)(off64[g] >> 32) + ipos] = r;
 }
 
+// WPL = 1: grid (segment blocks, views), one wave per segment; WPL = 4: fixed grid over the segments handed on
 template <int WPL>
-__global__ __launch_bounds__(256) void k_lists(uint32_t G, const ViewDev* __restrict__ views,
-                                               const PairDesc* __restrict__ pairs,
-                                               const uint32_t* __restrict__ seg_base,
+__global__ __launch_bounds__(256) void k_lists(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+                                               const ListView* __restrict__ lviews, const OutPair* __restrict__ opairs,
                                                const uint32_t* __restrict__ gseg_view,
-                                               const uint32_t* __restrict__ vout_off,
-                                               const uint32_t* __restrict__ vout_pairs,
                                                const unsigned long long* __restrict__ off64,
                                                const InvRec* __restrict__ inv, const Slot* __restrict__ slots,
                                                uint32_t uniform_K, const ListPools lp) {
@@ -374,11 +411,13 @@ __global__ __launch_bounds__(256) void k_lists(uint32_t G, const ViewDev* __rest
     typedef ListCfg<WPL> Cfg;
     if (WPL == 1) {
         const uint32_t wave = threadIdx.x >> 6;
-        const uint32_t g = blockIdx.x * 4 + wave;
-        if (g >= G) return;
-        const int rc = process_list<1>(g, (L3D_LDS char*)smem + wave * Cfg::BYTES, views, pairs, seg_base, gseg_view,
-                                       vout_off, vout_pairs, off64, inv, slots, uniform_K, lp);
+        const uint32_t vi = blockIdx.y, seg = blockIdx.x * 4 + wave;
+        if (seg >= lviews[vi].M) return;
+        const uint32_t pool = (blockIdx.y * gridDim.x + blockIdx.x) % kListPools;
+        const int rc = process_list<1>(vi, seg, pool, (L3D_LDS char*)smem + wave * Cfg::BYTES, views, pairs, lviews, opairs,
+                                       off64, inv, slots, uniform_K, lp);
         if (rc && lane_id() == 0) {
+            const uint32_t g = lviews[vi].seg_base + seg;
             const uint32_t L = (uint32_t)(off64[g + 1] - off64[g]);
             if (L > 65535u) atomicOr(&lp.flags[1], 1u);
             else if (L > ListCfg<4>::CAP) lp.listH[atomicAdd(&lp.flags[5], 1u)] = g;
@@ -388,8 +427,9 @@ __global__ __launch_bounds__(256) void k_lists(uint32_t G, const ViewDev* __rest
         const uint32_t n4 = lp.flags[4];
         for (uint32_t idx = blockIdx.x; idx < n4; idx += gridDim.x) {
             const uint32_t g = lp.list4[idx];
-            (void)process_list<WPL>(g, (L3D_LDS char*)smem, views, pairs, seg_base, gseg_view, vout_off, vout_pairs,
-                                    off64, inv, slots, uniform_K, lp);
+            const uint32_t vi = gseg_view[g];
+            (void)process_list<WPL>(vi, g - lviews[vi].seg_base, blockIdx.x % kListPools, (L3D_LDS char*)smem, views, pairs,
+                                    lviews, opairs, off64, inv, slots, uniform_K, lp);
             __syncthreads();
         }
     }
@@ -402,10 +442,9 @@ struct HugeScratch {
     uint32_t cap;
 };
 __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
-                                                    const uint32_t* __restrict__ seg_base,
+                                                    const ListView* __restrict__ lviews,
+                                                    const OutPair* __restrict__ opairs,
                                                     const uint32_t* __restrict__ gseg_view,
-                                                    const uint32_t* __restrict__ vout_off,
-                                                    const uint32_t* __restrict__ vout_pairs,
                                                     const unsigned long long* __restrict__ off64,
                                                     const InvRec* __restrict__ inv, const Slot* __restrict__ slots,
                                                     const ListPools lp, const HugeScratch hs) {
@@ -424,7 +463,9 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
         float* e_d1 = hs.d1 + base; float* e_d2 = hs.d2 + base;
         uint32_t* e_tv = hs.tv + base; uint32_t* e_ref = hs.ref + base; uint32_t* e_pf = hs.pf + base;
         uint64_t* keys = hs.key + base;
-        const uint32_t vi = gseg_view[g], seg = g - seg_base[vi];
+        const uint32_t vi = gseg_view[g];
+        const ListView lv = lviews[vi];
+        const uint32_t seg = g - lv.seg_base;
         const ViewDev& v = views[vi];
         const uint32_t ib = (uint32_t)(off64[g] >> 32), n_inv = (uint32_t)(off64[g + 1] >> 32) - ib;
         for (uint32_t x = t; x < n_inv; x += 256) { const InvRec r = inv[ib + x]; keys[x] = ((uint64_t)r.src_view << 32) | r.src_row; }
@@ -438,17 +479,16 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
             e_d1[rank] = r.dq1; e_d2[rank] = r.dq2; e_tv[rank] = r.src_view; e_ref[rank] = r.ref; e_pf[rank] = r.pair | kHypInv;
         }
         uint32_t pos = n_inv;
-        for (uint32_t q = vout_off[vi]; q < vout_off[vi + 1]; ++q) {
-            const uint32_t pi = vout_pairs[q];
-            const PairDesc& pd = pairs[pi];
-            const uint64_t row0 = pd.slot_off + (uint64_t)seg * pd.K;
-            for (uint32_t j0 = 0; j0 < pd.K; j0 += 256) {
+        for (uint32_t q = lv.q0; q < lv.q0 + lv.nq; ++q) {
+            const OutPair op = opairs[q];
+            const uint64_t row0 = op.slot_off + (uint64_t)seg * op.K;
+            for (uint32_t j0 = 0; j0 < op.K; j0 += 256) {
                 bool alive = false;
                 Slot s;
-                if (j0 + t < pd.K) { s = slots[row0 + j0 + t]; alive = s.tgt_seg != kEmpty && (s.flags & kSlotAlive); }
+                if (j0 + t < op.K) { s = slots[row0 + j0 + t]; alive = s.tgt_seg != kEmpty && (s.flags & kSlotAlive); }
                 uint32_t total;
                 const uint32_t at = pos + group_scan<4>(alive ? 1u : 0u, total, red);
-                if (alive && at < L) { e_d1[at] = s.dp1; e_d2[at] = s.dp2; e_tv[at] = pd.tgt; e_ref[at] = (uint32_t)(row0 + j0 + t); e_pf[at] = pi; }
+                if (alive && at < L) { e_d1[at] = s.dp1; e_d2[at] = s.dp2; e_tv[at] = op.tgt; e_ref[at] = (uint32_t)(row0 + j0 + t); e_pf[at] = op.pair; }
                 pos += total;
             }
         }
@@ -639,21 +679,35 @@ __global__ __launch_bounds__(256) void k_edges(const ViewDev* __restrict__ views
 }
 
 // ---- the chain as a monotone fixed point ------------------------------------------------------------------------
-// grid (header blocks, pools).  Sweep s runs only if sweep s-1 changed something (changed[] is zeroed by the host).
+// grid (header blocks, pools).  Launch s runs only if launch s-1 changed something (changed[] is zeroed by the host).
+// Inside a launch an undecided header looks again a few times: all headers are resident at once, so a bit set by
+// another thread (device-scope store / load, the L2 is the meeting point) travels down a dependency chain within the
+// same launch instead of one launch per link.
+constexpr uint32_t kSweepLooks = 2;
 __global__ void k_chain_sweep(const ListPools lp, uint8_t* __restrict__ positive, uint32_t* __restrict__ changed,
                               uint32_t sweep) {
     if (sweep && !changed[sweep - 1]) return;
     const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= min(lp.cnt[pool * 16 + 1], lp.hcap)) return;
     const HypHdr& h = lp.hyps[pool * lp.hcap + k];
-    if ((h.pair_flags & kHypInv) || positive[h.ref]) return;   // an inverse hypothesis exists iff its SOURCE is positive
-    for (uint32_t e = 0; e < h.edge_cnt; ++e) {
-        const EdgeRec& ed = lp.edges[h.edge_begin + e];
-        if (!(ed.j_cam & kEdgeInv) || positive[ed.ref_j]) {   // a fresh supporter always exists (line3D.cc:1680)
-            positive[h.ref] = 1;
-            changed[sweep] = 1;
-            return;
+    if (h.pair_flags & kHypInv) return;                       // an inverse hypothesis exists iff its SOURCE is positive
+    if (__hip_atomic_load(&positive[h.ref], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const uint32_t n = h.edge_cnt, e0 = h.edge_begin;
+    for (uint32_t look = 0; look < kSweepLooks; ++look) {
+        bool any_inverse = false;
+        for (uint32_t e = 0; e < n; ++e) {
+            const EdgeRec& ed = lp.edges[e0 + e];
+            const bool inv = (ed.j_cam & kEdgeInv) != 0;
+            any_inverse |= inv;
+            // a fresh supporter always exists (line3D.cc:1680)
+            if (!inv || __hip_atomic_load(&positive[ed.ref_j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(&positive[h.ref], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                changed[sweep] = 1;
+                return;
+            }
         }
+        if (!any_inverse) return;                             // cannot become positive
+        __builtin_amdgcn_s_sleep(8);
     }
 }
 
@@ -663,31 +717,45 @@ __global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ pos
                              const uint32_t* __restrict__ gseg_view, Slot* __restrict__ slots,
                              uint32_t* __restrict__ max_score_bits) {
     const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= min(lp.cnt[pool * 16 + 1], lp.hcap)) return;
-    HypHdr& h = lp.hyps[pool * lp.hcap + k];
-    const bool inv = (h.pair_flags & kHypInv) != 0;
-    const bool exists = !inv || positive[h.ref] != 0;
-    float score3D = 0.0f, cur = 0.0f;
-    uint32_t cur_cam = kEmpty;
-    if (exists)
-        for (uint32_t e = 0; e < h.edge_cnt; ++e) {
-            const EdgeRec ed = lp.edges[h.edge_begin + e];
-            if ((ed.j_cam & kEdgeInv) && !positive[ed.ref_j]) continue;
-            if (ed.tv_j == cur_cam) {
-                if (ed.sim > cur) { score3D -= cur; score3D += ed.sim; cur = ed.sim; }
-            } else {
-                score3D += ed.sim; cur = ed.sim; cur_cam = ed.tv_j;
+    const bool active = k < min(lp.cnt[pool * 16 + 1], lp.hcap);
+    float score3D = 0.0f;
+    uint32_t view = kEmpty;
+    if (active) {
+        HypHdr& h = lp.hyps[pool * lp.hcap + k];
+        const bool inv = (h.pair_flags & kHypInv) != 0;
+        const bool exists = !inv || positive[h.ref] != 0;
+        float cur = 0.0f;
+        uint32_t cur_cam = kEmpty;
+        if (exists)
+            for (uint32_t e = 0; e < h.edge_cnt; ++e) {
+                const EdgeRec ed = lp.edges[h.edge_begin + e];
+                if ((ed.j_cam & kEdgeInv) && !positive[ed.ref_j]) continue;
+                if (ed.tv_j == cur_cam) {
+                    if (ed.sim > cur) { score3D -= cur; score3D += ed.sim; cur = ed.sim; }
+                } else {
+                    score3D += ed.sim; cur = ed.sim; cur_cam = ed.tv_j;
+                }
             }
+        h.score3D = score3D;
+        h.state = exists ? kHypExists : 0u;
+        if (exists && !inv) slots[h.ref].score3D = score3D;
+        view = gseg_view[h.g];
+    }
+    // the view's maximum: neighbouring headers mostly belong to one view -- one atomic per (wave, view), and none
+    // when the view's maximum already exceeds the wave's
+    uint64_t todo = __ballot(score3D > 0.0f);
+    while (todo) {
+        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+        const uint32_t lv = __builtin_amdgcn_readlane(view, leader);
+        const bool mine = score3D > 0.0f && view == lv;
+        float mx = mine ? score3D : 0.0f;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+        if (lane_id() == leader) {
+            uint32_t* p = &max_score_bits[lv];
+            if (__float_as_uint(mx) > *(volatile uint32_t*)p) atomicMax(p, __float_as_uint(mx));
         }
-    h.score3D = score3D;
-    h.state = exists ? kHypExists : 0u;
-    if (exists) {
-        if (!inv) slots[h.ref].score3D = score3D;
-        // (most threads see a maximum that already exceeds theirs: the plain read skips the contended atomic)
-        if (score3D > 0.0f) {
-            uint32_t* mx = &max_score_bits[gseg_view[h.g]];
-            if (__float_as_uint(score3D) > *(volatile uint32_t*)mx) atomicMax(mx, __float_as_uint(score3D));
-        }
+        todo &= ~__ballot(mine);
     }
 }
 
@@ -889,26 +957,29 @@ hipError_t launch_inv_records(const PairDesc* pairs, uint32_t n_pairs, uint64_t 
     return hipGetLastError();
 }
 
-hipError_t launch_lists(uint32_t G, const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base,
-                        const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
-                        const unsigned long long* off64, const InvRec* inv, const Slot* slots, uint32_t uniform_K,
-                        SimConst sc, ListPools lp, uint32_t* seg_of_g, HugeScratchArgs hsa, hipStream_t st) {
-    if (!G) return hipSuccess;
+hipError_t launch_lists(uint32_t V, uint32_t max_M, const ViewDev* views, const PairDesc* pairs, const ListView* lviews,
+                        const OutPair* opairs, const uint32_t* gseg_view, const unsigned long long* off64,
+                        const InvRec* inv, const Slot* slots, uint32_t uniform_K, SimConst sc, ListPools lp,
+                        uint32_t* seg_of_g, HugeScratchArgs hsa, hipStream_t st) {
+    if (!V || !max_M) return hipSuccess;
     const size_t lds1 = 4 * (size_t)ListCfg<1>::BYTES, lds4 = ListCfg<4>::BYTES;
     hipError_t e = hipFuncSetAttribute((const void*)k_lists<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)k_lists<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_lists<1>), dim3((G + 3) / 4), dim3(256), lds1, st, G, views, pairs, seg_base, gseg_view, vout_off,
-                       vout_pairs, off64, inv, slots, uniform_K, lp);
-    hipLaunchKernelGGL((k_lists<4>), dim3(2048), dim3(256), lds4, st, G, views, pairs, seg_base, gseg_view, vout_off,
-                       vout_pairs, off64, inv, slots, uniform_K, lp);
+    for (uint32_t v0 = 0; v0 < V; v0 += 65535u) {   // grid.y limit
+        const uint32_t nv = V - v0 < 65535u ? V - v0 : 65535u;
+        hipLaunchKernelGGL((k_lists<1>), dim3((max_M + 3) / 4, nv), dim3(256), lds1, st, views, pairs, lviews + v0, opairs,
+                           gseg_view, off64, inv, slots, uniform_K, lp);
+    }
+    hipLaunchKernelGGL((k_lists<4>), dim3(2048), dim3(256), lds4, st, views, pairs, lviews, opairs, gseg_view, off64, inv,
+                       slots, uniform_K, lp);
     HugeScratch hs;
     hs.d1 = hsa.f32; hs.d2 = hsa.f32 + hsa.cap;
     hs.tv = hsa.u32; hs.ref = hsa.u32 + hsa.cap; hs.pf = hsa.u32 + 2 * (size_t)hsa.cap;
     hs.key = hsa.u64; hs.cap = hsa.cap;
-    hipLaunchKernelGGL(k_lists_huge, dim3(256), dim3(256), 0, st, views, pairs, seg_base, gseg_view, vout_off, vout_pairs,
-                       off64, inv, slots, lp, hs);
+    hipLaunchKernelGGL(k_lists_huge, dim3(256), dim3(256), 0, st, views, pairs, lviews, opairs, gseg_view, off64, inv,
+                       slots, lp, hs);
     hipLaunchKernelGGL(k_edges, dim3((lp.scap + 3) / 4, kListPools), dim3(256), 0, st, views, pairs, gseg_view, sc, lp,
                        seg_of_g);
     return hipGetLastError();

@@ -602,13 +602,33 @@ __global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __
         for (int i = 0; i < 9; ++i) F[i] = pd.F[i];
         const float4 s4 = vs.seg4[src];
         const SegX sx = vs.segx[src];
+        // the row's two epipolar lines for the conservative fp32 pre-filter (as the prologue of k_match_pairs): only
+        // its survivors go through the double-precision test
+        float e1x = 0, e1y = 0, e1z = 0, e2x = 0, e2y = 0, e2z = 0;
+        bool live = false;
+        {
+            const d3 e1 = mul33(F, d3{(double)s4.x, (double)s4.y, 1.0});
+            const d3 e2 = mul33(F, d3{(double)s4.z, (double)s4.w, 1.0});
+            const double n1 = sqrt(e1.x * e1.x + e1.y * e1.y), n2 = sqrt(e2.x * e2.x + e2.y * e2.y);
+            if (n1 > 0.0 && n2 > 0.0) {
+                const double cx = (double)vt.cx, cy = (double)vt.cy;
+                e1x = (float)(e1.x / n1); e1y = (float)(e1.y / n1); e1z = (float)((e1.z + (e1.x * cx + e1.y * cy)) / n1);
+                e2x = (float)(e2.x / n2); e2y = (float)(e2.y / n2); e2z = (float)((e2.z + (e2.x * cx + e2.y * cy)) / n2);
+                live = true;
+            }
+        }
         // ---- every target through the acceptance test; accepted ones in ascending target order ----
         uint32_t n = 0;                           // accepted so far (block-uniform)
         for (uint32_t c0 = 0; c0 < Mt; c0 += kTieBlock) {
             const uint32_t cc = c0 + tid;
             bool acc = false;
             PairResult res{};
-            if (cc < Mt) acc = exact_pair(F, s4, vt.seg4[cc], sx, vt.segx[cc], vs.C, vt.C, thr, res);
+            if (cc < Mt && live) {
+                const SegF f = vt.segf[cc];
+                const v4f q = {f.qx, f.qy, f.dx, f.dy};
+                if (prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q, thr))
+                    acc = exact_pair(F, s4, vt.seg4[cc], sx, vt.segx[cc], vs.C, vt.C, thr, res);
+            }
             const uint64_t m = __ballot(acc);
             if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(m);
             __syncthreads();

@@ -256,7 +256,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_off64.release(); c->d_cnt64.release(); c->d_off64s.release(); c->d_scan64_tmp.release(); c->d_tot64.release();
     c->d_huge_u64.release(); c->d_inv_recs.release(); c->d_lzero.release(); c->d_list4.release(); c->d_listH.release();
     c->d_seg_of_g.release(); c->d_huge_u32.release(); c->d_huge_f32.release(); c->d_ledges.release(); c->d_lhyps.release();
-    c->d_lsegs.release(); c->d_lcands.release(); c->d_lchdrs.release();
+    c->d_lsegs.release(); c->d_lcands.release(); c->d_lchdrs.release(); c->d_ltab.release(); c->h_ltab.release();
     c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
     c->d_chunk_band.release(); c->d_tgt_sf.release(); c->d_tgt_band.release();
     c->d_row_counts.release();
@@ -725,7 +725,8 @@ int l3d_match_finish(l3d_ctx* c) {
 // One pass of the sparse phase B from the zeroed work arrays to the view medians (k_lists.hip): the list pass (only
 // when `with_lists`), the chain sweeps, scores, filterMatches, outputs.  Everything is enqueued; the results of the
 // run (totals, overflow / convergence flags, pool fill, medians) are copied to pinned memory for the caller's sync.
-static constexpr uint32_t kChainSweeps = 12;   // sweeps enqueued blindly (each one is a no-op once nothing changes)
+static constexpr uint32_t kChainSweeps = 10;   // chain launches enqueued blindly (each one is a no-op once nothing changes;
+                                               // a launch follows a dependency chain for several links, k_chain_sweep)
 
 static ListPools list_pools(l3d_ctx* c) {
     ListPools lp;
@@ -765,9 +766,13 @@ static int finish_pass(l3d_ctx* c, bool with_lists, bool more_sweeps) {
         L3D_HIP_CHECK(hipMemsetAsync(c->d_positive.p, 0, std::max<uint64_t>(c->n_slots, 1), st));
         L3D_HIP_CHECK(hipMemsetAsync(c->d_seg_of_g.p, 0xFF, ((size_t)G + 1) * 4, st));
         const HugeScratchArgs hsa{c->d_huge_f32.p, c->d_huge_u32.p, (uint64_t*)c->d_huge_u64.p, c->huge_cap};
-        L3D_HIP_CHECK(launch_lists(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p, c->d_vout_off.p,
-                                   c->d_vout_pairs.p, c->d_off64.p, c->d_inv_recs.p, c->d_slots.p,
-                                   c->kNN > 0 ? (uint32_t)c->kNN : 0u, simc, lp, c->d_seg_of_g.p, hsa, st));
+        uint32_t max_M = 0;
+        for (auto* v : c->order) max_M = std::max(max_M, v->M);
+        const ListView* lviews = (const ListView*)c->d_ltab.p;
+        const OutPair* opairs = (const OutPair*)(c->d_ltab.p + (size_t)V * 32);
+        L3D_HIP_CHECK(launch_lists(V, max_M, c->d_views.p, c->d_pairs.p, lviews, opairs, c->d_gseg_view.p, c->d_off64.p,
+                                   c->d_inv_recs.p, c->d_slots.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, simc, lp,
+                                   c->d_seg_of_g.p, hsa, st));
     } else {
         // keep the records of the list pass and what the sweeps have found; reset what the later stages accumulate
         L3D_HIP_CHECK(hipMemsetAsync(changed, 0, (z.words - z.changed) * 4, st));
@@ -822,22 +827,28 @@ static int match_finish_impl(l3d_ctx* c) {
         for (auto* v : c->order) max_M = std::max(max_M, v->M);
         L3D_HIP_CHECK(launch_fill_gseg_view(c->d_seg_base.p, V, max_M, c->d_gseg_view.p, st));
     }
-    // outgoing pairs of every view (ascending target), for the fresh part of the lists
-    // staged as [vout_off (V+1) | vout_pairs (P)] in one pinned buffer
-    c->vout_off.assign(V + 1, 0);
-    L3D_HIP_CHECK(c->h_vout.reserve((size_t)V + 1 + P + 1));
+    // per-view / per-outgoing-pair tables of the list pass (l3d_lists.h), staged in one pinned buffer:
+    // [ListView x V | OutPair x P], outgoing pairs of a view in ascending target order
     {
+        static_assert(sizeof(ListView) == 32 && sizeof(OutPair) == 32, "table layout");
+        L3D_HIP_CHECK(c->h_ltab.reserve(((size_t)V + P + 1) * 32));
+        ListView* hv = (ListView*)c->h_ltab.p;
+        OutPair* hp = (OutPair*)(c->h_ltab.p + (size_t)V * 32);
         uint32_t n = 0;
-        uint32_t* vp = c->h_vout.p + (V + 1);
         for (uint32_t vi = 0; vi < V; ++vi) {
-            for (uint32_t p : c->order[vi]->out_pairs) vp[n++] = p;
-            c->vout_off[vi + 1] = n;
+            ListView& lv = hv[vi];
+            lv = ListView{};
+            lv.seg_base = c->seg_base[vi]; lv.M = c->order[vi]->M; lv.q0 = n; lv.k = c->order[vi]->k;
+            for (uint32_t p : c->order[vi]->out_pairs) {
+                const PairDesc& pd = c->pairs[p];
+                OutPair op{};
+                op.slot_off = pd.slot_off; op.tgt = pd.tgt; op.pair = p; op.K = pd.K;
+                hp[n++] = op;
+            }
+            lv.nq = n - lv.q0;
         }
-        std::memcpy(c->h_vout.p, c->vout_off.data(), ((size_t)V + 1) * 4);
-        L3D_HIP_CHECK(c->d_vout_pairs.reserve((size_t)n + 1));
-        L3D_HIP_CHECK(c->d_vout_off.reserve(V + 1));
-        L3D_HIP_CHECK(hipMemcpyAsync(c->d_vout_off.p, c->h_vout.p, ((size_t)V + 1) * 4, hipMemcpyHostToDevice, st));
-        if (n) L3D_HIP_CHECK(hipMemcpyAsync(c->d_vout_pairs.p, vp, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        L3D_HIP_CHECK(c->d_ltab.reserve(((size_t)V + P + 1) * 32));
+        L3D_HIP_CHECK(hipMemcpyAsync(c->d_ltab.p, c->h_ltab.p, ((size_t)V + n) * 32, hipMemcpyHostToDevice, st));
     }
     // ---- pre-pass: orientation flags and hypothesis counters of the pairs that do not carry them yet ----
     // (bounded kNN: done by the match epilogue / the exchange expansion; what is left are the pairs of the keep-all
@@ -921,6 +932,7 @@ static int match_finish_impl(l3d_ctx* c) {
     c->n_ents = h[0];
     c->n_surv = h[2]; c->n_hyps = h[3];
     c->tm.list_entries = h[0];
+    for (uint32_t s2 = 0; s2 < kChainSweeps; ++s2) c->tm.chain_sweeps += h[36 + s2] ? 1u : 0u;   // of the last round
     {
         uint64_t ne = 0;
         for (uint32_t q = 0; q < kListPools; ++q) ne += h[128 + q * 16];

@@ -199,6 +199,8 @@ struct l3d_ctx {
     DevBuf<CandHdr> d_lchdrs;
     uint32_t lp_ecap = 0, lp_hcap = 0, lp_scap = 0, lp_ccap = 0, huge_cap = 0;   // per-pool capacities (grow on overflow, kept across calls)
     PinnedBuf<uint32_t> h_fin;
+    PinnedBuf<char> h_ltab;
+    DevBuf<char> d_ltab;   // [ListView x V | OutPair x P]
     std::vector<uint32_t> h_surv_off, h_hyp_off;    // lazily fetched for the accessors
     bool host_offsets_valid = false;
     // affinity

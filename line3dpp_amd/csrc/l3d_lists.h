@@ -24,6 +24,21 @@ struct InvRec {
 };
 static_assert(sizeof(InvRec) == 24, "InvRec is 24 bytes");
 
+// per view / per outgoing pair of a view: what the list pass needs of ViewDev / PairDesc, packed so that a wave gets
+// it with one or two loads instead of a chain of dependent ones (view -> pair list -> pair -> slot)
+struct ListView {
+    uint32_t seg_base, M;     // first global segment id, segments
+    uint32_t q0, nq;          // outgoing pairs [q0, q0 + nq) in the OutPair table, ascending target view
+    float k;                  // View::k_
+    uint32_t pad[3];
+};
+struct OutPair {
+    uint64_t slot_off;        // first slot of the pair
+    uint32_t tgt, pair, K;    // target view, pair index, slots per source segment
+    uint32_t pad[3];
+};
+static_assert(sizeof(ListView) == 32 && sizeof(OutPair) == 32, "table records are 32 bytes");
+
 // hypothesis i of a list is supported by hypothesis j (other camera, similarityForScoring > 0.5): sim is the value
 struct EdgeRec {
     uint32_t ref_j;      // slot of the supporter (its existence bit lives in positive[ref_j] when it is inverse)
