@@ -228,7 +228,10 @@ using namespace l3d;
 extern "C" {
 
 const char* l3d_last_error(void) { return g_err.c_str(); }
-const char* l3d_build_info(void) { return "libl3dpp_hip gfx950 hip fp-contract=off"; }
+#ifndef L3D_BUILD_ID
+#define L3D_BUILD_ID "unknown"
+#endif
+const char* l3d_build_info(void) { return "libl3dpp_hip gfx950 hip fp-contract=off build=" L3D_BUILD_ID; }
 
 l3d_ctx* l3d_create(int device, void* stream) {
     if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed: no usable HIP device"); return nullptr; }

@@ -1,0 +1,24 @@
+"""Candidate counters of phase A from the -DL3D_STATS build, as JSON on stdout:
+   L3D_LIB=gpurun_scratch/libl3dpp_hip_stats.so python tools/phase_a_stats.py C1"""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from line3dpp_amd import _lib
+from line3dpp_amd.api import Line3D
+from line3dpp_amd.scene import make_config
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C1"
+sc = make_config(cfg)
+g = Line3D(); g.add_scene(sc)
+L = _lib.load()
+out = (C.c_ulonglong * 8)()
+L.l3d_debug_stats(out, 1)
+assert g.matchBegin() and g.matchPairs(0, len(g.pairs()[0]))
+L.l3d_debug_stats(out, 0)
+nominal = sc.pair_tests()[0]
+print(json.dumps({"config": cfg, "build_info": L.l3d_build_info().decode(), "nominal_pair_tests": nominal,
+                  "prefilter_tests": int(out[0]), "exact_tests": int(out[1]), "passed_overlap": int(out[2]),
+                  "accepted": int(out[3]), "prefilter_fraction_of_nominal": out[0] / nominal}))
