@@ -36,7 +36,9 @@ def run_cpu_baseline(scene, args, pair_tests, kNN, l3d):
     consecutive views at the configured size and neighbour count.  Returns (cpu_baseline, parity)."""
     from oracle import oracle as O
     from tests import helpers as H
-    use_ref = O.have_reference()     # the reference's own line3D.cc/view.cc (oracle/_ref), else the restatement
+    # the reference's own line3D.cc/view.cc (oracle/_ref) in its Release configuration (-O3 -DNDEBUG, CMakeLists.txt:3;
+    # tests/test_reference_pin.py: results byte-identical to the -O2 build the parity tests use), else the restatement
+    use_ref = "release" if O.have_release() else O.have_reference()
 
     def Oracle(threads):
         return O.Oracle(threads=threads, reference=use_ref)
@@ -72,7 +74,8 @@ def run_cpu_baseline(scene, args, pair_tests, kNN, l3d):
            "kind": "reference" if use_ref else "port", "host_cpus": ncpu, "thread_scan_M_per_s": scan,
            "sample": f"{what} ({sample_tests} pair tests, {cdt:.2f} s) with the thread count that scored best on an "
                      f"8-view sub-scene; " +
-                     ("the reference's own OpenMP CPU path (line3D.cc/view.cc compiled in place, oracle/_ref)" if use_ref
+                     ("the reference's own OpenMP CPU path (line3D.cc/view.cc compiled in place, oracle/_ref" +
+                      (", -O3 -DNDEBUG)" if use_ref == "release" else ", -O2)") if use_ref
                       else "OpenMP oracle = restatement of the reference CPU path")}
     # ---- parity of the HIP result with that reference run (same scene, same parameters) ----
     if sample is scene:

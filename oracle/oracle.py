@@ -11,7 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libl3d_oracle.so")
-_REF_SO = os.path.join(_HERE, "_ref", "libl3d_ref.so")   # the reference's own sources, compiled in place
+_REF_SO = os.path.join(_HERE, "_ref", "libl3d_ref.so")   # the reference's own sources, compiled in place (-O2, asserts on)
+_REL_SO = os.path.join(_HERE, "_ref", "libl3d_ref_release.so")   # the same at -O3 -DNDEBUG (the reference's Release build)
 
 # commons.h:186-203
 MATCH_DTYPE = np.dtype([
@@ -40,13 +41,20 @@ def have_reference():
     return os.path.exists(_REF_SO)
 
 
+def have_release():
+    return os.path.exists(_REL_SO)
+
+
 def lib(reference=False):
-    key = "ref" if reference else "port"
+    """reference: False = the restatement, True = the reference's own code (-O2 build), "release" = its -O3 -DNDEBUG
+    build (CMAKE_BUILD_TYPE Release of the reference's CMakeLists.txt:3)"""
+    key = "rel" if reference == "release" else ("ref" if reference else "port")
     if key not in _libs:
         if reference:
-            if not have_reference():
-                raise RuntimeError("oracle/_ref/libl3d_ref.so is missing (needs /root/reference to build)")
-            L = C.CDLL(_REF_SO)
+            path = _REL_SO if key == "rel" else _REF_SO
+            if not os.path.exists(path):
+                raise RuntimeError(path + " is missing (needs /root/reference to build)")
+            L = C.CDLL(path)
         else:
             build()
             L = C.CDLL(_SO)

@@ -835,8 +835,24 @@ def test_real_testdata_c0_parity_and_fixture_plausibility():
     if O.have_reference():
         r = O.Oracle(threads=1, reference=True)
         r.add_scene(sc); r.match_images(); r.reconstruct(3)
-        theirs = [frozenset(map(tuple, np.asarray(L["residuals"]).reshape(-1, 2).tolist())) for L in r.lines()]
+        rl = r.lines()
+        theirs = [frozenset(map(tuple, np.asarray(L["residuals"]).reshape(-1, 2).tolist())) for L in rl]
         assert set(mine) == set(theirs) and len(mine) == len(theirs)
+        # final 3D end points of EVERY line against the reference's own code on the real data: north_star's 1e-4,
+        # relative to the scene extent (an end point is a position, its coordinates have no scale of their own)
+        by_key = {k: L for k, L in zip(theirs, rl)}
+        pts = np.concatenate([np.concatenate([L["collinear3Dsegments"]["P1"], L["collinear3Dsegments"]["P2"]], 0) for L in lines], 0)
+        extent = float(np.linalg.norm(np.percentile(pts, 95, axis=0) - np.percentile(pts, 5, axis=0)))
+        worst_ep, n_ep = 0.0, 0
+        for L, key in zip(lines, mine):
+            a = np.concatenate([L["collinear3Dsegments"]["P1"], L["collinear3Dsegments"]["P2"]], 1)
+            b = np.asarray(by_key[key]["collinear3Dsegments"])[:, :6]
+            assert a.shape == b.shape, "collinear 3D segments of a line"
+            for p, q in zip(a, b):
+                qs = np.concatenate([q[3:], q[:3]])
+                worst_ep = max(worst_ep, min(np.abs(p - q).max(), np.abs(p - qs).max()) / extent)
+                n_ep += 1
+        assert n_ep > 1500 and worst_ep < H.REL_TOL, (n_ep, worst_ep, extent)
     d = np.load(C0_FILE)
     inv = {}
     for i, m in enumerate(mine):

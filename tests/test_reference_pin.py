@@ -59,6 +59,16 @@ def test_parameter_modes_equal_reference_code(params):
     assert_identical(run(sc, True, **params), run(sc, False, **params), sc)
 
 
+def test_release_build_of_the_reference_gives_identical_results():
+    """oracle/_ref/libl3d_ref_release.so = the same reference sources at -O3 -DNDEBUG (the reference's own Release
+    configuration, CMakeLists.txt:3), which bench.py times as cpu_baseline: byte-identical to the -O2 build."""
+    if not O.have_release():
+        pytest.skip("release build of oracle/_ref not present")
+    sc = make_scene(10, 500, n_neighbors=6, seed=17)
+    assert_identical(run(sc, "release"), run(sc, True), sc)
+    assert_identical(run(sc, "release", threads=4), run(sc, True), sc, ordered=False)
+
+
 def test_asymmetric_neighbours_equal_reference_code():
     sc = make_scene(7, 220, n_neighbors=4, seed=19)
     remap = {i: 10 + 7 * i for i in range(7)}
