@@ -181,3 +181,108 @@ def format_3d_lines_bin(lines, lib_version=10):
             out.append(struct.pack("<II", int(cam), int(seg)))
         out.append(struct.pack("<I", int(L["reference_view"])))
     return b"".join(out)
+
+
+# ---- input side: the segment cache and VisualSfM .nvm files ---------------------------------------
+# Segment cache = what Line3D::detectLineSegments stores / loads per image when `load_segments` is set
+# (line3D.cc:295-309, 362-366): "<data folder>/segments_L3D++_<camID>_<width>x<height>_<max segments>.bin", a
+# boost::archive::binary_oarchive of L3DPP::DataArray<float4> (dataArray.h:352-374): width_, height_, real_width_
+# (u32), pitchCPU_, strideCPU_, pitchGPU_, strideGPU_ (u64), then real_width_ * height_ float4 elements, each through
+# serialize(float4) (dataArray.h:62-69: the class header of float4 appears once, before the first element).
+# width_ = number of segments, height_ = 1; the host row is padded to a multiple of 32 bytes (dataArray.h:111-122), so
+# an odd number of segments carries one padding element.
+def segment_cache_name(camID, width, height, max_segments=3000):
+    return f"segments_L3D++_{camID}_{width}x{height}_{max_segments}.bin"
+
+
+def _data_array_geometry(n):
+    pitch = n * 16
+    real = n + (0 if pitch % 32 == 0 else (32 - pitch % 32) // 16)
+    return real, real * 16, real           # real_width_, pitchCPU_, strideCPU_
+
+
+def format_segment_cache(segs, lib_version=10):
+    """the bytes serializeToFile(name, DataArray<float4>(n, 1, false, segments)) writes for [n,4] float32 (x1,y1,x2,y2)"""
+    import struct
+    segs = np.ascontiguousarray(segs, np.float32).reshape(-1, 4)
+    n = len(segs)
+    real, pitch, stride = _data_array_geometry(n)
+    data = np.zeros((real, 4), np.float32)
+    data[:n] = segs
+    return b"".join([struct.pack("<Q", len(_BIN_SIG)), _BIN_SIG, struct.pack("<H", lib_version), bytes([4, 8, 4, 8, 1, 0, 0, 0]),
+                     _CLASS_HDR, struct.pack("<IIIQQQQ", n, 1, real, pitch, stride, 0, 0),
+                     _CLASS_HDR if real else b"", data.tobytes()])
+
+
+def read_segment_cache(path):
+    """-> [n,4] float32 segments of a cache file written by the reference (or by format_segment_cache)"""
+    r = _Reader(open(path, "rb").read())
+    if r.take("Q") != len(_BIN_SIG) or r.b[r.p:r.p + len(_BIN_SIG)] != _BIN_SIG:
+        raise ValueError(f"{path}: not a boost binary archive")
+    r.p += len(_BIN_SIG)
+    r.take("H")
+    if bytes(r.b[r.p:r.p + 8]) != bytes([4, 8, 4, 8, 1, 0, 0, 0]):
+        raise ValueError(f"{path}: written on a platform with other type sizes / endianness")
+    r.p += 8
+    r.hdr("DataArray<float4>")
+    width, height, real, pitch, stride, _, _ = r.take("IIIQQQQ")
+    if height != 1 or real < width or pitch != real * 16 or stride != real:
+        raise ValueError(f"{path}: not a one-row DataArray<float4> (width {width}, height {height}, real width {real})")
+    if real:
+        r.hdr("float4")
+    data = np.frombuffer(r.b, np.float32, real * 4, r.p).reshape(real, 4)
+    r.p += real * 16
+    if r.p != len(r.b):
+        raise ValueError(f"{path}: {len(r.b) - r.p} trailing bytes")
+    return data[:width].copy()
+
+
+# VisualSfM .nvm as main_vsfm.cpp:144-250 reads it: two ignored lines, the number of cameras, one line per camera
+# (file name, focal length, quaternion w x y z, camera centre, radial distortion, 0), an ignored line, the number of 3D
+# points, one line per point (position, colour, number of measurements, then per measurement camera index, feature
+# index, x, y).
+def nvm_rotation(qw, qx, qy, qz):
+    """main_vsfm.cpp:188-199"""
+    return np.array([[1.0 - 2.0 * qy * qy - 2.0 * qz * qz, 2.0 * qx * qy - 2.0 * qz * qw, 2.0 * qx * qz + 2.0 * qy * qw],
+                     [2.0 * qx * qy + 2.0 * qz * qw, 1.0 - 2.0 * qx * qx - 2.0 * qz * qz, 2.0 * qy * qz - 2.0 * qx * qw],
+                     [2.0 * qx * qz - 2.0 * qy * qw, 2.0 * qy * qz + 2.0 * qx * qw, 1.0 - 2.0 * qx * qx - 2.0 * qy * qy]])
+
+
+def read_nvm(path):
+    """-> list of cameras in file order (the reference uses the index as camID): dict(filename, focal, R, t, C,
+    distortion, worldpoints = ids of the 3D points it sees, median_depth = sorted distances to them [n/2] as float32,
+    main_vsfm.cpp:300-303; None for a camera without points, which the reference skips)"""
+    with open(path) as f:
+        lines = f.read().split("\n")
+    pos = 2
+    n_cams = int(lines[pos].split()[0]); pos += 1
+    if n_cams == 0:
+        raise ValueError("No aligned cameras in NVM file!")          # main_vsfm.cpp:157-161
+    cams = []
+    for i in range(n_cams):
+        tok = lines[pos].split(); pos += 1
+        focal, qw, qx, qy, qz, cx, cy, cz, dist = (float(x) for x in tok[1:10])
+        R = nvm_rotation(qw, qx, qy, qz)
+        Cc = np.array([cx, cy, cz])
+        cams.append(dict(filename=tok[0], focal=np.float32(focal), R=R, t=-R @ Cc, C=Cc, distortion=np.float32(dist),
+                         worldpoints=[], _depths=[]))
+    pos += 1
+    n_pts = int(lines[pos].split()[0]); pos += 1
+    for i in range(n_pts):
+        tok = lines[pos].split(); pos += 1
+        p = np.array([float(tok[0]), float(tok[1]), float(tok[2])])
+        nv = int(tok[6])
+        for j in range(nv):
+            cam = int(tok[7 + 4 * j])
+            cams[cam]["worldpoints"].append(i)
+            cams[cam]["_depths"].append(np.float32(np.linalg.norm(p - cams[cam]["C"])))
+    for c in cams:
+        d = sorted(c.pop("_depths"))
+        c["median_depth"] = d[len(d) // 2] if d else None
+    return cams
+
+
+def nvm_intrinsics(focal, width, height):
+    """K as main_vsfm.cpp:272-282 builds it: principal point at the image centre (float arithmetic there)"""
+    return np.array([[np.float32(focal), 0.0, np.float32(width) / np.float32(2.0)],
+                     [0.0, np.float32(focal), np.float32(height) / np.float32(2.0)], [0.0, 0.0, 1.0]], np.float64)
