@@ -97,6 +97,121 @@ class _StubLine3D:
         return bool(self.done.all())
 
 
+class _ReplayContext:
+    """A CPU context behind the interface match_images_sharded drives (line3dpp_amd.api.Line3D): phase A of a pair
+    range is COMPUTED here (the restatement's matchingCPU, pair by pair, laid out as the HIP path lays slots out), the
+    index buffer the ranks exchange is this object's real buffer, the expansion checks that what arrived for a foreign
+    pair is what that pair's owner computed (against its own recomputation), and matchFinish only succeeds when every
+    pair is present -- then it produces the scene's real results (surviving matches, A_) for the cross-rank comparison.
+    No GPU, no stub answers: a wrong range, a missing broadcast or a mis-sized slice changes the outcome."""
+
+    def __init__(self, scene, kNN):
+        from line3dpp_amd._lib import EMPTY
+        from oracle.oracle import Oracle
+        self.scene, self.kNN, self.EMPTY = scene, kNN, EMPTY
+        self.o = Oracle(threads=1); self.o.add_scene(scene)
+        self._M = {v.cam: len(v.segs) for v in scene.views}
+        self.state, self.log = "idle", []
+        self.L, self.h = self, None
+
+    def _pair_indices(self, s, t):
+        m, off = self.o.match_pair(int(s), int(t))
+        sl = np.full((self._M[int(s)], self.kNN), self.EMPTY, np.uint32)
+        for r in range(self._M[int(s)]):
+            rows = m[off[r]:off[r + 1]]
+            sl[r, :len(rows)] = rows["tgt_seg"]          # the reference's own row order (priority_queue pops)
+        return sl.reshape(-1)
+
+    def matchBegin(self, **kw):
+        assert self.state == "idle"
+        self.o.begin_match(kNN=self.kNN)
+        _, prs = self.scene.pair_tests()
+        self.pairs_ = np.array(prs, np.uint32).reshape(-1, 2)
+        sizes = [self._M[int(s)] * self.kNN for s, _ in self.pairs_]
+        self.offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        self.n_slots = int(self.offs[-1])
+        self.idx = np.full(self.n_slots, 0xDEADBEEF, np.uint32)        # poison: an unexchanged slice is noticed
+        self.present = np.zeros(len(self.pairs_), bool)
+        self.packed = np.zeros(len(self.pairs_), bool)
+        self.own = {}
+        self.state = "begun"; self.log.append("begin")
+        return True
+
+    def pairs(self):
+        return self.pairs_, self.offs[:-1]
+
+    def matchPairs(self, first, count):
+        if self.state != "begun":
+            return False
+        for p in range(first, first + count):
+            self.own[p] = self._pair_indices(*self.pairs_[p])
+            self.present[p] = True
+        return True
+
+    def packSlotIndices(self, first, count):
+        for p in range(first, first + count):
+            if p not in self.own:
+                return False
+            self.idx[int(self.offs[p]):int(self.offs[p + 1])] = self.own[p]
+            self.packed[p] = True
+        return True
+
+    def slot_index_buffer(self):
+        return self.idx, self.n_slots
+
+    def expandSlotIndices(self, first, count):
+        for p in range(first, first + count):
+            if self.present[p]:
+                return False
+            got = self.idx[int(self.offs[p]):int(self.offs[p + 1])]
+            if not np.array_equal(got, self._pair_indices(*self.pairs_[p])):
+                return False
+            self.present[p] = True
+        return True
+
+    def matchAbort(self):
+        if self.state == "begun":
+            self.o.end_match()
+        self.state = "idle"; self.log.append("abort")
+        return True
+
+    def matchFinish(self):
+        if self.state != "begun" or not self.present.all():
+            return False
+        self.o.end_match()
+        self.o.match_images(kNN=self.kNN); self.o.compute_affinity()
+        self.state = "matched"; self.log.append("finish")
+        return True
+
+    def digest(self):
+        import hashlib
+        h = hashlib.sha256()
+        for v in self.scene.views:
+            m, off = self.o.matches(v.cam)
+            h.update(m.tobytes()); h.update(off.tobytes())
+        e, l = self.o.affinity()
+        h.update(e.tobytes()); h.update(l.tobytes())
+        return h.hexdigest()
+
+
+def _replayed_run(dist, rank, world, scene, kNN):
+    """match_images_sharded over gloo on a context that really matches its pair range; returns the result digest"""
+    ctx = _ReplayContext(scene, kNN)
+    real = dist.device_tensor
+    dist.device_tensor = lambda arr, nbytes, device: torch.from_numpy(arr.view(np.uint8))[:nbytes]
+    try:
+        ok = dist.match_images_sharded(ctx, rank, world, device=None, kNN=kNN)
+    finally:
+        dist.device_tensor = real
+    M = ctx._M
+    ranges = dist.pair_ranges([M[int(s)] * M[int(t)] for s, t in ctx.pairs_], world)
+    mine = set(range(ranges[rank][0], ranges[rank][0] + ranges[rank][1]))
+    assert ok and ctx.log == ["begin", "finish"], ctx.log
+    assert set(ctx.own) == mine, "a rank matches exactly its own range"
+    assert not (ctx.idx == 0xDEADBEEF).any(), "every slice arrived"
+    return ctx.digest()
+
+
 def _sharded_control_flow(dist, rank, world, pairs, offs, n_slots, M, idx_full):
     """match_images_sharded end to end over gloo with the stub: own range matched and packed, every foreign pair
     expanded from what the exchange delivered, finish only after that"""
@@ -155,7 +270,12 @@ def _worker(rank, world, port, q):
         ok = ok and bool(np.array_equal(buf4.numpy(), idx_full)) and how4 == how
         covered = covered and sum(h - l for l, h in br4) == len(idx_full) == 4 * n_slots
         ok = ok and _sharded_control_flow(dist, rank, world, pairs, offs, n_slots, M, idx_full)
-        q.put((rank, ok, covered, [c for _, c in ranges]))
+        # the same control flow on a context that computes: every rank ends with the single-process result
+        digest = _replayed_run(dist, rank, world, scene, 5)
+        single = _ReplayContext(scene, 5)
+        assert single.matchBegin() and single.matchPairs(0, len(single.pairs_)) and single.matchFinish()
+        ok = ok and digest == single.digest()
+        q.put((rank, ok, covered, [c for _, c in ranges], digest))
     finally:
         dist_t.destroy_process_group()
 
@@ -172,6 +292,7 @@ def test_sharded_exchange_reproduces_single_process_buffer(world):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, ok, covered, counts in res:
+    for rank, ok, covered, counts, digest in res:
         assert ok and covered, (rank, ok, covered)
         assert sum(counts) == 12 and all(c > 0 for c in counts)
+    assert len({r[4] for r in res}) == 1, "all ranks hold the same surviving matches and affinity matrix"
