@@ -74,7 +74,9 @@ typedef enum l3d_status {
     L3D_ERR_NO_VIEWS = -6,     /* line3D.cc:385 */
     L3D_ERR_STATE = -7,        /* call order */
     L3D_ERR_HIP = -8,          /* HIP runtime error */
-    L3D_ERR_LIMIT = -9         /* size limit of this build */
+    L3D_ERR_LIMIT = -9,        /* size limit of this build */
+    L3D_ERR_RETRY = -10        /* l3d_match_finish after l3d_lists_shard: the record pools were enlarged, repeat
+                                * l3d_lists_shard + the exchange of its slabs + l3d_match_finish (every rank gets it) */
 } l3d_status;
 
 typedef struct l3d_ctx l3d_ctx;
@@ -137,6 +139,17 @@ int l3d_slot_index_buffer(l3d_ctx*, void** dev_ptr, uint64_t* n_slots);
 int l3d_pack_slot_indices(l3d_ctx*, uint32_t first, uint32_t count);
 int l3d_expand_slot_indices(l3d_ctx*, uint32_t first, uint32_t count);
 int l3d_match_finish(l3d_ctx*);
+/* Phase B sharded over ranks as well (optional step between the slot exchange and l3d_match_finish; every pair must be
+ * present): the dense part of phase B -- one pass over every 2D segment's hypothesis list that finds the supporting
+ * pairs of similarityForScoring (line3D.cc:1208-1294, 1417-1446) -- is run for the views of rank `rank` of `world`
+ * only (contiguous view ranges of equal segment count).  Its output records live in pools; rank r fills the pools
+ * [r * 256/world, (r+1) * 256/world) of four arrays (edges, headers, segment headers, pool counters).  On return
+ * slab_ptr[k] / slab_bytes[k] describe THIS rank's slab of array k and full_ptr[k] the array itself (device
+ * pointers; rank r's slab starts at full_ptr[k] + r * slab_bytes[k]): the caller all-gathers the four arrays slab by
+ * slab (e.g. ncclAllGather) and then calls l3d_match_finish, which runs the cheap sparse remainder of phase B (the
+ * chain of inverse matches, scores, filterMatches, outputs) on the complete records on every rank.  Returns when the
+ * slabs are complete in device memory. */
+int l3d_lists_shard(l3d_ctx*, uint32_t rank, uint32_t world, void* slab_ptr[4], uint64_t slab_bytes[4], void* full_ptr[4]);
 /* Leaves an open l3d_match_begin without results: everything queued is drained, the views are moved back
  * (matchImages translates them for its duration, line3D.cc:436/493), the context is idle again.  A no-op when no
  * begin is open.  Every failing l3d_match_begin / l3d_match_images / l3d_match_finish does this itself; callers that

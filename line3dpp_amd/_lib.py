@@ -51,7 +51,7 @@ EXPORTS = [
     "l3d_reconstruct_3d_lines", "l3d_num_3d_lines", "l3d_get_3d_lines", "l3d_diffuse_affinity",
     "l3d_output_filename", "l3d_save_3d_lines_txt", "l3d_save_result_stl", "l3d_save_result_obj",
     "l3d_get_segment_coords2d", "l3d_find_collinear_segments", "l3d_score_matches",
-    "l3d_slot_index_buffer", "l3d_pack_slot_indices", "l3d_expand_slot_indices", "l3d_match_abort", "l3d_save_3d_lines_bin",
+    "l3d_slot_index_buffer", "l3d_pack_slot_indices", "l3d_expand_slot_indices", "l3d_match_abort", "l3d_save_3d_lines_bin", "l3d_lists_shard",
 ]
 
 _lib = None
@@ -81,6 +81,7 @@ def load():
     L.l3d_slot_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.l3d_match_finish.argtypes = [vp]
     L.l3d_match_abort.argtypes = [vp]
+    L.l3d_lists_shard.argtypes = [vp, u32, u32, vp, vp, vp]
     L.l3d_compute_affinity.argtypes = [vp]
     L.l3d_synchronize.argtypes = [vp]
     L.l3d_pair_tests.argtypes = [vp, C.POINTER(u64)]

@@ -103,6 +103,14 @@ class Line3D:
     def matchFinish(self):
         return self._check(self.L.l3d_match_finish(self.h), "matchFinish")
 
+    def listsShard(self, rank, world):
+        """phase B's list pass for this rank's share of the views (l3d_lists_shard): returns [(slab pointer, slab
+        bytes, full-array pointer)] x 4 (edges, headers, segment headers, pool counters) or None"""
+        sp = (C.c_void_p * 4)(); sb = (C.c_uint64 * 4)(); fp = (C.c_void_p * 4)()
+        if not self._check(self.L.l3d_lists_shard(self.h, int(rank), int(world), sp, sb, fp), "listsShard"):
+            return None
+        return [(sp[k], int(sb[k]), fp[k]) for k in range(4)]
+
     def matchAbort(self):
         """closes an open matchBegin without results (views untranslated, context idle); no-op otherwise"""
         return self.L.l3d_match_abort(self.h) == 0

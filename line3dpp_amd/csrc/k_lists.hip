@@ -382,10 +382,10 @@ __device__ __forceinline__ int process_list(uint32_t vi, uint32_t seg, uint32_t 
 __global__ void k_inv_records(const PairDesc* __restrict__ pairs, uint32_t first_pair,
                               const uint32_t* __restrict__ seg_base, const Slot* __restrict__ slots,
                               const unsigned long long* __restrict__ off64, const uint32_t* __restrict__ inv_pos,
-                              InvRec* __restrict__ recs) {
+                              InvRec* __restrict__ recs, uint32_t tgt_v0, uint32_t tgt_v1) {
     const uint32_t pi = first_pair + blockIdx.y;
     const PairDesc& pd = pairs[pi];
-    if (pd.tgt <= pd.src) return;
+    if (pd.tgt <= pd.src || pd.tgt < tgt_v0 || pd.tgt >= tgt_v1) return;   // only the target views of this pass
     const uint64_t n = (uint64_t)pd.Ms * pd.K;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -406,14 +406,14 @@ __global__ __launch_bounds__(256) void k_lists(const ViewDev* __restrict__ views
                                                const uint32_t* __restrict__ gseg_view,
                                                const unsigned long long* __restrict__ off64,
                                                const InvRec* __restrict__ inv, const Slot* __restrict__ slots,
-                                               uint32_t uniform_K, const ListPools lp) {
+                                               uint32_t uniform_K, const ListPools lp, uint32_t view0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef ListCfg<WPL> Cfg;
     if (WPL == 1) {
         const uint32_t wave = threadIdx.x >> 6;
-        const uint32_t vi = blockIdx.y, seg = blockIdx.x * 4 + wave;
+        const uint32_t vi = view0 + blockIdx.y, seg = blockIdx.x * 4 + wave;
         if (seg >= lviews[vi].M) return;
-        const uint32_t pool = (blockIdx.y * gridDim.x + blockIdx.x) % kListPools;
+        const uint32_t pool = lp.pool0 + (blockIdx.y * gridDim.x + blockIdx.x) % lp.npools;
         const int rc = process_list<1>(vi, seg, pool, (L3D_LDS char*)smem + wave * Cfg::BYTES, views, pairs, lviews, opairs,
                                        off64, inv, slots, uniform_K, lp);
         if (rc && lane_id() == 0) {
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void k_lists(const ViewDev* __restrict__ views
         for (uint32_t idx = blockIdx.x; idx < n4; idx += gridDim.x) {
             const uint32_t g = lp.list4[idx];
             const uint32_t vi = gseg_view[g];
-            (void)process_list<WPL>(vi, g - lviews[vi].seg_base, blockIdx.x % kListPools, (L3D_LDS char*)smem, views, pairs,
+            (void)process_list<WPL>(vi, g - lviews[vi].seg_base, lp.pool0 + blockIdx.x % lp.npools, (L3D_LDS char*)smem, views, pairs,
                                     lviews, opairs, off64, inv, slots, uniform_K, lp);
             __syncthreads();
         }
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
         __threadfence_block();
         __syncthreads();
         if (H == 0) continue;
-        const uint32_t pool = blockIdx.x % kListPools;
+        const uint32_t pool = lp.pool0 + blockIdx.x % lp.npools;
         if (t == 0) {
             red[8] = atomicAdd(&lp.cnt[pool * 16 + 3], H);
             red[9] = atomicAdd(&lp.cnt[pool * 16 + 4], 1u);
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
 __global__ __launch_bounds__(256) void k_edges(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
                                                const uint32_t* __restrict__ gseg_view, const SimConst sc,
                                                const ListPools lp, uint32_t* __restrict__ seg_of_g) {
-    const uint32_t pool = blockIdx.y, wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t pool = lp.pool0 + blockIdx.y, wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t k = blockIdx.x * 4 + wave;
     if (k >= min(lp.cnt[pool * 16 + 4], lp.scap)) return;
     const CandHdr ch = lp.chdrs[pool * lp.scap + k];
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void k_edges(const ViewDev* __restrict__ views
         }
         n_h += (uint32_t)__popcll(__ballot(first));
     }
-    const uint32_t opool = blockIdx.x % kListPools;           // spread the reservations independently of the input pool
+    const uint32_t opool = lp.pool0 + blockIdx.x % lp.npools; // spread the reservations independently of the input pool
     uint32_t eb = 0, hb = 0, sb = 0;
     if (lane == 0) {
         eb = atomicAdd(&lp.cnt[opool * 16 + 0], n_acc);
@@ -947,41 +947,62 @@ hipError_t launch_scan64(const unsigned long long* in, uint32_t n, unsigned long
 // ---- launchers --------------------------------------------------------------------------------------------------
 hipError_t launch_inv_records(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
                               const Slot* slots, const unsigned long long* off64, const uint32_t* inv_pos, InvRec* recs,
-                              hipStream_t st) {
+                              uint32_t tgt_v0, uint32_t tgt_v1, hipStream_t st) {
     if (!n_pairs || !max_slots) return hipSuccess;
     for (uint32_t p0 = 0; p0 < n_pairs; p0 += 65535u) {
         const uint32_t n = n_pairs - p0 < 65535u ? n_pairs - p0 : 65535u;
         hipLaunchKernelGGL(k_inv_records, dim3((uint32_t)((max_slots + 255) / 256), n), dim3(256), 0, st, pairs, p0,
-                           seg_base, slots, off64, inv_pos, recs);
+                           seg_base, slots, off64, inv_pos, recs, tgt_v0, tgt_v1);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_lists(uint32_t V, uint32_t max_M, const ViewDev* views, const PairDesc* pairs, const ListView* lviews,
-                        const OutPair* opairs, const uint32_t* gseg_view, const unsigned long long* off64,
-                        const InvRec* inv, const Slot* slots, uint32_t uniform_K, SimConst sc, ListPools lp,
-                        uint32_t* seg_of_g, HugeScratchArgs hsa, hipStream_t st) {
-    if (!V || !max_M) return hipSuccess;
+// per-rank status next to the counters of the pass' first pool (words 8..12: the four flags and the scratch cursor):
+// travels with the counter slab when the list pass is sharded
+__global__ void k_publish_flags(const ListPools lp) {
+    if (threadIdx.x < 4) lp.cnt[lp.pool0 * 16 + 8 + threadIdx.x] = lp.flags[threadIdx.x];
+    if (threadIdx.x == 4) lp.cnt[lp.pool0 * 16 + 12] = lp.flags[6];
+}
+
+// seg_of_g of every segment header present (after the slabs of all ranks have arrived)
+__global__ void k_seg_index(const ListPools lp, uint32_t* __restrict__ seg_of_g) {
+    const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= min(lp.cnt[pool * 16 + 2], lp.scap)) return;
+    seg_of_g[lp.segs[pool * lp.scap + k].g] = pool * lp.scap + k;
+}
+hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(seg_of_g, 0xFF, ((size_t)G + 1) * 4, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_seg_index, dim3((lp.scap + 255) / 256, kListPools), dim3(256), 0, st, lp, seg_of_g);
+    return hipGetLastError();
+}
+
+hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev* views, const PairDesc* pairs,
+                        const ListView* lviews, const OutPair* opairs, const uint32_t* gseg_view,
+                        const unsigned long long* off64, const InvRec* inv, const Slot* slots, uint32_t uniform_K,
+                        SimConst sc, ListPools lp, uint32_t* seg_of_g, HugeScratchArgs hsa, hipStream_t st) {
+    if (!nv || !max_M) return hipSuccess;
     const size_t lds1 = 4 * (size_t)ListCfg<1>::BYTES, lds4 = ListCfg<4>::BYTES;
     hipError_t e = hipFuncSetAttribute((const void*)k_lists<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)k_lists<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
     if (e != hipSuccess) return e;
-    for (uint32_t v0 = 0; v0 < V; v0 += 65535u) {   // grid.y limit
-        const uint32_t nv = V - v0 < 65535u ? V - v0 : 65535u;
-        hipLaunchKernelGGL((k_lists<1>), dim3((max_M + 3) / 4, nv), dim3(256), lds1, st, views, pairs, lviews + v0, opairs,
-                           gseg_view, off64, inv, slots, uniform_K, lp);
+    for (uint32_t a = 0; a < nv; a += 65535u) {   // grid.y limit
+        const uint32_t n = nv - a < 65535u ? nv - a : 65535u;
+        hipLaunchKernelGGL((k_lists<1>), dim3((max_M + 3) / 4, n), dim3(256), lds1, st, views, pairs, lviews, opairs,
+                           gseg_view, off64, inv, slots, uniform_K, lp, v0 + a);
     }
     hipLaunchKernelGGL((k_lists<4>), dim3(2048), dim3(256), lds4, st, views, pairs, lviews, opairs, gseg_view, off64, inv,
-                       slots, uniform_K, lp);
+                       slots, uniform_K, lp, 0u);
     HugeScratch hs;
     hs.d1 = hsa.f32; hs.d2 = hsa.f32 + hsa.cap;
     hs.tv = hsa.u32; hs.ref = hsa.u32 + hsa.cap; hs.pf = hsa.u32 + 2 * (size_t)hsa.cap;
     hs.key = hsa.u64; hs.cap = hsa.cap;
     hipLaunchKernelGGL(k_lists_huge, dim3(256), dim3(256), 0, st, views, pairs, lviews, opairs, gseg_view, off64, inv,
                        slots, lp, hs);
-    hipLaunchKernelGGL(k_edges, dim3((lp.scap + 3) / 4, kListPools), dim3(256), 0, st, views, pairs, gseg_view, sc, lp,
+    hipLaunchKernelGGL(k_edges, dim3((lp.scap + 3) / 4, lp.npools), dim3(256), 0, st, views, pairs, gseg_view, sc, lp,
                        seg_of_g);
+    hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, st, lp);
     return hipGetLastError();
 }
 

@@ -334,6 +334,7 @@ static void abort_match(l3d_ctx* c) {
     untranslate(*c);
     c->timing_pending = false; c->pending_launches = 0;
     c->state = l3d_ctx::IDLE;
+    c->shard_world = 0; c->lists_ready = false; c->lists_prepared = false;
 }
 
 int l3d_match_abort(l3d_ctx* c) {
@@ -451,6 +452,7 @@ static int match_begin_body(l3d_ctx* c) {
     }
     c->pair_done.assign(c->pairs.size(), 0);
     c->pair_counted.assign(c->pairs.size(), 0);
+    c->shard_world = 0; c->lists_ready = false; c->lists_prepared = false;
     int rc = upload_views(*c);
     if (rc) return rc;
     {   // packed hypothesis counters of phase B: fed by the match epilogue (bounded kNN) or by k_orient_all
@@ -706,8 +708,58 @@ int l3d_expand_slot_indices(l3d_ctx* c, uint32_t first, uint32_t count) {
     return L3D_OK;
 }
 
-// phase B: line3D.cc:745-773 for every view in ascending camID order (k_views.hip)
+// phase B: line3D.cc:745-773 for every view in ascending camID order (k_lists.hip)
 static int match_finish_impl(l3d_ctx* c);
+static int lists_prepare(l3d_ctx* c);
+static int lists_reserve(l3d_ctx* c);
+static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint32_t npools);
+
+// The list pass of phase B for this rank's share of the views (include/l3dpp_hip.h)
+int l3d_lists_shard(l3d_ctx* c, uint32_t rank, uint32_t world, void* slab_ptr[4], uint64_t slab_bytes[4], void* full_ptr[4]) {
+    if (!c || !slab_ptr || !slab_bytes || !full_ptr) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (c->state != l3d_ctx::BEGUN) return fail(L3D_ERR_STATE, "l3d_match_begin must precede l3d_lists_shard");
+    if (world == 0 || world > kListPools || rank >= world) return fail(L3D_ERR_ARG, "rank / world out of range");
+    for (size_t p = 0; p < c->pairs.size(); ++p)
+        if (!c->pair_done[p]) return fail(L3D_ERR_STATE, "l3d_lists_shard: the slots of some pairs are not present on this rank");
+    (void)hipSetDevice(c->device);
+    const int rc = [&]() -> int {
+        int r2;
+        if (!c->lists_prepared) {
+            r2 = lists_prepare(c);
+            if (r2) return r2;
+            c->lists_prepared = true; c->lp_attempts = 0;
+        }
+        r2 = lists_reserve(c);
+        if (r2) return r2;
+        // contiguous view ranges of (nearly) equal segment count, the same partition on every rank
+        const uint32_t V = (uint32_t)c->order.size(), G = c->G;
+        auto bound = [&](uint32_t r) -> uint32_t {
+            if (r >= world) return V;
+            const uint64_t target = (uint64_t)G * r / world;
+            uint32_t v = 0;
+            while (v < V && c->seg_base[v] < target) ++v;
+            return v;
+        };
+        const uint32_t v0 = bound(rank), v1 = bound(rank + 1);
+        const uint32_t ppr = kListPools / world, pool0 = rank * ppr;
+        r2 = lists_run(c, v0, v1 - v0, pool0, ppr);
+        if (r2) return r2;
+        L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->shard_world = world; c->lists_ready = true;
+        slab_ptr[0] = c->d_ledges.p + (size_t)pool0 * c->lp_ecap; slab_bytes[0] = (uint64_t)ppr * c->lp_ecap * sizeof(EdgeRec); full_ptr[0] = c->d_ledges.p;
+        slab_ptr[1] = c->d_lhyps.p + (size_t)pool0 * c->lp_hcap; slab_bytes[1] = (uint64_t)ppr * c->lp_hcap * sizeof(HypHdr); full_ptr[1] = c->d_lhyps.p;
+        slab_ptr[2] = c->d_lsegs.p + (size_t)pool0 * c->lp_scap; slab_bytes[2] = (uint64_t)ppr * c->lp_scap * sizeof(SegHdr); full_ptr[2] = c->d_lsegs.p;
+        slab_ptr[3] = c->d_lzero.p + (size_t)pool0 * 16; slab_bytes[3] = (uint64_t)ppr * 16 * 4; full_ptr[3] = c->d_lzero.p;
+        return L3D_OK;
+    }();
+    if (rc != L3D_OK) {
+        const std::string why = l3d_last_error();
+        abort_match(c);
+        set_error(why);
+    }
+    return rc;
+}
 
 int l3d_match_finish(l3d_ctx* c) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
@@ -715,6 +767,7 @@ int l3d_match_finish(l3d_ctx* c) {
     if (c->state != l3d_ctx::BEGUN) return fail(L3D_ERR_STATE, "l3d_match_begin must precede l3d_match_finish");
     (void)hipSetDevice(c->device);
     const int rc = match_finish_impl(c);
+    if (rc == L3D_ERR_RETRY) return rc;   // sharded list pass with enlarged pools: the call stays open (l3d_lists_shard again)
     if (rc != L3D_OK) {
         // leave a defined state behind: drain every stream this call may have used, restore the views
         // (matchImages translates them, line3D.cc:436/493) and require a new l3d_match_begin
@@ -725,19 +778,27 @@ int l3d_match_finish(l3d_ctx* c) {
     return rc;
 }
 
-// One pass of the sparse phase B from the zeroed work arrays to the view medians (k_lists.hip): the list pass (only
-// when `with_lists`), the chain sweeps, scores, filterMatches, outputs.  Everything is enqueued; the results of the
-// run (totals, overflow / convergence flags, pool fill, medians) are copied to pinned memory for the caller's sync.
+// ---- phase B (sparse form, k_lists.hip) in three host stages -------------------------------------------------------
+//   lists_prepare  tables, list offsets (one scan of the packed counters): once per matchImages
+//   lists_run      the list pass for a range of views into a range of pools: zero the work arrays, inverse records of
+//                  those views' segments, candidates (k_lists), edges + headers (k_edges)
+//   tail_run       chain sweeps, scores, filterMatches, outputs, view medians + the read-backs of the pass
+// One GPU runs prepare, lists_run(all views, all pools), tail_run.  With the list pass sharded over ranks
+// (l3d_lists_shard) every rank runs lists_run for ITS views into ITS pools, the pool slabs are all-gathered by the
+// caller, and every rank runs tail_run on the complete records.  Everything is enqueued without host synchronisation;
+// sizes are optimistic (pools sized from the slot count or from what an earlier call needed): a pass that outgrows them
+// says so and is repeated with larger ones, so the one host synchronisation of matchImages is the one at its end.
 static constexpr uint32_t kChainSweeps = 10;   // chain launches enqueued blindly (each one is a no-op once nothing changes;
                                                // a launch follows a dependency chain for several links, k_chain_sweep)
 
-static ListPools list_pools(l3d_ctx* c) {
+static ListPools list_pools(l3d_ctx* c, uint32_t pool0 = 0, uint32_t npools = kListPools) {
     ListPools lp;
     lp.cnt = c->d_lzero.p; lp.edges = c->d_ledges.p; lp.hyps = c->d_lhyps.p; lp.segs = c->d_lsegs.p;
     lp.cands = c->d_lcands.p; lp.chdrs = c->d_lchdrs.p;
     lp.ecap = c->lp_ecap; lp.hcap = c->lp_hcap; lp.scap = c->lp_scap; lp.ccap = c->lp_ccap;
     lp.flags = c->d_lzero.p + kListPools * 16;
     lp.list4 = c->d_list4.p; lp.listH = c->d_listH.p;
+    lp.pool0 = pool0; lp.npools = npools;
     return lp;
 }
 
@@ -753,53 +814,7 @@ static ZeroLayout zero_layout(uint32_t V, uint32_t G) {
     return z;
 }
 
-static int finish_pass(l3d_ctx* c, bool with_lists, bool more_sweeps) {
-    hipStream_t st = c->stream;
-    const uint32_t V = (uint32_t)c->order.size(), P = (uint32_t)c->pairs.size(), G = c->G;
-    const ZeroLayout z = zero_layout(V, G);
-    const ListPools lp = list_pools(c);
-    uint32_t* changed = c->d_lzero.p + z.changed;
-    uint32_t* max_score = c->d_lzero.p + z.max_score;
-    uint32_t* kept = c->d_lzero.p + z.kept;
-    unsigned long long* best = (unsigned long long*)(c->d_lzero.p + z.best);
-    const SimConst simc = sim_thresholds(c->two_sigA_sqr);
-    (void)P;
-    if (with_lists) {
-        L3D_HIP_CHECK(hipMemsetAsync(c->d_lzero.p, 0, z.words * 4, st));
-        L3D_HIP_CHECK(hipMemsetAsync(c->d_positive.p, 0, std::max<uint64_t>(c->n_slots, 1), st));
-        L3D_HIP_CHECK(hipMemsetAsync(c->d_seg_of_g.p, 0xFF, ((size_t)G + 1) * 4, st));
-        const HugeScratchArgs hsa{c->d_huge_f32.p, c->d_huge_u32.p, (uint64_t*)c->d_huge_u64.p, c->huge_cap};
-        uint32_t max_M = 0;
-        for (auto* v : c->order) max_M = std::max(max_M, v->M);
-        const ListView* lviews = (const ListView*)c->d_ltab.p;
-        const OutPair* opairs = (const OutPair*)(c->d_ltab.p + (size_t)V * 32);
-        L3D_HIP_CHECK(launch_lists(V, max_M, c->d_views.p, c->d_pairs.p, lviews, opairs, c->d_gseg_view.p, c->d_off64.p,
-                                   c->d_inv_recs.p, c->d_slots.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, simc, lp,
-                                   c->d_seg_of_g.p, hsa, st));
-    } else {
-        // keep the records of the list pass and what the sweeps have found; reset what the later stages accumulate
-        L3D_HIP_CHECK(hipMemsetAsync(changed, 0, (z.words - z.changed) * 4, st));
-    }
-    for (uint32_t s2 = 0; s2 < kChainSweeps; ++s2)
-        L3D_HIP_CHECK(launch_chain_sweep(lp, c->d_positive.p, changed, s2, st));
-    (void)more_sweeps;
-    L3D_HIP_CHECK(launch_hyp_scores(lp, c->d_positive.p, c->d_gseg_view.p, c->d_slots.p, max_score, st));
-    L3D_HIP_CHECK(launch_hyp_filter(lp, G, c->d_gseg_view.p, max_score, kept, best, c->d_cnt64.p, st));
-    L3D_HIP_CHECK(launch_scan64(c->d_cnt64.p, G, c->d_off64s.p, c->d_scan64_tmp.p, c->d_tot64.p + 1, st));
-    L3D_HIP_CHECK(launch_seg_write(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p, c->d_off64s.p, best,
-                                   c->d_seg_of_g.p, lp, c->d_slots.p, c->d_surv_off.p, c->d_hyp_off.p, c->d_surv.p,
-                                   c->d_surv_tg.p, c->d_surv_sg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_depths.p, st));
-    L3D_HIP_CHECK(launch_median_all(V, c->d_depths.p, c->d_hyp_off.p, c->d_seg_base.p, c->d_medians.p, st));
-    // read-backs (pinned): [0..3] two 64-bit totals, [4..35] flags, [36..99] changed, [128..] pool counters
-    uint32_t* h = c->h_fin.p;
-    L3D_HIP_CHECK(hipMemcpyAsync(h, c->d_tot64.p, 16, hipMemcpyDeviceToHost, st));
-    L3D_HIP_CHECK(hipMemcpyAsync(h + 4, c->d_lzero.p + z.flags, (32 + 64) * 4, hipMemcpyDeviceToHost, st));
-    L3D_HIP_CHECK(hipMemcpyAsync(h + 128, c->d_lzero.p, (size_t)kListPools * 16 * 4, hipMemcpyDeviceToHost, st));
-    L3D_HIP_CHECK(hipMemcpyAsync(c->h_med.p, c->d_medians.p, (size_t)V * 4, hipMemcpyDeviceToHost, st));
-    return L3D_OK;
-}
-
-static int match_finish_impl(l3d_ctx* c) {
+static int lists_prepare(l3d_ctx* c) {
     hipStream_t st = c->stream;
     const uint32_t V = (uint32_t)c->order.size(), P = (uint32_t)c->pairs.size();
     // global segment ids
@@ -867,11 +882,6 @@ static int match_finish_impl(l3d_ctx* c) {
     }
     // list offsets (low words) and offsets of the inverse records (high words) in ONE scan of the packed counters
     L3D_HIP_CHECK(launch_scan64(c->d_cnt_pack.p, G, c->d_off64.p, c->d_scan64_tmp.p, c->d_tot64.p, st));
-    L3D_HIP_CHECK(launch_inv_records(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_off64.p,
-                                     c->d_inv_pos.p, c->d_inv_recs.p, st));
-    // ---- the sparse phase B with optimistic sizes: the pools are sized from the slot count (or from what an earlier
-    // call needed); a pass that outgrows them says so and is repeated with larger ones -- no sizing read-back sits in
-    // the common path, the one host synchronisation of matchImages is the one at its end ----
     if (!c->lp_ecap) {
         c->lp_ecap = (uint32_t)std::max<uint64_t>(c->n_slots / 4 / kListPools, 512);
         c->lp_hcap = (uint32_t)std::max<uint64_t>(c->n_slots / 8 / kListPools, 256);
@@ -879,58 +889,122 @@ static int match_finish_impl(l3d_ctx* c) {
     }
     c->lp_scap = std::max<uint32_t>(c->lp_scap, 2 * (G / kListPools) + 64);
     if (!c->huge_cap) c->huge_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->n_slots / 16, 1u << 20), 1u << 30);
+    return L3D_OK;
+}
+
+static int lists_reserve(l3d_ctx* c) {
+    const uint32_t V = (uint32_t)c->order.size();
+    const ZeroLayout z = zero_layout(V, c->G);
+    L3D_HIP_CHECK(c->d_lzero.reserve(z.words + 2));
+    L3D_HIP_CHECK(c->d_ledges.reserve((size_t)kListPools * c->lp_ecap));
+    L3D_HIP_CHECK(c->d_lhyps.reserve((size_t)kListPools * c->lp_hcap));
+    L3D_HIP_CHECK(c->d_lsegs.reserve((size_t)kListPools * c->lp_scap));
+    L3D_HIP_CHECK(c->d_lchdrs.reserve((size_t)kListPools * c->lp_scap));
+    L3D_HIP_CHECK(c->d_lcands.reserve((size_t)kListPools * c->lp_ccap));
+    L3D_HIP_CHECK(c->d_huge_f32.reserve(2 * (size_t)c->huge_cap)); L3D_HIP_CHECK(c->d_huge_u32.reserve(3 * (size_t)c->huge_cap));
+    L3D_HIP_CHECK(c->d_huge_u64.reserve(c->huge_cap));
+    // n_surv <= number of headers: the outputs are sized by that bound
+    const size_t surv_cap = (size_t)kListPools * c->lp_hcap;
+    L3D_HIP_CHECK(c->d_surv.reserve(surv_cap)); L3D_HIP_CHECK(c->d_surv_tg.reserve(surv_cap));
+    L3D_HIP_CHECK(c->d_surv_sg.reserve(surv_cap));
+    return L3D_OK;
+}
+
+// the list pass of the views [v0, v0 + nv) into the pools [pool0, pool0 + npools)
+static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint32_t npools) {
+    hipStream_t st = c->stream;
+    const uint32_t V = (uint32_t)c->order.size(), P = (uint32_t)c->pairs.size(), G = c->G;
     const ZeroLayout z = zero_layout(V, G);
-    for (int attempt = 0;; ++attempt) {
-        L3D_HIP_CHECK(c->d_lzero.reserve(z.words + 2));
-        L3D_HIP_CHECK(c->d_ledges.reserve((size_t)kListPools * c->lp_ecap));
-        L3D_HIP_CHECK(c->d_lhyps.reserve((size_t)kListPools * c->lp_hcap));
-        L3D_HIP_CHECK(c->d_lsegs.reserve((size_t)kListPools * c->lp_scap));
-        L3D_HIP_CHECK(c->d_lchdrs.reserve((size_t)kListPools * c->lp_scap));
-        L3D_HIP_CHECK(c->d_lcands.reserve((size_t)kListPools * c->lp_ccap));
-        L3D_HIP_CHECK(c->d_huge_f32.reserve(2 * (size_t)c->huge_cap)); L3D_HIP_CHECK(c->d_huge_u32.reserve(3 * (size_t)c->huge_cap));
-        L3D_HIP_CHECK(c->d_huge_u64.reserve(c->huge_cap));
-        // n_surv <= number of headers: the outputs are sized by that bound
-        const size_t surv_cap = (size_t)kListPools * c->lp_hcap;
-        L3D_HIP_CHECK(c->d_surv.reserve(surv_cap)); L3D_HIP_CHECK(c->d_surv_tg.reserve(surv_cap));
-        L3D_HIP_CHECK(c->d_surv_sg.reserve(surv_cap));
-        int rc = finish_pass(c, true, false);
-        if (rc) return rc;
-        L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
-        g_trace.mark("phase B enqueued, waiting");
-        L3D_HIP_CHECK(hipStreamSynchronize(st));   // the one point at which matchImages waits for the GPU
-        g_trace.mark("phase B done");
-        const uint32_t* h = c->h_fin.p;
-        const uint32_t* fl = h + 4;
-        if (fl[1]) return fail(L3D_ERR_LIMIT, "a 2D segment has more than 65535 match hypotheses");
-        if (fl[3]) return fail(L3D_ERR_HIP, "internal error: hypothesis counters and slot flags disagree");
-        if (fl[0] || fl[2]) {
-            if (attempt >= 6) return fail(L3D_ERR_LIMIT, "phase-B pools keep overflowing");
-            if (fl[0]) {   // size from what this pass asked for, with head room
-                // (a pass that ran out of candidate space never reached the edges: those pools double)
-                uint32_t me = 0, mh = 0, ms = 0, mc = 0;
-                for (uint32_t q = 0; q < kListPools; ++q) {
-                    me = std::max(me, h[128 + q * 16]); mh = std::max(mh, h[128 + q * 16 + 1]);
-                    ms = std::max(ms, std::max(h[128 + q * 16 + 2], h[128 + q * 16 + 4])); mc = std::max(mc, h[128 + q * 16 + 3]);
-                }
-                const bool cands_over = mc > c->lp_ccap || ms > c->lp_scap;
-                c->lp_ccap = std::max(c->lp_ccap, mc + mc / 2 + 64); c->lp_scap = std::max(c->lp_scap, ms + ms / 2 + 64);
-                c->lp_ecap = std::max(cands_over ? 2 * c->lp_ecap : c->lp_ecap, me + me / 2 + 64);
-                c->lp_hcap = std::max(cands_over ? 2 * c->lp_hcap : c->lp_hcap, mh + mh / 2 + 64);
-            }
-            if (fl[2]) c->huge_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * c->huge_cap, fl[6] + 1024ull), 1u << 31);
-            continue;
-        }
-        // the chain: not converged within the blind sweeps -> keep sweeping (exact for any chain depth), then redo
-        // the stages that follow it
-        while (h[36 + kChainSweeps - 1]) {
-            rc = finish_pass(c, false, true);
-            if (rc) return rc;
-            L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
-            L3D_HIP_CHECK(hipStreamSynchronize(st));
-            ++c->tm.chain_extra_rounds;
-        }
-        break;
+    const ListPools lp = list_pools(c, pool0, npools);
+    const SimConst simc = sim_thresholds(c->two_sigA_sqr);
+    uint64_t max_slots = 0;
+    for (auto& pd : c->pairs) max_slots = std::max<uint64_t>(max_slots, (uint64_t)pd.Ms * pd.K);
+    L3D_HIP_CHECK(hipMemsetAsync(c->d_lzero.p, 0, z.words * 4, st));
+    L3D_HIP_CHECK(hipMemsetAsync(c->d_positive.p, 0, std::max<uint64_t>(c->n_slots, 1), st));
+    L3D_HIP_CHECK(hipMemsetAsync(c->d_seg_of_g.p, 0xFF, ((size_t)G + 1) * 4, st));
+    L3D_HIP_CHECK(launch_inv_records(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_off64.p,
+                                     c->d_inv_pos.p, c->d_inv_recs.p, v0, v0 + nv, st));
+    const HugeScratchArgs hsa{c->d_huge_f32.p, c->d_huge_u32.p, (uint64_t*)c->d_huge_u64.p, c->huge_cap};
+    uint32_t max_M = 0;
+    for (uint32_t vi = v0; vi < v0 + nv; ++vi) max_M = std::max(max_M, c->order[vi]->M);
+    const ListView* lviews = (const ListView*)c->d_ltab.p;
+    const OutPair* opairs = (const OutPair*)(c->d_ltab.p + (size_t)V * 32);
+    L3D_HIP_CHECK(launch_lists(v0, nv, max_M, c->d_views.p, c->d_pairs.p, lviews, opairs, c->d_gseg_view.p, c->d_off64.p,
+                               c->d_inv_recs.p, c->d_slots.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, simc, lp,
+                               c->d_seg_of_g.p, hsa, st));
+    return L3D_OK;
+}
+
+// chain, scores, filterMatches, outputs, medians on the complete records (`fresh`: first tail after a list pass;
+// otherwise the chain continues from what earlier sweeps found and only the later stages start over)
+static int tail_run(l3d_ctx* c, bool fresh) {
+    hipStream_t st = c->stream;
+    const uint32_t V = (uint32_t)c->order.size(), G = c->G;
+    const ZeroLayout z = zero_layout(V, G);
+    const ListPools lp = list_pools(c);
+    uint32_t* changed = c->d_lzero.p + z.changed;
+    uint32_t* max_score = c->d_lzero.p + z.max_score;
+    uint32_t* kept = c->d_lzero.p + z.kept;
+    unsigned long long* best = (unsigned long long*)(c->d_lzero.p + z.best);
+    if (!fresh) L3D_HIP_CHECK(hipMemsetAsync(changed, 0, (z.words - z.changed) * 4, st));
+    for (uint32_t s2 = 0; s2 < kChainSweeps; ++s2)
+        L3D_HIP_CHECK(launch_chain_sweep(lp, c->d_positive.p, changed, s2, st));
+    L3D_HIP_CHECK(launch_hyp_scores(lp, c->d_positive.p, c->d_gseg_view.p, c->d_slots.p, max_score, st));
+    L3D_HIP_CHECK(launch_hyp_filter(lp, G, c->d_gseg_view.p, max_score, kept, best, c->d_cnt64.p, st));
+    L3D_HIP_CHECK(launch_scan64(c->d_cnt64.p, G, c->d_off64s.p, c->d_scan64_tmp.p, c->d_tot64.p + 1, st));
+    L3D_HIP_CHECK(launch_seg_write(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p, c->d_off64s.p, best,
+                                   c->d_seg_of_g.p, lp, c->d_slots.p, c->d_surv_off.p, c->d_hyp_off.p, c->d_surv.p,
+                                   c->d_surv_tg.p, c->d_surv_sg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_depths.p, st));
+    L3D_HIP_CHECK(launch_median_all(V, c->d_depths.p, c->d_hyp_off.p, c->d_seg_base.p, c->d_medians.p, st));
+    // read-backs (pinned): [0..3] two 64-bit totals, [4..35] flags, [36..99] changed, [128..] pool counters
+    uint32_t* h = c->h_fin.p;
+    L3D_HIP_CHECK(hipMemcpyAsync(h, c->d_tot64.p, 16, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipMemcpyAsync(h + 4, c->d_lzero.p + z.flags, (32 + 64) * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipMemcpyAsync(h + 128, c->d_lzero.p, (size_t)kListPools * 16 * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipMemcpyAsync(c->h_med.p, c->d_medians.p, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
+    return L3D_OK;
+}
+
+// flags of the finished pass (own, and in sharded mode those every rank published in its first pool's counters):
+// L3D_OK, an error, or kRetry after the pools were enlarged
+static constexpr int kRetry = 1;
+static int check_pass(l3d_ctx* c) {
+    const uint32_t* h = c->h_fin.p;
+    uint32_t fl[8];
+    for (int k = 0; k < 8; ++k) fl[k] = h[4 + k];
+    if (c->shard_world > 1) {
+        const uint32_t ppr = kListPools / c->shard_world;
+        for (uint32_t r = 0; r < c->shard_world; ++r)
+            for (int k = 0; k < 4; ++k) fl[k] |= h[128 + (size_t)r * ppr * 16 + 8 + k];
+        fl[6] = 0;
+        for (uint32_t r = 0; r < c->shard_world; ++r) fl[6] = std::max(fl[6], h[128 + (size_t)r * ppr * 16 + 12]);
     }
+    if (fl[1]) return fail(L3D_ERR_LIMIT, "a 2D segment has more than 65535 match hypotheses");
+    if (fl[3]) return fail(L3D_ERR_HIP, "internal error: hypothesis counters and slot flags disagree");
+    if (fl[0] || fl[2]) {
+        if (++c->lp_attempts > 6) return fail(L3D_ERR_LIMIT, "phase-B pools keep overflowing");
+        if (fl[0]) {   // size from what this pass asked for, with head room
+            // (a pass that ran out of candidate space never reached the edges: those pools double)
+            uint32_t me = 0, mh = 0, ms = 0, mc = 0;
+            for (uint32_t q = 0; q < kListPools; ++q) {
+                me = std::max(me, h[128 + q * 16]); mh = std::max(mh, h[128 + q * 16 + 1]);
+                ms = std::max(ms, std::max(h[128 + q * 16 + 2], h[128 + q * 16 + 4])); mc = std::max(mc, h[128 + q * 16 + 3]);
+            }
+            const bool cands_over = mc > c->lp_ccap || ms > c->lp_scap;
+            c->lp_ccap = std::max(c->lp_ccap, mc + mc / 2 + 64); c->lp_scap = std::max(c->lp_scap, ms + ms / 2 + 64);
+            c->lp_ecap = std::max(cands_over ? 2 * c->lp_ecap : c->lp_ecap, me + me / 2 + 64);
+            c->lp_hcap = std::max(cands_over ? 2 * c->lp_hcap : c->lp_hcap, mh + mh / 2 + 64);
+        }
+        if (fl[2]) c->huge_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * c->huge_cap, fl[6] + 1024ull), 1u << 31);
+        return kRetry;
+    }
+    return L3D_OK;
+}
+
+// results of the converged pass -> context; matchImages' epilogue (line3D.cc:493)
+static int finish_commit(l3d_ctx* c) {
+    const uint32_t V = (uint32_t)c->order.size();
     const uint32_t* h = c->h_fin.p;
     c->n_ents = h[0];
     c->n_surv = h[2]; c->n_hyps = h[3];
@@ -953,7 +1027,56 @@ static int match_finish_impl(l3d_ctx* c) {
     c->tm.begin_ms = ev_ms(c->ev[0], c->ev[1]);
     untranslate(*c);   // line3D.cc:493
     c->state = l3d_ctx::MATCHED;
+    c->shard_world = 0; c->lists_ready = false; c->lists_prepared = false;
     return L3D_OK;
+}
+
+// the tail until the chain has converged (the blind sweeps normally suffice; any chain depth is handled)
+static int tail_until_converged(l3d_ctx* c) {
+    hipStream_t st = c->stream;
+    int rc = tail_run(c, true);
+    if (rc) return rc;
+    g_trace.mark("phase B enqueued, waiting");
+    L3D_HIP_CHECK(hipStreamSynchronize(st));   // the one point at which matchImages waits for the GPU
+    g_trace.mark("phase B done");
+    rc = check_pass(c);
+    if (rc) return rc;
+    while (c->h_fin.p[36 + kChainSweeps - 1]) {
+        rc = tail_run(c, false);
+        if (rc) return rc;
+        L3D_HIP_CHECK(hipStreamSynchronize(st));
+        ++c->tm.chain_extra_rounds;
+    }
+    return L3D_OK;
+}
+
+static int match_finish_impl(l3d_ctx* c) {
+    int rc;
+    if (c->lists_ready) {
+        // the list pass ran sharded (l3d_lists_shard) and the caller has all-gathered the pool slabs: index the segment
+        // headers of all ranks, then the tail on the complete records
+        const ListPools lp = list_pools(c);
+        L3D_HIP_CHECK(launch_seg_index(lp, c->d_seg_of_g.p, c->G, c->stream));
+        rc = tail_until_converged(c);
+        if (rc == kRetry) { c->lists_ready = false; return fail(L3D_ERR_RETRY, "phase-B pools enlarged: repeat l3d_lists_shard and the exchange"); }
+        if (rc) return rc;
+        return finish_commit(c);
+    }
+    rc = lists_prepare(c);
+    if (rc) return rc;
+    c->lp_attempts = 0;
+    const uint32_t V = (uint32_t)c->order.size();
+    for (;;) {
+        rc = lists_reserve(c);
+        if (rc) return rc;
+        rc = lists_run(c, 0, V, 0, kListPools);
+        if (rc) return rc;
+        rc = tail_until_converged(c);
+        if (rc == kRetry) continue;
+        if (rc) return rc;
+        break;
+    }
+    return finish_commit(c);
 }
 
 int l3d_match_images(l3d_ctx* c, const l3d_match_params* p) {

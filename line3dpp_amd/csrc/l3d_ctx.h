@@ -197,7 +197,11 @@ struct l3d_ctx {
     DevBuf<SegHdr> d_lsegs;
     DevBuf<CandRec> d_lcands;
     DevBuf<CandHdr> d_lchdrs;
-    uint32_t lp_ecap = 0, lp_hcap = 0, lp_scap = 0, lp_ccap = 0, huge_cap = 0;   // per-pool capacities (grow on overflow, kept across calls)
+    uint32_t lp_ecap = 0, lp_hcap = 0, lp_scap = 0, lp_ccap = 0, huge_cap = 0;
+    uint32_t lp_attempts = 0;
+    // list pass sharded over ranks (l3d_lists_shard): world size of the running call, slabs received
+    uint32_t shard_world = 0;
+    bool lists_ready = false, lists_prepared = false;   // per-pool capacities (grow on overflow, kept across calls)
     PinnedBuf<uint32_t> h_fin;
     PinnedBuf<char> h_ltab;
     DevBuf<char> d_ltab;   // [ListView x V | OutPair x P]

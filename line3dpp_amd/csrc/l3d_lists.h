@@ -106,6 +106,8 @@ struct ListPools {
                            // [5] lists handed to the global-memory kernel, [6] scratch cursor of the latter
     uint32_t* list4;       // [G] segments for the 4-wave kernel
     uint32_t* listH;       // [G] segments for the global-memory kernel
+    uint32_t pool0, npools; // the pools this pass allocates from (all of them on one GPU; a rank's share when the list
+                            // pass is sharded: the filled pools of all ranks are all-gathered slab by slab)
 };
 
 }  // namespace l3d

@@ -7,8 +7,11 @@ ranks then exchange their slices of the fixed-layout slot buffer with an all-gat
 compact form: only the uint32 target index of every slot travels (4 B instead of the 32-byte l3d_slot
 record), the receiving rank re-derives overlap and depths with the match kernel's own device functions
 (l3d_pack_slot_indices / l3d_expand_slot_indices; L3D_EXCHANGE_FULL=1 sends the full records instead; the
-keep-all mode kNN <= 0 has no fixed slot layout and runs unsharded on every rank).  Phase B (the per-view chain, line3D.cc:745-773) is order dependent in
-ascending camID and is replicated on every rank after the exchange (SURVEY.md §8e option 1).
+keep-all mode kNN <= 0 has no fixed slot layout and runs unsharded on every rank).  Phase B (the per-view part, line3D.cc:745-773): its dense part -- the pass over every 2D
+segment's hypothesis list that finds the supporting pairs of scoringCPU -- is sharded by views as well
+(l3d_lists_shard); the records it produces (edges / headers, a few MB) are all-gathered and the sparse remainder (the
+chain of inverse matches in ascending camID, scores, filterMatches) runs on every rank (SURVEY.md §8e option 2 for
+the part that carries the work, option 1 for the order-dependent rest).
 
 The exchange is written as one in-place broadcast per owning rank: slices are uneven, and
 `ncclBroadcast` of a slice of the one shared buffer is the all-gather(v) primitive RCCL offers.
@@ -93,9 +96,27 @@ def _wait_for_exchange(buf, device):
         torch.cuda.synchronize(device)
 
 
-def match_images_sharded(l3d, rank, world_size, device=None, group=None, **params):
+def gather_slabs(slabs, rank, world_size, device, group=None):
+    """all-gather of the record arrays of the sharded list pass (Line3D.listsShard): every rank's slab of every array
+    lands at its place in every rank's array.  slabs = [(slab pointer, slab bytes, full-array pointer)]; equal slab
+    sizes by construction, so each array is ONE all_gather_into_tensor."""
+    import torch.distributed as dist
+    for sp, sb, fp in slabs:
+        if not sb:
+            continue
+        full = device_tensor(fp, sb * world_size, device)
+        dist.all_gather_into_tensor(full, full[rank * sb:(rank + 1) * sb].clone(), group=group)
+    if slabs:
+        _wait_for_exchange(device_tensor(slabs[0][2], 1, device), device)
+
+
+def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_lists=None, **params):
     """matchImages with phase A sharded over `world_size` ranks.  `l3d` is a line3dpp_amd.Line3D that
     already holds all views (every rank adds the same views).
+
+    shard_lists (default: on, L3D_SHARD_LISTS=0 turns it off): the dense part of phase B -- the pass over every 2D
+    segment's hypothesis list -- is sharded by views as well (Line3D.listsShard); its records (a few MB) are
+    all-gathered and only the cheap sparse remainder of phase B runs replicated.  Off: all of phase B is replicated.
 
     Keep-all mode (kNN <= 0, line3D.cc:987-992): a row's slot count is only known after the count pass over ALL
     pairs, so there is no fixed slot layout to shard; every rank then runs the whole call itself (replicas, no
@@ -105,6 +126,8 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, **param
     closed with matchAbort (views untranslated, idle), so the next call starts from a clean state."""
     if world_size == 1 or params.get("kNN", 10) <= 0:
         return l3d.matchImages(**params)   # one call: nothing waits for the GPU between the phases
+    if shard_lists is None:
+        shard_lists = os.environ.get("L3D_SHARD_LISTS", "1") != "0"
     if not l3d.matchBegin(**params):
         return False                       # a failing matchBegin restores the context itself
 
@@ -143,4 +166,20 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, **param
             _wait_for_exchange(buf, device)
         # every pair is now present on this rank
         l3d.L.l3d_slots_exchanged(l3d.h)
+    if shard_lists and hasattr(l3d, "listsShard"):
+        # phase B's list pass for this rank's views; its record pools are all-gathered slab by slab; the tail of
+        # phase B then runs on the complete records on every rank.  Pools that turn out too small are enlarged by
+        # l3d_match_finish on EVERY rank alike (all ranks see all counters) and the step is repeated.
+        for _ in range(8):
+            slabs = l3d.listsShard(rank, world_size)
+            if slabs is None:
+                return False               # a failing listsShard restores the context itself
+            gather_slabs(slabs, rank, world_size, device, group)
+            rc = l3d.L.l3d_match_finish(l3d.h)
+            l3d.last_status = rc
+            if rc == 0:
+                return True
+            if rc != -10:                  # L3D_ERR_RETRY
+                return l3d._check(rc, "matchFinish")
+        return give_up()
     return l3d.matchFinish()               # a failing matchFinish restores the context itself

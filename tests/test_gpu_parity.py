@@ -746,6 +746,63 @@ def test_compact_exchange_emulated_on_one_gpu(world):
     assert ge.tobytes() == re_.tobytes()
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_list_pass_emulated_on_one_gpu(world):
+    """Phase B's list pass sharded by views (l3d_lists_shard, line3dpp_amd/dist.py): `world` contexts on one GPU; every
+    context holds all slots (as after the slot exchange), runs the list pass for ITS views into ITS pools, the pool
+    slabs are copied where the all-gather would put them, and every context finishes on the complete records.
+    Surviving matches, best hypotheses, view medians and A_ must equal a single context's, byte for byte."""
+    import torch
+    from line3dpp_amd import dist
+    sc = H.split_scene(make_scene(11, 420, n_neighbors=6, seed=29))
+    for i, v in enumerate(sc.views):                 # ragged views: view ranges of unequal length
+        v.segs = v.segs[:len(v.segs) - 9 * i].copy()
+    ref = _gpu(sc)
+    assert ref.matchImages() and ref.computeAffinity()
+    dev = torch.device("cuda", 0)
+    ctxs = [_gpu(sc) for _ in range(world)]
+    for g in ctxs:
+        assert g.matchBegin() and g.matchPairs(0, len(g.pairs()[0]))
+    for attempt in range(8):
+        slabs = []
+        for r, g in enumerate(ctxs):
+            sl = g.listsShard(r, world)
+            assert sl is not None and len(sl) == 4
+            slabs.append(sl)
+        for k in range(4):
+            sizes = {sl[k][1] for sl in slabs}
+            assert len(sizes) == 1, "equal slab sizes on every rank"
+            sb = sizes.pop()
+            fulls = [dist.device_tensor(sl[k][2], sb * world, dev) for sl in slabs]
+            for r in range(world):
+                assert slabs[r][k][0] == slabs[r][k][2] + r * sb
+                for q in range(world):
+                    if q != r:
+                        fulls[q][r * sb:(r + 1) * sb].copy_(fulls[r][r * sb:(r + 1) * sb])
+        torch.cuda.synchronize()
+        rcs = [g.L.l3d_match_finish(g.h) for g in ctxs]
+        assert len(set(rcs)) == 1, "every rank takes the same decision (all of them see all pool counters)"
+        if rcs[0] == 0:
+            break
+        assert rcs[0] == -10, rcs               # L3D_ERR_RETRY: pools enlarged on every rank alike, repeat the step
+    else:
+        raise AssertionError("the pools never became large enough")
+    for g in ctxs:
+        assert g.computeAffinity()
+        for v in sc.views:
+            a, ao = g.matches(v.cam); b, bo = ref.matches(v.cam)
+            assert np.array_equal(ao, bo) and a.tobytes() == b.tobytes()
+            assert g.view_info(v.cam) == ref.view_info(v.cam)
+        for x, y in zip(g.best(), ref.best()):
+            assert x.tobytes() == y.tobytes()
+        ge, gl, _ = g.affinity(); re_, rl, _ = ref.affinity()
+        assert ge.tobytes() == re_.tobytes() and gl.tobytes() == rl.tobytes()
+    # order: the list pass needs every pair's slots
+    g = _gpu(sc)
+    assert g.matchBegin() and g.matchPairs(0, 1) and g.listsShard(0, 2) is None and g.last_status == -7
+    assert g.matchImages()                           # the failed call left a clean context
+
+
 def test_txt_writer_matches_accessor_and_reference_writer(tmp_path):
     """l3d_save_3d_lines_txt (Line3D::save3DLinesAsTXT): file name and content against get3Dlines() and against
     the file the reference's own writer produces for the same scene (oracle/_ref)."""
