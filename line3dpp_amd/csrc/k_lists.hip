@@ -552,6 +552,7 @@ __global__ __launch_bounds__(256) void k_edges(const ViewDev* __restrict__ views
                                                const ListPools lp, uint32_t* __restrict__ seg_of_g) {
     const uint32_t pool = lp.pool0 + blockIdx.y, wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t k = blockIdx.x * 4 + wave;
+    if (lp.flags[0] | lp.flags[2]) return;   // the candidate pools overflowed: headers beyond the last complete list are not valid
     if (k >= min(lp.cnt[pool * 16 + 4], lp.scap)) return;
     const CandHdr ch = lp.chdrs[pool * lp.scap + k];
     const uint32_t g = ch.g, n = ch.cnt;
@@ -686,6 +687,7 @@ __global__ __launch_bounds__(256) void k_edges(const ViewDev* __restrict__ views
 constexpr uint32_t kSweepLooks = 2;
 __global__ void k_chain_sweep(const ListPools lp, uint8_t* __restrict__ positive, uint32_t* __restrict__ changed,
                               uint32_t sweep) {
+    if (lp.flags[0] | lp.flags[2]) return;                    // an overflowed pass is discarded: its records are incomplete
     if (sweep && !changed[sweep - 1]) return;
     const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= min(lp.cnt[pool * 16 + 1], lp.hcap)) return;
@@ -717,7 +719,7 @@ __global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ pos
                              const uint32_t* __restrict__ gseg_view, Slot* __restrict__ slots,
                              uint32_t* __restrict__ max_score_bits) {
     const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = k < min(lp.cnt[pool * 16 + 1], lp.hcap);
+    const bool active = !(lp.flags[0] | lp.flags[2]) && k < min(lp.cnt[pool * 16 + 1], lp.hcap);
     float score3D = 0.0f;
     uint32_t view = kEmpty;
     if (active) {
@@ -765,7 +767,7 @@ __global__ void k_hyp_filter(const ListPools lp, const uint32_t* __restrict__ gs
                              const uint32_t* __restrict__ max_score_bits, uint32_t* __restrict__ kept_cnt,
                              unsigned long long* __restrict__ best_pack) {
     const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= min(lp.cnt[pool * 16 + 1], lp.hcap)) return;
+    if ((lp.flags[0] | lp.flags[2]) || k >= min(lp.cnt[pool * 16 + 1], lp.hcap)) return;
     HypHdr& h = lp.hyps[pool * lp.hcap + k];
     const float lim = kMinBestScorePerc * __uint_as_float(max_score_bits[gseg_view[h.g]]);
     const float s = h.score3D;
@@ -814,7 +816,7 @@ __global__ void k_seg_write(uint32_t G, const ViewDev* __restrict__ views, const
     const unsigned long long o = off64s[g];
     surv_off[g] = (uint32_t)o; hyp_off[g] = (uint32_t)(o >> 32);
     if (g == G) return;
-    const bool ok = (off64s[g + 1] >> 32) != (o >> 32);
+    const bool ok = (off64s[g + 1] >> 32) != (o >> 32) && !(lp.flags[0] | lp.flags[2]);
     if (!ok) { hyp_of_seg[g] = -1; return; }
     const uint32_t view = gseg_view[g], seg = g - seg_base[view];
     const ViewDev& v = views[view];
@@ -964,15 +966,27 @@ __global__ void k_publish_flags(const ListPools lp) {
     if (threadIdx.x == 4) lp.cnt[lp.pool0 * 16 + 12] = lp.flags[6];
 }
 
+// flags of all ranks (published next to the counters of each rank's first pool) -> this rank's flags: the tail
+// kernels discard a pass in which ANY rank overflowed
+__global__ void k_merge_flags(const ListPools lp, uint32_t world) {
+    const uint32_t ppr = kListPools / world;
+    uint32_t f0 = 0, f2 = 0;
+    for (uint32_t r = 0; r < world; ++r) { f0 |= lp.cnt[(size_t)r * ppr * 16 + 8]; f2 |= lp.cnt[(size_t)r * ppr * 16 + 10]; }
+    if (f0) lp.flags[0] = 1;
+    if (f2) lp.flags[2] = 1;
+}
+
 // seg_of_g of every segment header present (after the slabs of all ranks have arrived)
 __global__ void k_seg_index(const ListPools lp, uint32_t* __restrict__ seg_of_g) {
+    if (lp.flags[0] | lp.flags[2]) return;
     const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= min(lp.cnt[pool * 16 + 2], lp.scap)) return;
     seg_of_g[lp.segs[pool * lp.scap + k].g] = pool * lp.scap + k;
 }
-hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, hipStream_t st) {
+hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, uint32_t world, hipStream_t st) {
     hipError_t e = hipMemsetAsync(seg_of_g, 0xFF, ((size_t)G + 1) * 4, st);
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_merge_flags, dim3(1), dim3(1), 0, st, lp, world ? world : 1u);
     hipLaunchKernelGGL(k_seg_index, dim3((lp.scap + 255) / 256, kListPools), dim3(256), 0, st, lp, seg_of_g);
     return hipGetLastError();
 }

@@ -1056,7 +1056,7 @@ static int match_finish_impl(l3d_ctx* c) {
         // the list pass ran sharded (l3d_lists_shard) and the caller has all-gathered the pool slabs: index the segment
         // headers of all ranks, then the tail on the complete records
         const ListPools lp = list_pools(c);
-        L3D_HIP_CHECK(launch_seg_index(lp, c->d_seg_of_g.p, c->G, c->stream));
+        L3D_HIP_CHECK(launch_seg_index(lp, c->d_seg_of_g.p, c->G, c->shard_world, c->stream));
         rc = tail_until_converged(c);
         if (rc == kRetry) { c->lists_ready = false; return fail(L3D_ERR_RETRY, "phase-B pools enlarged: repeat l3d_lists_shard and the exchange"); }
         if (rc) return rc;

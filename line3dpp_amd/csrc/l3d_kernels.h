@@ -77,7 +77,7 @@ hipError_t launch_scan64(const unsigned long long* in, uint32_t n, unsigned long
 hipError_t launch_inv_records(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
                               const Slot* slots, const unsigned long long* off64, const uint32_t* inv_pos, InvRec* recs,
                               uint32_t tgt_v0, uint32_t tgt_v1, hipStream_t st);
-hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, hipStream_t st);
+hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, uint32_t world, hipStream_t st);
 struct ListView; struct OutPair;
 hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev* views, const PairDesc* pairs,
                         const ListView* lviews, const OutPair* opairs, const uint32_t* gseg_view,
