@@ -163,24 +163,26 @@ __device__ __forceinline__ float window_sq(float dp, float k, float kt, float cc
     return (r < 1e30f) ? r : __builtin_inff();     // NaN / huge: the whole list is the window
 }
 
-template <int WPL>
+// BASE = hypotheses one wave stages (128 for scenes with short lists: 8 waves per SIMD; 256 for long lists, where the
+// multi-wave tiers would otherwise carry most of the work)
+template <int WPL, int BASE>
 struct ListCfg {
     static constexpr uint32_t GS = 64 * WPL;      // threads per list
-    static constexpr uint32_t CAP = 192 * WPL;    // hypotheses staged in LDS
-    static constexpr uint32_t NKEY = 256 * WPL;   // sort keys (power of two >= CAP)
+    static constexpr uint32_t CAP = BASE * WPL;   // hypotheses staged in LDS
+    static constexpr uint32_t NKEY = BASE * WPL;  // sort keys (power of two >= CAP)
     static constexpr uint32_t BYTES = CAP * 20 + NKEY * 8 + CAP * 2 + 64;   // LDS per list
 };
 
 // One list: its candidate pairs.  Returns 0 (done / nothing to do) or 1 (needs a larger kernel: nothing was written).
 // Group-uniform control flow.
-template <int WPL>
+template <int WPL, int BASE>
 __device__ __forceinline__ int process_list(uint32_t vi, uint32_t seg, uint32_t pool, L3D_LDS char* lds,
                                             const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
                                             const ListView* __restrict__ lviews, const OutPair* __restrict__ opairs,
                                             const unsigned long long* __restrict__ off64,
                                             const InvRec* __restrict__ inv, const Slot* __restrict__ slots,
                                             uint32_t uniform_K, const ListPools lp) {
-    typedef ListCfg<WPL> Cfg;
+    typedef ListCfg<WPL, BASE> Cfg;
     constexpr uint32_t GS = Cfg::GS, CAP = Cfg::CAP, NKEY = Cfg::NKEY;
     const uint32_t t = WPL == 1 ? lane_id() : threadIdx.x;
     const ListView lv = lviews[vi];
@@ -400,35 +402,37 @@ __global__ void k_inv_records(const PairDesc* __restrict__ pairs, uint32_t first
 }
 
 // WPL = 1: grid (segment blocks, views), one wave per segment; WPL = 4: fixed grid over the segments handed on
-template <int WPL>
-__global__ __launch_bounds__(256) void k_lists(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+// (one list per workgroup also for WPL = 1: with four lists per workgroup the LDS of a workgroup stayed allocated until
+// its longest list was done -- 3.7 resident waves per SIMD on average where 6 fit)
+template <int WPL, int BASE>
+__global__ __launch_bounds__(64 * WPL) void k_lists(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
                                                const ListView* __restrict__ lviews, const OutPair* __restrict__ opairs,
                                                const uint32_t* __restrict__ gseg_view,
                                                const unsigned long long* __restrict__ off64,
                                                const InvRec* __restrict__ inv, const Slot* __restrict__ slots,
                                                uint32_t uniform_K, const ListPools lp, uint32_t view0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef ListCfg<WPL> Cfg;
     if (WPL == 1) {
-        const uint32_t wave = threadIdx.x >> 6;
-        const uint32_t vi = view0 + blockIdx.y, seg = blockIdx.x * 4 + wave;
+        const uint32_t vi = view0 + blockIdx.y, seg = blockIdx.x;
         if (seg >= lviews[vi].M) return;
-        const uint32_t pool = lp.pool0 + (blockIdx.y * gridDim.x + blockIdx.x) % lp.npools;
-        const int rc = process_list<1>(vi, seg, pool, (L3D_LDS char*)smem + wave * Cfg::BYTES, views, pairs, lviews, opairs,
+        const uint32_t pool = lp.pool0 + ((blockIdx.y * gridDim.x + blockIdx.x) >> 2) % lp.npools;
+        const int rc = process_list<1, BASE>(vi, seg, pool, (L3D_LDS char*)smem, views, pairs, lviews, opairs,
                                        off64, inv, slots, uniform_K, lp);
         if (rc && lane_id() == 0) {
             const uint32_t g = lviews[vi].seg_base + seg;
             const uint32_t L = (uint32_t)(off64[g + 1] - off64[g]);
             if (L > 65535u) atomicOr(&lp.flags[1], 1u);
-            else if (L > ListCfg<4>::CAP) lp.listH[atomicAdd(&lp.flags[5], 1u)] = g;
-            else lp.list4[atomicAdd(&lp.flags[4], 1u)] = g;
+            else if (L > ListCfg<4, BASE>::CAP) lp.listH[atomicAdd(&lp.flags[5], 1u)] = g;
+            else if (L > ListCfg<2, BASE>::CAP) lp.list4[atomicAdd(&lp.flags[4], 1u)] = g;
+            else lp.list2[atomicAdd(&lp.flags[7], 1u)] = g;
         }
     } else {
-        const uint32_t n4 = lp.flags[4];
-        for (uint32_t idx = blockIdx.x; idx < n4; idx += gridDim.x) {
-            const uint32_t g = lp.list4[idx];
+        const uint32_t n = WPL == 2 ? lp.flags[7] : lp.flags[4];
+        const uint32_t* list = WPL == 2 ? lp.list2 : lp.list4;
+        for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {
+            const uint32_t g = list[idx];
             const uint32_t vi = gseg_view[g];
-            (void)process_list<WPL>(vi, g - lviews[vi].seg_base, lp.pool0 + blockIdx.x % lp.npools, (L3D_LDS char*)smem, views, pairs,
+            (void)process_list<WPL, BASE>(vi, g - lviews[vi].seg_base, lp.pool0 + blockIdx.x % lp.npools, (L3D_LDS char*)smem, views, pairs,
                                     lviews, opairs, off64, inv, slots, uniform_K, lp);
             __syncthreads();
         }
@@ -547,11 +551,11 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
 // candidate (one per lane, full lanes: this is where the fp64 unprojections, acos and exp live), then the accepted
 // ones as EDGES in (i, j) order with one HEADER per hypothesis i that has any.  The candidates arrive grouped by i
 // in canonical order (one contiguous run per i, j in walk order), so the order only has to be fixed inside a run.
-__global__ __launch_bounds__(256) void k_edges(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+__global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
                                                const uint32_t* __restrict__ gseg_view, const SimConst sc,
                                                const ListPools lp, uint32_t* __restrict__ seg_of_g) {
-    const uint32_t pool = lp.pool0 + blockIdx.y, wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t k = blockIdx.x * 4 + wave;
+    const uint32_t pool = lp.pool0 + blockIdx.y, wave = 0, lane = lane_id();   // one segment per workgroup (as k_lists)
+    const uint32_t k = blockIdx.x;
     if (lp.flags[0] | lp.flags[2]) return;   // the candidate pools overflowed: headers beyond the last complete list are not valid
     if (k >= min(lp.cnt[pool * 16 + 4], lp.scap)) return;
     const CandHdr ch = lp.chdrs[pool * lp.scap + k];
@@ -567,8 +571,8 @@ __global__ __launch_bounds__(256) void k_edges(const ViewDev* __restrict__ views
     // (ij, sim) of the list's candidates live in LDS for the order fixing below (lists beyond kEdgeLds entries walk
     // global memory instead: correct, slow, rare)
     constexpr uint32_t kEdgeLds = 512;
-    __shared__ uint32_t s_ij[4][kEdgeLds];
-    __shared__ float s_sim[4][kEdgeLds];
+    __shared__ uint32_t s_ij[1][kEdgeLds];
+    __shared__ float s_sim[1][kEdgeLds];
     const bool in_lds = n <= kEdgeLds;
     // pass 1: the exact test
     uint32_t n_acc = 0;
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(256) void k_edges(const ViewDev* __restrict__ views
         }
         n_h += (uint32_t)__popcll(__ballot(first));
     }
-    const uint32_t opool = lp.pool0 + blockIdx.x % lp.npools; // spread the reservations independently of the input pool
+    const uint32_t opool = lp.pool0 + (blockIdx.x >> 2) % lp.npools; // spread the reservations independently of the input pool
     uint32_t eb = 0, hb = 0, sb = 0;
     if (lane == 0) {
         eb = atomicAdd(&lp.cnt[opool * 16 + 0], n_acc);
@@ -996,25 +1000,37 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
                         const unsigned long long* off64, const InvRec* inv, const Slot* slots, uint32_t uniform_K,
                         SimConst sc, ListPools lp, uint32_t* seg_of_g, HugeScratchArgs hsa, hipStream_t st) {
     if (!nv || !max_M) return hipSuccess;
-    const size_t lds1 = 4 * (size_t)ListCfg<1>::BYTES, lds4 = ListCfg<4>::BYTES;
-    hipError_t e = hipFuncSetAttribute((const void*)k_lists<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_lists<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-    if (e != hipSuccess) return e;
-    for (uint32_t a = 0; a < nv; a += 65535u) {   // grid.y limit
-        const uint32_t n = nv - a < 65535u ? nv - a : 65535u;
-        hipLaunchKernelGGL((k_lists<1>), dim3((max_M + 3) / 4, n), dim3(256), lds1, st, views, pairs, lviews, opairs,
-                           gseg_view, off64, inv, slots, uniform_K, lp, v0 + a);
-    }
-    hipLaunchKernelGGL((k_lists<4>), dim3(2048), dim3(256), lds4, st, views, pairs, lviews, opairs, gseg_view, off64, inv,
-                       slots, uniform_K, lp, 0u);
+    // the one-wave tier stages 128 hypotheses (8 waves per SIMD) unless the scene's lists are long on average
+    const bool wide = hsa.mean_list > 96;
+#define L3D_LISTS(B)                                                                                                       \
+    do {                                                                                                                   \
+        const size_t lds1 = ListCfg<1, B>::BYTES, lds2 = ListCfg<2, B>::BYTES, lds4 = ListCfg<4, B>::BYTES;                \
+        hipError_t e = hipFuncSetAttribute((const void*)k_lists<1, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); \
+        if (e != hipSuccess) return e;                                                                                     \
+        e = hipFuncSetAttribute((const void*)k_lists<2, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);        \
+        if (e != hipSuccess) return e;                                                                                     \
+        e = hipFuncSetAttribute((const void*)k_lists<4, B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);        \
+        if (e != hipSuccess) return e;                                                                                     \
+        for (uint32_t a = 0; a < nv; a += 65535u) { /* grid.y limit */                                                     \
+            const uint32_t n = nv - a < 65535u ? nv - a : 65535u;                                                          \
+            hipLaunchKernelGGL((k_lists<1, B>), dim3(max_M, n), dim3(64), lds1, st, views, pairs, lviews, opairs,          \
+                               gseg_view, off64, inv, slots, uniform_K, lp, v0 + a);                                       \
+        }                                                                                                                  \
+        /* lists beyond one wave's capacity: two waves up to 2x, four up to 4x (fixed grids over the hand-over lists) */   \
+        hipLaunchKernelGGL((k_lists<2, B>), dim3(16384), dim3(128), lds2, st, views, pairs, lviews, opairs, gseg_view,     \
+                           off64, inv, slots, uniform_K, lp, 0u);                                                          \
+        hipLaunchKernelGGL((k_lists<4, B>), dim3(4096), dim3(256), lds4, st, views, pairs, lviews, opairs, gseg_view,      \
+                           off64, inv, slots, uniform_K, lp, 0u);                                                          \
+    } while (0)
+    if (wide) L3D_LISTS(256); else L3D_LISTS(128);
+#undef L3D_LISTS
     HugeScratch hs;
     hs.d1 = hsa.f32; hs.d2 = hsa.f32 + hsa.cap;
     hs.tv = hsa.u32; hs.ref = hsa.u32 + hsa.cap; hs.pf = hsa.u32 + 2 * (size_t)hsa.cap;
     hs.key = hsa.u64; hs.cap = hsa.cap;
     hipLaunchKernelGGL(k_lists_huge, dim3(256), dim3(256), 0, st, views, pairs, lviews, opairs, gseg_view, off64, inv,
                        slots, lp, hs);
-    hipLaunchKernelGGL(k_edges, dim3((lp.scap + 3) / 4, lp.npools), dim3(256), 0, st, views, pairs, gseg_view, sc, lp,
+    hipLaunchKernelGGL(k_edges, dim3(lp.scap, lp.npools), dim3(64), 0, st, views, pairs, gseg_view, sc, lp,
                        seg_of_g);
     hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, st, lp);
     return hipGetLastError();

@@ -257,7 +257,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->h_views.release(); c->h_pairs.release(); c->h_cull.release(); c->h_work.release(); c->h_vout.release();
     c->h_small.release(); c->h_cnt.release(); c->h_med.release(); c->h_fin.release();
     c->d_off64.release(); c->d_cnt64.release(); c->d_off64s.release(); c->d_scan64_tmp.release(); c->d_tot64.release();
-    c->d_huge_u64.release(); c->d_inv_recs.release(); c->d_lzero.release(); c->d_list4.release(); c->d_listH.release();
+    c->d_huge_u64.release(); c->d_inv_recs.release(); c->d_lzero.release(); c->d_list2.release(); c->d_list4.release(); c->d_listH.release();
     c->d_seg_of_g.release(); c->d_huge_u32.release(); c->d_huge_f32.release(); c->d_ledges.release(); c->d_lhyps.release();
     c->d_lsegs.release(); c->d_lcands.release(); c->d_lchdrs.release(); c->d_ltab.release(); c->h_ltab.release();
     c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
@@ -797,7 +797,7 @@ static ListPools list_pools(l3d_ctx* c, uint32_t pool0 = 0, uint32_t npools = kL
     lp.cands = c->d_lcands.p; lp.chdrs = c->d_lchdrs.p;
     lp.ecap = c->lp_ecap; lp.hcap = c->lp_hcap; lp.scap = c->lp_scap; lp.ccap = c->lp_ccap;
     lp.flags = c->d_lzero.p + kListPools * 16;
-    lp.list4 = c->d_list4.p; lp.listH = c->d_listH.p;
+    lp.list2 = c->d_list2.p; lp.list4 = c->d_list4.p; lp.listH = c->d_listH.p;
     lp.pool0 = pool0; lp.npools = npools;
     return lp;
 }
@@ -829,7 +829,7 @@ static int lists_prepare(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_hyp_of_seg.reserve(G + 1)); L3D_HIP_CHECK(c->d_medians.reserve(V + 1));
     L3D_HIP_CHECK(c->d_off64.reserve(G + 2)); L3D_HIP_CHECK(c->d_cnt64.reserve(G + 2)); L3D_HIP_CHECK(c->d_off64s.reserve(G + 2));
     L3D_HIP_CHECK(c->d_scan64_tmp.reserve(G / 4096 + 1024)); L3D_HIP_CHECK(c->d_tot64.reserve(4));
-    L3D_HIP_CHECK(c->d_seg_of_g.reserve(G + 1)); L3D_HIP_CHECK(c->d_list4.reserve(G + 1)); L3D_HIP_CHECK(c->d_listH.reserve(G + 1));
+    L3D_HIP_CHECK(c->d_seg_of_g.reserve(G + 1)); L3D_HIP_CHECK(c->d_list2.reserve(G + 1)); L3D_HIP_CHECK(c->d_list4.reserve(G + 1)); L3D_HIP_CHECK(c->d_listH.reserve(G + 1));
     L3D_HIP_CHECK(c->d_hyps.reserve(std::max<uint32_t>(G, 1))); L3D_HIP_CHECK(c->d_depths.reserve(2 * (size_t)G + 2));
     L3D_HIP_CHECK(c->d_positive.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(c->d_inv_recs.reserve(std::max<uint64_t>(c->n_slots, 1)));
@@ -887,7 +887,7 @@ static int lists_prepare(l3d_ctx* c) {
         c->lp_hcap = (uint32_t)std::max<uint64_t>(c->n_slots / 8 / kListPools, 256);
         c->lp_ccap = (uint32_t)std::max<uint64_t>(c->n_slots / 2 / kListPools, 1024);
     }
-    c->lp_scap = std::max<uint32_t>(c->lp_scap, 2 * (G / kListPools) + 64);
+    c->lp_scap = std::max<uint32_t>(c->lp_scap, G / kListPools + 64);   // 30-50 % of the segments have candidates; grows on demand
     if (!c->huge_cap) c->huge_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->n_slots / 16, 1u << 20), 1u << 30);
     return L3D_OK;
 }
@@ -924,7 +924,11 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
     L3D_HIP_CHECK(hipMemsetAsync(c->d_seg_of_g.p, 0xFF, ((size_t)G + 1) * 4, st));
     L3D_HIP_CHECK(launch_inv_records(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_off64.p,
                                      c->d_inv_pos.p, c->d_inv_recs.p, v0, v0 + nv, st));
-    const HugeScratchArgs hsa{c->d_huge_f32.p, c->d_huge_u32.p, (uint64_t*)c->d_huge_u64.p, c->huge_cap};
+    // mean list length: every alive slot is a hypothesis of its source segment and, towards a later view, of its target
+    // segment too (~0.8 of the slots are alive, ~half of the pairs hand inverse matches over); exact after the first call
+    const uint32_t mean_list = c->n_ents ? (uint32_t)(c->n_ents / std::max<uint32_t>(G, 1))
+                                         : (uint32_t)(1.5 * (double)c->n_slots / std::max<uint32_t>(G, 1));
+    const HugeScratchArgs hsa{c->d_huge_f32.p, c->d_huge_u32.p, (uint64_t*)c->d_huge_u64.p, c->huge_cap, mean_list};
     uint32_t max_M = 0;
     for (uint32_t vi = v0; vi < v0 + nv; ++vi) max_M = std::max(max_M, c->order[vi]->M);
     const ListView* lviews = (const ListView*)c->d_ltab.p;

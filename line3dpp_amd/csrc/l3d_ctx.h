@@ -190,7 +190,7 @@ struct l3d_ctx {
     // sparse phase B (k_lists.hip, l3d_lists.h)
     DevBuf<unsigned long long> d_off64, d_cnt64, d_off64s, d_scan64_tmp, d_tot64, d_huge_u64;
     DevBuf<InvRec> d_inv_recs;
-    DevBuf<uint32_t> d_lzero, d_list4, d_listH, d_seg_of_g, d_huge_u32;
+    DevBuf<uint32_t> d_lzero, d_list2, d_list4, d_listH, d_seg_of_g, d_huge_u32;
     DevBuf<float> d_huge_f32;
     DevBuf<EdgeRec> d_ledges;
     DevBuf<HypHdr> d_lhyps;

@@ -71,7 +71,7 @@ hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t ma
 
 // ---- k_lists.hip: the sparse phase B (l3d_lists.h) ----
 struct InvRec; struct ListPools;
-struct HugeScratchArgs { float* f32; uint32_t* u32; uint64_t* u64; uint32_t cap; };   // [2 cap] [3 cap] [cap]
+struct HugeScratchArgs { float* f32; uint32_t* u32; uint64_t* u64; uint32_t cap; uint32_t mean_list; };   // [2 cap] [3 cap] [cap]; mean list length (estimate)
 hipError_t launch_scan64(const unsigned long long* in, uint32_t n, unsigned long long* out, unsigned long long* tmp,
                          unsigned long long* total, hipStream_t st);
 hipError_t launch_inv_records(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,

@@ -103,7 +103,9 @@ struct ListPools {
     uint32_t ecap, hcap, scap, ccap;
     uint32_t* flags;       // [0] pool overflow, [1] list longer than 65535 hypotheses, [2] scratch overflow,
                            // [3] counters and slots disagree (internal error), [4] lists handed to the 4-wave kernel,
-                           // [5] lists handed to the global-memory kernel, [6] scratch cursor of the latter
+                           // [5] lists handed to the global-memory kernel, [6] scratch cursor of the latter,
+                           // [7] lists handed to the 2-wave kernel
+    uint32_t* list2;       // [G] segments for the 2-wave kernel
     uint32_t* list4;       // [G] segments for the 4-wave kernel
     uint32_t* listH;       // [G] segments for the global-memory kernel
     uint32_t pool0, npools; // the pools this pass allocates from (all of them on one GPU; a rank's share when the list
