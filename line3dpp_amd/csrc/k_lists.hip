@@ -717,6 +717,7 @@ __global__ void k_chain_sweep(const ListPools lp, uint8_t* __restrict__ positive
     }
 }
 
+constexpr uint32_t kMaxReplicas = 16;   // the view maxima are kept in 16 replicas (by pool) against atomic contention
 // score3D of every header: the existing supporters in canonical order with the reference's per-camera
 // replace/subtract accumulation (line3D.cc:1255-1274); the view's maximum for filterMatches
 __global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ positive,
@@ -758,7 +759,7 @@ __global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ pos
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
         if (lane_id() == leader) {
-            uint32_t* p = &max_score_bits[lv];
+            uint32_t* p = &max_score_bits[lv * kMaxReplicas + (pool & (kMaxReplicas - 1))];   // replicas: less contention
             if (__float_as_uint(mx) > *(volatile uint32_t*)p) atomicMax(p, __float_as_uint(mx));
         }
         todo &= ~__ballot(mine);
@@ -773,7 +774,13 @@ __global__ void k_hyp_filter(const ListPools lp, const uint32_t* __restrict__ gs
     const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     if ((lp.flags[0] | lp.flags[2]) || k >= min(lp.cnt[pool * 16 + 1], lp.hcap)) return;
     HypHdr& h = lp.hyps[pool * lp.hcap + k];
-    const float lim = kMinBestScorePerc * __uint_as_float(max_score_bits[gseg_view[h.g]]);
+    uint32_t mx = 0;
+    {
+        const uint32_t* p = max_score_bits + (size_t)gseg_view[h.g] * kMaxReplicas;
+#pragma unroll
+        for (uint32_t r = 0; r < kMaxReplicas; ++r) mx = max(mx, p[r]);   // positive floats order like their bit patterns
+    }
+    const float lim = kMinBestScorePerc * __uint_as_float(mx);
     const float s = h.score3D;
     if ((h.state & kHypExists) && s > 0.0f && s > lim) {
         h.state |= kHypKeep;

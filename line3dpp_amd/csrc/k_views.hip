@@ -1011,14 +1011,20 @@ __global__ __launch_bounds__(1024) void k_median_all(const float* __restrict__ d
             if ((bits & himask) == prefix) atomicAdd(&hist[(bits >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t r = s_rank, acc = 0, d = 0;
-            for (; d < 256; ++d) {
-                if (acc + hist[d] > r) break;
-                acc += hist[d];
+        if (threadIdx.x < 64) {   // one wave: bin d with cum(d-1) <= rank < cum(d)  (4 bins per lane, wave prefix)
+            const uint32_t l = threadIdx.x;
+            const uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+            uint32_t x = h0 + h1 + h2 + h3;
+            const uint32_t mine = x;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (l >= (uint32_t)d) x += y; }
+            const uint32_t before = x - mine, r = s_rank;
+            if (r >= before && r < x) {
+                uint32_t acc = before, d = 4 * l;
+                if (acc + h0 <= r) { acc += h0; ++d; if (acc + h1 <= r) { acc += h1; ++d; if (acc + h2 <= r) { acc += h2; ++d; } } }
+                s_rank = r - acc;
+                s_prefix = prefix | (d << shift);
             }
-            s_rank = r - acc;
-            s_prefix = prefix | (d << shift);
         }
         __syncthreads();
     }

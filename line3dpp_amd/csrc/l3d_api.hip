@@ -788,7 +788,7 @@ int l3d_match_finish(l3d_ctx* c) {
 // caller, and every rank runs tail_run on the complete records.  Everything is enqueued without host synchronisation;
 // sizes are optimistic (pools sized from the slot count or from what an earlier call needed): a pass that outgrows them
 // says so and is repeated with larger ones, so the one host synchronisation of matchImages is the one at its end.
-static constexpr uint32_t kChainSweeps = 10;   // chain launches enqueued blindly (each one is a no-op once nothing changes;
+static constexpr uint32_t kChainSweeps = 16;   // chain launches enqueued blindly (each one is a no-op once nothing changes;
                                                // a launch follows a dependency chain for several links, k_chain_sweep)
 
 static ListPools list_pools(l3d_ctx* c, uint32_t pool0 = 0, uint32_t npools = kListPools) {
@@ -808,7 +808,7 @@ struct ZeroLayout { size_t flags, changed, max_score, kept, best, words; };
 static ZeroLayout zero_layout(uint32_t V, uint32_t G) {
     ZeroLayout z;
     z.flags = (size_t)kListPools * 16; z.changed = z.flags + 32; z.max_score = z.changed + 64;
-    z.kept = z.max_score + V + 1;
+    z.kept = z.max_score + ((size_t)V + 1) * 16;   // 16 replicas per view (k_lists.hip: kMaxReplicas)
     z.best = (z.kept + G + 1) & ~(size_t)1;
     z.words = z.best + 2 * (size_t)G + 2;
     return z;
@@ -951,7 +951,11 @@ static int tail_run(l3d_ctx* c, bool fresh) {
     uint32_t* kept = c->d_lzero.p + z.kept;
     unsigned long long* best = (unsigned long long*)(c->d_lzero.p + z.best);
     if (!fresh) L3D_HIP_CHECK(hipMemsetAsync(changed, 0, (z.words - z.changed) * 4, st));
-    for (uint32_t s2 = 0; s2 < kChainSweeps; ++s2)
+    // as many launches as the last call needed + 2 (a launch is a no-op once nothing changes; the last one enqueued
+    // must report "no change", else the host keeps sweeping)
+    const uint32_t n_sweeps = std::min(kChainSweeps, std::max(4u, c->chain_need + 2));
+    c->chain_enqueued = n_sweeps;
+    for (uint32_t s2 = 0; s2 < n_sweeps; ++s2)
         L3D_HIP_CHECK(launch_chain_sweep(lp, c->d_positive.p, changed, s2, st));
     L3D_HIP_CHECK(launch_hyp_scores(lp, c->d_positive.p, c->d_gseg_view.p, c->d_slots.p, max_score, st));
     L3D_HIP_CHECK(launch_hyp_filter(lp, G, c->d_gseg_view.p, max_score, kept, best, c->d_cnt64.p, st));
@@ -1013,7 +1017,8 @@ static int finish_commit(l3d_ctx* c) {
     c->n_ents = h[0];
     c->n_surv = h[2]; c->n_hyps = h[3];
     c->tm.list_entries = h[0];
-    for (uint32_t s2 = 0; s2 < kChainSweeps; ++s2) c->tm.chain_sweeps += h[36 + s2] ? 1u : 0u;   // of the last round
+    for (uint32_t s2 = 0; s2 < c->chain_enqueued; ++s2) c->tm.chain_sweeps += h[36 + s2] ? 1u : 0u;   // of the last round
+    c->chain_need = c->tm.chain_extra_rounds ? kChainSweeps : c->tm.chain_sweeps;
     {
         uint64_t ne = 0;
         for (uint32_t q = 0; q < kListPools; ++q) ne += h[128 + q * 16];
@@ -1045,7 +1050,7 @@ static int tail_until_converged(l3d_ctx* c) {
     g_trace.mark("phase B done");
     rc = check_pass(c);
     if (rc) return rc;
-    while (c->h_fin.p[36 + kChainSweeps - 1]) {
+    while (c->h_fin.p[36 + c->chain_enqueued - 1]) {
         rc = tail_run(c, false);
         if (rc) return rc;
         L3D_HIP_CHECK(hipStreamSynchronize(st));

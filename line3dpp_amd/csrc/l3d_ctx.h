@@ -199,6 +199,7 @@ struct l3d_ctx {
     DevBuf<CandHdr> d_lchdrs;
     uint32_t lp_ecap = 0, lp_hcap = 0, lp_scap = 0, lp_ccap = 0, huge_cap = 0;
     uint32_t lp_attempts = 0;
+    uint32_t chain_need = 8, chain_enqueued = 10;   // chain launches that changed something last time / enqueued this time
     // list pass sharded over ranks (l3d_lists_shard): world size of the running call, slabs received
     uint32_t shard_world = 0;
     bool lists_ready = false, lists_prepared = false;   // per-pool capacities (grow on overflow, kept across calls)
