@@ -24,6 +24,7 @@
 // Roofline: compulsory HBM traffic per directed pair is 16*(Ms+Mt) B read + 32*K*Ms B written;
 // per pair test that is < 0.2 B against ~30 fp32 VALU issues, so the kernel is VALU-issue bound
 // (DESIGN.md §roofline).  No MFMA: there is no contraction here.
+#include <algorithm>
 #include <cstdlib>
 
 #include "l3d_dev.h"
@@ -885,8 +886,13 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
     const bool tgt_side = blockIdx.y != 0;       // grid.y = 2: the two sorts of a pair run in different workgroups
     uint32_t n2 = 64;
     while (n2 < (tgt_side ? Mt : Ms)) n2 <<= 1;
-    uint64_t* keys = (uint64_t*)smem;
-    uint32_t* cb = (uint32_t*)(keys + n2);       // [2 * n2/64] chunk bands, orderable floats
+    // keys in LDS up to kCullLdsSegs per side; beyond that in this pair's global scratch (same code, L2 instead of LDS:
+    // slower, but a view of 16 385 segments no longer falls back to unculled matching)
+    uint32_t n2s = 64;
+    while (n2s < Ms) n2s <<= 1;
+    const bool big = pc.k_off != ~0ull;
+    uint64_t* keys = big ? cp.big_keys + pc.k_off + (tgt_side ? n2s : 0u) : (uint64_t*)smem;
+    uint32_t* cb = big ? (uint32_t*)smem : (uint32_t*)(keys + n2);       // [2 * n2/64] chunk bands, orderable floats
     __shared__ uint32_t span[2];
     const uint32_t tid = threadIdx.x;
 
@@ -966,7 +972,9 @@ hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint
     if (!count || !pools.cull) return hipSuccess;
     uint32_t n2 = 64;
     while (n2 < max_M) n2 <<= 1;
-    const size_t lds = (size_t)n2 * 8 + (size_t)(n2 / 64) * 8;
+    // (views beyond the LDS capacity keep their keys in global scratch: only the chunk bands stay in LDS)
+    const size_t lds = n2 <= kCullLdsSegs ? (size_t)n2 * 8 + (size_t)(n2 / 64) * 8
+                                           : std::max<size_t>((size_t)kCullLdsSegs * 8 + (kCullLdsSegs / 64) * 8, (size_t)(n2 / 64) * 8);
     hipError_t e = hipFuncSetAttribute((const void*)k_cull_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_cull_prepare, dim3(count, 2), dim3(kCullBlock), lds, stream, views, pairs, first, pools);

@@ -261,7 +261,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_seg_of_g.release(); c->d_huge_u32.release(); c->d_huge_f32.release(); c->d_ledges.release(); c->d_lhyps.release();
     c->d_lsegs.release(); c->d_lcands.release(); c->d_lchdrs.release(); c->d_ltab.release(); c->h_ltab.release();
     c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
-    c->d_chunk_band.release(); c->d_tgt_sf.release(); c->d_tgt_band.release();
+    c->d_chunk_band.release(); c->d_cull_keys.release(); c->d_tgt_sf.release(); c->d_tgt_band.release();
     c->d_row_counts.release();
     c->d_seg_base.release(); c->d_gseg_view.release(); c->d_cnt.release(); c->d_off.release();
     c->d_scan_tmp.release(); c->d_scal.release(); c->d_max_score.release(); c->d_surv_cnt.release();
@@ -402,7 +402,7 @@ static int match_begin_body(l3d_ctx* c) {
                 if (c->views.count(n)) v->visual_nbrs.insert(n);
     // directed pair list, line3D.cc:704-741
     c->pairs.clear(); c->pair_src_cam.clear(); c->pair_tgt_cam.clear(); c->cull.clear();
-    uint64_t cs_off = 0, ct_off = 0; uint32_t cc_off = 0;
+    uint64_t cs_off = 0, ct_off = 0, ck_off = 0; uint32_t cc_off = 0;
     std::map<uint32_t, std::set<uint32_t>> matched;
     uint64_t slot_off = 0; uint32_t row_off = 0;
     c->pair_tests = 0;
@@ -427,7 +427,13 @@ static int match_begin_body(l3d_ctx* c) {
             PairCull pc{};
             if (c->use_cull && c->kNN > 0 && pd.Ms <= kCullMaxSegs && pd.Mt <= kCullMaxSegs && pd.Ms && pd.Mt)
                 make_cull(pd.F, v->width, v->height, t->width, t->height, pc);
-            pc.s_off = cs_off; pc.t_off = ct_off; pc.c_off = cc_off;
+            pc.s_off = cs_off; pc.t_off = ct_off; pc.c_off = cc_off; pc.k_off = ~0ull;
+            if (pc.enabled && std::max(pd.Ms, pd.Mt) > kCullLdsSegs) {   // sort keys of this pair in global scratch
+                uint32_t a = 64, b = 64;
+                while (a < pd.Ms) a <<= 1;
+                while (b < pd.Mt) b <<= 1;
+                pc.k_off = ck_off; ck_off += (uint64_t)a + b;
+            }
             if (pc.enabled) { cs_off += pd.Ms; ct_off += pd.Mt; cc_off += (pd.Mt + 63) / 64; }
             c->cull.push_back(pc);
             c->pair_src_cam.push_back(v->cam); c->pair_tgt_cam.push_back(tcam);
@@ -483,6 +489,7 @@ static int match_begin_body(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_tgt_sf.reserve(std::max<uint64_t>(ct_off, 1)));
     L3D_HIP_CHECK(c->d_tgt_band.reserve(std::max<uint64_t>(ct_off, 1)));
     L3D_HIP_CHECK(c->d_chunk_band.reserve(std::max<uint32_t>(cc_off, 1)));
+    L3D_HIP_CHECK(c->d_cull_keys.reserve(std::max<uint64_t>(ck_off, 1)));
     L3D_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
     c->tm = l3d_timings{};
     c->state = l3d_ctx::BEGUN;
@@ -547,7 +554,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     L3D_HIP_CHECK(hipMemcpyAsync(c->d_work.p, work, n_work * sizeof(WorkItem), hipMemcpyHostToDevice, c->stream));
     L3D_HIP_CHECK(hipEventRecord(c->ev[8], c->stream));
     CullPools pools{c->d_cull.p, c->d_src_perm.p, c->d_src_band.p, c->d_tgt_perm.p, c->d_tgt_sf.p, c->d_tgt_band.p,
-                    c->d_chunk_band.p};
+                    c->d_chunk_band.p, c->d_cull_keys.p};
     if (mode != 0 || c->brute || !maxM) pools.cull = nullptr;
     else L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
     L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));

@@ -23,6 +23,8 @@ struct PairCull {
     uint64_t t_off;        // first entry in the target pools
     uint32_t c_off;        // first chunk band
     uint32_t enabled;      // 0: geometry not suited (epipole in/near the image, degenerate F) -> plain streaming
+    uint64_t k_off;        // views beyond the LDS sort capacity: this pair's sort keys in CullPools::big_keys (source
+                           // side first, target side behind it); ~0 when both sides sort in LDS
 };
 struct CullPools {
     const PairCull* cull;      // [n_pairs] or nullptr
@@ -32,8 +34,10 @@ struct CullPools {
     float4* tgt_sf;            // [sum Mt] SegF records in sorted order
     float2* tgt_band;          // [sum Mt] their tau bands
     float2* chunk_band;        // [sum ceil(Mt/64)] tau band of each 64-record chunk
+    uint64_t* big_keys;        // global sort scratch of the pairs whose views exceed kCullLdsSegs
 };
-constexpr uint32_t kCullMaxSegs = 16384;   // LDS sort capacity of k_cull_prepare
+constexpr uint32_t kCullLdsSegs = 16384;   // LDS sort capacity of k_cull_prepare (larger views sort in global memory)
+constexpr uint32_t kCullMaxSegs = 1u << 20; // 20 index bits in the sort keys beside class and band
 
 // the orientation filter of phase B fused into whatever produces a slot (match epilogue, exchange expansion)
 struct OrientFuse {

@@ -161,13 +161,13 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
                          // derives global segment ids from it for the phase-B counters it feeds
     DevBuf<unsigned long long> cnt_pack; DevBuf<uint32_t> inv_pos, tie_count, tie_ix; DevBuf<uint2> tie_list; DevBuf<float> tie_ov;
     DevBuf<double> consts; DevBuf<ViewDev> dv; DevBuf<PairDesc> dp; DevBuf<WorkItem> dw; DevBuf<Slot> ds;
-    DevBuf<PairCull> dc; DevBuf<uint32_t> sperm, tperm; DevBuf<float2> sband, tband, cband; DevBuf<float4> tsf;
+    DevBuf<PairCull> dc; DevBuf<uint64_t> ckeys; DevBuf<uint32_t> sperm, tperm; DevBuf<float2> sband, tband, cband; DevBuf<float4> tsf;
     auto cleanup = [&]() {
         for (int i = 0; i < 2; ++i) { seg4[i].release(); segf[i].release(); }
         segx.release(); cnt_pack.release(); inv_pos.release();
         tie_count.release(); tie_ix.release(); tie_list.release(); tie_ov.release();
         consts.release(); dv.release(); dp.release(); dw.release(); ds.release();
-        dc.release(); sperm.release(); tperm.release(); sband.release(); tband.release(); cband.release(); tsf.release();
+        dc.release(); ckeys.release(); sperm.release(); tperm.release(); sband.release(); tband.release(); cband.release(); tsf.release();
     };
     int rc = [&]() -> int {
         ViewDev hv[2];
@@ -201,13 +201,22 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         PairCull pc{};
         if (Ms <= kCullMaxSegs && Mt <= kCullMaxSegs && std::getenv("L3D_NO_CULL") == nullptr)
             make_cull(pd.F, width, height, width, height, pc);
+        pc.k_off = ~0ull;
+        uint64_t n_keys = 0;
+        if (pc.enabled && std::max(Ms, Mt) > kCullLdsSegs) {
+            uint32_t a = 64, b = 64;
+            while (a < Ms) a <<= 1;
+            while (b < Mt) b <<= 1;
+            pc.k_off = 0; n_keys = (uint64_t)a + b;
+        }
         CullPools pools{};
         if (pc.enabled) {
             L3D_HIP_CHECK(dc.reserve(1)); L3D_HIP_CHECK(sperm.reserve(Ms)); L3D_HIP_CHECK(sband.reserve(Ms));
             L3D_HIP_CHECK(tperm.reserve(Mt)); L3D_HIP_CHECK(tsf.reserve(Mt)); L3D_HIP_CHECK(tband.reserve(Mt));
             L3D_HIP_CHECK(cband.reserve((Mt + 63) / 64));
             L3D_HIP_CHECK(hipMemcpy(dc.p, &pc, sizeof(pc), hipMemcpyHostToDevice));
-            pools = CullPools{dc.p, sperm.p, sband.p, tperm.p, tsf.p, tband.p, cband.p};
+            L3D_HIP_CHECK(ckeys.reserve(std::max<uint64_t>(n_keys, 1)));
+            pools = CullPools{dc.p, sperm.p, sband.p, tperm.p, tsf.p, tband.p, cband.p, ckeys.p};
             L3D_HIP_CHECK(launch_cull_prepare(dv.p, dp.p, 0, 1, std::max(Ms, Mt), pools, 0));
         }
         // the kernel also applies the orientation filter (slot flags) and feeds the phase-B counters: scratch here
