@@ -563,158 +563,6 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
     return hipGetLastError();
 }
 
-// ---- rows with equal overlaps: the reference's kNN order, replayed ------------------------------------------------
-// Line3D::matchingCPU keeps a row's accepted matches in a std::priority_queue keyed by the overlap alone and pops
-// kNN of them (line3D.cc:982-1007): with equal overlaps, which entries come out and in which order is the pop order
-// of libstdc++'s binary heap.  k_match_pairs selects by (overlap desc, target asc), which is the same thing for
-// distinct overlaps, and hands every row in which it saw equal overlaps -- inside the table or at the kNN-th place --
-// to this kernel (one wave per row): all Mt targets through the exact test in ascending target order, accepted ones
-// pushed into the very heap the reference builds (l3d_heap.h), kNN pops, then the same slot / orientation / counter
-// work as the match epilogue.  Such rows are rare (C1: none, C4: a few per 10^5 rows), duplicated segments make many.
-constexpr uint32_t kTieBlock = 512;       // threads per tied row (all Mt exact tests in Mt/512 steps)
-constexpr uint32_t kTieLdsHeap = 7168;    // accepted (overlap, target) pairs kept in LDS (56 KiB); more: global scratch
-
-// tie_count[0] = rows queued by the match kernel, [1] = blocks done (the last one resets [0] for the next launch),
-// [2] = rows replayed since the context was created (diagnostics)
-__global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __restrict__ views,
-                                                               const PairDesc* __restrict__ pairs,
-                                                               Slot* __restrict__ slots, float thr, const OrientFuse of,
-                                                               float* __restrict__ scratch_ov,
-                                                               uint32_t* __restrict__ scratch_ix, uint32_t scratch_stride) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float s_hov[kTieLdsHeap];
-    __shared__ uint32_t s_hix[kTieLdsHeap];
-    __shared__ uint32_t s_wcnt[kTieBlock / 64];
-    __shared__ uint32_t s_nwin;
-    float* win_ov = (float*)smem;                 // [K] dynamic
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t n_tied = min(of.tie_count[0], of.tie_cap);
-    float* gov = scratch_ov + (size_t)blockIdx.x * scratch_stride;
-    uint32_t* gix = scratch_ix + (size_t)blockIdx.x * scratch_stride;
-    for (uint32_t t = blockIdx.x; t < n_tied; t += gridDim.x) {
-        const uint2 item = of.tie_list[t];
-        const PairDesc& pd = pairs[item.x];
-        const uint32_t src = item.y, K = pd.K, Mt = pd.Mt;
-        uint32_t* win_ix = (uint32_t*)(win_ov + K);
-        const ViewDev& vs = views[pd.src];
-        const ViewDev& vt = views[pd.tgt];
-        double F[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) F[i] = pd.F[i];
-        const float4 s4 = vs.seg4[src];
-        const SegX sx = vs.segx[src];
-        // the row's two epipolar lines for the conservative fp32 pre-filter (as the prologue of k_match_pairs): only
-        // its survivors go through the double-precision test
-        float e1x = 0, e1y = 0, e1z = 0, e2x = 0, e2y = 0, e2z = 0;
-        bool live = false;
-        {
-            const d3 e1 = mul33(F, d3{(double)s4.x, (double)s4.y, 1.0});
-            const d3 e2 = mul33(F, d3{(double)s4.z, (double)s4.w, 1.0});
-            const double n1 = sqrt(e1.x * e1.x + e1.y * e1.y), n2 = sqrt(e2.x * e2.x + e2.y * e2.y);
-            if (n1 > 0.0 && n2 > 0.0) {
-                const double cx = (double)vt.cx, cy = (double)vt.cy;
-                e1x = (float)(e1.x / n1); e1y = (float)(e1.y / n1); e1z = (float)((e1.z + (e1.x * cx + e1.y * cy)) / n1);
-                e2x = (float)(e2.x / n2); e2y = (float)(e2.y / n2); e2z = (float)((e2.z + (e2.x * cx + e2.y * cy)) / n2);
-                live = true;
-            }
-        }
-        // ---- every target through the acceptance test; accepted ones in ascending target order ----
-        uint32_t n = 0;                           // accepted so far (block-uniform)
-        for (uint32_t c0 = 0; c0 < Mt; c0 += kTieBlock) {
-            const uint32_t cc = c0 + tid;
-            bool acc = false;
-            PairResult res{};
-            if (cc < Mt && live) {
-                const SegF f = vt.segf[cc];
-                const v4f q = {f.qx, f.qy, f.dx, f.dy};
-                if (prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q, thr))
-                    acc = exact_pair(F, s4, vt.seg4[cc], sx, vt.segx[cc], vs.C, vt.C, thr, res);
-            }
-            const uint64_t m = __ballot(acc);
-            if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(m);
-            __syncthreads();
-            uint32_t before = 0, total = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < kTieBlock / 64; ++w) { const uint32_t x = s_wcnt[w]; before += w < wave ? x : 0u; total += x; }
-            if (acc) {
-                const uint32_t k = n + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (k < kTieLdsHeap) { s_hov[k] = res.overlap; s_hix[k] = cc; }
-                else { gov[k] = res.overlap; gix[k] = cc; }
-            }
-            n += total;
-            __syncthreads();
-        }
-        // ---- the reference's heap: push all in order, pop K (one thread; n is a few dozen to a few hundred) ----
-        if (n > kTieLdsHeap) {   // outgrown the LDS list: continue in this block's global scratch
-            for (uint32_t i = tid; i < kTieLdsHeap; i += kTieBlock) { gov[i] = s_hov[i]; gix[i] = s_hix[i]; }
-            __threadfence_block();
-        }
-        __syncthreads();
-        if (tid == 0) {
-            float* hov = n > kTieLdsHeap ? gov : s_hov;       // generic pointers
-            uint32_t* hix = n > kTieLdsHeap ? gix : s_hix;
-            for (uint32_t i = 1; i < n; ++i) heap_push(hov, hix, i, hov[i], hix[i]);   // in place: the heap is the prefix
-            uint32_t w = 0, left = n;
-            while (w < K && left > 0) {
-                float v; uint32_t x;
-                heap_pop(hov, hix, left, v, x);
-                --left;
-                win_ov[w] = v; win_ix[w] = x; ++w;
-            }
-            s_nwin = w;
-        }
-        __syncthreads();
-        const uint32_t n_win = s_nwin;
-        const uint32_t gs = (uint32_t)(vs.segx - views[0].segx), gt = (uint32_t)(vt.segx - views[0].segx);
-        const bool hands_inverse = pd.tgt > pd.src;
-        // ---- the row's K slots: depths, orientation filter, phase-B counters (as the match epilogue) ----
-        for (uint32_t j0 = 0; j0 < K; j0 += kTieBlock) {
-            const uint32_t j = j0 + tid;
-            Slot o;
-            o.tgt_seg = kEmpty; o.overlap = 0; o.dp1 = o.dp2 = o.dq1 = o.dq2 = 0; o.score3D = 0.0f; o.flags = 0;
-            uint32_t ipos = kEmpty;
-            if (j < n_win) {
-                const uint32_t xj = win_ix[j];
-                const SegX tx = vt.segx[xj];
-                PairResult res{};
-                exact_depths(sx, tx, vs.C, vt.C, res);
-                res.overlap = win_ov[j];
-                o.tgt_seg = xj; o.overlap = res.overlap;
-                o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
-                o.flags = fuse_orientation(of, vs.C, vt.C, sx, tx, res, hands_inverse, gt + xj, ipos);
-            }
-            if (j < K) {
-                const uint64_t at = pd.slot_off + (uint64_t)src * K + j;
-                slots[at] = o;
-                of.inv_pos[at] = ipos;
-            }
-            const uint32_t n_alive = (uint32_t)__popcll(__ballot((o.flags & kSlotAlive) != 0));
-            if (lane == 0 && n_alive) atomicAdd(&of.cnt_pack[gs + src], (unsigned long long)n_alive);
-        }
-        __syncthreads();
-    }
-    // the last block to finish re-arms the queue for the next match launch
-    if (tid == 0) {
-        __threadfence();
-        if (atomicAdd(&of.tie_count[1], 1u) == gridDim.x - 1) {
-            of.tie_count[2] += n_tied;
-            of.tie_count[0] = 0; of.tie_count[1] = 0;
-            __threadfence();
-        }
-    }
-}
-
-uint32_t match_tied_grid() { return 128; }
-
-hipError_t launch_match_tied_rows(const ViewDev* views, const PairDesc* pairs, Slot* slots, uint32_t maxK, float thr,
-                                  OrientFuse of, float* scratch_ov, uint32_t* scratch_ix, uint32_t scratch_stride,
-                                  hipStream_t stream) {
-    if (!of.tie_count || !of.tie_list || !scratch_ov || !scratch_ix) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_match_tied_rows, dim3(match_tied_grid()), dim3(kTieBlock), (size_t)maxK * 8, stream, views, pairs,
-                       slots, thr, of, scratch_ov, scratch_ix, scratch_stride);
-    return hipGetLastError();
-}
-
 // ---- compact slot exchange (N > 1 ranks) ---------------------------------------------------------------------
 // Between ranks only the target index of every slot travels (4 B instead of the 32-byte record): overlap and
 // depths are functions of (pair, source row, target index) alone, so the receiving rank re-derives them with the
@@ -978,6 +826,199 @@ hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint
     hipError_t e = hipFuncSetAttribute((const void*)k_cull_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_cull_prepare, dim3(count, 2), dim3(kCullBlock), lds, stream, views, pairs, first, pools);
+    return hipGetLastError();
+}
+
+// ---- rows with equal overlaps: the reference's kNN order, replayed ------------------------------------------------
+// Line3D::matchingCPU keeps a row's accepted matches in a std::priority_queue keyed by the overlap alone and pops
+// kNN of them (line3D.cc:982-1007): with equal overlaps, which entries come out and in which order is the pop order
+// of libstdc++'s binary heap.  k_match_pairs selects by (overlap desc, target asc), which is the same thing for
+// distinct overlaps, and hands every row in which it saw equal overlaps -- inside the table or at the kNN-th place --
+// to this kernel (one wave per row): all Mt targets through the exact test in ascending target order, accepted ones
+// pushed into the very heap the reference builds (l3d_heap.h), kNN pops, then the same slot / orientation / counter
+// work as the match epilogue.  Such rows are rare (C1: none, C4: a few per 10^5 rows), duplicated segments make many.
+constexpr uint32_t kTieBlock = 512;       // threads per tied row (all Mt exact tests in Mt/512 steps)
+constexpr uint32_t kTieLdsHeap = 1024;    // accepted (overlap, target) entries kept in LDS (8 KiB + 8 KiB sort buffer: four
+                                          // workgroups per CU); more: the workgroup's global scratch
+
+// arrival order -> ascending target order (rank by counting: targets are distinct), then the reference's heap: push
+// all, pop K (l3d_heap.h).  One thread walks the heap -- every access is a dependent round trip, which is why the
+// entries are packed and why the LDS case is instantiated with LDS pointers rather than generic ones.
+template <class Ptr>
+__device__ __forceinline__ uint32_t tie_select(Ptr list, Ptr sorted, uint32_t n, uint32_t K, float* win_ov, uint32_t* win_ix,
+                                               uint32_t tid) {
+    for (uint32_t i = tid; i < n; i += kTieBlock) {
+        const uint64_t me = list[i];
+        uint32_t rank = 0;
+        for (uint32_t y = 0; y < n; ++y) rank += (uint32_t)list[y] < (uint32_t)me ? 1u : 0u;
+        sorted[rank] = me;
+    }
+    __threadfence_block();
+    __syncthreads();
+    uint32_t w = 0;
+    if (tid == 0) {
+        for (uint32_t i = 1; i < n; ++i) heap_push_packed(sorted, i, sorted[i]);   // in place: the heap is the prefix
+        uint32_t left = n;
+        while (w < K && left > 0) {
+            const uint64_t e = heap_pop_packed(sorted, left);
+            --left;
+            win_ov[w] = heap_overlap(e); win_ix[w] = (uint32_t)e; ++w;
+        }
+    }
+    return w;
+}
+
+// tie_count[0] = rows queued by the match kernel, [1] = blocks done (the last one resets [0] for the next launch),
+// [2] = rows replayed since the context was created (diagnostics)
+__global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __restrict__ views,
+                                                               const PairDesc* __restrict__ pairs,
+                                                               Slot* __restrict__ slots, float thr, const OrientFuse of,
+                                                               const CullPools cp, uint64_t* __restrict__ scratch,
+                                                               uint32_t scratch_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint64_t s_list[kTieLdsHeap], s_sorted[kTieLdsHeap];
+    __shared__ uint32_t s_n;
+    __shared__ uint32_t s_nwin;
+    float* win_ov = (float*)smem;                 // [K] dynamic
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t n_tied = min(of.tie_count[0], of.tie_cap);
+    uint64_t* glist = scratch + (size_t)blockIdx.x * 2 * scratch_stride;      // [2 stride]: list + sort buffer
+    for (uint32_t t = blockIdx.x; t < n_tied; t += gridDim.x) {
+        const uint2 item = of.tie_list[t];
+        const PairDesc& pd = pairs[item.x];
+        const uint32_t src = item.y, K = pd.K, Mt = pd.Mt;
+        uint32_t* win_ix = (uint32_t*)(win_ov + K);
+        const ViewDev& vs = views[pd.src];
+        const ViewDev& vt = views[pd.tgt];
+        double F[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) F[i] = pd.F[i];
+        const float4 s4 = vs.seg4[src];
+        const SegX sx = vs.segx[src];
+        // the row's two epipolar lines for the conservative fp32 pre-filter (as the prologue of k_match_pairs): only
+        // its survivors go through the double-precision test
+        float e1x = 0, e1y = 0, e1z = 0, e2x = 0, e2y = 0, e2z = 0;
+        bool live = false;
+        {
+            const d3 e1 = mul33(F, d3{(double)s4.x, (double)s4.y, 1.0});
+            const d3 e2 = mul33(F, d3{(double)s4.z, (double)s4.w, 1.0});
+            const double n1 = sqrt(e1.x * e1.x + e1.y * e1.y), n2 = sqrt(e2.x * e2.x + e2.y * e2.y);
+            if (n1 > 0.0 && n2 > 0.0) {
+                const double cx = (double)vt.cx, cy = (double)vt.cy;
+                e1x = (float)(e1.x / n1); e1y = (float)(e1.y / n1); e1z = (float)((e1.z + (e1.x * cx + e1.y * cy)) / n1);
+                e2x = (float)(e2.x / n2); e2y = (float)(e2.y / n2); e2z = (float)((e2.z + (e2.x * cx + e2.y * cy)) / n2);
+                live = true;
+            }
+        }
+        // ---- every target that can match through the acceptance test.  A culled pair (k_cull_prepare ran for it):
+        // only the chunks / targets whose epipolar band meets the row's, in band order -- the accepted ones are put
+        // back into ascending target order afterwards, the order in which the reference pushes them ----
+        const PairCull* pc = (cp.cull && cp.cull[item.x].enabled) ? &cp.cull[item.x] : nullptr;
+        float blo = -__builtin_inff(), bhi = __builtin_inff();
+        if (pc) { const Band bb = src_band(*pc, s4); blo = bb.lo; bhi = bb.hi; }
+        const uint32_t n_units = pc ? (Mt + 63) / 64 * 64 : Mt;     // culled: whole 64-target chunks, one per wave
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < n_units; c0 += kTieBlock) {
+            const uint32_t p = c0 + tid;          // sorted position (culled) or target index
+            bool acc = false;
+            uint32_t cc = p;
+            PairResult res{};
+            if (p < Mt && live) {
+                bool cand;
+                if (pc) {
+                    const float2 cb = cp.chunk_band[pc->c_off + (p >> 6)];
+                    cand = !(cb.y < blo || cb.x > bhi);
+                    if (cand) { const float2 tb = cp.tgt_band[pc->t_off + p]; cand = !(tb.y < blo || tb.x > bhi); }
+                    if (cand) {
+                        const float4 f = cp.tgt_sf[pc->t_off + p];
+                        const v4f q = {f.x, f.y, f.z, f.w};
+                        cand = prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q, thr);
+                        if (cand) cc = cp.tgt_perm[pc->t_off + p];
+                    }
+                } else {
+                    const SegF f = vt.segf[p];
+                    const v4f q = {f.qx, f.qy, f.dx, f.dy};
+                    cand = prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q, thr);
+                }
+                if (cand) acc = exact_pair(F, s4, vt.seg4[cc], sx, vt.segx[cc], vs.C, vt.C, thr, res);
+            }
+            // accepted ones are appended in any order (one LDS atomic each, no barrier in this loop): they are sorted by
+            // target index below anyway
+            if (acc) {
+                const uint32_t k = atomicAdd(&s_n, 1u);
+                const uint64_t e = heap_pack(res.overlap, cc);
+                if (k < kTieLdsHeap) s_list[k] = e;
+                else glist[k] = e;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        const uint32_t n = s_n;
+        // ---- the reference's heap: push all in ascending target order, pop K ----
+        uint32_t w;
+        if (n <= kTieLdsHeap) {
+            w = tie_select(s_list, s_sorted, n, K, win_ov, win_ix, tid);
+        } else {                 // outgrown the LDS list: continue in this block's global scratch
+            for (uint32_t i = tid; i < kTieLdsHeap; i += kTieBlock) glist[i] = s_list[i];
+            __threadfence_block();
+            __syncthreads();
+            w = tie_select(glist, glist + scratch_stride, n, K, win_ov, win_ix, tid);
+        }
+        if (tid == 0) s_nwin = w;
+        __syncthreads();
+        const uint32_t n_win = s_nwin;
+        const uint32_t gs = (uint32_t)(vs.segx - views[0].segx), gt = (uint32_t)(vt.segx - views[0].segx);
+        const bool hands_inverse = pd.tgt > pd.src;
+        // ---- the row's K slots: depths, orientation filter, phase-B counters (as the match epilogue) ----
+        for (uint32_t j0 = 0; j0 < K; j0 += kTieBlock) {
+            const uint32_t j = j0 + tid;
+            Slot o;
+            o.tgt_seg = kEmpty; o.overlap = 0; o.dp1 = o.dp2 = o.dq1 = o.dq2 = 0; o.score3D = 0.0f; o.flags = 0;
+            uint32_t ipos = kEmpty;
+            if (j < n_win) {
+                const uint32_t xj = win_ix[j];
+                const SegX tx = vt.segx[xj];
+                PairResult res{};
+                exact_depths(sx, tx, vs.C, vt.C, res);
+                res.overlap = win_ov[j];
+                o.tgt_seg = xj; o.overlap = res.overlap;
+                o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
+                o.flags = fuse_orientation(of, vs.C, vt.C, sx, tx, res, hands_inverse, gt + xj, ipos);
+            }
+            if (j < K) {
+                const uint64_t at = pd.slot_off + (uint64_t)src * K + j;
+                slots[at] = o;
+                of.inv_pos[at] = ipos;
+            }
+            const uint32_t n_alive = (uint32_t)__popcll(__ballot((o.flags & kSlotAlive) != 0));
+            if (lane == 0 && n_alive) atomicAdd(&of.cnt_pack[gs + src], (unsigned long long)n_alive);
+        }
+        __syncthreads();
+    }
+    // the last block to finish re-arms the queue for the next match launch
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(&of.tie_count[1], 1u) == gridDim.x - 1) {
+            of.tie_count[2] += n_tied;
+            of.tie_count[0] = 0; of.tie_count[1] = 0;
+            __threadfence();
+        }
+    }
+}
+
+// four workgroups per CU; fewer when the per-workgroup scratch (16 bytes per target) would pass 128 MiB in total
+uint32_t match_tied_grid(uint32_t scratch_stride) {
+    const uint64_t per_wg = 2ull * std::max(scratch_stride, 1u) * 8;
+    return (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, (128ull << 20) / per_wg));
+}
+
+hipError_t launch_match_tied_rows(const ViewDev* views, const PairDesc* pairs, Slot* slots, uint32_t maxK, float thr,
+                                  OrientFuse of, CullPools cp, uint64_t* scratch, uint32_t scratch_stride,
+                                  hipStream_t stream) {
+    if (!of.tie_count || !of.tie_list || !scratch) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_match_tied_rows, dim3(match_tied_grid(scratch_stride)), dim3(kTieBlock), (size_t)maxK * 8, stream,
+                       views, pairs, slots, thr, of, cp, scratch, scratch_stride);
     return hipGetLastError();
 }
 

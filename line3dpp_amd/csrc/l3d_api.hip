@@ -268,7 +268,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_has_best.release(); c->d_best_pos.release(); c->d_surv_off.release(); c->d_hyp_off.release();
     c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_bits.release(); c->d_eref.release(); c->d_positive.release(); c->d_bits_len.release(); c->d_boff.release(); c->d_cnt_inv.release(); c->d_long_list.release();
     c->d_cnt_pack.release(); c->d_inv_pos.release(); c->d_gsegx.release();
-    c->d_tie_count.release(); c->d_tie_list.release(); c->d_tie_ov.release(); c->d_tie_ix.release();
+    c->d_tie_count.release(); c->d_tie_list.release(); c->d_tie_heap.release();
     c->d_coll_cnt.release(); c->d_coll_off.release(); c->d_coll_idx.release(); c->d_item_cnt.release();
     c->d_item_off.release(); c->d_item_seg.release(); c->d_item_sim.release();
     c->d_inv_off.release(); c->d_vout_pairs.release(); c->d_vout_off.release(); c->d_dents.release(); c->d_surv.release();
@@ -572,16 +572,15 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
             L3D_HIP_CHECK(hipMemsetAsync(c->d_tie_count.p, 0, 16, c->stream));
         }
         L3D_HIP_CHECK(c->d_tie_list.reserve(std::max<uint32_t>(c->n_rows_total, 1)));
-        L3D_HIP_CHECK(c->d_tie_ov.reserve((size_t)match_tied_grid() * tie_stride));
-        L3D_HIP_CHECK(c->d_tie_ix.reserve((size_t)match_tied_grid() * tie_stride));
+        L3D_HIP_CHECK(c->d_tie_heap.reserve(2 * (size_t)match_tied_grid(tie_stride) * tie_stride));
         of.tie_count = c->d_tie_count.p; of.tie_list = c->d_tie_list.p; of.tie_cap = c->n_rows_total;
     }
     L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work, maxK,
                                      c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, of, ix16, c->stream));
     L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));
     if (mode == 0) {
-        L3D_HIP_CHECK(launch_match_tied_rows(c->d_views.p, c->d_pairs.p, c->d_slots.p, maxK, c->epipolar_overlap, of,
-                                             c->d_tie_ov.p, c->d_tie_ix.p, tie_stride, c->stream));
+        L3D_HIP_CHECK(launch_match_tied_rows(c->d_views.p, c->d_pairs.p, c->d_slots.p, maxK, c->epipolar_overlap, of, pools,
+                                             c->d_tie_heap.p, tie_stride, c->stream));
         for (uint32_t p = first; p < first + count; ++p) c->pair_counted[p] = 1;
     }
     if (pools.cull)

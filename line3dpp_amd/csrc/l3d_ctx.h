@@ -167,9 +167,9 @@ struct l3d_ctx {
     uint32_t pending_launches = 0;
     DevBuf<uint32_t> d_row_counts;
     // rows with equal overlaps (k_match_tied_rows): counter, (pair, row) list, heap scratch of the replay kernel
-    DevBuf<uint32_t> d_tie_count, d_tie_ix;
+    DevBuf<uint32_t> d_tie_count;
     DevBuf<uint2> d_tie_list;
-    DevBuf<float> d_tie_ov;
+    DevBuf<uint64_t> d_tie_heap;
     // phase B (global over all views; G = sum of M)
     uint32_t G = 0, n_ents = 0, n_surv = 0, n_hyps = 0;
     std::vector<uint32_t> seg_base;                 // [V+1]

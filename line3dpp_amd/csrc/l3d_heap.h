@@ -61,4 +61,63 @@ L3D_HEAP_HD void heap_pop(OvPtr ov, IxPtr ix, uint32_t n, float& top_v, uint32_t
     ov[hole] = v; ix[hole] = x;
 }
 
+// The same two operations on PACKED entries: overlap bits in the high word, target in the low word, one 64-bit access
+// per element instead of two 32-bit ones (the replay kernel's heap lives in LDS and one thread walks it: every access
+// is a dependent round trip).  The overlaps that reach the heap are positive floats, whose IEEE bit patterns order
+// like the values, so the comparison is on the high words as unsigned integers -- the low word (target) must not
+// take part, the reference's comparator does not look at it.
+L3D_HEAP_HD uint64_t heap_pack(float ov, uint32_t ix) {
+    union { float f; uint32_t u; } c; c.f = ov;
+    return (uint64_t)c.u << 32 | ix;
+}
+L3D_HEAP_HD float heap_overlap(uint64_t e) {
+    union { float f; uint32_t u; } c; c.u = (uint32_t)(e >> 32);
+    return c.f;
+}
+L3D_HEAP_HD bool heap_less(uint64_t a, uint64_t b) { return (uint32_t)(a >> 32) < (uint32_t)(b >> 32); }
+
+template <class Ptr>
+L3D_HEAP_HD void heap_push_packed(Ptr h, uint32_t n, uint64_t e) {
+    uint32_t hole = n;
+    while (hole > 0) {
+        const uint32_t parent = (hole - 1) / 2;
+        const uint64_t p = h[parent];
+        if (!heap_less(p, e)) break;
+        h[hole] = p;
+        hole = parent;
+    }
+    h[hole] = e;
+}
+
+template <class Ptr>
+L3D_HEAP_HD uint64_t heap_pop_packed(Ptr h, uint32_t n) {
+    const uint64_t top = h[0];
+    const uint32_t len = n - 1;
+    if (len == 0) return top;
+    const uint64_t e = h[len];
+    uint32_t hole = 0, second = 0;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        const uint64_t r = h[second], l = h[second - 1];    // independent loads: one round trip per level
+        uint64_t pick = r;
+        if (heap_less(r, l)) { --second; pick = l; }
+        h[hole] = pick;
+        hole = second;
+    }
+    if ((len & 1u) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        h[hole] = h[second - 1];
+        hole = second - 1;
+    }
+    while (hole > 0) {
+        const uint32_t parent = (hole - 1) / 2;
+        const uint64_t p = h[parent];
+        if (!heap_less(p, e)) break;
+        h[hole] = p;
+        hole = parent;
+    }
+    h[hole] = e;
+    return top;
+}
+
 }  // namespace l3d

@@ -61,10 +61,11 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
                               uint32_t* row_counts, float thr, CullPools pools, OrientFuse of, bool ix16,
                               hipStream_t stream);
 // rows flagged by the match kernel (equal overlaps): the reference's priority_queue order, replayed; scratch = one
-// region of scratch_stride (>= max Mt) entries per workgroup of match_tied_grid()
-uint32_t match_tied_grid();
+// region of 2 * scratch_stride (stride >= max Mt) packed entries per workgroup of match_tied_grid(stride); cp: the culling pools of the
+// match launch (cp.cull == nullptr: every target is visited)
+uint32_t match_tied_grid(uint32_t scratch_stride);
 hipError_t launch_match_tied_rows(const ViewDev* views, const PairDesc* pairs, Slot* slots, uint32_t maxK, float thr,
-                                  OrientFuse of, float* scratch_ov, uint32_t* scratch_ix, uint32_t scratch_stride,
+                                  OrientFuse of, CullPools cp, uint64_t* scratch, uint32_t scratch_stride,
                                   hipStream_t stream);
 // compact exchange of slots between ranks: target indices out, full records back (bit-identical re-derivation)
 hipError_t launch_pack_slot_idx(const Slot* slots, uint32_t* idx, uint64_t lo, uint64_t hi, hipStream_t stream);

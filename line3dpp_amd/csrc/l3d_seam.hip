@@ -159,13 +159,13 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
     DevBuf<float4> seg4[2]; DevBuf<SegF> segf[2];
     DevBuf<SegX> segx;   // one array for both views (source first), like the context's global array: the match kernel
                          // derives global segment ids from it for the phase-B counters it feeds
-    DevBuf<unsigned long long> cnt_pack; DevBuf<uint32_t> inv_pos, tie_count, tie_ix; DevBuf<uint2> tie_list; DevBuf<float> tie_ov;
+    DevBuf<unsigned long long> cnt_pack; DevBuf<uint32_t> inv_pos, tie_count; DevBuf<uint2> tie_list; DevBuf<uint64_t> tie_heap;
     DevBuf<double> consts; DevBuf<ViewDev> dv; DevBuf<PairDesc> dp; DevBuf<WorkItem> dw; DevBuf<Slot> ds;
     DevBuf<PairCull> dc; DevBuf<uint64_t> ckeys; DevBuf<uint32_t> sperm, tperm; DevBuf<float2> sband, tband, cband; DevBuf<float4> tsf;
     auto cleanup = [&]() {
         for (int i = 0; i < 2; ++i) { seg4[i].release(); segf[i].release(); }
         segx.release(); cnt_pack.release(); inv_pos.release();
-        tie_count.release(); tie_ix.release(); tie_list.release(); tie_ov.release();
+        tie_count.release(); tie_list.release(); tie_heap.release();
         consts.release(); dv.release(); dp.release(); dw.release(); ds.release();
         dc.release(); ckeys.release(); sperm.release(); tperm.release(); sband.release(); tband.release(); cband.release(); tsf.release();
     };
@@ -223,14 +223,14 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         L3D_HIP_CHECK(cnt_pack.reserve((size_t)Ms + Mt + 1)); L3D_HIP_CHECK(inv_pos.reserve((size_t)Ms * pd.K));
         L3D_HIP_CHECK(hipMemset(cnt_pack.p, 0, ((size_t)Ms + Mt + 1) * 8));
         L3D_HIP_CHECK(tie_count.reserve(4)); L3D_HIP_CHECK(tie_list.reserve(Ms));
-        L3D_HIP_CHECK(tie_ov.reserve((size_t)match_tied_grid() * Mt)); L3D_HIP_CHECK(tie_ix.reserve((size_t)match_tied_grid() * Mt));   // (l3d_kernels.h: one scratch region per workgroup)
+        L3D_HIP_CHECK(tie_heap.reserve(2 * (size_t)match_tied_grid(Mt) * std::max(Mt, 1u)));   // (l3d_kernels.h: one scratch region per workgroup)
         L3D_HIP_CHECK(hipMemset(tie_count.p, 0, 16));
         OrientFuse of{cnt_pack.p, inv_pos.p, OrientThr{-1.0, 1.0}, tie_count.p, tie_list.p, Ms};
         orientation_thresholds(of.thr.lo, of.thr.hi);
         L3D_HIP_CHECK(launch_match_pairs(0, false, dv.p, dp.p, dw.p, (uint32_t)work.size(), pd.K, ds.p, nullptr, thr,
                                          pools, of, Mt < 65536u && pd.K < 65536u, 0));
         // rows with equal overlaps: the reference's priority_queue order (line3D.cc:982-1007)
-        L3D_HIP_CHECK(launch_match_tied_rows(dv.p, dp.p, ds.p, pd.K, thr, of, tie_ov.p, tie_ix.p, Mt, 0));
+        L3D_HIP_CHECK(launch_match_tied_rows(dv.p, dp.p, ds.p, pd.K, thr, of, pools, tie_heap.p, std::max(Mt, 1u), 0));
         L3D_HIP_CHECK(hipDeviceSynchronize());
         L3D_HIP_CHECK(hipMemcpy(out_slots, ds.p, (size_t)Ms * pd.K * sizeof(Slot), hipMemcpyDeviceToHost));
         return L3D_OK;
