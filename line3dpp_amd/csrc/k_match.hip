@@ -158,8 +158,10 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware order: consecutive work items (same pair => same target view) go to one XCD
     // (block b runs on XCD b % 8, MI355X_MICROARCH.md), so the target view stays in that XCD's L2.
+    // With a longest-first order (k_order_items) workgroup b simply takes the b-th longest item.
     const uint32_t per_xcd = (nwork + 7) / 8;
-    const uint32_t w = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    uint32_t w = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (cp.item_order) w = blockIdx.x < nwork ? cp.item_order[blockIdx.x] : nwork;
     if (w >= nwork) return;
     const WorkItem wi = work[w];
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
@@ -531,7 +533,7 @@ uint32_t match_waves_per_group(int mode, bool brute, uint32_t nwork) {
     if (mode != 0 || brute) return 1;   // keep-all rows need ascending target order; the brute path is a test hook
     static const int forced = [] { const char* e = std::getenv("L3D_MATCH_WPG"); return e ? std::atoi(e) : 0; }();
     if (forced == 1 || forced == 2) return (uint32_t)forced;
-    return nwork <= 16384u ? 2u : 1u;
+    return nwork <= kMatchOrderMaxItems ? 2u : 1u;
 }
 
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,
@@ -720,18 +722,126 @@ __device__ void lds_sort(uint64_t* keys, uint32_t n2) {
 
 }  // namespace
 
+// ---- longest-first launch order -----------------------------------------------------------------------------------
+// A work item's length is set by the targets its wave walks: those whose band meets the hull of its 64 rows' bands.
+// The spread is large (a group of wide-band rows walks the whole view, a group of narrow ones a twentieth of it), a
+// workgroup cannot migrate, and with one to three items per wave slot the launch ends when the longest late starter
+// does.  k_order_items (after k_cull_prepare; grid = pairs of the launch) counts, for every item of its pair, the
+// targets (beyond 4096 per view: the 64-target chunks) the item will walk and files it in one of kOrderBuckets
+// classes; the last workgroup to finish lays all items out by descending class (histogram, scan and cursors in its
+// LDS) and the match kernel's workgroup b takes item order[b].  Launches with many rounds of items keep the list
+// order: their tail is short against the whole, and the list order keeps the waves of a pair on one XCD.
+__global__ __launch_bounds__(kCullBlock) void k_order_items(const PairDesc* __restrict__ pairs, uint32_t first,
+                                                            const CullPools cp, uint32_t nwork) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t s_last;
+    const uint32_t p = first + blockIdx.x;
+    const PairCull& pc = cp.cull[p];
+    const uint32_t Ms = pairs[p].Ms, Mt = pairs[p].Mt;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, n_waves = kCullBlock / 64;
+    {   // ---- this pair's items: one wave per item, the pair's target (or chunk) bands staged once in LDS ----
+        float2* bands = (float2*)smem;
+        const bool by_target = Mt <= 4096;
+        const uint32_t n_bands = !pc.enabled ? 0u : by_target ? Mt : (Mt + 63) / 64;
+        const float2* src = by_target ? cp.tgt_band + pc.t_off : cp.chunk_band + pc.c_off;
+        for (uint32_t i = tid; i < n_bands; i += kCullBlock) bands[i] = src[i];
+        __syncthreads();
+        const uint32_t n_items = (Ms + 63) / 64;
+        uint32_t* bucket = cp.item_bucket + (pc.w_item0 - cp.w_base);
+        const uint64_t cmax = cp.cost_max ? cp.cost_max : 1u;
+        for (uint32_t it = wave; it < n_items; it += n_waves) {
+            uint32_t cost = Mt;                  // streamed unculled: every item walks all Mt targets
+            if (pc.enabled) {
+                const uint32_t r = it * 64 + lane;
+                float lo = __builtin_inff(), hi = -__builtin_inff();
+                if (r < Ms) { const float2 b = cp.src_band[pc.s_off + r]; lo = b.x; hi = b.y; }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+                uint32_t n = 0;
+                for (uint32_t t = lane; t < n_bands; t += 64) {
+                    const float2 tb = bands[t];
+                    n += !(tb.y < lo || tb.x > hi) ? 1u : 0u;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+                cost = by_target ? n : n * 64;
+            }
+            if (lane == 0) {
+                const uint64_t q = (uint64_t)cost * kOrderBuckets / cmax;
+                bucket[it] = q < kOrderBuckets ? (uint32_t)q : kOrderBuckets - 1;
+            }
+        }
+    }
+    // ---- the last workgroup orders all items of the launch ----
+    __syncthreads();                             // this workgroup's buckets have reached L2
+    if (tid == 0) {
+        __threadfence();                         // ... and are visible to the other XCDs
+        s_last = atomicAdd(cp.order_done, 1u) == gridDim.x - 1;
+        __threadfence();
+    }
+    __syncthreads();
+    if (!s_last) return;
+    uint32_t* hist = (uint32_t*)smem;            // [kOrderBuckets] counts, then first position of each class
+    for (uint32_t i = tid; i < kOrderBuckets; i += kCullBlock) hist[i] = 0;
+    constexpr uint32_t kPer = kMatchOrderMaxItems / kCullBlock;     // items per thread, kept in registers
+    uint32_t mine[kPer];
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) {        // independent loads (not through this CU's L1: written by other CUs)
+        const uint32_t w = k * kCullBlock + tid;
+        mine[k] = w < nwork ? __hip_atomic_load(&cp.item_bucket[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k)
+        if (k * kCullBlock + tid < nwork) atomicAdd(&hist[mine[k]], 1u);
+    __syncthreads();
+    if (wave == 0) {                             // descending exclusive scan of 1024 counters by one wave
+        constexpr uint32_t per = kOrderBuckets / 64;
+        uint32_t h[per], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < per; ++k) { h[k] = hist[kOrderBuckets - 1 - (lane * per + k)]; sum += h[k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (uint32_t k = 0; k < per; ++k) { hist[kOrderBuckets - 1 - (lane * per + k)] = run; run += h[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) {
+        const uint32_t w = k * kCullBlock + tid;
+        if (w < nwork) {
+            const uint32_t pos = atomicAdd(&hist[mine[k]], 1u);
+            if (pos < nwork) cp.item_order[pos] = w;
+        }
+    }
+    if (tid == 0) *cp.order_done = 0;            // re-armed for the next launch
+}
+
+hipError_t launch_order_items(const PairDesc* pairs, uint32_t first, uint32_t count, uint32_t max_Mt, CullPools pools,
+                              uint32_t nwork, hipStream_t stream) {
+    if (!pools.item_order || !nwork || !count) return hipSuccess;
+    if (nwork > kMatchOrderMaxItems) return hipErrorInvalidValue;   // the ordering workgroup keeps its items in registers
+    const size_t lds = std::max<size_t>((size_t)(max_Mt <= 4096 ? max_Mt : (max_Mt + 63) / 64) * 8, kOrderBuckets * 4);
+    hipError_t e = hipFuncSetAttribute((const void*)k_order_items, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_order_items, dim3(count), dim3(kCullBlock), lds, stream, pairs, first, pools, nwork);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __restrict__ views,
                                                              const PairDesc* __restrict__ pairs, uint32_t first,
                                                              const CullPools cp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t p = first + blockIdx.x;
     const PairCull& pc = cp.cull[p];
-    if (!pc.enabled) return;
     const PairDesc& pd = pairs[p];
-    const ViewDev& vs = views[pd.src];
-    const ViewDev& vt = views[pd.tgt];
     const uint32_t Ms = pd.Ms, Mt = pd.Mt;
     const bool tgt_side = blockIdx.y != 0;       // grid.y = 2: the two sorts of a pair run in different workgroups
+    if (!pc.enabled) return;
+    const ViewDev& vs = views[pd.src];
+    const ViewDev& vt = views[pd.tgt];
     uint32_t n2 = 64;
     while (n2 < (tgt_side ? Mt : Ms)) n2 <<= 1;
     // keys in LDS up to kCullLdsSegs per side; beyond that in this pair's global scratch (same code, L2 instead of LDS:

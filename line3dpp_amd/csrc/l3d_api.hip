@@ -268,7 +268,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_has_best.release(); c->d_best_pos.release(); c->d_surv_off.release(); c->d_hyp_off.release();
     c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_bits.release(); c->d_eref.release(); c->d_positive.release(); c->d_bits_len.release(); c->d_boff.release(); c->d_cnt_inv.release(); c->d_long_list.release();
     c->d_cnt_pack.release(); c->d_inv_pos.release(); c->d_gsegx.release();
-    c->d_tie_count.release(); c->d_tie_list.release(); c->d_tie_heap.release();
+    c->d_tie_count.release(); c->d_tie_list.release(); c->d_tie_heap.release(); c->d_item_bucket.release(); c->d_item_order.release(); c->d_order_done.release();
     c->d_coll_cnt.release(); c->d_coll_off.release(); c->d_coll_idx.release(); c->d_item_cnt.release();
     c->d_item_off.release(); c->d_item_seg.release(); c->d_item_sim.release();
     c->d_inv_off.release(); c->d_vout_pairs.release(); c->d_vout_off.release(); c->d_dents.release(); c->d_surv.release();
@@ -402,7 +402,7 @@ static int match_begin_body(l3d_ctx* c) {
                 if (c->views.count(n)) v->visual_nbrs.insert(n);
     // directed pair list, line3D.cc:704-741
     c->pairs.clear(); c->pair_src_cam.clear(); c->pair_tgt_cam.clear(); c->cull.clear();
-    uint64_t cs_off = 0, ct_off = 0, ck_off = 0; uint32_t cc_off = 0;
+    uint64_t cs_off = 0, ct_off = 0, ck_off = 0; uint32_t cc_off = 0, w_item = 0;
     std::map<uint32_t, std::set<uint32_t>> matched;
     uint64_t slot_off = 0; uint32_t row_off = 0;
     c->pair_tests = 0;
@@ -428,6 +428,7 @@ static int match_begin_body(l3d_ctx* c) {
             if (c->use_cull && c->kNN > 0 && pd.Ms <= kCullMaxSegs && pd.Mt <= kCullMaxSegs && pd.Ms && pd.Mt)
                 make_cull(pd.F, v->width, v->height, t->width, t->height, pc);
             pc.s_off = cs_off; pc.t_off = ct_off; pc.c_off = cc_off; pc.k_off = ~0ull;
+            pc.w_item0 = w_item; pc.pad = 0; w_item += (pd.Ms + kMatchRows - 1) / kMatchRows;
             if (pc.enabled && std::max(pd.Ms, pd.Mt) > kCullLdsSegs) {   // sort keys of this pair in global scratch
                 uint32_t a = 64, b = 64;
                 while (a < pd.Ms) a <<= 1;
@@ -556,7 +557,23 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     CullPools pools{c->d_cull.p, c->d_src_perm.p, c->d_src_band.p, c->d_tgt_perm.p, c->d_tgt_sf.p, c->d_tgt_band.p,
                     c->d_chunk_band.p, c->d_cull_keys.p};
     if (mode != 0 || c->brute || !maxM) pools.cull = nullptr;
-    else L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
+    else {
+        static const int no_order = [] { const char* e = std::getenv("L3D_MATCH_ORDER"); return e && std::atoi(e) == 0; }();
+        // longest-first launch order (k_order_items) where the launch has one to three items per wave slot (fewer: all
+        // start at once; more: the tail is short against the whole) -- C1: kernel 1.08 -> 1.03 ms; C2 / C4: +6 % with it
+        if (!no_order && n_work > kMatchOrderMinItems && n_work <= kMatchOrderMaxItems) {
+            L3D_HIP_CHECK(c->d_item_bucket.reserve(n_work)); L3D_HIP_CHECK(c->d_item_order.reserve(n_work));
+            if (!c->d_order_done.p) {            // zeroed once: the kernel re-arms it
+                L3D_HIP_CHECK(c->d_order_done.reserve(1));
+                L3D_HIP_CHECK(hipMemsetAsync(c->d_order_done.p, 0, 4, c->stream));
+            }
+            pools.item_bucket = c->d_item_bucket.p; pools.item_order = c->d_item_order.p;
+            pools.order_done = c->d_order_done.p;
+            pools.w_base = c->cull[first].w_item0; pools.cost_max = maxMt;
+        }
+        L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
+        L3D_HIP_CHECK(launch_order_items(c->d_pairs.p, first, count, maxMt, pools, (uint32_t)n_work, c->stream));
+    }
     L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
     const bool ix16 = maxMt < 65536u && maxK < 65536u;   // 16-bit indices in the kernel's LDS tables
     // bounded kNN: the orientation filter and the hypothesis counters of phase B are fused into the epilogue

@@ -25,6 +25,8 @@ struct PairCull {
     uint32_t enabled;      // 0: geometry not suited (epipole in/near the image, degenerate F) -> plain streaming
     uint64_t k_off;        // views beyond the LDS sort capacity: this pair's sort keys in CullPools::big_keys (source
                            // side first, target side behind it); ~0 when both sides sort in LDS
+    uint32_t w_item0;      // first work item (64 source rows each) of the pair, counted over all pairs of the context
+    uint32_t pad;
 };
 struct CullPools {
     const PairCull* cull;      // [n_pairs] or nullptr
@@ -35,7 +37,14 @@ struct CullPools {
     float2* tgt_band;          // [sum Mt] their tau bands
     float2* chunk_band;        // [sum ceil(Mt/64)] tau band of each 64-record chunk
     uint64_t* big_keys;        // global sort scratch of the pairs whose views exceed kCullLdsSegs
+    // longest-first order of the work items of a launch (nullptr: launch order = list order), see k_order_items
+    uint32_t* item_bucket;     // [items of the launch] length class of each item
+    uint32_t* item_order;      // [items of the launch] work item started by workgroup b
+    uint32_t* order_done;      // workgroups of k_order_items that have filed their items (zero between launches)
+    uint32_t w_base;           // PairCull::w_item0 of the first pair of the launch
+    uint32_t cost_max;         // largest Mt of the launch
 };
+constexpr uint32_t kOrderBuckets = 1024;
 constexpr uint32_t kCullLdsSegs = 16384;   // LDS sort capacity of k_cull_prepare (larger views sort in global memory)
 constexpr uint32_t kCullMaxSegs = 1u << 20; // 20 index bits in the sort keys beside class and band
 
@@ -53,9 +62,13 @@ struct OrientFuse {
 
 // ---- k_match.hip ----
 size_t match_lds_bytes(int mode, uint32_t K, bool ix16 = false, uint32_t waves = 1);
+constexpr uint32_t kMatchOrderMaxItems = 16384;   // launches up to this many work items: two waves per item
+constexpr uint32_t kMatchOrderMinItems = 3584;    // ... and, from this many on (more waves than wave slots), longest-first order
 uint32_t match_waves_per_group(int mode, bool brute, uint32_t nwork);   // waves that share one 64-row work item of k_match_pairs
 hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
                                uint32_t max_M, CullPools pools, hipStream_t stream);
+hipError_t launch_order_items(const PairDesc* pairs, uint32_t first, uint32_t count, uint32_t max_Mt, CullPools pools,
+                              uint32_t nwork, hipStream_t stream);
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,
                               const WorkItem* work, uint32_t nwork, uint32_t maxK, Slot* slots,
                               uint32_t* row_counts, float thr, CullPools pools, OrientFuse of, bool ix16,
