@@ -173,7 +173,9 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     const uint32_t K = pd.K, Ms = pd.Ms, Mt = pd.Mt;
     typedef typename IdxT<IX16>::type idx_t;
     Lds<IX16> L = carve<IX16>((L3D_LDS char*)smem, MODE == 0 ? K : 0, WPG);
-    const uint32_t q = WPG > 1 ? threadIdx.x >> 6 : 0u;          // wave of the workgroup
+    // wave of the workgroup -- through readfirstlane: the compiler must know it is wave-uniform, or the chunk loop
+    // below (its mask depends on q) is compiled as a divergent loop with vector addresses
+    const uint32_t q = WPG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
     const uint32_t tid = threadIdx.x & 63u, lane = tid;          // row of the work item = lane
     L3D_LDS volatile uint32_t* ring = L.ring + q * kRing;
     // epipolar-band culling (kNN mode only: the keep-all rows must be filled in ascending target order)
@@ -349,9 +351,8 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     // walks the chunk by broadcasting one record at a time through SGPRs (v_readlane) -- no LDS tile, no barrier.
     // With culling, 32 chunk bands are tested at once (one per lane), then inside a visited chunk one target band
     // per lane; only the targets whose band meets the wave's band are walked (ascending order).
-    auto bc = [](float v, uint32_t j) -> float {
-        return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), j));
-    };
+    typedef const __attribute__((address_space(4))) v4f* RecPtr;
+    RecPtr tfc = (RecPtr)(unsigned long)tf;
     const uint32_t nch = (Mt + 63) / 64;
     for (uint32_t g0 = 0; g0 < nch; g0 += 32) {
         uint32_t wm;
@@ -371,9 +372,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
             const uint32_t tb = (g0 + (uint32_t)__builtin_ctz(wm)) * 64;
             wm &= wm - 1;
             const uint32_t ti = tb + lane;
-            v4f rec = {0, 0, 0, 0};
             bool in = ti < Mt;
-            if (in) rec = tf[ti];
             if (cull && in) {
                 const float2 b = tband[ti];
                 in = !(b.y < wlo || b.x > whi);
@@ -384,10 +383,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
                 const bool v1 = m != 0; const uint32_t j1 = v1 ? __builtin_ctzll(m) : j0; m &= m - 1;
                 const bool v2 = m != 0; const uint32_t j2 = v2 ? __builtin_ctzll(m) : j0; m &= m - 1;
                 const bool v3 = m != 0; const uint32_t j3 = v3 ? __builtin_ctzll(m) : j0; m &= m - 1;
-                const v4f q0 = {bc(rec.x, j0), bc(rec.y, j0), bc(rec.z, j0), bc(rec.w, j0)};
-                const v4f q1 = {bc(rec.x, j1), bc(rec.y, j1), bc(rec.z, j1), bc(rec.w, j1)};
-                const v4f q2 = {bc(rec.x, j2), bc(rec.y, j2), bc(rec.z, j2), bc(rec.w, j2)};
-                const v4f q3 = {bc(rec.x, j3), bc(rec.y, j3), bc(rec.z, j3), bc(rec.w, j3)};
+                const v4f q0 = tfc[tb + j0], q1 = tfc[tb + j1], q2 = tfc[tb + j2], q3 = tfc[tb + j3];
                 const bool c0b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
                 const bool c1b = v1 & (BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL)));
                 const bool c2b = v2 & (BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL)));
