@@ -158,11 +158,11 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware order: consecutive work items (same pair => same target view) go to one XCD
     // (block b runs on XCD b % 8, MI355X_MICROARCH.md), so the target view stays in that XCD's L2.
-    // With a longest-first order (k_order_items) workgroup b simply takes the b-th longest item.
+    // With a longest-first order (k_order_items) each XCD's part of the list is walked longest item first.
     const uint32_t per_xcd = (nwork + 7) / 8;
-    uint32_t w = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if (cp.item_order) w = blockIdx.x < nwork ? cp.item_order[blockIdx.x] : nwork;
+    uint32_t w = (blockIdx.x >> 3) < per_xcd ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : nwork;
     if (w >= nwork) return;
+    if (cp.item_order) w = cp.item_order[w];
     const WorkItem wi = work[w];
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
     const unsigned long long t_start = wall_clock64();
@@ -354,7 +354,27 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     typedef const __attribute__((address_space(4))) v4f* RecPtr;
     RecPtr tfc = (RecPtr)(unsigned long)tf;
     const uint32_t nch = (Mt + 63) / 64;
-    for (uint32_t g0 = 0; g0 < nch; g0 += 32) {
+    // CENTRE-OUT: rows and targets are both ordered by the lower end of their bands, and a row's best matches are the
+    // targets whose band nearly coincides with its own.  Walking the chunks in ascending order fills every row's table
+    // with poor matches from the far left first, which the good ones in the middle then evict one by one -- each through
+    // the double-precision test.  So the walk starts at the chunk where the targets' bands begin where the wave's
+    // median row's band does (cc), goes up to the end, then from cc - 1 down to the start: the tables fill with good
+    // matches at once, the K-th best overlap fed back into the pre-filter is high early, and fewer candidates reach the
+    // exact test.  The result does not depend on the order (total order of the insertion; ties are replayed).
+    uint32_t cc = 0;
+    if (cull) {
+        const uint32_t n_rows = min((uint32_t)kBlock, Ms - wi.src0);
+        const float mid = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(blo), n_rows / 2));
+        for (uint32_t c0 = 0; c0 < nch; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            cc += (uint32_t)__popcll(__ballot(c < nch && cband[c].x < mid));
+        }
+    }
+    const uint32_t ngrp = (nch + 31) / 32, gc = cc / 32;
+    for (uint32_t pass = 0; pass < (cull ? 2u : 1u); ++pass) {
+      const uint32_t n_g = pass == 0 ? ngrp - min(gc, ngrp) : gc + 1;
+      for (uint32_t gi = 0; gi < n_g; ++gi) {
+        const uint32_t g0 = (pass == 0 ? gc + gi : gc - gi) * 32;
         uint32_t wm;
         if (cull) {
             bool vis = false;
@@ -364,13 +384,15 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
                 vis = !(cb.y < wlo || cb.x > whi);
             }
             wm = (uint32_t)__ballot(vis);
+            if (gi == 0) { const uint32_t below = (1u << (cc & 31u)) - 1u; wm &= pass == 0 ? ~below : below; }
         } else {
             wm = (nch - g0 >= 32) ? 0xFFFFFFFFu : ((1u << (nch - g0)) - 1u);
         }
         if (WPG > 1) wm &= 0x55555555u << q;   // this wave's chunks: index = q (mod 2)
         while (wm) {
-            const uint32_t tb = (g0 + (uint32_t)__builtin_ctz(wm)) * 64;
-            wm &= wm - 1;
+            const uint32_t bit = pass == 0 ? (uint32_t)__builtin_ctz(wm) : 31u - (uint32_t)__builtin_clz(wm);
+            const uint32_t tb = (g0 + bit) * 64;
+            wm &= ~(1u << bit);
             const uint32_t ti = tb + lane;
             bool in = ti < Mt;
             if (cull && in) {
@@ -406,6 +428,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
                 }
             }
         }
+      }
     }
     while (tail != head) drain();
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
@@ -724,8 +747,8 @@ __device__ void lds_sort(uint64_t* keys, uint32_t n2) {
 // workgroup cannot migrate, and with one to three items per wave slot the launch ends when the longest late starter
 // does.  k_order_items (after k_cull_prepare; grid = pairs of the launch) counts, for every item of its pair, the
 // targets (beyond 4096 per view: the 64-target chunks) the item will walk and files it in one of kOrderBuckets
-// classes; the last workgroup to finish lays all items out by descending class (histogram, scan and cursors in its
-// LDS) and the match kernel's workgroup b takes item order[b].  Launches with many rounds of items keep the list
+// classes; the last workgroup to finish lays the items out by descending class (histogram, scan and cursors in its
+// LDS) and the match kernel's workgroups follow that order.  Launches with many rounds of items keep the list
 // order: their tail is short against the whole, and the list order keeps the waves of a pair on one XCD.
 __global__ __launch_bounds__(kCullBlock) void k_order_items(const PairDesc* __restrict__ pairs, uint32_t first,
                                                             const CullPools cp, uint32_t nwork) {
@@ -777,31 +800,38 @@ __global__ __launch_bounds__(kCullBlock) void k_order_items(const PairDesc* __re
     }
     __syncthreads();
     if (!s_last) return;
-    uint32_t* hist = (uint32_t*)smem;            // [kOrderBuckets] counts, then first position of each class
-    for (uint32_t i = tid; i < kOrderBuckets; i += kCullBlock) hist[i] = 0;
+    // The list is cut into 8 contiguous parts, one per XCD (workgroup b runs on XCD b % 8): the items of a pair stay on
+    // one XCD, whose L2 then holds the pair's two views; each part is ordered by itself.
+    uint32_t* hist = (uint32_t*)smem;            // [8][kOrderBuckets] counts, then first position of each class
+    const uint32_t per_xcd = (nwork + 7) / 8;
+    for (uint32_t i = tid; i < 8 * kOrderBuckets; i += kCullBlock) hist[i] = 0;
     constexpr uint32_t kPer = kMatchOrderMaxItems / kCullBlock;     // items per thread, kept in registers
     uint32_t mine[kPer];
 #pragma unroll
     for (uint32_t k = 0; k < kPer; ++k) {        // independent loads (not through this CU's L1: written by other CUs)
         const uint32_t w = k * kCullBlock + tid;
-        mine[k] = w < nwork ? __hip_atomic_load(&cp.item_bucket[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        mine[k] = w < nwork ? (w / per_xcd) * kOrderBuckets +
+                                  __hip_atomic_load(&cp.item_bucket[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                            : 0u;
     }
     __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < kPer; ++k)
         if (k * kCullBlock + tid < nwork) atomicAdd(&hist[mine[k]], 1u);
     __syncthreads();
-    if (wave == 0) {                             // descending exclusive scan of 1024 counters by one wave
+    {                                            // wave x: descending exclusive scan of the counters of part x
+        static_assert(kCullBlock / 64 == 8, "one wave per XCD");
+        uint32_t* hx = hist + wave * kOrderBuckets;
         constexpr uint32_t per = kOrderBuckets / 64;
         uint32_t h[per], sum = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < per; ++k) { h[k] = hist[kOrderBuckets - 1 - (lane * per + k)]; sum += h[k]; }
+        for (uint32_t k = 0; k < per; ++k) { h[k] = hx[kOrderBuckets - 1 - (lane * per + k)]; sum += h[k]; }
         uint32_t incl = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
-        uint32_t run = incl - sum;
+        uint32_t run = wave * per_xcd + incl - sum;
 #pragma unroll
-        for (uint32_t k = 0; k < per; ++k) { hist[kOrderBuckets - 1 - (lane * per + k)] = run; run += h[k]; }
+        for (uint32_t k = 0; k < per; ++k) { hx[kOrderBuckets - 1 - (lane * per + k)] = run; run += h[k]; }
     }
     __syncthreads();
 #pragma unroll
@@ -819,7 +849,7 @@ hipError_t launch_order_items(const PairDesc* pairs, uint32_t first, uint32_t co
                               uint32_t nwork, hipStream_t stream) {
     if (!pools.item_order || !nwork || !count) return hipSuccess;
     if (nwork > kMatchOrderMaxItems) return hipErrorInvalidValue;   // the ordering workgroup keeps its items in registers
-    const size_t lds = std::max<size_t>((size_t)(max_Mt <= 4096 ? max_Mt : (max_Mt + 63) / 64) * 8, kOrderBuckets * 4);
+    const size_t lds = std::max<size_t>((size_t)(max_Mt <= 4096 ? max_Mt : (max_Mt + 63) / 64) * 8, 8 * kOrderBuckets * 4);
     hipError_t e = hipFuncSetAttribute((const void*)k_order_items, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_order_items, dim3(count), dim3(kCullBlock), lds, stream, pairs, first, pools, nwork);

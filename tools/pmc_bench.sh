@@ -19,6 +19,8 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VAL
   n=$((n+1))
 done
 cd $R
-bash tools/build_stats_lib.sh > $out/stats_build.log 2>&1
+# the diagnostic build travels with the snapshot when it was made beforehand (tools/build_stats_lib.sh); its build id is
+# compared with the product library's in pmc_to_json.py
+[ -f $R/gpurun_scratch/libl3dpp_hip_stats.so ] || bash tools/build_stats_lib.sh > $out/stats_build.log 2>&1
 L3D_LIB=$R/gpurun_scratch/libl3dpp_hip_stats.so python tools/phase_a_stats.py $cfg > $out/stats.json 2> $out/stats.err
 python tools/pmc_to_json.py $out $cfg $tag
