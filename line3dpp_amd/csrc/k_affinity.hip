@@ -83,8 +83,13 @@ __global__ void k_aff_sim(uint32_t N, const uint32_t* __restrict__ surv_sg, cons
 __global__ void k_aff_flag(uint32_t N, const uint32_t* __restrict__ surv_off, const uint32_t* __restrict__ surv_sg,
                            const uint32_t* __restrict__ surv_tg, const float* __restrict__ simv,
                            const int32_t* __restrict__ cand_a, const int32_t* __restrict__ cand_b,
-                           uint32_t* __restrict__ flag) {
+                           uint32_t* __restrict__ flag, uint32_t* __restrict__ first_touch, uint32_t H,
+                           uint32_t* __restrict__ touch_flag) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    // initial state of the two passes that follow (k_aff_touch, k_aff_mark), set on the way: grid covers max(N, H)
+    if (c < H) first_touch[c] = kEmpty;
+    if (c < N) { touch_flag[2 * c] = 0; touch_flag[2 * c + 1] = 0; }
+    if (c == 0) touch_flag[2 * (size_t)N] = 0;
     if (c >= N) return;
     uint32_t f = 0;
     if (simv[c] > kMinAffinity) {
@@ -256,9 +261,11 @@ hipError_t launch_aff_sim(uint32_t N, const uint32_t* surv_sg, const uint32_t* s
     return hipGetLastError();
 }
 hipError_t launch_aff_flag(uint32_t N, const uint32_t* surv_off, const uint32_t* surv_sg, const uint32_t* surv_tg,
-                           const float* simv, const int32_t* ca, const int32_t* cb, uint32_t* flag, hipStream_t st) {
+                           const float* simv, const int32_t* ca, const int32_t* cb, uint32_t* flag,
+                           uint32_t* first_touch, uint32_t H, uint32_t* touch_flag, hipStream_t st) {
     if (!N) return hipSuccess;
-    hipLaunchKernelGGL(k_aff_flag, grid1(N), dim3(256), 0, st, N, surv_off, surv_sg, surv_tg, simv, ca, cb, flag);
+    hipLaunchKernelGGL(k_aff_flag, grid1(std::max(N, H)), dim3(256), 0, st, N, surv_off, surv_sg, surv_tg, simv, ca, cb,
+                       flag, first_touch, H, touch_flag);
     return hipGetLastError();
 }
 hipError_t launch_fill_u32(uint32_t* p, uint32_t n, uint32_t val, hipStream_t st) {

@@ -863,100 +863,6 @@ __global__ void k_seg_write(uint32_t G, const ViewDev* __restrict__ views, const
     hyp_of_seg[g] = (int32_t)hx;
 }
 
-// ---- 64-bit exclusive scan (two 32-bit counters per word are summed at once: low and high words never carry into
-// each other for totals below 2^32) ---------------------------------------------------------------------------------
-namespace {
-constexpr uint32_t kS64Block = 1024, kS64Items = 4, kS64Tile = kS64Block * kS64Items;
-__device__ __forceinline__ unsigned long long block_scan64(unsigned long long v, unsigned long long* wsum /*[17]*/,
-                                                           unsigned long long& block_total) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    unsigned long long x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long y = __shfl_up(x, d);
-        if (lane >= (uint32_t)d) x += y;
-    }
-    if (lane == 63) wsum[wave] = x;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long acc = 0;
-        for (uint32_t w = 0; w < kS64Block / 64; ++w) { const unsigned long long t = wsum[w]; wsum[w] = acc; acc += t; }
-        wsum[16] = acc;
-    }
-    __syncthreads();
-    block_total = wsum[16];
-    const unsigned long long r = wsum[wave] + x - v;
-    __syncthreads();
-    return r;
-}
-}  // namespace
-
-__global__ __launch_bounds__(kS64Block) void k_scan64_sums(const unsigned long long* __restrict__ in, uint32_t n,
-                                                           unsigned long long* __restrict__ sums) {
-    __shared__ unsigned long long wsum[17];
-    const uint32_t base = blockIdx.x * kS64Tile + threadIdx.x * kS64Items;
-    unsigned long long v = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kS64Items; ++k) v += (base + k < n) ? in[base + k] : 0ull;
-    unsigned long long total;
-    (void)block_scan64(v, wsum, total);
-    if (threadIdx.x == 0) sums[blockIdx.x] = total;
-}
-__global__ __launch_bounds__(kS64Block) void k_scan64_top(unsigned long long* __restrict__ sums, uint32_t nb,
-                                                          unsigned long long* __restrict__ total_out) {
-    __shared__ unsigned long long wsum[17];
-    __shared__ unsigned long long carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t b0 = 0; b0 < nb; b0 += kS64Block) {
-        const uint32_t i = b0 + threadIdx.x;
-        const unsigned long long v = i < nb ? sums[i] : 0ull;
-        unsigned long long total;
-        const unsigned long long ex = block_scan64(v, wsum, total);
-        const unsigned long long c = carry;
-        if (i < nb) sums[i] = c + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) carry = c + total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && total_out) *total_out = carry;
-}
-__global__ __launch_bounds__(kS64Block) void k_scan64_down(const unsigned long long* __restrict__ in, uint32_t n,
-                                                           const unsigned long long* __restrict__ sums,
-                                                           unsigned long long* __restrict__ out,
-                                                           const unsigned long long* total) {
-    __shared__ unsigned long long wsum[17];
-    const uint32_t base = blockIdx.x * kS64Tile + threadIdx.x * kS64Items;
-    unsigned long long a[kS64Items];
-    unsigned long long v = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kS64Items; ++k) { a[k] = (base + k < n) ? in[base + k] : 0ull; v += a[k]; }
-    unsigned long long tot;
-    unsigned long long ex = block_scan64(v, wsum, tot) + sums[blockIdx.x];
-#pragma unroll
-    for (uint32_t k = 0; k < kS64Items; ++k) {
-        if (base + k < n) out[base + k] = ex;
-        ex += a[k];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
-}
-
-// out[0..n] = exclusive scan of in[0..n) (out[n] = total, also stored to *total).  tmp: >= n/4096 + 2 words.
-// in and out may be the same array.
-hipError_t launch_scan64(const unsigned long long* in, uint32_t n, unsigned long long* out, unsigned long long* tmp,
-                         unsigned long long* total, hipStream_t st) {
-    const uint32_t nb = (n + kS64Tile - 1) / kS64Tile;
-    if (nb == 0) {
-        hipLaunchKernelGGL(k_scan64_top, dim3(1), dim3(kS64Block), 0, st, tmp, 0u, total);
-        hipLaunchKernelGGL(k_scan64_down, dim3(1), dim3(kS64Block), 0, st, in, 0u, tmp, out, total);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(k_scan64_sums, dim3(nb), dim3(kS64Block), 0, st, in, n, tmp);
-    hipLaunchKernelGGL(k_scan64_top, dim3(1), dim3(kS64Block), 0, st, tmp, nb, total);
-    hipLaunchKernelGGL(k_scan64_down, dim3(nb), dim3(kS64Block), 0, st, in, n, tmp, out, total);
-    return hipGetLastError();
-}
-
 // ---- launchers --------------------------------------------------------------------------------------------------
 hipError_t launch_inv_records(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
                               const Slot* slots, const unsigned long long* off64, const uint32_t* inv_pos, InvRec* recs,
@@ -995,8 +901,6 @@ __global__ void k_seg_index(const ListPools lp, uint32_t* __restrict__ seg_of_g)
     seg_of_g[lp.segs[pool * lp.scap + k].g] = pool * lp.scap + k;
 }
 hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, uint32_t world, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(seg_of_g, 0xFF, ((size_t)G + 1) * 4, st);
-    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_merge_flags, dim3(1), dim3(1), 0, st, lp, world ? world : 1u);
     hipLaunchKernelGGL(k_seg_index, dim3((lp.scap + 255) / 256, kListPools), dim3(256), 0, st, lp, seg_of_g);
     return hipGetLastError();
@@ -1035,11 +939,14 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
     hs.d1 = hsa.f32; hs.d2 = hsa.f32 + hsa.cap;
     hs.tv = hsa.u32; hs.ref = hsa.u32 + hsa.cap; hs.pf = hsa.u32 + 2 * (size_t)hsa.cap;
     hs.key = hsa.u64; hs.cap = hsa.cap;
-    hipLaunchKernelGGL(k_lists_huge, dim3(256), dim3(256), 0, st, views, pairs, lviews, opairs, gseg_view, off64, inv,
-                       slots, lp, hs);
+    // lists beyond the four-wave tier: rare; when the previous pass over the same kind of scene handed none over the
+    // launch is left out (a pass that then does hand one over is repeated with it: flags[5], l3d_api.hip check_pass)
+    if (hsa.run_huge)
+        hipLaunchKernelGGL(k_lists_huge, dim3(256), dim3(256), 0, st, views, pairs, lviews, opairs, gseg_view, off64, inv,
+                           slots, lp, hs);
     hipLaunchKernelGGL(k_edges, dim3(lp.scap, lp.npools), dim3(64), 0, st, views, pairs, gseg_view, sc, lp,
                        seg_of_g);
-    hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, st, lp);
+    if (lp.npools < kListPools) hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, st, lp);   // sharded pass
     return hipGetLastError();
 }
 

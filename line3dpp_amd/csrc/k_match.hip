@@ -785,19 +785,16 @@ __global__ __launch_bounds__(kCullBlock) void k_order_items(const PairDesc* __re
                 for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
                 cost = by_target ? n : n * 64;
             }
-            if (lane == 0) {
+            if (lane == 0) {   // (agent-scope store: read by the ordering workgroup on another XCD, no L2 write-back needed)
                 const uint64_t q = (uint64_t)cost * kOrderBuckets / cmax;
-                bucket[it] = q < kOrderBuckets ? (uint32_t)q : kOrderBuckets - 1;
+                __hip_atomic_store(&bucket[it], q < kOrderBuckets ? (uint32_t)q : kOrderBuckets - 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
     // ---- the last workgroup orders all items of the launch ----
-    __syncthreads();                             // this workgroup's buckets have reached L2
-    if (tid == 0) {
-        __threadfence();                         // ... and are visible to the other XCDs
-        s_last = atomicAdd(cp.order_done, 1u) == gridDim.x - 1;
-        __threadfence();
-    }
+    __syncthreads();                             // this workgroup's bucket stores are complete
+    if (tid == 0) s_last = atomicAdd(cp.order_done, 1u) == gridDim.x - 1;
     __syncthreads();
     if (!s_last) return;
     // The list is cut into 8 contiguous parts, one per XCD (workgroup b runs on XCD b % 8): the items of a pair stay on
@@ -1159,10 +1156,13 @@ hipError_t launch_match_tied_rows(const ViewDev* views, const PairDesc* pairs, S
 }
 
 // ---- per-view precompute (after translate), all views in one launch: grid = (segment blocks, views) -----
-__global__ void k_prep_views(const ViewDev* __restrict__ views) {
+__global__ void k_prep_views(const ViewDev* __restrict__ views, unsigned long long* __restrict__ cnt_pack, uint32_t G) {
     const ViewDev& v = views[blockIdx.y];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cnt_pack && blockIdx.y == 0 && i == 0) cnt_pack[G] = 0;
     if (i >= v.M) return;
+    // the packed hypothesis counters of phase B (fed by the match epilogue) start from zero in every matchImages
+    if (cnt_pack) cnt_pack[(uint32_t)(v.segx - views[0].segx) + i] = 0;
     double A[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) A[k] = v.RtKinv[k];
@@ -1186,9 +1186,10 @@ __global__ void k_prep_views(const ViewDev* __restrict__ views) {
     const_cast<SegF*>(v.segf)[i] = f;
 }
 
-hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, hipStream_t stream) {
-    if (!n_views || !max_M) return hipSuccess;
-    hipLaunchKernelGGL(k_prep_views, dim3((max_M + 255) / 256, n_views), dim3(256), 0, stream, views);
+hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, unsigned long long* cnt_pack,
+                             uint32_t G, hipStream_t stream) {
+    if (!n_views || !max_M) return cnt_pack ? hipMemsetAsync(cnt_pack, 0, ((size_t)G + 1) * 8, stream) : hipSuccess;
+    hipLaunchKernelGGL(k_prep_views, dim3((max_M + 255) / 256, n_views), dim3(256), 0, stream, views, cnt_pack, G);
     return hipGetLastError();
 }
 

@@ -1031,96 +1031,6 @@ __global__ __launch_bounds__(1024) void k_median_all(const float* __restrict__ d
     if (threadIdx.x == 0) out_median[v] = __uint_as_float(s_prefix);
 }
 
-// ---- exclusive scan of uint32 arrays of any length: block sums, scan of sums, downsweep ------------
-constexpr uint32_t kScanBlock = 1024, kScanItems = 4, kScanTile = kScanBlock * kScanItems;
-
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wsum /*[17]*/, uint32_t& block_total) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d);
-        if (lane >= (uint32_t)d) x += y;
-    }
-    if (lane == 63) wsum[wave] = x;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (uint32_t w = 0; w < kScanBlock / 64; ++w) { const uint32_t t = wsum[w]; wsum[w] = acc; acc += t; }
-        wsum[16] = acc;
-    }
-    __syncthreads();
-    block_total = wsum[16];
-    const uint32_t r = wsum[wave] + x - v;
-    __syncthreads();
-    return r;
-}
-
-__global__ __launch_bounds__(kScanBlock) void k_scan_sums(const uint32_t* __restrict__ in, uint32_t n,
-                                                          uint32_t* __restrict__ sums) {
-    __shared__ uint32_t wsum[17];
-    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    uint32_t v = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kScanItems; ++k) v += (base + k < n) ? in[base + k] : 0u;
-    uint32_t total;
-    (void)block_exclusive_scan(v, wsum, total);
-    if (threadIdx.x == 0) sums[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(kScanBlock) void k_scan_top(uint32_t* __restrict__ sums, uint32_t nb,
-                                                         uint32_t* __restrict__ total_out) {
-    __shared__ uint32_t wsum[17];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t b0 = 0; b0 < nb; b0 += kScanBlock) {
-        const uint32_t i = b0 + threadIdx.x;
-        const uint32_t v = i < nb ? sums[i] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan(v, wsum, total);
-        const uint32_t c = carry;
-        if (i < nb) sums[i] = c + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) carry = c + total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && total_out) *total_out = carry;
-}
-
-__global__ __launch_bounds__(kScanBlock) void k_scan_down(const uint32_t* __restrict__ in, uint32_t n,
-                                                          const uint32_t* __restrict__ sums,
-                                                          uint32_t* __restrict__ out, const uint32_t* total) {
-    __shared__ uint32_t wsum[17];
-    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    uint32_t a[kScanItems];
-    uint32_t v = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kScanItems; ++k) { a[k] = (base + k < n) ? in[base + k] : 0u; v += a[k]; }
-    uint32_t tot;
-    uint32_t ex = block_exclusive_scan(v, wsum, tot) + sums[blockIdx.x];
-#pragma unroll
-    for (uint32_t k = 0; k < kScanItems; ++k) {
-        if (base + k < n) out[base + k] = ex;
-        ex += a[k];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
-}
-
-// out[0..n] = exclusive scan of in[0..n) (out[n] = total, also stored to *total).  tmp: >= n/4096+2 words.
-hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, uint32_t* total, hipStream_t st) {
-    const uint32_t nb = (n + kScanTile - 1) / kScanTile;
-    if (nb == 0) {
-        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, st, tmp, 0u, total);
-        hipLaunchKernelGGL(k_scan_down, dim3(1), dim3(kScanBlock), 0, st, in, 0u, tmp, out, total);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(kScanBlock), 0, st, in, n, tmp);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kScanBlock), 0, st, tmp, nb, total);
-    hipLaunchKernelGGL(k_scan_down, dim3(nb), dim3(kScanBlock), 0, st, in, n, tmp, out, total);
-    return hipGetLastError();
-}
-
 // ---- launchers --------------------------------------------------------------------------------------
 // gseg_view[g] = view of global segment g: grid = (segment blocks, views)
 __global__ void k_fill_gseg_view(const uint32_t* __restrict__ seg_base, uint32_t* __restrict__ gseg_view) {

@@ -21,7 +21,7 @@ static int affinity_collinear(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_coll_cnt.reserve(G + 1)); L3D_HIP_CHECK(c->d_coll_off.reserve(G + 1));
     L3D_HIP_CHECK(launch_collin(0, c->d_views.p, V, max_M, c->d_seg_base.p, c->collinearity_t, c->d_coll_cnt.p, nullptr,
                                 nullptr, st));
-    L3D_HIP_CHECK(launch_scan(c->d_coll_cnt.p, G, c->d_coll_off.p, c->d_scan_tmp.p, c->d_scal.p + 9, st));
+    L3D_HIP_CHECK(launch_scan(c->d_coll_cnt.p, G, c->d_coll_off.p, c->d_scan_ws.p, c->d_scal.p + 9, st));
     uint32_t n_coll = 0;
     L3D_HIP_CHECK(hipMemcpyAsync(&n_coll, c->d_scal.p + 9, 4, hipMemcpyDeviceToHost, st));
     L3D_HIP_CHECK(hipStreamSynchronize(st));
@@ -35,10 +35,10 @@ static int affinity_collinear(l3d_ctx* c) {
     for (int mode = 0; mode < 2; ++mode) {
         const uint32_t n = n_items[mode];
         L3D_HIP_CHECK(c->d_item_cnt.reserve(n + 1)); L3D_HIP_CHECK(c->d_item_off.reserve(n + 1));
-        L3D_HIP_CHECK(c->d_scan_tmp.reserve((size_t)n / 4096 + 1024));
+        L3D_HIP_CHECK(c->d_scan_ws.reserve_zeroed(scan_ws_words(n, 4), st));
         L3D_HIP_CHECK(launch_aff_coll_count(mode, n, c->d_surv_tg.p, c->d_simv.p, c->d_hyps.p, c->d_seg_base.p,
                                             c->d_coll_off.p, c->d_item_cnt.p, st));
-        L3D_HIP_CHECK(launch_scan(c->d_item_cnt.p, n, c->d_item_off.p, c->d_scan_tmp.p, c->d_scal.p + 10, st));
+        L3D_HIP_CHECK(launch_scan(c->d_item_cnt.p, n, c->d_item_off.p, c->d_scan_ws.p, c->d_scal.p + 10, st));
         uint32_t total = 0;
         L3D_HIP_CHECK(hipMemcpyAsync(&total, c->d_scal.p + 10, 4, hipMemcpyDeviceToHost, st));
         L3D_HIP_CHECK(hipStreamSynchronize(st));
@@ -46,7 +46,7 @@ static int affinity_collinear(l3d_ctx* c) {
         L3D_HIP_CHECK(c->d_item_sim.reserve(std::max<uint32_t>(total, 1)));
         L3D_HIP_CHECK(launch_aff_coll_sim(mode, n, c->d_surv_sg.p, c->d_surv_tg.p, c->d_hyp_of_seg.p, c->d_hyps.p,
                                           c->d_views.p, c->d_seg_base.p, c->d_gseg_view.p, c->d_coll_off.p,
-                                          c->d_coll_idx.p, c->d_item_off.p, c->d_vaff.p, c->d_medians.p, c->d_msdl.p,
+                                          c->d_coll_idx.p, c->d_item_off.p, c->d_vaff.p, (c->d_medians.p + 8), (const float*)(c->d_vaff.p + V),
                                           c->two_sigA_sqr, c->d_item_seg.p, c->d_item_sim.p, st));
         off[mode].resize((size_t)n + 1); seg[mode].resize(total); sim[mode].resize(total);
         L3D_HIP_CHECK(hipMemcpyAsync(off[mode].data(), c->d_item_off.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, st));
@@ -131,22 +131,23 @@ int affinity_core(l3d_ctx* c) {
     for (auto* v : c->order) if (v->median_depth > kEps) sd.push_back(v->median_depth);
     if (!sd.empty()) { std::sort(sd.begin(), sd.end()); c->med_scene_depth_lines = sd[sd.size() / 2]; }
     else c->med_scene_depth_lines = 0.0f;
-    std::vector<ViewAff> va(V);
+    // [ViewAff x V | med_scene_depth_lines]: one table, sent only when it differs from what the device holds
+    std::vector<ViewAff> va(V + 1);
     for (uint32_t vi = 0; vi < V; ++vi) { va[vi].k = c->order[vi]->k; va[vi].pad = 0; }
+    va[V].k = c->med_scene_depth_lines; va[V].pad = 0;
     const uint32_t N = c->n_surv, H = c->n_hyps;
     L3D_HIP_CHECK(c->d_scal.reserve(16));
-    L3D_HIP_CHECK(c->d_scan_tmp.reserve(((size_t)c->G + 2 * (size_t)N) / 4096 + 1024));
+    L3D_HIP_CHECK(c->d_scan_ws.reserve_zeroed(scan_ws_words((size_t)c->G + 2 * (size_t)N, 4), st));
     L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
     if (N > 0 && H > 0) {
-        L3D_HIP_CHECK(c->d_vaff.reserve(V)); L3D_HIP_CHECK(c->d_msdl.reserve(1));
+        L3D_HIP_CHECK(c->d_vaff.reserve(V + 1));
         L3D_HIP_CHECK(c->d_simv.reserve(N)); L3D_HIP_CHECK(c->d_ca.reserve(N)); L3D_HIP_CHECK(c->d_cb.reserve(N));
         L3D_HIP_CHECK(c->d_flag.reserve(N + 1)); L3D_HIP_CHECK(c->d_epos.reserve(N + 1));
         L3D_HIP_CHECK(c->d_first_touch.reserve(H));
-        L3D_HIP_CHECK(c->d_scan_tmp.reserve(std::max<size_t>(N, 2 * (size_t)N) / 4096 + 1024));
-        L3D_HIP_CHECK(hipMemcpyAsync(c->d_vaff.p, va.data(), V * sizeof(ViewAff), hipMemcpyHostToDevice, st));
-        L3D_HIP_CHECK(hipMemcpyAsync(c->d_msdl.p, &c->med_scene_depth_lines, 4, hipMemcpyHostToDevice, st));
+        L3D_HIP_CHECK(c->d_scan_ws.reserve_zeroed(scan_ws_words(2 * (size_t)N, 4), st));
+        L3D_HIP_CHECK(upload_table(c->d_vaff, c->h_vaff, va.data(), ((size_t)V + 1) * sizeof(ViewAff), c->up_vaff, st));
         L3D_HIP_CHECK(launch_aff_sim(N, c->d_surv_sg.p, c->d_surv_tg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_vaff.p,
-                                     c->d_medians.p, c->d_msdl.p, c->two_sigA_sqr, c->d_simv.p, c->d_ca.p, c->d_cb.p,
+                                     (c->d_medians.p + 8), (const float*)(c->d_vaff.p + V), c->two_sigA_sqr, c->d_simv.p, c->d_ca.p, c->d_cb.p,
                                      st));
         if (c->collinearity_t > (float)kEps) {
             const int rc = affinity_collinear(c);
@@ -157,9 +158,10 @@ int affinity_core(l3d_ctx* c) {
             c->affinity_done = true;
             return L3D_OK;
         }
+        L3D_HIP_CHECK(c->d_touch_flag.reserve(2 * (size_t)N + 1));
         L3D_HIP_CHECK(launch_aff_flag(N, c->d_surv_off.p, c->d_surv_sg.p, c->d_surv_tg.p, c->d_simv.p, c->d_ca.p,
-                                      c->d_cb.p, c->d_flag.p, st));
-        L3D_HIP_CHECK(launch_scan(c->d_flag.p, N, c->d_epos.p, c->d_scan_tmp.p, c->d_scal.p + 3, st));
+                                      c->d_cb.p, c->d_flag.p, c->d_first_touch.p, H, c->d_touch_flag.p, st));
+        L3D_HIP_CHECK(launch_scan(c->d_flag.p, N, c->d_epos.p, c->d_scan_ws.p, c->d_scal.p + 3, st));
         // no read-back of the edge count: everything downstream is sized by its upper bound N (flags beyond the
         // 2E touched positions stay zero), the two counts are read once at the end
         {
@@ -167,11 +169,10 @@ int affinity_core(l3d_ctx* c) {
             L3D_HIP_CHECK(c->d_touch_rank.reserve(2 * (size_t)N + 1));
             L3D_HIP_CHECK(c->d_edges.reserve(2 * (size_t)N));
             L3D_HIP_CHECK(c->d_l2g.reserve(H));
-            L3D_HIP_CHECK(launch_fill_u32(c->d_first_touch.p, H, kEmpty, st));
-            L3D_HIP_CHECK(hipMemsetAsync(c->d_touch_flag.p, 0, (2 * (size_t)N + 1) * 4, st));
+            // (first_touch = none and touch_flag = 0 were set by k_aff_flag on its way)
             L3D_HIP_CHECK(launch_aff_touch(N, c->d_flag.p, c->d_epos.p, c->d_ca.p, c->d_cb.p, c->d_first_touch.p, st));
             L3D_HIP_CHECK(launch_aff_mark(H, c->d_first_touch.p, c->d_touch_flag.p, st));
-            L3D_HIP_CHECK(launch_scan(c->d_touch_flag.p, 2 * N, c->d_touch_rank.p, c->d_scan_tmp.p, c->d_scal.p + 4, st));
+            L3D_HIP_CHECK(launch_scan(c->d_touch_flag.p, 2 * N, c->d_touch_rank.p, c->d_scan_ws.p, c->d_scal.p + 4, st));
             L3D_HIP_CHECK(launch_aff_emit(N, c->d_flag.p, c->d_epos.p, c->d_ca.p, c->d_cb.p, c->d_simv.p,
                                           c->d_first_touch.p, c->d_touch_rank.p, c->d_hyps.p, c->d_edges.p,
                                           c->d_l2g.p, st));

@@ -129,14 +129,15 @@ void make_cull(const double F[9], double ws, double hs, double wt, double ht, Pa
 int upload_views(l3d_ctx& c) {
     const size_t V = c.order.size();
     L3D_HIP_CHECK(c.d_views.reserve(V));
-    L3D_HIP_CHECK(c.h_views.reserve(V));
-    ViewDev* hv = c.h_views.p;
+    std::vector<ViewDev> table(V);
+    ViewDev* hv = table.data();
     uint32_t max_M = 0;
     // the per-segment invariants of all views live in ONE array indexed by the global segment id, so that the
     // phase-B kernels reach them with one load (gsegx[g]) instead of g -> view -> pointer -> record
     size_t Gtot = 0;
     for (size_t i = 0; i < V; ++i) Gtot += c.order[i]->M;
     L3D_HIP_CHECK(c.d_gsegx.reserve(std::max<size_t>(Gtot, 1)));
+    std::memset((void*)hv, 0, V * sizeof(ViewDev));   // (padding bytes take part in the comparison of upload_table)
     size_t gbase = 0;
     for (size_t i = 0; i < V; ++i) {
         HostView& v = *c.order[i];
@@ -149,8 +150,10 @@ int upload_views(l3d_ctx& c) {
         d.cx = 0.5f * (float)v.width; d.cy = 0.5f * (float)v.height; d.pad = 0;
         max_M = std::max(max_M, v.M);
     }
-    L3D_HIP_CHECK(hipMemcpyAsync(c.d_views.p, hv, V * sizeof(ViewDev), hipMemcpyHostToDevice, c.stream));
-    L3D_HIP_CHECK(launch_prep_views(c.d_views.p, (uint32_t)V, max_M, c.stream));
+    L3D_HIP_CHECK(upload_table(c.d_views, c.h_views, hv, V * sizeof(ViewDev), c.up_views, c.stream));
+    // per-segment invariants (k_prep_views), and the packed hypothesis counters of phase B zeroed on the way
+    L3D_HIP_CHECK(c.d_cnt_pack.reserve(Gtot + 1));
+    L3D_HIP_CHECK(launch_prep_views(c.d_views.p, (uint32_t)V, max_M, c.d_cnt_pack.p, (uint32_t)Gtot, c.stream));
     return L3D_OK;
 }
 
@@ -255,8 +258,8 @@ void l3d_destroy(l3d_ctx* c) {
     }
     c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release(); c->d_slot_idx.release();
     c->h_views.release(); c->h_pairs.release(); c->h_cull.release(); c->h_work.release(); c->h_vout.release();
-    c->h_small.release(); c->h_cnt.release(); c->h_med.release(); c->h_fin.release();
-    c->d_off64.release(); c->d_cnt64.release(); c->d_off64s.release(); c->d_scan64_tmp.release(); c->d_tot64.release();
+    c->h_small.release(); c->h_segb.release(); c->h_cnt.release(); c->h_fin.release();
+    c->d_off64.release(); c->d_cnt64.release(); c->d_off64s.release(); c->d_scan_ws.release();
     c->d_huge_u64.release(); c->d_inv_recs.release(); c->d_lzero.release(); c->d_list2.release(); c->d_list4.release(); c->d_listH.release();
     c->d_seg_of_g.release(); c->d_huge_u32.release(); c->d_huge_f32.release(); c->d_ledges.release(); c->d_lhyps.release();
     c->d_lsegs.release(); c->d_lcands.release(); c->d_lchdrs.release(); c->d_ltab.release(); c->h_ltab.release();
@@ -264,16 +267,16 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_chunk_band.release(); c->d_cull_keys.release(); c->d_tgt_sf.release(); c->d_tgt_band.release();
     c->d_row_counts.release();
     c->d_seg_base.release(); c->d_gseg_view.release(); c->d_cnt.release(); c->d_off.release();
-    c->d_scan_tmp.release(); c->d_scal.release(); c->d_max_score.release(); c->d_surv_cnt.release();
+    c->d_scal.release(); c->d_max_score.release(); c->d_surv_cnt.release();
     c->d_has_best.release(); c->d_best_pos.release(); c->d_surv_off.release(); c->d_hyp_off.release();
-    c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_bits.release(); c->d_eref.release(); c->d_positive.release(); c->d_bits_len.release(); c->d_boff.release(); c->d_cnt_inv.release(); c->d_long_list.release();
+    c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_bits.release(); c->d_eref.release(); c->d_bits_len.release(); c->d_boff.release(); c->d_cnt_inv.release(); c->d_long_list.release();
     c->d_cnt_pack.release(); c->d_inv_pos.release(); c->d_gsegx.release();
     c->d_tie_count.release(); c->d_tie_list.release(); c->d_tie_heap.release(); c->d_item_bucket.release(); c->d_item_order.release(); c->d_order_done.release();
     c->d_coll_cnt.release(); c->d_coll_off.release(); c->d_coll_idx.release(); c->d_item_cnt.release();
     c->d_item_off.release(); c->d_item_seg.release(); c->d_item_sim.release();
     c->d_inv_off.release(); c->d_vout_pairs.release(); c->d_vout_off.release(); c->d_dents.release(); c->d_surv.release();
     c->d_hyp_of_seg.release(); c->d_depths.release(); c->d_medians.release(); c->d_hyps.release();
-    c->d_vaff.release(); c->d_simv.release(); c->d_msdl.release(); c->d_ca.release(); c->d_cb.release();
+    c->d_vaff.release(); c->d_simv.release(); c->h_vaff.release(); c->d_ca.release(); c->d_cb.release();
     c->d_flag.release(); c->d_epos.release(); c->d_first_touch.release(); c->d_touch_flag.release();
     c->d_touch_rank.release(); c->d_edges.release(); c->d_l2g.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -465,25 +468,19 @@ static int match_begin_body(l3d_ctx* c) {
     {   // packed hypothesis counters of phase B: fed by the match epilogue (bounded kNN) or by k_orient_all
         uint64_t G = 0;
         for (auto* v : c->order) G += v->M;
-        L3D_HIP_CHECK(c->d_cnt_pack.reserve(G + 1));
-        L3D_HIP_CHECK(hipMemsetAsync(c->d_cnt_pack.p, 0, (G + 1) * 8, c->stream));
+        (void)G;   // (d_cnt_pack: sized and zeroed by upload_views / k_prep_views)
         if (c->kNN > 0) L3D_HIP_CHECK(c->d_inv_pos.reserve(std::max<uint64_t>(c->n_slots, 1)));
     }
     L3D_HIP_CHECK(c->d_pairs.reserve(std::max<size_t>(c->pairs.size(), 1)));
-    if (!c->pairs.empty()) {
-        L3D_HIP_CHECK(c->h_pairs.reserve(c->pairs.size()));
-        std::memcpy(c->h_pairs.p, c->pairs.data(), c->pairs.size() * sizeof(PairDesc));
-        L3D_HIP_CHECK(hipMemcpyAsync(c->d_pairs.p, c->h_pairs.p, c->pairs.size() * sizeof(PairDesc),
-                                     hipMemcpyHostToDevice, c->stream));
+    {
+        bool sent = false;
+        L3D_HIP_CHECK(upload_table(c->d_pairs, c->h_pairs, c->pairs.data(), c->pairs.size() * sizeof(PairDesc), c->up_pairs,
+                                   c->stream, &sent));
+        if (sent || c->pairs.empty()) ++c->pairs_version;
     }
     if (c->kNN > 0) L3D_HIP_CHECK(c->d_slots.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(c->d_cull.reserve(std::max<size_t>(c->cull.size(), 1)));
-    if (!c->cull.empty()) {
-        L3D_HIP_CHECK(c->h_cull.reserve(c->cull.size()));
-        std::memcpy(c->h_cull.p, c->cull.data(), c->cull.size() * sizeof(PairCull));
-        L3D_HIP_CHECK(hipMemcpyAsync(c->d_cull.p, c->h_cull.p, c->cull.size() * sizeof(PairCull),
-                                     hipMemcpyHostToDevice, c->stream));
-    }
+    L3D_HIP_CHECK(upload_table(c->d_cull, c->h_cull, c->cull.data(), c->cull.size() * sizeof(PairCull), c->up_cull, c->stream));
     L3D_HIP_CHECK(c->d_src_perm.reserve(std::max<uint64_t>(cs_off, 1)));
     L3D_HIP_CHECK(c->d_src_band.reserve(std::max<uint64_t>(cs_off, 1)));
     L3D_HIP_CHECK(c->d_tgt_perm.reserve(std::max<uint64_t>(ct_off, 1)));
@@ -539,20 +536,27 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     uint32_t maxK = 0, maxM = 0, maxMt = 0;
     for (uint32_t p = first; p < first + count; ++p) n_work += (c->pairs[p].Ms + kMatchRows - 1) / kMatchRows;
     if (!n_work) return L3D_OK;
-    L3D_HIP_CHECK(c->h_work.reserve(n_work));
-    WorkItem* work = c->h_work.p;
-    size_t w = 0;
     for (uint32_t p = first; p < first + count; ++p) {
         const PairDesc& pd = c->pairs[p];
         maxK = std::max(maxK, pd.K);
         if (c->cull[p].enabled) maxM = std::max(maxM, std::max(pd.Ms, pd.Mt));
         maxMt = std::max(maxMt, pd.Mt);
-        for (uint32_t s0 = 0; s0 < pd.Ms; s0 += kMatchRows) work[w++] = WorkItem{p, s0};
     }
     if (match_lds_bytes(mode, maxK, false, match_waves_per_group(mode, c->brute, (uint32_t)n_work)) > 160 * 1024)
         return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
     L3D_HIP_CHECK(c->d_work.reserve(n_work));
-    L3D_HIP_CHECK(hipMemcpyAsync(c->d_work.p, work, n_work * sizeof(WorkItem), hipMemcpyHostToDevice, c->stream));
+    // the work list of these pairs is on the device already when the pair list has not changed since it was sent
+    if (!(c->work_key.version == c->pairs_version && c->work_key.first == first && c->work_key.count == count &&
+          c->work_key.dev == (const void*)c->d_work.p)) {
+        L3D_HIP_CHECK(c->h_work.reserve(n_work));
+        WorkItem* work = c->h_work.p;
+        size_t w = 0;
+        for (uint32_t p = first; p < first + count; ++p)
+            for (uint32_t s0 = 0; s0 < c->pairs[p].Ms; s0 += kMatchRows) work[w++] = WorkItem{p, s0};
+        L3D_HIP_CHECK(hipMemcpyAsync(c->d_work.p, work, n_work * sizeof(WorkItem), hipMemcpyHostToDevice, c->stream));
+        c->work_key.version = c->pairs_version; c->work_key.first = first; c->work_key.count = count;
+        c->work_key.dev = c->d_work.p;
+    }
     L3D_HIP_CHECK(hipEventRecord(c->ev[8], c->stream));
     CullPools pools{c->d_cull.p, c->d_src_perm.p, c->d_src_band.p, c->d_tgt_perm.p, c->d_tgt_sf.p, c->d_tgt_band.p,
                     c->d_chunk_band.p, c->d_cull_keys.p};
@@ -825,9 +829,19 @@ static ListPools list_pools(l3d_ctx* c, uint32_t pool0 = 0, uint32_t npools = kL
     return lp;
 }
 
+// d_medians = [tot64 x 4 (list entries | inverse records; survivors | hypotheses) | median depth of each view]
+static unsigned long long* tot64_of(l3d_ctx* c) { return (unsigned long long*)c->d_medians.p; }
+static float* medians_of(l3d_ctx* c) { return c->d_medians.p + 8; }
+static size_t fin_b1(uint32_t V) { return ((size_t)8 + V + 3) & ~(size_t)3; }   // second part of h_fin (tail_run)
+
 // layout of the zero block d_lzero (one memset per pass): pool counters | flags (32) | changed (64) | max_score (V+1)
 // | kept_cnt (G) | best_pack (G x u64, 8-byte aligned)
 struct ZeroLayout { size_t flags, changed, max_score, kept, best, words; };
+static ZeroLayout zero_layout(uint32_t V, uint32_t G);
+// positive[slot]: the hypothesis of that slot has a positive score (k_chain_sweep); lives behind the zero block
+static uint8_t* positive_of(l3d_ctx* c) {
+    return (uint8_t*)(c->d_lzero.p + zero_layout((uint32_t)c->order.size(), c->G).words);
+}
 static ZeroLayout zero_layout(uint32_t V, uint32_t G) {
     ZeroLayout z;
     z.flags = (size_t)kListPools * 16; z.changed = z.flags + 32; z.max_score = z.changed + 64;
@@ -849,32 +863,34 @@ static int lists_prepare(l3d_ctx* c) {
     if (2 * c->n_slots >= (1ull << 32)) return fail(L3D_ERR_LIMIT, "more than 2^32 hypotheses");
     L3D_HIP_CHECK(c->d_seg_base.reserve(V + 1)); L3D_HIP_CHECK(c->d_gseg_view.reserve(G + 1));
     L3D_HIP_CHECK(c->d_surv_off.reserve(G + 2)); L3D_HIP_CHECK(c->d_hyp_off.reserve(G + 2));
-    L3D_HIP_CHECK(c->d_hyp_of_seg.reserve(G + 1)); L3D_HIP_CHECK(c->d_medians.reserve(V + 1));
+    L3D_HIP_CHECK(c->d_hyp_of_seg.reserve(G + 1)); L3D_HIP_CHECK(c->d_medians.reserve(V + 1 + 8));   // [two 64-bit totals + spare | medians]: read back together
     L3D_HIP_CHECK(c->d_off64.reserve(G + 2)); L3D_HIP_CHECK(c->d_cnt64.reserve(G + 2)); L3D_HIP_CHECK(c->d_off64s.reserve(G + 2));
-    L3D_HIP_CHECK(c->d_scan64_tmp.reserve(G / 4096 + 1024)); L3D_HIP_CHECK(c->d_tot64.reserve(4));
+    L3D_HIP_CHECK(c->d_scan_ws.reserve_zeroed(scan_ws_words(G, 8), st));
     L3D_HIP_CHECK(c->d_seg_of_g.reserve(G + 1)); L3D_HIP_CHECK(c->d_list2.reserve(G + 1)); L3D_HIP_CHECK(c->d_list4.reserve(G + 1)); L3D_HIP_CHECK(c->d_listH.reserve(G + 1));
     L3D_HIP_CHECK(c->d_hyps.reserve(std::max<uint32_t>(G, 1))); L3D_HIP_CHECK(c->d_depths.reserve(2 * (size_t)G + 2));
-    L3D_HIP_CHECK(c->d_positive.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(c->d_inv_recs.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(c->d_inv_pos.reserve(std::max<uint64_t>(c->n_slots, 1)));
-    L3D_HIP_CHECK(c->h_fin.reserve(128 + kListPools * 16)); L3D_HIP_CHECK(c->h_med.reserve(V + 1));
+    L3D_HIP_CHECK(c->h_fin.reserve(fin_b1(V) + kListPools * 16 + 96));
     L3D_HIP_CHECK(c->h_small.reserve(V + 1));
     L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
     g_trace.mark("finish: reserves done");
-    std::memcpy(c->h_small.p, c->seg_base.data(), ((size_t)V + 1) * 4);
-    L3D_HIP_CHECK(hipMemcpyAsync(c->d_seg_base.p, c->h_small.p, ((size_t)V + 1) * 4, hipMemcpyHostToDevice, st));
-    {
-        uint32_t max_M = 0;
-        for (auto* v : c->order) max_M = std::max(max_M, v->M);
-        L3D_HIP_CHECK(launch_fill_gseg_view(c->d_seg_base.p, V, max_M, c->d_gseg_view.p, st));
+    {   // segment -> view table: a function of the view sizes alone, kept while they (and the array) are the same
+        bool sent = false;
+        L3D_HIP_CHECK(upload_table(c->d_seg_base, c->h_segb, c->seg_base.data(), ((size_t)V + 1) * 4, c->up_seg_base, st, &sent));
+        if (sent || c->gseg_view_for != (const void*)c->d_gseg_view.p) {
+            uint32_t max_M = 0;
+            for (auto* v : c->order) max_M = std::max(max_M, v->M);
+            L3D_HIP_CHECK(launch_fill_gseg_view(c->d_seg_base.p, V, max_M, c->d_gseg_view.p, st));
+            c->gseg_view_for = c->d_gseg_view.p;
+        }
     }
     // per-view / per-outgoing-pair tables of the list pass (l3d_lists.h), staged in one pinned buffer:
     // [ListView x V | OutPair x P], outgoing pairs of a view in ascending target order
     {
         static_assert(sizeof(ListView) == 32 && sizeof(OutPair) == 32, "table layout");
-        L3D_HIP_CHECK(c->h_ltab.reserve(((size_t)V + P + 1) * 32));
-        ListView* hv = (ListView*)c->h_ltab.p;
-        OutPair* hp = (OutPair*)(c->h_ltab.p + (size_t)V * 32);
+        std::vector<char> table(((size_t)V + P + 1) * 32, 0);
+        ListView* hv = (ListView*)table.data();
+        OutPair* hp = (OutPair*)(table.data() + (size_t)V * 32);
         uint32_t n = 0;
         for (uint32_t vi = 0; vi < V; ++vi) {
             ListView& lv = hv[vi];
@@ -889,7 +905,7 @@ static int lists_prepare(l3d_ctx* c) {
             lv.nq = n - lv.q0;
         }
         L3D_HIP_CHECK(c->d_ltab.reserve(((size_t)V + P + 1) * 32));
-        L3D_HIP_CHECK(hipMemcpyAsync(c->d_ltab.p, c->h_ltab.p, ((size_t)V + n) * 32, hipMemcpyHostToDevice, st));
+        L3D_HIP_CHECK(upload_table(c->d_ltab, c->h_ltab, table.data(), ((size_t)V + n) * 32, c->up_ltab, st));
     }
     // ---- pre-pass: orientation flags and hypothesis counters of the pairs that do not carry them yet ----
     // (bounded kNN: done by the match epilogue / the exchange expansion; what is left are the pairs of the keep-all
@@ -904,7 +920,7 @@ static int lists_prepare(l3d_ctx* c) {
         p0 = p1;
     }
     // list offsets (low words) and offsets of the inverse records (high words) in ONE scan of the packed counters
-    L3D_HIP_CHECK(launch_scan64(c->d_cnt_pack.p, G, c->d_off64.p, c->d_scan64_tmp.p, c->d_tot64.p, st));
+    L3D_HIP_CHECK(launch_scan64(c->d_cnt_pack.p, G, c->d_off64.p, c->d_scan_ws.p, tot64_of(c), st));
     if (!c->lp_ecap) {
         c->lp_ecap = (uint32_t)std::max<uint64_t>(c->n_slots / 4 / kListPools, 512);
         c->lp_hcap = (uint32_t)std::max<uint64_t>(c->n_slots / 8 / kListPools, 256);
@@ -918,7 +934,7 @@ static int lists_prepare(l3d_ctx* c) {
 static int lists_reserve(l3d_ctx* c) {
     const uint32_t V = (uint32_t)c->order.size();
     const ZeroLayout z = zero_layout(V, c->G);
-    L3D_HIP_CHECK(c->d_lzero.reserve(z.words + 2));
+    L3D_HIP_CHECK(c->d_lzero.reserve(z.words + 2 + (c->n_slots + 3) / 4));   // zero block | positive[] (one byte per slot)
     L3D_HIP_CHECK(c->d_ledges.reserve((size_t)kListPools * c->lp_ecap));
     L3D_HIP_CHECK(c->d_lhyps.reserve((size_t)kListPools * c->lp_hcap));
     L3D_HIP_CHECK(c->d_lsegs.reserve((size_t)kListPools * c->lp_scap));
@@ -942,16 +958,18 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
     const SimConst simc = sim_thresholds(c->two_sigA_sqr);
     uint64_t max_slots = 0;
     for (auto& pd : c->pairs) max_slots = std::max<uint64_t>(max_slots, (uint64_t)pd.Ms * pd.K);
-    L3D_HIP_CHECK(hipMemsetAsync(c->d_lzero.p, 0, z.words * 4, st));
-    L3D_HIP_CHECK(hipMemsetAsync(c->d_positive.p, 0, std::max<uint64_t>(c->n_slots, 1), st));
-    L3D_HIP_CHECK(hipMemsetAsync(c->d_seg_of_g.p, 0xFF, ((size_t)G + 1) * 4, st));
+    // one memset per pass: the zero block and, behind it, positive[] (seg_of_g needs none: it is only read for
+    // segments with surviving hypotheses, whose header this very pass has written)
+    L3D_HIP_CHECK(hipMemsetAsync(c->d_lzero.p, 0, z.words * 4 + std::max<uint64_t>(c->n_slots, 1), st));
     L3D_HIP_CHECK(launch_inv_records(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_off64.p,
                                      c->d_inv_pos.p, c->d_inv_recs.p, v0, v0 + nv, st));
     // mean list length: every alive slot is a hypothesis of its source segment and, towards a later view, of its target
     // segment too (~0.8 of the slots are alive, ~half of the pairs hand inverse matches over); exact after the first call
     const uint32_t mean_list = c->n_ents ? (uint32_t)(c->n_ents / std::max<uint32_t>(G, 1))
                                          : (uint32_t)(1.5 * (double)c->n_slots / std::max<uint32_t>(G, 1));
-    const HugeScratchArgs hsa{c->d_huge_f32.p, c->d_huge_u32.p, (uint64_t*)c->d_huge_u64.p, c->huge_cap, mean_list};
+    const HugeScratchArgs hsa{c->d_huge_f32.p, c->d_huge_u32.p, (uint64_t*)c->d_huge_u64.p, c->huge_cap, mean_list,
+                              c->huge_skip ? 0u : 1u};
+    c->huge_ran = !c->huge_skip;
     uint32_t max_M = 0;
     for (uint32_t vi = v0; vi < v0 + nv; ++vi) max_M = std::max(max_M, c->order[vi]->M);
     const ListView* lviews = (const ListView*)c->d_ltab.p;
@@ -974,25 +992,24 @@ static int tail_run(l3d_ctx* c, bool fresh) {
     uint32_t* kept = c->d_lzero.p + z.kept;
     unsigned long long* best = (unsigned long long*)(c->d_lzero.p + z.best);
     if (!fresh) L3D_HIP_CHECK(hipMemsetAsync(changed, 0, (z.words - z.changed) * 4, st));
-    // as many launches as the last call needed + 2 (a launch is a no-op once nothing changes; the last one enqueued
+    // as many launches as the last call needed + 1 (a launch is a no-op once nothing changes; the last one enqueued
     // must report "no change", else the host keeps sweeping)
-    const uint32_t n_sweeps = std::min(kChainSweeps, std::max(4u, c->chain_need + 2));
+    const uint32_t n_sweeps = std::min(kChainSweeps, std::max(3u, c->chain_need + 1));
     c->chain_enqueued = n_sweeps;
     for (uint32_t s2 = 0; s2 < n_sweeps; ++s2)
-        L3D_HIP_CHECK(launch_chain_sweep(lp, c->d_positive.p, changed, s2, st));
-    L3D_HIP_CHECK(launch_hyp_scores(lp, c->d_positive.p, c->d_gseg_view.p, c->d_slots.p, max_score, st));
+        L3D_HIP_CHECK(launch_chain_sweep(lp, positive_of(c), changed, s2, st));
+    L3D_HIP_CHECK(launch_hyp_scores(lp, positive_of(c), c->d_gseg_view.p, c->d_slots.p, max_score, st));
     L3D_HIP_CHECK(launch_hyp_filter(lp, G, c->d_gseg_view.p, max_score, kept, best, c->d_cnt64.p, st));
-    L3D_HIP_CHECK(launch_scan64(c->d_cnt64.p, G, c->d_off64s.p, c->d_scan64_tmp.p, c->d_tot64.p + 1, st));
+    L3D_HIP_CHECK(launch_scan64(c->d_cnt64.p, G, c->d_off64s.p, c->d_scan_ws.p, tot64_of(c) + 1, st));
     L3D_HIP_CHECK(launch_seg_write(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p, c->d_off64s.p, best,
                                    c->d_seg_of_g.p, lp, c->d_slots.p, c->d_surv_off.p, c->d_hyp_off.p, c->d_surv.p,
                                    c->d_surv_tg.p, c->d_surv_sg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_depths.p, st));
-    L3D_HIP_CHECK(launch_median_all(V, c->d_depths.p, c->d_hyp_off.p, c->d_seg_base.p, c->d_medians.p, st));
-    // read-backs (pinned): [0..3] two 64-bit totals, [4..35] flags, [36..99] changed, [128..] pool counters
+    L3D_HIP_CHECK(launch_median_all(V, c->d_depths.p, c->d_hyp_off.p, c->d_seg_base.p, medians_of(c), st));
+    // read-backs (pinned), two copies: [0..7] 64-bit totals, [8..8+V) medians | from fin_b1(V): pool counters, flags (32),
+    // changed (64) -- the head of the zero block
     uint32_t* h = c->h_fin.p;
-    L3D_HIP_CHECK(hipMemcpyAsync(h, c->d_tot64.p, 16, hipMemcpyDeviceToHost, st));
-    L3D_HIP_CHECK(hipMemcpyAsync(h + 4, c->d_lzero.p + z.flags, (32 + 64) * 4, hipMemcpyDeviceToHost, st));
-    L3D_HIP_CHECK(hipMemcpyAsync(h + 128, c->d_lzero.p, (size_t)kListPools * 16 * 4, hipMemcpyDeviceToHost, st));
-    L3D_HIP_CHECK(hipMemcpyAsync(c->h_med.p, c->d_medians.p, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipMemcpyAsync(h, c->d_medians.p, (8 + (size_t)V) * 4, hipMemcpyDeviceToHost, st));
+    L3D_HIP_CHECK(hipMemcpyAsync(h + fin_b1(V), c->d_lzero.p, ((size_t)kListPools * 16 + 96) * 4, hipMemcpyDeviceToHost, st));
     L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
     return L3D_OK;
 }
@@ -1001,9 +1018,11 @@ static int tail_run(l3d_ctx* c, bool fresh) {
 // L3D_OK, an error, or kRetry after the pools were enlarged
 static constexpr int kRetry = 1;
 static int check_pass(l3d_ctx* c) {
-    const uint32_t* h = c->h_fin.p;
+    const uint32_t* h0 = c->h_fin.p;
+    const uint32_t* h = h0 + fin_b1((uint32_t)c->order.size()) - 128;   // h[128 + ...]: pool counters
+    const uint32_t* hf = h + 128 + kListPools * 16;                       // flags
     uint32_t fl[8];
-    for (int k = 0; k < 8; ++k) fl[k] = h[4 + k];
+    for (int k = 0; k < 8; ++k) fl[k] = hf[k];
     if (c->shard_world > 1) {
         const uint32_t ppr = kListPools / c->shard_world;
         for (uint32_t r = 0; r < c->shard_world; ++r)
@@ -1012,6 +1031,10 @@ static int check_pass(l3d_ctx* c) {
         for (uint32_t r = 0; r < c->shard_world; ++r) fl[6] = std::max(fl[6], h[128 + (size_t)r * ppr * 16 + 12]);
     }
     if (fl[1]) return fail(L3D_ERR_LIMIT, "a 2D segment has more than 65535 match hypotheses");
+    // lists for the global-memory kernel although its launch was left out: repeat with it (and keep it from now on)
+    const bool huge_missed = fl[5] && !c->huge_ran;
+    c->huge_skip = fl[5] == 0 && c->shard_world <= 1;
+    if (huge_missed) return kRetry;
     if (fl[3]) return fail(L3D_ERR_HIP, "internal error: hypothesis counters and slot flags disagree");
     if (fl[0] || fl[2]) {
         if (++c->lp_attempts > 6) return fail(L3D_ERR_LIMIT, "phase-B pools keep overflowing");
@@ -1036,11 +1059,13 @@ static int check_pass(l3d_ctx* c) {
 // results of the converged pass -> context; matchImages' epilogue (line3D.cc:493)
 static int finish_commit(l3d_ctx* c) {
     const uint32_t V = (uint32_t)c->order.size();
-    const uint32_t* h = c->h_fin.p;
-    c->n_ents = h[0];
-    c->n_surv = h[2]; c->n_hyps = h[3];
-    c->tm.list_entries = h[0];
-    for (uint32_t s2 = 0; s2 < c->chain_enqueued; ++s2) c->tm.chain_sweeps += h[36 + s2] ? 1u : 0u;   // of the last round
+    const uint32_t* h0 = c->h_fin.p;
+    const uint32_t* h = h0 + fin_b1(V) - 128;                             // h[128 + ...]: pool counters
+    const uint32_t* changed = h + 128 + kListPools * 16 + 32;
+    c->n_ents = h0[0];
+    c->n_surv = h0[2]; c->n_hyps = h0[3];
+    c->tm.list_entries = h0[0];
+    for (uint32_t s2 = 0; s2 < c->chain_enqueued; ++s2) c->tm.chain_sweeps += changed[s2] ? 1u : 0u;   // of the last round
     c->chain_need = c->tm.chain_extra_rounds ? kChainSweeps : c->tm.chain_sweeps;
     {
         uint64_t ne = 0;
@@ -1049,7 +1074,7 @@ static int finish_commit(l3d_ctx* c) {
     }
     // View::update_median_depth for every view (line3D.cc:1665-1668); in fixed-regulariser mode k is
     // re-set to the same sigma_p/med_scene_depth value, so k is unchanged either way
-    for (uint32_t vi = 0; vi < V; ++vi) c->order[vi]->median_depth = c->h_med.p[vi];
+    for (uint32_t vi = 0; vi < V; ++vi) c->order[vi]->median_depth = ((const float*)h0)[8 + vi];
     c->host_offsets_valid = false;
     if (c->timing_pending) {   // phase A ran unsynchronised (l3d_match_images)
         collect_match_timing(c);
@@ -1073,7 +1098,7 @@ static int tail_until_converged(l3d_ctx* c) {
     g_trace.mark("phase B done");
     rc = check_pass(c);
     if (rc) return rc;
-    while (c->h_fin.p[36 + c->chain_enqueued - 1]) {
+    while (c->h_fin.p[fin_b1((uint32_t)c->order.size()) + kListPools * 16 + 32 + c->chain_enqueued - 1]) {
         rc = tail_run(c, false);
         if (rc) return rc;
         L3D_HIP_CHECK(hipStreamSynchronize(st));

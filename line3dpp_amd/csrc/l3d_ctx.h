@@ -25,7 +25,9 @@ struct l3d_ctx;
 namespace l3d {
 
 // ---- prototypes of the launchers in k_views.hip / k_affinity.hip -------------------------------
-hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, uint32_t* tmp, uint32_t* total, hipStream_t);
+// k_scan.hip: single-launch exclusive scans; ws = scan_ws_words(n, bytes per element) zeroed 64-bit words
+size_t scan_ws_words(size_t n, uint32_t bytes_per_element);
+hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, unsigned long long* ws, uint32_t* total, hipStream_t);
 hipError_t launch_collin(int pass, const ViewDev* views, uint32_t n_views, uint32_t max_M, const uint32_t* seg_base,
                          float collin_t, uint32_t* cnt, const uint32_t* coll_off, uint32_t* coll_idx, hipStream_t);
 hipError_t launch_aff_coll_count(int mode, uint32_t n_items, const uint32_t* surv_tg, const float* simv, const HypRec*,
@@ -78,7 +80,8 @@ hipError_t launch_aff_sim(uint32_t N, const uint32_t* surv_sg, const uint32_t* s
                           const HypRec*, const ViewAff*, const float* medians, const float* msdl, float two_sigA_sqr,
                           float* simv, int32_t* ca, int32_t* cb, hipStream_t);
 hipError_t launch_aff_flag(uint32_t N, const uint32_t* surv_off, const uint32_t* surv_sg, const uint32_t* surv_tg,
-                           const float* simv, const int32_t* ca, const int32_t* cb, uint32_t* flag, hipStream_t);
+                           const float* simv, const int32_t* ca, const int32_t* cb, uint32_t* flag,
+                           uint32_t* first_touch, uint32_t H, uint32_t* touch_flag, hipStream_t);
 hipError_t launch_fill_u32(uint32_t*, uint32_t n, uint32_t val, hipStream_t);
 hipError_t launch_aff_touch(uint32_t N, const uint32_t* flag, const uint32_t* epos, const int32_t* ca,
                             const int32_t* cb, uint32_t* first_touch, hipStream_t);
@@ -149,7 +152,6 @@ struct l3d_ctx {
     uint32_t aff_n_edges = 0, aff_n_rows = 0;
     bool aff_host_valid = true;
     PinnedBuf<uint32_t> h_cnt;
-    PinnedBuf<float> h_med;
     hipStream_t aux[2] = {nullptr, nullptr};        // aux[0] high priority (phase-A first half, the chain), aux[1]
     std::vector<hipEvent_t> pipe_ev;
     std::vector<uint8_t> pair_counted;   // the pair's slots carry orientation flags and are in the phase-B counters
@@ -163,7 +165,11 @@ struct l3d_ctx {
     PinnedBuf<PairDesc> h_pairs;
     PinnedBuf<PairCull> h_cull;
     PinnedBuf<WorkItem> h_work;
-    PinnedBuf<uint32_t> h_vout, h_small;
+    UploadTag up_views, up_pairs, up_cull, up_seg_base, up_ltab;   // what the device tables hold (upload_table)
+    uint64_t pairs_version = 0;                     // bumped whenever the pair list on the device changes
+    struct { uint64_t version = ~0ull; uint32_t first = 0, count = 0; const void* dev = nullptr; } work_key;   // d_work holds the items of these pairs
+    PinnedBuf<uint32_t> h_vout, h_small, h_segb;
+    const void* gseg_view_for = nullptr;            // d_gseg_view was filled for the seg_base the device holds
     bool timing_pending = false;                    // phase-A events recorded but not read yet
     uint32_t pending_launches = 0;
     DevBuf<uint32_t> d_row_counts;
@@ -174,12 +180,11 @@ struct l3d_ctx {
     // phase B (global over all views; G = sum of M)
     uint32_t G = 0, n_ents = 0, n_surv = 0, n_hyps = 0;
     std::vector<uint32_t> seg_base;                 // [V+1]
-    DevBuf<uint32_t> d_seg_base, d_gseg_view, d_cnt, d_off, d_scan_tmp, d_scal, d_max_score;
+    DevBuf<uint32_t> d_seg_base, d_gseg_view, d_cnt, d_off, d_scal, d_max_score;
     DevBuf<uint32_t> d_surv_cnt, d_has_best, d_best_pos, d_surv_off, d_hyp_off, d_surv_tg, d_surv_sg;
     DevBuf<InvRef> d_refs;
     DevBuf<uint64_t> d_bits;
     DevBuf<uint32_t> d_eref;
-    DevBuf<uint8_t> d_positive;
     DevBuf<uint32_t> d_bits_len, d_boff, d_long_list;
     DevBuf<uint32_t> d_cnt_inv, d_inv_off, d_vout_pairs, d_vout_off, d_inv_pos;
     DevBuf<unsigned long long> d_cnt_pack;
@@ -187,10 +192,10 @@ struct l3d_ctx {
     DevBuf<DEntry> d_dents;
     DevBuf<Match> d_surv;
     DevBuf<int32_t> d_hyp_of_seg;
-    DevBuf<float> d_depths, d_medians;              // d_medians[V]
+    DevBuf<float> d_depths, d_medians;              // d_medians: 8 words of 64-bit totals, then [V] medians
     DevBuf<HypRec> d_hyps;
     // sparse phase B (k_lists.hip, l3d_lists.h)
-    DevBuf<unsigned long long> d_off64, d_cnt64, d_off64s, d_scan64_tmp, d_tot64, d_huge_u64;
+    DevBuf<unsigned long long> d_off64, d_cnt64, d_off64s, d_scan_ws, d_huge_u64;
     DevBuf<InvRec> d_inv_recs;
     DevBuf<uint32_t> d_lzero, d_list2, d_list4, d_listH, d_seg_of_g, d_huge_u32;
     DevBuf<float> d_huge_f32;
@@ -201,6 +206,7 @@ struct l3d_ctx {
     DevBuf<CandHdr> d_lchdrs;
     uint32_t lp_ecap = 0, lp_hcap = 0, lp_scap = 0, lp_ccap = 0, huge_cap = 0;
     uint32_t lp_attempts = 0;
+    bool huge_skip = false, huge_ran = true;        // k_lists_huge left out while the passes hand it no lists
     uint32_t chain_need = 8, chain_enqueued = 10;   // chain launches that changed something last time / enqueued this time
     // list pass sharded over ranks (l3d_lists_shard): world size of the running call, slabs received
     uint32_t shard_world = 0;
@@ -212,7 +218,8 @@ struct l3d_ctx {
     bool host_offsets_valid = false;
     // affinity
     DevBuf<ViewAff> d_vaff;
-    DevBuf<float> d_simv, d_msdl;
+    DevBuf<float> d_simv;
+    PinnedBuf<ViewAff> h_vaff; UploadTag up_vaff;
     DevBuf<int32_t> d_ca, d_cb;
     DevBuf<uint32_t> d_flag, d_epos, d_first_touch, d_touch_flag, d_touch_rank;
     DevBuf<l3d_cledge> d_edges;

@@ -40,6 +40,13 @@ struct DevBuf {
         if (e == hipSuccess) cap = n;
         return e;
     }
+    // work space that its kernels leave all-zero between launches (k_scan.hip): zeroed when it is (re)allocated
+    hipError_t reserve_zeroed(size_t n, hipStream_t st) {
+        if (n <= cap) return hipSuccess;
+        hipError_t e = reserve(n);
+        if (e == hipSuccess) e = hipMemsetAsync(p, 0, n * sizeof(T), st);
+        return e;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
@@ -58,6 +65,30 @@ struct PinnedBuf {
     }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
+
+// Host -> device through a pinned staging buffer, left out when the device array already holds these very bytes: the
+// view table, the pair list and the small tables of phase B are the same from one matchImages call to the next as
+// long as the scene is, and each copy is a launch of its own on the stream.  The staging buffer doubles as the record
+// of what was sent; `dev_seen` remembers which device allocation received it.  Larger tables are simply sent.
+struct UploadTag { const void* dev_seen = nullptr; size_t bytes = 0; };
+template <class T, class S>
+hipError_t upload_table(DevBuf<T>& dev, PinnedBuf<S>& stage, const void* src, size_t bytes, UploadTag& tag,
+                        hipStream_t st, bool* sent = nullptr) {
+    if (sent) *sent = false;
+    if (!bytes) return hipSuccess;
+    const size_t n_stage = (bytes + sizeof(S) - 1) / sizeof(S);
+    const bool stage_kept = n_stage <= stage.cap;
+    hipError_t e = stage.reserve(n_stage);
+    if (e != hipSuccess) return e;
+    if (stage_kept && tag.dev_seen == (const void*)dev.p && tag.bytes == bytes && bytes <= (256u << 10) &&
+        std::memcmp(stage.p, src, bytes) == 0)
+        return hipSuccess;
+    std::memcpy(stage.p, src, bytes);
+    e = hipMemcpyAsync(dev.p, stage.p, bytes, hipMemcpyHostToDevice, st);
+    tag.dev_seen = dev.p; tag.bytes = bytes;
+    if (sent) *sent = true;
+    return e;
+}
 
 // ---- host double 3x3 algebra (mirrors Eigen's fixed-size behaviour; see l3d_dev.h) -------------
 struct M3 { double m[9]; };

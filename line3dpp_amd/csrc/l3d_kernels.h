@@ -85,11 +85,13 @@ hipError_t launch_pack_slot_idx(const Slot* slots, uint32_t* idx, uint64_t lo, u
 hipError_t launch_expand_slot_idx(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
                                   uint32_t max_row_slots, const uint32_t* idx, Slot* slots, OrientFuse of,
                                   hipStream_t stream);
-hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, hipStream_t stream);
+// per-segment invariants of all views; cnt_pack (may be null): [G + 1] packed counters zeroed on the way
+hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, unsigned long long* cnt_pack,
+                             uint32_t G, hipStream_t stream);
 
 // ---- k_lists.hip: the sparse phase B (l3d_lists.h) ----
 struct InvRec; struct ListPools;
-struct HugeScratchArgs { float* f32; uint32_t* u32; uint64_t* u64; uint32_t cap; uint32_t mean_list; };   // [2 cap] [3 cap] [cap]; mean list length (estimate)
+struct HugeScratchArgs { float* f32; uint32_t* u32; uint64_t* u64; uint32_t cap; uint32_t mean_list; uint32_t run_huge; };   // [2 cap] [3 cap] [cap]; mean list length (estimate)
 hipError_t launch_scan64(const unsigned long long* in, uint32_t n, unsigned long long* out, unsigned long long* tmp,
                          unsigned long long* total, hipStream_t st);
 hipError_t launch_inv_records(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,

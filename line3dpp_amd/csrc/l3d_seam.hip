@@ -41,12 +41,12 @@ int l3d_find_collinear_segments(int device, const float* lines4, uint32_t M, flo
     for (uint32_t i = 0; i <= M; ++i) offsets[i] = 0;
     if (!M || !(dist_t > (float)kEps)) return L3D_OK;                       // view.cc:158: nothing to do
     if (hipSetDevice(device) != hipSuccess) return fail(L3D_ERR_HIP, "hipSetDevice failed: no usable HIP device");
-    DevBuf<float4> seg4; DevBuf<ViewDev> dv; DevBuf<uint32_t> base, cnt, off, tmp, tot, lists;
+    DevBuf<float4> seg4; DevBuf<ViewDev> dv; DevBuf<uint32_t> base, cnt, off, tot, lists; DevBuf<unsigned long long> tmp;
     auto cleanup = [&]() { seg4.release(); dv.release(); base.release(); cnt.release(); off.release(); tmp.release();
                            tot.release(); lists.release(); };
     const int rc = [&]() -> int {
         L3D_HIP_CHECK(seg4.reserve(M)); L3D_HIP_CHECK(dv.reserve(1)); L3D_HIP_CHECK(base.reserve(2));
-        L3D_HIP_CHECK(cnt.reserve(M + 1)); L3D_HIP_CHECK(off.reserve(M + 1)); L3D_HIP_CHECK(tmp.reserve(M / 4096 + 1024));
+        L3D_HIP_CHECK(cnt.reserve(M + 1)); L3D_HIP_CHECK(off.reserve(M + 1)); L3D_HIP_CHECK(tmp.reserve_zeroed(scan_ws_words(M, 4), 0));
         L3D_HIP_CHECK(tot.reserve(1));
         L3D_HIP_CHECK(hipMemcpy(seg4.p, lines4, (size_t)M * 16, hipMemcpyHostToDevice));
         ViewDev hv{};
@@ -98,7 +98,7 @@ int l3d_score_matches(int device, const float* lines4, uint32_t M, const float* 
     }
     if (hipSetDevice(device) != hipSuccess) return fail(L3D_ERR_HIP, "hipSetDevice failed: no usable HIP device");
     DevBuf<float4> seg4, m4; DevBuf<float2> rt; DevBuf<SegF> segf; DevBuf<SegX> segx; DevBuf<ViewDev> dv;
-    DevBuf<uint32_t> d_off, d_boff, d_len, d_tmp, d_scal, d_gv, d_long, d_max; DevBuf<DEntry> dents; DevBuf<uint64_t> bits;
+    DevBuf<uint32_t> d_off, d_boff, d_len, d_scal, d_gv, d_long, d_max; DevBuf<unsigned long long> d_tmp; DevBuf<DEntry> dents; DevBuf<uint64_t> bits;
     DevBuf<float> d_scores;
     auto cleanup = [&]() { seg4.release(); m4.release(); rt.release(); segf.release(); segx.release(); dv.release();
                            d_off.release(); d_boff.release(); d_len.release(); d_tmp.release(); d_scal.release();
@@ -108,7 +108,7 @@ int l3d_score_matches(int device, const float* lines4, uint32_t M, const float* 
         L3D_HIP_CHECK(seg4.reserve(M)); L3D_HIP_CHECK(segf.reserve(M)); L3D_HIP_CHECK(segx.reserve(M));
         L3D_HIP_CHECK(m4.reserve(n)); L3D_HIP_CHECK(rt.reserve(n)); L3D_HIP_CHECK(dv.reserve(1));
         L3D_HIP_CHECK(d_off.reserve(M + 1)); L3D_HIP_CHECK(d_boff.reserve(M + 1)); L3D_HIP_CHECK(d_len.reserve(M + 1));
-        L3D_HIP_CHECK(d_tmp.reserve(M / 4096 + 1024)); L3D_HIP_CHECK(d_scal.reserve(4)); L3D_HIP_CHECK(d_gv.reserve(M + 1));
+        L3D_HIP_CHECK(d_tmp.reserve_zeroed(scan_ws_words(M, 4), 0)); L3D_HIP_CHECK(d_scal.reserve(4)); L3D_HIP_CHECK(d_gv.reserve(M + 1));
         L3D_HIP_CHECK(d_long.reserve(M + 1)); L3D_HIP_CHECK(d_max.reserve(2)); L3D_HIP_CHECK(dents.reserve(n));
         L3D_HIP_CHECK(d_scores.reserve(n));
         L3D_HIP_CHECK(hipMemcpy(seg4.p, lines4, (size_t)M * 16, hipMemcpyHostToDevice));
@@ -121,7 +121,7 @@ int l3d_score_matches(int device, const float* lines4, uint32_t M, const float* 
         std::memcpy(hv.C, C, 24); std::memcpy(hv.RtKinv, RtKinv, 72);
         hv.seg4 = seg4.p; hv.segf = segf.p; hv.segx = segx.p; hv.M = M; hv.k = k;
         L3D_HIP_CHECK(hipMemcpy(dv.p, &hv, sizeof(hv), hipMemcpyHostToDevice));
-        L3D_HIP_CHECK(launch_prep_views(dv.p, 1, M, 0));
+        L3D_HIP_CHECK(launch_prep_views(dv.p, 1, M, nullptr, 0, 0));
         L3D_HIP_CHECK(launch_seam_entries(n, m4.p, rt.p, dv.p, k, dents.p, 0));
         L3D_HIP_CHECK(launch_bits_len(M, d_off.p, d_len.p, d_long.p, d_scal.p + 1, 0));
         L3D_HIP_CHECK(launch_scan(d_len.p, M, d_boff.p, d_tmp.p, d_scal.p + 0, 0));
@@ -193,7 +193,7 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         L3D_HIP_CHECK(dv.reserve(2)); L3D_HIP_CHECK(dp.reserve(1)); L3D_HIP_CHECK(dw.reserve(work.size()));
         L3D_HIP_CHECK(ds.reserve((size_t)Ms * pd.K));
         L3D_HIP_CHECK(hipMemcpy(dv.p, hv, sizeof(hv), hipMemcpyHostToDevice));
-        L3D_HIP_CHECK(launch_prep_views(dv.p, 2, std::max(Ms, Mt), 0));
+        L3D_HIP_CHECK(launch_prep_views(dv.p, 2, std::max(Ms, Mt), nullptr, 0, 0));
         L3D_HIP_CHECK(hipMemcpy(dp.p, &pd, sizeof(pd), hipMemcpyHostToDevice));
         L3D_HIP_CHECK(hipMemcpy(dw.p, work.data(), work.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
         const float thr = std::fmin(std::fabs(epi_overlap), 0.99f);
