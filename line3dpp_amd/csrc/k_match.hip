@@ -722,7 +722,8 @@ __device__ __forceinline__ Band tgt_band(const PairCull& pc, const float4 s, flo
     return make_band(lo, hi, cls);
 }
 
-// bitonic sort of n2 (power of two) 64-bit keys in LDS
+// bitonic sort of n2 (power of two) 64-bit keys in place (LDS or, for the views beyond the LDS capacity, global memory):
+// one barrier per stage
 __device__ void lds_sort(uint64_t* keys, uint32_t n2) {
     for (uint32_t k = 2; k <= n2; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -737,6 +738,83 @@ __device__ void lds_sort(uint64_t* keys, uint32_t n2) {
             }
         }
     __syncthreads();
+}
+
+// The same network for n2 = KPT * kCullBlock keys in LDS with the keys held in REGISTERS, thread t owning the KPT
+// consecutive elements t*KPT ..: a stage whose partner distance j is below KPT is a register exchange, up to
+// 32 threads away a lane exchange inside the wave, and only the last three distances (64, 128, 256 threads) go through
+// LDS with barriers -- for 2048 keys 6 stages with barriers instead of 66 (the sort was 80 % of k_cull_prepare).
+// The keys are distinct (the element index is part of them), so "keep the smaller / the larger" is an exact exchange.
+template <int KPT>
+__device__ void reg_sort(uint64_t* keys) {
+    constexpr uint32_t n2 = KPT * kCullBlock;
+    const uint32_t t = threadIdx.x;
+    uint64_t v[KPT];
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) v[r] = keys[t * KPT + r];
+    for (uint32_t k = 2; k <= n2; k <<= 1) {
+        // ---- partner in another wave ----
+        for (uint32_t j = k >> 1; j >= 64u * KPT; j >>= 1) {
+            __syncthreads();                                   // the reads of the previous exchange are done
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) keys[t * KPT + r] = v[r];
+            __syncthreads();
+            const uint32_t pt = t ^ (j / KPT);
+            const bool lower = (t & (j / KPT)) == 0;
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) {
+                const uint64_t o = keys[pt * KPT + r];
+                const bool up = ((t * KPT + r) & k) == 0;
+                v[r] = (lower == up) ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
+            }
+        }
+        // ---- partner in this wave ----
+        for (uint32_t j = min(k >> 1, 32u * KPT); j >= (uint32_t)KPT; j >>= 1) {
+            const uint32_t d = j / KPT;
+            const bool lower = (t & d) == 0;
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) {
+                const uint64_t o = __shfl_xor((unsigned long long)v[r], (int)d);
+                const bool up = ((t * KPT + r) & k) == 0;
+                v[r] = (lower == up) ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
+            }
+        }
+        // ---- partner in this thread ----
+#pragma unroll
+        for (int jj = KPT / 2; jj > 0; jj >>= 1) {
+            if ((uint32_t)jj < k) {
+#pragma unroll
+                for (int r = 0; r < KPT; ++r) {
+                    if ((r & jj) == 0) {
+                        const uint64_t a = v[r], b = v[r | jj];
+                        const bool up = ((t * KPT + r) & k) == 0;
+                        if ((a > b) == up) { v[r] = b; v[r | jj] = a; }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) keys[t * KPT + r] = v[r];
+    __syncthreads();
+}
+
+// n2 >= kCullBlock keys in LDS (a power of two up to KMAX * kCullBlock), or any power of two in global memory.
+// KMAX is a template parameter of the kernel: the register budget (two per key and thread) is that of the largest view
+// of the LAUNCH, not of the largest the code can handle.
+template <int KMAX>
+__device__ void cull_sort(uint64_t* keys, uint32_t n2, bool in_lds) {
+    if (in_lds) {
+        const uint32_t kpt = n2 / kCullBlock;
+        if (kpt == 1) { reg_sort<1>(keys); return; }
+        if constexpr (KMAX >= 2) if (kpt == 2) { reg_sort<2>(keys); return; }
+        if constexpr (KMAX >= 4) if (kpt == 4) { reg_sort<4>(keys); return; }
+        if constexpr (KMAX >= 8) if (kpt == 8) { reg_sort<8>(keys); return; }
+        if constexpr (KMAX >= 16) if (kpt == 16) { reg_sort<16>(keys); return; }
+        if constexpr (KMAX >= 32) if (kpt == 32) { reg_sort<32>(keys); return; }
+    }
+    lds_sort(keys, n2);
 }
 
 }  // namespace
@@ -853,6 +931,7 @@ hipError_t launch_order_items(const PairDesc* pairs, uint32_t first, uint32_t co
     return hipGetLastError();
 }
 
+template <int KMAX>
 __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __restrict__ views,
                                                              const PairDesc* __restrict__ pairs, uint32_t first,
                                                              const CullPools cp) {
@@ -865,7 +944,7 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
     if (!pc.enabled) return;
     const ViewDev& vs = views[pd.src];
     const ViewDev& vt = views[pd.tgt];
-    uint32_t n2 = 64;
+    uint32_t n2 = kCullBlock;                    // (at least one key per thread: reg_sort)
     while (n2 < (tgt_side ? Mt : Ms)) n2 <<= 1;
     // keys in LDS up to kCullLdsSegs per side; beyond that in this pair's global scratch (same code, L2 instead of LDS:
     // slower, but a view of 16 385 segments no longer falls back to unculled matching)
@@ -902,7 +981,8 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
             }
             keys[i] = key;
         }
-        lds_sort(keys, n2);
+        __syncthreads();
+        cull_sort<KMAX>(keys, n2, !big);
         for (uint32_t i = tid; i < Ms; i += kCullBlock) {
             const uint32_t row = (uint32_t)(keys[i] & 0xFFFFFFu);
             const Band b = src_band(pc, vs.seg4[row]);
@@ -933,7 +1013,8 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
         }
         keys[i] = key;
     }
-    lds_sort(keys, n2);
+    __syncthreads();
+    cull_sort<KMAX>(keys, n2, !big);
     for (uint32_t i = tid; i < Mt; i += kCullBlock) {
         const uint32_t seg = (uint32_t)(keys[i] & 0xFFFFFFu);
         const Band b = tgt_band(pc, vt.seg4[seg], slo, shi);
@@ -951,14 +1032,22 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
 hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
                                uint32_t max_M, CullPools pools, hipStream_t stream) {
     if (!count || !pools.cull) return hipSuccess;
-    uint32_t n2 = 64;
+    uint32_t n2 = kCullBlock;
     while (n2 < max_M) n2 <<= 1;
     // (views beyond the LDS capacity keep their keys in global scratch: only the chunk bands stay in LDS)
     const size_t lds = n2 <= kCullLdsSegs ? (size_t)n2 * 8 + (size_t)(n2 / 64) * 8
                                            : std::max<size_t>((size_t)kCullLdsSegs * 8 + (kCullLdsSegs / 64) * 8, (size_t)(n2 / 64) * 8);
-    hipError_t e = hipFuncSetAttribute((const void*)k_cull_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_cull_prepare, dim3(count, 2), dim3(kCullBlock), lds, stream, views, pairs, first, pools);
+#define L3D_CULL(K)                                                                                                        \
+    do {                                                                                                                   \
+        hipError_t e = hipFuncSetAttribute((const void*)k_cull_prepare<K>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                           (int)lds);                                                                      \
+        if (e != hipSuccess) return e;                                                                                     \
+        hipLaunchKernelGGL(k_cull_prepare<K>, dim3(count, 2), dim3(kCullBlock), lds, stream, views, pairs, first, pools);  \
+    } while (0)
+    const uint32_t kmax = std::min(n2, kCullLdsSegs) / kCullBlock;
+    if (kmax <= 1) L3D_CULL(1); else if (kmax == 2) L3D_CULL(2); else if (kmax == 4) L3D_CULL(4);
+    else if (kmax == 8) L3D_CULL(8); else if (kmax == 16) L3D_CULL(16); else L3D_CULL(32);
+#undef L3D_CULL
     return hipGetLastError();
 }
 
@@ -1014,7 +1103,7 @@ __global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __
     __shared__ uint32_t s_nwin;
     float* win_ov = (float*)smem;                 // [K] dynamic
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t n_tied = min(of.tie_count[0], of.tie_cap);
+    const uint32_t n_tied = min(__hip_atomic_load(&of.tie_count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), of.tie_cap);
     uint64_t* glist = scratch + (size_t)blockIdx.x * 2 * scratch_stride;      // [2 stride]: list + sort buffer
     for (uint32_t t = blockIdx.x; t < n_tied; t += gridDim.x) {
         const uint2 item = of.tie_list[t];
@@ -1129,13 +1218,15 @@ __global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __
         }
         __syncthreads();
     }
-    // the last block to finish re-arms the queue for the next match launch
+    // the last block to finish re-arms the queue for the next match launch (every block has read tie_count[0] before
+    // it counts itself; nothing but these counters passes between the blocks, so no fence -- an agent-scope release
+    // fence writes the whole L2 back, 1024 of them cost more than the rows)
+    __syncthreads();                            // every wave of this block has read the count
     if (tid == 0) {
-        __threadfence();
         if (atomicAdd(&of.tie_count[1], 1u) == gridDim.x - 1) {
-            of.tie_count[2] += n_tied;
-            of.tie_count[0] = 0; of.tie_count[1] = 0;
-            __threadfence();
+            __hip_atomic_fetch_add(&of.tie_count[2], n_tied, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&of.tie_count[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&of.tie_count[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
