@@ -880,19 +880,14 @@ __global__ __launch_bounds__(kCullBlock) void k_order_items(const PairDesc* __re
     uint32_t* hist = (uint32_t*)smem;            // [8][kOrderBuckets] counts, then first position of each class
     const uint32_t per_xcd = (nwork + 7) / 8;
     for (uint32_t i = tid; i < 8 * kOrderBuckets; i += kCullBlock) hist[i] = 0;
-    constexpr uint32_t kPer = kMatchOrderMaxItems / kCullBlock;     // items per thread, kept in registers
-    uint32_t mine[kPer];
-#pragma unroll
-    for (uint32_t k = 0; k < kPer; ++k) {        // independent loads (not through this CU's L1: written by other CUs)
-        const uint32_t w = k * kCullBlock + tid;
-        mine[k] = w < nwork ? (w / per_xcd) * kOrderBuckets +
-                                  __hip_atomic_load(&cp.item_bucket[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                            : 0u;
-    }
+    // (the buckets are read twice rather than kept in registers: the registers would be every workgroup's, and this
+    // kernel is all launch latency -- agent-scope loads: written by other CUs)
+    auto key_of = [&](uint32_t w) {
+        return (w / per_xcd) * kOrderBuckets + __hip_atomic_load(&cp.item_bucket[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     __syncthreads();
-#pragma unroll
-    for (uint32_t k = 0; k < kPer; ++k)
-        if (k * kCullBlock + tid < nwork) atomicAdd(&hist[mine[k]], 1u);
+#pragma unroll 4
+    for (uint32_t w = tid; w < nwork; w += kCullBlock) atomicAdd(&hist[key_of(w)], 1u);
     __syncthreads();
     {                                            // wave x: descending exclusive scan of the counters of part x
         static_assert(kCullBlock / 64 == 8, "one wave per XCD");
@@ -909,13 +904,10 @@ __global__ __launch_bounds__(kCullBlock) void k_order_items(const PairDesc* __re
         for (uint32_t k = 0; k < per; ++k) { hx[kOrderBuckets - 1 - (lane * per + k)] = run; run += h[k]; }
     }
     __syncthreads();
-#pragma unroll
-    for (uint32_t k = 0; k < kPer; ++k) {
-        const uint32_t w = k * kCullBlock + tid;
-        if (w < nwork) {
-            const uint32_t pos = atomicAdd(&hist[mine[k]], 1u);
-            if (pos < nwork) cp.item_order[pos] = w;
-        }
+#pragma unroll 4
+    for (uint32_t w = tid; w < nwork; w += kCullBlock) {
+        const uint32_t pos = atomicAdd(&hist[key_of(w)], 1u);
+        if (pos < nwork) cp.item_order[pos] = w;
     }
     if (tid == 0) *cp.order_done = 0;            // re-armed for the next launch
 }
@@ -923,7 +915,6 @@ __global__ __launch_bounds__(kCullBlock) void k_order_items(const PairDesc* __re
 hipError_t launch_order_items(const PairDesc* pairs, uint32_t first, uint32_t count, uint32_t max_Mt, CullPools pools,
                               uint32_t nwork, hipStream_t stream) {
     if (!pools.item_order || !nwork || !count) return hipSuccess;
-    if (nwork > kMatchOrderMaxItems) return hipErrorInvalidValue;   // the ordering workgroup keeps its items in registers
     const size_t lds = std::max<size_t>((size_t)(max_Mt <= 4096 ? max_Mt : (max_Mt + 63) / 64) * 8, 8 * kOrderBuckets * 4);
     hipError_t e = hipFuncSetAttribute((const void*)k_order_items, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1090,8 +1081,7 @@ __device__ __forceinline__ uint32_t tie_select(Ptr list, Ptr sorted, uint32_t n,
     return w;
 }
 
-// tie_count[0] = rows queued by the match kernel, [1] = blocks done (the last one resets [0] for the next launch),
-// [2] = rows replayed since the context was created (diagnostics)
+// of.tie_count = rows queued by the match kernel that has just run
 __global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __restrict__ views,
                                                                const PairDesc* __restrict__ pairs,
                                                                Slot* __restrict__ slots, float thr, const OrientFuse of,
@@ -1100,10 +1090,10 @@ __global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint64_t s_list[kTieLdsHeap], s_sorted[kTieLdsHeap];
     __shared__ uint32_t s_n;
-    __shared__ uint32_t s_nwin;
+    __shared__ uint32_t s_nwin, s_nvis;
     float* win_ov = (float*)smem;                 // [K] dynamic
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t n_tied = min(__hip_atomic_load(&of.tie_count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), of.tie_cap);
+    const uint32_t n_tied = min(*of.tie_count, of.tie_cap);
     uint64_t* glist = scratch + (size_t)blockIdx.x * 2 * scratch_stride;      // [2 stride]: list + sort buffer
     for (uint32_t t = blockIdx.x; t < n_tied; t += gridDim.x) {
         const uint2 item = of.tie_list[t];
@@ -1138,20 +1128,18 @@ __global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __
         const PairCull* pc = (cp.cull && cp.cull[item.x].enabled) ? &cp.cull[item.x] : nullptr;
         float blo = -__builtin_inff(), bhi = __builtin_inff();
         if (pc) { const Band bb = src_band(*pc, s4); blo = bb.lo; bhi = bb.hi; }
-        const uint32_t n_units = pc ? (Mt + 63) / 64 * 64 : Mt;     // culled: whole 64-target chunks, one per wave
         if (tid == 0) s_n = 0;
         __syncthreads();
-        for (uint32_t c0 = 0; c0 < n_units; c0 += kTieBlock) {
-            const uint32_t p = c0 + tid;          // sorted position (culled) or target index
+        // p: sorted position (culled pair) or target index
+        auto visit = [&](uint32_t p) {
             bool acc = false;
             uint32_t cc = p;
             PairResult res{};
             if (p < Mt && live) {
                 bool cand;
                 if (pc) {
-                    const float2 cb = cp.chunk_band[pc->c_off + (p >> 6)];
-                    cand = !(cb.y < blo || cb.x > bhi);
-                    if (cand) { const float2 tb = cp.tgt_band[pc->t_off + p]; cand = !(tb.y < blo || tb.x > bhi); }
+                    const float2 tb = cp.tgt_band[pc->t_off + p];
+                    cand = !(tb.y < blo || tb.x > bhi);
                     if (cand) {
                         const float4 f = cp.tgt_sf[pc->t_off + p];
                         const v4f q = {f.x, f.y, f.z, f.w};
@@ -1165,14 +1153,39 @@ __global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __
                 }
                 if (cand) acc = exact_pair(F, s4, vt.seg4[cc], sx, vt.segx[cc], vs.C, vt.C, thr, res);
             }
-            // accepted ones are appended in any order (one LDS atomic each, no barrier in this loop): they are sorted by
-            // target index below anyway
+            // accepted ones are appended in any order (one LDS atomic each, no barrier in the loops): they are sorted
+            // by target index below anyway
             if (acc) {
                 const uint32_t k = atomicAdd(&s_n, 1u);
                 const uint64_t e = heap_pack(res.overlap, cc);
                 if (k < kTieLdsHeap) s_list[k] = e;
                 else glist[k] = e;
             }
+        };
+        if (pc) {
+            // the chunks whose band meets the row's are listed first (one pass over the chunk bands), then their targets
+            // are visited 512 at a time: the row's neighbourhood is a fifth of the view, i.e. one or two rounds of
+            // dependent loads instead of Mt / 512 (the list lives in the sort buffer, not needed yet)
+            uint32_t* s_vis = (uint32_t*)s_sorted;
+            constexpr uint32_t kVisCap = 2 * kTieLdsHeap;
+            const uint32_t nch = (Mt + 63) / 64;
+            for (uint32_t cb0 = 0; cb0 < nch; cb0 += kVisCap) {
+                if (tid == 0) s_nvis = 0;
+                __syncthreads();
+                for (uint32_t c = cb0 + tid; c < min(nch, cb0 + kVisCap); c += kTieBlock) {
+                    const float2 cb = cp.chunk_band[pc->c_off + c];
+                    if (!(cb.y < blo || cb.x > bhi)) s_vis[atomicAdd(&s_nvis, 1u)] = c;
+                }
+                __syncthreads();
+                const uint32_t n_units = s_nvis * 64;
+                for (uint32_t u0 = 0; u0 < n_units; u0 += kTieBlock) {
+                    const uint32_t u = u0 + tid;
+                    if (u < n_units) visit(s_vis[u >> 6] * 64 + (u & 63u));
+                }
+                __syncthreads();               // before the list is rebuilt
+            }
+        } else {
+            for (uint32_t c0 = 0; c0 < Mt; c0 += kTieBlock) visit(c0 + tid);
         }
         __threadfence_block();
         __syncthreads();
@@ -1218,29 +1231,27 @@ __global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __
         }
         __syncthreads();
     }
-    // the last block to finish re-arms the queue for the next match launch (every block has read tie_count[0] before
-    // it counts itself; nothing but these counters passes between the blocks, so no fence -- an agent-scope release
-    // fence writes the whole L2 back, 1024 of them cost more than the rows)
-    __syncthreads();                            // every wave of this block has read the count
-    if (tid == 0) {
-        if (atomicAdd(&of.tie_count[1], 1u) == gridDim.x - 1) {
-            __hip_atomic_fetch_add(&of.tie_count[2], n_tied, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&of.tie_count[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&of.tie_count[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    // The queue of the NEXT match launch is the other one of two alternating counters (tie_next): it is idle while this
+    // kernel runs, so one thread zeroes it and no workgroup has to wait for, or count, the others (512 same-address
+    // device atomics were a third of this kernel's time).
+    if (blockIdx.x == 0 && tid == 0) {
+        *of.tie_next = 0;
+        of.tie_total[0] += n_tied;              // rows replayed since the context was created (diagnostics)
     }
 }
 
-// four workgroups per CU; fewer when the per-workgroup scratch (16 bytes per target) would pass 128 MiB in total
+// two workgroups per CU -- what its registers let be resident at once: more would only queue up behind them, and with
+// the usual handful of rows the launch is all latency; fewer when the per-workgroup scratch (16 bytes per target)
+// would pass 128 MiB in total
 uint32_t match_tied_grid(uint32_t scratch_stride) {
     const uint64_t per_wg = 2ull * std::max(scratch_stride, 1u) * 8;
-    return (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(64, (128ull << 20) / per_wg));
+    return (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(64, (128ull << 20) / per_wg));
 }
 
 hipError_t launch_match_tied_rows(const ViewDev* views, const PairDesc* pairs, Slot* slots, uint32_t maxK, float thr,
                                   OrientFuse of, CullPools cp, uint64_t* scratch, uint32_t scratch_stride,
                                   hipStream_t stream) {
-    if (!of.tie_count || !of.tie_list || !scratch) return hipErrorInvalidValue;
+    if (!of.tie_count || !of.tie_next || !of.tie_total || !of.tie_list || !scratch) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_match_tied_rows, dim3(match_tied_grid(scratch_stride)), dim3(kTieBlock), (size_t)maxK * 8, stream,
                        views, pairs, slots, thr, of, cp, scratch, scratch_stride);
     return hipGetLastError();

@@ -582,19 +582,22 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     const bool ix16 = maxMt < 65536u && maxK < 65536u;   // 16-bit indices in the kernel's LDS tables
     // bounded kNN: the orientation filter and the hypothesis counters of phase B are fused into the epilogue
     OrientFuse of{mode == 0 ? c->d_cnt_pack.p : nullptr, mode == 0 ? c->d_inv_pos.p : nullptr,
-                  OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u};
+                  OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
     uint32_t tie_stride = 0;
     if (mode == 0) {   // rows with equal overlaps are collected here and replayed in the reference's heap order
         uint32_t mt = 0;
         for (auto& pd : c->pairs) mt = std::max(mt, pd.Mt);
         tie_stride = std::max(mt, 1u);
-        if (!c->d_tie_count.p) {   // zeroed once: the replay kernel re-arms the queue itself after every launch
+        if (!c->d_tie_count.p) {   // zeroed once: the replay kernel zeroes the next launch's counter
             L3D_HIP_CHECK(c->d_tie_count.reserve(4));
             L3D_HIP_CHECK(hipMemsetAsync(c->d_tie_count.p, 0, 16, c->stream));
         }
         L3D_HIP_CHECK(c->d_tie_list.reserve(std::max<uint32_t>(c->n_rows_total, 1)));
         L3D_HIP_CHECK(c->d_tie_heap.reserve(2 * (size_t)match_tied_grid(tie_stride) * tie_stride));
-        of.tie_count = c->d_tie_count.p; of.tie_list = c->d_tie_list.p; of.tie_cap = c->n_rows_total;
+        // two alternating queue counters ([0], [1]); [2] = rows replayed so far
+        of.tie_count = c->d_tie_count.p + (c->tie_seq & 1u); of.tie_next = c->d_tie_count.p + ((c->tie_seq + 1) & 1u);
+        of.tie_total = c->d_tie_count.p + 2; ++c->tie_seq;
+        of.tie_list = c->d_tie_list.p; of.tie_cap = c->n_rows_total;
     }
     L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work, maxK,
                                      c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, of, ix16, c->stream));
@@ -728,7 +731,7 @@ int l3d_expand_slot_indices(l3d_ctx* c, uint32_t first, uint32_t count) {
         max_row_slots = std::max<uint64_t>(max_row_slots, (uint64_t)c->pairs[p].Ms * c->pairs[p].K);
     for (uint32_t p = first; p < first + count; ++p)
         if (c->pair_done[p]) return fail(L3D_ERR_STATE, "l3d_expand_slot_indices: pair already present on this rank");
-    const OrientFuse of{c->d_cnt_pack.p, c->d_inv_pos.p, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u};
+    const OrientFuse of{c->d_cnt_pack.p, c->d_inv_pos.p, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
     L3D_HIP_CHECK(launch_expand_slot_idx(c->d_views.p, c->d_pairs.p, first, count, max_row_slots, c->d_slot_idx.p,
                                          c->d_slots.p, of, c->stream));
     for (uint32_t p = first; p < first + count; ++p) c->pair_done[p] = c->pair_counted[p] = 1;

@@ -175,6 +175,7 @@ struct l3d_ctx {
     DevBuf<uint32_t> d_row_counts;
     // rows with equal overlaps (k_match_tied_rows): counter, (pair, row) list, heap scratch of the replay kernel
     DevBuf<uint32_t> d_tie_count;
+    uint32_t tie_seq = 0;                           // match launches so far: which of the two queue counters is current
     DevBuf<uint2> d_tie_list;
     DevBuf<uint64_t> d_tie_heap;
     // phase B (global over all views; G = sum of M)

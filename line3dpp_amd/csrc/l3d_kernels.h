@@ -55,9 +55,11 @@ struct OrientFuse {
     OrientThr thr;
     // rows in which the match kernel saw equal overlaps (the reference's heap order decides there): (pair, source row),
     // replayed by k_match_tied_rows
-    uint32_t* tie_count;
+    uint32_t* tie_count;            // rows queued by this match launch
     uint2* tie_list;
     uint32_t tie_cap;
+    uint32_t* tie_next;             // the counter the next match launch will use (zeroed by k_match_tied_rows)
+    uint32_t* tie_total;            // rows replayed so far (diagnostics)
 };
 
 // ---- k_match.hip ----
