@@ -44,6 +44,9 @@ constexpr float kKappa0 = 2.0e-4f;
 // or a lambda capture loses it and every access becomes a flat_load/flat_store (plus, for volatile, sc0 sc1
 // and an immediate s_waitcnt) instead of ds_read/ds_write.
 #define L3D_LDS __attribute__((address_space(3)))
+// HIP's __ballot(p) is icmp(int(p) != 0): the flag is first turned into 0/1 in a VGPR and compared again (two VALU
+// instructions per ballot); the builtin takes the comparison's lane mask as it is
+#define L3D_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 // diagnostics builds only (-DL3D_STATS: candidate counters, slow; -DL3D_CYCLES: per-work-item timeline)
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
 __device__ unsigned long long g_stats[8];   // 0 pre-filter tests, 1 candidates, 2 passed overlap, 3 accepted, 4 drains
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
         // culling a row therefore sees its candidates in ascending target order, which MODE 2 relies on)
         // With several waves per row group the row's table is a critical section: compare-and-swap lock (a wave's
         // own contenders are serialised by the LDS atomic unit just the same), released after the update.
-        while (__ballot(pending)) {
+        while (L3D_BALLOT(pending)) {
             bool win;
             if (WPG > 1) {
                 win = false;
@@ -344,6 +347,8 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     // the compaction prefix is v_mbcnt (population count of the ballot below this lane).
     const v4f* __restrict__ tf = cull ? (const v4f*)(cp.tgt_sf + pc->t_off) : (const v4f*)vt.segf;
     const uint32_t ent_hi = tid << 23;
+    const bool lane_on = BRUTE ? active : live;           // lanes that can produce candidates
+    const uint64_t lanes_on = L3D_BALLOT(lane_on);
     auto prefix = [&](uint64_t m) -> uint32_t {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     };
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
         const float mid = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(blo), n_rows / 2));
         for (uint32_t c0 = 0; c0 < nch; c0 += 64) {
             const uint32_t c = c0 + lane;
-            cc += (uint32_t)__popcll(__ballot(c < nch && cband[c].x < mid));
+            cc += (uint32_t)__popcll(L3D_BALLOT(c < nch && cband[c].x < mid));
         }
     }
     const uint32_t ngrp = (nch + 31) / 32, gc = cc / 32;
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
                 const float2 cb = cband[c];
                 vis = !(cb.y < wlo || cb.x > whi);
             }
-            wm = (uint32_t)__ballot(vis);
+            wm = (uint32_t)L3D_BALLOT(vis);
             if (gi == 0) { const uint32_t below = (1u << (cc & 31u)) - 1u; wm &= pass == 0 ? ~below : below; }
         } else {
             wm = (nch - g0 >= 32) ? 0xFFFFFFFFu : ((1u << (nch - g0)) - 1u);
@@ -399,32 +404,24 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
                 const float2 b = tband[ti];
                 in = !(b.y < wlo || b.x > whi);
             }
-            uint64_t m = __ballot(in);
+            uint64_t m = L3D_BALLOT(in);
             while (m) {
+                // two targets per step: after their pushes the ring holds at most 63 + 2*64 candidates (kRing = 256, which
+                // is what lets a seventh wave per SIMD fit the LDS); the candidate flags go from the comparison straight
+                // into the execution mask of their push
                 const uint32_t j0 = __builtin_ctzll(m); m &= m - 1;
                 const bool v1 = m != 0; const uint32_t j1 = v1 ? __builtin_ctzll(m) : j0; m &= m - 1;
-                const bool v2 = m != 0; const uint32_t j2 = v2 ? __builtin_ctzll(m) : j0; m &= m - 1;
-                const bool v3 = m != 0; const uint32_t j3 = v3 ? __builtin_ctzll(m) : j0; m &= m - 1;
-                const v4f q0 = tfc[tb + j0], q1 = tfc[tb + j1], q2 = tfc[tb + j2], q3 = tfc[tb + j3];
-                const bool c0b = BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL));
-                const bool c1b = v1 & (BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL)));
-                const bool c2b = v2 & (BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q2, thrL)));
-                const bool c3b = v3 & (BRUTE ? active : (live & prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q3, thrL)));
-                const uint64_t m0 = __ballot(c0b), m1 = __ballot(c1b), m2 = __ballot(c2b), m3 = __ballot(c3b);
-                if (lane == 0) L3D_STAT(0, 64 * (1 + v1 + v2 + v3));
-                if (m0 | m1 | m2 | m3) {
-                    // two pushes, then drain: the ring never holds more than 63 + 2*64 candidates (kRing = 256,
-                    // which is what lets a seventh wave per SIMD fit the LDS).  One loop body for both halves keeps
-                    // a single copy of drain() in the instruction stream.
-#pragma nounroll
-                    for (uint32_t h = 0; h < 2; ++h) {
-                        const uint64_t ma = h ? m2 : m0, mb = h ? m3 : m1;
-                        const bool ca = h ? c2b : c0b, cb = h ? c3b : c1b;
-                        const uint32_t ja = h ? j2 : j0, jb = h ? j3 : j1;
-                        if (ma) { if (ca) ring[(tail + prefix(ma)) & (kRing - 1)] = ent_hi | (tb + ja); tail += __popcll(ma); }
-                        if (mb) { if (cb) ring[(tail + prefix(mb)) & (kRing - 1)] = ent_hi | (tb + jb); tail += __popcll(mb); }
-                        while (tail - head >= 64) drain();
-                    }
+                const v4f q0 = tfc[tb + j0], q1 = tfc[tb + j1];
+                // (the lane masks are built from the comparison itself and the uniform masks by scalar ANDs: a ballot of
+                // `live & test` would first turn the flag into 0/1 in a VGPR)
+                const bool c0b = BRUTE || prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL);
+                const bool c1b = BRUTE || prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL);
+                const uint64_t m0 = L3D_BALLOT(c0b) & lanes_on, m1 = L3D_BALLOT(c1b) & lanes_on & (v1 ? ~0ull : 0ull);
+                if (lane == 0) L3D_STAT(0, 64 * (1 + v1));
+                if (m0 | m1) {
+                    if (m0) { if (c0b & lane_on) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | (tb + j0); tail += __popcll(m0); }
+                    if (m1) { if (c1b & lane_on) ring[(tail + prefix(m1)) & (kRing - 1)] = ent_hi | (tb + j1); tail += __popcll(m1); }
+                    while (tail - head >= 64) drain();
                 }
             }
         }
@@ -526,7 +523,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
             of.inv_pos[at] = ipos;
         }
         // fresh alive hypotheses of the row: its items are neighbouring lanes, one counter update per (row, pass)
-        const uint64_t m = __ballot((o.flags & kSlotAlive) != 0);
+        const uint64_t m = L3D_BALLOT((o.flags & kSlotAlive) != 0);
         const uint32_t r0 = r * K;
         const uint32_t lo = (r0 > base ? r0 : base) - base;
         const uint32_t he = r0 + K < base + 64 ? r0 + K : base + 64;
