@@ -46,7 +46,7 @@ __device__ __forceinline__ uint32_t group_scan(uint32_t v, uint32_t& total, uint
 template <int WPL>
 __device__ __forceinline__ uint32_t group_count(bool f, uint32_t& total, uint32_t* red) {
     if (WPL == 1) {
-        const uint64_t m = __ballot(f);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(f);
         total = (uint32_t)__popcll(m);
         return (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
     }
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views,
             if (in_lds) { s_ij[wave][x] = r.ij; s_sim[wave][x] = sim; }
             else if (ok) cand[x].sim = sim;
         }
-        n_acc += (uint32_t)__popcll(__ballot(ok));
+        n_acc += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ok));
     }
     if (n_acc == 0) return;
     if (in_lds) {
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views,
                 if (sim_of(y) >= 0.0f) { first = false; break; }
             }
         }
-        n_h += (uint32_t)__popcll(__ballot(first));
+        n_h += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(first));
     }
     const uint32_t opool = lp.pool0 + (blockIdx.x >> 2) % lp.npools; // spread the reservations independently of the input pool
     uint32_t eb = 0, hb = 0, sb = 0;
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views,
             acc = sim >= 0.0f;
             if (acc) { in_run(x, rank, earlier, mine); first = earlier == 0; }
         }
-        const uint64_t ma = __ballot(acc), mf = __ballot(first);
+        const uint64_t ma = __builtin_amdgcn_ballot_w64(acc), mf = __builtin_amdgcn_ballot_w64(first);
         if (acc) {
             const CandRec r = cand[x];
             const uint32_t run0 = acc_before + (uint32_t)__popcll(ma & lt_mask) - earlier;
@@ -750,7 +750,7 @@ __global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ pos
     }
     // the view's maximum: neighbouring headers mostly belong to one view -- one atomic per (wave, view), and none
     // when the view's maximum already exceeds the wave's
-    uint64_t todo = __ballot(score3D > 0.0f);
+    uint64_t todo = __builtin_amdgcn_ballot_w64(score3D > 0.0f);
     while (todo) {
         const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
         const uint32_t lv = __builtin_amdgcn_readlane(view, leader);
@@ -762,7 +762,7 @@ __global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ pos
             uint32_t* p = &max_score_bits[lv * kMaxReplicas + (pool & (kMaxReplicas - 1))];   // replicas: less contention
             if (__float_as_uint(mx) > *(volatile uint32_t*)p) atomicMax(p, __float_as_uint(mx));
         }
-        todo &= ~__ballot(mine);
+        todo &= ~__builtin_amdgcn_ballot_w64(mine);
     }
 }
 

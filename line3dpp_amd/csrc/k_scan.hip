@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(const T* __restrict__ in, u
                         do s = __hip_atomic_load(&state[(size_t)t * LANES + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         while ((s >> 32) == 0);
                     }
-                    const uint64_t incl = __ballot((s >> 32) == 2);
+                    const uint64_t incl = __builtin_amdgcn_ballot_w64((s >> 32) == 2);
                     if (incl) {
                         const uint32_t first = (uint32_t)__builtin_ctzll(incl);
                         acc += wave_sum(lane <= first ? (uint32_t)s : 0u);

@@ -396,16 +396,38 @@ static int match_begin_body(l3d_ctx* c) {
         if (!c->fixed3Dregularizer) v->k = spatial_reg(*v, c->sigma_p);      // computeSpatialRegularizer
         else v->k = c->sigma_p / c->med_scene_depth;                          // update_k, view.h:124-127
         v->median_depth = 0.0f;
-        v->out_pairs.clear(); v->in_pairs.clear();
     }
     // fixed neighbours, line3D.cc:467-479 (sets persist across calls like visual_neighbors_)
     for (auto* v : c->order)
         if (v->visual_nbrs.empty())
             for (uint32_t n : v->fixed_nbrs)
                 if (c->views.count(n)) v->visual_nbrs.insert(n);
+    // The pair list, the fundamental matrices and the culling set-up are a function of the (translated) views, their
+    // neighbour sets and kNN alone: when those are byte for byte what the previous call saw, the lists it built are
+    // kept (C1: 0.1 ms of host work before the first kernel of the call can be enqueued).
+    std::vector<unsigned char> sig;
+    {
+        auto put = [&](const void* q, size_t n) { const unsigned char* b = (const unsigned char*)q; sig.insert(sig.end(), b, b + n); };
+        const int32_t head[3] = {c->kNN, c->use_cull ? 1 : 0, c->brute ? 1 : 0};
+        put(head, sizeof(head));
+        for (auto* v : c->order) {
+            const uint32_t iv[5] = {v->cam, v->index, v->M, (uint32_t)v->width, (uint32_t)v->height};
+            put(iv, sizeof(iv));
+            put(v->K.m, 72); put(v->R.m, 72); put(&v->t, sizeof(v->t)); put(&v->C, sizeof(v->C));
+            const uint32_t nn = (uint32_t)v->visual_nbrs.size();
+            put(&nn, 4);
+            for (uint32_t n : v->visual_nbrs) put(&n, 4);
+        }
+    }
+    const bool same_scene = c->begin_sig_valid && sig == c->begin_sig;
+    uint64_t cs_off = c->cull_tot[0], ct_off = c->cull_tot[1], ck_off = c->cull_tot[2]; uint32_t cc_off = (uint32_t)c->cull_tot[3];
+    if (!same_scene) {
+    c->begin_sig_valid = false;
+    for (auto* v : c->order) { v->out_pairs.clear(); v->in_pairs.clear(); }
+    cs_off = ct_off = ck_off = 0; cc_off = 0;
     // directed pair list, line3D.cc:704-741
     c->pairs.clear(); c->pair_src_cam.clear(); c->pair_tgt_cam.clear(); c->cull.clear();
-    uint64_t cs_off = 0, ct_off = 0, ck_off = 0; uint32_t cc_off = 0, w_item = 0;
+    uint32_t w_item = 0;
     std::map<uint32_t, std::set<uint32_t>> matched;
     uint64_t slot_off = 0; uint32_t row_off = 0;
     c->pair_tests = 0;
@@ -459,6 +481,9 @@ static int match_begin_body(l3d_ctx* c) {
             return fail(L3D_ERR_LIMIT, "kNN = " + std::to_string(c->kNN) + " exceeds the per-row top-K table in LDS: the "
                         "largest bounded kNN of this build is " + std::to_string(lo) + " (kNN <= 0 keeps every match)");
         }
+    }
+    c->cull_tot[0] = cs_off; c->cull_tot[1] = ct_off; c->cull_tot[2] = ck_off; c->cull_tot[3] = cc_off;
+    c->begin_sig.swap(sig); c->begin_sig_valid = true;
     }
     c->pair_done.assign(c->pairs.size(), 0);
     c->pair_counted.assign(c->pairs.size(), 0);

@@ -166,6 +166,8 @@ struct l3d_ctx {
     PinnedBuf<PairCull> h_cull;
     PinnedBuf<WorkItem> h_work;
     UploadTag up_views, up_pairs, up_cull, up_seg_base, up_ltab;   // what the device tables hold (upload_table)
+    std::vector<unsigned char> begin_sig; bool begin_sig_valid = false;   // what the pair list was built from (l3d_match_begin)
+    uint64_t cull_tot[4] = {0, 0, 0, 0};            // pool sizes of the culling set-up of that list
     uint64_t pairs_version = 0;                     // bumped whenever the pair list on the device changes
     struct { uint64_t version = ~0ull; uint32_t first = 0, count = 0; const void* dev = nullptr; } work_key;   // d_work holds the items of these pairs
     PinnedBuf<uint32_t> h_vout, h_small, h_segb;
