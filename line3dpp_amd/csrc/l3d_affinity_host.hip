@@ -22,9 +22,11 @@ static int affinity_collinear(l3d_ctx* c) {
     L3D_HIP_CHECK(launch_collin(0, c->d_views.p, V, max_M, c->d_seg_base.p, c->collinearity_t, c->d_coll_cnt.p, nullptr,
                                 nullptr, st));
     L3D_HIP_CHECK(launch_scan(c->d_coll_cnt.p, G, c->d_coll_off.p, c->d_scan_ws.p, c->d_scal.p + 9, st));
+    // (read-backs of this function: the stream is drained first and the copy is a blocking one, so that no early return
+    // can leave a copy in flight towards a destination that has gone out of scope)
     uint32_t n_coll = 0;
-    L3D_HIP_CHECK(hipMemcpyAsync(&n_coll, c->d_scal.p + 9, 4, hipMemcpyDeviceToHost, st));
     L3D_HIP_CHECK(hipStreamSynchronize(st));
+    L3D_HIP_CHECK(hipMemcpy(&n_coll, c->d_scal.p + 9, 4, hipMemcpyDeviceToHost));
     L3D_HIP_CHECK(c->d_coll_idx.reserve(std::max<uint32_t>(n_coll, 1)));
     L3D_HIP_CHECK(launch_collin(1, c->d_views.p, V, max_M, c->d_seg_base.p, c->collinearity_t, nullptr, c->d_coll_off.p,
                                 c->d_coll_idx.p, st));
@@ -40,8 +42,8 @@ static int affinity_collinear(l3d_ctx* c) {
                                             c->d_coll_off.p, c->d_item_cnt.p, st));
         L3D_HIP_CHECK(launch_scan(c->d_item_cnt.p, n, c->d_item_off.p, c->d_scan_ws.p, c->d_scal.p + 10, st));
         uint32_t total = 0;
-        L3D_HIP_CHECK(hipMemcpyAsync(&total, c->d_scal.p + 10, 4, hipMemcpyDeviceToHost, st));
         L3D_HIP_CHECK(hipStreamSynchronize(st));
+        L3D_HIP_CHECK(hipMemcpy(&total, c->d_scal.p + 10, 4, hipMemcpyDeviceToHost));
         L3D_HIP_CHECK(c->d_item_seg.reserve(std::max<uint32_t>(total, 1)));
         L3D_HIP_CHECK(c->d_item_sim.reserve(std::max<uint32_t>(total, 1)));
         L3D_HIP_CHECK(launch_aff_coll_sim(mode, n, c->d_surv_sg.p, c->d_surv_tg.p, c->d_hyp_of_seg.p, c->d_hyps.p,
@@ -49,22 +51,22 @@ static int affinity_collinear(l3d_ctx* c) {
                                           c->d_coll_idx.p, c->d_item_off.p, c->d_vaff.p, (c->d_medians.p + 8), (const float*)(c->d_vaff.p + V),
                                           c->two_sigA_sqr, c->d_item_seg.p, c->d_item_sim.p, st));
         off[mode].resize((size_t)n + 1); seg[mode].resize(total); sim[mode].resize(total);
-        L3D_HIP_CHECK(hipMemcpyAsync(off[mode].data(), c->d_item_off.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, st));
-        if (total) {
-            L3D_HIP_CHECK(hipMemcpyAsync(seg[mode].data(), c->d_item_seg.p, (size_t)total * 4, hipMemcpyDeviceToHost, st));
-            L3D_HIP_CHECK(hipMemcpyAsync(sim[mode].data(), c->d_item_sim.p, (size_t)total * 4, hipMemcpyDeviceToHost, st));
-        }
         L3D_HIP_CHECK(hipStreamSynchronize(st));
+        L3D_HIP_CHECK(hipMemcpy(off[mode].data(), c->d_item_off.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+        if (total) {
+            L3D_HIP_CHECK(hipMemcpy(seg[mode].data(), c->d_item_seg.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+            L3D_HIP_CHECK(hipMemcpy(sim[mode].data(), c->d_item_sim.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+        }
     }
     // ---- primary stream + hypothesis -> segment map ----
     std::vector<uint32_t> surv_off((size_t)G + 1), surv_tg(N);
     std::vector<float> simv(N);
     std::vector<int32_t> hyp_of_seg(G);
-    L3D_HIP_CHECK(hipMemcpyAsync(surv_off.data(), c->d_surv_off.p, ((size_t)G + 1) * 4, hipMemcpyDeviceToHost, st));
-    L3D_HIP_CHECK(hipMemcpyAsync(surv_tg.data(), c->d_surv_tg.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
-    L3D_HIP_CHECK(hipMemcpyAsync(simv.data(), c->d_simv.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
-    L3D_HIP_CHECK(hipMemcpyAsync(hyp_of_seg.data(), c->d_hyp_of_seg.p, (size_t)G * 4, hipMemcpyDeviceToHost, st));
     L3D_HIP_CHECK(hipStreamSynchronize(st));
+    L3D_HIP_CHECK(hipMemcpy(surv_off.data(), c->d_surv_off.p, ((size_t)G + 1) * 4, hipMemcpyDeviceToHost));
+    if (N) L3D_HIP_CHECK(hipMemcpy(surv_tg.data(), c->d_surv_tg.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (N) L3D_HIP_CHECK(hipMemcpy(simv.data(), c->d_simv.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (G) L3D_HIP_CHECK(hipMemcpy(hyp_of_seg.data(), c->d_hyp_of_seg.p, (size_t)G * 4, hipMemcpyDeviceToHost));
     std::vector<uint32_t> seg_of_hyp(H, kEmpty);
     for (uint32_t g = 0; g < G; ++g) if (hyp_of_seg[g] >= 0) seg_of_hyp[(uint32_t)hyp_of_seg[g]] = g;
     // ---- the sequential pass: unused() (line3D.cc:1982-2002), getLocalID() (:2005-2023) ----

@@ -101,3 +101,41 @@ def test_failed_and_abandoned_calls_leave_a_clean_context():
     assert g.reconstruct3Dlines() and fresh.reconstruct3Dlines()
     for x, y in zip(g.get3Dlines(), fresh.get3Dlines()):
         assert x["collinear3Dsegments"].tobytes() == y["collinear3Dsegments"].tobytes()
+
+
+def test_repeated_calls_and_a_growing_scene_see_what_the_reference_sees():
+    """l3d_match_begin keeps its pair list / fundamental matrices / culling set-up, and the device keeps its tables,
+    while views, neighbour sets and kNN are those of the previous call (l3d_api.hip: begin_sig, l3d_host.h: upload_table).
+    Whatever changes in between must be seen: (1) the same call three times, (2) two more views added to the same context,
+    (3) another kNN, (4) the first parameters again -- after every step the context equals the reference's own code
+    driven through the same sequence (its visual_neighbors_ persist across calls exactly like this context's)."""
+    sc = make_scene(8, 220, n_neighbors=4, seed=31)
+    first, rest = sc.views[:6], sc.views[6:]
+    from line3dpp_amd.api import Line3D
+    g = Line3D()
+    o = O.Oracle(threads=1, reference=O.have_reference())
+
+    def add(views):
+        for v in views:
+            g.addImage(v.cam, (v.width, v.height), v.K, v.R, v.t, v.median_depth, v.neighbors, v.segs)
+            assert o.add_view(v.cam, v.segs, v.K, v.R, v.t, v.width, v.height, v.median_depth, v.neighbors) == 0
+
+    class _Part:                 # what full_result_diff walks: the views present so far
+        def __init__(self, views): self.views = views
+
+    def step(kw, views):
+        assert g.matchImages(**_g(kw)) and g.computeAffinity()
+        o.match_images(**kw); o.compute_affinity()
+        return _assert_same(g, o, _Part(views))
+
+    add(first)
+    r0 = step(dict(), first)
+    for _ in range(2):           # (1) nothing changed: the kept lists and tables are used
+        r = step(dict(), first)
+        assert r["surviving"] == r0["surviving"]
+    add(rest)                    # (2) the scene grows
+    r1 = step(dict(), sc.views)
+    assert r1["surviving"] > r0["surviving"]
+    step(dict(kNN=4), sc.views)  # (3) other slot layout
+    r2 = step(dict(), sc.views)  # (4) back
+    assert r2["surviving"] == r1["surviving"]
