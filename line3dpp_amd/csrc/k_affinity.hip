@@ -9,7 +9,7 @@
 // construction:
 //   k_aff_sim    similarity of every (hypothesis, surviving match) candidate
 //   k_aff_flag   a candidate emits unless the reverse candidate precedes it and also passes
-//   k_scan       edge index = exclusive scan of the emit flags (k_views.hip)
+//   k_scan       edge index = exclusive scan of the emit flags (k_scan.hip)
 //   k_aff_touch  first-touch position of every 2D segment = atomicMin over its edge endpoints
 //   k_aff_mark / k_scan / k_aff_emit   row id = rank of the first touch; write CLEdge pairs
 #include "l3d_dev.h"

@@ -10,8 +10,10 @@
 //                image-centre origin)
 //   k_cull_prepare orders rows and targets of the pair by epipolar band (tau); the wave visits only the
 //                64-target chunks, and inside them only the targets, whose band meets its rows' bands
-//                (exact culling); lane l loads record l of a visited chunk and the wave walks
-//                the chunk by broadcasting one 16-byte SegF record at a time through SGPRs (v_readlane)
+//                (exact culling), centre-out from where the targets' bands begin where its rows' do;
+//                a target record reaches all lanes as scalar operands (s_load through the constant address space:
+//                the record index is wave-uniform) -- no LDS tile, no barrier, no lane broadcast
+//   k_order_items (launches with few items per wave slot) starts the longest work items first
 //   fp32 pre-filter (conservative) -> __ballot -> popcount-prefix compaction of
 //                the few survivors into a per-wave LDS ring
 //   ring holds >= 64 candidates -> the wave drains 64 of them, one per lane, through the EXACT
@@ -19,7 +21,9 @@
 //   accepted candidates are inserted into the per-source-segment top-K in LDS (kNN selection by
 //                (overlap desc, tgt asc)); the K-th best overlap feeds back into the lane's
 //                pre-filter threshold, so the candidate rate decays as the row fills
-//   epilogue   = rank the <= K winners of each row and write the fixed-slot row (32 B slots)
+//   epilogue   = rank the <= K winners of each row and write the fixed-slot row (32 B slots), with the orientation
+//                filter of phase B and its hypothesis counters fused in; rows with equal overlaps are replayed in the
+//                reference's heap order by k_match_tied_rows
 //
 // Roofline: compulsory HBM traffic per directed pair is 16*(Ms+Mt) B read + 32*K*Ms B written;
 // per pair test that is < 0.2 B against ~30 fp32 VALU issues, so the kernel is VALU-issue bound
@@ -352,10 +356,11 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     auto prefix = [&](uint64_t m) -> uint32_t {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     };
-    // The target view is visited in chunks of 64 records: lane l holds record l of the chunk in VGPRs and the wave
-    // walks the chunk by broadcasting one record at a time through SGPRs (v_readlane) -- no LDS tile, no barrier.
-    // With culling, 32 chunk bands are tested at once (one per lane), then inside a visited chunk one target band
-    // per lane; only the targets whose band meets the wave's band are walked (ascending order).
+    // The target view is visited in chunks of 64 records.  With culling, 32 chunk bands are tested at once (one per
+    // lane), then inside a visited chunk one target band per lane; only the targets whose band meets the wave's band
+    // are walked (ascending order inside a chunk), their records fetched as scalar operands: the index is wave-uniform
+    // and the sorted copy of the records was written by k_cull_prepare before this launch, so a load through the
+    // constant address space is an s_load_dwordx4 -- no LDS tile, no barrier, no lane broadcast.
     typedef const __attribute__((address_space(4))) v4f* RecPtr;
     RecPtr tfc = (RecPtr)(unsigned long)tf;
     const uint32_t nch = (Mt + 63) / 64;

@@ -1,36 +1,17 @@
-// k_views.hip -- phase B: the per-view part of Line3D::computeMatches (line3D.cc:745-773).
+// k_views.hip -- what is left of the dense form of phase B (round 1), and small per-view passes.
 //
-// The reference processes views in ascending camID order, and view v's hypothesis lists contain the
-// inverse matches of earlier views u < v whose score was > 0 (storeInverseMatches, :1672-1699): a true
-// sequential chain.  Only ONE bit per inverse hypothesis depends on that chain ("did u score it > 0?");
-// everything else is geometry.  So the work is split in three:
+// matchImages runs phase B in its sparse form (k_lists.hip).  The dense kernels that remain here serve the seam entry
+// l3d_score_matches (the replacement of score_matches_GPU, cudawrapper.h:70-73: one view, the caller's match list, every
+// match present) and the paths that do not come out of the match epilogue:
 //
-//   pre-pass (all views at once, chain independent)
-//     (bounded kNN: checkMatchOrientation (:811-858) and the per-segment hypothesis counts come out of the match
-//                       kernel's epilogue / the exchange expansion, k_match.hip)
-//     k_orient_all      the same for slots that did not: keep-all mode, full records received from another rank --
-//                       orientation of every slot in its source frame and, for pairs that hand inverse matches to
-//                       their target, in the target frame; per-segment hypothesis counts
-//     scans + k_inv_fill  CSR offsets of every 2D segment's hypothesis list and a compact transposed index
-//                       (16-byte refs) of the slots that point at it as potential inverse matches
-//   lists (all views at once, chain independent)
-//     k_build_lists_all every 2D segment's list of potential hypotheses in canonical (= reference
-//                       single-thread) order -- inverse refs rank-sorted, fresh rows by ballot prefix, no
-//                       atomics -- with the spatial regularisers scoring needs (scoringCPU :1233-1248); the
-//                       unprojected 3D direction is recomputed where needed (32-byte entries)
-//     k_support<WPL>    one wave (long lists: one workgroup) per 2D segment: the similarityForScoring decisions
-//                       inside each hypothesis' depth window -> support bitsets
-//   chain (one launch per view, ascending camID)
-//     k_presence_view   one wave per 2D segment: which inverse hypotheses exist, which fresh ones are
-//                       supported -- pure bit operations on the support bitsets
-//   scores (per chunk of views, pipelined with the chain)
-//     k_score_all       O(#supporters) similarityForScoring (:1417-1446) with the
-//                       reference's per-camera replace/subtract accumulation (:1255-1274) over the hypotheses
-//                       the chain marked present
-//   post-pass (all views at once)
-//     k_filter_all / scans / k_filter_write_all / k_median_all
-//                       filterMatches (:1586-1669): 10 % of the view's best score, first strict maximum,
-//                       0.75 gate, surviving lists, best 3D hypothesis per segment, per-view median depth
+//   k_orient_all      checkMatchOrientation (line3D.cc:811-858) + packed hypothesis counters for slots that did not get
+//                     them from the match kernel: keep-all mode, full records received from another rank
+//   k_seam_entries / k_bits_len / k_support<WPL> / k_seam_all_present / k_score_all / k_seam_scores_out
+//                     one view's hypothesis lists with the spatial regularisers scoring needs (scoringCPU :1233-1248),
+//                     support bitsets from the similarityForScoring decisions inside each hypothesis' depth window,
+//                     scores with the reference's per-camera replace/subtract accumulation (:1255-1274)
+//   k_median_all      per-view median depth (View::update_median_depth, view.h:108-121): radix select
+//   k_fill_gseg_view  global segment id -> view
 #include "l3d_dev.h"
 #include "l3d_kernels.h"
 
@@ -112,31 +93,7 @@ __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* 
     }
 }
 
-__global__ void k_unpack_counts(uint32_t G, const unsigned long long* __restrict__ cnt_pack,
-                                uint32_t* __restrict__ cnt_all, uint32_t* __restrict__ cnt_inv) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G) return;
-    const unsigned long long c = cnt_pack[g];
-    cnt_all[g] = (uint32_t)c;
-    cnt_inv[g] = (uint32_t)(c >> 32);
-}
 
-// transposed index of the potential inverse hypotheses: which slots point at global segment g
-__global__ void k_inv_fill(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ seg_base,
-                           const Slot* __restrict__ slots, const uint32_t* __restrict__ inv_off,
-                           const uint32_t* __restrict__ inv_pos, InvRef* __restrict__ refs) {
-    const PairDesc& pd = pairs[blockIdx.y];
-    if (pd.tgt <= pd.src) return;
-    const uint64_t n = (uint64_t)pd.Ms * pd.K;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t ipos = inv_pos[pd.slot_off + i];
-    if (ipos == kEmpty) return;
-    const uint32_t g = seg_base[pd.tgt] + slots[pd.slot_off + i].tgt_seg;
-    InvRef r;
-    r.src_view = pd.src; r.src_row = (uint32_t)(i / pd.K); r.pair = blockIdx.y; r.j = (uint32_t)(i % pd.K);
-    refs[inv_off[g] + ipos] = r;
-}
 
 // scoringCPU line3D.cc:1233-1248: unprojection + spatial regularisers of one hypothesis
 __device__ __forceinline__ DEntry make_dentry(const ViewDev& v, const ViewDev& vt, const SegX& sx, float dp1,
@@ -166,214 +123,7 @@ __device__ __forceinline__ d3 entry_dir(const double* C, const SegX& sx, float d
     return unproject(C, sx.r1, sx.r2, dp1, dp2).dir;
 }
 
-// Batched list build, one wave per 2D segment of any view (global segment id g): writes the segment's
-// hypotheses in canonical (= reference single-thread) order into dents[off[g] ...]:
-//   phase 1 (integer work): inverse refs rank-sorted by (source view, source segment), then the fresh rows
-//           of the view's outgoing pairs (ascending target) compacted by ballot/popcount prefix; only the
-//           descriptor fields of each DEntry are written;
-//   phase 2 (fp64 work, full lanes): unprojection + regularisers of every hypothesis.
-constexpr uint32_t kKeyCap = 512;   // per-wave LDS copy of the inverse sort keys
-constexpr uint32_t kDescCap = 192;  // fast path: whole list staged in LDS (keys + 20-byte descriptors)
-__global__ __launch_bounds__(256) void k_build_lists_all(uint32_t G, const ViewDev* __restrict__ views,
-                                                         const PairDesc* __restrict__ pairs,
-                                                         const uint32_t* __restrict__ seg_base,
-                                                         const uint32_t* __restrict__ gseg_view,
-                                                         const uint32_t* __restrict__ vout_off,
-                                                         const uint32_t* __restrict__ vout_pairs,
-                                                         const uint32_t* __restrict__ off,
-                                                         const uint32_t* __restrict__ inv_off,
-                                                         const InvRef* __restrict__ refs,
-                                                         const Slot* __restrict__ slots, DEntry* __restrict__ dents,
-                                                         uint32_t* __restrict__ eref, uint32_t uniform_K) {
-    // per wave: kKeyCap sort keys (general path) or kDescCap keys + kDescCap 20-byte descriptors (fast path)
-    constexpr uint32_t kWaveWords = (kDescCap * 28 + 7) / 8 > kKeyCap ? (kDescCap * 28 + 7) / 8 : kKeyCap;
-    __shared__ uint64_t s_mem[4][kWaveWords];
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    uint64_t (&s_key)[4][kWaveWords] = s_mem;
-    const uint32_t g = blockIdx.x * 4 + wave;
-    if (g >= G) return;
-    const uint32_t b = off[g], L = off[g + 1] - b;
-    if (L == 0) return;
-    const uint32_t vi = gseg_view[g], seg = g - seg_base[vi];
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    const uint32_t ib = inv_off[g], n_inv = inv_off[g + 1] - ib;
-    // ---- fast path (bounded kNN, list fits LDS, at most 128 own slots): the two gather chains (inverse refs ->
-    // pair -> slot, outgoing pair -> slot) are issued back to back, the descriptors go through LDS instead of a
-    // global write + read-back, and every entry is written to global memory exactly once (coalesced) ----
-    if (uniform_K && L <= kDescCap) {
-        const uint32_t q0 = vout_off[vi], T = (vout_off[vi + 1] - q0) * uniform_K;
-        if (T <= 128) {
-            uint64_t* keys = s_mem[wave];
-            uint32_t* d_ref = (uint32_t*)(keys + kDescCap);
-            float* d_dp1 = (float*)(d_ref + kDescCap);
-            float* d_dp2 = d_dp1 + kDescCap;
-            uint32_t* d_tv = (uint32_t*)(d_dp2 + kDescCap);
-            uint32_t* d_pf = d_tv + kDescCap;                 // pair | inverse << 31
-            // own slots: loads first (up to two per lane)
-            Slot sA{}, sB{};
-            uint32_t piA = 0, tvA = 0, piB = 0, tvB = 0, refA = 0, refB = 0;
-            bool aA = false, aB = false;
-            if (lane < T) {
-                piA = vout_pairs[q0 + lane / uniform_K];
-                const PairDesc& pd = pairs[piA];
-                tvA = pd.tgt; refA = (uint32_t)(pd.slot_off + (uint64_t)seg * uniform_K + lane % uniform_K);
-                sA = slots[refA];
-                aA = sA.tgt_seg != kEmpty && (sA.flags & kSlotAlive);
-            }
-            if (64 + lane < T) {
-                piB = vout_pairs[q0 + (64 + lane) / uniform_K];
-                const PairDesc& pd = pairs[piB];
-                tvB = pd.tgt; refB = (uint32_t)(pd.slot_off + (uint64_t)seg * uniform_K + (64 + lane) % uniform_K);
-                sB = slots[refB];
-                aB = sB.tgt_seg != kEmpty && (sB.flags & kSlotAlive);
-            }
-            // inverse refs: keys to LDS, rank = canonical position
-            for (uint32_t m0 = 0; m0 < n_inv; m0 += 64)
-                if (m0 + lane < n_inv) {
-                    const InvRef r = refs[ib + m0 + lane];
-                    keys[m0 + lane] = ((uint64_t)r.src_view << 32) | r.src_row;
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            for (uint32_t m0 = 0; m0 < n_inv; m0 += 64)
-                if (m0 + lane < n_inv) {
-                    const InvRef r = refs[ib + m0 + lane];
-                    const uint64_t key = ((uint64_t)r.src_view << 32) | r.src_row;
-                    uint32_t rank = 0;
-                    for (uint32_t j = 0; j < n_inv; ++j) rank += (keys[j] < key) ? 1u : 0u;
-                    const PairDesc& pd = pairs[r.pair];
-                    const uint32_t ref = (uint32_t)(pd.slot_off + (uint64_t)r.src_row * pd.K + r.j);
-                    const Slot s = slots[ref];
-                    d_ref[rank] = ref; d_dp1[rank] = s.dq1; d_dp2[rank] = s.dq2; d_tv[rank] = r.src_view;
-                    d_pf[rank] = r.pair | 0x80000000u;
-                }
-            // own slots: compaction by ballot prefix (ascending (target view, slot) order)
-            uint32_t pos = n_inv;
-            {
-                const uint64_t m = __ballot(aA);
-                if (aA) {
-                    const uint32_t k = pos + (uint32_t)__popcll(m & lt_mask);
-                    d_ref[k] = refA; d_dp1[k] = sA.dp1; d_dp2[k] = sA.dp2; d_tv[k] = tvA; d_pf[k] = piA;
-                }
-                pos += (uint32_t)__popcll(m);
-                const uint64_t m2 = __ballot(aB);
-                if (aB) {
-                    const uint32_t k = pos + (uint32_t)__popcll(m2 & lt_mask);
-                    d_ref[k] = refB; d_dp1[k] = sB.dp1; d_dp2[k] = sB.dp2; d_tv[k] = tvB; d_pf[k] = piB;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const ViewDev& v = views[vi];
-            const SegX sx = v.segx[seg];
-            for (uint32_t m0 = 0; m0 < L; m0 += 64) {
-                const uint32_t i = m0 + lane;
-                if (i < L) {
-                    const uint32_t pf = d_pf[i], tv = d_tv[i];
-                    dents[b + i] = make_dentry(v, views[tv], sx, d_dp1[i], d_dp2[i], d_ref[i], tv, pf & 0x7FFFFFFFu,
-                                               (pf >> 31) != 0);
-                    eref[b + i] = d_ref[i];
-                }
-            }
-            return;
-        }
-    }
-    // ---- phase 1a: inverse hypotheses ----
-    const bool keys_in_lds = n_inv <= kKeyCap;
-    if (keys_in_lds) {
-        for (uint32_t m0 = 0; m0 < n_inv; m0 += 64)
-            if (m0 + lane < n_inv) {
-                const InvRef r = refs[ib + m0 + lane];
-                s_key[wave][m0 + lane] = ((uint64_t)r.src_view << 32) | r.src_row;
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    for (uint32_t m0 = 0; m0 < n_inv; m0 += 64) {
-        if (m0 + lane < n_inv) {
-            const InvRef r = refs[ib + m0 + lane];
-            const uint64_t key = ((uint64_t)r.src_view << 32) | r.src_row;
-            uint32_t rank = 0;
-            if (keys_in_lds) {
-                for (uint32_t j = 0; j < n_inv; ++j) rank += (s_key[wave][j] < key) ? 1u : 0u;
-            } else {
-                for (uint32_t j = 0; j < n_inv; ++j) {
-                    const InvRef o = refs[ib + j];
-                    rank += ((((uint64_t)o.src_view << 32) | o.src_row) < key) ? 1u : 0u;
-                }
-            }
-            const PairDesc& pd = pairs[r.pair];
-            const uint64_t ref = pd.slot_off + (uint64_t)r.src_row * pd.K + r.j;
-            const Slot s = slots[ref];
-            DEntry& d = dents[b + rank];
-            d.ref = (uint32_t)ref; d.dp1 = s.dq1; d.dp2 = s.dq2; d.tgt_view = r.src_view; d.pair = r.pair; d.flags = kDInverse;
-        }
-    }
-    // ---- phase 1b: fresh hypotheses ----
-    uint32_t pos = b + n_inv;
-    if (uniform_K) {
-        // bounded kNN: every pair has K slots per row -> lane = (outgoing pair, slot) packs 64 slots per step
-        // (still ascending (target view, slot) order, so the ballot prefix keeps the canonical order)
-        const uint32_t q0 = vout_off[vi], T = (vout_off[vi + 1] - q0) * uniform_K;
-        for (uint32_t t0 = 0; t0 < T; t0 += 64) {
-            const uint32_t t = t0 + lane;
-            bool alive = false;
-            Slot s;
-            uint64_t ref = 0; uint32_t pi = 0, tv = 0;
-            if (t < T) {
-                pi = vout_pairs[q0 + t / uniform_K];
-                const PairDesc& pd = pairs[pi];
-                tv = pd.tgt;
-                ref = pd.slot_off + (uint64_t)seg * uniform_K + t % uniform_K;
-                s = slots[ref];
-                alive = s.tgt_seg != kEmpty && (s.flags & kSlotAlive);
-            }
-            const uint64_t m = __ballot(alive);
-            if (alive) {
-                DEntry& d = dents[pos + (uint32_t)__popcll(m & lt_mask)];
-                d.ref = (uint32_t)ref; d.dp1 = s.dp1; d.dp2 = s.dp2; d.tgt_view = tv; d.pair = pi; d.flags = 0;
-            }
-            pos += (uint32_t)__popcll(m);
-        }
-    } else
-    for (uint32_t q = vout_off[vi]; q < vout_off[vi + 1]; ++q) {
-        const uint32_t pi = vout_pairs[q];
-        const PairDesc& pd = pairs[pi];
-        const uint64_t row0 = pd.slot_off + (uint64_t)seg * pd.K;
-        for (uint32_t j0 = 0; j0 < pd.K; j0 += 64) {
-            bool alive = false;
-            Slot s;
-            if (j0 + lane < pd.K) {
-                s = slots[row0 + j0 + lane];
-                alive = s.tgt_seg != kEmpty && (s.flags & kSlotAlive);
-            }
-            const uint64_t m = __ballot(alive);
-            if (alive) {
-                DEntry& d = dents[pos + (uint32_t)__popcll(m & lt_mask)];
-                d.ref = (uint32_t)(row0 + j0 + lane); d.dp1 = s.dp1; d.dp2 = s.dp2; d.tgt_view = pd.tgt; d.pair = pi; d.flags = 0;
-            }
-            pos += (uint32_t)__popcll(m);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    // ---- phase 2: derived quantities, one hypothesis per lane ----
-    const ViewDev& v = views[vi];
-    const SegX sx = v.segx[seg];
-    for (uint32_t m0 = 0; m0 < L; m0 += 64) {
-        if (m0 + lane < L) {
-            DEntry& d = dents[b + m0 + lane];
-            d = make_dentry(v, views[d.tgt_view], sx, d.dp1, d.dp2, d.ref, d.tgt_view, d.pair, (d.flags & kDInverse) != 0);
-            eref[b + m0 + lane] = d.ref;   // slot index; the first n_inv entries of a list are the inverse ones
-        }
-    }
-}
-
-// ---- chain ------------------------------------------------------------------------------------------
+// ---- similarity of two hypotheses of one 2D segment ------------------------------------------------
 // similarityForScoring (line3D.cc:1417-1446) for hypotheses a (the scored one) and b of the same 2D
 // segment.  Decisions are taken on the float quantities the reference compares; acos/exp are
 // evaluated in double and rounded to float (glibc's expf/acos differ from that by < 1 float ulp).
@@ -621,58 +371,6 @@ void k_support(uint32_t G, const uint32_t* __restrict__ off, const uint32_t* __r
 //             supported (score3D > 0  <=>  some existing hypothesis of another camera has similarity > 0.5),
 //             which that view's launch recorded in positive[slot] (line3D.cc:1680)
 //   support:  fresh hypothesis i is positive iff S_i intersects the presence mask
-constexpr uint32_t kPCap = 64;   // presence-mask words kept in LDS per wave (lists up to 4096 hypotheses)
-__global__ __launch_bounds__(256) void k_presence_view(uint32_t g0, uint32_t M, const uint32_t* __restrict__ off,
-                                                       const uint32_t* __restrict__ boff,
-                                                       const uint32_t* __restrict__ inv_off,
-                                                       const uint32_t* __restrict__ eref,
-                                                       uint64_t* __restrict__ bits, uint8_t* __restrict__ positive) {
-    __shared__ uint64_t s_P[4][kPCap];
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t seg = blockIdx.x * 4 + wave;
-    if (seg >= M) return;
-    const uint32_t g = g0 + seg;
-    const uint32_t b = off[g], L = off[g + 1] - b;
-    if (L == 0) return;
-    const uint32_t W = (L + 63) / 64;
-    const uint32_t n_inv = inv_off[g + 1] - inv_off[g];   // the inverse hypotheses come first in canonical order
-    uint64_t* rows = bits + boff[g];
-    uint64_t* P = rows + (size_t)L * W;
-    if (W <= 2) {
-        // Short lists (the common case): every load that does not depend on the chain state -- the inverse refs, this
-        // lane's support rows, the slots it may mark -- is issued up front, so that the launch is two dependent memory
-        // round trips deep (header -> refs/rows -> positive[]) instead of five; the presence words stay in registers.
-        const uint32_t j1 = 64 + lane, i0 = n_inv + lane, i1 = i0 + 64;
-        const uint32_t e0 = lane < n_inv ? eref[b + lane] : 0u, e1 = j1 < n_inv ? eref[b + j1] : 0u;
-        uint64_t r00 = 0, r01 = 0, r10 = 0, r11 = 0;
-        uint32_t w0 = 0, w1 = 0;
-        if (i0 < L) { r00 = rows[(size_t)i0 * W]; if (W == 2) r01 = rows[(size_t)i0 * W + 1]; w0 = eref[b + i0]; }
-        if (i1 < L) { r10 = rows[(size_t)i1 * W]; if (W == 2) r11 = rows[(size_t)i1 * W + 1]; w1 = eref[b + i1]; }
-        const bool p0 = lane < L && (lane >= n_inv || positive[e0] != 0);
-        const bool p1 = j1 < L && (j1 >= n_inv || positive[e1] != 0);
-        const uint64_t P0 = __ballot(p0), P1 = __ballot(p1);
-        if (lane == 0) { P[0] = P0; if (W == 2) P[1] = P1; }
-        if (i0 < L && ((r00 & P0) | (r01 & P1))) positive[w0] = 1;
-        if (i1 < L && ((r10 & P0) | (r11 & P1))) positive[w1] = 1;
-        return;
-    }
-    const bool in_lds = W <= kPCap;
-    for (uint32_t w = 0; w < W; ++w) {
-        const uint32_t j = w * 64 + lane;
-        const bool present = j < L && (j >= n_inv || positive[eref[b + j]] != 0);
-        const uint64_t m = __ballot(present);
-        if (lane == 0) { P[w] = m; if (in_lds) s_P[wave][w] = m; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (uint32_t i = n_inv + lane; i < L; i += 64) {
-        uint64_t any = 0;
-        if (in_lds) for (uint32_t w = 0; w < W; ++w) any |= rows[(size_t)i * W + w] & s_P[wave][w];
-        else for (uint32_t w = 0; w < W; ++w) any |= rows[(size_t)i * W + w] & P[w];
-        if (any) positive[eref[b + i]] = 1;
-    }
-}
 
 constexpr uint32_t kScoreCap = 192;   // per-wave LDS staging of a list: 50 B per hypothesis
 // scores of all views (batched): for every existing hypothesis i walk the existing supporters (S_i & P) in
@@ -867,120 +565,8 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
     if (lane == 0 && vmax > 0.0f) atomicMax(&max_score_bits[vi], __float_as_uint(vmax));
 }
 
-// ---- post-pass --------------------------------------------------------------------------------------
-// filterMatches, line3D.cc:1602-1653: one wave per 2D segment (global segment id), lists in canonical order.
-__global__ __launch_bounds__(256) void k_filter_all(uint32_t G, const uint32_t* __restrict__ off,
-                                                    const uint32_t* __restrict__ gseg_view,
-                                                    DEntry* __restrict__ dents,
-                                                    const uint32_t* __restrict__ max_score_bits,
-                                                    uint32_t* __restrict__ surv_cnt, uint32_t* __restrict__ has_best,
-                                                    uint32_t* __restrict__ best_pos) {
-    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = lane_id();
-    if (g >= G) return;
-    const uint32_t b = off[g], L = off[g + 1] - b;
-    const float lim = kMinBestScorePerc * __uint_as_float(max_score_bits[gseg_view[g]]);
-    float best = 0.0f;
-    uint32_t bpos = kEmpty, kept = 0;
-    for (uint32_t m0 = 0; m0 < L; m0 += 64) {
-        const uint32_t i = b + m0 + lane;
-        bool keep = false;
-        float s = 0.0f;
-        if (m0 + lane < L) {
-            const DEntry& d = dents[i];
-            s = d.score3D;
-            keep = (d.flags & kDPresent) && s > 0.0f && s > lim;
-        }
-        kept += (uint32_t)__popcll(__ballot(keep));
-        const float sv = keep ? s : 0.0f;
-        float mx = sv;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-        if (mx > best) {   // first strict maximum: the lowest position holding the chunk maximum
-            const uint64_t who = __ballot(keep && sv == mx);
-            best = mx;
-            bpos = b + m0 + (uint32_t)__ffsll((long long)who) - 1u;
-        }
-    }
-    const bool ok = best > kMinBestScore3D;
-    if (ok)
-        for (uint32_t m0 = 0; m0 < L; m0 += 64) {
-            const uint32_t i = b + m0 + lane;
-            if (m0 + lane < L) {
-                DEntry& d = dents[i];
-                const float s = d.score3D;
-                const bool keep = (d.flags & kDPresent) && s > 0.0f && s > lim;
-                d.flags = keep ? (d.flags | kDKeep) : (d.flags & ~kDKeep);
-            }
-        }
-    if (lane == 0) {
-        surv_cnt[g] = ok ? kept : 0u;
-        has_best[g] = ok ? 1u : 0u;
-        best_pos[g] = ok ? bpos : kEmpty;
-    }
-}
 
-__device__ __forceinline__ void make_match(const ViewDev* views, uint32_t view, uint32_t seg, const DEntry& d,
-                                           const Slot& s, uint32_t row_of_slot, Match& m, uint32_t& tgt_seg) {
-    // a fresh hypothesis reads its slot as is; an inverse one swaps the roles (line3D.cc:1682-1692)
-    const bool inv = (d.flags & kDInverse) != 0;
-    tgt_seg = inv ? row_of_slot : s.tgt_seg;
-    m.src_cam = views[view].cam; m.src_seg = seg;
-    m.tgt_cam = views[d.tgt_view].cam; m.tgt_seg = tgt_seg;
-    m.overlap = s.overlap; m.score3D = d.score3D;
-    m.dp1 = d.dp1; m.dp2 = d.dp2;
-    m.dq1 = inv ? s.dp1 : s.dq1; m.dq2 = inv ? s.dp2 : s.dq2;
-}
 
-// write the surviving matches (reference Match layout) and the best hypothesis of every segment
-__global__ void k_filter_write_all(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
-                                   const uint32_t* __restrict__ seg_base, uint32_t G,
-                                   const uint32_t* __restrict__ gseg_view, const uint32_t* __restrict__ off,
-                                   const DEntry* __restrict__ dents, const Slot* __restrict__ slots,
-                                   const uint32_t* __restrict__ surv_off,
-                                   const uint32_t* __restrict__ hyp_off, const uint32_t* __restrict__ best_pos,
-                                   Match* __restrict__ surv, uint32_t* __restrict__ surv_tg,
-                                   uint32_t* __restrict__ surv_sg, int32_t* __restrict__ hyp_of_seg,
-                                   HypRec* __restrict__ hyps, float* __restrict__ depths) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G) return;
-    const uint32_t bp = best_pos[g];
-    if (bp == kEmpty) { hyp_of_seg[g] = -1; return; }
-    const uint32_t view = gseg_view[g], seg = g - seg_base[view];
-    const ViewDev& v = views[view];
-    uint32_t w = surv_off[g];
-    for (uint32_t i = off[g]; i < off[g + 1]; ++i) {
-        const DEntry& d = dents[i];
-        if (!(d.flags & kDKeep)) continue;
-        const Slot s = slots[d.ref];
-        const PairDesc& pd = pairs[d.pair];
-        const uint32_t row = (uint32_t)((d.ref - pd.slot_off) / pd.K);
-        Match m; uint32_t tseg;
-        make_match(views, view, seg, d, s, row, m, tseg);
-        surv_tg[w] = seg_base[d.tgt_view] + tseg;
-        surv_sg[w] = g;
-        surv[w++] = m;
-    }
-    const DEntry& d = dents[bp];
-    const Slot s = slots[d.ref];
-    const PairDesc& pd = pairs[d.pair];
-    const uint32_t row = (uint32_t)((d.ref - pd.slot_off) / pd.K);
-    const uint32_t h = hyp_off[g];
-    HypRec r;
-    const SegX& sx = v.segx[seg];
-    const Seg3 s3 = unproject(v.C, sx.r1, sx.r2, d.dp1, d.dp2);   // unprojectMatch(best,true), :1638
-    r.P1[0] = s3.P1.x; r.P1[1] = s3.P1.y; r.P1[2] = s3.P1.z;
-    r.P2[0] = s3.P2.x; r.P2[1] = s3.P2.y; r.P2[2] = s3.P2.z;
-    r.dir[0] = s3.dir.x; r.dir[1] = s3.dir.y; r.dir[2] = s3.dir.z;
-    r.length = s3.length;
-    r.valid = s3.length > 0.0f ? 1u : 0u;
-    uint32_t tseg;
-    make_match(views, view, seg, d, s, row, r.m, tseg);
-    r.view = view; r.pad = 0;
-    hyps[h] = r;
-    hyp_of_seg[g] = (int32_t)h;
-    depths[2 * h] = d.dp1;
-    depths[2 * h + 1] = d.dp2;
-}
 
 // median = sorted(depths)[n/2] by 4-pass radix select on the (positive) float bit patterns;
 // n == 0 -> L3D_EPS (line3D.cc:1658).  One workgroup per view.
@@ -1050,29 +636,6 @@ hipError_t launch_orient_pairs(const ViewDev* views, const PairDesc* pairs, uint
     if (!n_pairs || !max_slots) return hipSuccess;
     hipLaunchKernelGGL(k_orient_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, views,
                        pairs, seg_base, slots, cnt_pack, inv_pos, OrientThr{thr_lo, thr_hi});
-    return hipGetLastError();
-}
-hipError_t launch_unpack_counts(uint32_t G, const unsigned long long* cnt_pack, uint32_t* cnt_all, uint32_t* cnt_inv,
-                                hipStream_t st) {
-    if (!G) return hipSuccess;
-    hipLaunchKernelGGL(k_unpack_counts, dim3((G + 255) / 256), dim3(256), 0, st, G, cnt_pack, cnt_all, cnt_inv);
-    return hipGetLastError();
-}
-hipError_t launch_inv_fill(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
-                           const Slot* slots, const uint32_t* inv_off, const uint32_t* inv_pos, InvRef* refs,
-                           hipStream_t st) {
-    if (!n_pairs || !max_slots) return hipSuccess;
-    hipLaunchKernelGGL(k_inv_fill, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, pairs,
-                       seg_base, slots, inv_off, inv_pos, refs);
-    return hipGetLastError();
-}
-hipError_t launch_build_lists_all(uint32_t G, const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base,
-                                  const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
-                                  const uint32_t* off, const uint32_t* inv_off, const InvRef* refs, const Slot* slots,
-                                  DEntry* dents, uint32_t* eref, uint32_t uniform_K, hipStream_t st) {
-    if (!G) return hipSuccess;
-    hipLaunchKernelGGL(k_build_lists_all, dim3((G + 3) / 4), dim3(256), 0, st, G, views, pairs, seg_base, gseg_view,
-                       vout_off, vout_pairs, off, inv_off, refs, slots, dents, eref, uniform_K);
     return hipGetLastError();
 }
 hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, uint32_t* long_list, uint32_t* n_long,
@@ -1154,40 +717,12 @@ hipError_t launch_seam_scores_out(uint32_t n, const DEntry* dents, float* scores
     hipLaunchKernelGGL(k_seam_scores_out, dim3((n + 255) / 256), dim3(256), 0, st, n, dents, scores);
     return hipGetLastError();
 }
-hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff,
-                                const uint32_t* inv_off, const uint32_t* eref, uint64_t* bits, uint8_t* positive,
-                                hipStream_t st) {
-    if (!M) return hipSuccess;
-    hipLaunchKernelGGL(k_presence_view, dim3((M + 3) / 4), dim3(256), 0, st, g0, M, off, boff, inv_off, eref, bits,
-                       positive);
-    return hipGetLastError();
-}
 hipError_t launch_score_all(uint32_t g0, uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view,
                             DEntry* dents, const uint64_t* bits, Slot* slots, uint32_t* max_score_bits,
                             const ViewDev* views, const uint32_t* seg_base, SimConst sc, hipStream_t st) {
     if (G <= g0) return hipSuccess;
     hipLaunchKernelGGL(k_score_all, dim3((G - g0 + 3) / 4), dim3(256), 0, st, G, off, boff, gseg_view, dents, bits,
                        slots, max_score_bits, views, seg_base, sc, g0);
-    return hipGetLastError();
-}
-hipError_t launch_filter_all(uint32_t G, const uint32_t* off, const uint32_t* gseg_view, DEntry* dents,
-                             const uint32_t* max_score_bits, uint32_t* surv_cnt, uint32_t* has_best,
-                             uint32_t* best_pos, hipStream_t st) {
-    if (!G) return hipSuccess;
-    hipLaunchKernelGGL(k_filter_all, dim3((G + 3) / 4), dim3(256), 0, st, G, off, gseg_view, dents, max_score_bits,
-                       surv_cnt, has_best, best_pos);
-    return hipGetLastError();
-}
-hipError_t launch_filter_write_all(const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base, uint32_t G,
-                                   const uint32_t* gseg_view, const uint32_t* off, const DEntry* dents,
-                                   const Slot* slots, const uint32_t* surv_off,
-                                   const uint32_t* hyp_off, const uint32_t* best_pos, Match* surv, uint32_t* surv_tg,
-                                   uint32_t* surv_sg, int32_t* hyp_of_seg, HypRec* hyps, float* depths,
-                                   hipStream_t st) {
-    if (!G) return hipSuccess;
-    hipLaunchKernelGGL(k_filter_write_all, dim3((G + 127) / 128), dim3(128), 0, st, views, pairs, seg_base, G,
-                       gseg_view, off, dents, slots, surv_off, hyp_off, best_pos, surv, surv_tg, surv_sg,
-                       hyp_of_seg, hyps, depths);
     return hipGetLastError();
 }
 hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base,

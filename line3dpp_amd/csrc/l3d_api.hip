@@ -257,8 +257,8 @@ void l3d_destroy(l3d_ctx* c) {
         v.d_seg4.release(); v.d_segf.release();
     }
     c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release(); c->d_slot_idx.release();
-    c->h_views.release(); c->h_pairs.release(); c->h_cull.release(); c->h_work.release(); c->h_vout.release();
-    c->h_small.release(); c->h_segb.release(); c->h_cnt.release(); c->h_fin.release();
+    c->h_views.release(); c->h_pairs.release(); c->h_cull.release(); c->h_work.release();
+    c->h_segb.release(); c->h_cnt.release(); c->h_fin.release();
     c->d_off64.release(); c->d_cnt64.release(); c->d_off64s.release(); c->d_scan_ws.release();
     c->d_huge_u64.release(); c->d_inv_recs.release(); c->d_lzero.release(); c->d_list2.release(); c->d_list4.release(); c->d_listH.release();
     c->d_seg_of_g.release(); c->d_huge_u32.release(); c->d_huge_f32.release(); c->d_ledges.release(); c->d_lhyps.release();
@@ -266,15 +266,15 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
     c->d_chunk_band.release(); c->d_cull_keys.release(); c->d_tgt_sf.release(); c->d_tgt_band.release();
     c->d_row_counts.release();
-    c->d_seg_base.release(); c->d_gseg_view.release(); c->d_cnt.release(); c->d_off.release();
-    c->d_scal.release(); c->d_max_score.release(); c->d_surv_cnt.release();
-    c->d_has_best.release(); c->d_best_pos.release(); c->d_surv_off.release(); c->d_hyp_off.release();
-    c->d_surv_tg.release(); c->d_surv_sg.release(); c->d_refs.release(); c->d_bits.release(); c->d_eref.release(); c->d_bits_len.release(); c->d_boff.release(); c->d_cnt_inv.release(); c->d_long_list.release();
+    c->d_seg_base.release(); c->d_gseg_view.release();
+    c->d_scal.release();
+    c->d_surv_off.release(); c->d_hyp_off.release();
+    c->d_surv_tg.release(); c->d_surv_sg.release();
     c->d_cnt_pack.release(); c->d_inv_pos.release(); c->d_gsegx.release();
     c->d_tie_count.release(); c->d_tie_list.release(); c->d_tie_heap.release(); c->d_item_bucket.release(); c->d_item_order.release(); c->d_order_done.release();
     c->d_coll_cnt.release(); c->d_coll_off.release(); c->d_coll_idx.release(); c->d_item_cnt.release();
     c->d_item_off.release(); c->d_item_seg.release(); c->d_item_sim.release();
-    c->d_inv_off.release(); c->d_vout_pairs.release(); c->d_vout_off.release(); c->d_dents.release(); c->d_surv.release();
+    c->d_surv.release();
     c->d_hyp_of_seg.release(); c->d_depths.release(); c->d_medians.release(); c->d_hyps.release();
     c->d_vaff.release(); c->d_simv.release(); c->h_vaff.release(); c->d_ca.release(); c->d_cb.release();
     c->d_flag.release(); c->d_epos.release(); c->d_first_touch.release(); c->d_touch_flag.release();
@@ -899,7 +899,6 @@ static int lists_prepare(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_inv_recs.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(c->d_inv_pos.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(c->h_fin.reserve(fin_b1(V) + kListPools * 16 + 96));
-    L3D_HIP_CHECK(c->h_small.reserve(V + 1));
     L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
     g_trace.mark("finish: reserves done");
     {   // segment -> view table: a function of the view sizes alone, kept while they (and the array) are the same

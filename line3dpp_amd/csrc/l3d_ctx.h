@@ -24,7 +24,7 @@ struct l3d_ctx;
 
 namespace l3d {
 
-// ---- prototypes of the launchers in k_views.hip / k_affinity.hip -------------------------------
+// ---- prototypes of the launchers in k_views.hip / k_scan.hip / k_affinity.hip -------------------------------
 // k_scan.hip: single-launch exclusive scans; ws = scan_ws_words(n, bytes per element) zeroed 64-bit words
 size_t scan_ws_words(size_t n, uint32_t bytes_per_element);
 hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, unsigned long long* ws, uint32_t* total, hipStream_t);
@@ -44,15 +44,6 @@ hipError_t launch_fill_gseg_view(const uint32_t* seg_base, uint32_t V, uint32_t 
 hipError_t launch_orient_pairs(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
                                const uint32_t* seg_base, Slot* slots, unsigned long long* cnt_pack, uint32_t* inv_pos,
                                double thr_lo, double thr_hi, hipStream_t);
-hipError_t launch_unpack_counts(uint32_t G, const unsigned long long* cnt_pack, uint32_t* cnt_all, uint32_t* cnt_inv,
-                                hipStream_t);
-hipError_t launch_inv_fill(const PairDesc*, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
-                           const Slot* slots, const uint32_t* inv_off, const uint32_t* inv_pos, InvRef* refs,
-                           hipStream_t);
-hipError_t launch_build_lists_all(uint32_t G, const ViewDev*, const PairDesc*, const uint32_t* seg_base,
-                                  const uint32_t* gseg_view, const uint32_t* vout_off, const uint32_t* vout_pairs,
-                                  const uint32_t* off, const uint32_t* inv_off, const InvRef*, const Slot*, DEntry*,
-                                  uint32_t* eref, uint32_t uniform_K, hipStream_t);
 hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, uint32_t* long_list, uint32_t* n_long,
                            hipStream_t);
 hipError_t launch_support_long(uint32_t n_long, const uint32_t* long_list, const uint32_t* off, const uint32_t* boff,
@@ -60,20 +51,9 @@ hipError_t launch_support_long(uint32_t n_long, const uint32_t* long_list, const
                                hipStream_t);
 hipError_t launch_support_all(uint32_t g0, uint32_t G, const uint32_t* off, const uint32_t* boff, const DEntry*, uint64_t* bits,
                               const ViewDev*, const uint32_t* seg_base, const uint32_t* gseg_view, SimConst, hipStream_t);
-hipError_t launch_presence_view(uint32_t g0, uint32_t M, const uint32_t* off, const uint32_t* boff,
-                                const uint32_t* inv_off, const uint32_t* eref, uint64_t* bits, uint8_t* positive,
-                                hipStream_t);
 hipError_t launch_score_all(uint32_t g0, uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view, DEntry*,
                             const uint64_t* bits, Slot*, uint32_t* max_score_bits, const ViewDev*, const uint32_t* seg_base,
                             SimConst, hipStream_t);
-hipError_t launch_filter_all(uint32_t G, const uint32_t* off, const uint32_t* gseg_view, DEntry*,
-                             const uint32_t* max_score_bits, uint32_t* surv_cnt, uint32_t* has_best,
-                             uint32_t* best_pos, hipStream_t);
-hipError_t launch_filter_write_all(const ViewDev*, const PairDesc*, const uint32_t* seg_base, uint32_t G,
-                                   const uint32_t* gseg_view, const uint32_t* off, const DEntry*, const Slot*,
-                                   const uint32_t* surv_off, const uint32_t* hyp_off, const uint32_t* best_pos,
-                                   Match* surv, uint32_t* surv_tg, uint32_t* surv_sg, int32_t* hyp_of_seg, HypRec*,
-                                   float* depths, hipStream_t);
 hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base,
                              float* out, hipStream_t);
 hipError_t launch_aff_sim(uint32_t N, const uint32_t* surv_sg, const uint32_t* surv_tg, const int32_t* hyp_of_seg,
@@ -170,7 +150,7 @@ struct l3d_ctx {
     uint64_t cull_tot[4] = {0, 0, 0, 0};            // pool sizes of the culling set-up of that list
     uint64_t pairs_version = 0;                     // bumped whenever the pair list on the device changes
     struct { uint64_t version = ~0ull; uint32_t first = 0, count = 0; const void* dev = nullptr; } work_key;   // d_work holds the items of these pairs
-    PinnedBuf<uint32_t> h_vout, h_small, h_segb;
+    PinnedBuf<uint32_t> h_segb;
     const void* gseg_view_for = nullptr;            // d_gseg_view was filled for the seg_base the device holds
     bool timing_pending = false;                    // phase-A events recorded but not read yet
     uint32_t pending_launches = 0;
@@ -183,16 +163,10 @@ struct l3d_ctx {
     // phase B (global over all views; G = sum of M)
     uint32_t G = 0, n_ents = 0, n_surv = 0, n_hyps = 0;
     std::vector<uint32_t> seg_base;                 // [V+1]
-    DevBuf<uint32_t> d_seg_base, d_gseg_view, d_cnt, d_off, d_scal, d_max_score;
-    DevBuf<uint32_t> d_surv_cnt, d_has_best, d_best_pos, d_surv_off, d_hyp_off, d_surv_tg, d_surv_sg;
-    DevBuf<InvRef> d_refs;
-    DevBuf<uint64_t> d_bits;
-    DevBuf<uint32_t> d_eref;
-    DevBuf<uint32_t> d_bits_len, d_boff, d_long_list;
-    DevBuf<uint32_t> d_cnt_inv, d_inv_off, d_vout_pairs, d_vout_off, d_inv_pos;
+    DevBuf<uint32_t> d_seg_base, d_gseg_view, d_scal;
+    DevBuf<uint32_t> d_surv_off, d_hyp_off, d_surv_tg, d_surv_sg;
+    DevBuf<uint32_t> d_inv_pos;
     DevBuf<unsigned long long> d_cnt_pack;
-    std::vector<uint32_t> vout_off;
-    DevBuf<DEntry> d_dents;
     DevBuf<Match> d_surv;
     DevBuf<int32_t> d_hyp_of_seg;
     DevBuf<float> d_depths, d_medians;              // d_medians: 8 words of 64-bit totals, then [V] medians
