@@ -237,6 +237,12 @@ def main():
             "phase_ms": {k: round(v / args.steps, 4) for k, v in phase.items()},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }
+        if world > 1 and getattr(l3d, "dist_ms", None):
+            # rank 0's host wall time between the synchronisation points of the sharded call, per call (all calls incl.
+            # warm-up): this rank's pairs | index all-gather | expansion + this rank's share of the list pass | all-gather
+            # of its records | replicated remainder of phase B -- what the N-GPU time is made of
+            calls = max(l3d.dist_ms.get("calls", 1), 1)
+            out["phase_wall_ms"] = {k: round(v / calls, 4) for k, v in l3d.dist_ms.items() if k != "calls"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

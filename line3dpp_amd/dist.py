@@ -128,6 +128,20 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_l
         return l3d.matchImages(**params)   # one call: nothing waits for the GPU between the phases
     if shard_lists is None:
         shard_lists = os.environ.get("L3D_SHARD_LISTS", "1") != "0"
+    # host wall time between the synchronisation points of the call, summed over calls in l3d.dist_ms (bench.py
+    # prints it per step for N > 1: match = begin + this rank's pairs, exchange_slots = pack + collective, lists =
+    # expansion of the received pairs + this rank's share of the list pass, exchange_lists, finish)
+    import time
+    acc = getattr(l3d, "dist_ms", None)
+    if acc is None:
+        acc = l3d.dist_ms = dict(match=0.0, exchange_slots=0.0, lists=0.0, exchange_lists=0.0, finish=0.0, calls=0)
+    t_last = [time.perf_counter()]
+
+    def lap(key):
+        now = time.perf_counter()
+        acc[key] += 1e3 * (now - t_last[0])
+        t_last[0] = now
+    acc["calls"] += 1
     if not l3d.matchBegin(**params):
         return False                       # a failing matchBegin restores the context itself
 
@@ -141,6 +155,7 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_l
     first, count = ranges[rank]
     if count and not l3d.matchPairs(first, count):
         return give_up()
+    lap("match")
     n_pairs = len(pairs)
     if os.environ.get("L3D_EXCHANGE_FULL") is None:
         # compact exchange: 4 B per slot (the target index) travel; the rest of a slot is re-derived on arrival
@@ -153,6 +168,7 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_l
             buf = device_tensor(ptr, n_slots * 4, device)
             exchange_slots(buf, slot_byte_ranges(ranges, slot_off, n_slots, slot_bytes=4), group)
             _wait_for_exchange(buf, device)
+        lap("exchange_slots")
         ok = (first == 0 or l3d.expandSlotIndices(0, first)) and \
              (first + count == n_pairs or l3d.expandSlotIndices(first + count, n_pairs - first - count))
         if not ok:
@@ -164,6 +180,7 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_l
             buf = device_tensor(ptr, n_slots * 32, device)
             exchange_slots(buf, slot_byte_ranges(ranges, slot_off, n_slots), group)
             _wait_for_exchange(buf, device)
+        lap("exchange_slots")
         # every pair is now present on this rank
         l3d.L.l3d_slots_exchanged(l3d.h)
     if shard_lists and hasattr(l3d, "listsShard"):
@@ -174,12 +191,17 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_l
             slabs = l3d.listsShard(rank, world_size)
             if slabs is None:
                 return False               # a failing listsShard restores the context itself
+            lap("lists")
             gather_slabs(slabs, rank, world_size, device, group)
+            lap("exchange_lists")
             rc = l3d.L.l3d_match_finish(l3d.h)
             l3d.last_status = rc
+            lap("finish")
             if rc == 0:
                 return True
             if rc != -10:                  # L3D_ERR_RETRY
                 return l3d._check(rc, "matchFinish")
         return give_up()
-    return l3d.matchFinish()               # a failing matchFinish restores the context itself
+    ok = l3d.matchFinish()                 # a failing matchFinish restores the context itself
+    lap("finish")
+    return ok
