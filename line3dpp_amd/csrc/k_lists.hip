@@ -163,6 +163,64 @@ __device__ __forceinline__ float window_sq(float dp, float k, float kt, float cc
     return (r < 1e30f) ? r : __builtin_inff();     // NaN / huge: the whole list is the window
 }
 
+// Bitonic sort of the list's depth keys with the keys in REGISTERS (thread t owns the KPT consecutive elements
+// t*KPT ..): partner distance below KPT = register exchange, below 64 threads = lane exchange, and only the partners in
+// another wave of the group go through LDS with barriers -- for the usual list of 65..128 hypotheses handled by one wave
+// none at all instead of 28 LDS round trips, for 256 keys on two waves one barrier stage instead of 36.  The keys are
+// distinct (the canonical index is part of them).  Leaves the sorted keys in keys[0 .. 64*WPL*KPT).
+template <int WPL, int KPT>
+__device__ __forceinline__ void list_sort_regs(L3D_LDS uint64_t* keys, L3D_LDS const float* e_d1, uint32_t L, uint32_t t) {
+    constexpr uint32_t GS = 64 * WPL, N = GS * KPT;
+    uint64_t v[KPT];
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) {
+        const uint32_t x = t * KPT + r;
+        v[r] = x < L ? (((uint64_t)f2ord(e_d1[x]) << 32) | x) : ~0ull;
+    }
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j >= 64u * KPT; j >>= 1) {        // partner in another wave (WPL > 1 only)
+            group_barrier<WPL>();
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) keys[t * KPT + r] = v[r];
+            group_barrier<WPL>();
+            const uint32_t pt = t ^ (j / KPT);
+            const bool lower = (t & (j / KPT)) == 0;
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) {
+                const uint64_t o = keys[pt * KPT + r];
+                const bool up = ((t * KPT + r) & k) == 0;
+                v[r] = (lower == up) ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
+            }
+        }
+        for (uint32_t j = min(k >> 1, 32u * KPT); j >= (uint32_t)KPT; j >>= 1) {   // partner in this wave
+            const uint32_t d = j / KPT;
+            const bool lower = (t & d) == 0;
+#pragma unroll
+            for (int r = 0; r < KPT; ++r) {
+                const uint64_t o = __shfl_xor((unsigned long long)v[r], (int)d);
+                const bool up = ((t * KPT + r) & k) == 0;
+                v[r] = (lower == up) ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
+            }
+        }
+#pragma unroll
+        for (int jj = KPT / 2; jj > 0; jj >>= 1) {                   // partner in this thread
+            if ((uint32_t)jj < k) {
+#pragma unroll
+                for (int r = 0; r < KPT; ++r) {
+                    if ((r & jj) == 0) {
+                        const uint64_t a = v[r], b = v[r | jj];
+                        const bool up = ((t * KPT + r) & k) == 0;
+                        if ((a > b) == up) { v[r] = b; v[r | jj] = a; }
+                    }
+                }
+            }
+        }
+    }
+    group_barrier<WPL>();
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) keys[t * KPT + r] = v[r];
+}
+
 // BASE = hypotheses one wave stages (128 for scenes with short lists: 8 waves per SIMD; 256 for long lists, where the
 // multi-wave tiers would otherwise carry most of the work)
 template <int WPL, int BASE>
@@ -282,6 +340,10 @@ __device__ __forceinline__ int process_list(uint32_t vi, uint32_t seg, uint32_t 
                 key = keep_min ? (key < other ? key : other) : (key > other ? key : other);
             }
         keys[t] = key;
+    } else if (N == 2 * GS) {
+        list_sort_regs<WPL, 2>(keys, e_d1, L, t);
+    } else if (CAP >= 4 * GS && N == 4 * GS) {
+        list_sort_regs<WPL, (CAP >= 4 * GS ? 4 : 2)>(keys, e_d1, L, t);
     } else {
     for (uint32_t x = t; x < N; x += GS) keys[x] = x < L ? (((uint64_t)f2ord(e_d1[x]) << 32) | x) : ~0ull;
     for (uint32_t k = 2; k <= N; k <<= 1)
