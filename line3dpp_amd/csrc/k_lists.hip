@@ -163,6 +163,34 @@ __device__ __forceinline__ float window_sq(float dp, float k, float kt, float cc
     return (r < 1e30f) ? r : __builtin_inff();     // NaN / huge: the whole list is the window
 }
 
+// ---- compare-exchange steps of the sorting networks with SCALAR direction logic ---------------------------------------
+// In a bitonic network, which lanes keep the smaller key of a pair is a fixed pattern of the lane index per stage.
+// Written as `keep_min ? min : max` it costs two comparisons and four selects per 64-bit key and stage; here the pattern
+// is a 64-bit constant, the comparison result is taken as a lane mask (ballot), the two are combined on the scalar unit
+// and the key is selected by that mask: one VALU comparison + two v_cndmask per key and stage (the sort was ~45 % of
+// the list pass's VALU instructions, and the pass is VALU-bound: 1 030 instructions x 128 k lists = its 0.2 ms).
+// bit t of the result: (t & d) == 0 for a power of two d < 64; all lanes for d >= 64 of a one-wave index
+__device__ __forceinline__ uint64_t lanes_bit_clear(uint32_t d) {
+    return d == 1 ? 0x5555555555555555ull : d == 2 ? 0x3333333333333333ull : d == 4 ? 0x0F0F0F0F0F0F0F0Full :
+           d == 8 ? 0x00FF00FF00FF00FFull : d == 16 ? 0x0000FFFF0000FFFFull : d == 32 ? 0x00000000FFFFFFFFull : ~0ull;
+}
+// per lane: mask bit set -> a, else b
+__device__ __forceinline__ uint64_t select_lanes(uint64_t mask_in, uint64_t a, uint64_t b) {
+    // (the mask is wave-uniform by construction; readfirstlane makes the compiler keep it in SGPRs, which the "s"
+    // constraint alone does not enforce for a 64-bit operand)
+    const uint64_t mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(mask_in >> 32)) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)mask_in);   // (the builtin returns int)
+    uint32_t lo, hi;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"((uint32_t)b), "v"((uint32_t)a), "s"(mask));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"((uint32_t)(b >> 32)), "v"((uint32_t)(a >> 32)), "s"(mask));
+    return ((uint64_t)hi << 32) | lo;
+}
+// own key v, partner's key o (distinct, or both the padding value); keep_min: lanes that end up with the smaller one
+__device__ __forceinline__ uint64_t cmp_exchange(uint64_t v, uint64_t o, uint64_t keep_min) {
+    const uint64_t own_less = __builtin_amdgcn_ballot_w64(v < o);
+    return select_lanes(~(own_less ^ keep_min), v, o);
+}
+
 // Bitonic sort of the list's depth keys with the keys in REGISTERS (thread t owns the KPT consecutive elements
 // t*KPT ..): partner distance below KPT = register exchange, below 64 threads = lane exchange, and only the partners in
 // another wave of the group go through LDS with barriers -- for the usual list of 65..128 hypotheses handled by one wave
@@ -177,29 +205,33 @@ __device__ __forceinline__ void list_sort_regs(L3D_LDS uint64_t* keys, L3D_LDS c
         const uint32_t x = t * KPT + r;
         v[r] = x < L ? (((uint64_t)f2ord(e_d1[x]) << 32) | x) : ~0ull;
     }
+    const uint32_t wave_t = __builtin_amdgcn_readfirstlane(t) & ~63u;   // first thread index of this wave (uniform)
+    // lanes whose element t*KPT + r has bit k clear ("ascending" half of the k-merge)
+    auto up_mask = [&](uint32_t k, int r) -> uint64_t {
+        if (k < (uint32_t)KPT) return ((uint32_t)r & k) == 0 ? ~0ull : 0ull;
+        const uint32_t kk = k / KPT;
+        return kk < 64 ? lanes_bit_clear(kk) : ((wave_t & kk) == 0 ? ~0ull : 0ull);
+    };
+#pragma unroll
     for (uint32_t k = 2; k <= N; k <<= 1) {
+#pragma unroll
         for (uint32_t j = k >> 1; j >= 64u * KPT; j >>= 1) {        // partner in another wave (WPL > 1 only)
             group_barrier<WPL>();
 #pragma unroll
             for (int r = 0; r < KPT; ++r) keys[t * KPT + r] = v[r];
             group_barrier<WPL>();
             const uint32_t pt = t ^ (j / KPT);
-            const bool lower = (t & (j / KPT)) == 0;
+            const uint64_t lower = (wave_t & (j / KPT)) == 0 ? ~0ull : 0ull;
 #pragma unroll
-            for (int r = 0; r < KPT; ++r) {
-                const uint64_t o = keys[pt * KPT + r];
-                const bool up = ((t * KPT + r) & k) == 0;
-                v[r] = (lower == up) ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
-            }
+            for (int r = 0; r < KPT; ++r) v[r] = cmp_exchange(v[r], keys[pt * KPT + r], ~(lower ^ up_mask(k, r)));
         }
-        for (uint32_t j = min(k >> 1, 32u * KPT); j >= (uint32_t)KPT; j >>= 1) {   // partner in this wave
+#pragma unroll
+        for (uint32_t j = (k >> 1) < 32u * KPT ? (k >> 1) : 32u * KPT; j >= (uint32_t)KPT; j >>= 1) {   // partner in this wave
             const uint32_t d = j / KPT;
-            const bool lower = (t & d) == 0;
 #pragma unroll
             for (int r = 0; r < KPT; ++r) {
                 const uint64_t o = __shfl_xor((unsigned long long)v[r], (int)d);
-                const bool up = ((t * KPT + r) & k) == 0;
-                v[r] = (lower == up) ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
+                v[r] = cmp_exchange(v[r], o, ~(lanes_bit_clear(d) ^ up_mask(k, r)));
             }
         }
 #pragma unroll
@@ -209,8 +241,9 @@ __device__ __forceinline__ void list_sort_regs(L3D_LDS uint64_t* keys, L3D_LDS c
                 for (int r = 0; r < KPT; ++r) {
                     if ((r & jj) == 0) {
                         const uint64_t a = v[r], b = v[r | jj];
-                        const bool up = ((t * KPT + r) & k) == 0;
-                        if ((a > b) == up) { v[r] = b; v[r | jj] = a; }
+                        // swap where (a > b) == ascending
+                        const uint64_t sw = ~(__builtin_amdgcn_ballot_w64(a > b) ^ up_mask(k, r));
+                        v[r] = select_lanes(sw, b, a); v[r | jj] = select_lanes(sw, a, b);
                     }
                 }
             }
@@ -333,11 +366,13 @@ __device__ __forceinline__ int process_list(uint32_t vi, uint32_t seg, uint32_t 
     if (WPL == 1 && N <= 64) {
         // one key per lane: the bitonic network runs on lane exchanges, no LDS round trip per stage
         uint64_t key = t < L ? (((uint64_t)f2ord(e_d1[t]) << 32) | t) : ~0ull;
+#pragma unroll
         for (uint32_t k = 2; k <= 64; k <<= 1)
+#pragma unroll
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
                 const uint64_t other = __shfl_xor(key, (int)j);
-                const bool keep_min = ((t & j) == 0) == ((t & k) == 0);
-                key = keep_min ? (key < other ? key : other) : (key > other ? key : other);
+                // lanes that keep the smaller key: ((t & j) == 0) == ((t & k) == 0)
+                key = cmp_exchange(key, other, ~(lanes_bit_clear(j) ^ lanes_bit_clear(k)));
             }
         keys[t] = key;
     } else if (N == 2 * GS) {
