@@ -245,14 +245,17 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     const float2* __restrict__ cband = cull ? cp.chunk_band + pc->c_off : nullptr;
     const float2* __restrict__ tband = cull ? cp.tgt_band + pc->t_off : nullptr;
 
-    // worst entry of a full row under (overlap desc, tgt asc): pipelined (non-volatile) LDS reads
+    // worst entry of a full row: the smallest overlap (pipelined, non-volatile LDS reads).  Among EQUAL overlaps any entry
+    // will do: whenever equal overlaps decide what a row keeps -- inside the final table, or between the K-th best and an
+    // entry that lost to it or was evicted -- the row is flagged and replayed in the reference's heap order
+    // (k_match_tied_rows), so this kernel's own choice among them never reaches the result.  That keeps the target index
+    // out of the comparisons of the hot insertion path (half of its VALU instructions).
     auto rescan_worst = [&](uint32_t sl) {
         L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)sl * K;
-        L3D_LDS const idx_t* ix = (L3D_LDS const idx_t*)L.top_ix + (size_t)sl * K;
-        uint32_t wj = 0; float wo = ov[0]; uint32_t wx = ix[0];
+        uint32_t wj = 0; float wo = ov[0];
         for (uint32_t j = 1; j < K; ++j) {
-            const float o = ov[j]; const uint32_t x = ix[j];
-            if (better(wo, wx, o, x)) { wo = o; wx = x; wj = j; }
+            const float o = ov[j];
+            if (o < wo) { wo = o; wj = j; }
         }
         L.minov[sl] = wo;
         L.minpos[sl] = wj;
@@ -328,12 +331,12 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
                     } else {
                         const uint32_t wj = L.minpos[sl];
                         const float mo = L.minov[sl];
-                        if (better(res.overlap, tg, mo, ix[wj])) {
+                        if (res.overlap > mo) {
                             ov[wj] = res.overlap; ix[wj] = tg;
                             rescan_worst(sl);
                             if (L.minov[sl] == mo) L.tie[sl] = 1;   // the evicted entry ties with the new K-th best
                         } else if (res.overlap == mo) {
-                            L.tie[sl] = 1;                          // loses a tie at the K-th place
+                            L.tie[sl] = 1;                          // a tie at the K-th place (whichever index would win)
                         }
                     }
                 }
