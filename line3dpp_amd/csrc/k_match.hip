@@ -502,8 +502,10 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
             L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)r * K;
             L3D_LDS const idx_t* ix = (L3D_LDS const idx_t*)L.top_ix + (size_t)r * K;
             const float oj = ov[j]; const uint32_t xj = ix[j];
+            // (a row that gets here has no two equal overlaps -- the pass above flagged those --, so the order
+            // (overlap desc, target asc) is the order by overlap)
             uint32_t rank = 0;
-            for (uint32_t i = 0; i < c; ++i) rank += better(ov[i], ix[i], oj, xj) ? 1u : 0u;
+            for (uint32_t i = 0; i < c; ++i) rank += ov[i] > oj ? 1u : 0u;
             dst = rank;
             // Three short stages that each fetch only the invariants they use (depths: rays + plane; orientation:
             // rays + mid ray).  The pointers are laundered between the stages so that the compiler does not keep both
