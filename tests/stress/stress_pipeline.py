@@ -1,8 +1,8 @@
 """Randomised full-pipeline stress (run on the GPU box: python tests/stress/stress_pipeline.py [n]): matchImages + affinity
 of the HIP path against the CPU oracle on random ring geometries / parameters: surviving-match sets, best
 hypotheses and affinity edges must be identical, float values within 1e-4 (incl. metric regulariser, keep-all kNN,
-ragged views, asymmetric neighbour lists; args: n_scenes seed).  Round 1: 114 scenes (v7 build) + 45 scenes (v8: orientation fused into the match epilogue), 0 mismatches; round 2: 120 scenes mid-round + 200
-on the final kernels (sparse phase B, centre-out walk, longest-first order), 0 mismatches."""
+ragged views, asymmetric neighbour lists; args: n_scenes seed).  Round 1: 114 scenes (v7 build) + 45 scenes (v8: orientation fused into the match epilogue), 0 mismatches; round 2: 120 scenes mid-round, 200 on the late
+builds and 300 on the final one (sparse phase B, centre-out walk, longest-first order, overlap-only insertion), 0 mismatches."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
