@@ -1,7 +1,7 @@
 """Randomised stress (run on the GPU box: python tests/stress/stress_culling.py): phase A with epipolar-band culling + fp32
 pre-filter against the brute-force path (every pair through the exact test) on random ring geometries, image
 scalings, kNN and overlap thresholds (args: n_scenes seed).  Round 1: 180 scenes, 2615 directed pairs, 17.5 M matches,
-0 differences; round 2: 240 scenes on the late builds and 360 on the final one (5382 directed pairs, 34.6 M matches), 0 differences."""
+0 differences; round 2: 300 scenes on the late builds and 300 on the final one (4574 directed pairs, 29.6 M matches), 0 differences."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
