@@ -11,10 +11,18 @@ in HBM before the timed region (uploaded at addImage).  Workload at N=1: BASELIN
 N>1 (torchrun, one rank per GPU): the directed view pairs are sharded over the ranks, slot slices are
 all-gathered over RCCL, the per-view chain is replicated ("scaling": "strong": same scene at every N).
 
-Prints ONE JSON line with `roofline` (pair-matching kernel, HIP events on its launch stream) and
-`cpu_baseline` (the CPU oracle = port of the reference OpenMP path, timed on this box, rank 0, N=1).
+Prints ONE JSON line with
+  `roofline`      the pair-matching kernel, timed with HIP events on its launch stream; VALU-issue roof priced with the
+                  instruction mix of the kernel (PMC, keyed by build id) and the per-class issue cycles measured on this
+                  kind of box (profiles/*_valu_calibration.json); `useful_frac`; the HBM figure beside it
+  `cpu_baseline`  the reference's own OpenMP CPU path (oracle/_ref), timed on this box, rank 0, N=1
+  `parity`        the HIP result of the benchmarked scene against that very reference run -- or, with --parity-digest,
+                  against the stored record of a reference run of the FULL configuration (tests/full_digest.py)
+  `cold_ms` / `second_scene_ms`   the first matchImages + affinity of a fresh context (allocations, pool growth and
+                  extra chain rounds included) and of a fresh context for ANOTHER scene of the same size afterwards
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -27,21 +35,29 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def run_cpu_baseline(scene, args, pair_tests, kNN, l3d):
-    """The reference's own OpenMP CPU path (oracle/_ref; the restatement where _ref is absent) on this box's host
-    cores, and -- because that run IS the reference result for the benchmarked scene -- the parity check of the HIP
-    result against it.  The reference's structure (std::list / std::map / priority_queue per row) stops scaling long
-    before 256 threads, so the thread count is picked by a short scan on a sub-scene.  The sample is the full workload
-    while it stays below ~6e9 pair tests (C0, C1, C3: 5-25 s); the larger configurations are sampled by a slice of
-    consecutive views at the configured size and neighbour count.  Returns (cpu_baseline, parity)."""
+def reference_oracle():
+    """(constructor, kind) of the reference's own code; None when oracle/_ref is absent -- the caller reports that as a
+    FAILED parity check: there is no downgrade to the restatement"""
     from oracle import oracle as O
-    from tests import helpers as H
-    # the reference's own line3D.cc/view.cc (oracle/_ref) in its Release configuration (-O3 -DNDEBUG, CMakeLists.txt:3;
-    # tests/test_reference_pin.py: results byte-identical to the -O2 build the parity tests use), else the restatement
-    use_ref = "release" if O.have_release() else O.have_reference()
+    if not O.have_reference():
+        return None, None
+    kind = "release" if O.have_release() else True
+    return (lambda threads: O.Oracle(threads=threads, reference=kind)), kind
 
-    def Oracle(threads):
-        return O.Oracle(threads=threads, reference=use_ref)
+
+def run_cpu_baseline(scene, args, pair_tests, kNN, l3d):
+    """The reference's own OpenMP CPU path (oracle/_ref: line3D.cc / view.cc compiled in place, Release flags) on this
+    box's host cores, and -- because that run IS the reference result for the benchmarked scene -- the parity check of
+    the HIP result against it.  The reference's structure (std::list / std::map / priority_queue per row) stops scaling
+    long before 256 threads, so the thread count is picked by a short scan on a sub-scene.  The sample is the full
+    workload while it stays below ~6e9 pair tests (C0, C1, C3: 5-25 s) or when --full-parity asks for it (C2: minutes);
+    otherwise a slice of consecutive views at the configured size and neighbour count.  Returns (cpu_baseline, parity)."""
+    from tests import helpers as H
+    Oracle, use_ref = reference_oracle()
+    if Oracle is None:
+        why = "oracle/_ref/libl3d_ref.so is missing (built by oracle/Makefile where /root/reference exists): no reference, " \
+              "no parity claim"
+        return None, {"config": args.config, "checked": False, "ok": False, "error": why}
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     if args.cpu_threads:
         best_t, scan = args.cpu_threads, {}
@@ -52,31 +68,29 @@ def run_cpu_baseline(scene, args, pair_tests, kNN, l3d):
         for t in sorted({1, 8, 16, 32, 64, ncpu}):
             if t > ncpu:
                 continue
-            o = Oracle(threads=t); o.add_scene(sub)
+            o = Oracle(t); o.add_scene(sub)
             t1 = time.perf_counter(); o.match_images(kNN=kNN); o.compute_affinity()
             scan[t] = round(sub_tests / (time.perf_counter() - t1) / 1e6, 1)
             if scan[t] < 0.5 * max(scan.values()):
                 break                                    # past the knee: more threads only get slower
         best_t = max(scan, key=scan.get)
     sample, sample_tests, what = scene, pair_tests, f"full {args.config} workload once"
-    if pair_tests > 6e9:
+    if pair_tests > 6e9 and not args.full_parity:
         n = scene.n_views
         while n > 4 and H.ring_slice(scene, 0, n).pair_tests()[0] > 5e9:
             n -= 1
         sample = H.ring_slice(scene, 0, n)
         sample_tests = sample.pair_tests()[0]
         what = f"slice of the first {n} views of {args.config} (configured segments/view and neighbour count) once"
-    o = Oracle(threads=best_t); o.add_scene(sample)
+    o = Oracle(best_t); o.add_scene(sample)
     t1 = time.perf_counter()
     o.match_images(kNN=kNN); o.compute_affinity()
     cdt = time.perf_counter() - t1
     cpu = {"value": round(sample_tests / cdt / 1e6, 2), "unit": "M segment-pair scores/s", "cores": best_t,
-           "kind": "reference" if use_ref else "port", "host_cpus": ncpu, "thread_scan_M_per_s": scan,
+           "kind": "reference", "host_cpus": ncpu, "thread_scan_M_per_s": scan,
            "sample": f"{what} ({sample_tests} pair tests, {cdt:.2f} s) with the thread count that scored best on an "
-                     f"8-view sub-scene; " +
-                     ("the reference's own OpenMP CPU path (line3D.cc/view.cc compiled in place, oracle/_ref" +
-                      (", -O3 -DNDEBUG)" if use_ref == "release" else ", -O2)") if use_ref
-                      else "OpenMP oracle = restatement of the reference CPU path")}
+                     f"8-view sub-scene; the reference's own OpenMP CPU path (line3D.cc/view.cc compiled in place, oracle/_ref"
+                     + (", -O3 -DNDEBUG)" if use_ref == "release" else ", -O2)")}
     # ---- parity of the HIP result with that reference run (same scene, same parameters) ----
     if sample is scene:
         g = l3d                                          # the context of the timed steps holds the last step's result
@@ -85,7 +99,8 @@ def run_cpu_baseline(scene, args, pair_tests, kNN, l3d):
         g = Line3D(device=torch.cuda.current_device()); g.add_scene(sample)
         assert g.matchImages(kNN=kNN) and g.computeAffinity()
     d = H.full_result_diff(g, o, sample)
-    parity = {"config": args.config, "checked": True, "against": cpu["kind"], "scene": what, "ok": d["ok"],
+    parity = {"config": args.config, "checked": True, "against": "reference (live run of oracle/_ref)", "scene": what,
+              "ok": d["ok"],
               "surviving_matches": d["surviving"], "set_diff": d["set_diff"], "best_hypotheses": d["best"],
               "best_set_diff": d["best_set_diff"], "best_choice_diff": d.get("best_choice_diff"),
               "affinity_entries": d["affinity_entries"], "affinity_set_diff": d["affinity_set_diff"],
@@ -97,6 +112,90 @@ def run_cpu_baseline(scene, args, pair_tests, kNN, l3d):
     return cpu, parity
 
 
+def digest_parity(scene, args, l3d):
+    """The HIP result of the FULL benchmarked scene against the stored record of a run of the reference's own code on
+    it (tests/full_digest.py, written by tools/ref_digest.py): identical sets / order / phase-A fields through SHA-256
+    digests, float fields at REL_TOL when the float arrays are at hand."""
+    from tests import full_digest as FD
+    from tests import helpers as H
+    meta, floats = FD.load_reference(args.config)
+    if meta is None:
+        return {"config": args.config, "checked": False, "ok": False,
+                "error": f"tests/golden/full/{args.config}.json is missing (tools/ref_digest.py {args.config})"}
+    if meta["scene_sha256"] != FD.scene_hash(scene):
+        return {"config": args.config, "checked": False, "ok": False, "error": "stored reference record is of another scene"}
+    exact, fl = FD.result_record(l3d, scene, False)
+    r = FD.compare(exact, fl, meta["exact"], floats, H.REL_TOL)
+    return {"config": args.config, "checked": True,
+            "against": f"stored record of the reference's own code ({meta['reference_library']} md5 {meta['reference_library_md5']}, "
+                       f"{meta['seconds']} s on {meta['threads']} threads, tools/ref_digest.py)",
+            "scene": f"full {args.config} workload", "ok": r["ok"], "surviving_matches": r["surviving"],
+            "set_diff": 0 if not r["differing_views"] else None, "differing_views": r["differing_views"][:16],
+            "best_hypotheses": r["best"], "best_equal": r["best_equal"], "affinity_entries": r["affinity_entries"],
+            "affinity_pairs_equal": r["affinity_pairs_equal"], "floats_checked": r["floats_checked"],
+            "max_rel": r["max_rel"], "max_rel_by_field": r.get("max_rel_by_field"), "tolerance": H.REL_TOL}
+
+
+# ---- roofline of k_match_pairs --------------------------------------------------------------------------------------
+# class of the SQ_INSTS_VALU_* counters -> the calibrated stream that prices it (tools/valu_calib.hip)
+_CLASS_OPS = {"ADD_F32": ["add_f32"], "MUL_F32": ["mul_f32"], "FMA_F32": ["fma_f32"], "TRANS_F32": ["rcp_f32", "rsq_f32", "sqrt_f32"],
+              "ADD_F64": ["add_f64"], "MUL_F64": ["mul_f64"], "FMA_F64": ["fma_f64"], "TRANS_F64": ["rcp_f64", "rsq_f64"],
+              "CVT": ["cvt_f64_f32", "cvt_f32_f64"], "INT32": ["add_u32", "and_b32", "lshl_b32"], "INT64": ["lshl_b64"],
+              # everything the class counters do not cover (compares, selects, moves, min/max, lane ops): priced at the
+              # cheapest stream measured -- the choice that makes the roof highest, i.e. the fraction smallest
+              "other": ["mov_b32", "max_f32"]}
+
+
+def valu_roof(pmc, calib):
+    """mix-weighted VALU issue ceiling: (G wave64 instructions/s at 1024 SIMDs x 2.4 GHz, basis dict) or (None, why)"""
+    cls = pmc.get("valu_class_insts_per_launch")
+    if not cls or not calib:
+        return None, "needs the per-class instruction counters (tools/pmc_bench.sh) and profiles/*_valu_calibration.json"
+    ops = {o["op"]: o for o in calib["ops"]}
+    total = pmc["valu_insts_per_launch"]
+    counted = {k: v for k, v in cls.items() if k in _CLASS_OPS and k != "other"}
+    mix = dict(counted, other=max(total - sum(counted.values()), 0))
+    cyc = {}
+    for k in mix:
+        have = [ops[n]["cycles_per_unit_simd_best"] for n in _CLASS_OPS[k] if n in ops]
+        if not have:
+            return None, f"calibration lacks a stream for class {k}"
+        cyc[k] = min(have) if k == "other" else sum(have) / len(have)
+    mean_cycles = sum(mix[k] * cyc[k] for k in mix) / max(total, 1)
+    peak = 1024 * 2.4 / mean_cycles
+    return peak, {"simds": 1024, "clock_ghz": 2.4, "mean_issue_cycles_per_instruction": round(mean_cycles, 3),
+                  "cycles_per_class": {k: round(v, 3) for k, v in cyc.items()},
+                  "mix_fraction": {k: round(v / max(total, 1), 4) for k, v in mix.items()},
+                  "calibration": calib.get("_file"), "note": "issue cycles per wave64 instruction and SIMD measured with "
+                  "single-instruction streams (tools/valu_calib.hip); `other` priced at the cheapest stream"}
+
+
+def load_json_newest(pattern, pred=lambda d: True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if pred(d):
+            d["_file"] = os.path.relpath(path, ROOT)
+            return d
+    return None
+
+
+def cold_call(scene, kNN, device_index, step_fn_factory):
+    """first matchImages + affinity of a fresh context: (ms, timings dict, context)"""
+    from line3dpp_amd.api import Line3D
+    g = Line3D(device=device_index)
+    g.add_scene(scene)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step_fn_factory(g)()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0)
+    tm = g.timings()
+    return ms, {k: tm[k] for k in ("pool_retries", "chain_extra_rounds", "chain_sweeps")}, g
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,6 +204,11 @@ def main():
     ap.add_argument("--config", default="C1", help="BASELINE config: C0 | C1 | C2 | C3 | C4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores)")
+    ap.add_argument("--full-parity", action="store_true",
+                    help="run the reference on the FULL configuration (C2: ~2 min, C4: ~5 min of CPU) instead of a slice")
+    ap.add_argument("--parity-digest", action="store_true",
+                    help="parity of the full scene against the stored reference record (tests/golden/full) instead of a live run")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-call / second-scene measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,12 +225,10 @@ def main():
 
     from line3dpp_amd import dist as l3d_dist
     from line3dpp_amd.api import Line3D
-    from line3dpp_amd.scene import CONFIGS, make_config
+    from line3dpp_amd.scene import CONFIGS, make_config, make_scene
 
     scene = make_config(args.config)
     cfg = CONFIGS[args.config]
-    l3d = Line3D(device=local_rank)
-    l3d.add_scene(scene)            # segment arrays now resident in HBM
     pair_tests, pairs = scene.pair_tests()
     kNN = 10
 
@@ -135,10 +237,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    def step():
-        ok = l3d_dist.match_images_sharded(l3d, rank, world, device=device, kNN=kNN)
-        assert ok, "matchImages failed"
-        assert l3d.computeAffinity(), "affinity failed"
+    def stepper(ctx):
+        def step():
+            ok = l3d_dist.match_images_sharded(ctx, rank, world, device=device, kNN=kNN)
+            assert ok, "matchImages failed"
+            assert ctx.computeAffinity(), "affinity failed"
+        return step
+
+    # ---- cold call: the FIRST matchImages + affinity of a fresh context (a user of Line3D::matchImages pays this once per
+    # scene).  Only the code objects are warm: a tiny scene on a throw-away context loads the kernels first.
+    cold = None
+    if world == 1 and not args.no_cold:
+        tiny = Line3D(device=local_rank); tiny.add_scene(make_scene(4, 200, n_neighbors=2, seed=3))
+        assert tiny.matchImages() and tiny.computeAffinity()
+        tiny.close()
+        cold_ms, cold_tm, l3d = cold_call(scene, kNN, local_rank, stepper)
+        cold = {"cold_ms": round(cold_ms, 3), "cold_call": cold_tm}
+    else:
+        l3d = Line3D(device=local_rank)
+        l3d.add_scene(scene)            # segment arrays now resident in HBM
+    step = stepper(l3d)
 
     for _ in range(args.warmup):
         step()
@@ -181,29 +299,44 @@ def main():
     # workload is the same); otherwise the block says so and falls back to the HBM figure, which is always live.
     from line3dpp_amd import _lib
     build = _lib.load().l3d_build_info().decode()
-    pmc, pmc_note = None, "no PMC summary under profiles/ for this build"
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_match.json")), reverse=True):
-        try:
-            tr = json.load(open(path))
-        except Exception:
-            continue
-        if tr.get("build_info") == build and tr.get("config") == args.config and world == 1:
-            pmc, pmc_note = tr, os.path.relpath(path, ROOT) + " (rocprofv3 --pmc, same build id)"
-            break
-        pmc_note = f"{os.path.relpath(path, ROOT)} was measured on another build / workload ({tr.get('build_info')}, " \
-                   f"{tr.get('config')}): not quoted"
-    valu_peak = 256 * 4 * 2.4e9 / 4 / 1e9          # wave64 VALU instructions per second, all SIMDs (4 cycles each): G/s
+    pmc = load_json_newest("*_pmc_match.json", lambda d: d.get("build_info") == build and d.get("config") == args.config) \
+        if world == 1 else None
+    pmc_note = (pmc["_file"] + " (rocprofv3 --pmc, same build id)") if pmc else \
+        "no PMC summary under profiles/ for this build and workload (tools/pmc_bench.sh): VALU figures not quoted"
+    calib = load_json_newest("*_valu_calibration.json")
+    fit = load_json_newest("*_valu_fit.json", lambda d: d.get("build_info") == build)
     hbm = {"achieved": round(hbm_achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(hbm_achieved / 8000.0, 6),
-           "algorithmic_bytes": algo_bytes, "traffic": pmc["traffic_bytes_per_launch"] if pmc else None}
+           "algorithmic_bytes": algo_bytes, "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+           "traffic_over_algorithmic": round(pmc["traffic_bytes_per_launch"] / algo_bytes, 2) if pmc else None}
     common = {"kernel": f"k_match_pairs<0,false,true,{wpg}>", "kernel_ms": round(avg_ms, 4),
               "nominal_pair_tests_per_s": round(my_tests / (avg_ms * 1e-3), 1) if avg_ms > 0 else 0.0,
               "pmc_source": pmc_note, "build": build}
     if pmc:
         valu_achieved = pmc["valu_insts_per_launch"] / (avg_ms * 1e-3) / 1e9
+        peak, basis = valu_roof(pmc, calib)
+        if peak is None:
+            # uncalibrated fallback: the fastest rate the microarchitecture guide gives (2 cycles per wave64 fp32
+            # instruction on a SIMD-32) -- an upper bound of any mix's ceiling, i.e. the smallest defensible fraction
+            peak, basis = 1024 * 2.4 / 2.0, {"note": "UNCALIBRATED: " + basis + "; priced at 2 cycles per instruction "
+                                             "(MI355X_MICROARCH.md: wave64 v_fma_f32 on a SIMD-32), an upper bound of the ceiling"}
         cand = pmc.get("candidates") or {}
-        roofline = {"bound": "valu", "achieved": round(valu_achieved, 2), "peak": round(valu_peak, 1),
-                    "unit": "G wave64 VALU instr/s", "frac": round(valu_achieved / valu_peak, 4),
+        useful = None
+        if fit and cand.get("band_pairs") and cand.get("kept_slots"):
+            # useful work: a walk that visits, per ROW, only the targets whose band meets the row's own band, and exact
+            # tests + epilogue work for the slots that are kept -- priced with the fitted per-unit VALU costs
+            # (profiles/*_valu_fit.json) -- over the VALU instructions the launch executed
+            uv = (cand["band_pairs"] / 64.0) * fit["valu_per_target_visit"] + \
+                 (cand["kept_slots"] / 64.0) * (fit["valu_per_drain"] + fit["valu_per_epilogue_pass"])
+            useful = {"useful_frac": round(uv / pmc["valu_insts_per_launch"], 4),
+                      "useful_valu_insts": round(uv), "executed_valu_insts": pmc["valu_insts_per_launch"],
+                      "band_pairs": cand["band_pairs"], "prefilter_tests": cand.get("prefilter_tests"),
+                      "kept_slots": cand["kept_slots"], "exact_tests": cand.get("exact_tests"), "accepted": cand.get("accepted"),
+                      "exact_tests_over_accepted": round(cand["exact_tests"] / max(cand["accepted"], 1), 3) if cand.get("exact_tests") else None,
+                      "valu_per_target_visit": fit["valu_per_target_visit"], "valu_per_drain": fit["valu_per_drain"],
+                      "valu_per_epilogue_pass": fit["valu_per_epilogue_pass"], "fit": fit["_file"]}
+        roofline = {"bound": "valu", "achieved": round(valu_achieved, 2), "peak": round(peak, 1),
+                    "unit": "G wave64 VALU instr/s", "frac": round(valu_achieved / peak, 4), "peak_basis": basis,
+                    "useful_frac": useful["useful_frac"] if useful else None, "useful_work": useful,
                     "traffic": pmc["traffic_bytes_per_launch"],
                     "valu_busy_fraction_pmc": pmc["valu_busy_fraction"], "avg_waves_per_simd": pmc["avg_waves_per_simd"],
                     # the metric counts nominal Ms*Mt tests; most are culled before any arithmetic:
@@ -217,8 +350,23 @@ def main():
                             "this build (tools/pmc_bench.sh)", **common}
 
     cpu_baseline, parity = None, {"config": args.config, "checked": False}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline, parity = run_cpu_baseline(scene, args, pair_tests, kNN, l3d)
+    if rank == 0 and world == 1:
+        if args.parity_digest:
+            parity = digest_parity(scene, args, l3d)
+        if not args.no_cpu_baseline:
+            cpu_baseline, live = run_cpu_baseline(scene, args, pair_tests, kNN, l3d)
+            parity = parity if args.parity_digest else live
+            if args.parity_digest:
+                parity["live_sample"] = {k: live.get(k) for k in ("scene", "ok", "set_diff", "max_rel", "error")}
+
+    # ---- another scene of the same size on a fresh context, after the first context has gone (a process that serves
+    # one Line3D object per scene): what a second scene costs once the process is warm
+    if cold is not None:
+        l3d.close()
+        scene2 = make_config(args.config, seed=0x5EED0002) if args.config != "C0" else scene
+        ms2, tm2, g2 = cold_call(scene2, kNN, local_rank, stepper)
+        cold.update(second_scene_ms=round(ms2, 3), second_scene_call=tm2)
+        g2.close()
 
     if rank == 0:
         out = {
@@ -235,6 +383,8 @@ def main():
                        "pair_tests_per_step": pair_tests, "directed_pairs": len(pairs),
                        "parallelism": f"pair-sharded x{world}" if world > 1 else "single GPU"},
             "phase_ms": {k: round(v / args.steps, 4) for k, v in phase.items()},
+            "cold_ms": cold["cold_ms"] if cold else None, "second_scene_ms": cold.get("second_scene_ms") if cold else None,
+            "cold": cold,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }
         if world > 1 and getattr(l3d, "dist_ms", None):

@@ -226,6 +226,8 @@ typedef struct l3d_timings {
                             * (cumulative since l3d_create) */
     uint32_t chain_sweeps; /* phase B: sweeps of the chain fixed point that still changed something (last round) */
     uint32_t chain_extra_rounds; /* phase B: extra rounds of chain sweeps beyond the ones enqueued blindly (0 normally) */
+    uint32_t pool_retries; /* phase B: list passes of the last matchImages that outgrew their record pools and were repeated
+                            * with larger ones (0 once the pools have the scene's size; a first call may need one) */
 } l3d_timings;
 int l3d_get_timings(l3d_ctx*, l3d_timings*);
 

@@ -39,7 +39,7 @@ class Timings(C.Structure):
                 ("affinity_ms", C.c_float), ("match_kernel_launches", C.c_uint32), ("match_kernel_ms", C.c_float),
                 ("cull_prepare_ms", C.c_float), ("culled_pairs", C.c_uint32),
                 ("list_entries", C.c_uint32), ("support_words", C.c_uint32), ("tied_rows", C.c_uint32), ("chain_sweeps", C.c_uint32),
-                ("chain_extra_rounds", C.c_uint32)]
+                ("chain_extra_rounds", C.c_uint32), ("pool_retries", C.c_uint32)]
 
 
 EXPORTS = [

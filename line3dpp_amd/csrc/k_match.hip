@@ -53,7 +53,9 @@ constexpr float kKappa0 = 2.0e-4f;
 #define L3D_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 // diagnostics builds only (-DL3D_STATS: candidate counters, slow; -DL3D_CYCLES: per-work-item timeline)
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
-__device__ unsigned long long g_stats[8];   // 0 pre-filter tests, 1 candidates, 2 passed overlap, 3 accepted, 4 drains
+__device__ unsigned long long g_stats[8];   // 0 pre-filter tests, 1 candidates, 2 passed overlap, 3 accepted, 4 drains,
+                                            // 5 (row, target) pairs whose OWN bands intersect (what a per-row walk would
+                                            // test), 6 slots kept, 7 work items
 __device__ unsigned long long g_cycles[1 << 16][2];   // per work item: start, duration (wall_clock64 ticks)
 #endif
 #ifdef L3D_STATS
@@ -426,6 +428,17 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
                 const bool c1b = BRUTE || prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q1, thrL);
                 const uint64_t m0 = L3D_BALLOT(c0b) & lanes_on, m1 = L3D_BALLOT(c1b) & lanes_on & (v1 ? ~0ull : 0ull);
                 if (lane == 0) L3D_STAT(0, 64 * (1 + v1));
+#ifdef L3D_STATS
+                {   // the row's own band against the target's: the pairs a walk without the 64-row hull would test
+                    uint32_t nb = 0;
+                    if (cull) {
+                        const float2 b0 = tband[tb + j0], b1 = tband[tb + j1];
+                        nb += (uint32_t)__popcll(L3D_BALLOT(!(b0.y < blo || b0.x > bhi)) & lanes_on);
+                        if (v1) nb += (uint32_t)__popcll(L3D_BALLOT(!(b1.y < blo || b1.x > bhi)) & lanes_on);
+                    } else nb = (uint32_t)__popcll(lanes_on) * (1 + v1);
+                    if (lane == 0) L3D_STAT(5, nb);
+                }
+#endif
                 if (m0 | m1) {
                     if (m0) { if (c0b & lane_on) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | (tb + j0); tail += __popcll(m0); }
                     if (m1) { if (c1b & lane_on) ring[(tail + prefix(m1)) & (kRing - 1)] = ent_hi | (tb + j1); tail += __popcll(m1); }
@@ -438,6 +451,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     while (tail != head) drain();
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
     if (threadIdx.x == 0 && w < (1u << 16)) { g_cycles[w][0] = t_start; g_cycles[w][1] = wall_clock64() - t_start; }
+    if (threadIdx.x == 0) L3D_STAT(7, 1);
 #endif
 
     // ---- epilogue ----
@@ -532,6 +546,9 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
             slots[at] = o;
             of.inv_pos[at] = ipos;
         }
+#ifdef L3D_STATS
+        { const uint32_t nk = (uint32_t)__popcll(L3D_BALLOT(j < c)); if (lane == 0 && nk) L3D_STAT(6, nk); }
+#endif
         // fresh alive hypotheses of the row: its items are neighbouring lanes, one counter update per (row, pass)
         const uint64_t m = L3D_BALLOT((o.flags & kSlotAlive) != 0);
         const uint32_t r0 = r * K;

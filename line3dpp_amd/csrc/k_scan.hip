@@ -114,9 +114,12 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(const T* __restrict__ in, u
         out[n] = total;
         if (total_out) *total_out = total;
     }
-    // the last tile to get here leaves the work space zeroed for the next scan
+    // the last tile to get here leaves the work space zeroed for the next scan.  The count is a release / acquire pair at
+    // agent scope: a tile's state stores are ordered before its increment and the last tile's zeroing after it has seen
+    // every increment, so no straggling state store can land behind the zeroing (relaxed operations on different
+    // addresses carry no order of their own; one s_waitcnt per tile).
     __syncthreads();
-    if (tid == 0) s_last = __hip_atomic_fetch_add(&ws[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&ws[0], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
     __syncthreads();
     if (s_last) {
         for (uint32_t i = tid; i < nb * LANES; i += kScanBlock)

@@ -765,7 +765,7 @@ int l3d_expand_slot_indices(l3d_ctx* c, uint32_t first, uint32_t count) {
 
 // phase B: line3D.cc:745-773 for every view in ascending camID order (k_lists.hip)
 static int match_finish_impl(l3d_ctx* c);
-static int lists_prepare(l3d_ctx* c);
+static int lists_prepare(l3d_ctx* c, int caps_mode);
 static int lists_reserve(l3d_ctx* c);
 static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint32_t npools);
 
@@ -774,14 +774,15 @@ int l3d_lists_shard(l3d_ctx* c, uint32_t rank, uint32_t world, void* slab_ptr[4]
     if (!c || !slab_ptr || !slab_bytes || !full_ptr) return fail(L3D_ERR_ARG, "null argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (c->state != l3d_ctx::BEGUN) return fail(L3D_ERR_STATE, "l3d_match_begin must precede l3d_lists_shard");
-    if (world == 0 || world > kListPools || rank >= world) return fail(L3D_ERR_ARG, "rank / world out of range");
-    for (size_t p = 0; p < c->pairs.size(); ++p)
-        if (!c->pair_done[p]) return fail(L3D_ERR_STATE, "l3d_lists_shard: the slots of some pairs are not present on this rank");
     (void)hipSetDevice(c->device);
+    // every exit that is not L3D_OK closes the open call (views untranslated, context idle), as the header promises
     const int rc = [&]() -> int {
+        if (world == 0 || world > kListPools || rank >= world) return fail(L3D_ERR_ARG, "rank / world out of range");
+        for (size_t p = 0; p < c->pairs.size(); ++p)
+            if (!c->pair_done[p]) return fail(L3D_ERR_STATE, "l3d_lists_shard: the slots of some pairs are not present on this rank");
         int r2;
         if (!c->lists_prepared) {
-            r2 = lists_prepare(c);
+            r2 = lists_prepare(c, 1);
             if (r2) return r2;
             c->lists_prepared = true; c->lp_attempts = 0;
         }
@@ -879,7 +880,16 @@ static ZeroLayout zero_layout(uint32_t V, uint32_t G) {
     return z;
 }
 
-static int lists_prepare(l3d_ctx* c) {
+static int lists_prepare(l3d_ctx* c, int caps_mode) {
+    if (caps_mode != c->caps_mode) {   // the capacities of the other kind of call (l3d_ctx.h: caps_saved)
+        c->caps_saved[c->caps_mode] = l3d_ctx::PoolCaps{c->lp_ecap, c->lp_hcap, c->lp_scap, c->lp_ccap, c->huge_cap, c->huge_skip};
+        const l3d_ctx::PoolCaps& pc = c->caps_saved[caps_mode];
+        c->lp_ecap = pc.e; c->lp_hcap = pc.h; c->lp_scap = pc.s; c->lp_ccap = pc.c; c->huge_cap = pc.huge; c->huge_skip = pc.huge_skip;
+        c->caps_mode = caps_mode;
+    }
+    // a sharded list pass always runs k_lists_huge: whether a rank's views hold a list for it is not known to the other
+    // ranks before the pass, and a rank that had to repeat the pass alone would leave the collectives of the others
+    if (caps_mode == 1) c->huge_skip = false;
     hipStream_t st = c->stream;
     const uint32_t V = (uint32_t)c->order.size(), P = (uint32_t)c->pairs.size();
     // global segment ids
@@ -949,9 +959,13 @@ static int lists_prepare(l3d_ctx* c) {
     // list offsets (low words) and offsets of the inverse records (high words) in ONE scan of the packed counters
     L3D_HIP_CHECK(launch_scan64(c->d_cnt_pack.p, G, c->d_off64.p, c->d_scan_ws.p, tot64_of(c), st));
     if (!c->lp_ecap) {
-        c->lp_ecap = (uint32_t)std::max<uint64_t>(c->n_slots / 4 / kListPools, 512);
-        c->lp_hcap = (uint32_t)std::max<uint64_t>(c->n_slots / 8 / kListPools, 256);
-        c->lp_ccap = (uint32_t)std::max<uint64_t>(c->n_slots / 2 / kListPools, 1024);
+        // L3D_POOL_SCALE (diagnostic): scales the initial record pools; a small value makes the first list passes
+        // overflow, so that the regrow path (check_pass) can be exercised at any scene size
+        const double scale = [] { const char* e = std::getenv("L3D_POOL_SCALE"); const double v = e ? std::atof(e) : 1.0; return v > 0.0 ? v : 1.0; }();
+        const double ns = scale * (double)c->n_slots;
+        c->lp_ecap = (uint32_t)std::max<double>(ns / 4 / kListPools, scale < 1.0 ? 16 : 512);
+        c->lp_hcap = (uint32_t)std::max<double>(ns / 8 / kListPools, scale < 1.0 ? 16 : 256);
+        c->lp_ccap = (uint32_t)std::max<double>(ns / 2 / kListPools, scale < 1.0 ? 32 : 1024);
     }
     c->lp_scap = std::max<uint32_t>(c->lp_scap, G / kListPools + 64);   // 30-50 % of the segments have candidates; grows on demand
     if (!c->huge_cap) c->huge_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->n_slots / 16, 1u << 20), 1u << 30);
@@ -1061,9 +1075,10 @@ static int check_pass(l3d_ctx* c) {
     // lists for the global-memory kernel although its launch was left out: repeat with it (and keep it from now on)
     const bool huge_missed = fl[5] && !c->huge_ran;
     c->huge_skip = fl[5] == 0 && c->shard_world <= 1;
-    if (huge_missed) return kRetry;
+    if (huge_missed) { ++c->tm.pool_retries; return kRetry; }
     if (fl[3]) return fail(L3D_ERR_HIP, "internal error: hypothesis counters and slot flags disagree");
     if (fl[0] || fl[2]) {
+        ++c->tm.pool_retries;
         if (++c->lp_attempts > 6) return fail(L3D_ERR_LIMIT, "phase-B pools keep overflowing");
         if (fl[0]) {   // size from what this pass asked for, with head room
             // (a pass that ran out of candidate space never reached the edges: those pools double)
@@ -1146,7 +1161,7 @@ static int match_finish_impl(l3d_ctx* c) {
         if (rc) return rc;
         return finish_commit(c);
     }
-    rc = lists_prepare(c);
+    rc = lists_prepare(c, 0);
     if (rc) return rc;
     c->lp_attempts = 0;
     const uint32_t V = (uint32_t)c->order.size();

@@ -184,6 +184,12 @@ struct l3d_ctx {
     uint32_t lp_ecap = 0, lp_hcap = 0, lp_scap = 0, lp_ccap = 0, huge_cap = 0;
     uint32_t lp_attempts = 0;
     bool huge_skip = false, huge_ran = true;        // k_lists_huge left out while the passes hand it no lists
+    // The pool capacities (and huge_skip) are kept across calls, separately for unsharded calls [0] and for calls whose
+    // list pass is sharded over ranks [1]: the slabs the ranks all-gather must have one size on every rank, and the
+    // sharded set only ever changes by decisions every rank takes alike (check_pass sees all ranks' counters), whatever
+    // unsharded calls a rank's context has served in between.  caps_mode = the set the members above hold.
+    struct PoolCaps { uint32_t e = 0, h = 0, s = 0, c = 0, huge = 0; bool huge_skip = false; } caps_saved[2];
+    int caps_mode = 0;
     uint32_t chain_need = 8, chain_enqueued = 10;   // chain launches that changed something last time / enqueued this time
     // list pass sharded over ranks (l3d_lists_shard): world size of the running call, slabs received
     uint32_t shard_world = 0;

@@ -176,6 +176,7 @@ int l3d_save_result_obj(l3d_ctx* c, const char* output_folder, int max_image_wid
 
 int l3d_num_3d_lines(l3d_ctx* c, uint32_t* n_lines, uint32_t* n_segments, uint32_t* n_residuals) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (!c->lines_done) return fail(L3D_ERR_STATE, "l3d_reconstruct_3d_lines has not run");
     uint32_t ns = 0, nr = 0;
     for (auto& L : c->lines3D) { ns += (uint32_t)L.collinear.size(); nr += (uint32_t)L.residuals.size(); }
@@ -188,6 +189,7 @@ int l3d_num_3d_lines(l3d_ctx* c, uint32_t* n_lines, uint32_t* n_segments, uint32
 int l3d_get_3d_lines(l3d_ctx* c, uint32_t* seg_offsets, l3d_segment3d* segments, uint32_t* res_offsets,
                      l3d_segment2d* residuals, l3d_segment3d* cluster_lines, uint32_t* reference_views) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (!c->lines_done) return fail(L3D_ERR_STATE, "l3d_reconstruct_3d_lines has not run");
     auto put = [](l3d_segment3d& o, const ReconSeg3D& s) {
         o.P1[0] = s.P1.x; o.P1[1] = s.P1.y; o.P1[2] = s.P1.z; o.P2[0] = s.P2.x; o.P2[1] = s.P2.y; o.P2[2] = s.P2.z;

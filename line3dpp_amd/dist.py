@@ -190,7 +190,8 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_l
         for _ in range(8):
             slabs = l3d.listsShard(rank, world_size)
             if slabs is None:
-                return False               # a failing listsShard restores the context itself
+                return give_up()           # (l3d_lists_shard closes the call on every failing exit; matchAbort is a
+                                           # no-op then, and the safety net for a binding that fails before the call)
             lap("lists")
             gather_slabs(slabs, rank, world_size, device, group)
             lap("exchange_lists")

@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libl3d_oracle.so")
 _REF_SO = os.path.join(_HERE, "_ref", "libl3d_ref.so")   # the reference's own sources, compiled in place (-O2, asserts on)
 _REL_SO = os.path.join(_HERE, "_ref", "libl3d_ref_release.so")   # the same at -O3 -DNDEBUG (the reference's Release build)
+# the reference WITH its CUDA path, every CUDA construct executed on the host (oracle/ref_shim_cuda): pins performRDD
+_CUDA_SO = os.path.join(_HERE, "_ref", "libl3d_ref_cuda.so")
 
 # commons.h:186-203
 MATCH_DTYPE = np.dtype([
@@ -43,6 +45,31 @@ def have_reference():
 
 def have_release():
     return os.path.exists(_REL_SO)
+
+
+def have_cuda_path():
+    return os.path.exists(_CUDA_SO)
+
+
+_cuda_lib = None
+
+
+def rdd_reference(edges, n_rows):
+    """Replicator-dynamics diffusion + symmetrisation of an affinity edge list by the reference's OWN code:
+    Line3D::performRDD (line3D.cc:2026-2076) -> SparseMatrix (sparsematrix.cc) -> replicator_dynamics_diffusion_GPU and
+    the K_sparseMat_* kernels (cudawrapper.cu:432-544, 708-766), compiled in place and run as host code
+    (oracle/_ref/libl3d_ref_cuda.so).  10 iterations (L3D_DEF_RDD_MAX_ITER)."""
+    global _cuda_lib
+    if _cuda_lib is None:
+        if not os.path.exists(_CUDA_SO):
+            raise RuntimeError(_CUDA_SO + " is missing (needs /root/reference to build)")
+        _cuda_lib = C.CDLL(_CUDA_SO)
+        _cuda_lib.lo_ref_rdd.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        _cuda_lib.lo_ref_rdd.restype = C.c_uint32
+    e = np.ascontiguousarray(edges, CLEDGE_DTYPE)
+    out = np.zeros(2 * max(len(e), 1), CLEDGE_DTYPE)
+    n = _cuda_lib.lo_ref_rdd(_p(e), len(e), int(n_rows), _p(out))
+    return out[:n]
 
 
 def lib(reference=False):

@@ -268,6 +268,38 @@ void lo_get_lines(void* p, uint32_t* seg_offsets, double* segments9, uint32_t* r
     seg_offsets[r.size()] = ns; res_offsets[r.size()] = nr;
 }
 
+#ifdef L3DPP_CUDA
+// ---- the build with the reference's CUDA path as host code (oracle/ref_shim_cuda, libl3d_ref_cuda.so) ---------------
+}  // extern "C"
+thread_local uint3 blockIdx, threadIdx;          // the variables L3D_SHIM_LAUNCH sets for the "kernels"
+thread_local dim3 blockDim, gridDim;
+extern "C" {
+int lo_has_cuda_path() { return 1; }
+// The replicator-dynamics diffusion of an arbitrary affinity list by the reference's OWN code: A_ and the matrix size
+// (global2local_.size(), the only use performRDD makes of that map) are set, then Line3D::performRDD
+// (line3D.cc:2026-2076) runs: SparseMatrix (sparsematrix.cc:8-139), replicator_dynamics_diffusion_GPU
+// (cudawrapper.cu:708-766) with K_sparseMat_row_normalization / K_sparseMat_diffusion_step (:432-544) executed thread
+// by thread on the host, and the min(w12, w21) symmetrisation.  out: room for 2 n edges; returns the count.
+uint32_t lo_ref_rdd(const CLEdgeOut* in, uint32_t n, uint32_t n_rows, CLEdgeOut* out) {
+    Quiet q;
+    L3DPP::Line3D* l = new L3DPP::Line3D("/tmp", false, -1, 3000, false, false);
+    l->A_.clear();
+    for (uint32_t i = 0; i < n; ++i) { L3DPP::CLEdge e; e.i_ = in[i].i_; e.j_ = in[i].j_; e.w_ = in[i].w_; l->A_.push_back(e); }
+    l->global2local_.clear();
+    for (uint32_t i = 0; i < n_rows; ++i) l->global2local_[L3DPP::Segment2D(0, i)] = (int)i;
+    l->performRDD();
+    uint32_t k = 0;
+    for (std::list<L3DPP::CLEdge>::const_iterator it = l->A_.begin(); it != l->A_.end(); ++it, ++k) { out[k].i_ = it->i_; out[k].j_ = it->j_; out[k].w_ = it->w_; }
+    delete l;
+    return k;
+}
+// Line3D::reconstruct3Dlines with perform_diffusion = true (the flag only exists in a CUDA build, line3D.cc:1728-1736)
+void lo_reconstruct_rdd(void* p, uint32_t visibility_t) {
+    Quiet q;
+    ((Ref*)p)->l3d->reconstruct3Dlines(visibility_t, true, -1.0f, false, 250);
+}
+#endif
+
 // stage-level entry points exist only in the restatement
 void lo_begin_match(void*, float, float, uint32_t, float, int, float) {}
 void lo_end_match(void*) {}

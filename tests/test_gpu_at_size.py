@@ -1,5 +1,6 @@
-"""GPU parity at the BASELINE sizes (pytest -m gpu): the HIP path against the reference's own CPU code (oracle/_ref;
-the restatement when _ref is absent) on
+"""GPU parity at the BASELINE sizes (pytest -m gpu): the HIP path against the reference's own CPU code (oracle/_ref =
+line3D.cc / view.cc / clustering.cc compiled in place by oracle/Makefile; its absence FAILS these tests -- there is no
+downgrade to the restatement) on
 
   C1  full (64 views x 2000 segments, 10 neighbours) -- the configuration bench.py's headline number is quoted on
   C3  full (1024 views x 1000 segments, two rings)
@@ -35,7 +36,9 @@ def _context(scene):
 
 def _reference(scene):
     from oracle import oracle as O
-    o = O.Oracle(threads=THREADS, reference=O.have_reference())
+    assert O.have_reference(), "oracle/_ref/libl3d_ref.so (the reference's own code, built by oracle/Makefile where " \
+                               "/root/reference exists) is missing: the at-size parity tests do not fall back"
+    o = O.Oracle(threads=THREADS, reference=True)
     o.add_scene(scene)
     t0 = time.perf_counter()
     o.match_images(); o.compute_affinity()

@@ -151,3 +151,32 @@ def test_real_testdata_scene_equals_reference_code():
     # the inputs are only the segments that survived in the fixture and the cameras are estimates, still most of the
     # reference's published 3D lines come back
     assert len(lines) > 1500 and found > 0.6 * (len(off) - 1), (len(lines), found)
+
+
+@pytest.mark.skipif(not O.have_cuda_path(), reason="oracle/_ref/libl3d_ref_cuda.so not built (needs /root/reference)")
+def test_rdd_restatement_equals_the_reference_cuda_path_run_as_host_code():
+    """the replicator-dynamics diffusion has no CPU path in the reference.  oracle/Makefile compiles its
+    CUDA path in place -- line3D.cc (performRDD, :2026-2076), sparsematrix.cc, cudawrapper.cu (K_sparseMat_* :432-544,
+    replicator_dynamics_diffusion_GPU :708-766) -- against a host stand-in for the CUDA runtime (oracle/ref_shim_cuda:
+    device memory = host memory, a launch = a loop over the grid) and the restatement lo_rdd, which the product's
+    k_rdd.hip used to be checked against, must reproduce it byte for byte: symmetric patterns (A_ always holds (i,j) and
+    (j,i); with a one-sided entry the reference's kernels index row -1, undefined behaviour that cannot be pinned), rows
+    without entries, duplicate-free random patterns, asymmetric weights, weights down to the L3D_EPS_GPU clamp."""
+    rng = np.random.default_rng(11)
+    total = 0
+    for trial, (n, m, sym) in enumerate([(2, 4, True), (3, 6, True), (40, 120, True), (300, 1500, True), (300, 1500, False),
+                                         (1000, 6000, True), (64, 2000, True)]):
+        pairs = {(int(a), int(b)) for a, b in rng.integers(0, n, (m, 2)) if a != b}
+        pairs |= {(b, a) for a, b in pairs}
+        if not pairs:
+            continue
+        w = {}
+        for a, b in sorted(pairs):     # sym: w(i,j) == w(j,i) as computingAffinityMatrix emits them; else independent weights
+            w[(a, b)] = w.get((b, a), np.float32(rng.uniform(1e-6 if trial % 2 else 0.5, 1.0))) if sym else np.float32(rng.uniform(0.05, 1.0))
+        e = np.array([(a, b, w[(a, b)]) for a, b in sorted(pairs)], dtype=O.CLEDGE_DTYPE)
+        e = e[rng.permutation(len(e))]
+        ref = O.rdd_reference(e, n)
+        port = O.Oracle.rdd(e, n)
+        assert ref.tobytes() == port.tobytes(), (trial, n, len(e))
+        total += len(ref)
+    assert total > 10_000

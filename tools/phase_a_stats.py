@@ -21,4 +21,6 @@ L.l3d_debug_stats(out, 0)
 nominal = sc.pair_tests()[0]
 print(json.dumps({"config": cfg, "build_info": L.l3d_build_info().decode(), "nominal_pair_tests": nominal,
                   "prefilter_tests": int(out[0]), "exact_tests": int(out[1]), "passed_overlap": int(out[2]),
-                  "accepted": int(out[3]), "prefilter_fraction_of_nominal": out[0] / nominal}))
+                  "accepted": int(out[3]), "drains": int(out[4]), "band_pairs": int(out[5]), "kept_slots": int(out[6]),
+                  "work_items": int(out[7]), "prefilter_fraction_of_nominal": out[0] / nominal,
+                  "band_fraction_of_nominal": out[5] / nominal}))

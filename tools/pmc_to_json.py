@@ -33,6 +33,8 @@ out = {
     "valu_busy_fraction": round(4.0 * m["SQ_ACTIVE_INST_VALU"] / (cycles * simds), 4),
     "avg_waves_per_simd": round(4.0 * m["SQ_WAVE_CYCLES"] / (cycles * simds), 3),
     "valu_insts_per_launch": round(m["SQ_INSTS_VALU"]),
+    # dynamic instruction mix (wave-instructions per launch by class; "other" = compares, selects, moves, min/max, lane ops)
+    "valu_class_insts_per_launch": {k[14:]: round(v) for k, v in sorted(m.items()) if k.startswith("SQ_INSTS_VALU_")},
     "read_bytes_per_launch": round(2 * 1024 * m["FETCH_SIZE"]), "write_bytes_per_launch": round(1024 * m["WRITE_SIZE"]),
     "traffic_bytes_per_launch": round(2 * 1024 * m["FETCH_SIZE"] + 1024 * m["WRITE_SIZE"]),
     "other_kernels": {k: {c: round(v) for c, v in sorted(cs.items())} for k, cs in per.items() if k != name},
@@ -40,8 +42,9 @@ out = {
 try:
     st = json.load(open(os.path.join(d, "stats.json")))
     if st.get("build_info") == build:
-        out["candidates"] = {k: st[k] for k in ("nominal_pair_tests", "prefilter_tests", "exact_tests", "passed_overlap", "accepted",
-                                                 "prefilter_fraction_of_nominal")}
+        out["candidates"] = {k: st.get(k) for k in ("nominal_pair_tests", "prefilter_tests", "exact_tests", "passed_overlap", "accepted",
+                                                     "drains", "band_pairs", "kept_slots", "work_items",
+                                                     "prefilter_fraction_of_nominal", "band_fraction_of_nominal")}
 except Exception as e:   # noqa
     out["candidates"] = None
 path = os.path.join(ROOT, "gpurun_out", "%s_pmc_match.json" % tag)
