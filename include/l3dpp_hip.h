@@ -206,6 +206,10 @@ int l3d_get_affinity(l3d_ctx*, l3d_cledge* edges, l3d_segment2d* local2global, f
  * sorted by row or column, start_indices[n_rows] with -1 for empty rows/columns */
 int l3d_get_sparse_matrix(l3d_ctx*, int sort_by_row, l3d_float4* entries, int32_t* start_indices);
 
+/* test hook (host only): principal direction of a row-major symmetric 3x3 scatter matrix as Line3D::get3DlineFromCluster
+ * (line3D.cc:2196-2211) takes it from JacobiSVD -- this library's closed-form solver, checked against LAPACK on the CPU */
+int l3d_principal_direction(const double S9[9], double dir3[3]);
+
 /* test hook: route every segment pair through the exact double-precision test (no fp32 pre-filter);
  * used by the tests to prove that the pre-filter never loses a match */
 int l3d_set_brute_force(l3d_ctx*, int on);

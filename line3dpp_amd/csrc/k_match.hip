@@ -1264,6 +1264,31 @@ __global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __
     }
 }
 
+// kNN beyond what the per-row top-K tables of k_match_pairs hold in LDS: EVERY row is replayed by k_match_tied_rows (the
+// reference's own selection: all accepted matches pushed into its heap, kNN pops, line3D.cc:982-1007), whose winners
+// live in dynamic LDS sized by kNN and whose heap spills to global scratch.  This kernel queues the rows of the pairs
+// [first, first + count): grid (row blocks, pairs).
+__global__ __launch_bounds__(256) void k_queue_all_rows(const PairDesc* __restrict__ pairs, uint32_t first,
+                                                        const OrientFuse of, uint32_t list_base) {
+    const PairDesc& pd = pairs[first + blockIdx.y];
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= pd.Ms) return;
+    // rows of a pair are contiguous in the list: position = rows of the earlier pairs of the launch + r
+    const uint32_t pos = (pd.row_off - list_base) + r;
+    if (pos < of.tie_cap) of.tie_list[pos] = make_uint2(first + blockIdx.y, r);
+    atomicAdd(of.tie_count, 1u);
+}
+hipError_t launch_queue_all_rows(const PairDesc* pairs, uint32_t first, uint32_t count, uint32_t max_Ms, uint32_t list_base,
+                                 OrientFuse of, hipStream_t stream) {
+    if (!count || !max_Ms) return hipSuccess;
+    if (!of.tie_count || !of.tie_list) return hipErrorInvalidValue;
+    for (uint32_t p0 = 0; p0 < count; p0 += 65535u) {
+        const uint32_t n = count - p0 < 65535u ? count - p0 : 65535u;
+        hipLaunchKernelGGL(k_queue_all_rows, dim3((max_Ms + 255) / 256, n), dim3(256), 0, stream, pairs, first + p0, of, list_base);
+    }
+    return hipGetLastError();
+}
+
 // two workgroups per CU -- what its registers let be resident at once: more would only queue up behind them, and with
 // the usual handful of rows the launch is all latency; fewer when the per-workgroup scratch (16 bytes per target)
 // would pass 128 MiB in total

@@ -475,13 +475,9 @@ static int match_begin_body(l3d_ctx* c) {
         for (auto& pd : c->pairs) { n_work += (pd.Ms + kMatchRows - 1) / kMatchRows; maxMt = std::max(maxMt, pd.Mt); }
         const uint32_t wpg = match_waves_per_group(0, c->brute, (uint32_t)std::min<size_t>(n_work, 0xFFFFFFFFu));
         auto fits = [&](uint32_t K) { return match_lds_bytes(0, K, maxMt < 65536u && K < 65536u && !c->brute, wpg) <= 160 * 1024; };
-        if (!fits((uint32_t)c->kNN)) {
-            uint32_t lo = 1, hi = (uint32_t)c->kNN;           // largest K that fits
-            while (lo + 1 < hi) { const uint32_t m = (lo + hi) / 2; if (fits(m)) lo = m; else hi = m; }
-            return fail(L3D_ERR_LIMIT, "kNN = " + std::to_string(c->kNN) + " exceeds the per-row top-K table in LDS: the "
-                        "largest bounded kNN of this build is " + std::to_string(lo) + " (kNN <= 0 keeps every match)");
-        }
-    }
+        // beyond that, every row takes the exact replay path (k_match_tied_rows): slower per row, any kNN <= 4096
+        c->knn_replay = !fits((uint32_t)c->kNN);
+    } else c->knn_replay = false;
     c->cull_tot[0] = cs_off; c->cull_tot[1] = ct_off; c->cull_tot[2] = ck_off; c->cull_tot[3] = cc_off;
     c->begin_sig.swap(sig); c->begin_sig_valid = true;
     }
@@ -567,7 +563,8 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         if (c->cull[p].enabled) maxM = std::max(maxM, std::max(pd.Ms, pd.Mt));
         maxMt = std::max(maxMt, pd.Mt);
     }
-    if (match_lds_bytes(mode, maxK, false, match_waves_per_group(mode, c->brute, (uint32_t)n_work)) > 160 * 1024)
+    const bool replay_all = mode == 0 && c->knn_replay;   // kNN beyond the LDS tables: every row through k_match_tied_rows
+    if (!replay_all && match_lds_bytes(mode, maxK, false, match_waves_per_group(mode, c->brute, (uint32_t)n_work)) > 160 * 1024)
         return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
     L3D_HIP_CHECK(c->d_work.reserve(n_work));
     // the work list of these pairs is on the device already when the pair list has not changed since it was sent
@@ -624,6 +621,11 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         of.tie_total = c->d_tie_count.p + 2; ++c->tie_seq;
         of.tie_list = c->d_tie_list.p; of.tie_cap = c->n_rows_total;
     }
+    if (replay_all) {
+        uint32_t maxMs = 0;
+        for (uint32_t p = first; p < first + count; ++p) maxMs = std::max(maxMs, c->pairs[p].Ms);
+        L3D_HIP_CHECK(launch_queue_all_rows(c->d_pairs.p, first, count, maxMs, c->pairs[first].row_off, of, c->stream));
+    } else
     L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work, maxK,
                                      c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, of, ix16, c->stream));
     L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));

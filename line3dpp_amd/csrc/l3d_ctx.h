@@ -101,6 +101,8 @@ struct l3d_ctx {
     int kNN = 10, num_neighbors = 10;
     bool fixed3Dregularizer = false;
     bool brute = false;                             // test hook: disable the fp32 pre-filter
+    bool knn_replay = false;                        // kNN beyond the LDS top-K tables of k_match_pairs: every row goes
+                                                    // through k_match_tied_rows (the reference's heap, any kNN <= 4096)
     double orient_lo = -1.0, orient_hi = 1.0;       // dp window equivalent to acos(dp) in (PI/32, 31PI/32)
     d3 translation{0, 0, 0};
     // state

@@ -79,6 +79,10 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
 // region of 2 * scratch_stride (stride >= max Mt) packed entries per workgroup of match_tied_grid(stride); cp: the culling pools of the
 // match launch (cp.cull == nullptr: every target is visited)
 uint32_t match_tied_grid(uint32_t scratch_stride);
+// kNN beyond the LDS tables of k_match_pairs: every row of the pairs [first, first + count) is queued for
+// k_match_tied_rows instead (list_base = PairDesc::row_off of pair `first`)
+hipError_t launch_queue_all_rows(const PairDesc* pairs, uint32_t first, uint32_t count, uint32_t max_Ms, uint32_t list_base,
+                                 OrientFuse of, hipStream_t stream);
 hipError_t launch_match_tied_rows(const ViewDev* views, const PairDesc* pairs, Slot* slots, uint32_t maxK, float thr,
                                   OrientFuse of, CullPools cp, uint64_t* scratch, uint32_t scratch_stride,
                                   hipStream_t stream);

@@ -53,27 +53,54 @@ Universe perform_clustering(std::vector<l3d_cledge> edges, int num_nodes, float 
     return u;
 }
 
-// principal direction of a symmetric positive semi-definite 3x3 matrix (what JacobiSVD + maxCoeff give in
-// get3DlineFromCluster): cyclic Jacobi eigenvalue iteration
+// Principal direction of a symmetric positive semi-definite 3x3 matrix -- what JacobiSVD + maxCoeff give in
+// get3DlineFromCluster (line3D.cc:2196-2211).  Not an iteration of Jacobi rotations (that is how the checker's Eigen
+// stand-in, oracle/ref_shim, solves it; the product must not be compared with its own code): the largest eigenvalue in
+// closed form (trigonometric solution of the characteristic cubic of the trace-free, scaled matrix), its eigenvector as
+// the largest cross product of two rows of S - lambda*I (the rows span the plane orthogonal to it), polished by two
+// steps of power iteration with the matrix itself.  The sign of the direction is free (the sweep of
+// findCollinearSegments starts from the end point farthest from the centre of gravity, whichever way the line points);
+// the largest component is made positive.
 d3 principal_direction(double S[3][3]) {
-    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int sweep = 0; sweep < 64; ++sweep) {
-        const double off = S[0][1] * S[0][1] + S[0][2] * S[0][2] + S[1][2] * S[1][2];
-        if (off < 1e-300) break;
-        for (int p = 0; p < 3; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                if (std::fabs(S[p][q]) < 1e-300) continue;
-                const double th = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
-                const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
-                const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
-                for (int k = 0; k < 3; ++k) { const double a = S[k][p], b = S[k][q]; S[k][p] = cs * a - sn * b; S[k][q] = sn * a + cs * b; }
-                for (int k = 0; k < 3; ++k) { const double a = S[p][k], b = S[q][k]; S[p][k] = cs * a - sn * b; S[q][k] = sn * a + cs * b; }
-                for (int k = 0; k < 3; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = cs * a - sn * b; V[k][q] = sn * a + cs * b; }
-            }
+    double scale = 0.0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) scale = std::fmax(scale, std::fabs(S[i][j]));
+    if (!(scale > 0.0) || !std::isfinite(scale)) return d3{1.0, 0.0, 0.0};
+    double A[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = 0.5 * (S[i][j] + S[j][i]) / scale;
+    const double q = (A[0][0] + A[1][1] + A[2][2]) / 3.0;
+    const double p1 = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    const double d0 = A[0][0] - q, d1 = A[1][1] - q, d2 = A[2][2] - q;
+    const double p2 = d0 * d0 + d1 * d1 + d2 * d2 + 2.0 * p1;
+    d3 v{1.0, 0.0, 0.0};
+    if (p2 > 1e-300) {
+        const double p = std::sqrt(p2 / 6.0);
+        // B = (A - q I) / p; det(B) / 2 = cos(3 phi)
+        const double b00 = d0 / p, b11 = d1 / p, b22 = d2 / p, b01 = A[0][1] / p, b02 = A[0][2] / p, b12 = A[1][2] / p;
+        const double detB = b00 * (b11 * b22 - b12 * b12) - b01 * (b01 * b22 - b12 * b02) + b02 * (b01 * b12 - b11 * b02);
+        const double r = std::fmin(std::fmax(0.5 * detB, -1.0), 1.0);
+        const double lambda = q + 2.0 * p * std::cos(std::acos(r) / 3.0);     // the largest of the three roots
+        const d3 r0{A[0][0] - lambda, A[0][1], A[0][2]}, r1{A[0][1], A[1][1] - lambda, A[1][2]}, r2{A[0][2], A[1][2], A[2][2] - lambda};
+        const d3 c[3] = {cross(r0, r1), cross(r0, r2), cross(r1, r2)};
+        int best = 0; double bn = -1.0;
+        for (int k = 0; k < 3; ++k) { const double n2 = dot(c[k], c[k]); if (n2 > bn) { bn = n2; best = k; } }
+        if (bn > 1e-300) v = c[best] * (1.0 / std::sqrt(bn));
+        else {   // two equal largest eigenvalues or a multiple of the identity: any direction of the eigenspace; take
+                 // the coordinate axis with the largest diagonal entry as the start of the power iteration
+            const int m = (A[1][1] > A[0][0] ? (A[2][2] > A[1][1] ? 2 : 1) : (A[2][2] > A[0][0] ? 2 : 0));
+            v = d3{m == 0 ? 1.0 : 0.0, m == 1 ? 1.0 : 0.0, m == 2 ? 1.0 : 0.0};
+        }
     }
-    int m = 0;
-    for (int i = 1; i < 3; ++i) if (std::fabs(S[i][i]) > std::fabs(S[m][m])) m = i;
-    return normalized(d3{V[0][m], V[1][m], V[2][m]});
+    for (int it = 0; it < 2; ++it) {
+        const d3 w{A[0][0] * v.x + A[0][1] * v.y + A[0][2] * v.z, A[0][1] * v.x + A[1][1] * v.y + A[1][2] * v.z,
+                   A[0][2] * v.x + A[1][2] * v.y + A[2][2] * v.z};
+        const double n = norm(w);
+        if (!(n > 1e-300)) break;
+        v = w * (1.0 / n);
+    }
+    const double ax = std::fabs(v.x), ay = std::fabs(v.y), az = std::fabs(v.z);
+    const double lead = (ax >= ay && ax >= az) ? v.x : (ay >= az ? v.y : v.z);
+    if (lead < 0.0) v = v * -1.0;
+    return normalized(v);
 }
 
 d3 ray_of(const HostView& v, uint32_t seg, bool first) {  // View::getNormalizedLinePointRay, view.cc:330-353
@@ -110,6 +137,8 @@ void project(const HostView& v, const d3& P, double& x, double& y) {
 }
 
 }  // namespace
+
+d3 principal_direction_of(double S[3][3]) { return principal_direction(S); }   // (named entry for the test hook below)
 
 void reconstruct_lines(const ReconInput& in, std::vector<ReconLine>& out, uint32_t* n_clusters, uint32_t* n_valid) {
     out.clear();
@@ -234,3 +263,14 @@ void reconstruct_lines(const ReconInput& in, std::vector<ReconLine>& out, uint32
 }
 
 }  // namespace l3d
+
+// test hook (host only, no device needed): the principal direction get3DlineFromCluster takes from its 3x3 scatter
+// matrix (row-major S9), as this library computes it -- checked against LAPACK in tests/test_host_logic.py
+extern "C" int l3d_principal_direction(const double S9[9], double dir3[3]) {
+    if (!S9 || !dir3) return -1;
+    double S[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) S[i][j] = S9[3 * i + j];
+    const l3d::d3 d = l3d::principal_direction_of(S);
+    dir3[0] = d.x; dir3[1] = d.y; dir3[2] = d.z;
+    return 0;
+}

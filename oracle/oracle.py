@@ -120,6 +120,9 @@ def lib(reference=False):
         if not reference:
             L.lo_rdd.argtypes = [vp, u32, u32, u32, vp]; L.lo_rdd.restype = u32
         if reference:
+            L.lo_ref_view_matrices.argtypes = [vp, u32, vp, vp]
+            L.lo_ref_fundamental.argtypes = [vp, u32, u32, vp]
+            L.lo_ref_principal_direction.argtypes = [vp, vp]
             L.lo_reconstruct.argtypes = [vp, u32]
             L.lo_reconstruct_collin.argtypes = [vp, u32, f32]
             L.lo_save_txt.argtypes = [vp, C.c_char_p]
@@ -272,6 +275,26 @@ class Oracle:
         out = np.zeros(2 * max(len(e), 1), CLEDGE_DTYPE)
         n = L.lo_rdd(_p(e), len(e), int(n_rows), int(iterations), _p(out))
         return out[:n]
+
+    # ---- the reference's linear algebra as compiled here (oracle/ref_shim Eigen subset), for tests/test_shim_vs_lapack.py
+    def ref_view_matrices(self, cam):
+        assert self.reference
+        a = np.zeros((3, 3)); b = np.zeros((3, 3))
+        self.L.lo_ref_view_matrices(self.h, int(cam), _p(a), _p(b))
+        return a, b
+
+    def ref_fundamental(self, src, tgt):
+        assert self.reference
+        F = np.zeros((3, 3))
+        self.L.lo_ref_fundamental(self.h, int(src), int(tgt), _p(F))
+        return F
+
+    @staticmethod
+    def ref_principal_direction(S):
+        L = lib(True)
+        S = np.ascontiguousarray(S, np.float64).reshape(3, 3); d = np.zeros(3)
+        L.lo_ref_principal_direction(_p(S), _p(d))
+        return d
 
     # ---- reconstruction tail: only through the reference's own code (oracle/_ref) -------------------------
     def reconstruct(self, visibility_t=3, collinearity_t=-1.0):

@@ -268,6 +268,34 @@ void lo_get_lines(void* p, uint32_t* seg_offsets, double* segments9, uint32_t* r
     seg_offsets[r.size()] = ns; res_offsets[r.size()] = nr;
 }
 
+// ---- linear algebra of the reference as compiled here (i.e. through oracle/ref_shim's Eigen subset), handed out so
+// that tests can bound its distance from a real linear-algebra library (numpy / LAPACK): tests/test_shim_vs_lapack.py
+void lo_ref_view_matrices(void* p, uint32_t cam, double* Kinv9, double* RtKinv9) {
+    L3DPP::View* v = ((Ref*)p)->l3d->views_[cam];
+    const Eigen::Matrix3d a = v->Kinv(), b = v->RtKinv();
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { Kinv9[3 * i + j] = a(i, j); RtKinv9[3 * i + j] = b(i, j); }
+}
+// Line3D::getFundamentalMatrix (line3D.cc:861-897) of the views as they stand (call between addImage and matchImages:
+// untranslated frame; F does not depend on the frame beyond rounding)
+void lo_ref_fundamental(void* p, uint32_t src, uint32_t tgt, double* F9) {
+    L3DPP::Line3D* l = ((Ref*)p)->l3d;
+    const Eigen::Matrix3d F = l->getFundamentalMatrix(l->views_[src], l->views_[tgt]);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) F9[3 * i + j] = F(i, j);
+}
+// what get3DlineFromCluster (line3D.cc:2196-2211) does with its 3x3 scatter matrix: JacobiSVD, column of the largest
+// singular value, normalised
+void lo_ref_principal_direction(const double* S9, double* dir3) {
+    Eigen::MatrixXd Scat(3, 3);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Scat(i, j) = S9[3 * i + j];
+    Eigen::JacobiSVD<Eigen::MatrixXd> svd(Scat, Eigen::ComputeThinU);
+    Eigen::MatrixXd U; Eigen::VectorXd S;
+    U = svd.matrixU(); S = svd.singularValues();
+    int maxPos; S.maxCoeff(&maxPos);
+    Eigen::Vector3d dir = Eigen::Vector3d(U(0, maxPos), U(1, maxPos), U(2, maxPos));
+    dir.normalize();
+    dir3[0] = dir.x(); dir3[1] = dir.y(); dir3[2] = dir.z();
+}
+
 #ifdef L3DPP_CUDA
 // ---- the build with the reference's CUDA path as host code (oracle/ref_shim_cuda, libl3d_ref_cuda.so) ---------------
 }  // extern "C"

@@ -127,3 +127,34 @@ def test_reference_obj_and_stl_formats():
     stl = format_stl(lines).splitlines()
     assert stl[0] == "solid lineModel" and stl[-1] == "endsolid lineModel" and len(stl) == 2 + 7 * n_seg
     assert stl[1] == " facet normal 1.0e+000 0.0e+000 0.0e+000" and stl[3].startswith("   vertex 4.716430e+00 ")
+
+
+def test_principal_direction_of_the_library_agrees_with_lapack():
+    """get3DlineFromCluster's 3x3 scatter problem (line3D.cc:2196-2211): the library's closed-form solver
+    (l3d_recon.hip: principal_direction, host code, reachable without a GPU through the test hook
+    l3d_principal_direction) against numpy.linalg.eigh.  The checker's Eigen stand-in solves the same problem with Jacobi
+    rotations (oracle/ref_shim, bounded against LAPACK in tests/test_shim_vs_lapack.py): two independent codes, both
+    within 1e-12 of LAPACK, so the reconstruction tail is not compared with itself."""
+    import ctypes as C
+    from line3dpp_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for trial in range(500):
+        n = int(rng.integers(3, 40))
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        pts = rng.normal(size=3)[:, None] * 5 + d[:, None] * rng.uniform(-3, 3, 2 * n)[None, :] + \
+            rng.normal(scale=10.0 ** rng.uniform(-6, -0.5), size=(3, 2 * n))
+        Cm = np.eye(2 * n) - np.full((2 * n, 2 * n), 1.0 / (2 * n))
+        S = np.ascontiguousarray(pts @ Cm @ pts.T)
+        out = np.zeros(3)
+        assert L.l3d_principal_direction(S.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+        w, V = np.linalg.eigh(S)
+        want = V[:, np.argmax(w)]
+        assert abs(np.linalg.norm(out) - 1.0) <= 1e-14
+        err = min(np.linalg.norm(out - want), np.linalg.norm(out + want))
+        gap = (w[-1] - w[-2]) / w[-1]
+        assert err <= 1e-12 / max(gap, 1e-3), (trial, err, gap)
+        worst = max(worst, err)
+        assert out[np.argmax(np.abs(out))] > 0          # sign convention: largest component positive
+    assert worst <= 1e-9
