@@ -41,6 +41,7 @@ namespace {
 
 constexpr int kBlock = kMatchRows;  // rows per work item = lanes of a wave64; a workgroup is WPG (1 or 2) such waves
 constexpr int kRing = 256;          // candidate ring (entries); >= 63 + 2*64 (drained after every two pushes)
+constexpr int kRing2 = 128;         // second ring (bounded kNN): candidates that passed the depth test; >= 63 + 64
 constexpr float kKappa = 1.0e-2f;  // pre-filter slack, px: margin = kKappa * max|1/d| + kKappa0
 constexpr float kKappa0 = 2.0e-4f;
 
@@ -53,9 +54,10 @@ constexpr float kKappa0 = 2.0e-4f;
 #define L3D_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 // diagnostics builds only (-DL3D_STATS: candidate counters, slow; -DL3D_CYCLES: per-work-item timeline)
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
-__device__ unsigned long long g_stats[8];   // 0 pre-filter tests, 1 candidates, 2 passed overlap, 3 accepted, 4 drains,
+__device__ unsigned long long g_stats[12];   // 0 pre-filter tests, 1 candidates, 2 passed overlap, 3 accepted, 4 drains,
                                             // 5 (row, target) pairs whose OWN bands intersect (what a per-row walk would
-                                            // test), 6 slots kept, 7 work items
+                                            // test), 6 slots kept, 7 work items, 8 stage-1 drains (depth decision), 9 candidates
+                                            // that passed it (1 = candidates into stage 1, 4 = stage-2 drains (exact overlap))
 __device__ unsigned long long g_cycles[1 << 16][2];   // per work item: start, duration (wall_clock64 ticks)
 #endif
 #ifdef L3D_STATS
@@ -73,6 +75,7 @@ template <bool IX16>
 struct Lds {
     typedef typename IdxT<IX16>::type idx_t;
     L3D_LDS volatile uint32_t* ring;   // [waves][kRing]
+    L3D_LDS volatile uint32_t* ring2;  // [waves][kRing2] (bounded kNN only)
     L3D_LDS volatile uint32_t* row_src;  // [kBlock] source segment of each row (epilogue)
     L3D_LDS volatile float* minov;     // [kBlock]
     L3D_LDS volatile uint32_t* claim;  // [kBlock]
@@ -84,10 +87,11 @@ struct Lds {
 };
 
 template <bool IX16>
-__device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K, uint32_t waves) {
+__device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K, uint32_t waves, bool two_rings) {
     typedef typename IdxT<IX16>::type idx_t;
     Lds<IX16> l;
     l.ring = (L3D_LDS volatile uint32_t*)base; base += waves * kRing * sizeof(uint32_t);
+    l.ring2 = (L3D_LDS volatile uint32_t*)base; if (two_rings) base += waves * kRing2 * sizeof(uint32_t);
     l.row_src = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
     l.minov = (L3D_LDS volatile float*)base; base += kBlock * 4;
     l.claim = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
@@ -157,7 +161,7 @@ __device__ __forceinline__ uint32_t fuse_orientation(const OrientFuse& of, const
 //      inserted); a row's table is guarded by a compare-and-swap lock in LDS.
 // amdgpu_waves_per_eu(7): the LDS tables leave room for 7 waves per SIMD; the two-wave variant would otherwise take 75
 // VGPRs (6 waves) -- held to 72 it spills one register and runs 2.7 % faster on C1.
-template <int MODE, bool BRUTE, bool IX16, int WPG>
+template <int MODE, bool BRUTE, bool IX16, int WPG, bool STAGED>
 __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7))) void k_match_pairs(const ViewDev* __restrict__ views,
                                                            const PairDesc* __restrict__ pairs,
                                                            const WorkItem* __restrict__ work, uint32_t nwork,
@@ -181,12 +185,14 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     const ViewDev& vt = views[pd.tgt];
     const uint32_t K = pd.K, Ms = pd.Ms, Mt = pd.Mt;
     typedef typename IdxT<IX16>::type idx_t;
-    Lds<IX16> L = carve<IX16>((L3D_LDS char*)smem, MODE == 0 ? K : 0, WPG);
+    static_assert(!STAGED || (MODE == 0 && !BRUTE), "the two-stage candidate pipeline exists for the bounded-kNN variant");
+    Lds<IX16> L = carve<IX16>((L3D_LDS char*)smem, MODE == 0 ? K : 0, WPG, STAGED);
     // wave of the workgroup -- through readfirstlane: the compiler must know it is wave-uniform, or the chunk loop
     // below (its mask depends on q) is compiled as a divergent loop with vector addresses
     const uint32_t q = WPG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
     const uint32_t tid = threadIdx.x & 63u, lane = tid;          // row of the work item = lane
     L3D_LDS volatile uint32_t* ring = L.ring + q * kRing;
+    L3D_LDS volatile uint32_t* ring2 = L.ring2 + q * kRing2;
     // epipolar-band culling (kNN mode only: the keep-all rows must be filled in ascending target order)
     const PairCull* pc = (MODE == 0 && !BRUTE && cp.cull && cp.cull[wi.pair].enabled) ? &cp.cull[wi.pair] : nullptr;
     const bool cull = pc != nullptr;
@@ -261,6 +267,105 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
         }
         L.minov[sl] = wo;
         L.minpos[sl] = wj;
+    };
+
+    auto prefix = [&](uint64_t m) -> uint32_t {
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    };
+    // ---- bounded kNN: the candidates of the pre-filter pass through TWO full-lane stages ----
+    //   stage 1  the DECISION of the depth test (all four triangulated depths > L3D_EPS, line3D.cc:960-980) without its
+    //            divisions (l3d_dev.h depths_positive: ~60 VALU instead of ~95): a third of the candidates of the
+    //            BASELINE scenes fail it, and they used to go through the ~350-instruction overlap first
+    //   stage 2  the exact epipolar overlap of the survivors (compacted into a second ring, so again one per lane) and
+    //            the kNN insertion
+    // The depth VALUES are only computed for the winners (epilogue), as before.  What the exact tests read of a target
+    // comes from the copies k_cull_prepare keeps in walk order (tgt_s4 / tgt_sd): a wave's candidates are neighbours
+    // there.  Table entries are positions in that order; the epilogue translates the winners (tgt_perm).
+    uint32_t head2 = 0, tail2 = 0;
+    const float4* __restrict__ ts4 = cull ? cp.tgt_s4 + pc->t_off : vt.seg4;
+    const char* __restrict__ tsd = cull ? (const char*)(cp.tgt_sd + pc->t_off) : (const char*)vt.segx;
+    const uint32_t tsd_stride = cull ? (uint32_t)sizeof(SegD) : (uint32_t)sizeof(SegX);
+    auto stage1 = [&]() {
+        const uint32_t n = min(64u, tail - head);
+        const bool has = lane < n;
+        if (lane == 0) { L3D_STAT(1, n); L3D_STAT(8, 1); }
+        const uint32_t ent = ring[(head + lane) & (kRing - 1)];
+        head += n;
+        const uint32_t sl = ent >> 23, tp = ent & 0x7FFFFFu;
+        const uint32_t sg = __shfl(src, sl);   // the ring of a wave only holds rows of that wave
+        bool pass = false;
+        if (has) {
+            const SegD& sd = *(const SegD*)&vs.segx[sg];                       // a SegX starts with its SegD
+            const SegD& td = *(const SegD*)(tsd + (size_t)tp * tsd_stride);
+            pass = depths_positive(sd, td, vs.C, vt.C);
+        }
+        const uint64_t m = L3D_BALLOT(pass);
+        if (pass) ring2[(tail2 + prefix(m)) & (kRing2 - 1)] = ent;
+        tail2 += (uint32_t)__popcll(m);
+        if (lane == 0) L3D_STAT(9, __popcll(m));
+    };
+    auto stage2 = [&]() {
+        const uint32_t n = min(64u, tail2 - head2);
+        const bool has = lane < n;
+        if (lane == 0) L3D_STAT(4, 1);
+        const uint32_t ent = ring2[(head2 + lane) & (kRing2 - 1)];
+        head2 += n;
+        const uint32_t sl = ent >> 23, tg = ent & 0x7FFFFFu;
+        const uint32_t sg = __shfl(src, sl);
+        bool pending = false;
+        float ovv = 0.0f;
+        if (has) {
+            const float4 s4 = vs.seg4[sg], t4 = ts4[tg];
+            const float ov = exact_overlap(F, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w);
+            // a full row only admits overlaps that reach its K-th best (minov == thr while the row is not full); an overlap
+            // EQUAL to the K-th best goes on to the insertion: a tie at the kNN-th place flags the row for the exact replay
+            const float need = L.minov[sl];
+            if (ov > thr && ov >= need) { pending = true; ovv = ov; L3D_STAT(2, 1); L3D_STAT(3, 1); }
+        }
+        // several candidates of one drain may belong to the same row: one at a time (compare-and-swap lock with two waves
+        // per row group; a wave's own contenders are serialised by the LDS atomic unit just the same)
+        while (L3D_BALLOT(pending)) {
+            bool win;
+            if (WPG > 1) {
+                win = false;
+                if (pending) {
+                    uint32_t expect = kEmpty;
+                    win = __hip_atomic_compare_exchange_strong((L3D_LDS uint32_t*)&L.claim[sl], &expect, threadIdx.x,
+                                                               __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
+                if (pending) __hip_atomic_fetch_min((L3D_LDS uint32_t*)&L.claim[sl], lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                win = pending && (L.claim[sl] == lane);
+            }
+            if (win) {
+                if (WPG == 1) L.claim[sl] = kEmpty;
+                pending = false;
+                const uint32_t c = L.cnt[sl];
+                L3D_LDS volatile float* ov = L.top_ov + (size_t)sl * K;
+                L3D_LDS volatile idx_t* ix = L.top_ix + (size_t)sl * K;
+                if (c < K) {
+                    ov[c] = ovv; ix[c] = tg;
+                    L.cnt[sl] = c + 1;
+                    if (c + 1 == K) rescan_worst(sl);
+                } else {
+                    const uint32_t wj = L.minpos[sl];
+                    const float mo = L.minov[sl];
+                    if (ovv > mo) {
+                        ov[wj] = ovv; ix[wj] = tg;
+                        rescan_worst(sl);
+                        if (L.minov[sl] == mo) L.tie[sl] = 1;   // the evicted entry ties with the new K-th best
+                    } else if (ovv == mo) {
+                        L.tie[sl] = 1;                          // a tie at the K-th place (whichever index would win)
+                    }
+                }
+                if (WPG > 1)
+                    __hip_atomic_store((L3D_LDS uint32_t*)&L.claim[sl], kEmpty, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        // feed the K-th best overlap back into the owning lane's pre-filter threshold
+        if (live) thrL = L.minov[tid];
     };
 
     // one exact test per lane on up to 64 queued candidates, then kNN insertion
@@ -358,8 +463,17 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     const uint32_t ent_hi = tid << 23;
     const bool lane_on = BRUTE ? active : live;           // lanes that can produce candidates
     const uint64_t lanes_on = L3D_BALLOT(lane_on);
-    auto prefix = [&](uint64_t m) -> uint32_t {
-        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    // the candidate pipeline is run whenever the first ring holds a full drain (flush: until both rings are empty)
+    auto pump = [&](bool flush) {
+        if (STAGED) {
+            while (tail - head >= (flush ? 1u : 64u)) {
+                stage1();
+                while (tail2 - head2 >= 64) stage2();
+            }
+            if (flush) while (tail2 != head2) stage2();
+        } else {
+            while (flush ? (tail != head) : (tail - head >= 64)) drain();
+        }
     };
     // The target view is visited in chunks of 64 records.  With culling, 32 chunk bands are tested at once (one per
     // lane), then inside a visited chunk one target band per lane; only the targets whose band meets the wave's band
@@ -442,13 +556,13 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
                 if (m0 | m1) {
                     if (m0) { if (c0b & lane_on) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | (tb + j0); tail += __popcll(m0); }
                     if (m1) { if (c1b & lane_on) ring[(tail + prefix(m1)) & (kRing - 1)] = ent_hi | (tb + j1); tail += __popcll(m1); }
-                    while (tail - head >= 64) drain();
+                    pump(false);
                 }
             }
         }
       }
     }
-    while (tail != head) drain();
+    pump(true);
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
     if (threadIdx.x == 0 && w < (1u << 16)) { g_cycles[w][0] = t_start; g_cycles[w][1] = wall_clock64() - t_start; }
     if (threadIdx.x == 0) L3D_STAT(7, 1);
@@ -515,7 +629,8 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
         if (j < c) {
             L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)r * K;
             L3D_LDS const idx_t* ix = (L3D_LDS const idx_t*)L.top_ix + (size_t)r * K;
-            const float oj = ov[j]; const uint32_t xj = ix[j];
+            const float oj = ov[j];
+            const uint32_t xj = (STAGED && cull) ? tperm[ix[j]] : (uint32_t)ix[j];   // staged, culled pair: the table holds walk-order positions
             // (a row that gets here has no two equal overlaps -- the pass above flagged those --, so the order
             // (overlap desc, target asc) is the order by overlap)
             uint32_t rank = 0;
@@ -563,9 +678,16 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     }
 }
 
+// the two-stage candidate pipeline (default) or the single-stage one of round 2 (L3D_MATCH_STAGED=0: A/B switch; the
+// brute-force test hook always takes the single-stage path, so the two check each other)
+bool match_staged(int mode, bool brute) {
+    static const bool off = [] { const char* e = std::getenv("L3D_MATCH_STAGED"); return e && std::atoi(e) == 0; }();
+    return mode == 0 && !brute && !off;
+}
 size_t match_lds_bytes(int mode, uint32_t K, bool ix16, uint32_t waves) {
     const size_t ib = ix16 ? 2 : 4;
-    return (size_t)waves * kRing * 4 + 3 * kBlock * 4 + 2 * kBlock * ib + (mode == 0 ? (size_t)kBlock * K * (4 + ib) : 0) + kBlock;
+    return (size_t)waves * (kRing + (match_staged(mode, false) ? kRing2 : 0)) * 4 + 3 * kBlock * 4 + 2 * kBlock * ib +
+           (mode == 0 ? (size_t)kBlock * K * (4 + ib) : 0) + kBlock;
 }
 
 // Two waves per work item pay off while the launch has few items for the machine (C0: kernel 0.34 -> 0.24 ms, C1 with
@@ -589,21 +711,23 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
     if (!(mode == 0 && !brute)) ix16 = false;       // the compact layout is only instantiated for the hot variant
     const uint32_t wpg = match_waves_per_group(mode, brute, nwork);
     const size_t lds = match_lds_bytes(mode, maxK, ix16, wpg);
-#define L3D_LAUNCH(M, B, X, W)                                                                                \
+#define L3D_LAUNCH(M, B, X, W, S)                                                                             \
     do {                                                                                                      \
-        hipError_t e = hipFuncSetAttribute((const void*)k_match_pairs<M, B, X, W>,                            \
+        hipError_t e = hipFuncSetAttribute((const void*)k_match_pairs<M, B, X, W, S>,                         \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
         if (e != hipSuccess) return e;                                                                        \
-        hipLaunchKernelGGL((k_match_pairs<M, B, X, W>), dim3(grid), dim3(kBlock * W), lds, stream, views,     \
+        hipLaunchKernelGGL((k_match_pairs<M, B, X, W, S>), dim3(grid), dim3(kBlock * W), lds, stream, views,  \
                            pairs, work, nwork, slots, row_counts, thr, pools, of);                            \
     } while (0)
+#define L3D_LAUNCH_HOT(X, W) do { if (match_staged(mode, brute)) L3D_LAUNCH(0, false, X, W, true); else L3D_LAUNCH(0, false, X, W, false); } while (0)
     if (mode == 0) {
-        if (brute) L3D_LAUNCH(0, true, false, 1);
-        else if (ix16) { if (wpg == 2) L3D_LAUNCH(0, false, true, 2); else L3D_LAUNCH(0, false, true, 1); }
-        else { if (wpg == 2) L3D_LAUNCH(0, false, false, 2); else L3D_LAUNCH(0, false, false, 1); }
+        if (brute) L3D_LAUNCH(0, true, false, 1, false);
+        else if (ix16) { if (wpg == 2) L3D_LAUNCH_HOT(true, 2); else L3D_LAUNCH_HOT(true, 1); }
+        else { if (wpg == 2) L3D_LAUNCH_HOT(false, 2); else L3D_LAUNCH_HOT(false, 1); }
     }
-    else if (mode == 1) { if (brute) L3D_LAUNCH(1, true, false, 1); else L3D_LAUNCH(1, false, false, 1); }
-    else { if (brute) L3D_LAUNCH(2, true, false, 1); else L3D_LAUNCH(2, false, false, 1); }
+    else if (mode == 1) { if (brute) L3D_LAUNCH(1, true, false, 1, false); else L3D_LAUNCH(1, false, false, 1, false); }
+    else { if (brute) L3D_LAUNCH(2, true, false, 1, false); else L3D_LAUNCH(2, false, false, 1, false); }
+#undef L3D_LAUNCH_HOT
 #undef L3D_LAUNCH
     return hipGetLastError();
 }
@@ -1035,6 +1159,8 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
         const Band b = tgt_band(pc, vt.seg4[seg], slo, shi);
         cp.tgt_perm[pc.t_off + i] = seg;
         cp.tgt_sf[pc.t_off + i] = *(const float4*)&vt.segf[seg];
+        cp.tgt_s4[pc.t_off + i] = vt.seg4[seg];
+        cp.tgt_sd[pc.t_off + i] = *(const SegD*)&vt.segx[seg];
         cp.tgt_band[pc.t_off + i] = make_float2(b.lo, b.hi);
         atomicMin(&cb[2 * (i >> 6)], f2ord(b.lo));
         atomicMax(&cb[2 * (i >> 6) + 1], f2ord(b.hi));
@@ -1349,7 +1475,7 @@ hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t ma
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
 extern "C" void l3d_debug_stats(unsigned long long* out, int reset) {
     hipMemcpyFromSymbol(out, HIP_SYMBOL(l3d::g_stats), sizeof(l3d::g_stats));
-    if (reset) { unsigned long long z[8] = {}; hipMemcpyToSymbol(HIP_SYMBOL(l3d::g_stats), z, sizeof(z)); }
+    if (reset) { unsigned long long z[12] = {}; hipMemcpyToSymbol(HIP_SYMBOL(l3d::g_stats), z, sizeof(z)); }
 }
 extern "C" void l3d_debug_cycles(unsigned long long* out, int n) {
     hipMemcpyFromSymbol(out, HIP_SYMBOL(l3d::g_cycles), (size_t)n * 16);

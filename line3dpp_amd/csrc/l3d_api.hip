@@ -264,7 +264,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_seg_of_g.release(); c->d_huge_u32.release(); c->d_huge_f32.release(); c->d_ledges.release(); c->d_lhyps.release();
     c->d_lsegs.release(); c->d_lcands.release(); c->d_lchdrs.release(); c->d_ltab.release(); c->h_ltab.release();
     c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
-    c->d_chunk_band.release(); c->d_cull_keys.release(); c->d_tgt_sf.release(); c->d_tgt_band.release();
+    c->d_chunk_band.release(); c->d_cull_keys.release(); c->d_tgt_sf.release(); c->d_tgt_band.release(); c->d_tgt_s4.release(); c->d_tgt_sd.release();
     c->d_row_counts.release();
     c->d_seg_base.release(); c->d_gseg_view.release();
     c->d_scal.release();
@@ -506,6 +506,8 @@ static int match_begin_body(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_src_band.reserve(std::max<uint64_t>(cs_off, 1)));
     L3D_HIP_CHECK(c->d_tgt_perm.reserve(std::max<uint64_t>(ct_off, 1)));
     L3D_HIP_CHECK(c->d_tgt_sf.reserve(std::max<uint64_t>(ct_off, 1)));
+    L3D_HIP_CHECK(c->d_tgt_s4.reserve(std::max<uint64_t>(ct_off, 1)));
+    L3D_HIP_CHECK(c->d_tgt_sd.reserve(std::max<uint64_t>(ct_off, 1)));
     L3D_HIP_CHECK(c->d_tgt_band.reserve(std::max<uint64_t>(ct_off, 1)));
     L3D_HIP_CHECK(c->d_chunk_band.reserve(std::max<uint32_t>(cc_off, 1)));
     L3D_HIP_CHECK(c->d_cull_keys.reserve(std::max<uint64_t>(ck_off, 1)));
@@ -582,6 +584,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     L3D_HIP_CHECK(hipEventRecord(c->ev[8], c->stream));
     CullPools pools{c->d_cull.p, c->d_src_perm.p, c->d_src_band.p, c->d_tgt_perm.p, c->d_tgt_sf.p, c->d_tgt_band.p,
                     c->d_chunk_band.p, c->d_cull_keys.p};
+    pools.tgt_s4 = c->d_tgt_s4.p; pools.tgt_sd = c->d_tgt_sd.p;
     if (mode != 0 || c->brute || !maxM) pools.cull = nullptr;
     else {
         static const int no_order = [] { const char* e = std::getenv("L3D_MATCH_ORDER"); return e && std::atoi(e) == 0; }();

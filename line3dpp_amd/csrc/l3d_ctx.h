@@ -124,7 +124,8 @@ struct l3d_ctx {
     DevBuf<PairCull> d_cull;
     DevBuf<uint32_t> d_src_perm, d_tgt_perm;
     DevBuf<float2> d_src_band, d_chunk_band, d_tgt_band;
-    DevBuf<float4> d_tgt_sf;
+    DevBuf<float4> d_tgt_sf, d_tgt_s4;
+    DevBuf<SegD> d_tgt_sd;
     DevBuf<uint32_t> d_item_bucket, d_item_order, d_order_done;   // longest-first launch order (k_order_items)
     DevBuf<uint64_t> d_cull_keys;   // sort scratch of pairs whose views exceed the LDS sort capacity
     bool use_cull = true;

@@ -48,6 +48,13 @@ struct SegX {
     double r1[3], r2[3], n[3], cn, rm[3];
 };  // 13 doubles = 104 B
 
+// the part of SegX the depth test needs (its first ten doubles: a SegX can be read as a SegD); k_cull_prepare keeps a
+// copy of the target view's records in this form in the order in which the match kernel walks them
+struct SegD {
+    double r1[3], r2[3], n[3], cn;
+};  // 80 B
+static_assert(sizeof(SegD) == 80 && sizeof(SegX) == 104, "SegD is the prefix of SegX");
+
 // fp32 pre-filter record of a segment in the target role: end point 1 relative to the image
 // centre and the end-point difference.
 struct __attribute__((aligned(16))) SegF {
@@ -242,6 +249,37 @@ L3D_HD bool exact_depths(const SegX& sx, const SegX& tx, const double* Cs, const
     if (!(ds1 > kEps && ds2 > kEps && dt1 > kEps && dt2 > kEps)) return false;
     out.dp1 = (float)ds1; out.dp2 = (float)ds2; out.dq1 = (float)dt1; out.dq2 = (float)dt2;
     return true;
+}
+
+// ---- the DECISION of the depth test without its divisions ----------------------------------------------------------
+// exact_depths accepts iff num/da > L3D_EPS (IEEE division) for the four (num, da) pairs it forms.  For |da| >= L3D_EPS
+// the quotient exceeds L3D_EPS iff num lies beyond L3D_EPS * da on the side of da's sign -- except when num / da is
+// within a few ulp of L3D_EPS, where the roundings of the division and of the product could disagree.  tri_positive
+// decides with one multiplication per depth and reports `certain = false` in that sliver (|num - eps*da| <= 2^-48 |eps*da|,
+// a hundred times the rounding of either operation), where the caller falls back to the division itself.  Same da, db
+// and num, operation for operation, as tri_depths.
+L3D_HD bool tri_positive(const double* Ca, const double* ra, const double* rb, const double* n, double cn, bool& certain) {
+    d3 N{n[0], n[1], n[2]}, A{ra[0], ra[1], ra[2]}, B{rb[0], rb[1], rb[2]}, C1{Ca[0], Ca[1], Ca[2]};
+    const double da = dot(A, N), db = dot(B, N);
+    if (fabs(da) < kEps || fabs(db) < kEps) return false;          // tri_depths: (-1, -1)
+    const double num = cn - dot(N, C1);
+    const double pa = kEps * da, pb = kEps * db;
+    const double ea = num - pa, eb = num - pb;
+    if (!(fabs(ea) > 3.5527136788005009e-15 * fabs(pa)) || !(fabs(eb) > 3.5527136788005009e-15 * fabs(pb))) certain = false;
+    // num / da > eps  <=>  (da > 0 ? num > eps*da : num < eps*da)
+    return (da > 0.0 ? ea > 0.0 : ea < 0.0) && (db > 0.0 ? eb > 0.0 : eb < 0.0);
+}
+// the decision of exact_depths (all four depths > L3D_EPS) for source record s and target record t (SegX or SegD)
+template <class S, class T>
+L3D_HD bool depths_positive(const S& sx, const T& tx, const double* Cs, const double* Ct) {
+    bool certain = true;
+    const bool a = tri_positive(Cs, sx.r1, sx.r2, tx.n, tx.cn, certain);
+    const bool b = tri_positive(Ct, tx.r1, tx.r2, sx.n, sx.cn, certain);
+    if (certain) return a && b;
+    double ds1, ds2, dt1, dt2;                                      // the sliver: the reference's own arithmetic
+    tri_depths(Cs, sx.r1, sx.r2, tx.n, tx.cn, ds1, ds2);
+    tri_depths(Ct, tx.r1, tx.r2, sx.n, sx.cn, dt1, dt2);
+    return ds1 > kEps && ds2 > kEps && dt1 > kEps && dt2 > kEps;
 }
 
 // full acceptance test of one (src seg, tgt seg) pair: line3D.cc:931-995

@@ -43,6 +43,10 @@ struct CullPools {
     uint32_t* order_done;      // workgroups of k_order_items that have filed their items (zero between launches)
     uint32_t w_base;           // PairCull::w_item0 of the first pair of the launch
     uint32_t cost_max;         // largest Mt of the launch
+    // what the exact tests read of a target, in sorted order as well (the candidates of a wave are neighbours in that
+    // order: gathers by original index miss the L2s on large views -- C4 read 132 x its segment records)
+    float4* tgt_s4;            // [sum Mt] raw segments (x1,y1,x2,y2)
+    SegD* tgt_sd;              // [sum Mt] rays, plane normal, plane offset (the depth test's share of SegX)
 };
 constexpr uint32_t kOrderBuckets = 1024;
 constexpr uint32_t kCullLdsSegs = 16384;   // LDS sort capacity of k_cull_prepare (larger views sort in global memory)

@@ -161,13 +161,13 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
                          // derives global segment ids from it for the phase-B counters it feeds
     DevBuf<unsigned long long> cnt_pack; DevBuf<uint32_t> inv_pos, tie_count; DevBuf<uint2> tie_list; DevBuf<uint64_t> tie_heap;
     DevBuf<double> consts; DevBuf<ViewDev> dv; DevBuf<PairDesc> dp; DevBuf<WorkItem> dw; DevBuf<Slot> ds;
-    DevBuf<PairCull> dc; DevBuf<uint64_t> ckeys; DevBuf<uint32_t> sperm, tperm; DevBuf<float2> sband, tband, cband; DevBuf<float4> tsf;
+    DevBuf<PairCull> dc; DevBuf<uint64_t> ckeys; DevBuf<uint32_t> sperm, tperm; DevBuf<float2> sband, tband, cband; DevBuf<float4> tsf, ts4; DevBuf<SegD> tsd;
     auto cleanup = [&]() {
         for (int i = 0; i < 2; ++i) { seg4[i].release(); segf[i].release(); }
         segx.release(); cnt_pack.release(); inv_pos.release();
         tie_count.release(); tie_list.release(); tie_heap.release();
         consts.release(); dv.release(); dp.release(); dw.release(); ds.release();
-        dc.release(); ckeys.release(); sperm.release(); tperm.release(); sband.release(); tband.release(); cband.release(); tsf.release();
+        dc.release(); ckeys.release(); sperm.release(); tperm.release(); sband.release(); tband.release(); cband.release(); tsf.release(); ts4.release(); tsd.release();
     };
     int rc = [&]() -> int {
         ViewDev hv[2];
@@ -216,7 +216,9 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
             L3D_HIP_CHECK(cband.reserve((Mt + 63) / 64));
             L3D_HIP_CHECK(hipMemcpy(dc.p, &pc, sizeof(pc), hipMemcpyHostToDevice));
             L3D_HIP_CHECK(ckeys.reserve(std::max<uint64_t>(n_keys, 1)));
+            L3D_HIP_CHECK(ts4.reserve(Mt)); L3D_HIP_CHECK(tsd.reserve(Mt));
             pools = CullPools{dc.p, sperm.p, sband.p, tperm.p, tsf.p, tband.p, cband.p, ckeys.p};
+            pools.tgt_s4 = ts4.p; pools.tgt_sd = tsd.p;
             L3D_HIP_CHECK(launch_cull_prepare(dv.p, dp.p, 0, 1, std::max(Ms, Mt), pools, 0));
         }
         // the kernel also applies the orientation filter (slot flags) and feeds the phase-B counters: scratch here

@@ -19,7 +19,7 @@ sc = make_scene(16, 2000, n_neighbors=10, seed=7)
 g = Line3D(); g.add_scene(sc)
 L = _lib.load()
 stats = hasattr(L, "l3d_debug_stats")
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 12)()
 rows = []
 for thr, k in RUNS:
     if stats:
@@ -31,6 +31,7 @@ for thr, k in RUNS:
     if stats:
         L.l3d_debug_stats(out, 0)
         row.update(prefilter_tests=int(out[0]), exact_tests=int(out[1]), passed_overlap=int(out[2]), accepted=int(out[3]),
-                   drains=int(out[4]), band_pairs=int(out[5]), kept_slots=int(out[6]), work_items=int(out[7]))
+                   drains=int(out[4]), band_pairs=int(out[5]), kept_slots=int(out[6]), work_items=int(out[7]),
+                   stage1_drains=int(out[8]), depth_passed=int(out[9]))
     rows.append(row)
 print(json.dumps({"build_info": L.l3d_build_info().decode(), "stats_build": bool(stats), "runs": rows}))
