@@ -127,7 +127,7 @@ def digest_parity(scene, args, l3d):
     exact, fl = FD.result_record(l3d, scene, False)
     r = FD.compare(exact, fl, meta["exact"], floats, H.REL_TOL)
     return {"config": args.config, "checked": True,
-            "against": f"stored record of the reference's own code ({meta['reference_library']} md5 {meta['reference_library_md5']}, "
+            "against": f"stored record of the reference's own code ({meta['reference_library']}, objects md5 {meta.get('reference_objects_md5')}, "
                        f"{meta['seconds']} s on {meta['threads']} threads, tools/ref_digest.py)",
             "scene": f"full {args.config} workload", "ok": r["ok"], "surviving_matches": r["surviving"],
             "set_diff": 0 if not r["differing_views"] else None, "differing_views": r["differing_views"][:16],
@@ -139,11 +139,13 @@ def digest_parity(scene, args, l3d):
 # ---- roofline of k_match_pairs --------------------------------------------------------------------------------------
 # class of the SQ_INSTS_VALU_* counters -> the calibrated stream that prices it (tools/valu_calib.hip)
 _CLASS_OPS = {"ADD_F32": ["add_f32"], "MUL_F32": ["mul_f32"], "FMA_F32": ["fma_f32"], "TRANS_F32": ["rcp_f32", "rsq_f32", "sqrt_f32"],
-              "ADD_F64": ["add_f64"], "MUL_F64": ["mul_f64"], "FMA_F64": ["fma_f64"], "TRANS_F64": ["rcp_f64", "rsq_f64"],
-              "CVT": ["cvt_f64_f32", "cvt_f32_f64"], "INT32": ["add_u32", "and_b32", "lshl_b32"], "INT64": ["lshl_b64"],
-              # everything the class counters do not cover (compares, selects, moves, min/max, lane ops): priced at the
-              # cheapest stream measured -- the choice that makes the roof highest, i.e. the fraction smallest
-              "other": ["mov_b32", "max_f32"]}
+              "ADD_F64": ["add_f64"], "MUL_F64": ["mul_f64"], "FMA_F64": ["fma_f64", "fmac_f64"], "TRANS_F64": ["rcp_f64", "rsq_f64"],
+              "CVT": ["cvt_f64_f32", "cvt_f32_f64"], "INT32": ["add_u32", "and_b32", "lshl_b32", "lshl_add_u32"], "INT64": ["lshl_b64"],
+              # everything the class counters do not cover (compares, selects, moves, min/max, lane ops, ldexp, the
+              # division helpers): the streams measured for such instructions (without VCC hazards); the roof is priced
+              # with the CHEAPEST of them -- the choice that makes the ceiling highest, i.e. the fraction smallest
+              "other": ["mov_b32", "mov_b64", "cndmask_s", "cmp_f32_s", "cmp_f64_s", "min_f32", "max_f32", "max_f64", "readlane",
+                        "writelane", "ldexp_f64", "cmp_class_f64", "div_scale_f64", "div_fmas_f64", "div_fixup_f64"]}
 
 
 def valu_roof(pmc, calib):
@@ -163,11 +165,15 @@ def valu_roof(pmc, calib):
         cyc[k] = min(have) if k == "other" else sum(have) / len(have)
     mean_cycles = sum(mix[k] * cyc[k] for k in mix) / max(total, 1)
     peak = 1024 * 2.4 / mean_cycles
+    other_all = [ops[n]["cycles_per_unit_simd_best"] for n in _CLASS_OPS["other"] if n in ops]
+    mean_if_other_avg = mean_cycles + mix["other"] * (sum(other_all) / len(other_all) - cyc["other"]) / max(total, 1)
     return peak, {"simds": 1024, "clock_ghz": 2.4, "mean_issue_cycles_per_instruction": round(mean_cycles, 3),
+                  "peak_if_other_priced_at_the_mean_of_its_streams": round(1024 * 2.4 / mean_if_other_avg, 1),
                   "cycles_per_class": {k: round(v, 3) for k, v in cyc.items()},
                   "mix_fraction": {k: round(v / max(total, 1), 4) for k, v in mix.items()},
                   "calibration": calib.get("_file"), "note": "issue cycles per wave64 instruction and SIMD measured with "
-                  "single-instruction streams (tools/valu_calib.hip); `other` priced at the cheapest stream"}
+                  "single-instruction streams (tools/valu_calib.hip: all instructions of a launch / (kernel time x measured clock x 1024 "
+                  "SIMDs)); `other` priced at the cheapest of its streams"}
 
 
 def load_json_newest(pattern, pred=lambda d: True):

@@ -25,8 +25,13 @@ o.match_images(); o.compute_affinity()
 secs = time.perf_counter() - t0
 exact, floats = FD.result_record(o, sc, True)
 lib = os.path.join(ROOT, "oracle", "_ref", "libl3d_ref_release.so" if kind == "release" else "libl3d_ref.so")
+_h = hashlib.md5()
+for _f in ("line3D.o", "view.o", "clustering.o"):   # the reference's own translation units (the driver around them may change)
+    _h.update(open(os.path.join(ROOT, "oracle", "_ref", "rel" if kind == "release" else "", _f), "rb").read())
+objs_md5 = _h.hexdigest()
 meta = {"config": cfg, "scene_sha256": FD.scene_hash(sc), "pair_tests": tests,
-        "reference_library": os.path.basename(lib), "reference_library_md5": hashlib.md5(open(lib, "rb").read()).hexdigest(),
+        "reference_library": os.path.basename(lib), "reference_objects_md5": objs_md5,
+        "reference_objects": "oracle/_ref/rel/{line3D,view,clustering}.o (the reference's translation units, oracle/Makefile)",
         "threads": threads, "seconds": round(secs, 1), "M_pair_tests_per_s": round(tests / secs / 1e6, 1),
         "parameters": "matchImages defaults (sigma_p 2.5, sigma_a 10, kNN 10, epipolar_overlap 0.25) + computeAffinity",
         "exact": exact}

@@ -51,6 +51,17 @@ struct WaveTime { unsigned long long cycles, realtime; };
 #define OP_cmp_f32(x) asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc");
 #define OP_cndmask_b32(x) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(b) : "vcc");
 #define OP_mov_b32(x) asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(b));
+// the same without VCC (no compiler-inserted s_nop between the instructions): SGPR-pair results / masks
+#define OP_cmp_f32_s(x) { unsigned long long m_; asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m_) : "v"(x), "v"(b)); }
+#define OP_cndmask_s(x) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(b), "s"(0x5555555555555555ull));
+#define OP_min_f32(x) asm volatile("v_min_f32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_readlane(x) { unsigned r_; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(r_) : "v"(x)); }
+#define OP_writelane(x) asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(x) : "s"(7u));
+DEF_KERNEL(cmp_f32_s, float, OP_cmp_f32_s)
+DEF_KERNEL(cndmask_s, float, OP_cndmask_s)
+DEF_KERNEL(min_f32, float, OP_min_f32)
+DEF_KERNEL(readlane, float, OP_readlane)
+DEF_KERNEL(writelane, float, OP_writelane)
 DEF_KERNEL(fma_f32, float, OP_fma_f32)
 DEF_KERNEL(mul_f32, float, OP_mul_f32)
 DEF_KERNEL(add_f32, float, OP_add_f32)
@@ -78,6 +89,16 @@ DEF_KERNEL(mov_b32, float, OP_mov_b32)
 #define OP_div_fmas_f64(x) asm volatile("v_div_fmas_f64 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c) : "vcc");
 #define OP_div_fixup_f64(x) asm volatile("v_div_fixup_f64 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
 #define OP_lshl_b64(x) asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(x));
+#define OP_mov_b64(x) asm volatile("v_mov_b64 %0, %1" : "=v"(x) : "v"(b));
+#define OP_ldexp_f64(x) asm volatile("v_ldexp_f64 %0, %0, 1" : "+v"(x));
+#define OP_cmp_f64_s(x) { unsigned long long m_; asm volatile("v_cmp_gt_f64_e64 %0, %1, %2" : "=s"(m_) : "v"(x), "v"(b)); }
+#define OP_cmp_class_f64(x) { unsigned long long m_; asm volatile("v_cmp_class_f64_e64 %0, %1, %2" : "=s"(m_) : "v"(x), "v"(0x260u)); }
+#define OP_fmac_f64(x) asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+DEF_KERNEL(mov_b64, double, OP_mov_b64)
+DEF_KERNEL(ldexp_f64, double, OP_ldexp_f64)
+DEF_KERNEL(cmp_f64_s, double, OP_cmp_f64_s)
+DEF_KERNEL(cmp_class_f64, double, OP_cmp_class_f64)
+DEF_KERNEL(fmac_f64, double, OP_fmac_f64)
 DEF_KERNEL(pk_fma_f32, double, OP_pk_fma_f32)
 DEF_KERNEL(pk_mul_f32, double, OP_pk_mul_f32)
 DEF_KERNEL(pk_add_f32, double, OP_pk_add_f32)
@@ -100,6 +121,10 @@ DEF_KERNEL(lshl_b64, double, OP_lshl_b64)
 #define OP_mul_lo_u32(x) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x) : "v"(b));
 #define OP_mbcnt(x) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(x) : "v"(b));
 #define OP_cmp_u32(x) asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc");
+#define OP_lshl_add_u32(x) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(x) : "v"(b));
+#define OP_cmp_u32_s(x) { unsigned long long m_; asm volatile("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(m_) : "v"(x), "v"(b)); }
+DEF_KERNEL(lshl_add_u32, unsigned, OP_lshl_add_u32)
+DEF_KERNEL(cmp_u32_s, unsigned, OP_cmp_u32_s)
 DEF_KERNEL(add_u32, unsigned, OP_add_u32)
 DEF_KERNEL(and_b32, unsigned, OP_and_b32)
 DEF_KERNEL(lshl_b32, unsigned, OP_lshl_b32)
@@ -206,6 +231,9 @@ int main(int argc, char** argv) {
         O(fma_f32, "FMA_F32", 0), O(mul_f32, "MUL_F32", 0), O(add_f32, "ADD_F32", 0), O(max_f32, "other", 0),
         O(rcp_f32, "TRANS_F32", 0), O(rsq_f32, "TRANS_F32", 0), O(sqrt_f32, "TRANS_F32", 0), O(exp_f32, "TRANS_F32", 0),
         O(cmp_f32, "other", 0), O(cndmask_b32, "other", 0), O(mov_b32, "other", 0),
+        O(cmp_f32_s, "other", 0), O(cndmask_s, "other", 0), O(min_f32, "other", 0), O(readlane, "other", 0), O(writelane, "other", 0),
+        O(mov_b64, "other", 1), O(ldexp_f64, "other", 1), O(cmp_f64_s, "other", 1), O(cmp_class_f64, "other", 1), O(fmac_f64, "FMA_F64", 1),
+        O(lshl_add_u32, "INT32", 2), O(cmp_u32_s, "INT32", 2),
         O(pk_fma_f32, "FMA_F32 (packed)", 1), O(pk_mul_f32, "MUL_F32 (packed)", 1), O(pk_add_f32, "ADD_F32 (packed)", 1),
         O(fma_f64, "FMA_F64", 1), O(mul_f64, "MUL_F64", 1), O(add_f64, "ADD_F64", 1), O(max_f64, "other", 1),
         O(rcp_f64, "TRANS_F64", 1), O(rsq_f64, "TRANS_F64", 1), O(sqrt_f64, "TRANS_F64", 1), O(cmp_f64, "other", 1),
