@@ -332,13 +332,15 @@ def main():
             # tests + epilogue work for the slots that are kept -- priced with the fitted per-unit VALU costs
             # (profiles/*_valu_fit.json) -- over the VALU instructions the launch executed
             uv = (cand["band_pairs"] / 64.0) * fit["valu_per_target_visit"] + \
-                 (cand["kept_slots"] / 64.0) * (fit["valu_per_drain"] + fit["valu_per_epilogue_pass"])
+                 (cand["kept_slots"] / 64.0) * ((fit.get("valu_per_stage1_drain") or 0.0) + fit["valu_per_drain"] +
+                                               fit["valu_per_epilogue_pass"])
             useful = {"useful_frac": round(uv / pmc["valu_insts_per_launch"], 4),
                       "useful_valu_insts": round(uv), "executed_valu_insts": pmc["valu_insts_per_launch"],
                       "band_pairs": cand["band_pairs"], "prefilter_tests": cand.get("prefilter_tests"),
                       "kept_slots": cand["kept_slots"], "exact_tests": cand.get("exact_tests"), "accepted": cand.get("accepted"),
                       "exact_tests_over_accepted": round(cand["exact_tests"] / max(cand["accepted"], 1), 3) if cand.get("exact_tests") else None,
-                      "valu_per_target_visit": fit["valu_per_target_visit"], "valu_per_drain": fit["valu_per_drain"],
+                      "valu_per_target_visit": fit["valu_per_target_visit"], "valu_per_stage1_drain": fit.get("valu_per_stage1_drain"),
+                      "valu_per_drain": fit["valu_per_drain"],
                       "valu_per_epilogue_pass": fit["valu_per_epilogue_pass"], "fit": fit["_file"]}
         roofline = {"bound": "valu", "achieved": round(valu_achieved, 2), "peak": round(peak, 1),
                     "unit": "G wave64 VALU instr/s", "frac": round(valu_achieved / peak, 4), "peak_basis": basis,

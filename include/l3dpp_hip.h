@@ -210,6 +210,11 @@ int l3d_get_sparse_matrix(l3d_ctx*, int sort_by_row, l3d_float4* entries, int32_
  * (line3D.cc:2196-2211) takes it from JacobiSVD -- this library's closed-form solver, checked against LAPACK on the CPU */
 int l3d_principal_direction(const double S9[9], double dir3[3]);
 
+/* test hook (device): the unscaled IEEE division / square root of the exact tests (l3d_dev.h: rcp_refined, div_by,
+ * sqrt_unscaled) against the compiler's own expansions on n random operand sets; counts[3] = results whose bits differ
+ * (single divisions, paired divisions, square roots) -- all zero on a correct build */
+int l3d_selftest_arith(int device, uint64_t n, uint64_t seed, uint64_t counts[3]);
+
 /* test hook: route every segment pair through the exact double-precision test (no fp32 pre-filter);
  * used by the tests to prove that the pre-filter never loses a match */
 int l3d_set_brute_force(l3d_ctx*, int on);

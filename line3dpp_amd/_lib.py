@@ -52,7 +52,7 @@ EXPORTS = [
     "l3d_output_filename", "l3d_save_3d_lines_txt", "l3d_save_result_stl", "l3d_save_result_obj",
     "l3d_get_segment_coords2d", "l3d_find_collinear_segments", "l3d_score_matches",
     "l3d_slot_index_buffer", "l3d_pack_slot_indices", "l3d_expand_slot_indices", "l3d_match_abort", "l3d_save_3d_lines_bin", "l3d_lists_shard",
-    "l3d_principal_direction",
+    "l3d_principal_direction", "l3d_selftest_arith",
 ]
 
 _lib = None
@@ -115,6 +115,7 @@ def load():
     L.l3d_get_segment_coords2d.argtypes = [vp, u32, u32, vp]
     L.l3d_find_collinear_segments.argtypes = [i32, vp, u32, f32, vp, vp, u64, vp]
     L.l3d_principal_direction.argtypes = [vp, vp]
+    L.l3d_selftest_arith.argtypes = [i32, u64, u64, vp]
     L.l3d_score_matches.argtypes = [i32, vp, u32, vp, vp, vp, u32, vp, vp, f32, f32, vp]
     for name in EXPORTS:
         fn = getattr(L, name)

@@ -728,7 +728,10 @@ __global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views,
         }
         n_h += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(first));
     }
-    const uint32_t opool = lp.pool0 + (blockIdx.x >> 2) % lp.npools; // spread the reservations independently of the input pool
+    // output pool: spread over ALL pools of the pass whatever the fill of the input pools (blockIdx.x only reaches the
+    // fullest input pool's count: on small scenes `(blockIdx.x >> 2) % npools` left most pools empty and overflowed the
+    // rest -- the one pool retry of a first C1 call)
+    const uint32_t opool = lp.pool0 + (blockIdx.x + 61u * blockIdx.y) % lp.npools;
     uint32_t eb = 0, hb = 0, sb = 0;
     if (lane == 0) {
         eb = atomicAdd(&lp.cnt[opool * 16 + 0], n_acc);

@@ -116,13 +116,21 @@ __device__ __forceinline__ bool prefilter(float e1x, float e1y, float e1z, float
     float d2 = __builtin_fmaf(e2x, q.z, e2y * q.w);
     float r1 = __builtin_amdgcn_rcpf(d1);
     float r2 = __builtin_amdgcn_rcpf(d2);
+    // inner = min(hi,1) - max(lo,0) and outer = max(hi,1) - min(lo,0) of [lo, hi] = the two intersection positions, in
+    // a form without min / max instructions (half rate on this hardware, tools/valu_calib.hip): for intervals that meet
+    // [0, 1] at all inner = |clamp(s1) - clamp(s2)| (clamp is monotone and free as the output modifier of the multiply)
+    // and inner + outer = |s1 - s2| + 1 (min + max of two numbers is their sum); for intervals that do not, the true
+    // overlap is zero and any answer is conservative.  NaN / inf from a degenerate d make u NaN -> candidate.
     float s1 = a1 * r1, s2 = a2 * r2;
-    float lo = fminf(s1, s2), hi = fmaxf(s1, s2);
-    float inner = fminf(hi, 1.0f) - fmaxf(lo, 0.0f);
-    float outer = fmaxf(hi, 1.0f) - fminf(lo, 0.0f);
+    float c1, c2;
+    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(c1) : "v"(a1), "v"(r1));
+    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(c2) : "v"(a2), "v"(r2));
+    float inner = fabsf(c1 - c2);
+    float w = fabsf(s1 - s2) + 1.0f;                      // inner + outer
     float rmax = fmaxf(fabsf(r1), fabsf(r2));
     float t = __builtin_fmaf(-kKappa, rmax, thr - kKappa0);
-    float u = __builtin_fmaf(-t, outer, inner);
+    // inner - t * outer = inner * (1 + t) - t * w
+    float u = __builtin_fmaf(inner, 1.0f + t, -(t * w));
     return !(u <= 0.0f);
 }
 
@@ -139,9 +147,9 @@ __device__ __forceinline__ uint32_t fuse_orientation(const OrientFuse& of, const
                                                      const SegX& sx, const SegX& tx, const PairResult& res,
                                                      bool hands_inverse, uint32_t g_tgt, uint32_t& ipos) {
     ipos = kEmpty;
-    if (!orientation_ok(Cs, sx, res.dp1, res.dp2, of.thr)) return 0u;
+    if (!orientation_ok_fast(Cs, sx, res.dp1, res.dp2, of.thr)) return 0u;
     uint32_t flags = kSlotAlive;
-    if (hands_inverse && orientation_ok(Ct, tx, res.dq1, res.dq2, of.thr)) {
+    if (hands_inverse && orientation_ok_fast(Ct, tx, res.dq1, res.dq2, of.thr)) {
         flags |= kSlotInvAlive;
         ipos = take_inverse_position(of, g_tgt);
     }
@@ -184,6 +192,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     const ViewDev& vs = views[pd.src];
     const ViewDev& vt = views[pd.tgt];
     const uint32_t K = pd.K, Ms = pd.Ms, Mt = pd.Mt;
+    const bool fastm = (pd.flags & kPairFastMath) != 0;     // l3d_dev.h: IEEE division / sqrt without operand scaling
     typedef typename IdxT<IX16>::type idx_t;
     static_assert(!STAGED || (MODE == 0 && !BRUTE), "the two-stage candidate pipeline exists for the bounded-kNN variant");
     Lds<IX16> L = carve<IX16>((L3D_LDS char*)smem, MODE == 0 ? K : 0, WPG, STAGED);
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
         float ovv = 0.0f;
         if (has) {
             const float4 s4 = vs.seg4[sg], t4 = ts4[tg];
-            const float ov = exact_overlap(F, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w);
+            const float ov = exact_overlap(F, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w, fastm);
             // a full row only admits overlaps that reach its K-th best (minov == thr while the row is not full); an overlap
             // EQUAL to the K-th best goes on to the insertion: a tie at the kNN-th place flags the row for the exact replay
             const float need = L.minov[sl];
@@ -643,14 +652,14 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
             const SegX* ptx = vt.segx + xj;
             asm volatile("" : "+v"(psx), "+v"(ptx));
             PairResult res{};
-            exact_depths(*psx, *ptx, vs.C, vt.C, res);
+            exact_depths(*psx, *ptx, vs.C, vt.C, res, fastm);
             o.tgt_seg = xj; o.overlap = oj;
             o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
             asm volatile("" : "+v"(psx));
-            if (orientation_ok(vs.C, *psx, res.dp1, res.dp2, of.thr)) {
+            if (orientation_ok_fast(vs.C, *psx, res.dp1, res.dp2, of.thr)) {
                 o.flags = kSlotAlive;
                 asm volatile("" : "+v"(ptx));
-                if (hands_inverse && orientation_ok(vt.C, *ptx, res.dq1, res.dq2, of.thr)) {
+                if (hands_inverse && orientation_ok_fast(vt.C, *ptx, res.dq1, res.dq2, of.thr)) {
                     o.flags |= kSlotInvAlive;
                     ipos = take_inverse_position(of, gt + xj);
                 }

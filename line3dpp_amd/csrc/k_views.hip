@@ -58,13 +58,13 @@ __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* 
         if (s.tgt_seg != kEmpty) {
             const ViewDev& vs = views[pd.src];
             uint32_t flags = 0;
-            if (orientation_ok(vs.C, vs.segx[row], s.dp1, s.dp2, othr)) {
+            if (orientation_ok_fast(vs.C, vs.segx[row], s.dp1, s.dp2, othr)) {
                 flags = kSlotAlive;
                 alive = true;
                 // inverse copy: only towards a view that is processed later (line3D.cc:1680)
                 if (pd.tgt > pd.src) {
                     const ViewDev& vt = views[pd.tgt];
-                    if (orientation_ok(vt.C, vt.segx[s.tgt_seg], s.dq1, s.dq2, othr)) {
+                    if (orientation_ok_fast(vt.C, vt.segx[s.tgt_seg], s.dq1, s.dq2, othr)) {
                         flags |= kSlotInvAlive;
                         // one 64-bit atomic: low word = list length, high word = number of inverse refs; the old
                         // high word is this slot's position among the inverse refs of the target segment

@@ -313,6 +313,7 @@ int l3d_add_view(l3d_ctx* c, uint32_t camID, const float* segs4, uint32_t M, con
     auto v = std::make_unique<HostView>();
     v->cam = camID; v->M = M;
     v->segs.assign(segs4, segs4 + 4 * (size_t)M);
+    for (float x : v->segs) v->coord_max = std::isfinite(x) ? std::fmax(v->coord_max, (double)std::fabs(x)) : INFINITY;
     v->width = width; v->height = height;
     v->initial_median_depth = (float)std::fmax(std::fabs(median_depth), kEps);
     init_view(*v, K, R, t);
@@ -442,7 +443,14 @@ static int match_begin_body(l3d_ctx* c) {
             pd.row_off = row_off; pd.slot_off = slot_off;
             {   // |C_src - C_tgt|, rounded up (k_lists.hip: window_sq)
                 const double d = norm(v->C - t->C);
-                pd.cc_dist = std::nextafterf((float)(d * (1.0 + 1e-6)), INFINITY); pd.pad = 0;
+                pd.cc_dist = std::nextafterf((float)(d * (1.0 + 1e-6)), INFINITY);
+                // kPairFastMath (l3d_dev.h): everything that enters the pair's exact arithmetic is finite and far from the
+                // ends of the double range, so that IEEE division / sqrt need no operand scaling
+                bool fm = v->coord_max <= 1e7 && t->coord_max <= 1e7;
+                for (int k = 0; k < 9 && fm; ++k) { const double a = std::fabs(pd.F[k]); fm = std::isfinite(a) && (a == 0.0 || (a >= 1e-30 && a <= 1e30)); }
+                for (double cval : {v->C.x, v->C.y, v->C.z, t->C.x, t->C.y, t->C.z}) fm = fm && std::isfinite(cval) && std::fabs(cval) <= 1e30;
+                static const bool no_fast = std::getenv("L3D_NO_FASTMATH") != nullptr;   // diagnostic switch: the compiler's own expansions
+                pd.flags = (fm && !no_fast) ? kPairFastMath : 0u;
             }
             slot_off += (uint64_t)pd.Ms * pd.K; row_off += pd.Ms;
             const uint32_t pi = (uint32_t)c->pairs.size();

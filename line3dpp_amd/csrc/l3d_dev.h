@@ -39,6 +39,47 @@ L3D_HD d3 mul33(const double* A, const d3& v) {
             (A[6] * v.x + A[7] * v.y) + A[8] * v.z};
 }
 
+// ---- IEEE double division and square root without the range scaffolding ------------------------------------------------
+// hipcc expands a / b into v_div_scale x2, v_rcp_f64, two Newton steps, q = a*y, r = fma(-b,q,a), v_div_fmas, v_div_fixup
+// (59 issue cycles per wave, tools/valu_calib.hip) and sqrt into v_rsq_f64 + Goldschmidt with ldexp scaling and a class
+// select (86).  The scale / fixup instructions only act on operands whose exponents are extreme (|exponent| beyond
+// several hundred: quotients or intermediate reciprocals that would leave the normal range); for everything else
+// they pass their inputs through and the sequence below IS the compiler's sequence, bit for bit.  The `fast` forms are
+// used where the host has checked the ranges of what enters the arithmetic (PairDesc::flags kPairFastMath: finite F
+// with entries in [1e-30, 1e30] or zero, pixel coordinates and camera centres below 1e7 / 1e30) and the reference's own
+// guards bound the denominators from below (|x.z| > L3D_EPS, |n.r| >= L3D_EPS); a reciprocal is shared by the divisions
+// that have the same denominator.  Host code (tests, restated helpers) always takes the plain operators.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double rcp_refined(double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0); y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0); y = __builtin_fma(y, e, y);
+    return y;
+}
+__device__ __forceinline__ double div_by(double a, double b, double y) {   // a / b, y = rcp_refined(b)
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+__device__ __forceinline__ double sqrt_unscaled(double x) {   // x == 0 or x in the normal range far from its ends
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x); g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x); g = __builtin_fma(d, h, g);
+    return x == 0.0 ? x : g;
+}
+#define L3D_DIV2(fast, a1, a2, b, o1, o2) do { if (fast) { const double y_ = rcp_refined(b); o1 = div_by(a1, b, y_); o2 = div_by(a2, b, y_); } else { o1 = (a1) / (b); o2 = (a2) / (b); } } while (0)
+#define L3D_DIV(fast, a, b) ((fast) ? div_by(a, b, rcp_refined(b)) : (a) / (b))
+#define L3D_SQRT(fast, x) ((fast) ? sqrt_unscaled(x) : sqrt(x))
+#else
+#define L3D_DIV2(fast, a1, a2, b, o1, o2) do { o1 = (a1) / (b); o2 = (a2) / (b); } while (0)
+#define L3D_DIV(fast, a, b) ((a) / (b))
+#define L3D_SQRT(fast, x) sqrt(x)
+#endif
+constexpr uint32_t kPairFastMath = 1u;   // PairDesc::flags: the operands of this pair's exact tests are inside the range above
+
 // ---- device-resident per-segment records ------------------------------------------------
 // exact (double) invariants of one 2D segment of one view; built by k_prep_view after
 // translate().  rays = normalize(RtKinv * p) (view.cc:317-321); n = normalize(r1 x r2) and
@@ -103,7 +144,7 @@ struct PairDesc {
     uint32_t row_off;   // first row of this pair in the per-row count array (kNN <= 0 mode)
     uint64_t slot_off;  // first slot of this pair in the slot buffer
     float cc_dist;      // |C_src - C_tgt| rounded up: bounds |P - C_other| of a hypothesis from its depth (k_lists.hip)
-    uint32_t pad;
+    uint32_t flags;     // kPairFastMath
 };
 
 // ---- phase-B records ------------------------------------------------------------------------
@@ -164,7 +205,7 @@ L3D_HD bool point_on_segment(double xx, double xy, double p1x, double p1y, doubl
 // is monotone in x, so when the largest squared distance exceeds every other one by more than 2^-21
 // relative (=> their square roots differ by more than one float ulp) the winner is known without the
 // other five square roots; only near-ties walk the reference's loop literally.  Same result bit for bit.
-L3D_HD float mutual_overlap(const double px[4], const double py[4]) {
+L3D_HD float mutual_overlap(const double px[4], const double py[4], bool fast = false) {
     if (!(point_on_segment(px[0], py[0], px[2], py[2], px[3], py[3]) ||
           point_on_segment(px[1], py[1], px[2], py[2], px[3], py[3]) ||
           point_on_segment(px[2], py[2], px[0], py[0], px[1], py[1]) ||
@@ -189,9 +230,9 @@ L3D_HD float mutual_overlap(const double px[4], const double py[4]) {
         else if (d2[k] > second) second = d2[k];
     }
     if (second < m2 * (1.0 - 4.76837158203125e-7)) {   // 2^-21: no float tie possible
-        const float max_dist = (float)sqrt(m2);
+        const float max_dist = (float)L3D_SQRT(fast, m2);
         if (max_dist < 1.0f) return 0.0f;
-        return (float)(sqrt(inner2) / (double)max_dist);
+        return (float)L3D_DIV(fast, L3D_SQRT(fast, inner2), (double)max_dist);
     }
     // near-tie: the reference's loop, literally
     float max_dist = 0.0f;
@@ -217,35 +258,37 @@ struct PairResult {
 // segment (raw float pixels), F row-major.  Returns the overlap score (0 when the epipolar
 // intersection is invalid).
 L3D_HD float exact_overlap(const double* F, float sx1, float sy1, float sx2, float sy2, float tx1, float ty1,
-                           float tx2, float ty2) {
+                           float tx2, float ty2, bool fast = false) {
     d3 p1{(double)sx1, (double)sy1, 1.0}, p2{(double)sx2, (double)sy2, 1.0};
     d3 e1 = mul33(F, p1), e2 = mul33(F, p2);
     d3 q1{(double)tx1, (double)ty1, 1.0}, q2{(double)tx2, (double)ty2, 1.0};
     d3 l2 = cross(q1, q2);
     d3 x1 = cross(l2, e1), x2 = cross(l2, e2);
     if (!(fabs(x1.z) > kEps && fabs(x2.z) > kEps)) return 0.0f;
-    double px[4] = {x1.x / x1.z, x2.x / x2.z, q1.x, q2.x};
-    double py[4] = {x1.y / x1.z, x2.y / x2.z, q1.y, q2.y};
-    return mutual_overlap(px, py);
+    double px[4], py[4];
+    L3D_DIV2(fast, x1.x, x1.y, x1.z, px[0], py[0]);
+    L3D_DIV2(fast, x2.x, x2.y, x2.z, px[1], py[1]);
+    px[2] = q1.x; px[3] = q2.x; py[2] = q1.y; py[3] = q2.y;
+    return mutual_overlap(px, py, fast);
 }
 
 // Line3D::triangulationDepths, line3D.cc:1168-1193, with the per-segment invariants hoisted:
 // depths of the two rays ra, rb (camera centre Ca) w.r.t. the plane (n, cn = Cplane.n).
 L3D_HD void tri_depths(const double* Ca, const double* ra, const double* rb, const double* n, double cn,
-                       double& d1, double& d2) {
+                       double& d1, double& d2, bool fast = false) {
     d3 N{n[0], n[1], n[2]}, A{ra[0], ra[1], ra[2]}, B{rb[0], rb[1], rb[2]}, C1{Ca[0], Ca[1], Ca[2]};
     double da = dot(A, N), db = dot(B, N);
     if (fabs(da) < kEps || fabs(db) < kEps) { d1 = -1.0; d2 = -1.0; return; }
     double num = cn - dot(N, C1);
-    d1 = num / da;
-    d2 = num / db;
+    d1 = L3D_DIV(fast, num, da);
+    d2 = L3D_DIV(fast, num, db);
 }
 
 // depth part of the acceptance test: line3D.cc:960-980 (both triangulations, all four depths > 1e-12)
-L3D_HD bool exact_depths(const SegX& sx, const SegX& tx, const double* Cs, const double* Ct, PairResult& out) {
+L3D_HD bool exact_depths(const SegX& sx, const SegX& tx, const double* Cs, const double* Ct, PairResult& out, bool fast = false) {
     double ds1, ds2, dt1, dt2;
-    tri_depths(Cs, sx.r1, sx.r2, tx.n, tx.cn, ds1, ds2);
-    tri_depths(Ct, tx.r1, tx.r2, sx.n, sx.cn, dt1, dt2);
+    tri_depths(Cs, sx.r1, sx.r2, tx.n, tx.cn, ds1, ds2, fast);
+    tri_depths(Ct, tx.r1, tx.r2, sx.n, sx.cn, dt1, dt2, fast);
     if (!(ds1 > kEps && ds2 > kEps && dt1 > kEps && dt2 > kEps)) return false;
     out.dp1 = (float)ds1; out.dp2 = (float)ds2; out.dq1 = (float)dt1; out.dq2 = (float)dt2;
     return true;
@@ -319,6 +362,25 @@ L3D_HD bool orientation_ok(const double* C, const SegX& sx, float d1, float d2, 
     const Seg3 s = unproject(C, sx.r1, sx.r2, d1, d2);
     const double dp = fmin(fmax(dot(d3{sx.rm[0], sx.rm[1], sx.rm[2]}, s.dir), -1.0), 1.0);
     return dp >= t.lo && dp <= t.hi;
+}
+// The same DECISION without the two square roots and three divisions of unproject (norm, normalized): with v = P2 - P1,
+// c = rm . v and n2 = v . v the reference's dp is c / sqrt(n2) up to a few ulp, and dp in [lo, hi] with lo < 0 < hi
+// (cos(31 PI/32) and cos(PI/32): checked by the caller of this form) is c^2 <= (c < 0 ? lo^2 : hi^2) * n2.  Within
+// 1e-11 relative of that boundary -- four orders of magnitude more than the rounding of either form -- and for segments
+// whose float length is not clearly above L3D_EPS, the reference's own arithmetic decides (orientation_ok).  v is
+// computed operation for operation as unproject computes it.
+L3D_HD bool orientation_ok_fast(const double* C, const SegX& sx, float d1, float d2, const OrientThr t) {
+    const d3 c{C[0], C[1], C[2]};
+    const d3 a = c + d3{sx.r1[0], sx.r1[1], sx.r1[2]} * (double)d1;
+    const d3 b = c + d3{sx.r2[0], sx.r2[1], sx.r2[2]} * (double)d2;
+    const d3 v = b - a;
+    const double n2 = dot(v, v);
+    const double cc = dot(d3{sx.rm[0], sx.rm[1], sx.rm[2]}, v);
+    const double T = cc < 0.0 ? t.lo * t.lo : t.hi * t.hi;
+    const double lhs = cc * cc, rhs = T * n2;
+    // (n2 > 1e-20: the float length sqrt(n2) is far above L3D_EPS = 1e-12; NaN fails every comparison -> exact path)
+    if (n2 > 1e-20 && fabs(lhs - rhs) > 1e-11 * rhs) return lhs < rhs;
+    return orientation_ok(C, sx, d1, d2, t);
 }
 
 // (overlap desc, tgt asc) total order used for the kNN selection of rows WITHOUT equal overlaps; rows with equal

@@ -122,6 +122,7 @@ struct HostView {
     d3 t{0, 0, 0}, C{0, 0, 0}, pp{0, 0, 0};
     uint32_t width = 0, height = 0;
     float initial_median_depth = 0, k = 0, median_depth = 0;
+    double coord_max = 0.0;             // largest |coordinate| of the view's segments (inf if any is not finite): kPairFastMath
     std::vector<uint32_t> fixed_nbrs;   // fixed_visual_neighbors_[cam]
     std::set<uint32_t> visual_nbrs;     // visual_neighbors_[cam]
     // device

@@ -186,6 +186,7 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         PairDesc pd;
         std::memcpy(pd.F, F, 72);
         pd.src = 0; pd.tgt = 1; pd.Ms = Ms; pd.Mt = Mt; pd.K = (uint32_t)kNN; pd.row_off = 0; pd.slot_off = 0;
+        pd.cc_dist = 0.0f; pd.flags = 0;   // (the seam entry keeps the compiler's own division / sqrt expansions)
         std::vector<WorkItem> work;
         for (uint32_t s0 = 0; s0 < Ms; s0 += kMatchRows) work.push_back(WorkItem{0, s0});
         if (match_lds_bytes(0, pd.K, false, match_waves_per_group(0, false, (uint32_t)work.size())) > 160 * 1024)

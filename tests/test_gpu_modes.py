@@ -166,3 +166,17 @@ def test_repeated_calls_and_a_growing_scene_see_what_the_reference_sees():
     step(dict(kNN=4), sc.views)  # (3) other slot layout
     r2 = step(dict(), sc.views)  # (4) back
     assert r2["surviving"] == r1["surviving"]
+
+
+def test_unscaled_division_and_sqrt_equal_the_compilers_expansions_on_the_device():
+    """l3d_dev.h: the exact tests of a pair whose operands the host has range-checked (kPairFastMath) divide and take
+    square roots without the operand scaling of the compiler's IEEE expansions (59 -> 29-46 and 86 -> 66 issue cycles,
+    tools/valu_calib.hip).  On 4e8 operand sets across and beyond that range -- exact zeros, denominators at L3D_EPS,
+    quotients next to 1, perfect squares -- every result must have the bits of `a / b` and `sqrt(x)` as hipcc compiles
+    them for the same device."""
+    import ctypes as C
+    from line3dpp_amd import _lib
+    L = _lib.load()
+    counts = (C.c_uint64 * 3)()
+    assert L.l3d_selftest_arith(0, 100_000_000, 20260925, counts) == 0
+    assert list(counts) == [0, 0, 0], list(counts)

@@ -25,3 +25,16 @@ def test_division_free_depth_decision_equals_the_reference_arithmetic(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "identical" in out.stdout and " 0 mismatches" in out.stdout
+
+
+def test_division_free_orientation_decision_equals_the_reference_arithmetic(tmp_path):
+    """l3d_dev.h: orientation_ok_fast (checkMatchOrientation's keep / drop decision, line3D.cc:811-858 with
+    View::segmentQualityAngle and unprojectSegment, as c^2 <= cos^2 * |v|^2 with a fallback to the reference's own
+    arithmetic near the thresholds and for near-zero-length segments) against orientation_ok on 2.5 million cases incl.
+    directions within a few ulp of both thresholds."""
+    exe = str(tmp_path / "orient_sign")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                           os.path.join(ROOT, "tests", "cpp", "orient_sign.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "identical" in out.stdout and " 0 mismatches" in out.stdout

@@ -22,16 +22,22 @@ assert len(ds) == len(runs), (len(ds), len(runs))
 K = [r["kNN"] for r in runs]
 # units: target visits of a wave (64 pre-filter tests each), drains (up to 64 exact tests each), epilogue passes of a wave
 # (64 (row, slot) items each: 64 rows x kNN items per work item = kNN passes, whatever the waves per item), waves
-A = np.array([[r["prefilter_tests"] / 64.0, r["drains"], r["work_items"] * k, d_["SQ_WAVES"]] for r, k, d_ in zip(runs, K, ds)])
+A = np.array([[r["prefilter_tests"] / 64.0, r.get("stage1_drains", 0), r["drains"], r["work_items"] * k, d_["SQ_WAVES"]]
+              for r, k, d_ in zip(runs, K, ds)])
+if not A[:, 1].any():      # single-stage build: no stage-1 column
+    A = np.delete(A, 1, axis=1)
 y = np.array([d_["SQ_INSTS_VALU"] for d_ in ds])
 x, res, rank, sv = np.linalg.lstsq(A, y, rcond=None)
 pred = A @ x
 out = {"_comment": "k_match_pairs: SQ_INSTS_VALU (product build, rocprofv3) of 12 runs of one 16-view x 2000-segment scene "
-                   "(epipolar-overlap threshold x kNN) fitted as a*target_visits + b*drains + e*epilogue_passes + w*waves; "
+                   "(epipolar-overlap threshold x kNN) fitted as a*target_visits + b1*stage1_drains (depth decision) + b*drains (exact "
+                   "overlap + insertion) + e*epilogue_passes + w*waves; "
                    "unit counts from the -DL3D_STATS build of the same sources",
        "build_info": pr["build_info"], "stats_build_info": st["build_info"],
-       "valu_per_target_visit": round(float(x[0]), 2), "valu_per_drain": round(float(x[1]), 1),
-       "valu_per_epilogue_pass": round(float(x[2]), 1), "valu_per_wave_fixed": round(float(x[3]), 1),
+       "valu_per_target_visit": round(float(x[0]), 2),
+       "valu_per_stage1_drain": round(float(x[1]), 1) if len(x) == 5 else None,
+       "valu_per_drain": round(float(x[-3]), 1),
+       "valu_per_epilogue_pass": round(float(x[-2]), 1), "valu_per_wave_fixed": round(float(x[-1]), 1),
        "max_rel_residual": round(float(np.max(np.abs(pred - y) / y)), 4),
        "runs": [dict(r, **{"SQ_INSTS_VALU": d_["SQ_INSTS_VALU"], "SQ_WAVES": d_["SQ_WAVES"], "kernel": d_["kernel"],
                            "fit": round(float(p))}) for r, d_, p in zip(runs, ds, pred)]}
