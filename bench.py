@@ -8,8 +8,11 @@ of Ms*Mt, divided by the wall time of the step, whole job over all ranks.  Segme
 in HBM before the timed region (uploaded at addImage).  Workload at N=1: BASELINE config C1
 (synthetic 64 views x 2000 segments/view, 10 visual neighbours).
 
-N>1 (torchrun, one rank per GPU): the directed view pairs are sharded over the ranks, slot slices are
-all-gathered over RCCL, the per-view chain is replicated ("scaling": "strong": same scene at every N).
+N>1 (torchrun, one rank per GPU): the halo form of line3dpp_amd/dist.py -- views cut into contiguous ranges, a rank
+matches the pairs of its views, the pairs across a cut travel point to point in compact form while the rest is being
+matched, the list pass of phase B is sharded by views, its records are all-gathered over RCCL, the tail of phase B runs
+on every rank ("scaling": "strong": same scene at every N).  No multi-GPU box has been available: at N = 1 the line
+carries `multi_gpu_model`, the expected N-GPU time term by term from this run's phase times.
 
 Prints ONE JSON line with
   `roofline`      the pair-matching kernel, timed with HIP events on its launch stream; VALU-issue roof priced with the
@@ -188,6 +191,38 @@ def load_json_newest(pattern, pred=lambda d: True):
     return None
 
 
+def multi_gpu_model(pairs, M, kNN, phase, lists_ms, record_bytes):
+    """What the halo form of the multi-GPU call (line3dpp_amd/dist.py) is expected to take on N GPUs of one node, term by
+    term, from THIS run's single-GPU phase times and the plan the N ranks would follow (l3d_plan_shards): no multi-GPU
+    box has been available to measure it, so the terms are printed for whoever has one.  Assumptions stated in the
+    output: 153 GB/s per xGMI link and direction, ring all-gather of the record slabs, expansion of a received slot at the
+    round-2 measured 2.8e-5 us, 0.03 ms of host latency per synchronisation point (5 per call)."""
+    from line3dpp_amd import dist as l3d_dist
+    cost = np.asarray([M[s] * M[t] for s, t in pairs], np.float64)
+    out = {"assumptions": {"link_GB_per_s": 153.0, "allgather": "ring", "expand_us_per_slot": 2.8e-5, "host_sync_ms": 0.03,
+                            "record_bytes": int(record_bytes)}}
+    tail_ms = max(phase["finish"] - lists_ms, 0.0)
+    t1 = phase["begin"] + phase["match"] + phase["finish"] + phase["affinity"]
+    for n in (2, 4, 8):
+        plan = l3d_dist.plan_halo(pairs, M, n)
+        pb = plan["pair_bounds"].astype(np.int64)
+        share = max(cost[pb[r]:pb[r + 1]].sum() for r in range(n)) / cost.sum()
+        halo_in = [0] * n
+        for r in range(n):
+            for (q, f, k) in plan["runs"][r]:
+                halo_in[q] += sum(M[pairs[p][0]] * kNN for p in range(f, f + k))
+        halo_slots = max(halo_in)
+        terms = {"begin": phase["begin"], "match_own_pairs": phase["match"] * share,
+                 "halo_exchange_hidden_behind_matching_MB": round(4e-6 * halo_slots, 2),
+                 "expand_received_pairs": 2.8e-5 * 1e-3 * halo_slots, "list_pass_own_views": lists_ms / n,
+                 "allgather_records": 1e3 * (n - 1) / n * record_bytes / 153e9, "tail_replicated": tail_ms,
+                 "affinity_replicated": phase["affinity"], "host_syncs": 0.15}
+        total = sum(v for k, v in terms.items() if not k.endswith("_MB"))
+        out[str(n)] = {"terms_ms": {k: round(v, 4) for k, v in terms.items()}, "total_ms": round(total, 4),
+                       "speedup_over_1_gpu": round(t1 / total, 2), "largest_pair_share": round(share, 4)}
+    return out
+
+
 def cold_call(scene, kNN, device_index, step_fn_factory):
     """first matchImages + affinity of a fresh context: (ms, timings dict, context)"""
     from line3dpp_amd.api import Line3D
@@ -267,6 +302,7 @@ def main():
     for _ in range(args.warmup):
         step()
     kern_ms, kern_launches, phase = 0.0, 0, dict(begin=0.0, match=0.0, finish=0.0, affinity=0.0)
+    lists_ms_sum, record_kbytes = 0.0, 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -275,6 +311,7 @@ def main():
         kern_ms += tm["match_kernel_ms"]; kern_launches += tm["match_kernel_launches"]
         phase["begin"] += tm["begin_ms"]; phase["match"] += tm["match_pairs_ms"]
         phase["finish"] += tm["finish_ms"]; phase["affinity"] += tm["affinity_ms"]
+        lists_ms_sum += tm.get("lists_ms", 0.0); record_kbytes = tm.get("record_kbytes", 0)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -286,15 +323,20 @@ def main():
 
     # ---- roofline of the dominant kernel (k_match_pairs), this rank's launches ----
     M = {v.cam: len(v.segs) for v in scene.views}
-    ranges = l3d_dist.pair_ranges([M[s] * M[t] for s, t in pairs], world)
-    f, c = ranges[rank]
+    if world > 1:       # the pairs this rank matches: those of its views (halo form, l3d_plan_shards)
+        pbounds = l3d_dist.plan_halo(pairs, M, world)["pair_bounds"]
+        f, c = int(pbounds[rank]), int(pbounds[rank + 1] - pbounds[rank])
+    else:
+        f, c = 0, len(pairs)
     my_pairs = pairs[f:f + c]
     # algorithmic bytes per launch (SURVEY.md §8d / DESIGN.md): per directed pair 16*(Ms+Mt) B of segment
     # records read + (32 + 4)*kNN*Ms B written: the result slots and, since the orientation filter is fused into
     # the kernel, the 4-byte inverse-list position of every slot (SURVEY's bound is 40*kNN*Ms)
     algo_bytes = sum(16 * (M[s] + M[t]) + 36 * kNN * M[s] for s, t in my_pairs)
     my_tests = sum(M[s] * M[t] for s, t in my_pairs)
-    avg_ms = kern_ms / max(kern_launches, 1)
+    # (one launch per step on one GPU; a rank of the halo form matches its pairs in two or three launches: the figures
+    # below are per step, i.e. over all of a step's launches of the kernel)
+    avg_ms = kern_ms / max(args.steps, 1)
     # two waves share a 64-row work item while the launch has few of them (k_match.hip: match_waves_per_group)
     wpg = 2 if sum((M[s] + 63) // 64 for s, _ in my_pairs) <= 16384 else 1
     hbm_achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -332,15 +374,13 @@ def main():
             # tests + epilogue work for the slots that are kept -- priced with the fitted per-unit VALU costs
             # (profiles/*_valu_fit.json) -- over the VALU instructions the launch executed
             uv = (cand["band_pairs"] / 64.0) * fit["valu_per_target_visit"] + \
-                 (cand["kept_slots"] / 64.0) * ((fit.get("valu_per_stage1_drain") or 0.0) + fit["valu_per_drain"] +
-                                               fit["valu_per_epilogue_pass"])
+                 (cand["kept_slots"] / 64.0) * (fit["valu_per_drain"] + fit["valu_per_epilogue_pass"])
             useful = {"useful_frac": round(uv / pmc["valu_insts_per_launch"], 4),
                       "useful_valu_insts": round(uv), "executed_valu_insts": pmc["valu_insts_per_launch"],
                       "band_pairs": cand["band_pairs"], "prefilter_tests": cand.get("prefilter_tests"),
                       "kept_slots": cand["kept_slots"], "exact_tests": cand.get("exact_tests"), "accepted": cand.get("accepted"),
                       "exact_tests_over_accepted": round(cand["exact_tests"] / max(cand["accepted"], 1), 3) if cand.get("exact_tests") else None,
-                      "valu_per_target_visit": fit["valu_per_target_visit"], "valu_per_stage1_drain": fit.get("valu_per_stage1_drain"),
-                      "valu_per_drain": fit["valu_per_drain"],
+                      "valu_per_target_visit": fit["valu_per_target_visit"], "valu_per_drain": fit["valu_per_drain"],
                       "valu_per_epilogue_pass": fit["valu_per_epilogue_pass"], "fit": fit["_file"]}
         roofline = {"bound": "valu", "achieved": round(valu_achieved, 2), "peak": round(peak, 1),
                     "unit": "G wave64 VALU instr/s", "frac": round(valu_achieved / peak, 4), "peak_basis": basis,
@@ -395,6 +435,10 @@ def main():
             "cold": cold,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }
+        if world == 1:
+            out["phase_ms"]["lists_part_of_finish"] = round(lists_ms_sum / args.steps, 4)
+            out["multi_gpu_model"] = multi_gpu_model(pairs, M, kNN, {k: v / args.steps for k, v in phase.items()},
+                                                     lists_ms_sum / args.steps, 1024.0 * record_kbytes)
         if world > 1 and getattr(l3d, "dist_ms", None):
             # rank 0's host wall time between the synchronisation points of the sharded call, per call (all calls incl.
             # warm-up): this rank's pairs | index all-gather | expansion + this rank's share of the list pass | all-gather

@@ -150,6 +150,20 @@ int l3d_match_finish(l3d_ctx*);
  * chain of inverse matches, scores, filterMatches, outputs) on the complete records on every rank.  Returns when the
  * slabs are complete in device memory. */
 int l3d_lists_shard(l3d_ctx*, uint32_t rank, uint32_t world, void* slab_ptr[4], uint64_t slab_bytes[4], void* full_ptr[4]);
+/* The same for an explicit range of views [view0, view1) (indices in ascending camID order) -- the halo form of a
+ * multi-GPU run (line3dpp_amd/dist.py, tests/cpp/rccl_driver.cpp): rank r owns the views l3d_plan_shards gives it,
+ * matches the pairs whose SOURCE view it owns, receives the pairs whose TARGET view it owns from their owners (compact
+ * index form, l3d_pack_slot_indices / l3d_expand_slot_indices per run of consecutive pairs) and runs the list pass of its
+ * views: only the pairs that touch [view0, view1) have to be present.  The records are all-gathered as above; the
+ * replicated remainder of phase B works on the records alone. */
+int l3d_lists_shard_views(l3d_ctx*, uint32_t rank, uint32_t world, uint32_t view0, uint32_t view1, void* slab_ptr[4],
+                          uint64_t slab_bytes[4], void* full_ptr[4]);
+/* Partition of a call over `world` ranks (host only; a function of the pair list of l3d_get_pairs): contiguous view
+ * ranges whose outgoing pairs carry equal shares of the cost (pair_cost[p], e.g. Ms * Mt); pair_src_view[p] = index of
+ * the pair's source view (the list is ordered by it).  view_bounds / pair_bounds receive world + 1 entries: rank r owns
+ * the views [view_bounds[r], view_bounds[r+1]) and the pairs [pair_bounds[r], pair_bounds[r+1]). */
+int l3d_plan_shards(uint32_t n_views, uint32_t n_pairs, const uint32_t* pair_src_view, const uint64_t* pair_cost,
+                    uint32_t world, uint32_t* view_bounds, uint32_t* pair_bounds);
 /* Leaves an open l3d_match_begin without results: everything queued is drained, the views are moved back
  * (matchImages translates them for its duration, line3D.cc:436/493), the context is idle again.  A no-op when no
  * begin is open.  Every failing l3d_match_begin / l3d_match_images / l3d_match_finish does this itself; callers that
@@ -237,6 +251,10 @@ typedef struct l3d_timings {
     uint32_t chain_extra_rounds; /* phase B: extra rounds of chain sweeps beyond the ones enqueued blindly (0 normally) */
     uint32_t pool_retries; /* phase B: list passes of the last matchImages that outgrew their record pools and were repeated
                             * with larger ones (0 once the pools have the scene's size; a first call may need one) */
+    float lists_ms;        /* phase B: the list pass (inverse records, candidate pairs, edges) -- the part of finish_ms that a
+                            * multi-GPU run shards by views; the rest of finish_ms is the tail every rank runs */
+    uint32_t record_kbytes;/* phase B: size of the four record arrays at their current pool strides, KiB: what the ranks of a
+                            * multi-GPU run all-gather */
 } l3d_timings;
 int l3d_get_timings(l3d_ctx*, l3d_timings*);
 

@@ -39,7 +39,8 @@ class Timings(C.Structure):
                 ("affinity_ms", C.c_float), ("match_kernel_launches", C.c_uint32), ("match_kernel_ms", C.c_float),
                 ("cull_prepare_ms", C.c_float), ("culled_pairs", C.c_uint32),
                 ("list_entries", C.c_uint32), ("support_words", C.c_uint32), ("tied_rows", C.c_uint32), ("chain_sweeps", C.c_uint32),
-                ("chain_extra_rounds", C.c_uint32), ("pool_retries", C.c_uint32)]
+                ("chain_extra_rounds", C.c_uint32), ("pool_retries", C.c_uint32),
+                ("lists_ms", C.c_float), ("record_kbytes", C.c_uint32)]
 
 
 EXPORTS = [
@@ -52,7 +53,7 @@ EXPORTS = [
     "l3d_output_filename", "l3d_save_3d_lines_txt", "l3d_save_result_stl", "l3d_save_result_obj",
     "l3d_get_segment_coords2d", "l3d_find_collinear_segments", "l3d_score_matches",
     "l3d_slot_index_buffer", "l3d_pack_slot_indices", "l3d_expand_slot_indices", "l3d_match_abort", "l3d_save_3d_lines_bin", "l3d_lists_shard",
-    "l3d_principal_direction", "l3d_selftest_arith",
+    "l3d_principal_direction", "l3d_selftest_arith", "l3d_lists_shard_views", "l3d_plan_shards",
 ]
 
 _lib = None
@@ -83,6 +84,8 @@ def load():
     L.l3d_match_finish.argtypes = [vp]
     L.l3d_match_abort.argtypes = [vp]
     L.l3d_lists_shard.argtypes = [vp, u32, u32, vp, vp, vp]
+    L.l3d_lists_shard_views.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp]
+    L.l3d_plan_shards.argtypes = [u32, u32, vp, vp, u32, vp, vp]
     L.l3d_compute_affinity.argtypes = [vp]
     L.l3d_synchronize.argtypes = [vp]
     L.l3d_pair_tests.argtypes = [vp, C.POINTER(u64)]

@@ -111,6 +111,15 @@ class Line3D:
             return None
         return [(sp[k], int(sb[k]), fp[k]) for k in range(4)]
 
+    def listsShardViews(self, rank, world, view0, view1):
+        """the same for an explicit view range (l3d_lists_shard_views: the halo form, only the pairs that touch the
+        range have to be present)"""
+        sp = (C.c_void_p * 4)(); sb = (C.c_uint64 * 4)(); fp = (C.c_void_p * 4)()
+        if not self._check(self.L.l3d_lists_shard_views(self.h, int(rank), int(world), int(view0), int(view1), sp, sb, fp),
+                           "listsShardViews"):
+            return None
+        return [(sp[k], int(sb[k]), fp[k]) for k in range(4)]
+
     def matchAbort(self):
         """closes an open matchBegin without results (views untranslated, context idle); no-op otherwise"""
         return self.L.l3d_match_abort(self.h) == 0

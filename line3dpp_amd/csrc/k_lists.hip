@@ -649,8 +649,8 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
 // ones as EDGES in (i, j) order with one HEADER per hypothesis i that has any.  The candidates arrive grouped by i
 // in canonical order (one contiguous run per i, j in walk order), so the order only has to be fixed inside a run.
 __global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
-                                               const uint32_t* __restrict__ gseg_view, const SimConst sc,
-                                               const ListPools lp, uint32_t* __restrict__ seg_of_g) {
+                                               const uint32_t* __restrict__ gseg_view, const Slot* __restrict__ slots,
+                                               const SimConst sc, const ListPools lp, uint32_t* __restrict__ seg_of_g) {
     const uint32_t pool = lp.pool0 + blockIdx.y, wave = 0, lane = lane_id();   // one segment per workgroup (as k_lists)
     const uint32_t k = blockIdx.x;
     if (lp.flags[0] | lp.flags[2]) return;   // the candidate pools overflowed: headers beyond the last complete list are not valid
@@ -899,18 +899,18 @@ __global__ void k_seg_filter(uint32_t G, const uint32_t* __restrict__ kept_cnt,
 }
 
 __device__ __forceinline__ void make_match(const ViewDev* views, const PairDesc* pairs, uint32_t view, uint32_t seg,
-                                           const HypHdr& h, const Slot& s, Match& m, uint32_t& tgt_view,
-                                           uint32_t& tgt_seg) {
-    // a fresh hypothesis reads its slot as is; an inverse one swaps the roles (line3D.cc:1682-1692)
+                                           const HypHdr& h, Match& m, uint32_t& tgt_view, uint32_t& tgt_seg) {
+    // (a fresh hypothesis reads its slot as is, an inverse one with the roles swapped, line3D.cc:1682-1692: k_edges has
+    // put both forms into the header)
     const bool inv = (h.pair_flags & kHypInv) != 0;
     const PairDesc& pd = pairs[h.pair_flags & 0x7FFFFFFFu];
     tgt_view = inv ? pd.src : pd.tgt;
-    tgt_seg = inv ? (uint32_t)((h.ref - pd.slot_off) / pd.K) : s.tgt_seg;
+    tgt_seg = h.tgt_seg;
     m.src_cam = views[view].cam; m.src_seg = seg;
     m.tgt_cam = views[tgt_view].cam; m.tgt_seg = tgt_seg;
-    m.overlap = s.overlap; m.score3D = h.score3D;
+    m.overlap = h.overlap; m.score3D = h.score3D;
     m.dp1 = h.dp1; m.dp2 = h.dp2;
-    m.dq1 = inv ? s.dp1 : s.dq1; m.dq2 = inv ? s.dp2 : s.dq2;
+    m.dq1 = h.oq1; m.dq2 = h.oq2;
 }
 
 // offsets of all segments + the outputs of the segments that keep a best hypothesis: surviving matches (reference
@@ -938,9 +938,8 @@ __global__ void k_seg_write(uint32_t G, const ViewDev* __restrict__ views, const
     for (uint32_t k = 0; k < sh.hyp_cnt; ++k) {
         const HypHdr& h = lp.hyps[sh.hyp_begin + k];
         if (!(h.state & kHypKeep)) continue;
-        const Slot s = slots[h.ref];
         Match m; uint32_t tv, tseg;
-        make_match(views, pairs, view, seg, h, s, m, tv, tseg);
+        make_match(views, pairs, view, seg, h, m, tv, tseg);
         surv_tg[w] = seg_base[tv] + tseg;
         surv_sg[w] = g;
         surv[w++] = m;
@@ -1044,7 +1043,7 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
     if (hsa.run_huge)
         hipLaunchKernelGGL(k_lists_huge, dim3(256), dim3(256), 0, st, views, pairs, lviews, opairs, gseg_view, off64, inv,
                            slots, lp, hs);
-    hipLaunchKernelGGL(k_edges, dim3(lp.scap, lp.npools), dim3(64), 0, st, views, pairs, gseg_view, sc, lp,
+    hipLaunchKernelGGL(k_edges, dim3(lp.scap, lp.npools), dim3(64), 0, st, views, pairs, gseg_view, slots, sc, lp,
                        seg_of_g);
     if (lp.npools < kListPools) hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, st, lp);   // sharded pass
     return hipGetLastError();

@@ -58,7 +58,9 @@ __device__ unsigned long long g_stats[12];   // 0 pre-filter tests, 1 candidates
                                             // 5 (row, target) pairs whose OWN bands intersect (what a per-row walk would
                                             // test), 6 slots kept, 7 work items, 8 stage-1 drains (depth decision), 9 candidates
                                             // that passed it (1 = candidates into stage 1, 4 = stage-2 drains (exact overlap))
-__device__ unsigned long long g_cycles[1 << 16][2];   // per work item: start, duration (wall_clock64 ticks)
+__device__ unsigned long long g_cycles[1 << 16][8];   // per work item (its first wave): start, main-loop duration, time in
+                                                      // stage 1 / stage 2 of the candidate pipeline, epilogue, wave end - start, in
+                                                      // shader cycles (s_memtime); [6] = XCC/CU id, [7] = SIMD/wave slot (HW_ID)
 #endif
 #ifdef L3D_STATS
 #define L3D_STAT(i, n) atomicAdd(&g_stats[i], (unsigned long long)(n))
@@ -186,7 +188,13 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     if (cp.item_order) w = cp.item_order[w];
     const WorkItem wi = work[w];
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
-    const unsigned long long t_start = wall_clock64();
+    const unsigned long long t_start = clock64();
+    unsigned long long t_s1 = 0, t_s2 = 0;
+#define L3D_TIC const unsigned long long tic_ = clock64()
+#define L3D_TOC(acc) acc += clock64() - tic_
+#else
+#define L3D_TIC ((void)0)
+#define L3D_TOC(acc) ((void)0)
 #endif
     const PairDesc& pd = pairs[wi.pair];
     const ViewDev& vs = views[pd.src];
@@ -476,10 +484,10 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     auto pump = [&](bool flush) {
         if (STAGED) {
             while (tail - head >= (flush ? 1u : 64u)) {
-                stage1();
-                while (tail2 - head2 >= 64) stage2();
+                { L3D_TIC; stage1(); L3D_TOC(t_s1); }
+                while (tail2 - head2 >= 64) { L3D_TIC; stage2(); L3D_TOC(t_s2); }
             }
-            if (flush) while (tail2 != head2) stage2();
+            if (flush) while (tail2 != head2) { L3D_TIC; stage2(); L3D_TOC(t_s2); }
         } else {
             while (flush ? (tail != head) : (tail - head >= 64)) drain();
         }
@@ -573,7 +581,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     }
     pump(true);
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
-    if (threadIdx.x == 0 && w < (1u << 16)) { g_cycles[w][0] = t_start; g_cycles[w][1] = wall_clock64() - t_start; }
+    const unsigned long long t_loop = clock64();
     if (threadIdx.x == 0) L3D_STAT(7, 1);
 #endif
 
@@ -685,6 +693,16 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
             if (n_alive) atomicAdd(&of.cnt_pack[gs + rsrc], (unsigned long long)n_alive);
         }
     }
+#if defined(L3D_STATS) || defined(L3D_CYCLES)
+    if (threadIdx.x == 0 && w < (1u << 16)) {
+        const unsigned long long t_end = clock64();
+        unsigned hw = 0, xcc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_cycles[w][0] = t_start; g_cycles[w][1] = t_loop - t_start; g_cycles[w][2] = t_s1; g_cycles[w][3] = t_s2;
+        g_cycles[w][4] = t_end - t_loop; g_cycles[w][5] = t_end - t_start; g_cycles[w][6] = xcc; g_cycles[w][7] = hw;
+    }
+#endif
 }
 
 // the two-stage candidate pipeline (default) or the single-stage one of round 2 (L3D_MATCH_STAGED=0: A/B switch; the
@@ -1487,6 +1505,6 @@ extern "C" void l3d_debug_stats(unsigned long long* out, int reset) {
     if (reset) { unsigned long long z[12] = {}; hipMemcpyToSymbol(HIP_SYMBOL(l3d::g_stats), z, sizeof(z)); }
 }
 extern "C" void l3d_debug_cycles(unsigned long long* out, int n) {
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(l3d::g_cycles), (size_t)n * 16);
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(l3d::g_cycles), (size_t)n * 64);
 }
 #endif

@@ -218,6 +218,45 @@ struct HostTrace {
 };
 static HostTrace g_trace;
 
+// ---- process-wide cache of released blocks (l3d_host.h) ----
+namespace {
+struct CachedBlock { void* p; size_t bytes; int device; bool pinned; };
+std::mutex g_cache_mu;
+std::vector<CachedBlock> g_cache;
+size_t g_cache_bytes[2] = {0, 0};
+constexpr size_t kCacheMaxBlocks = 512;
+constexpr size_t kCacheMaxBytes[2] = {(size_t)96 << 30, (size_t)1 << 30};   // device / pinned
+}  // namespace
+void* block_cache_take(bool pinned, size_t bytes, size_t* got_bytes) {
+    if (!bytes) return nullptr;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    size_t best = g_cache.size();
+    for (size_t i = 0; i < g_cache.size(); ++i) {   // smallest block that fits, at most twice (small: 64 KiB more than) the request
+        const CachedBlock& b = g_cache[i];
+        if (b.pinned != pinned || (!pinned && b.device != dev) || b.bytes < bytes || b.bytes > 2 * bytes + (64u << 10)) continue;
+        if (best == g_cache.size() || b.bytes < g_cache[best].bytes) best = i;
+    }
+    if (best == g_cache.size()) return nullptr;
+    const CachedBlock b = g_cache[best];
+    g_cache[best] = g_cache.back(); g_cache.pop_back();
+    g_cache_bytes[pinned] -= b.bytes;
+    *got_bytes = b.bytes;
+    return b.p;
+}
+bool block_cache_give(bool pinned, void* p, size_t bytes) {
+    static const bool off = std::getenv("L3D_NO_BLOCK_CACHE") != nullptr;   // diagnostic switch
+    if (off || !p || !bytes) return false;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (g_cache.size() >= kCacheMaxBlocks || g_cache_bytes[pinned] + bytes > kCacheMaxBytes[pinned]) return false;
+    g_cache.push_back(CachedBlock{p, bytes, dev, pinned});
+    g_cache_bytes[pinned] += bytes;
+    return true;
+}
+
 float ev_ms(hipEvent_t a, hipEvent_t b) {
     float ms = 0;
     (void)hipEventElapsedTime(&ms, a, b);
@@ -783,7 +822,8 @@ static int lists_reserve(l3d_ctx* c);
 static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint32_t npools);
 
 // The list pass of phase B for this rank's share of the views (include/l3dpp_hip.h)
-int l3d_lists_shard(l3d_ctx* c, uint32_t rank, uint32_t world, void* slab_ptr[4], uint64_t slab_bytes[4], void* full_ptr[4]) {
+static int lists_shard_impl(l3d_ctx* c, uint32_t rank, uint32_t world, int64_t view0, int64_t view1, void* slab_ptr[4],
+                            uint64_t slab_bytes[4], void* full_ptr[4]) {
     if (!c || !slab_ptr || !slab_bytes || !full_ptr) return fail(L3D_ERR_ARG, "null argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (c->state != l3d_ctx::BEGUN) return fail(L3D_ERR_STATE, "l3d_match_begin must precede l3d_lists_shard");
@@ -791,8 +831,34 @@ int l3d_lists_shard(l3d_ctx* c, uint32_t rank, uint32_t world, void* slab_ptr[4]
     // every exit that is not L3D_OK closes the open call (views untranslated, context idle), as the header promises
     const int rc = [&]() -> int {
         if (world == 0 || world > kListPools || rank >= world) return fail(L3D_ERR_ARG, "rank / world out of range");
-        for (size_t p = 0; p < c->pairs.size(); ++p)
-            if (!c->pair_done[p]) return fail(L3D_ERR_STATE, "l3d_lists_shard: the slots of some pairs are not present on this rank");
+        const uint32_t V = (uint32_t)c->order.size();
+        uint32_t v0, v1;
+        if (view0 >= 0) {
+            if (view1 < view0 || (uint64_t)view1 > V) return fail(L3D_ERR_ARG, "view range out of bounds");
+            v0 = (uint32_t)view0; v1 = (uint32_t)view1;
+        } else {
+            // contiguous view ranges of (nearly) equal segment count, the same partition on every rank
+            uint64_t G = 0;
+            std::vector<uint64_t> base(V + 1, 0);
+            for (uint32_t vi = 0; vi < V; ++vi) base[vi + 1] = base[vi] + c->order[vi]->M;
+            G = base[V];
+            auto bound = [&](uint32_t r) -> uint32_t {
+                if (r >= world) return V;
+                const uint64_t target = G * r / world;
+                uint32_t v = 0;
+                while (v < V && base[v] < target) ++v;
+                return v;
+            };
+            v0 = bound(rank); v1 = bound(rank + 1);
+        }
+        // what the pass reads: the fresh slots of the views' outgoing pairs and the inverse records of their incoming
+        // ones -- the pairs that touch [v0, v1) must be present (own pairs, or received: l3d_expand_slot_indices)
+        for (size_t p = 0; p < c->pairs.size(); ++p) {
+            const PairDesc& pd = c->pairs[p];
+            const bool touches = (pd.src >= v0 && pd.src < v1) || (pd.tgt >= v0 && pd.tgt < v1);
+            if (touches && !c->pair_done[p])
+                return fail(L3D_ERR_STATE, "l3d_lists_shard: the slots of a pair that touches this rank's views are not present");
+        }
         int r2;
         if (!c->lists_prepared) {
             r2 = lists_prepare(c, 1);
@@ -801,16 +867,6 @@ int l3d_lists_shard(l3d_ctx* c, uint32_t rank, uint32_t world, void* slab_ptr[4]
         }
         r2 = lists_reserve(c);
         if (r2) return r2;
-        // contiguous view ranges of (nearly) equal segment count, the same partition on every rank
-        const uint32_t V = (uint32_t)c->order.size(), G = c->G;
-        auto bound = [&](uint32_t r) -> uint32_t {
-            if (r >= world) return V;
-            const uint64_t target = (uint64_t)G * r / world;
-            uint32_t v = 0;
-            while (v < V && c->seg_base[v] < target) ++v;
-            return v;
-        };
-        const uint32_t v0 = bound(rank), v1 = bound(rank + 1);
         const uint32_t ppr = kListPools / world, pool0 = rank * ppr;
         r2 = lists_run(c, v0, v1 - v0, pool0, ppr);
         if (r2) return r2;
@@ -828,6 +884,47 @@ int l3d_lists_shard(l3d_ctx* c, uint32_t rank, uint32_t world, void* slab_ptr[4]
         set_error(why);
     }
     return rc;
+}
+
+int l3d_lists_shard(l3d_ctx* c, uint32_t rank, uint32_t world, void* slab_ptr[4], uint64_t slab_bytes[4], void* full_ptr[4]) {
+    return lists_shard_impl(c, rank, world, -1, -1, slab_ptr, slab_bytes, full_ptr);
+}
+int l3d_lists_shard_views(l3d_ctx* c, uint32_t rank, uint32_t world, uint32_t view0, uint32_t view1, void* slab_ptr[4],
+                          uint64_t slab_bytes[4], void* full_ptr[4]) {
+    return lists_shard_impl(c, rank, world, (int64_t)view0, (int64_t)view1, slab_ptr, slab_bytes, full_ptr);
+}
+
+// Partition of a matchImages call over `world` ranks (host only, no context: the plan is a function of the pair list):
+// contiguous ranges of views (ascending camID order) whose OUTGOING pairs carry equal shares of the matching cost.
+// Rank r matches the pairs whose source view it owns -- a contiguous range of the pair list, which is ordered by
+// source view -- and runs phase B's list pass for its views.  view_bounds / pair_bounds: world + 1 entries each.
+int l3d_plan_shards(uint32_t n_views, uint32_t n_pairs, const uint32_t* pair_src_view, const uint64_t* pair_cost,
+                    uint32_t world, uint32_t* view_bounds, uint32_t* pair_bounds) {
+    if (!world || !view_bounds || !pair_bounds || (n_pairs && (!pair_src_view || !pair_cost))) return fail(L3D_ERR_ARG, "null argument");
+    std::vector<double> vcost(n_views + 1, 0.0);
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+        if (pair_src_view[p] >= n_views || (p && pair_src_view[p] < pair_src_view[p - 1]))
+            return fail(L3D_ERR_ARG, "pair list is not ordered by source view");
+        vcost[pair_src_view[p]] += (double)pair_cost[p];
+    }
+    double total = 0.0;
+    for (uint32_t v = 0; v < n_views; ++v) total += vcost[v];
+    view_bounds[0] = 0;
+    uint32_t v = 0; double acc = 0.0;
+    for (uint32_t r = 1; r < world; ++r) {
+        const double target = total * r / world;
+        // the boundary whose cumulative cost is closest to the target, never behind the previous one
+        while (v < n_views && std::fabs(acc + vcost[v] - target) <= std::fabs(acc - target)) { acc += vcost[v]; ++v; }
+        view_bounds[r] = v;
+    }
+    view_bounds[world] = n_views;
+    uint32_t p = 0;
+    for (uint32_t r = 0; r <= world; ++r) {
+        while (p < n_pairs && pair_src_view[p] < view_bounds[r]) ++p;
+        pair_bounds[r] = p;
+    }
+    pair_bounds[world] = n_pairs;
+    return L3D_OK;
 }
 
 int l3d_match_finish(l3d_ctx* c) {
@@ -960,10 +1057,12 @@ static int lists_prepare(l3d_ctx* c, int caps_mode) {
     // ---- pre-pass: orientation flags and hypothesis counters of the pairs that do not carry them yet ----
     // (bounded kNN: done by the match epilogue / the exchange expansion; what is left are the pairs of the keep-all
     // mode and pairs whose full records arrived through l3d_slots_exchanged; d_cnt_pack was zeroed by l3d_match_begin)
+    // (pairs that are not present on this rank -- a multi-GPU run keeps the pairs that touch the rank's views only --
+    // are left alone: their slots are not valid)
     for (uint32_t p0 = 0; p0 < P;) {
-        if (c->pair_counted[p0]) { ++p0; continue; }
+        if (c->pair_counted[p0] || !c->pair_done[p0]) { ++p0; continue; }
         uint32_t p1 = p0;
-        while (p1 < P && !c->pair_counted[p1]) ++p1;
+        while (p1 < P && !c->pair_counted[p1] && c->pair_done[p1]) ++p1;
         L3D_HIP_CHECK(launch_orient_pairs(c->d_views.p, c->d_pairs.p + p0, p1 - p0, max_slots, c->d_seg_base.p,
                                           c->d_slots.p, c->d_cnt_pack.p, c->d_inv_pos.p, c->orient_lo, c->orient_hi, st));
         for (uint32_t p = p0; p < p1; ++p) c->pair_counted[p] = 1;
@@ -1031,6 +1130,7 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
     L3D_HIP_CHECK(launch_lists(v0, nv, max_M, c->d_views.p, c->d_pairs.p, lviews, opairs, c->d_gseg_view.p, c->d_off64.p,
                                c->d_inv_recs.p, c->d_slots.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, simc, lp,
                                c->d_seg_of_g.p, hsa, st));
+    L3D_HIP_CHECK(hipEventRecord(c->ev[9], st));
     return L3D_OK;
 }
 
@@ -1124,8 +1224,23 @@ static int finish_commit(l3d_ctx* c) {
     c->chain_need = c->tm.chain_extra_rounds ? kChainSweeps : c->tm.chain_sweeps;
     {
         uint64_t ne = 0;
-        for (uint32_t q = 0; q < kListPools; ++q) ne += h[128 + q * 16];
+        uint32_t me = 0, mh = 0, ms = 0, mc = 0;
+        for (uint32_t q = 0; q < kListPools; ++q) {
+            ne += h[128 + q * 16];
+            me = std::max(me, h[128 + q * 16]); mh = std::max(mh, h[128 + q * 16 + 1]);
+            ms = std::max(ms, std::max(h[128 + q * 16 + 2], h[128 + q * 16 + 4])); mc = std::max(mc, h[128 + q * 16 + 3]);
+        }
         c->tm.support_words = (uint32_t)ne;    // supporting (hypothesis, supporter) pairs
+        // Pool strides fitted to what the scene needs (the allocations stay): the record slabs a multi-GPU run
+        // all-gathers are pools x stride, so a stride several times the fullest pool's count is traffic for nothing.
+        // Every rank sees every counter, so every rank takes the same decision.  (A later call that needs more grows
+        // them again through the retry path.)
+        auto fit = [](uint32_t cap, uint32_t need, uint32_t lowest) {
+            const uint32_t want = std::max(need + need / 4 + 64, lowest);
+            return cap > want + want / 2 ? want : cap;
+        };
+        c->lp_ecap = fit(c->lp_ecap, me, 256); c->lp_hcap = fit(c->lp_hcap, mh, 128);
+        c->lp_scap = fit(c->lp_scap, ms, 64); c->lp_ccap = fit(c->lp_ccap, mc, 512);
     }
     // View::update_median_depth for every view (line3D.cc:1665-1668); in fixed-regulariser mode k is
     // re-set to the same sigma_p/med_scene_depth value, so k is unchanged either way
@@ -1136,6 +1251,9 @@ static int finish_commit(l3d_ctx* c) {
         c->tm.match_pairs_ms += ev_ms(c->ev[2], c->ev[3]);
     }
     c->tm.finish_ms = ev_ms(c->ev[6], c->ev[7]);
+    c->tm.lists_ms = ev_ms(c->ev[6], c->ev[9]);
+    c->tm.record_kbytes = (uint32_t)(((uint64_t)kListPools * ((uint64_t)c->lp_ecap * sizeof(EdgeRec) + (uint64_t)c->lp_hcap * sizeof(HypHdr) +
+                                                              (uint64_t)c->lp_scap * sizeof(SegHdr) + 64)) >> 10);
     c->tm.begin_ms = ev_ms(c->ev[0], c->ev[1]);
     untranslate(*c);   // line3D.cc:493
     c->state = l3d_ctx::MATCHED;

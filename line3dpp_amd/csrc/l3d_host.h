@@ -27,43 +27,59 @@ void set_error(const std::string& s);
         }                                                                                         \
     } while (0)
 
-// device buffer that grows but never shrinks (freed with the context)
+// Blocks released by a context (l3d_destroy, a buffer that grows) go to a process-wide cache and are handed to the next
+// reservation of similar size on the same device instead of back to the runtime: hipFree costs ~0.2 ms and
+// hipHostMalloc up to milliseconds on MI355X (tools/alloc_bench.hip), so a process that serves one Line3D object per
+// scene would otherwise pay ~10 ms per scene for memory it had a moment ago.  Bounded (blocks and bytes); l3d_api.hip.
+void* block_cache_take(bool pinned, size_t bytes, size_t* got_bytes);   // nullptr: nothing suitable cached
+bool block_cache_give(bool pinned, void* p, size_t bytes);              // false: cache full, caller frees
+
+// device buffer that grows but never shrinks (its block returns to the cache with the context)
 template <class T>
 struct DevBuf {
     T* p = nullptr;
-    size_t cap = 0;
+    size_t cap = 0;          // elements
+    size_t bytes_ = 0;       // size of the block behind p (a cached block may be larger than asked for)
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
+        release();
+        size_t got = 0;
+        if (void* q = block_cache_take(false, n * sizeof(T), &got)) { p = (T*)q; bytes_ = got; cap = got / sizeof(T); return hipSuccess; }
         hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
-        if (e == hipSuccess) cap = n;
+        if (e == hipSuccess) { cap = n; bytes_ = n * sizeof(T); } else p = nullptr;
         return e;
     }
     // work space that its kernels leave all-zero between launches (k_scan.hip): zeroed when it is (re)allocated
     hipError_t reserve_zeroed(size_t n, hipStream_t st) {
         if (n <= cap) return hipSuccess;
         hipError_t e = reserve(n);
-        if (e == hipSuccess) e = hipMemsetAsync(p, 0, n * sizeof(T), st);
+        if (e == hipSuccess) e = hipMemsetAsync(p, 0, cap * sizeof(T), st);
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() {
+        if (p && !block_cache_give(false, p, bytes_)) (void)hipFree(p);
+        p = nullptr; cap = 0; bytes_ = 0;
+    }
 };
 
 // pinned host staging: async H2D copies from it do not stall the stream (pageable sources are copied synchronously)
 template <class T>
 struct PinnedBuf {
     T* p = nullptr;
-    size_t cap = 0;
+    size_t cap = 0, bytes_ = 0;
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr; cap = 0;
+        release();
+        size_t got = 0;
+        if (void* q = block_cache_take(true, n * sizeof(T), &got)) { p = (T*)q; bytes_ = got; cap = got / sizeof(T); return hipSuccess; }
         hipError_t e = hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault);
-        if (e == hipSuccess) cap = n;
+        if (e == hipSuccess) { cap = n; bytes_ = n * sizeof(T); } else p = nullptr;
         return e;
     }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    void release() {
+        if (p && !block_cache_give(true, p, bytes_)) (void)hipHostFree(p);
+        p = nullptr; cap = 0; bytes_ = 0;
+    }
 };
 
 // Host -> device through a pinned staging buffer, left out when the device array already holds these very bytes: the

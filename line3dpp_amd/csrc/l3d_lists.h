@@ -61,9 +61,15 @@ struct HypHdr {
     uint32_t edge_cnt;
     float score3D;       // k_hyp_scores
     uint32_t state;      // bit0 exists (fresh, or inverse with positive source), bit1 kept by filterMatches
+    // what the surviving Match record needs of the hypothesis' slot (k_edges copies it here): the tail of phase B --
+    // chain, scores, filterMatches, outputs -- then works on the records alone, so that a rank of a multi-GPU run needs
+    // the slots of the pairs that touch ITS views only (the records of all ranks are all-gathered, the slots are not)
+    uint32_t tgt_seg;    // segment of the other view (fresh: the slot's target; inverse: the slot's source row)
+    float overlap;       // Match::overlap_score_
+    float oq1, oq2;      // depths of the other view's end points (fresh: dq1, dq2; inverse: the slot's dp1, dp2)
     uint32_t pad[2];
 };
-static_assert(sizeof(HypHdr) == 48, "HypHdr is 48 bytes");
+static_assert(sizeof(HypHdr) == 64, "HypHdr is 64 bytes");
 constexpr uint32_t kHypInv = 1u << 31;
 constexpr uint32_t kHypExists = 1u, kHypKeep = 2u;
 

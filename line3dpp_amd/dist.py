@@ -13,7 +13,15 @@ segment's hypothesis list that finds the supporting pairs of scoringCPU -- is sh
 chain of inverse matches in ascending camID, scores, filterMatches) runs on every rank (SURVEY.md §8e option 2 for
 the part that carries the work, option 1 for the order-dependent rest).
 
-The exchange is written as one in-place broadcast per owning rank: slices are uneven, and
+Default since round 3 -- the HALO form (match_images_halo): phase B's list pass is sharded by views, so a rank needs
+the slots of the pairs that TOUCH ITS VIEWS only.  The views are cut into contiguous ranges whose outgoing pairs carry
+equal shares of the matching cost (l3d_plan_shards); a rank matches the pairs whose source view it owns and sends, point
+to point, the compact indices of the pairs whose target view another rank owns (for a ring neighbourhood: the few pairs
+across a range boundary, ~2/N of what the all-gather moved).  Those pairs are matched first and travel while the rank
+matches the rest.  The record slabs of the list pass are all-gathered in place and the tail of phase B runs on the
+records alone (l3d_lists.h HypHdr carries what it needs of a slot).  L3D_DIST_ALLGATHER=1 selects the round-2 form below.
+
+The all-gather form: the exchange is written as one in-place broadcast per owning rank: slices are uneven, and
 `ncclBroadcast` of a slice of the one shared buffer is the all-gather(v) primitive RCCL offers.
 Works with backend "nccl" (= RCCL, device buffers) and "gloo" (CPU tensors, used by the tests).
 """
@@ -105,9 +113,146 @@ def gather_slabs(slabs, rank, world_size, device, group=None):
         if not sb:
             continue
         full = device_tensor(fp, sb * world_size, device)
-        dist.all_gather_into_tensor(full, full[rank * sb:(rank + 1) * sb].clone(), group=group)
+        mine = full[rank * sb:(rank + 1) * sb]
+        # RCCL gathers in place when the input is the rank's own slice of the output (no copy of the slab on the send
+        # side); the CPU backend of the tests gets a copy
+        dist.all_gather_into_tensor(full, mine if full.is_cuda else mine.clone(), group=group)
     if slabs:
         _wait_for_exchange(device_tensor(slabs[0][2], 1, device), device)
+
+
+def plan_halo(pairs, M, world_size):
+    """The partition of a call over `world_size` ranks (l3d_plan_shards) and what follows from it for every rank:
+    view_bounds, pair_bounds, and per rank the runs of consecutive pairs it sends (pairs it owns whose TARGET view another
+    rank owns): runs[r] = [(peer, first pair, pair count)].  A function of the pair list alone: identical on every rank."""
+    import ctypes as C
+    from . import _lib
+    cams = sorted(M)
+    vidx = {c: i for i, c in enumerate(cams)}
+    src = np.ascontiguousarray([vidx[int(s)] for s, _ in pairs], np.uint32)
+    tgt = np.asarray([vidx[int(t)] for _, t in pairs], np.uint32)
+    cost = np.ascontiguousarray([M[int(s)] * M[int(t)] for s, t in pairs], np.uint64)
+    vb = np.zeros(world_size + 1, np.uint32); pb = np.zeros(world_size + 1, np.uint32)
+    rc = _lib.load().l3d_plan_shards(len(cams), len(src), _lib.ptr(src), _lib.ptr(cost), world_size, _lib.ptr(vb), _lib.ptr(pb))
+    if rc != 0:
+        raise RuntimeError("l3d_plan_shards: " + _lib.last_error())
+    owner = np.searchsorted(vb[1:], np.arange(len(cams)), side="right")      # rank of every view
+    src_rank, tgt_rank = owner[src], owner[tgt]
+    runs = [[] for _ in range(world_size)]
+    for p in range(len(src)):
+        r, q = int(src_rank[p]), int(tgt_rank[p])
+        if r == q:
+            continue
+        if runs[r] and runs[r][-1][0] == q and runs[r][-1][1] + runs[r][-1][2] == p:
+            runs[r][-1] = (q, runs[r][-1][1], runs[r][-1][2] + 1)
+        else:
+            runs[r].append((q, p, 1))
+    return dict(view_bounds=vb, pair_bounds=pb, runs=runs)
+
+
+def early_ranges(first, count, halo_pairs):
+    """Order of a rank's own pair range [first, first + count): the pairs it has to SEND (halo_pairs, ascending) should
+    be matched first, the largest stretch without any last (it is matched while the halo travels).  Returns
+    ([(first, count)] to match before the exchange starts, (first, count) of the stretch matched during it)."""
+    if not count:
+        return [], (first, 0)
+    if not len(halo_pairs):
+        return [], (first, count)
+    edges = [first - 1] + [int(p) for p in halo_pairs] + [first + count]
+    gaps = [(edges[i + 1] - edges[i] - 1, edges[i] + 1) for i in range(len(edges) - 1)]
+    glen, gfirst = max(gaps)
+    early = []
+    if gfirst > first:
+        early.append((first, gfirst - first))
+    if gfirst + glen < first + count:
+        early.append((gfirst + glen, first + count - gfirst - glen))
+    return early, (gfirst, glen)
+
+
+def match_images_halo(l3d, rank, world_size, device=None, group=None, **params):
+    """matchImages over `world_size` ranks in the halo form (module docstring).  Same contract as match_images_sharded:
+    every rank ends with the complete result; False after a successful matchBegin means the context was closed with
+    matchAbort."""
+    import time
+    import torch.distributed as dist
+    acc = getattr(l3d, "dist_ms", None)
+    if acc is None:
+        acc = l3d.dist_ms = dict(match=0.0, exchange_slots=0.0, lists=0.0, exchange_lists=0.0, finish=0.0, calls=0)
+    acc.setdefault("match_early", 0.0)
+    t_last = [time.perf_counter()]
+
+    def lap(key):
+        now = time.perf_counter()
+        acc[key] += 1e3 * (now - t_last[0])
+        t_last[0] = now
+    acc["calls"] += 1
+    if not l3d.matchBegin(**params):
+        return False
+
+    def give_up():
+        l3d.matchAbort()
+        return False
+    pairs, slot_off = l3d.pairs()
+    M = l3d._M
+    plan = plan_halo(pairs, M, world_size)
+    l3d.halo_plan = plan
+    vb, pb, runs = plan["view_bounds"], plan["pair_bounds"], plan["runs"]
+    first, count = int(pb[rank]), int(pb[rank + 1] - pb[rank])
+    send = runs[rank]
+    recv = [(r, f, n) for r in range(world_size) for (q, f, n) in runs[r] if q == rank]   # (source rank, first, count)
+    halo_pairs = [p for (_, f, n) in send for p in range(f, f + n)]
+    early, late = early_ranges(first, count, halo_pairs)
+    for f, n in early:
+        if n and not l3d.matchPairs(f, n):
+            return give_up()
+    for _, f, n in send:
+        if not l3d.packSlotIndices(f, n):
+            return give_up()
+    lap("match_early")
+    # ---- the halo: compact indices of whole pair runs, point to point, at the pairs' own places in the index buffer ----
+    reqs = []
+    if send or recv:
+        ptr, n_slots = l3d.slot_index_buffer()
+        if ptr is None:
+            return give_up()
+        buf = device_tensor(ptr, n_slots * 4, device)
+        off = [int(o) for o in slot_off] + [int(n_slots)]
+
+        def span(f, n):
+            return buf[4 * off[f]:4 * off[f + n]]
+        glob = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+        ops = [dist.P2POp(dist.irecv, span(f, n), glob(r), group, tag=f) for (r, f, n) in recv] + \
+              [dist.P2POp(dist.isend, span(f, n), glob(q), group, tag=f) for (q, f, n) in send]
+        reqs = dist.batch_isend_irecv(ops)
+    # ---- the rest of this rank's pairs, matched while the halo travels ----
+    if late[1] and not l3d.matchPairs(late[0], late[1]):
+        for r in reqs:
+            r.wait()
+        return give_up()
+    lap("match")
+    for r in reqs:
+        r.wait()
+    if reqs:
+        _wait_for_exchange(buf, device)
+    lap("exchange_slots")
+    for _, f, n in recv:
+        if not l3d.expandSlotIndices(f, n):
+            return give_up()
+    for _ in range(8):
+        slabs = l3d.listsShardViews(rank, world_size, int(vb[rank]), int(vb[rank + 1]))
+        if slabs is None:
+            return give_up()
+        lap("lists")
+        gather_slabs(slabs, rank, world_size, device, group)
+        lap("exchange_lists")
+        rc = l3d.L.l3d_match_finish(l3d.h)
+        l3d.last_status = rc
+        lap("finish")
+        if rc == 0:
+            return True
+        if rc != -10:                  # L3D_ERR_RETRY
+            return l3d._check(rc, "matchFinish")
+    return give_up()
 
 
 def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_lists=None, **params):
@@ -126,6 +271,9 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_l
     closed with matchAbort (views untranslated, idle), so the next call starts from a clean state."""
     if world_size == 1 or params.get("kNN", 10) <= 0:
         return l3d.matchImages(**params)   # one call: nothing waits for the GPU between the phases
+    if os.environ.get("L3D_DIST_ALLGATHER") is None and os.environ.get("L3D_EXCHANGE_FULL") is None and shard_lists is not False \
+            and os.environ.get("L3D_SHARD_LISTS", "1") != "0" and hasattr(l3d, "listsShardViews"):
+        return match_images_halo(l3d, rank, world_size, device=device, group=group, **params)
     if shard_lists is None:
         shard_lists = os.environ.get("L3D_SHARD_LISTS", "1") != "0"
     # host wall time between the synchronisation points of the call, summed over calls in l3d.dist_ms (bench.py

@@ -296,3 +296,139 @@ def test_sharded_exchange_reproduces_single_process_buffer(world):
         assert ok and covered, (rank, ok, covered)
         assert sum(counts) == 12 and all(c > 0 for c in counts)
     assert len({r[4] for r in res}) == 1, "all ranks hold the same surviving matches and affinity matrix"
+
+
+# ---- the halo form (default of match_images_sharded since round 3) ---------------------------------------------------
+class _HaloReplayContext(_ReplayContext):
+    """_ReplayContext plus the view-sharded list pass (Line3D.listsShardViews) and the retry protocol of
+    l3d_match_finish, so that line3dpp_amd.dist.match_images_halo runs end to end on the CPU: point-to-point exchange of
+    the pairs across the cuts, expansion, list pass of the rank's views with ONLY the pairs that touch them present,
+    in-place all-gather of the record slabs, L3D_ERR_RETRY once, finish on the records of all ranks."""
+    SLAB = 256
+
+    def __init__(self, scene, kNN, rank, world):
+        super().__init__(scene, kNN)
+        self.rank, self.world = rank, world
+        self.attempt, self.full, self.last_status = 0, None, 0
+        cams = sorted(self._M)
+        self.vidx = {c: i for i, c in enumerate(cams)}
+
+    @staticmethod
+    def _sig(r, v0, v1, attempt, k):
+        import hashlib
+        d = hashlib.sha256(f"{r}:{v0}:{v1}:{attempt}:{k}".encode()).digest()
+        return np.frombuffer((d * (_HaloReplayContext.SLAB // len(d) + 1))[:_HaloReplayContext.SLAB], np.uint8)
+
+    def listsShardViews(self, rank, world, v0, v1):
+        assert (rank, world) == (self.rank, self.world) and self.state == "begun"
+        for p, (s, t) in enumerate(self.pairs_):
+            touches = v0 <= self.vidx[int(s)] < v1 or v0 <= self.vidx[int(t)] < v1
+            if touches and not self.present[p]:
+                self.matchAbort(); self.last_status = -7
+                return None
+        self.ranges_seen = (v0, v1)
+        self.full = [np.zeros(world * self.SLAB, np.uint8) for _ in range(4)]
+        for k in range(4):
+            self.full[k][rank * self.SLAB:(rank + 1) * self.SLAB] = self._sig(rank, v0, v1, self.attempt, k)
+        return [(None, self.SLAB, self.full[k]) for k in range(4)]
+
+    def l3d_match_finish(self, h):
+        vb = self.halo_plan["view_bounds"]
+        for r in range(self.world):
+            for k in range(4):
+                got = self.full[k][r * self.SLAB:(r + 1) * self.SLAB]
+                if not np.array_equal(got, self._sig(r, int(vb[r]), int(vb[r + 1]), self.attempt, k)):
+                    return -8                        # a slab that did not arrive (or arrived from another attempt)
+        if self.attempt == 0:                        # "pools enlarged on every rank alike": repeat list pass + gather
+            self.attempt = 1; self.log.append("retry")
+            return -10
+        self.o.end_match()
+        self.o.match_images(kNN=self.kNN); self.o.compute_affinity()
+        self.state = "matched"; self.log.append("finish")
+        return 0
+
+    def _check(self, rc, what):
+        self.last_status = rc
+        return rc == 0
+
+
+def _halo_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from line3dpp_amd import dist
+    from line3dpp_amd.scene import make_scene
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist_t.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        scene = make_scene(9, 60, n_neighbors=4, seed=6)
+        ctx = _HaloReplayContext(scene, 5, rank, world)
+        real = dist.device_tensor
+        dist.device_tensor = lambda arr, nbytes, device: torch.from_numpy(arr.view(np.uint8))[:nbytes]
+        try:
+            ok = dist.match_images_sharded(ctx, rank, world, device=None, kNN=5)
+        finally:
+            dist.device_tensor = real
+        plan = ctx.halo_plan
+        pb, vb, runs = plan["pair_bounds"], plan["view_bounds"], plan["runs"]
+        mine = set(range(int(pb[rank]), int(pb[rank + 1])))
+        incoming = {p for r in range(world) for (qq, f, n) in runs[r] if qq == rank for p in range(f, f + n)}
+        ok = bool(ok) and ctx.log == ["begin", "retry", "finish"]
+        ok = ok and set(ctx.own) == mine                                   # a rank matches exactly the pairs it owns
+        ok = ok and set(np.nonzero(ctx.present)[0].tolist()) == mine | incoming   # and holds those plus its halo, nothing else
+        ok = ok and ctx.ranges_seen == (int(vb[rank]), int(vb[rank + 1]))
+        single = _ReplayContext(scene, 5)
+        assert single.matchBegin() and single.matchPairs(0, len(single.pairs_)) and single.matchFinish()
+        q.put((rank, ok and ctx.digest() == single.digest(), len(mine), len(incoming), sum(len(r) for r in runs)))
+    finally:
+        dist_t.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_form_over_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert sum(r[2] for r in res) == 18                  # 9 views x 4 neighbours / 2: every pair matched exactly once
+    assert sum(r[3] for r in res) > 0 and res[0][4] > 0  # pairs did cross the cuts
+
+
+def test_halo_plan_balances_pairs_and_lists_every_crossing_pair_once():
+    """l3d_plan_shards + plan_halo on BASELINE C2's pair list (host only): contiguous view ranges with equal pair cost,
+    every pair owned by the rank of its source view, every pair whose target view lies elsewhere in exactly one run."""
+    sys.path.insert(0, ROOT)
+    from line3dpp_amd import dist
+    from line3dpp_amd.scene import CONFIGS
+    n, nb = CONFIGS["C2"]["n_views"], CONFIGS["C2"]["n_neighbors"]
+    # the pair list of a ring of n views with +-nb/2 neighbours (line3D.cc:704-741), without building the scene
+    M = {c: 4096 for c in range(n)}
+    matched = {c: set() for c in range(n)}
+    pairs = []
+    for c in range(n):
+        for t in sorted((c + d) % n for d in range(-nb // 2, nb // 2 + 1) if d):
+            if t not in matched[c]:
+                pairs.append((c, t)); matched[c].add(t); matched[t].add(c)
+    assert len(pairs) == 2560
+    for world in (2, 3, 8):
+        plan = dist.plan_halo(pairs, M, world)
+        vb, pb, runs = plan["view_bounds"], plan["pair_bounds"], plan["runs"]
+        counts = np.diff(pb.astype(np.int64))
+        assert counts.sum() == 2560 and counts.max() - counts.min() <= 2 * nb, counts
+        owner = np.searchsorted(vb[1:], np.arange(n), side="right")
+        crossing = {p for p, (s, t) in enumerate(pairs) if owner[s] != owner[t]}
+        listed = [p for r in range(world) for (_, f, k) in runs[r] for p in range(f, f + k)]
+        assert len(listed) == len(set(listed)) and set(listed) == crossing
+        for r in range(world):
+            for (qq, f, k) in runs[r]:
+                assert all(owner[pairs[p][0]] == r and owner[pairs[p][1]] == qq for p in range(f, f + k))
+            halo = [p for (_, f, k) in runs[r] for p in range(f, f + k)]
+            early, late = dist.early_ranges(int(pb[r]), int(counts[r]), halo)
+            assert sum(k for _, k in early) + late[1] == counts[r]
+            assert not any(late[0] <= p < late[0] + late[1] for p in halo)     # the stretch matched last sends nothing
+        assert len(crossing) < 0.2 * len(pairs) * (world - 1) / world + 120

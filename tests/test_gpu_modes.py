@@ -180,3 +180,40 @@ def test_unscaled_division_and_sqrt_equal_the_compilers_expansions_on_the_device
     counts = (C.c_uint64 * 3)()
     assert L.l3d_selftest_arith(0, 100_000_000, 20260925, counts) == 0
     assert list(counts) == [0, 0, 0], list(counts)
+
+
+def test_cpp_rccl_driver_single_rank_equals_the_python_front_end(tmp_path):
+    """tests/cpp/rccl_driver.cpp (C-ABI + RCCL, the halo sequence) with a one-rank communicator on this box's GPU: the
+    plan, the view-sharded list pass, the in-place all-gather of the record slabs and the finish on the records alone
+    give what l3d_match_images gives."""
+    import os
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "rccl_driver")
+    lib_dir = os.path.join(root, "line3dpp_amd", "csrc")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-w", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "rccl_driver.cpp"), "-o", exe, "-L" + lib_dir, "-ll3dpp_hip",
+                           "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath," + lib_dir])
+    sc = make_scene(8, 300, n_neighbors=4, seed=1)
+    path = str(tmp_path / "scene.bin")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", sc.n_views))
+        for v in sc.views:
+            f.write(struct.pack("<5I", v.cam, len(v.segs), v.width, v.height, len(v.neighbors)))
+            f.write(np.ascontiguousarray(v.K, np.float64).tobytes()); f.write(np.ascontiguousarray(v.R, np.float64).tobytes())
+            f.write(np.ascontiguousarray(v.t, np.float64).tobytes()); f.write(struct.pack("<f", v.median_depth))
+            f.write(np.asarray(v.neighbors, np.uint32).tobytes()); f.write(np.ascontiguousarray(v.segs, np.float32).tobytes())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([exe, path, "0", "1", str(tmp_path / "nccl_id")], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][0]
+    kv = dict(x.split("=") for x in line.split()[1:])
+    g = _gpu(sc)
+    assert g.matchImages() and g.computeAffinity()
+    ms = [g.matches(v.cam)[0] for v in sc.views]
+    assert int(kv["matches"]) == sum(len(m) for m in ms)
+    assert abs(float(kv["score_sum"]) - sum(float(m["score3D"].astype(np.float64).sum()) for m in ms)) < 1e-3
+    e, l2g, _ = g.affinity()
+    assert int(kv["hypotheses"]) == len(g.best()[0]) and int(kv["edges"]) == len(e) and int(kv["rows"]) == len(l2g)
+    assert abs(float(kv["wsum"]) - float(e["w"].astype(np.float64).sum())) < 1e-3

@@ -812,6 +812,95 @@ def test_sharded_list_pass_emulated_on_one_gpu(world):
     assert g.matchImages()                           # the failed call left a clean context
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_halo_form_emulated_on_one_gpu_at_c2_slice_size(world):
+    """The halo form of the multi-GPU call (line3dpp_amd/dist.py match_images_halo) with `world` contexts on one GPU, on
+    a 24-view slice of BASELINE C2 at the configured size (4096 segments per view, 20 neighbours): every context
+    matches the pairs whose source view it owns (l3d_plan_shards), the compact indices of the pairs whose target view
+    another context owns are copied where the point-to-point exchange would put them and expanded there, every context
+    runs the list pass of ITS views with only the pairs that touch them present, the record slabs are copied where the
+    all-gather would put them, and every context finishes on the records alone.  Everything a user can read back must
+    equal a single context's result byte for byte."""
+    import torch
+    from line3dpp_amd import dist
+    from line3dpp_amd.scene import make_config
+    sc = H.ring_slice(make_config("C2", max_views=24), 0, 24)
+    ref = _gpu(sc)
+    assert ref.matchImages() and ref.computeAffinity()
+    dev = torch.device("cuda", 0)
+    ctxs = [_gpu(sc) for _ in range(world)]
+    for g in ctxs:
+        assert g.matchBegin()
+    pairs, slot_off = ctxs[0].pairs()
+    plan = dist.plan_halo(pairs, ctxs[0]._M, world)
+    vb, pb, runs = plan["view_bounds"], plan["pair_bounds"], plan["runs"]
+    assert sum(len(r) for r in runs) > 0, "a ring slice cut into ranges has pairs across the cuts"
+    bufs = []
+    for r, g in enumerate(ctxs):
+        first, count = int(pb[r]), int(pb[r + 1] - pb[r])
+        halo = [p for (_, f, n) in runs[r] for p in range(f, f + n)]
+        early, late = dist.early_ranges(first, count, halo)
+        assert sum(n for _, n in early) + late[1] == count
+        for f, n in early + [late]:
+            assert n == 0 or g.matchPairs(f, n)
+        for _, f, n in runs[r]:
+            assert g.packSlotIndices(f, n)
+        ptr, n_slots = g.slot_index_buffer()
+        bufs.append(dist.device_tensor(ptr, n_slots * 4, dev))
+    off = [int(o) for o in slot_off] + [int(n_slots)]
+    moved = 0
+    for r in range(world):
+        for q, f, n in runs[r]:                      # what isend / irecv would move: rank r -> rank q
+            bufs[q][4 * off[f]:4 * off[f + n]].copy_(bufs[r][4 * off[f]:4 * off[f + n]])
+            moved += 4 * (off[f + n] - off[f])
+    torch.cuda.synchronize()
+    assert moved < 4 * n_slots * (world - 1) / 2, "the halo is a fraction of what an all-gather moves"
+    for q, g in enumerate(ctxs):
+        for r in range(world):
+            for qq, f, n in runs[r]:
+                if qq == q:
+                    assert g.expandSlotIndices(f, n)
+    for attempt in range(8):
+        slabs = []
+        for r, g in enumerate(ctxs):
+            sl = g.listsShardViews(r, world, int(vb[r]), int(vb[r + 1]))
+            assert sl is not None and len(sl) == 4
+            slabs.append(sl)
+        for k in range(4):
+            sizes = {sl[k][1] for sl in slabs}
+            assert len(sizes) == 1, "equal slab sizes on every rank"
+            sb = sizes.pop()
+            fulls = [dist.device_tensor(sl[k][2], sb * world, dev) for sl in slabs]
+            for r in range(world):
+                for q in range(world):
+                    if q != r:
+                        fulls[q][r * sb:(r + 1) * sb].copy_(fulls[r][r * sb:(r + 1) * sb])
+        torch.cuda.synchronize()
+        rcs = [g.L.l3d_match_finish(g.h) for g in ctxs]
+        assert len(set(rcs)) == 1, "every rank takes the same decision (all of them see all pool counters)"
+        if rcs[0] == 0:
+            break
+        assert rcs[0] == -10, rcs
+    else:
+        raise AssertionError("the pools never became large enough")
+    for g in ctxs:
+        assert g.computeAffinity()
+        for v in sc.views:
+            a, ao = g.matches(v.cam); b, bo = ref.matches(v.cam)
+            assert np.array_equal(ao, bo) and a.tobytes() == b.tobytes()
+            assert g.view_info(v.cam) == ref.view_info(v.cam)
+        for x, y in zip(g.best(), ref.best()):
+            assert x.tobytes() == y.tobytes()
+        ge, gl, _ = g.affinity(); re_, rl, _ = ref.affinity()
+        assert ge.tobytes() == re_.tobytes() and gl.tobytes() == rl.tobytes()
+    # a pair that touches the rank's views but never arrived is noticed (rank 1 receives the pairs across the first cut)
+    assert any(q == 1 for (q, _, _) in runs[0])
+    g = _gpu(sc)
+    assert g.matchBegin() and g.matchPairs(int(pb[1]), int(pb[2] - pb[1]))
+    assert g.listsShardViews(1, world, int(vb[1]), int(vb[2])) is None and g.last_status == -7
+    assert g.matchImages()                           # the failed call left a clean context
+
+
 def test_txt_writer_matches_accessor_and_reference_writer(tmp_path):
     """l3d_save_3d_lines_txt (Line3D::save3DLinesAsTXT): file name and content against get3Dlines() and against
     the file the reference's own writer produces for the same scene (oracle/_ref)."""

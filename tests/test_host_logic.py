@@ -158,3 +158,19 @@ def test_principal_direction_of_the_library_agrees_with_lapack():
         worst = max(worst, err)
         assert out[np.argmax(np.abs(out))] > 0          # sign convention: largest component positive
     assert worst <= 1e-9
+
+
+def test_cpp_rccl_driver_builds_and_links(tmp_path):
+    """tests/cpp/rccl_driver.cpp: the multi-GPU matchImages (halo form) as a C++ host drives it -- C-ABI + RCCL, one
+    process per GPU, no Python.  No multi-GPU box here: compiled and linked against libl3dpp_hip.so and librccl.so (every
+    C-ABI entry of the sequence resolves), run single-rank on the GPU box (tests/test_gpu_modes.py)."""
+    import subprocess
+    if not os.path.exists("/opt/rocm/lib/librccl.so"):
+        pytest.skip("no RCCL in this image")
+    exe = str(tmp_path / "rccl_driver")
+    lib_dir = os.path.join(ROOT, "line3dpp_amd", "csrc")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-w", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "rccl_driver.cpp"), "-o", exe, "-L" + lib_dir, "-ll3dpp_hip",
+                           "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath," + lib_dir])
+    out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "librccl" in out and "libl3dpp_hip" in out and "not found" not in out
