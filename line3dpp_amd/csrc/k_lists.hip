@@ -770,6 +770,14 @@ __global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views,
                 hdr.g = g; hdr.ref = r.ref_i; hdr.pair_flags = r.pf_i; hdr.canon = r.ij >> 16;
                 hdr.dp1 = r.a1; hdr.dp2 = r.a2;
                 hdr.edge_begin = e0 + run0; hdr.edge_cnt = mine; hdr.score3D = 0.0f; hdr.state = 0;
+                {   // the hypothesis' own slot, once per header (line3D.cc:1682-1692 for the role swap of an inverse one)
+                    const Slot hs = slots[r.ref_i];
+                    const bool hinv = (r.pf_i & kHypInv) != 0;
+                    const PairDesc& hp = pairs[r.pf_i & 0x7FFFFFFFu];
+                    hdr.tgt_seg = hinv ? (uint32_t)((r.ref_i - hp.slot_off) / hp.K) : hs.tgt_seg;
+                    hdr.overlap = hs.overlap;
+                    hdr.oq1 = hinv ? hs.dp1 : hs.dq1; hdr.oq2 = hinv ? hs.dp2 : hs.dq2;
+                }
                 hdr.pad[0] = hdr.pad[1] = 0;
                 lp.hyps[h0 + first_before + (uint32_t)__popcll(mf & lt_mask)] = hdr;
             }

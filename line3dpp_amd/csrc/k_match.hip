@@ -171,8 +171,11 @@ __device__ __forceinline__ uint32_t fuse_orientation(const OrientFuse& of, const
 //      inserted); a row's table is guarded by a compare-and-swap lock in LDS.
 // amdgpu_waves_per_eu(7): the LDS tables leave room for 7 waves per SIMD; the two-wave variant would otherwise take 75
 // VGPRs (6 waves) -- held to 72 it spills one register and runs 2.7 % faster on C1.
+#ifndef L3D_MATCH_WAVES
+#define L3D_MATCH_WAVES 7
+#endif
 template <int MODE, bool BRUTE, bool IX16, int WPG, bool STAGED>
-__global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7))) void k_match_pairs(const ViewDev* __restrict__ views,
+__global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3D_MATCH_WAVES))) void k_match_pairs(const ViewDev* __restrict__ views,
                                                            const PairDesc* __restrict__ pairs,
                                                            const WorkItem* __restrict__ work, uint32_t nwork,
                                                            Slot* __restrict__ slots,
@@ -299,9 +302,13 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
     // comes from the copies k_cull_prepare keeps in walk order (tgt_s4 / tgt_sd): a wave's candidates are neighbours
     // there.  Table entries are positions in that order; the epilogue translates the winners (tgt_perm).
     uint32_t head2 = 0, tail2 = 0;
-    const float4* __restrict__ ts4 = cull ? cp.tgt_s4 + pc->t_off : vt.seg4;
-    const char* __restrict__ tsd = cull ? (const char*)(cp.tgt_sd + pc->t_off) : (const char*)vt.segx;
-    const uint32_t tsd_stride = cull ? (uint32_t)sizeof(SegD) : (uint32_t)sizeof(SegX);
+    // (walk-order copies only where k_cull_prepare keeps them: large target views; otherwise the view's own arrays, by
+    // original index)
+    const bool sorted = cull && pc->sorted_copy != 0;
+    const float4* __restrict__ ts4 = sorted ? cp.tgt_s4 + pc->t_off : vt.seg4;
+    const char* __restrict__ tsd = sorted ? (const char*)(cp.tgt_sd + pc->t_off) : (const char*)vt.segx;
+    const uint32_t tsd_stride = sorted ? (uint32_t)sizeof(SegD) : (uint32_t)sizeof(SegX);
+    auto target_index = [&](uint32_t tp) -> uint32_t { return (cull && !sorted) ? tperm[tp] : tp; };
     auto stage1 = [&]() {
         const uint32_t n = min(64u, tail - head);
         const bool has = lane < n;
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
         bool pass = false;
         if (has) {
             const SegD& sd = *(const SegD*)&vs.segx[sg];                       // a SegX starts with its SegD
-            const SegD& td = *(const SegD*)(tsd + (size_t)tp * tsd_stride);
+            const SegD& td = *(const SegD*)(tsd + (size_t)target_index(tp) * tsd_stride);
             pass = depths_positive(sd, td, vs.C, vt.C);
         }
         const uint64_t m = L3D_BALLOT(pass);
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
         bool pending = false;
         float ovv = 0.0f;
         if (has) {
-            const float4 s4 = vs.seg4[sg], t4 = ts4[tg];
+            const float4 s4 = vs.seg4[sg], t4 = ts4[target_index(tg)];
             const float ov = exact_overlap(F, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w, fastm);
             // a full row only admits overlaps that reach its K-th best (minov == thr while the row is not full); an overlap
             // EQUAL to the K-th best goes on to the insertion: a tie at the kNN-th place flags the row for the exact replay
@@ -541,6 +548,15 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
             wm &= ~(1u << bit);
             const uint32_t ti = tb + lane;
             bool in = ti < Mt;
+#ifdef L3D_TARGETS_BY_READLANE
+            // Lane l fetches record l of the chunk (one coalesced 1 KiB load per chunk, requested together with the band);
+            // the record of the target being tested then reaches all lanes as scalar operands through v_readlane.  The
+            // round-2 form fetched every record with its own s_load_dwordx4: a stream of 16-byte records misses the scalar
+            // cache on every fourth load (25 % measured) and the wave sat on s_waitcnt at every step -- half of a wave's
+            // life was spent waiting.  Four v_readlane per target cost 17 issue cycles on a VALU that was ~60 % busy.
+            v4f rec = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (in) rec = tf[ti];
+#endif
             if (cull && in) {
                 const float2 b = tband[ti];
                 in = !(b.y < wlo || b.x > whi);
@@ -552,7 +568,19 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(7)
                 // into the execution mask of their push
                 const uint32_t j0 = __builtin_ctzll(m); m &= m - 1;
                 const bool v1 = m != 0; const uint32_t j1 = v1 ? __builtin_ctzll(m) : j0; m &= m - 1;
+#ifdef L3D_TARGETS_BY_READLANE
+                auto bcast = [&](uint32_t j) -> v4f {
+                    v4f q;
+                    q.x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rec.x), j));
+                    q.y = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rec.y), j));
+                    q.z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rec.z), j));
+                    q.w = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rec.w), j));
+                    return q;
+                };
+                const v4f q0 = bcast(j0), q1 = bcast(j1);
+#else
                 const v4f q0 = tfc[tb + j0], q1 = tfc[tb + j1];
+#endif
                 // (the lane masks are built from the comparison itself and the uniform masks by scalar ANDs: a ballot of
                 // `live & test` would first turn the flag into 0/1 in a VGPR)
                 const bool c0b = BRUTE || prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL);
@@ -1186,8 +1214,10 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
         const Band b = tgt_band(pc, vt.seg4[seg], slo, shi);
         cp.tgt_perm[pc.t_off + i] = seg;
         cp.tgt_sf[pc.t_off + i] = *(const float4*)&vt.segf[seg];
-        cp.tgt_s4[pc.t_off + i] = vt.seg4[seg];
-        cp.tgt_sd[pc.t_off + i] = *(const SegD*)&vt.segx[seg];
+        if (pc.sorted_copy) {
+            cp.tgt_s4[pc.t_off + i] = vt.seg4[seg];
+            cp.tgt_sd[pc.t_off + i] = *(const SegD*)&vt.segx[seg];
+        }
         cp.tgt_band[pc.t_off + i] = make_float2(b.lo, b.hi);
         atomicMin(&cb[2 * (i >> 6)], f2ord(b.lo));
         atomicMax(&cb[2 * (i >> 6) + 1], f2ord(b.hi));

@@ -500,7 +500,7 @@ static int match_begin_body(l3d_ctx* c) {
             if (c->use_cull && c->kNN > 0 && pd.Ms <= kCullMaxSegs && pd.Mt <= kCullMaxSegs && pd.Ms && pd.Mt)
                 make_cull(pd.F, v->width, v->height, t->width, t->height, pc);
             pc.s_off = cs_off; pc.t_off = ct_off; pc.c_off = cc_off; pc.k_off = ~0ull;
-            pc.w_item0 = w_item; pc.pad = 0; w_item += (pd.Ms + kMatchRows - 1) / kMatchRows;
+            pc.w_item0 = w_item; pc.sorted_copy = pd.Mt >= kSortedCopyMinSegs ? 1u : 0u; w_item += (pd.Ms + kMatchRows - 1) / kMatchRows;
             if (pc.enabled && std::max(pd.Ms, pd.Mt) > kCullLdsSegs) {   // sort keys of this pair in global scratch
                 uint32_t a = 64, b = 64;
                 while (a < pd.Ms) a <<= 1;
@@ -553,8 +553,12 @@ static int match_begin_body(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_src_band.reserve(std::max<uint64_t>(cs_off, 1)));
     L3D_HIP_CHECK(c->d_tgt_perm.reserve(std::max<uint64_t>(ct_off, 1)));
     L3D_HIP_CHECK(c->d_tgt_sf.reserve(std::max<uint64_t>(ct_off, 1)));
-    L3D_HIP_CHECK(c->d_tgt_s4.reserve(std::max<uint64_t>(ct_off, 1)));
-    L3D_HIP_CHECK(c->d_tgt_sd.reserve(std::max<uint64_t>(ct_off, 1)));
+    {   // walk-order copies of the targets' exact-test records: only when some pair keeps them (large views)
+        bool any_sorted = false;
+        for (const PairCull& pc : c->cull) any_sorted |= pc.enabled && pc.sorted_copy;
+        L3D_HIP_CHECK(c->d_tgt_s4.reserve(any_sorted ? std::max<uint64_t>(ct_off, 1) : 1));
+        L3D_HIP_CHECK(c->d_tgt_sd.reserve(any_sorted ? std::max<uint64_t>(ct_off, 1) : 1));
+    }
     L3D_HIP_CHECK(c->d_tgt_band.reserve(std::max<uint64_t>(ct_off, 1)));
     L3D_HIP_CHECK(c->d_chunk_band.reserve(std::max<uint32_t>(cc_off, 1)));
     L3D_HIP_CHECK(c->d_cull_keys.reserve(std::max<uint64_t>(ck_off, 1)));

@@ -26,8 +26,13 @@ struct PairCull {
     uint64_t k_off;        // views beyond the LDS sort capacity: this pair's sort keys in CullPools::big_keys (source
                            // side first, target side behind it); ~0 when both sides sort in LDS
     uint32_t w_item0;      // first work item (64 source rows each) of the pair, counted over all pairs of the context
-    uint32_t pad;
+    uint32_t sorted_copy;  // 1: k_cull_prepare also keeps the target's seg4 / SegD records in walk order (CullPools::tgt_s4 /
+                           // tgt_sd) and the exact tests read those.  For views of a few thousand segments the per-view arrays
+                           // stay in the L2s across the pairs of a view and gathers by original index hit; per-pair copies
+                           // would only add traffic (C1: +30 % bytes for nothing).  From 4096 segments on the gathers miss
+                           // (C4 read 132 x its segment records) and the copies pay.
 };
+constexpr uint32_t kSortedCopyMinSegs = 4096;
 struct CullPools {
     const PairCull* cull;      // [n_pairs] or nullptr
     uint32_t* src_perm;        // [sum Ms] source row visited at sorted position i

@@ -202,7 +202,7 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         PairCull pc{};
         if (Ms <= kCullMaxSegs && Mt <= kCullMaxSegs && std::getenv("L3D_NO_CULL") == nullptr)
             make_cull(pd.F, width, height, width, height, pc);
-        pc.k_off = ~0ull;
+        pc.k_off = ~0ull; pc.sorted_copy = Mt >= kSortedCopyMinSegs ? 1u : 0u;
         uint64_t n_keys = 0;
         if (pc.enabled && std::max(Ms, Mt) > kCullLdsSegs) {
             uint32_t a = 64, b = 64;

@@ -131,6 +131,27 @@ DEF_KERNEL(lshl_b32, unsigned, OP_lshl_b32)
 DEF_KERNEL(mul_lo_u32, unsigned, OP_mul_lo_u32)
 DEF_KERNEL(mbcnt, unsigned, OP_mbcnt)
 DEF_KERNEL(cmp_u32, unsigned, OP_cmp_u32)
+// ---- scalar ALU (one scalar unit per CU, shared by its four SIMDs): the walk of k_match_pairs issues ~0.7 SALU
+// instructions per VALU instruction ----
+#define OP_s_add_u32(x) asm volatile("s_add_u32 %0, %0, 3" : "+s"(x) : : "scc");
+#define OP_s_and_b32(x) asm volatile("s_and_b32 %0, %0, 0x7fffffff" : "+s"(x) : : "scc");
+#define OP_s_lshl_b32(x) asm volatile("s_lshl_b32 %0, %0, 1" : "+s"(x) : : "scc");
+#define DEF_SKERNEL(NAME, OPM)                                                                                   \
+    __global__ __launch_bounds__(64) void k_##NAME(WaveTime* out, int iters, unsigned b, unsigned c, unsigned* sink) { \
+        unsigned a0 = b + 1, a1 = b + 2, a2 = b + 3, a3 = b + 4, a4 = b + 5, a5 = b + 6, a6 = b + 7, a7 = b + 8, a8 = b + 9, \
+                 a9 = b + 10, a10 = b + 11, a11 = b + 12, a12 = b + 13, a13 = b + 14, a14 = b + 15, a15 = b + 16;  \
+        const unsigned long long t0 = clock64(), r0 = wall_clock64();                                             \
+        for (int i = 0; i < iters; ++i) {                                                                         \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) { REP16(OPM) }                                          \
+        }                                                                                                         \
+        const unsigned long long t1 = clock64(), r1 = wall_clock64();                                             \
+        unsigned s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + a8 + a9 + a10 + a11 + a12 + a13 + a14 + a15;         \
+        if (s == 123457u) *sink = s;                                                                              \
+        if (threadIdx.x == 0) out[blockIdx.x] = WaveTime{t1 - t0, r1 - r0};                                       \
+    }
+DEF_SKERNEL(s_add_u32, OP_s_add_u32)
+DEF_SKERNEL(s_and_b32, OP_s_and_b32)
+DEF_SKERNEL(s_lshl_b32, OP_s_lshl_b32)
 // ---- conversions (separate source and destination widths) ----
 __global__ __launch_bounds__(64) void k_cvt_f64_f32(WaveTime* out, int iters, float b, float c, float* sink) {
     double a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15;
@@ -241,6 +262,7 @@ int main(int argc, char** argv) {
         O(add_u32, "INT32", 2), O(and_b32, "INT32", 2), O(lshl_b32, "INT32", 2), O(mul_lo_u32, "INT32", 2),
         O(mbcnt, "INT32", 2), O(cmp_u32, "INT32", 2),
         O(cvt_f64_f32, "CVT", 3), O(cvt_f32_f64, "CVT", 3),
+        O(s_add_u32, "SALU", 2), O(s_and_b32, "SALU", 2), O(s_lshl_b32, "SALU", 2),
 #undef O
         Op{"c_div_f64", "composite: 16 x (IEEE double division + add) per iteration", 0, 4, (const void*)k_c_div_f64},
         Op{"c_sqrt_f64", "composite: 16 x (IEEE double sqrt + add) per iteration", 0, 4, (const void*)k_c_sqrt_f64},
