@@ -295,13 +295,15 @@ __device__ __forceinline__ int process_list(uint32_t vi, uint32_t seg, uint32_t 
     // ---- inverse hypotheses, placed at their canonical rank: (source view, source segment) ascending ----
     {
         constexpr uint32_t kInvPer = (CAP + GS - 1) / GS;               // records per thread (n_inv <= L <= CAP)
+        // (rank by slot index = rank by (source view, source row), l3d_lists.h; the keys array is not needed yet)
+        L3D_LDS uint32_t* k32 = (L3D_LDS uint32_t*)keys;
         InvRec mine[kInvPer];
 #pragma unroll
         for (uint32_t c = 0; c < kInvPer; ++c) {
             const uint32_t x = c * GS + t;
             if (x < n_inv) {
                 mine[c] = inv[ib + x];
-                keys[x] = ((uint64_t)mine[c].src_view << 32) | mine[c].src_row;
+                k32[x] = mine[c].ref;
             }
         }
         group_barrier<WPL>();
@@ -310,12 +312,12 @@ __device__ __forceinline__ int process_list(uint32_t vi, uint32_t seg, uint32_t 
             const uint32_t x = c * GS + t;
             if (x < n_inv) {
                 const InvRec& r = mine[c];
-                const uint64_t key = ((uint64_t)r.src_view << 32) | r.src_row;
                 uint32_t rank = 0;
-                for (uint32_t y = 0; y < n_inv; ++y) rank += (keys[y] < key) ? 1u : 0u;
-                e_d1[rank] = r.dq1; e_d2[rank] = r.dq2; e_tv[rank] = r.src_view; e_ref[rank] = r.ref; e_pf[rank] = r.pair | kHypInv;
+                for (uint32_t y = 0; y < n_inv; ++y) rank += (k32[y] < r.ref) ? 1u : 0u;
+                e_d1[rank] = r.dq1; e_d2[rank] = r.dq2; e_tv[rank] = pairs[r.pair].src; e_ref[rank] = r.ref; e_pf[rank] = r.pair | kHypInv;
             }
         }
+        group_barrier<WPL>();   // the ranks are taken: the keys array may be overwritten (sort keys, below)
     }
     // ---- fresh hypotheses: the alive slots of the view's outgoing pairs, ascending (target view, slot) ----
     uint32_t pos = n_inv;
@@ -493,7 +495,7 @@ __global__ void k_inv_records(const PairDesc* __restrict__ pairs, uint32_t first
     const Slot s = slots[pd.slot_off + i];
     const uint32_t g = seg_base[pd.tgt] + s.tgt_seg;
     InvRec r;
-    r.ref = (uint32_t)(pd.slot_off + i); r.pair = pi; r.src_view = pd.src; r.src_row = (uint32_t)(i / pd.K);
+    r.ref = (uint32_t)(pd.slot_off + i); r.pair = pi;
     r.dq1 = s.dq1; r.dq2 = s.dq2;
     recs[(uint32_t)(off64[g] >> 32) + ipos] = r;
 }
@@ -569,15 +571,14 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
         const uint32_t seg = g - lv.seg_base;
         const ViewDev& v = views[vi];
         const uint32_t ib = (uint32_t)(off64[g] >> 32), n_inv = (uint32_t)(off64[g + 1] >> 32) - ib;
-        for (uint32_t x = t; x < n_inv; x += 256) { const InvRec r = inv[ib + x]; keys[x] = ((uint64_t)r.src_view << 32) | r.src_row; }
+        for (uint32_t x = t; x < n_inv; x += 256) keys[x] = inv[ib + x].ref;
         __threadfence_block();
         __syncthreads();
         for (uint32_t x = t; x < n_inv; x += 256) {
             const InvRec r = inv[ib + x];
-            const uint64_t key = ((uint64_t)r.src_view << 32) | r.src_row;
             uint32_t rank = 0;
-            for (uint32_t y = 0; y < n_inv; ++y) rank += (keys[y] < key) ? 1u : 0u;
-            e_d1[rank] = r.dq1; e_d2[rank] = r.dq2; e_tv[rank] = r.src_view; e_ref[rank] = r.ref; e_pf[rank] = r.pair | kHypInv;
+            for (uint32_t y = 0; y < n_inv; ++y) rank += (keys[y] < (uint64_t)r.ref) ? 1u : 0u;
+            e_d1[rank] = r.dq1; e_d2[rank] = r.dq2; e_tv[rank] = pairs[r.pair].src; e_ref[rank] = r.ref; e_pf[rank] = r.pair | kHypInv;
         }
         uint32_t pos = n_inv;
         for (uint32_t q = lv.q0; q < lv.q0 + lv.nq; ++q) {

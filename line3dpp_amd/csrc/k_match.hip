@@ -169,10 +169,13 @@ __device__ __forceinline__ uint32_t fuse_orientation(const OrientFuse& of, const
 //      shortens the ramp-down tail of the launch (waves cannot migrate: at the end some SIMDs still hold a full set of
 //      long items while others are empty).  The waves meet at two barriers only (tables initialised / all candidates
 //      inserted); a row's table is guarded by a compare-and-swap lock in LDS.
-// amdgpu_waves_per_eu(7): the LDS tables leave room for 7 waves per SIMD; the two-wave variant would otherwise take 75
-// VGPRs (6 waves) -- held to 72 it spills one register and runs 2.7 % faster on C1.
+// amdgpu_waves_per_eu: with two waves per work item the LDS tables leave room for 7 waves per SIMD; the kernel would
+// otherwise take 75 VGPRs (6 waves) -- held to 72 it spills one register and runs 5 % faster on C1 (0.718 against
+// 0.754 ms).  One wave per item (the large scenes) is limited to 6 per SIMD by its LDS (6.3 KiB per wave) whatever the
+// registers: there the 84-register budget without the spill is the faster one (C2 13.88 against 14.26 ms, C4 25.6
+// against 26.2; profiles/r03_v2_ab_target_delivery.txt, rows sl6 / sl7).
 #ifndef L3D_MATCH_WAVES
-#define L3D_MATCH_WAVES 7
+#define L3D_MATCH_WAVES (WPG == 2 ? 7 : 6)
 #endif
 template <int MODE, bool BRUTE, bool IX16, int WPG, bool STAGED>
 __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3D_MATCH_WAVES))) void k_match_pairs(const ViewDev* __restrict__ views,

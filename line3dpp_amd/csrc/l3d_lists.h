@@ -14,15 +14,17 @@
 namespace l3d {
 
 // slot (pair, src_row, j) as a potential inverse hypothesis of its target segment, with what the list pass needs
-// (the slot itself is only read again if the hypothesis survives): 24 bytes, CSR over global segments (inv_off)
-struct InvRec {
+// (the slot itself is only read again by k_edges if the hypothesis has a supporter): 16 bytes, 16-byte aligned (the
+// 24-byte record of round 2 straddled 32-byte sectors: 2.7 counted bytes per payload byte written), CSR over global
+// segments.  The canonical order of a segment's inverse hypotheses -- (source view, source segment) ascending -- is the
+// order of their slot indices (slots are laid out by pair = by source view, then source row; two slots of one row
+// never share a target), and the source view is pairs[pair].src.
+struct __attribute__((aligned(16))) InvRec {
     uint32_t ref;        // slot index
     uint32_t pair;       // directed pair the slot belongs to
-    uint32_t src_view;   // canonical order of the inverse hypotheses: (source view, source segment) ascending
-    uint32_t src_row;
     float dq1, dq2;      // depths of the target segment's end points = this hypothesis' own depths
 };
-static_assert(sizeof(InvRec) == 24, "InvRec is 24 bytes");
+static_assert(sizeof(InvRec) == 16, "InvRec is 16 bytes");
 
 // per view / per outgoing pair of a view: what the list pass needs of ViewDev / PairDesc, packed so that a wave gets
 // it with one or two loads instead of a chain of dependent ones (view -> pair list -> pair -> slot)
