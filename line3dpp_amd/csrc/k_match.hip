@@ -42,8 +42,6 @@ namespace {
 constexpr int kBlock = kMatchRows;  // rows per work item = lanes of a wave64; a workgroup is WPG (1 or 2) such waves
 constexpr int kRing = 256;          // candidate ring (entries); >= 63 + 2*64 (drained after every two pushes)
 constexpr int kRing2 = 128;         // second ring (bounded kNN): candidates that passed the depth test; >= 63 + 64
-constexpr float kKappa = 1.0e-2f;  // pre-filter slack, px: margin = kKappa * max|1/d| + kKappa0
-constexpr float kKappa0 = 2.0e-4f;
 
 // All LDS pointers carry the LDS address space in their TYPE: a generic pointer that travels through a struct
 // or a lambda capture loses it and every access becomes a flat_load/flat_store (plus, for volatile, sc0 sc1
@@ -105,24 +103,19 @@ __device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K, uint3
     return l;
 }
 
-// conservative fp32 test "could overlap(src, tgt) exceed thr?".  (e?x,e?y) are unit normals of the
-// two epipolar lines, e?z their offsets w.r.t. the image centre; q = (q1 - centre, q1 - q2).
-// s_i = a_i / d_i is the position of the intersection of epipolar line i with the target line in
-// units of the target segment (q1 -> 0, q2 -> 1).  NaN/inf from degenerate d fall through as
-// "candidate" and are sorted out by the exact test.
+// conservative fp32 test "could overlap(src, tgt) exceed thr?" (l3d_dev.h: prefilter_products, the form without
+// reciprocals).  -DL3D_PREFILTER_RCP restores the round-2 form (two v_rcp_f32, clamp output modifier) for A/B runs.
 __device__ __forceinline__ bool prefilter(float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
                                           const v4f q, float thr) {
+#ifndef L3D_PREFILTER_RCP
+    return prefilter_products(e1x, e1y, e1z, e2x, e2y, e2z, q.x, q.y, q.z, q.w, thr);
+#else
     float a1 = __builtin_fmaf(e1x, q.x, __builtin_fmaf(e1y, q.y, e1z));
     float a2 = __builtin_fmaf(e2x, q.x, __builtin_fmaf(e2y, q.y, e2z));
     float d1 = __builtin_fmaf(e1x, q.z, e1y * q.w);
     float d2 = __builtin_fmaf(e2x, q.z, e2y * q.w);
     float r1 = __builtin_amdgcn_rcpf(d1);
     float r2 = __builtin_amdgcn_rcpf(d2);
-    // inner = min(hi,1) - max(lo,0) and outer = max(hi,1) - min(lo,0) of [lo, hi] = the two intersection positions, in
-    // a form without min / max instructions (half rate on this hardware, tools/valu_calib.hip): for intervals that meet
-    // [0, 1] at all inner = |clamp(s1) - clamp(s2)| (clamp is monotone and free as the output modifier of the multiply)
-    // and inner + outer = |s1 - s2| + 1 (min + max of two numbers is their sum); for intervals that do not, the true
-    // overlap is zero and any answer is conservative.  NaN / inf from a degenerate d make u NaN -> candidate.
     float s1 = a1 * r1, s2 = a2 * r2;
     float c1, c2;
     asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(c1) : "v"(a1), "v"(r1));
@@ -131,9 +124,9 @@ __device__ __forceinline__ bool prefilter(float e1x, float e1y, float e1z, float
     float w = fabsf(s1 - s2) + 1.0f;                      // inner + outer
     float rmax = fmaxf(fabsf(r1), fabsf(r2));
     float t = __builtin_fmaf(-kKappa, rmax, thr - kKappa0);
-    // inner - t * outer = inner * (1 + t) - t * w
-    float u = __builtin_fmaf(inner, 1.0f + t, -(t * w));
+    float u = __builtin_fmaf(inner, 1.0f + t, -(t * w));  // inner - t * outer
     return !(u <= 0.0f);
+#endif
 }
 
 // an inverse-alive slot takes its position among the inverse refs of its target segment (global id g_tgt) from the

@@ -249,6 +249,46 @@ L3D_HD float mutual_overlap(const double px[4], const double py[4], bool fast = 
     return (float)(sqrt(in2) / (double)max_dist);
 }
 
+// ---- fp32 pre-filter of the match kernel: "could overlap(src, tgt) exceed thr?" --------------------------------------
+// (e?x, e?y): unit normals of the source segment's two epipolar lines in the target image, e?z their offsets w.r.t. the
+// image centre; (qx, qy) = q1 - centre, (qz, qw) = q1 - q2 of the target segment.  s_i = a_i / d_i is the position of
+// the intersection of epipolar line i with the target line in units of the target segment (q1 -> 0, q2 -> 1), and for
+// intervals [s1, s2] that meet [0, 1] at all
+//     inner = |clamp(s1) - clamp(s2)|,   inner + outer = |s1 - s2| + 1          (overlap = inner / outer)
+// The test "inner > t * outer" with t = thr - kKappa0 - kKappa / min|d_i| (the slack covers the fp32 rounding of a and
+// d, in pixels) is evaluated WITHOUT the two reciprocals (v_rcp_f32: 8 issue cycles each, a quarter of the round-2
+// form's cost per target): multiplied through by |d1 d2| * min|d_i| > 0 it reads
+//     X * (dmin + T) - T * Y > 0,    X = |A1 d2 - A2 d1|,  A_i = d_i * clamp(a_i / d_i) = median(0, a_i, d_i) (either
+//     sign of d_i),  Y = |a1 d2 - a2 d1| + |d1 d2|,  T = t * dmin = (thr - kKappa0) * dmin - kKappa
+// For intervals that miss [0, 1] the true overlap is zero and any answer is conservative.  A degenerate d (zero, NaN)
+// gives u = 0 or NaN: "candidate", sorted out by the exact test.  tests/cpp/prefilter_cover.cpp pins, on the host,
+// that no pair whose exact overlap exceeds thr is ever rejected.
+constexpr float kKappa = 1.0e-2f;   // slack, px
+constexpr float kKappa0 = 2.0e-4f;
+L3D_HD float med3_zero(float a, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(0.0f, a, d);
+#else
+    const float lo = d < 0.0f ? d : 0.0f, hi = d < 0.0f ? 0.0f : d;
+    return a < lo ? lo : (a > hi ? hi : a);   // (NaN a: stays NaN -> u NaN -> candidate)
+#endif
+}
+L3D_HD bool prefilter_products(float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
+                               float qx, float qy, float qz, float qw, float thr) {
+    const float a1 = __builtin_fmaf(e1x, qx, __builtin_fmaf(e1y, qy, e1z));
+    const float a2 = __builtin_fmaf(e2x, qx, __builtin_fmaf(e2y, qy, e2z));
+    const float d1 = __builtin_fmaf(e1x, qz, e1y * qw);
+    const float d2 = __builtin_fmaf(e2x, qz, e2y * qw);
+    const float A1 = med3_zero(a1, d1), A2 = med3_zero(a2, d2);
+    const float X = __builtin_fmaf(A1, d2, -(A2 * d1));
+    const float V = __builtin_fmaf(a1, d2, -(a2 * d1));
+    const float Y = __builtin_fabsf(V) + __builtin_fabsf(d1 * d2);
+    const float dmin = __builtin_fminf(__builtin_fabsf(d1), __builtin_fabsf(d2));
+    const float T = __builtin_fmaf(thr - kKappa0, dmin, -kKappa);
+    const float u = __builtin_fmaf(__builtin_fabsf(X), dmin + T, -(T * Y));
+    return !(u < 0.0f);
+}
+
 struct PairResult {
     float overlap;
     float dp1, dp2, dq1, dq2;

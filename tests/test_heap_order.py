@@ -38,3 +38,16 @@ def test_division_free_orientation_decision_equals_the_reference_arithmetic(tmp_
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "identical" in out.stdout and " 0 mismatches" in out.stdout
+
+
+def test_prefilter_without_reciprocals_never_rejects_an_accepted_pair(tmp_path):
+    """l3d_dev.h: prefilter_products (the fp32 pre-filter of k_match_pairs in its form without v_rcp_f32) against the
+    reference's arithmetic (exact_overlap = Line3D::matchingCPU line3D.cc:919-958 + mutualOverlap :1086-1165): on 61
+    million (pair, threshold) cases -- random, along the epipolar band, nearly parallel to the pencil, end points on an
+    epipolar line, thresholds up to the pair's own overlap -- no pair with overlap > threshold is rejected."""
+    exe = str(tmp_path / "prefilter_cover")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                           os.path.join(ROOT, "tests", "cpp", "prefilter_cover.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "covered" in out.stdout and " 0 lost" in out.stdout

@@ -55,11 +55,15 @@ struct WaveTime { unsigned long long cycles, realtime; };
 #define OP_cmp_f32_s(x) { unsigned long long m_; asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m_) : "v"(x), "v"(b)); }
 #define OP_cndmask_s(x) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(b), "s"(0x5555555555555555ull));
 #define OP_min_f32(x) asm volatile("v_min_f32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_med3_f32(x) asm volatile("v_med3_f32 %0, %0, %1, 0" : "+v"(x) : "v"(b));
+#define OP_add_abs_f32(x) asm volatile("v_add_f32_e64 %0, |%0|, |%1|" : "+v"(x) : "v"(b));
 #define OP_readlane(x) { unsigned r_; asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(r_) : "v"(x)); }
 #define OP_writelane(x) asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(x) : "s"(7u));
 DEF_KERNEL(cmp_f32_s, float, OP_cmp_f32_s)
 DEF_KERNEL(cndmask_s, float, OP_cndmask_s)
 DEF_KERNEL(min_f32, float, OP_min_f32)
+DEF_KERNEL(med3_f32, float, OP_med3_f32)
+DEF_KERNEL(add_abs_f32, float, OP_add_abs_f32)
 DEF_KERNEL(readlane, float, OP_readlane)
 DEF_KERNEL(writelane, float, OP_writelane)
 DEF_KERNEL(fma_f32, float, OP_fma_f32)
@@ -252,7 +256,7 @@ int main(int argc, char** argv) {
         O(fma_f32, "FMA_F32", 0), O(mul_f32, "MUL_F32", 0), O(add_f32, "ADD_F32", 0), O(max_f32, "other", 0),
         O(rcp_f32, "TRANS_F32", 0), O(rsq_f32, "TRANS_F32", 0), O(sqrt_f32, "TRANS_F32", 0), O(exp_f32, "TRANS_F32", 0),
         O(cmp_f32, "other", 0), O(cndmask_b32, "other", 0), O(mov_b32, "other", 0),
-        O(cmp_f32_s, "other", 0), O(cndmask_s, "other", 0), O(min_f32, "other", 0), O(readlane, "other", 0), O(writelane, "other", 0),
+        O(cmp_f32_s, "other", 0), O(cndmask_s, "other", 0), O(min_f32, "other", 0), O(med3_f32, "other", 0), O(add_abs_f32, "ADD_F32 (VOP3, |x| modifiers)", 0), O(readlane, "other", 0), O(writelane, "other", 0),
         O(mov_b64, "other", 1), O(ldexp_f64, "other", 1), O(cmp_f64_s, "other", 1), O(cmp_class_f64, "other", 1), O(fmac_f64, "FMA_F64", 1),
         O(lshl_add_u32, "INT32", 2), O(cmp_u32_s, "INT32", 2),
         O(pk_fma_f32, "FMA_F32 (packed)", 1), O(pk_mul_f32, "MUL_F32 (packed)", 1), O(pk_add_f32, "ADD_F32 (packed)", 1),
