@@ -105,6 +105,10 @@ __device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K, uint3
 
 // conservative fp32 test "could overlap(src, tgt) exceed thr?" (l3d_dev.h: prefilter_products, the form without
 // reciprocals).  -DL3D_PREFILTER_RCP restores the round-2 form (two v_rcp_f32, clamp output modifier) for A/B runs.
+// scalar-unit bit operations the compiler does not select by itself (wave-uniform operands)
+__device__ __forceinline__ uint32_t s_ff1(uint64_t m) { uint32_t r; asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(m)); return r; }
+__device__ __forceinline__ uint64_t s_bitset0(uint64_t m, uint32_t bit) { asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit)); return m; }
+
 __device__ __forceinline__ bool prefilter(float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
                                           const v4f q, float thr) {
 #ifndef L3D_PREFILTER_RCP
@@ -317,7 +321,12 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         if (has) {
             const SegD& sd = *(const SegD*)&vs.segx[sg];                       // a SegX starts with its SegD
             const SegD& td = *(const SegD*)(tsd + (size_t)target_index(tp) * tsd_stride);
-            pass = depths_positive(sd, td, vs.C, vt.C);
+            // (the camera centres and, in stage 2, F are fetched here, per drain, through laundered pointers: hoisted out
+            // of the walk they occupy 30 SGPRs there, and the walk's own pointers are then spilled into VGPR lanes and
+            // come back by v_readlane at every step)
+            const ViewDev* pvs = &vs; const ViewDev* pvt = &vt;
+            asm volatile("" : "+s"(pvs), "+s"(pvt));
+            pass = depths_positive(sd, td, pvs->C, pvt->C);
         }
         const uint64_t m = L3D_BALLOT(pass);
         if (pass) ring2[(tail2 + prefix(m)) & (kRing2 - 1)] = ent;
@@ -336,7 +345,9 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         float ovv = 0.0f;
         if (has) {
             const float4 s4 = vs.seg4[sg], t4 = ts4[target_index(tg)];
-            const float ov = exact_overlap(F, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w, fastm);
+            const double* Fp = pd.F;
+            asm volatile("" : "+s"(Fp));
+            const float ov = exact_overlap(Fp, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w, fastm);
             // a full row only admits overlaps that reach its K-th best (minov == thr while the row is not full); an overlap
             // EQUAL to the K-th best goes on to the insertion: a tie at the kNN-th place flags the row for the exact replay
             const float need = L.minov[sl];
@@ -501,7 +512,8 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     // and the sorted copy of the records was written by k_cull_prepare before this launch, so a load through the
     // constant address space is an s_load_dwordx4 -- no LDS tile, no barrier, no lane broadcast.
     typedef const __attribute__((address_space(4))) v4f* RecPtr;
-    RecPtr tfc = (RecPtr)(unsigned long)tf;
+    typedef const __attribute__((address_space(4))) char* RecBytes;
+    RecBytes tfb = (RecBytes)(unsigned long)tf;
     const uint32_t nch = (Mt + 63) / 64;
     // CENTRE-OUT: rows and targets are both ordered by the lower end of their bands, and a row's best matches are the
     // targets whose band nearly coincides with its own.  Walking the chunks in ascending order fills every row's table
@@ -562,8 +574,12 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                 // two targets per step: after their pushes the ring holds at most 63 + 2*64 candidates (kRing = 256, which
                 // is what lets a seventh wave per SIMD fit the LDS); the candidate flags go from the comparison straight
                 // into the execution mask of their push
-                const uint32_t j0 = __builtin_ctzll(m); m &= m - 1;
-                const bool v1 = m != 0; const uint32_t j1 = v1 ? __builtin_ctzll(m) : j0; m &= m - 1;
+                // (scalar-unit economy: the walk costs ~30 scalar instructions per step at 4.3 issue cycles each, more than
+                // its vector instructions -- s_bitset0 instead of the three-instruction m &= m - 1; an empty m gives bit
+                // index -1, which clears bit 63 of zero)
+                const uint32_t j0 = s_ff1(m); m = s_bitset0(m, j0);
+                const bool v1 = m != 0; const uint32_t j1r = s_ff1(m); m = s_bitset0(m, j1r);
+                const uint32_t j1 = v1 ? j1r : j0;
 #ifdef L3D_TARGETS_BY_READLANE
                 auto bcast = [&](uint32_t j) -> v4f {
                     v4f q;
@@ -575,7 +591,11 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                 };
                 const v4f q0 = bcast(j0), q1 = bcast(j1);
 #else
-                const v4f q0 = tfc[tb + j0], q1 = tfc[tb + j1];
+                // (32-bit byte offsets: s_load_dwordx4 base, offset -- no 64-bit address arithmetic on the scalar unit)
+                v4f q0 = *(RecPtr)(tfb + ((tb + j0) << 4)), q1 = *(RecPtr)(tfb + ((tb + j1) << 4));
+#ifdef L3D_LOADS_FIRST
+                asm volatile("" : "+s"(q0), "+s"(q1));   // (A/B: both records requested before the first is used)
+#endif
 #endif
                 // (the lane masks are built from the comparison itself and the uniform masks by scalar ANDs: a ballot of
                 // `live & test` would first turn the flag into 0/1 in a VGPR)
