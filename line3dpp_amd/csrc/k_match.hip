@@ -318,14 +318,15 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t sl = ent >> 23, tp = ent & 0x7FFFFFu;
         const uint32_t sg = __shfl(src, sl);   // the ring of a wave only holds rows of that wave
         bool pass = false;
+        // (A/B -DL3D_LAUNDER: the camera centres and, in stage 2, F fetched per drain through laundered pointers, in
+        // wave-uniform control flow so that they stay scalar loads: hoisted out of the walk they occupy 42 SGPRs there)
+        const ViewDev* pvs = &vs; const ViewDev* pvt = &vt;
+#if defined(L3D_LAUNDER) || defined(L3D_LAUNDER_C)
+        asm volatile("" : "+s"(pvs), "+s"(pvt));
+#endif
         if (has) {
             const SegD& sd = *(const SegD*)&vs.segx[sg];                       // a SegX starts with its SegD
             const SegD& td = *(const SegD*)(tsd + (size_t)target_index(tp) * tsd_stride);
-            // (the camera centres and, in stage 2, F are fetched here, per drain, through laundered pointers: hoisted out
-            // of the walk they occupy 30 SGPRs there, and the walk's own pointers are then spilled into VGPR lanes and
-            // come back by v_readlane at every step)
-            const ViewDev* pvs = &vs; const ViewDev* pvt = &vt;
-            asm volatile("" : "+s"(pvs), "+s"(pvt));
             pass = depths_positive(sd, td, pvs->C, pvt->C);
         }
         const uint64_t m = L3D_BALLOT(pass);
@@ -343,10 +344,17 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t sg = __shfl(src, sl);
         bool pending = false;
         float ovv = 0.0f;
+#if defined(L3D_LAUNDER) || defined(L3D_LAUNDER_F)
+        const double* Fp = pd.F;
+        asm volatile("" : "+s"(Fp));
+#elif defined(L3D_LAUNDER_F2)
+        const double* Fp = F;
+        if (WPG == 2) { Fp = pd.F; asm volatile("" : "+s"(Fp)); }
+#else
+        const double* Fp = F;
+#endif
         if (has) {
             const float4 s4 = vs.seg4[sg], t4 = ts4[target_index(tg)];
-            const double* Fp = pd.F;
-            asm volatile("" : "+s"(Fp));
             const float ov = exact_overlap(Fp, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w, fastm);
             // a full row only admits overlaps that reach its K-th best (minov == thr while the row is not full); an overlap
             // EQUAL to the K-th best goes on to the insertion: a tie at the kNN-th place flags the row for the exact replay
@@ -577,9 +585,14 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                 // (scalar-unit economy: the walk costs ~30 scalar instructions per step at 4.3 issue cycles each, more than
                 // its vector instructions -- s_bitset0 instead of the three-instruction m &= m - 1; an empty m gives bit
                 // index -1, which clears bit 63 of zero)
+#ifndef L3D_NO_BITSET
                 const uint32_t j0 = s_ff1(m); m = s_bitset0(m, j0);
                 const bool v1 = m != 0; const uint32_t j1r = s_ff1(m); m = s_bitset0(m, j1r);
                 const uint32_t j1 = v1 ? j1r : j0;
+#else
+                const uint32_t j0 = __builtin_ctzll(m); m &= m - 1;
+                const bool v1 = m != 0; const uint32_t j1 = v1 ? __builtin_ctzll(m) : j0; m &= m - 1;
+#endif
 #ifdef L3D_TARGETS_BY_READLANE
                 auto bcast = [&](uint32_t j) -> v4f {
                     v4f q;
@@ -592,9 +605,13 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                 const v4f q0 = bcast(j0), q1 = bcast(j1);
 #else
                 // (32-bit byte offsets: s_load_dwordx4 base, offset -- no 64-bit address arithmetic on the scalar unit)
+#ifndef L3D_NO_OFF32
                 v4f q0 = *(RecPtr)(tfb + ((tb + j0) << 4)), q1 = *(RecPtr)(tfb + ((tb + j1) << 4));
-#ifdef L3D_LOADS_FIRST
-                asm volatile("" : "+s"(q0), "+s"(q1));   // (A/B: both records requested before the first is used)
+#else
+                v4f q0 = ((RecPtr)tfb)[tb + j0], q1 = ((RecPtr)tfb)[tb + j1];
+#endif
+#ifndef L3D_NO_LOADS_FIRST
+                asm volatile("" : "+s"(q0), "+s"(q1));   // both records requested before the first is used (C2 / C4 -1 %)
 #endif
 #endif
                 // (the lane masks are built from the comparison itself and the uniform masks by scalar ANDs: a ballot of
