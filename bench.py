@@ -147,7 +147,7 @@ _CLASS_OPS = {"ADD_F32": ["add_f32"], "MUL_F32": ["mul_f32"], "FMA_F32": ["fma_f
               # everything the class counters do not cover (compares, selects, moves, min/max, lane ops, ldexp, the
               # division helpers): the streams measured for such instructions (without VCC hazards); the roof is priced
               # with the CHEAPEST of them -- the choice that makes the ceiling highest, i.e. the fraction smallest
-              "other": ["mov_b32", "mov_b64", "cndmask_s", "cmp_f32_s", "cmp_f64_s", "min_f32", "max_f32", "max_f64", "readlane",
+              "other": ["mov_b32", "mov_b64", "cndmask_s", "cmp_f32_s", "cmp_f64_s", "min_f32", "max_f32", "med3_f32", "max_f64", "readlane",
                         "writelane", "ldexp_f64", "cmp_class_f64", "div_scale_f64", "div_fmas_f64", "div_fixup_f64"]}
 
 
@@ -382,9 +382,21 @@ def main():
                       "exact_tests_over_accepted": round(cand["exact_tests"] / max(cand["accepted"], 1), 3) if cand.get("exact_tests") else None,
                       "valu_per_target_visit": fit["valu_per_target_visit"], "valu_per_drain": fit["valu_per_drain"],
                       "valu_per_epilogue_pass": fit["valu_per_epilogue_pass"], "fit": fit["_file"]}
+        # the scalar unit: its instructions issue beside the vector ones (another wave's), one per ~4.3 cycles and SIMD
+        # (calibration streams s_add_u32 / s_and_b32 / s_lshl_b32) -- in the kernel's walk it is the busier port
+        scalar = None
+        n_salu = (pmc.get("counters_per_launch") or {}).get("SQ_INSTS_SALU")
+        if n_salu and calib:
+            sc = [o["cycles_per_unit_simd_best"] for o in calib["ops"] if o.get("class") == "SALU" and o.get("cycles_per_unit_simd_best")]
+            if sc:
+                cyc_s = sum(sc) / len(sc)
+                speak = 1024 * 2.4 / cyc_s
+                sach = n_salu / (avg_ms * 1e-3) / 1e9
+                scalar = {"achieved": round(sach, 2), "peak": round(speak, 1), "unit": "G SALU instr/s", "frac": round(sach / speak, 4),
+                          "issue_cycles_per_instruction": round(cyc_s, 3), "salu_per_valu_instruction": round(n_salu / pmc["valu_insts_per_launch"], 3)}
         roofline = {"bound": "valu", "achieved": round(valu_achieved, 2), "peak": round(peak, 1),
                     "unit": "G wave64 VALU instr/s", "frac": round(valu_achieved / peak, 4), "peak_basis": basis,
-                    "useful_frac": useful["useful_frac"] if useful else None, "useful_work": useful,
+                    "useful_frac": useful["useful_frac"] if useful else None, "useful_work": useful, "scalar_unit": scalar,
                     "traffic": pmc["traffic_bytes_per_launch"],
                     "valu_busy_fraction_pmc": pmc["valu_busy_fraction"], "avg_waves_per_simd": pmc["avg_waves_per_simd"],
                     # the metric counts nominal Ms*Mt tests; most are culled before any arithmetic:

@@ -1038,7 +1038,7 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
         /* lists beyond one wave's capacity: two waves up to 2x, four up to 4x (fixed grids over the hand-over lists) */   \
         hipLaunchKernelGGL((k_lists<2, B>), dim3(16384), dim3(128), lds2, st, views, pairs, lviews, opairs, gseg_view,     \
                            off64, inv, slots, uniform_K, lp, 0u);                                                          \
-        hipLaunchKernelGGL((k_lists<4, B>), dim3(4096), dim3(256), lds4, st, views, pairs, lviews, opairs, gseg_view,      \
+        hipLaunchKernelGGL((k_lists<4, B>), dim3(2048), dim3(256), lds4, st, views, pairs, lviews, opairs, gseg_view,      \
                            off64, inv, slots, uniform_K, lp, 0u);                                                          \
     } while (0)
     if (wide) L3D_LISTS(256); else L3D_LISTS(128);

@@ -41,6 +41,10 @@ namespace {
 
 constexpr int kBlock = kMatchRows;  // rows per work item = lanes of a wave64; a workgroup is WPG (1 or 2) such waves
 constexpr int kRing = 256;          // candidate ring (entries); >= 63 + 2*64 (drained after every two pushes)
+constexpr int kRing1 = 128;         // the same for the staged one-wave-per-item variant, which drains after EVERY push
+                                    // (>= 63 + 64): its LDS is then 5.5 KiB per wave at K = 10 = 11 allocation granules
+                                    // of 512 B, and 28 such waves fit a CU's 160 KiB (7 per SIMD; 6.3 KiB gave 6)
+__host__ __device__ constexpr int ring_entries(bool staged, uint32_t waves) { return (staged && waves == 1) ? kRing1 : kRing; }
 constexpr int kRing2 = 128;         // second ring (bounded kNN): candidates that passed the depth test; >= 63 + 64
 
 // All LDS pointers carry the LDS address space in their TYPE: a generic pointer that travels through a struct
@@ -74,32 +78,30 @@ template <> struct IdxT<true> { typedef uint16_t type; };
 template <bool IX16>
 struct Lds {
     typedef typename IdxT<IX16>::type idx_t;
-    L3D_LDS volatile uint32_t* ring;   // [waves][kRing]
+    L3D_LDS volatile uint32_t* ring;   // [waves][ring_entries]
     L3D_LDS volatile uint32_t* ring2;  // [waves][kRing2] (bounded kNN only)
-    L3D_LDS volatile uint32_t* row_src;  // [kBlock] source segment of each row (epilogue)
     L3D_LDS volatile float* minov;     // [kBlock]
     L3D_LDS volatile uint32_t* claim;  // [kBlock]
     L3D_LDS volatile float* top_ov;    // [kBlock*K]
     L3D_LDS volatile idx_t* cnt;       // [kBlock]
-    L3D_LDS volatile idx_t* minpos;    // [kBlock] slot of the worst entry of a full row
+    L3D_LDS volatile idx_t* minpos;    // [kBlock] slot of the worst entry of a full row; top bit (kTie): the row saw equal
+                                       // overlaps where the reference's heap order decides (written under the row's lock)
     L3D_LDS volatile idx_t* top_ix;    // [kBlock*K]
-    L3D_LDS volatile uint8_t* tie;     // [kBlock] row saw equal overlaps where the reference's heap order decides
+    static constexpr idx_t kTie = (idx_t)((idx_t)1 << (8 * sizeof(idx_t) - 1));
 };
 
 template <bool IX16>
 __device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K, uint32_t waves, bool two_rings) {
     typedef typename IdxT<IX16>::type idx_t;
     Lds<IX16> l;
-    l.ring = (L3D_LDS volatile uint32_t*)base; base += waves * kRing * sizeof(uint32_t);
+    l.ring = (L3D_LDS volatile uint32_t*)base; base += waves * ring_entries(two_rings, waves) * sizeof(uint32_t);
     l.ring2 = (L3D_LDS volatile uint32_t*)base; if (two_rings) base += waves * kRing2 * sizeof(uint32_t);
-    l.row_src = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
     l.minov = (L3D_LDS volatile float*)base; base += kBlock * 4;
     l.claim = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
     l.top_ov = (L3D_LDS volatile float*)base; base += (size_t)kBlock * K * 4;
     l.cnt = (L3D_LDS volatile idx_t*)base; base += kBlock * sizeof(idx_t);
     l.minpos = (L3D_LDS volatile idx_t*)base; base += kBlock * sizeof(idx_t);
     l.top_ix = (L3D_LDS volatile idx_t*)base; base += (size_t)kBlock * K * sizeof(idx_t);
-    l.tie = (L3D_LDS volatile uint8_t*)base;
     return l;
 }
 
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     if (cp.item_order) w = cp.item_order[w];
     const WorkItem wi = work[w];
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
-    const unsigned long long t_start = clock64();
+    const unsigned long long t_start = clock64(), w_start = wall_clock64();
     unsigned long long t_s1 = 0, t_s2 = 0;
 #define L3D_TIC const unsigned long long tic_ = clock64()
 #define L3D_TOC(acc) acc += clock64() - tic_
@@ -211,7 +213,9 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     // below (its mask depends on q) is compiled as a divergent loop with vector addresses
     const uint32_t q = WPG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
     const uint32_t tid = threadIdx.x & 63u, lane = tid;          // row of the work item = lane
-    L3D_LDS volatile uint32_t* ring = L.ring + q * kRing;
+    constexpr uint32_t kRingN = (uint32_t)ring_entries(STAGED, WPG);
+    constexpr idx_t kTie = Lds<IX16>::kTie;
+    L3D_LDS volatile uint32_t* ring = L.ring + q * kRingN;
     L3D_LDS volatile uint32_t* ring2 = L.ring2 + q * kRing2;
     // epipolar-band culling (kNN mode only: the keep-all rows must be filled in ascending target order)
     const PairCull* pc = (MODE == 0 && !BRUTE && cp.cull && cp.cull[wi.pair].enabled) ? &cp.cull[wi.pair] : nullptr;
@@ -253,8 +257,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         L.cnt[tid] = 0;
         L.minov[tid] = thr;
         L.claim[tid] = kEmpty;
-        L.row_src[tid] = src;
-        L.tie[tid] = 0;
+        L.minpos[tid] = 0;
     }
     if (WPG > 1) __syncthreads();
     uint32_t head = 0, tail = 0;   // wave-uniform ring cursors
@@ -286,8 +289,9 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             if (o < wo) { wo = o; wj = j; }
         }
         L.minov[sl] = wo;
-        L.minpos[sl] = wj;
+        L.minpos[sl] = (idx_t)(wj | (L.minpos[sl] & kTie));
     };
+    auto flag_tie = [&](uint32_t sl) { L.minpos[sl] = (idx_t)(L.minpos[sl] | kTie); };
 
     auto prefix = [&](uint64_t m) -> uint32_t {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t n = min(64u, tail - head);
         const bool has = lane < n;
         if (lane == 0) { L3D_STAT(1, n); L3D_STAT(8, 1); }
-        const uint32_t ent = ring[(head + lane) & (kRing - 1)];
+        const uint32_t ent = ring[(head + lane) & (kRingN - 1)];
         head += n;
         const uint32_t sl = ent >> 23, tp = ent & 0x7FFFFFu;
         const uint32_t sg = __shfl(src, sl);   // the ring of a wave only holds rows of that wave
@@ -360,6 +364,10 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             // EQUAL to the K-th best goes on to the insertion: a tie at the kNN-th place flags the row for the exact replay
             const float need = L.minov[sl];
             if (ov > thr && ov >= need) { pending = true; ovv = ov; L3D_STAT(2, 1); L3D_STAT(3, 1); }
+#ifdef L3D_STATS
+            else if (!(ov > thr)) L3D_STAT(10, 1);          // not a match at all: what the pre-filter's slack lets through
+            else L3D_STAT(11, 1);                           // a match that no longer reaches the row's K-th best
+#endif
         }
         // several candidates of one drain may belong to the same row: one at a time (compare-and-swap lock with two waves
         // per row group; a wave's own contenders are serialised by the LDS atomic unit just the same)
@@ -388,14 +396,14 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                     L.cnt[sl] = c + 1;
                     if (c + 1 == K) rescan_worst(sl);
                 } else {
-                    const uint32_t wj = L.minpos[sl];
+                    const uint32_t wj = L.minpos[sl] & (idx_t)~kTie;
                     const float mo = L.minov[sl];
                     if (ovv > mo) {
                         ov[wj] = ovv; ix[wj] = tg;
                         rescan_worst(sl);
-                        if (L.minov[sl] == mo) L.tie[sl] = 1;   // the evicted entry ties with the new K-th best
+                        if (L.minov[sl] == mo) flag_tie(sl);    // the evicted entry ties with the new K-th best
                     } else if (ovv == mo) {
-                        L.tie[sl] = 1;                          // a tie at the K-th place (whichever index would win)
+                        flag_tie(sl);                           // a tie at the K-th place (whichever index would win)
                     }
                 }
                 if (WPG > 1)
@@ -412,7 +420,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t n = min(64u, tail - head);
         const bool has = lane < n;
         if (lane == 0) { L3D_STAT(1, n); L3D_STAT(4, 1); }
-        const uint32_t ent = ring[(head + lane) & (kRing - 1)];
+        const uint32_t ent = ring[(head + lane) & (kRingN - 1)];
         head += n;
         const uint32_t sl = ent >> 23;
         uint32_t tg = ent & 0x7FFFFFu;
@@ -475,14 +483,14 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                         L.cnt[sl] = c + 1;
                         if (c + 1 == K) rescan_worst(sl);
                     } else {
-                        const uint32_t wj = L.minpos[sl];
+                        const uint32_t wj = L.minpos[sl] & (idx_t)~kTie;
                         const float mo = L.minov[sl];
                         if (res.overlap > mo) {
                             ov[wj] = res.overlap; ix[wj] = tg;
                             rescan_worst(sl);
-                            if (L.minov[sl] == mo) L.tie[sl] = 1;   // the evicted entry ties with the new K-th best
+                            if (L.minov[sl] == mo) flag_tie(sl);    // the evicted entry ties with the new K-th best
                         } else if (res.overlap == mo) {
-                            L.tie[sl] = 1;                          // a tie at the K-th place (whichever index would win)
+                            flag_tie(sl);                           // a tie at the K-th place (whichever index would win)
                         }
                     }
                 }
@@ -632,9 +640,23 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                 }
 #endif
                 if (m0 | m1) {
-                    if (m0) { if (c0b & lane_on) ring[(tail + prefix(m0)) & (kRing - 1)] = ent_hi | (tb + j0); tail += __popcll(m0); }
-                    if (m1) { if (c1b & lane_on) ring[(tail + prefix(m1)) & (kRing - 1)] = ent_hi | (tb + j1); tail += __popcll(m1); }
-                    pump(false);
+                    if (kRingN >= 63 + 2 * 64) {
+                        if (m0) { if (c0b & lane_on) ring[(tail + prefix(m0)) & (kRingN - 1)] = ent_hi | (tb + j0); tail += __popcll(m0); }
+                        if (m1) { if (c1b & lane_on) ring[(tail + prefix(m1)) & (kRingN - 1)] = ent_hi | (tb + j1); tail += __popcll(m1); }
+                        pump(false);
+                    } else {
+                        // the short ring holds one push beyond a partial drain: push, pump, push, pump (a loop, so that the
+                        // candidate pipeline is inlined once)
+                        for (uint32_t h = 0; h < 2; ++h) {
+                            const uint64_t mh = h ? m1 : m0;
+                            if (!mh) continue;
+                            const bool ch = h ? c1b : c0b;
+                            const uint32_t jh = h ? j1 : j0;
+                            if (ch & lane_on) ring[(tail + prefix(mh)) & (kRingN - 1)] = ent_hi | (tb + jh);
+                            tail += __popcll(mh);
+                            pump(false);
+                        }
+                    }
                 }
             }
         }
@@ -678,12 +700,11 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             const float oi = ov[i];
             for (uint32_t j = 0; j < i; ++j) t |= ov[j] == oi;
         }
-        if (t) L.tie[tid] = 1;
+        if (t) flag_tie(tid);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    L3D_LDS volatile uint32_t* row_src = L.row_src;
     const uint32_t n_rows = min((uint32_t)kBlock, Ms - wi.src0);
     const uint32_t gs = (uint32_t)(vs.segx - views[0].segx), gt = (uint32_t)(vt.segx - views[0].segx);
     const bool hands_inverse = pd.tgt > pd.src;   // inverse copy only towards a view processed later (:1680)
@@ -693,9 +714,9 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t it = base + lane;
         const bool in = it < n_items;
         const uint32_t r = in ? it / K : 0u, j = it - r * K;
-        const uint32_t rsrc = row_src[r];
+        const uint32_t rsrc = __shfl(src, r);           // every wave of the group holds the same 64 rows, row = lane
         // a flagged row is left to k_match_tied_rows entirely (slots, orientation flags, counters)
-        const bool tied = in && L.tie[r] != 0;
+        const bool tied = in && (L.minpos[r] & kTie) != 0;
         if (tied && j == 0) {
             const uint32_t pos = atomicAdd(of.tie_count, 1u);
             if (pos < of.tie_cap) of.tie_list[pos] = make_uint2(wi.pair, rsrc);
@@ -760,8 +781,9 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         unsigned hw = 0, xcc = 0;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_cycles[w][0] = t_start; g_cycles[w][1] = t_loop - t_start; g_cycles[w][2] = t_s1; g_cycles[w][3] = t_s2;
-        g_cycles[w][4] = t_end - t_loop; g_cycles[w][5] = t_end - t_start; g_cycles[w][6] = xcc; g_cycles[w][7] = hw;
+        // ([0], [6]: the 100 MHz wall counter -- s_memtime is not comparable between compute units)
+        g_cycles[w][0] = w_start; g_cycles[w][1] = t_loop - t_start; g_cycles[w][2] = t_s1; g_cycles[w][3] = t_s2;
+        g_cycles[w][4] = t_end - t_loop; g_cycles[w][5] = t_end - t_start; g_cycles[w][6] = wall_clock64(); g_cycles[w][7] = hw | ((unsigned long long)xcc << 32);
     }
 #endif
 }
@@ -772,10 +794,11 @@ bool match_staged(int mode, bool brute) {
     static const bool off = [] { const char* e = std::getenv("L3D_MATCH_STAGED"); return e && std::atoi(e) == 0; }();
     return mode == 0 && !brute && !off;
 }
-size_t match_lds_bytes(int mode, uint32_t K, bool ix16, uint32_t waves) {
+size_t match_lds_bytes(int mode, uint32_t K, bool ix16, uint32_t waves, bool brute) {
     const size_t ib = ix16 ? 2 : 4;
-    return (size_t)waves * (kRing + (match_staged(mode, false) ? kRing2 : 0)) * 4 + 3 * kBlock * 4 + 2 * kBlock * ib +
-           (mode == 0 ? (size_t)kBlock * K * (4 + ib) : 0) + kBlock;
+    const bool staged = match_staged(mode, brute);
+    return (size_t)waves * (ring_entries(staged, waves) + (staged ? kRing2 : 0)) * 4 + 2 * kBlock * 4 + 2 * kBlock * ib +
+           (mode == 0 ? (size_t)kBlock * K * (4 + ib) : 0);
 }
 
 // Two waves per work item pay off while the launch has few items for the machine (C0: kernel 0.34 -> 0.24 ms, C1 with
@@ -798,7 +821,7 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
     const uint32_t grid = ((nwork + 7) / 8) * 8;
     if (!(mode == 0 && !brute)) ix16 = false;       // the compact layout is only instantiated for the hot variant
     const uint32_t wpg = match_waves_per_group(mode, brute, nwork);
-    const size_t lds = match_lds_bytes(mode, maxK, ix16, wpg);
+    const size_t lds = match_lds_bytes(mode, maxK, ix16, wpg, brute);
 #define L3D_LAUNCH(M, B, X, W, S)                                                                             \
     do {                                                                                                      \
         hipError_t e = hipFuncSetAttribute((const void*)k_match_pairs<M, B, X, W, S>,                         \

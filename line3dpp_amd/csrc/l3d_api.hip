@@ -521,7 +521,7 @@ static int match_begin_body(l3d_ctx* c) {
         size_t n_work = 0; uint32_t maxMt = 0;
         for (auto& pd : c->pairs) { n_work += (pd.Ms + kMatchRows - 1) / kMatchRows; maxMt = std::max(maxMt, pd.Mt); }
         const uint32_t wpg = match_waves_per_group(0, c->brute, (uint32_t)std::min<size_t>(n_work, 0xFFFFFFFFu));
-        auto fits = [&](uint32_t K) { return match_lds_bytes(0, K, maxMt < 65536u && K < 65536u && !c->brute, wpg) <= 160 * 1024; };
+        auto fits = [&](uint32_t K) { return match_lds_bytes(0, K, maxMt < 65536u && K < 32768u && !c->brute, wpg, c->brute) <= 160 * 1024; };
         // beyond that, every row takes the exact replay path (k_match_tied_rows): slower per row, any kNN <= 4096
         c->knn_replay = !fits((uint32_t)c->kNN);
     } else c->knn_replay = false;
@@ -617,7 +617,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         maxMt = std::max(maxMt, pd.Mt);
     }
     const bool replay_all = mode == 0 && c->knn_replay;   // kNN beyond the LDS tables: every row through k_match_tied_rows
-    if (!replay_all && match_lds_bytes(mode, maxK, false, match_waves_per_group(mode, c->brute, (uint32_t)n_work)) > 160 * 1024)
+    if (!replay_all && match_lds_bytes(mode, maxK, false, match_waves_per_group(mode, c->brute, (uint32_t)n_work), c->brute) > 160 * 1024)
         return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
     L3D_HIP_CHECK(c->d_work.reserve(n_work));
     // the work list of these pairs is on the device already when the pair list has not changed since it was sent
@@ -655,7 +655,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         L3D_HIP_CHECK(launch_order_items(c->d_pairs.p, first, count, maxMt, pools, (uint32_t)n_work, c->stream));
     }
     L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
-    const bool ix16 = maxMt < 65536u && maxK < 65536u;   // 16-bit indices in the kernel's LDS tables
+    const bool ix16 = maxMt < 65536u && maxK < 32768u;   // 16-bit indices in the kernel's LDS tables (top bit of a row's minpos: tie flag)
     // bounded kNN: the orientation filter and the hypothesis counters of phase B are fused into the epilogue
     OrientFuse of{mode == 0 ? c->d_cnt_pack.p : nullptr, mode == 0 ? c->d_inv_pos.p : nullptr,
                   OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};

@@ -72,7 +72,7 @@ struct OrientFuse {
 };
 
 // ---- k_match.hip ----
-size_t match_lds_bytes(int mode, uint32_t K, bool ix16 = false, uint32_t waves = 1);
+size_t match_lds_bytes(int mode, uint32_t K, bool ix16 = false, uint32_t waves = 1, bool brute = false);
 constexpr uint32_t kMatchOrderMaxItems = 16384;   // launches up to this many work items: two waves per item
 constexpr uint32_t kMatchOrderMinItems = 3584;    // ... and, from this many on (more waves than wave slots), longest-first order
 uint32_t match_waves_per_group(int mode, bool brute, uint32_t nwork);   // waves that share one 64-row work item of k_match_pairs

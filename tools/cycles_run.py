@@ -31,16 +31,21 @@ n_items = min(sum((M[int(s)] + 63) // 64 for s, _ in pairs), 1 << 16)
 buf = np.zeros((n_items, 8), np.uint64)
 L.l3d_debug_cycles(buf.ctypes.data_as(C.c_void_p), n_items)
 start, loop, s1, s2, epi, total = (buf[:, k].astype(np.float64) for k in range(6))
+wend = buf[:, 6].astype(np.float64)
 ok = total > 0
-start, loop, s1, s2, epi, total = (a[ok] for a in (start, loop, s1, s2, epi, total))
-t0, t1 = start.min(), (start + total).max()
+start, loop, s1, s2, epi, total, wend = (a[ok] for a in (start, loop, s1, s2, epi, total, wend))
+# start / wend: 100 MHz wall counter (common to the whole device); the rest in shader cycles of the item's own CU
+t0, t1 = start.min(), wend.max()
 span = t1 - t0
+dur = wend - start
 out = {"config": cfg, "build_info": L.l3d_build_info().decode(), "items_recorded": int(ok.sum()), "match_kernel_ms": tm["match_kernel_ms"],
-       "launch_span_cycles": float(span),
+       "launch_span_us": float(span) / 100.0,
+       "item_us_pct_5_50_95_max": [float(x) / 100.0 for x in np.percentile(dur, [5, 50, 95, 100])],
        "item_cycles_pct_5_50_95_max": [float(x) for x in np.percentile(total, [5, 50, 95, 100])],
        "share_of_item_time": {"walk (pre-filter, pushes)": float(((loop - s1 - s2).sum()) / total.sum()), "stage 1 (depth decision)": float(s1.sum() / total.sum()),
                               "stage 2 (exact overlap + insertion)": float(s2.sum() / total.sum()), "epilogue": float(epi.sum() / total.sum())},
-       "sum_item_cycles_over_span": float(total.sum() / span)}
+       "mean_items_in_flight": float(dur.sum() / span)}
+total = dur
 # items in flight over the launch, by decile
 edges = np.linspace(t0, t1, 11)
 infl = []

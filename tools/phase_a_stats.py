@@ -22,5 +22,6 @@ nominal = sc.pair_tests()[0]
 print(json.dumps({"config": cfg, "build_info": L.l3d_build_info().decode(), "nominal_pair_tests": nominal,
                   "prefilter_tests": int(out[0]), "exact_tests": int(out[1]), "passed_overlap": int(out[2]),
                   "accepted": int(out[3]), "drains": int(out[4]), "band_pairs": int(out[5]), "kept_slots": int(out[6]),
-                  "work_items": int(out[7]), "stage1_drains": int(out[8]), "depth_passed": int(out[9]), "prefilter_fraction_of_nominal": out[0] / nominal,
+                  "work_items": int(out[7]), "stage1_drains": int(out[8]), "depth_passed": int(out[9]),
+                  "stage2_not_a_match": int(out[10]), "stage2_below_kth_best": int(out[11]), "prefilter_fraction_of_nominal": out[0] / nominal,
                   "band_fraction_of_nominal": out[5] / nominal}))
