@@ -16,7 +16,8 @@ for f in sorted(glob.glob(d + "/*/**/p_counter_collection.csv", recursive=True))
         k = r["Kernel_Name"].split("(")[0].split("::")[-1]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
 per = {k: {c: v / max(len(disp[(k, c)]), 1) for c, v in cs.items()} for k, cs in acc.items()}
-name = next(k for k in per if k.startswith("k_match_pairs"))
+# the variant that did the work (bench.py's cold call / parity sample may launch other instantiations on small scenes)
+name = max((k for k in per if k.startswith("k_match_pairs")), key=lambda k: acc[k].get("GRBM_GUI_ACTIVE", 0.0))
 m = per[name]
 from line3dpp_amd import _lib
 # (reading the build id needs the library only, not a GPU)
