@@ -105,18 +105,35 @@ def _wait_for_exchange(buf, device):
 
 
 def gather_slabs(slabs, rank, world_size, device, group=None):
-    """all-gather of the record arrays of the sharded list pass (Line3D.listsShard): every rank's slab of every array
-    lands at its place in every rank's array.  slabs = [(slab pointer, slab bytes, full-array pointer)]; equal slab
-    sizes by construction, so each array is ONE all_gather_into_tensor."""
+    """Every rank's slab of every record array of the sharded list pass (Line3D.listsShard) lands at its place in every
+    rank's array.  slabs = [(slab pointer, slab bytes, full-array pointer)]; equal slab sizes by construction.
+
+    Default: DIRECT exchange -- one send and one receive per peer, all posted at once (batch_isend_irecv).  The xGMI
+    fabric of an 8-GPU node is a full mesh (7 links per GPU, one per peer), so the seven transfers of a rank run on seven
+    links side by side and a link carries one slab; a ring all-gather moves (N-1) slabs over ONE link per rank, N-1
+    times as long.  L3D_GATHER_COLLECTIVE=1 uses all_gather_into_tensor instead (RCCL's choice of algorithm), for
+    whoever has a node to compare them on."""
     import torch.distributed as dist
-    for sp, sb, fp in slabs:
+    collective = bool(os.environ.get("L3D_GATHER_COLLECTIVE"))
+    ops = []
+    for i, (sp, sb, fp) in enumerate(slabs):
         if not sb:
             continue
         full = device_tensor(fp, sb * world_size, device)
         mine = full[rank * sb:(rank + 1) * sb]
-        # RCCL gathers in place when the input is the rank's own slice of the output (no copy of the slab on the send
-        # side); the CPU backend of the tests gets a copy
-        dist.all_gather_into_tensor(full, mine if full.is_cuda else mine.clone(), group=group)
+        if collective or world_size == 1:
+            # RCCL gathers in place when the input is the rank's own slice of the output (no copy of the slab on the
+            # send side); the CPU backend of the tests gets a copy
+            dist.all_gather_into_tensor(full, mine if full.is_cuda else mine.clone(), group=group)
+            continue
+        glob = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+        for q in range(world_size):       # disjoint slices of one array: sends read `mine`, receives fill the others
+            if q != rank:
+                ops.append(dist.P2POp(dist.irecv, full[q * sb:(q + 1) * sb], glob(q), group, tag=i))   # tag = array
+                ops.append(dist.P2POp(dist.isend, mine, glob(q), group, tag=i))
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
     if slabs:
         _wait_for_exchange(device_tensor(slabs[0][2], 1, device), device)
 

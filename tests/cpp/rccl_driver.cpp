@@ -10,7 +10,7 @@
 //   l3d_match_pairs   (late range)      the rest of its pairs, while the halo travels
 //   l3d_expand_slot_indices             received pairs -> slots (re-derived bit-identically)
 //   l3d_lists_shard_views               phase B's list pass for the rank's views
-//   ncclAllGather x 4 (in place)        record slabs of the list pass
+//   ncclSend/ncclRecv per peer x 4 arrays, one group (in place)   record slabs of the list pass
 //   l3d_match_finish                    tail of phase B on the records of all ranks (L3D_ERR_RETRY: pools enlarged, repeat)
 //   l3d_compute_affinity
 //
@@ -144,9 +144,16 @@ int main(int argc, char** argv) {
     for (int attempt = 0; attempt < 8 && rc == L3D_ERR_RETRY; ++attempt) {
         void* slab[4]; uint64_t bytes[4]; void* full[4];
         L3D(l3d_lists_shard_views(c, (uint32_t)rank, (uint32_t)world, vb[rank], vb[rank + 1], slab, bytes, full));
+        // direct exchange, in place (the rank's slab is its own slice of the array): one send and one receive per peer
+        // and array in ONE group -- the xGMI mesh gives every pair of GPUs its own link, so the N-1 transfers of a rank
+        // run side by side (a ring all-gather would push N-1 slabs through one link)
         NCCL(ncclGroupStart());
-        for (int k = 0; k < 4; ++k)   // in place: the rank's slab is its own slice of the array
-            NCCL(ncclAllGather(slab[k], full[k], (size_t)bytes[k], ncclUint8, comm, comm_stream));
+        for (int k = 0; k < 4; ++k)
+            for (int q = 0; q < world; ++q) {
+                if (q == rank || !bytes[k]) continue;
+                NCCL(ncclSend(slab[k], (size_t)bytes[k], ncclUint8, q, comm, comm_stream));
+                NCCL(ncclRecv((char*)full[k] + (size_t)q * bytes[k], (size_t)bytes[k], ncclUint8, q, comm, comm_stream));
+            }
         NCCL(ncclGroupEnd());
         HIP(hipStreamSynchronize(comm_stream));
         rc = l3d_match_finish(c);
