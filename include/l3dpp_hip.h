@@ -97,7 +97,7 @@ const char* l3d_build_info(void);
 
 /* ---- (1) context layer ------------------------------------------------------------- */
 
-/* Line3D::Line3D (line3D.cc:6-69) with neighbors_by_worldpoints=false, use_GPU=true.
+/* Line3D::Line3D (line3D.cc:6-69) with use_GPU=true (neighbours: per view, l3d_add_view / l3d_add_view_worldpoints).
  * `device` = HIP device ordinal.  `stream` = hipStream_t to launch on (0 = default stream). */
 l3d_ctx* l3d_create(int device, void* stream);
 void l3d_destroy(l3d_ctx*);
@@ -107,6 +107,24 @@ void l3d_destroy(l3d_ctx*);
 int l3d_add_view(l3d_ctx*, uint32_t camID, const float* segs4, uint32_t M, const double K[9],
                  const double R[9], const double t[3], uint32_t width, uint32_t height,
                  float median_depth, const uint32_t* neighbors, uint32_t n_neighbors);
+
+/* The same with a WORLDPOINT list instead of the neighbour list: Line3D::addImage on an instance constructed with
+ * neighbors_by_worldpoints=true (line3D.cc:216-219, processWPlist :230-240).  The view's visual neighbours are then
+ * found from the worldpoint overlap inside every matchImages / l3d_match_begin: Line3D::findVisualNeighborsFromWPs
+ * (line3D.cc:578-699; host code, line3dpp_amd/csrc/l3d_neighbors.hip). */
+int l3d_add_view_worldpoints(l3d_ctx*, uint32_t camID, const float* segs4, uint32_t M, const double K[9],
+                             const double R[9], const double t[3], uint32_t width, uint32_t height,
+                             float median_depth, const uint32_t* worldpoints, uint32_t n_worldpoints);
+/* visual_neighbors_[camID] (line3D.h:352) as the last matchImages / l3d_match_begin left it, ascending; *n = its size
+ * (out may be NULL or shorter: the first `cap` are written) */
+int l3d_get_visual_neighbors(l3d_ctx*, uint32_t camID, uint32_t* out, uint32_t cap, uint32_t* n);
+/* Line3D::findVisualNeighborsFromWPs for a set of cameras without a context (and without a GPU): cameras as handed to
+ * addImage (row-major K, R, t per view), worldpoint lists in CSR form (wp_offsets[n_views + 1]); the neighbour sets come
+ * back in CSR form (nb_offsets[n_views + 1]; neighbors may be NULL to ask for the sizes).  The cameras are moved by
+ * the median of their centres for the computation, as matchImages does (line3D.cc:436, 500-536). */
+int l3d_neighbors_from_worldpoints(uint32_t n_views, const uint32_t* cam_ids, const double* K9, const double* R9,
+                                   const double* t3, const uint64_t* wp_offsets, const uint32_t* worldpoints,
+                                   uint32_t num_neighbors, uint64_t* nb_offsets, uint32_t* neighbors, uint64_t cap);
 
 /* Line3D::matchImages (line3D.cc:375-497): the whole call on this context's GPU. */
 int l3d_match_images(l3d_ctx*, const l3d_match_params*);

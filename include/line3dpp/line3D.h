@@ -47,9 +47,9 @@ public:
         : prefix_("[L3D++] "), prefix_err_("[L3D++] ERROR: ") {
         (void)output_folder; (void)load_segments; (void)max_line_segments; (void)use_GPU;
         max_img_width_ = max_img_width;
-        if (neighbors_by_worldpoints)
-            std::cout << prefix_err_ << "worldpoint-derived neighbours are outside the accelerated path; "
-                         "pass explicit neighbour lists" << std::endl;
+        // addImage's list is a worldpoint list; neighbours from the worldpoint overlap at every matchImages
+        // (Line3D::findVisualNeighborsFromWPs, line3D.cc:578-699 -> l3d_add_view_worldpoints)
+        neighbors_by_worldpoints_ = neighbors_by_worldpoints;
         ctx_ = l3d_create(device, hip_stream);
         if (!ctx_) std::cout << prefix_err_ << l3d_last_error() << std::endl;
     }
@@ -73,9 +73,9 @@ public:
         for (size_t i = 0; i < line_segments.size(); ++i)
             for (int j = 0; j < 4; ++j) segs[4 * i + j] = line_segments[i][j];
         std::vector<uint32_t> nb(wps_or_neighbors.begin(), wps_or_neighbors.end());
-        const int rc = l3d_add_view(ctx_, camID, segs.data(), (uint32_t)line_segments.size(), k, r, tt,
-                                    (uint32_t)image.cols, (uint32_t)image.rows, median_depth, nb.data(),
-                                    (uint32_t)nb.size());
+        const int rc = (neighbors_by_worldpoints_ ? l3d_add_view_worldpoints : l3d_add_view)(
+            ctx_, camID, segs.data(), (uint32_t)line_segments.size(), k, r, tt, (uint32_t)image.cols, (uint32_t)image.rows,
+            median_depth, nb.data(), (uint32_t)nb.size());
         if (rc != L3D_OK) std::cout << prefix_err_ << "view [" << camID << "]: " << l3d_last_error() << std::endl;
         else num_lines_[camID] = (uint32_t)line_segments.size();
     }
@@ -215,6 +215,7 @@ public:
 private:
     l3d_ctx* ctx_ = nullptr;
     int max_img_width_ = -1;
+    bool neighbors_by_worldpoints_ = false;
     std::map<unsigned int, uint32_t> num_lines_;
     std::string prefix_, prefix_err_;
 };

@@ -54,6 +54,7 @@ EXPORTS = [
     "l3d_get_segment_coords2d", "l3d_find_collinear_segments", "l3d_score_matches",
     "l3d_slot_index_buffer", "l3d_pack_slot_indices", "l3d_expand_slot_indices", "l3d_match_abort", "l3d_save_3d_lines_bin", "l3d_lists_shard",
     "l3d_principal_direction", "l3d_selftest_arith", "l3d_lists_shard_views", "l3d_plan_shards",
+    "l3d_add_view_worldpoints", "l3d_get_visual_neighbors", "l3d_neighbors_from_worldpoints",
 ]
 
 _lib = None
@@ -75,6 +76,9 @@ def load():
     L.l3d_create.argtypes = [i32, vp]; L.l3d_create.restype = vp
     L.l3d_destroy.argtypes = [vp]; L.l3d_destroy.restype = None
     L.l3d_add_view.argtypes = [vp, u32, vp, u32, vp, vp, vp, u32, u32, f32, vp, u32]
+    L.l3d_add_view_worldpoints.argtypes = [vp, u32, vp, u32, vp, vp, vp, u32, u32, f32, vp, u32]
+    L.l3d_get_visual_neighbors.argtypes = [vp, u32, vp, u32, vp]
+    L.l3d_neighbors_from_worldpoints.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, vp, vp, u64]
     L.l3d_match_images.argtypes = [vp, C.POINTER(MatchParams)]
     L.l3d_match_begin.argtypes = [vp, C.POINTER(MatchParams)]
     L.l3d_num_pairs.argtypes = [vp, C.POINTER(u32)]

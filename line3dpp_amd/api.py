@@ -31,9 +31,9 @@ class Line3D:
 
     def __init__(self, output_folder="", load_segments=False, max_img_width=-1, max_line_segments=3000,
                  neighbors_by_worldpoints=False, use_GPU=True, device=0, stream=0, verbose=False):
-        if neighbors_by_worldpoints:
-            raise NotImplementedError("worldpoint-derived neighbours (line3D.cc:578-699) are outside the hot path; "
-                                      "pass explicit neighbour lists (neighbors_by_worldpoints=false)")
+        # neighbors_by_worldpoints (line3D.cc:6-69): addImage's list is a WORLDPOINT list and the visual neighbours are found
+        # from the worldpoint overlap at every matchImages (Line3D::findVisualNeighborsFromWPs, line3D.cc:578-699)
+        self.neighbors_by_worldpoints = bool(neighbors_by_worldpoints)
         self.L = _lib.load()
         self.verbose = verbose
         self.last_status = 0
@@ -70,14 +70,25 @@ class Line3D:
         R = np.ascontiguousarray(R, np.float64).reshape(3, 3)
         t = np.ascontiguousarray(t, np.float64).reshape(3)
         nb = np.ascontiguousarray(list(wps_or_neighbors), np.uint32)
-        rc = self.L.l3d_add_view(self.h, int(camID), ptr(segs), len(segs), ptr(K), ptr(R), ptr(t),
-                                 int(image_size[0]), int(image_size[1]), float(median_depth), ptr(nb), len(nb))
+        add = self.L.l3d_add_view_worldpoints if self.neighbors_by_worldpoints else self.L.l3d_add_view
+        rc = add(self.h, int(camID), ptr(segs), len(segs), ptr(K), ptr(R), ptr(t),
+                 int(image_size[0]), int(image_size[1]), float(median_depth), ptr(nb), len(nb))
         if self._check(rc, f"addImage [{camID}]"):
             self._M[int(camID)] = len(segs)
 
     def add_scene(self, scene):
         for v in scene.views:
-            self.addImage(v.cam, (v.width, v.height), v.K, v.R, v.t, v.median_depth, v.neighbors, v.segs)
+            lst = v.worldpoints if self.neighbors_by_worldpoints else v.neighbors
+            self.addImage(v.cam, (v.width, v.height), v.K, v.R, v.t, v.median_depth, lst, v.segs)
+
+    def visualNeighbors(self, camID):
+        """visual_neighbors_[camID] (line3D.h:352) as the last matchImages left it, ascending"""
+        n = C.c_uint32(0)
+        if not self._check(self.L.l3d_get_visual_neighbors(self.h, int(camID), None, 0, C.byref(n)), "visualNeighbors"):
+            return None
+        out = np.zeros(max(n.value, 1), np.uint32)
+        self._check(self.L.l3d_get_visual_neighbors(self.h, int(camID), ptr(out), n.value, C.byref(n)), "visualNeighbors")
+        return out[:n.value].copy()
 
     def _params(self, sigma_position, sigma_angle, num_neighbors, epipolar_overlap, kNN, const_regularization_depth):
         return MatchParams(float(sigma_position), float(sigma_angle), int(num_neighbors), float(epipolar_overlap),
@@ -341,3 +352,24 @@ def score_matches(lines, matches4, ranges2, reg_tgt2, RtKinv, C_, two_sigA_sqr, 
     if rc != 0:
         raise RuntimeError(f"l3d_score_matches failed [{rc}]: {_lib.last_error()}")
     return out
+
+
+def neighbors_from_worldpoints(cams, K, R, t, worldpoints, num_neighbors=10):
+    """Line3D::findVisualNeighborsFromWPs (line3D.cc:578-699) without a context or a GPU: cams = camera ids, K / R / t per
+    camera as handed to addImage, worldpoints = one list of worldpoint ids per camera -> {cam: ascending neighbour ids}"""
+    L = _lib.load()
+    n = len(cams)
+    ids = np.ascontiguousarray(cams, np.uint32)
+    Ka = np.ascontiguousarray(K, np.float64).reshape(n, 9); Ra = np.ascontiguousarray(R, np.float64).reshape(n, 9)
+    ta = np.ascontiguousarray(t, np.float64).reshape(n, 3)
+    off = np.zeros(n + 1, np.uint64); off[1:] = np.cumsum([len(w) for w in worldpoints])
+    wps = np.ascontiguousarray(np.concatenate([np.asarray(w, np.uint32) for w in worldpoints]) if off[-1] else np.zeros(1, np.uint32), np.uint32)
+    nb_off = np.zeros(n + 1, np.uint64)
+    rc = L.l3d_neighbors_from_worldpoints(n, ptr(ids), ptr(Ka), ptr(Ra), ptr(ta), ptr(off), ptr(wps), int(num_neighbors), ptr(nb_off), None, 0)
+    if rc != 0:
+        raise RuntimeError("l3d_neighbors_from_worldpoints: " + _lib.last_error())
+    nb = np.zeros(max(int(nb_off[-1]), 1), np.uint32)
+    rc = L.l3d_neighbors_from_worldpoints(n, ptr(ids), ptr(Ka), ptr(Ra), ptr(ta), ptr(off), ptr(wps), int(num_neighbors), ptr(nb_off), ptr(nb), len(nb))
+    if rc != 0:
+        raise RuntimeError("l3d_neighbors_from_worldpoints: " + _lib.last_error())
+    return {int(c): nb[int(nb_off[i]):int(nb_off[i + 1])].copy() for i, c in enumerate(cams)}

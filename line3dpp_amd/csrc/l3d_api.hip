@@ -30,12 +30,12 @@ void translate_view(HostView& v, const d3& d) {
     v.t = d3{-rc.x, -rc.y, -rc.z};
 }
 
-// Line3D::translate, line3D.cc:500-536
-void translate(l3d_ctx& c) {
+// Line3D::translate, line3D.cc:500-536: the median of the camera centres' coordinates
+d3 scene_translation(const std::vector<HostView*>& order) {
     double tr[3] = {0, 0, 0};
     for (int i = 0; i < 3; ++i) {
         std::vector<double> coords;
-        for (auto* v : c.order) {
+        for (auto* v : order) {
             const double val = i == 0 ? v->C.x : (i == 1 ? v->C.y : v->C.z);
             if (std::fabs(val) > kEps) coords.push_back(val);
         }
@@ -44,8 +44,11 @@ void translate(l3d_ctx& c) {
             tr[i] = coords[coords.size() / 2];
         }
     }
-    c.translation = d3{tr[0], tr[1], tr[2]};
-    for (auto* v : c.order) translate_view(*v, d3{-tr[0], -tr[1], -tr[2]});
+    return d3{tr[0], tr[1], tr[2]};
+}
+void translate(l3d_ctx& c) {
+    c.translation = scene_translation(c.order);
+    for (auto* v : c.order) translate_view(*v, d3{-c.translation.x, -c.translation.y, -c.translation.z});
 }
 void untranslate(l3d_ctx& c) {  // line3D.cc:539-545
     for (auto* v : c.order) translate_view(*v, c.translation);
@@ -338,14 +341,40 @@ int l3d_set_brute_force(l3d_ctx* c, int on) {  // test hook
     return L3D_OK;
 }
 
+static int add_view(l3d_ctx* c, uint32_t camID, const float* segs4, uint32_t M, const double K[9], const double R[9],
+                    const double t[3], uint32_t width, uint32_t height, float median_depth, const uint32_t* neighbors,
+                    uint32_t n_neighbors, bool by_worldpoints);
+
 int l3d_add_view(l3d_ctx* c, uint32_t camID, const float* segs4, uint32_t M, const double K[9], const double R[9],
                  const double t[3], uint32_t width, uint32_t height, float median_depth, const uint32_t* neighbors,
                  uint32_t n_neighbors) {
+    return add_view(c, camID, segs4, M, K, R, t, width, height, median_depth, neighbors, n_neighbors, false);
+}
+int l3d_add_view_worldpoints(l3d_ctx* c, uint32_t camID, const float* segs4, uint32_t M, const double K[9],
+                             const double R[9], const double t[3], uint32_t width, uint32_t height, float median_depth,
+                             const uint32_t* worldpoints, uint32_t n_worldpoints) {
+    return add_view(c, camID, segs4, M, K, R, t, width, height, median_depth, worldpoints, n_worldpoints, true);
+}
+int l3d_get_visual_neighbors(l3d_ctx* c, uint32_t camID, uint32_t* out, uint32_t cap, uint32_t* n) {
+    if (!c || !n) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    auto it = c->views.find(camID);
+    if (it == c->views.end()) return fail(L3D_ERR_ARG, "unknown camera ID");
+    *n = (uint32_t)it->second->visual_nbrs.size();
+    uint32_t i = 0;
+    if (out) for (uint32_t o : it->second->visual_nbrs) { if (i < cap) out[i] = o; ++i; }
+    return L3D_OK;
+}
+
+static int add_view(l3d_ctx* c, uint32_t camID, const float* segs4, uint32_t M, const double K[9], const double R[9],
+                    const double t[3], uint32_t width, uint32_t height, float median_depth, const uint32_t* neighbors,
+                    uint32_t n_neighbors, bool by_worldpoints) {
     if (!c || !K || !R || !t) return fail(L3D_ERR_ARG, "null argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (std::max(width, height) < 800) return fail(L3D_ERR_IMAGE_SMALL, "image is too small for reliable results");
     if (c->views.count(camID)) return fail(L3D_ERR_ID_IN_USE, "camera ID already in use");
-    if (n_neighbors == 0 || !neighbors) return fail(L3D_ERR_NO_NEIGHBORS, "view has no visual neighbors");
+    if (n_neighbors == 0 || !neighbors)
+        return fail(L3D_ERR_NO_NEIGHBORS, by_worldpoints ? "view has no worldpoints" : "view has no visual neighbors");
     if (M == 0 || !segs4) return fail(L3D_ERR_NO_SEGMENTS, "no line segments");
     if (M >= (1u << 23)) return fail(L3D_ERR_LIMIT, "more than 2^23 segments per view");
     (void)hipSetDevice(c->device);
@@ -356,7 +385,8 @@ int l3d_add_view(l3d_ctx* c, uint32_t camID, const float* segs4, uint32_t M, con
     v->width = width; v->height = height;
     v->initial_median_depth = (float)std::fmax(std::fabs(median_depth), kEps);
     init_view(*v, K, R, t);
-    v->fixed_nbrs.assign(neighbors, neighbors + n_neighbors);
+    if (by_worldpoints) { v->by_worldpoints = true; v->worldpoints.assign(neighbors, neighbors + n_neighbors); }   // processWPlist
+    else v->fixed_nbrs.assign(neighbors, neighbors + n_neighbors);                                                  // setVisualNeighbors
     L3D_HIP_CHECK(v->d_seg4.reserve(M));
     L3D_HIP_CHECK(v->d_segf.reserve(M));
     L3D_HIP_CHECK(hipMemcpy(v->d_seg4.p, v->segs.data(), (size_t)M * 16, hipMemcpyHostToDevice));
@@ -439,9 +469,16 @@ static int match_begin_body(l3d_ctx* c) {
     }
     // fixed neighbours, line3D.cc:467-479 (sets persist across calls like visual_neighbors_)
     for (auto* v : c->order)
-        if (v->visual_nbrs.empty())
+        if (!v->by_worldpoints && v->visual_nbrs.empty())
             for (uint32_t n : v->fixed_nbrs)
                 if (c->views.count(n)) v->visual_nbrs.insert(n);
+    // neighbours from the worldpoint overlap, line3D.cc:480-484 (every call anew, on the translated views)
+    {
+        bool any = false;
+        std::map<uint32_t, HostView*> vm;
+        for (auto& kv : c->views) { vm[kv.first] = kv.second.get(); any |= kv.second->by_worldpoints; }
+        if (any) neighbors_from_worldpoints(vm, (uint32_t)c->num_neighbors);
+    }
     // The pair list, the fundamental matrices and the culling set-up are a function of the (translated) views, their
     // neighbour sets and kNN alone: when those are byte for byte what the previous call saw, the lists it built are
     // kept (C1: 0.1 ms of host work before the first kernel of the call can be enqueued).

@@ -73,6 +73,10 @@ hipError_t launch_aff_emit(uint32_t N, const uint32_t* flag, const uint32_t* epo
 // ---- host helpers shared by the translation units (defined in l3d_api.hip) ----
 int fail(int code, const std::string& msg);
 const char* last_error_cstr();
+void init_view(HostView& v, const double K[9], const double R[9], const double t[3]);
+void translate_view(HostView& v, const d3& d);
+d3 scene_translation(const std::vector<HostView*>& order);
+void neighbors_from_worldpoints(const std::map<uint32_t, HostView*>& views, uint32_t num_neighbors);   // l3d_neighbors.hip
 void translate(::l3d_ctx& c);      // Line3D::translate, line3D.cc:500-536
 void untranslate(::l3d_ctx& c);    // line3D.cc:539-545
 void make_cull(const double F[9], double ws, double hs, double wt, double ht, PairCull& pc);

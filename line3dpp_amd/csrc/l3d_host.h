@@ -140,6 +140,8 @@ struct HostView {
     float initial_median_depth = 0, k = 0, median_depth = 0;
     double coord_max = 0.0;             // largest |coordinate| of the view's segments (inf if any is not finite): kPairFastMath
     std::vector<uint32_t> fixed_nbrs;   // fixed_visual_neighbors_[cam]
+    bool by_worldpoints = false;        // added with a worldpoint list (neighbors_by_worldpoints_): neighbours are found
+    std::vector<uint32_t> worldpoints;  // from the worldpoint overlap at every matchImages (views2worldpoints_[cam])
     std::set<uint32_t> visual_nbrs;     // visual_neighbors_[cam]
     // device
     DevBuf<float4> d_seg4;

@@ -32,6 +32,7 @@ class ViewData:
     height: int
     median_depth: float
     neighbors: list
+    worldpoints: list = field(default_factory=list)   # ids of the SfM points the view sees (neighbors_by_worldpoints)
 
 
 @dataclass
@@ -210,3 +211,19 @@ def make_config(name, seed=None, max_views=None):
         return load_scene_npz(C0_FILE, "C0")
     idx = list(CONFIGS).index(name)
     return make_scene(seed=(0x4C334450 + idx) if seed is None else seed, name=name, max_views=max_views, **CONFIGS[name])
+
+
+def add_worldpoints(scene, n_points=4000, seed=7, extent=12.0, keep=0.7):
+    """SfM-like worldpoint lists for the views of `scene` (the input of Line3D instances constructed with
+    neighbors_by_worldpoints=true): random 3D points around the origin; a view sees a point that lies in front of it,
+    projects into its image and survives a random drop-out (a feature detector's miss).  Returns the points."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-extent, extent, (n_points, 3)) * np.array([1.0, 1.0, 0.4])
+    for v in scene.views:
+        Xc = (v.R @ X.T).T + v.t
+        x = (v.K @ Xc.T).T
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = x[:, 0] / x[:, 2]; w = x[:, 1] / x[:, 2]
+        vis = (Xc[:, 2] > 0.5) & (u >= 0) & (u < v.width) & (w >= 0) & (w < v.height) & (rng.random(n_points) < keep)
+        v.worldpoints = [int(i) for i in np.nonzero(vis)[0]]
+    return X

@@ -139,12 +139,22 @@ def _p(a):
 class Oracle:
     """Mirror of the slice of L3DPP::Line3D the hot path needs (explicit segments + neighbours)."""
 
-    def __init__(self, record_scored=False, threads=1, reference=False):
+    def __init__(self, record_scored=False, threads=1, reference=False, by_worldpoints=False):
         """reference=True drives the reference's own translation units (oracle/_ref) instead of the
-        restatement; stage-level calls (begin_match/match_pair/scored) exist only in the restatement."""
+        restatement; stage-level calls (begin_match/match_pair/scored) exist only in the restatement.
+        by_worldpoints=True (reference only): the instance is constructed with neighbors_by_worldpoints=true -- add_view's
+        list is a worldpoint list and matchImages finds the visual neighbours itself (line3D.cc:578-699)."""
         self.reference = reference
+        self.by_worldpoints = by_worldpoints
         self.L = lib(reference)
-        self.h = C.c_void_p(self.L.lo_create())
+        if by_worldpoints:
+            assert reference, "worldpoint-derived neighbours are pinned on the reference's own code only"
+            self.L.lo_create_worldpoints.restype = C.c_void_p
+            self.L.lo_get_visual_neighbors.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+            self.L.lo_get_visual_neighbors.restype = C.c_uint32
+            self.h = C.c_void_p(self.L.lo_create_worldpoints())
+        else:
+            self.h = C.c_void_p(self.L.lo_create())
         self.L.lo_set_record_scored(self.h, int(record_scored))
         self.L.lo_set_threads(int(threads))
         self.M = {}
@@ -168,8 +178,16 @@ class Oracle:
 
     def add_scene(self, scene):
         for v in scene.views:
-            rc = self.add_view(v.cam, v.segs, v.K, v.R, v.t, v.width, v.height, v.median_depth, v.neighbors)
+            rc = self.add_view(v.cam, v.segs, v.K, v.R, v.t, v.width, v.height, v.median_depth,
+                               v.worldpoints if self.by_worldpoints else v.neighbors)
             assert rc == 0, rc
+
+    def visual_neighbors(self, cam):
+        """visual_neighbors_[cam] after match_images (reference, by_worldpoints)"""
+        n = self.L.lo_get_visual_neighbors(self.h, cam, None, 0)
+        out = np.zeros(max(n, 1), np.uint32)
+        self.L.lo_get_visual_neighbors(self.h, cam, _p(out), n)
+        return out[:n].copy()
 
     def match_images(self, sigma_p=2.5, sigma_a=10.0, num_neighbors=10, epi_overlap=0.25, kNN=10,
                      const_reg_depth=-1.0):

@@ -63,6 +63,24 @@ void* lo_create() {
     r->l3d = new L3DPP::Line3D("/tmp", false, -1, 3000, false, false);
     return r;
 }
+// the same instance with neighbors_by_worldpoints=true: addImage's list is a worldpoint list, matchImages finds the
+// neighbours itself (Line3D::findVisualNeighborsFromWPs) -- the pin of line3dpp_amd/csrc/l3d_neighbors.hip
+void* lo_create_worldpoints() {
+    Quiet q;
+    Ref* r = new Ref();
+    r->l3d = new L3DPP::Line3D("/tmp", false, -1, 3000, true, false);
+    return r;
+}
+// visual_neighbors_[cam] after matchImages, ascending; returns its size
+uint32_t lo_get_visual_neighbors(void* p, uint32_t cam, uint32_t* out, uint32_t cap) {
+    L3DPP::Line3D* l = ((Ref*)p)->l3d;
+    std::map<unsigned int, std::set<unsigned int> >::const_iterator it = l->visual_neighbors_.find(cam);
+    if (it == l->visual_neighbors_.end()) return 0;
+    uint32_t n = 0;
+    for (std::set<unsigned int>::const_iterator s = it->second.begin(); s != it->second.end(); ++s, ++n)
+        if (out && n < cap) out[n] = *s;
+    return n;
+}
 void lo_destroy(void* p) { Ref* r = (Ref*)p; { Quiet q; delete r->l3d; } delete r; }
 void lo_set_record_scored(void*, int) {}
 void lo_set_threads(int n) {

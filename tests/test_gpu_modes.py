@@ -217,3 +217,38 @@ def test_cpp_rccl_driver_single_rank_equals_the_python_front_end(tmp_path):
     e, l2g, _ = g.affinity()
     assert int(kv["hypotheses"]) == len(g.best()[0]) and int(kv["edges"]) == len(e) and int(kv["rows"]) == len(l2g)
     assert abs(float(kv["wsum"]) - float(e["w"].astype(np.float64).sum())) < 1e-3
+
+
+@pytest.mark.parametrize("num_neighbors", [3, 8])
+def test_worldpoint_lists_instead_of_neighbour_lists(num_neighbors):
+    """An instance constructed with neighbors_by_worldpoints=true (line3D.cc:216-219): addImage takes the view's SfM
+    worldpoints, matchImages finds the visual neighbours from the worldpoint overlap (findVisualNeighborsFromWPs,
+    line3D.cc:578-699 -> l3d_neighbors.hip, inside l3d_match_begin on the translated views) and matches what it found.
+    Everything downstream -- pair list, matches, best hypotheses, affinity -- against the reference's own run in the same
+    mode; a second call with another num_neighbors finds the neighbours anew (the reference resets the set each call)."""
+    from line3dpp_amd.api import Line3D
+    from line3dpp_amd.scene import add_worldpoints
+    sc = make_scene(12, 220, n_neighbors=4, seed=21, rings=2)
+    add_worldpoints(sc, n_points=2500, seed=5, keep=0.4)
+    assert O.have_reference(), "oracle/_ref is missing: this test compares with the reference's own code only"
+    o = O.Oracle(threads=1, reference=True, by_worldpoints=True)
+    o.add_scene(sc)
+    g = Line3D(neighbors_by_worldpoints=True)
+    g.add_scene(sc)
+    for nn in (num_neighbors, num_neighbors + 2):
+        o.match_images(num_neighbors=nn)
+        assert g.matchImages(num_neighbors=nn)
+        sizes = []
+        for v in sc.views:
+            ref_nb = o.visual_neighbors(v.cam)
+            assert np.array_equal(g.visualNeighbors(v.cam), ref_nb), (v.cam, g.visualNeighbors(v.cam), ref_nb)
+            sizes.append(len(ref_nb))
+        assert max(sizes) == nn
+    o.compute_affinity()
+    assert g.computeAffinity()
+    r = _assert_same(g, o, sc)
+    assert r["surviving"] > 0
+    # a view without worldpoints is refused like a view without neighbours (line3D.cc:153-166)
+    v = sc.views[0]
+    g.addImage(999, (v.width, v.height), v.K, v.R, v.t, v.median_depth, [], v.segs)
+    assert g.last_status == -4
