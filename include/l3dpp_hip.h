@@ -126,6 +126,31 @@ int l3d_neighbors_from_worldpoints(uint32_t n_views, const uint32_t* cam_ids, co
                                    const double* t3, const uint64_t* wp_offsets, const uint32_t* worldpoints,
                                    uint32_t num_neighbors, uint64_t* nb_offsets, uint32_t* neighbors, uint64_t cap);
 
+/* ---- input side (host code, no GPU) ---------------------------------------------------------------------------------
+ * VisualSfM .nvm exactly as main_vsfm.cpp:144-250 reads it, with what it derives per camera (:188-206, :300-303).  The
+ * camera index is the camID main_vsfm.cpp passes to addImage; a camera that sees no point has n_worldpoints == 0 and
+ * is skipped there (:258). */
+typedef struct l3d_nvm l3d_nvm;
+typedef struct l3d_nvm_camera {
+    const char* filename;             /* valid while the handle lives */
+    float focal, distortion;          /* (float vectors in main_vsfm.cpp:164-169) */
+    float median_depth;               /* sorted point distances [n/2], the value handed to addImage */
+    uint32_t n_worldpoints;
+    double R[9], t[3], C[3];          /* row-major R from the quaternion, t = -R C */
+} l3d_nvm_camera;
+int l3d_nvm_open(const char* path, l3d_nvm** out);    /* L3D_ERR_NO_VIEWS: "No aligned cameras in NVM file!" (:157-161) */
+uint32_t l3d_nvm_num_cameras(const l3d_nvm*);
+int l3d_nvm_get_camera(const l3d_nvm*, uint32_t index, l3d_nvm_camera* out);
+int l3d_nvm_get_worldpoints(const l3d_nvm*, uint32_t index, uint32_t* out, uint32_t cap);   /* = addImage's wps list */
+void l3d_nvm_close(l3d_nvm*);
+void l3d_nvm_intrinsics(float focal, uint32_t width, uint32_t height, double K[9]);          /* main_vsfm.cpp:272-282 */
+/* The segment cache Line3D::detectLineSegments loads / stores per image when load_segments is set (line3D.cc:295-309,
+ * 362-366): "<data folder>/segments_L3D++_<camID>_<width>x<height>_<max segments>.bin", the boost binary archive of a
+ * one-row L3DPP::DataArray<float4> (dataArray.h:352-374).  segs4 = n x (x1, y1, x2, y2). */
+int l3d_segment_cache_name(uint32_t camID, uint32_t width, uint32_t height, uint32_t max_segments, char* out, uint32_t cap);
+int l3d_read_segment_cache(const char* path, float* segs4 /* may be NULL */, uint32_t cap, uint32_t* n);
+int l3d_write_segment_cache(const char* path, const float* segs4, uint32_t n);
+
 /* Line3D::matchImages (line3D.cc:375-497): the whole call on this context's GPU. */
 int l3d_match_images(l3d_ctx*, const l3d_match_params*);
 

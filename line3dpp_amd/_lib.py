@@ -55,6 +55,8 @@ EXPORTS = [
     "l3d_slot_index_buffer", "l3d_pack_slot_indices", "l3d_expand_slot_indices", "l3d_match_abort", "l3d_save_3d_lines_bin", "l3d_lists_shard",
     "l3d_principal_direction", "l3d_selftest_arith", "l3d_lists_shard_views", "l3d_plan_shards",
     "l3d_add_view_worldpoints", "l3d_get_visual_neighbors", "l3d_neighbors_from_worldpoints",
+    "l3d_nvm_open", "l3d_nvm_num_cameras", "l3d_nvm_get_camera", "l3d_nvm_get_worldpoints", "l3d_nvm_close",
+    "l3d_nvm_intrinsics", "l3d_segment_cache_name", "l3d_read_segment_cache", "l3d_write_segment_cache",
 ]
 
 _lib = None
@@ -79,6 +81,15 @@ def load():
     L.l3d_add_view_worldpoints.argtypes = [vp, u32, vp, u32, vp, vp, vp, u32, u32, f32, vp, u32]
     L.l3d_get_visual_neighbors.argtypes = [vp, u32, vp, u32, vp]
     L.l3d_neighbors_from_worldpoints.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, vp, vp, u64]
+    L.l3d_nvm_open.argtypes = [C.c_char_p, vp]
+    L.l3d_nvm_num_cameras.argtypes = [vp]; L.l3d_nvm_num_cameras.restype = u32
+    L.l3d_nvm_get_camera.argtypes = [vp, u32, vp]
+    L.l3d_nvm_get_worldpoints.argtypes = [vp, u32, vp, u32]
+    L.l3d_nvm_close.argtypes = [vp]; L.l3d_nvm_close.restype = None
+    L.l3d_nvm_intrinsics.argtypes = [f32, u32, u32, vp]; L.l3d_nvm_intrinsics.restype = None
+    L.l3d_segment_cache_name.argtypes = [u32, u32, u32, u32, C.c_char_p, u32]
+    L.l3d_read_segment_cache.argtypes = [C.c_char_p, vp, u32, vp]
+    L.l3d_write_segment_cache.argtypes = [C.c_char_p, vp, u32]
     L.l3d_match_images.argtypes = [vp, C.POINTER(MatchParams)]
     L.l3d_match_begin.argtypes = [vp, C.POINTER(MatchParams)]
     L.l3d_num_pairs.argtypes = [vp, C.POINTER(u32)]

@@ -93,7 +93,10 @@ class _Reader:
 
     def take(self, fmt):
         import struct
-        v = struct.unpack_from("<" + fmt, self.b, self.p)
+        try:
+            v = struct.unpack_from("<" + fmt, self.b, self.p)
+        except struct.error as e:
+            raise ValueError(f"truncated archive at byte {self.p}: {e}") from None
         self.p += struct.calcsize("<" + fmt)
         return v if len(v) > 1 else v[0]
 
@@ -230,6 +233,8 @@ def read_segment_cache(path):
         raise ValueError(f"{path}: not a one-row DataArray<float4> (width {width}, height {height}, real width {real})")
     if real:
         r.hdr("float4")
+    if r.p + real * 16 > len(r.b):
+        raise ValueError(f"{path}: truncated ({len(r.b) - r.p} of {real * 16} element bytes)")
     data = np.frombuffer(r.b, np.float32, real * 4, r.p).reshape(real, 4)
     r.p += real * 16
     if r.p != len(r.b):
