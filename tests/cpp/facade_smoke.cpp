@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <list>
+#include <string>
 #include <vector>
 
 #include "line3dpp/line3D.h"
@@ -18,7 +19,10 @@ int main(int argc, char** argv) {
     if (!f) return 3;
     uint32_t nv = 0;
     if (fread(&nv, 4, 1, f) != 1) return 4;
-    L3DPP_HIP::Line3D l3d("/tmp", false, -1, 3000, false, true);
+    // argv[2] == "worldpoints": the per-view list of the scene file is a worldpoint list and the instance is constructed
+    // with neighbors_by_worldpoints = true, as main_vsfm.cpp:140-141 does
+    const bool by_wps = argc > 2 && std::string(argv[2]) == "worldpoints";
+    L3DPP_HIP::Line3D l3d("/tmp", false, -1, 3000, by_wps, true);
     std::vector<uint32_t> cams;
     for (uint32_t i = 0; i < nv; ++i) {
         uint32_t hdr[5];  // cam, M, width, height, n_nb

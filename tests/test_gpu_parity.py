@@ -393,8 +393,11 @@ def test_properties_at_full_c1_size():
     assert lim_ok > 0
 
 
-def test_cpp_facade_matches_python_front_end(tmp_path):
-    """include/line3dpp/line3D.h (C++ mirror of L3DPP::Line3D) driven like a reference main_*.cpp."""
+@pytest.mark.parametrize("mode", ["neighbors", "worldpoints"])
+def test_cpp_facade_matches_python_front_end(tmp_path, mode):
+    """include/line3dpp/line3D.h (C++ mirror of L3DPP::Line3D) driven like a reference main_*.cpp -- with explicit
+    neighbour lists (main_mavmap.cpp) and with worldpoint lists on an instance constructed with
+    neighbors_by_worldpoints=true (main_vsfm.cpp)."""
     import struct
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -404,19 +407,27 @@ def test_cpp_facade_matches_python_front_end(tmp_path):
                            os.path.join(root, "tests", "cpp", "facade_smoke.cpp"), "-o", exe, "-L" + lib_dir,
                            "-ll3dpp_hip", "-Wl,-rpath," + lib_dir])
     sc = make_scene(8, 300, n_neighbors=4, seed=1)
+    wps = mode == "worldpoints"
+    if wps:
+        from line3dpp_amd.scene import add_worldpoints
+        add_worldpoints(sc, n_points=1500, seed=4, keep=0.5)
     path = str(tmp_path / "scene.bin")
     with open(path, "wb") as f:
         f.write(struct.pack("<I", sc.n_views))
         for v in sc.views:
-            f.write(struct.pack("<5I", v.cam, len(v.segs), v.width, v.height, len(v.neighbors)))
+            lst = v.worldpoints if wps else v.neighbors
+            f.write(struct.pack("<5I", v.cam, len(v.segs), v.width, v.height, len(lst)))
             f.write(np.ascontiguousarray(v.K, np.float64).tobytes()); f.write(np.ascontiguousarray(v.R, np.float64).tobytes())
             f.write(np.ascontiguousarray(v.t, np.float64).tobytes()); f.write(struct.pack("<f", v.median_depth))
-            f.write(np.asarray(v.neighbors, np.uint32).tobytes()); f.write(np.ascontiguousarray(v.segs, np.float32).tobytes())
-    out = subprocess.check_output([exe, path]).decode()
+            f.write(np.asarray(lst, np.uint32).tobytes()); f.write(np.ascontiguousarray(v.segs, np.float32).tobytes())
+    out = subprocess.check_output([exe, path, mode]).decode()
     line = [l for l in out.splitlines() if l.startswith("RESULT")][0]
     kv = dict(x.split("=") for x in line.split()[1:])
-    g = _gpu(sc)
+    from line3dpp_amd.api import Line3D
+    g = Line3D(neighbors_by_worldpoints=wps)
+    g.add_scene(sc)
     assert g.matchImages() and g.computeAffinity()
+    assert sum(len(m) for m in [g.matches(v.cam)[0] for v in sc.views]) > 0
     ms = [g.matches(v.cam)[0] for v in sc.views]
     assert int(kv["images"]) == 8 and int(kv["matches"]) == sum(len(m) for m in ms)
     assert abs(float(kv["score_sum"]) - sum(float(m["score3D"].astype(np.float64).sum()) for m in ms)) < 1e-3
