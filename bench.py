@@ -22,7 +22,8 @@ Prints ONE JSON line with
   `parity`        the HIP result of the benchmarked scene against that very reference run -- or, with --parity-digest,
                   against the stored record of a reference run of the FULL configuration (tests/full_digest.py)
   `cold_ms` / `second_scene_ms`   the first matchImages + affinity of a fresh context (allocations, pool growth and
-                  extra chain rounds included) and of a fresh context for ANOTHER scene of the same size afterwards
+                  extra chain rounds included) and of a fresh context for ANOTHER scene of the same size afterwards;
+                  `cold.fresh_process`: the first call of a fresh PROCESS (subprocess), beside its context creation
 """
 import argparse
 import glob
@@ -237,6 +238,33 @@ def cold_call(scene, kNN, device_index, step_fn_factory):
     return ms, {k: tm[k] for k in ("pool_retries", "chain_extra_rounds", "chain_sweeps")}, g
 
 
+_PROCESS_COLD = """
+import json, sys, time
+sys.path.insert(0, %r)
+from line3dpp_amd.api import Line3D
+from line3dpp_amd.scene import make_config
+sc = make_config(%r)
+t0 = time.perf_counter()
+g = Line3D(device=%d); g.add_scene(sc)
+t1 = time.perf_counter()
+ok = g.matchImages(kNN=%d) and g.computeAffinity()
+t2 = time.perf_counter()
+print(json.dumps({"ok": bool(ok), "create_and_add_ms": round(1e3 * (t1 - t0), 1), "first_call_ms": round(1e3 * (t2 - t1), 3)}))
+"""
+
+
+def process_cold(config, device_index, kNN):
+    """the FIRST matchImages + affinity of a fresh PROCESS (nothing of the runtime warm: what a one-scene command-line run
+    pays), next to the context creation that precedes it (HIP start-up, code objects, copy paths: l3d_create)"""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, "-c", _PROCESS_COLD % (ROOT, config, device_index, kNN)], capture_output=True,
+                             text=True, timeout=600)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:   # noqa: BLE001 -- a diagnostic beside the benchmark, never its failure
+        return {"error": repr(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,6 +322,8 @@ def main():
         tiny.close()
         cold_ms, cold_tm, l3d = cold_call(scene, kNN, local_rank, stepper)
         cold = {"cold_ms": round(cold_ms, 3), "cold_call": cold_tm}
+        if rank == 0:
+            cold["fresh_process"] = process_cold(args.config, local_rank, kNN)
     else:
         l3d = Line3D(device=local_rank)
         l3d.add_scene(scene)            # segment arrays now resident in HBM

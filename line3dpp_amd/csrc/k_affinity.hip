@@ -331,3 +331,14 @@ hipError_t launch_aff_coll_sim(int mode, uint32_t n_items, const uint32_t* surv_
     return hipGetLastError();
 }
 }  // namespace l3d
+
+
+// ---- start-up (l3d_create): the runtime loads a translation unit's code object at the first launch of one of its
+// kernels (~0.6 ms each, measured on the first matchImages of a process); an empty launch pays that at context creation
+namespace l3d {
+namespace { __global__ void k_warm_affinity() {} }
+hipError_t warm_affinity(hipStream_t st) {
+    hipLaunchKernelGGL(k_warm_affinity, dim3(1), dim3(64), 0, st);
+    return hipGetLastError();
+}
+}  // namespace l3d

@@ -1088,3 +1088,14 @@ hipError_t launch_seg_write(uint32_t G, const ViewDev* views, const PairDesc* pa
 }
 
 }  // namespace l3d
+
+
+// ---- start-up (l3d_create): the runtime loads a translation unit's code object at the first launch of one of its
+// kernels (~0.6 ms each, measured on the first matchImages of a process); an empty launch pays that at context creation
+namespace l3d {
+namespace { __global__ void k_warm_lists() {} }
+hipError_t warm_lists(hipStream_t st) {
+    hipLaunchKernelGGL(k_warm_lists, dim3(1), dim3(64), 0, st);
+    return hipGetLastError();
+}
+}  // namespace l3d

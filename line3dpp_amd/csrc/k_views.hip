@@ -740,3 +740,14 @@ extern "C" void l3d_debug_bstats(unsigned long long* out, int reset) {
     if (reset) { unsigned long long z[8] = {}; hipMemcpyToSymbol(HIP_SYMBOL(l3d::g_bstats), z, sizeof(z)); }
 }
 #endif
+
+
+// ---- start-up (l3d_create): the runtime loads a translation unit's code object at the first launch of one of its
+// kernels (~0.6 ms each, measured on the first matchImages of a process); an empty launch pays that at context creation
+namespace l3d {
+namespace { __global__ void k_warm_views() {} }
+hipError_t warm_views(hipStream_t st) {
+    hipLaunchKernelGGL(k_warm_views, dim3(1), dim3(64), 0, st);
+    return hipGetLastError();
+}
+}  // namespace l3d

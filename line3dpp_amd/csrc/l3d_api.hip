@@ -287,6 +287,28 @@ l3d_ctx* l3d_create(int device, void* stream) {
     c->use_cull = std::getenv("L3D_NO_CULL") == nullptr;   // diagnostic switch: stream every pair unculled
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); delete c; return nullptr; }
+    // What the runtime sets up lazily is set up HERE, beside its own start-up (~0.3 s), not inside the first
+    // matchImages of the process: the code object of every translation unit with kernels (loaded at the first launch
+    // of one of its kernels, ~0.6 ms each) and the copy paths of both directions (the first device-to-host
+    // hipMemcpyAsync of a process took 7.3 ms -- of an 11 ms first call on a scene whose later calls take 0.3 ms).
+    // L3D_NO_WARMUP=1 leaves it to the first call (diagnostic).
+    if (!std::getenv("L3D_NO_WARMUP")) {
+        hipStream_t st = c->stream;
+        DevBuf<uint32_t> d; PinnedBuf<uint32_t> h;
+        // (a copy of a few bytes goes another way inside the runtime: it is the first copy of some KiB that pays)
+        constexpr size_t kWarmWords = 16384;
+        bool ok = d.reserve(kWarmWords) == hipSuccess && h.reserve(kWarmWords) == hipSuccess;
+        ok = ok && hipMemsetAsync(d.p, 0, kWarmWords * 4, st) == hipSuccess;
+        ok = ok && hipMemcpyAsync(h.p, d.p, kWarmWords * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d.p, h.p, kWarmWords * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+        ok = ok && hipMemcpyAsync(h.p, d.p, 64, hipMemcpyDeviceToHost, st) == hipSuccess;
+        ok = ok && hipMemcpyAsync(d.p, h.p, 64, hipMemcpyHostToDevice, st) == hipSuccess;
+        ok = ok && warm_match(st) == hipSuccess && warm_lists(st) == hipSuccess && warm_scan(st) == hipSuccess &&
+             warm_views(st) == hipSuccess && warm_affinity(st) == hipSuccess && warm_rdd(st) == hipSuccess;
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        d.release(); h.release();
+        if (!ok) { set_error("start-up launches failed: no usable HIP device"); l3d_destroy(c); return nullptr; }
+    }
     return c;
 }
 
@@ -1126,6 +1148,7 @@ static int lists_prepare(l3d_ctx* c, int caps_mode) {
 }
 
 static int lists_reserve(l3d_ctx* c) {
+    g_trace.mark("lists_reserve enter");
     const uint32_t V = (uint32_t)c->order.size();
     const ZeroLayout z = zero_layout(V, c->G);
     L3D_HIP_CHECK(c->d_lzero.reserve(z.words + 2 + (c->n_slots + 3) / 4));   // zero block | positive[] (one byte per slot)
@@ -1145,6 +1168,7 @@ static int lists_reserve(l3d_ctx* c) {
 
 // the list pass of the views [v0, v0 + nv) into the pools [pool0, pool0 + npools)
 static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint32_t npools) {
+    g_trace.mark("lists_run enter");
     hipStream_t st = c->stream;
     const uint32_t V = (uint32_t)c->order.size(), P = (uint32_t)c->pairs.size(), G = c->G;
     const ZeroLayout z = zero_layout(V, G);
@@ -1155,8 +1179,10 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
     // one memset per pass: the zero block and, behind it, positive[] (seg_of_g needs none: it is only read for
     // segments with surviving hypotheses, whose header this very pass has written)
     L3D_HIP_CHECK(hipMemsetAsync(c->d_lzero.p, 0, z.words * 4 + std::max<uint64_t>(c->n_slots, 1), st));
+    g_trace.mark("zero block memset enqueued");
     L3D_HIP_CHECK(launch_inv_records(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_off64.p,
                                      c->d_inv_pos.p, c->d_inv_recs.p, v0, v0 + nv, st));
+    g_trace.mark("inv_records enqueued");
     // mean list length: every alive slot is a hypothesis of its source segment and, towards a later view, of its target
     // segment too (~0.8 of the slots are alive, ~half of the pairs hand inverse matches over); exact after the first call
     const uint32_t mean_list = c->n_ents ? (uint32_t)(c->n_ents / std::max<uint32_t>(G, 1))
@@ -1172,12 +1198,14 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
                                c->d_inv_recs.p, c->d_slots.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, simc, lp,
                                c->d_seg_of_g.p, hsa, st));
     L3D_HIP_CHECK(hipEventRecord(c->ev[9], st));
+    g_trace.mark("list pass enqueued");
     return L3D_OK;
 }
 
 // chain, scores, filterMatches, outputs, medians on the complete records (`fresh`: first tail after a list pass;
 // otherwise the chain continues from what earlier sweeps found and only the later stages start over)
 static int tail_run(l3d_ctx* c, bool fresh) {
+    g_trace.mark("tail_run enter");
     hipStream_t st = c->stream;
     const uint32_t V = (uint32_t)c->order.size(), G = c->G;
     const ZeroLayout z = zero_layout(V, G);
@@ -1193,19 +1221,28 @@ static int tail_run(l3d_ctx* c, bool fresh) {
     c->chain_enqueued = n_sweeps;
     for (uint32_t s2 = 0; s2 < n_sweeps; ++s2)
         L3D_HIP_CHECK(launch_chain_sweep(lp, positive_of(c), changed, s2, st));
+    g_trace.mark("chain sweeps enqueued");
     L3D_HIP_CHECK(launch_hyp_scores(lp, positive_of(c), c->d_gseg_view.p, c->d_slots.p, max_score, st));
+    g_trace.mark("hyp_scores enqueued");
     L3D_HIP_CHECK(launch_hyp_filter(lp, G, c->d_gseg_view.p, max_score, kept, best, c->d_cnt64.p, st));
+    g_trace.mark("hyp_filter enqueued");
     L3D_HIP_CHECK(launch_scan64(c->d_cnt64.p, G, c->d_off64s.p, c->d_scan_ws.p, tot64_of(c) + 1, st));
+    g_trace.mark("scan enqueued");
     L3D_HIP_CHECK(launch_seg_write(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p, c->d_off64s.p, best,
                                    c->d_seg_of_g.p, lp, c->d_slots.p, c->d_surv_off.p, c->d_hyp_off.p, c->d_surv.p,
                                    c->d_surv_tg.p, c->d_surv_sg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_depths.p, st));
+    g_trace.mark("seg_write enqueued");
     L3D_HIP_CHECK(launch_median_all(V, c->d_depths.p, c->d_hyp_off.p, c->d_seg_base.p, medians_of(c), st));
+    g_trace.mark("median enqueued");
     // read-backs (pinned), two copies: [0..7] 64-bit totals, [8..8+V) medians | from fin_b1(V): pool counters, flags (32),
     // changed (64) -- the head of the zero block
     uint32_t* h = c->h_fin.p;
     L3D_HIP_CHECK(hipMemcpyAsync(h, c->d_medians.p, (8 + (size_t)V) * 4, hipMemcpyDeviceToHost, st));
+    g_trace.mark("read-back 1 enqueued");
     L3D_HIP_CHECK(hipMemcpyAsync(h + fin_b1(V), c->d_lzero.p, ((size_t)kListPools * 16 + 96) * 4, hipMemcpyDeviceToHost, st));
+    g_trace.mark("read-back 2 enqueued");
     L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
+    g_trace.mark("tail enqueued");
     return L3D_OK;
 }
 

@@ -70,6 +70,10 @@ hipError_t launch_aff_emit(uint32_t N, const uint32_t* flag, const uint32_t* epo
                            const int32_t* cb, const float* simv, const uint32_t* first_touch,
                            const uint32_t* touch_rank, const HypRec*, void* edges, void* local2global, hipStream_t);
 
+// start-up launches, one per translation unit with kernels (see l3d_create)
+hipError_t warm_affinity(hipStream_t); hipError_t warm_lists(hipStream_t); hipError_t warm_match(hipStream_t);
+hipError_t warm_rdd(hipStream_t); hipError_t warm_scan(hipStream_t); hipError_t warm_views(hipStream_t);
+
 // ---- host helpers shared by the translation units (defined in l3d_api.hip) ----
 int fail(int code, const std::string& msg);
 const char* last_error_cstr();

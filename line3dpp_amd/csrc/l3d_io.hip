@@ -98,7 +98,7 @@ int l3d_nvm_get_camera(const l3d_nvm* n, uint32_t i, l3d_nvm_camera* out) {
 int l3d_nvm_get_worldpoints(const l3d_nvm* n, uint32_t i, uint32_t* out, uint32_t cap) {
     if (!n || i >= n->cams.size() || (cap && !out)) return fail(L3D_ERR_ARG, "bad argument");
     const auto& w = n->cams[i].worldpoints;
-    std::memcpy(out, w.data(), 4 * (size_t)std::min<size_t>(cap, w.size()));
+    if (cap && !w.empty()) std::memcpy(out, w.data(), 4 * (size_t)std::min<size_t>(cap, w.size()));
     return w.size() > cap ? fail(L3D_ERR_LIMIT, "worldpoint buffer too small") : L3D_OK;
 }
 
