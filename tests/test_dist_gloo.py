@@ -382,7 +382,7 @@ def _halo_worker(rank, world, port, q):
         dist_t.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_halo_form_over_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
