@@ -174,3 +174,31 @@ def test_cpp_rccl_driver_builds_and_links(tmp_path):
                            "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath," + lib_dir])
     out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
     assert "librccl" in out and "libl3dpp_hip" in out and "not found" not in out
+
+
+def test_bench_multi_gpu_model_terms():
+    """bench.py prints what the halo form is expected to take on 2 / 4 / 8 GPUs from a single-GPU run's phase times
+    (no node has been available): the terms must follow the plan the ranks would use (l3d_plan_shards) and the direct
+    record exchange (one slab per xGMI link), with the ring figure beside it"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    from line3dpp_amd.scene import CONFIGS
+    cfg = CONFIGS["C2"]
+    nv, nn = cfg["n_views"], cfg["n_neighbors"]
+    pairs = sorted({(min(i, (i + d) % nv), max(i, (i + d) % nv)) for i in range(nv) for d in range(1, nn // 2 + 1)})
+    M = {i: cfg["n_segs"] for i in range(nv)}
+    phase = dict(begin=0.13, match=14.0, finish=9.4, affinity=0.27)
+    out = b.multi_gpu_model(pairs, M, 10, phase, lists_ms=7.8, record_bytes=510e6)
+    t1 = sum(phase.values())
+    for n in ("2", "4", "8"):
+        m = out[n]; t = m["terms_ms"]
+        assert abs(t["gather_records_direct"] - 1e3 * 510e6 / int(n) / 153e9) < 1e-3
+        assert abs(t["gather_records_if_ring"] - (int(n) - 1) * t["gather_records_direct"]) < 2e-3
+        assert abs(m["total_ms"] - sum(v for k, v in t.items() if not k.endswith("_MB") and not k.endswith("_if_ring"))) < 1e-3
+        assert 1.0 / int(n) <= m["largest_pair_share"] < 1.3 / int(n)          # the plan balances the matching cost
+        assert abs(m["speedup_over_1_gpu"] - t1 / m["total_ms"]) < 0.02
+    assert out["8"]["speedup_over_1_gpu"] > out["4"]["speedup_over_1_gpu"] > out["2"]["speedup_over_1_gpu"] > 1.0
