@@ -274,11 +274,17 @@ def read_nvm(path):
     pos += 1
     n_pts = int(lines[pos].split()[0]); pos += 1
     for i in range(n_pts):
+        if pos >= len(lines):
+            break                      # the file ends early: the stream parser of main_vsfm.cpp sees no further measurements
         tok = lines[pos].split(); pos += 1
+        if len(tok) < 7:
+            continue
         p = np.array([float(tok[0]), float(tok[1]), float(tok[2])])
         nv = int(tok[6])
         for j in range(nv):
             cam = int(tok[7 + 4 * j])
+            if cam >= n_cams:
+                raise ValueError("malformed measurement in NVM file")
             cams[cam]["worldpoints"].append(i)
             cams[cam]["_depths"].append(np.float32(np.linalg.norm(p - cams[cam]["C"])))
     for c in cams:

@@ -215,3 +215,28 @@ def test_nvm_to_neighbours_end_to_end_on_the_host(tmp_path):
     o.match_images(num_neighbors=4, kNN=2)
     for i in ids:
         assert np.array_equal(got[i], o.visual_neighbors(i)) and len(got[i]) > 0
+
+
+def test_c_abi_nvm_reader_tolerates_what_the_stream_parser_tolerates(tmp_path):
+    """main_vsfm.cpp reads with getline + operator>>: extra blanks, a missing trailing section and a file that ends early
+    are not errors there (the remaining points are simply not seen); a measurement that names a camera beyond the camera
+    list would index out of bounds in the reference -- the library refuses it"""
+    L, lib = _lib()
+    h = C.c_void_p()
+    p = tmp_path / "ragged.nvm"
+    p.write_text("NVM_V3\n\n2\n   a.jpg   1000   1 0 0 0   0 0 0   0 0\nb.jpg 1200 1 0 0 0 1 0 0 0.5 0\n\n3\n"
+                 "0 0 5 1 2 3 2 0 0 1 1 1 0 2 2\n0 1 6 1 2 3 1 1 7 3 3\n")          # third point missing: file ends early
+    assert lib.l3d_nvm_open(str(p).encode(), C.byref(h)) == 0 and lib.l3d_nvm_num_cameras(h) == 2
+    cam = _NvmCamera()
+    assert lib.l3d_nvm_get_camera(h, 0, C.byref(cam)) == 0 and cam.n_worldpoints == 1 and cam.focal == 1000.0
+    assert lib.l3d_nvm_get_camera(h, 1, C.byref(cam)) == 0 and cam.n_worldpoints == 2 and cam.distortion == 0.5
+    assert np.array_equal(np.array(cam.R).reshape(3, 3), np.eye(3)) and list(cam.t) == [-1.0, 0.0, 0.0]
+    ids = np.zeros(2, np.uint32)
+    assert lib.l3d_nvm_get_worldpoints(h, 1, L.ptr(ids), 2) == 0 and ids.tolist() == [0, 1]
+    assert lib.l3d_nvm_get_worldpoints(h, 1, L.ptr(ids), 1) == -9                     # L3D_ERR_LIMIT
+    lib.l3d_nvm_close(h)
+    got = io.read_nvm(p)
+    assert [len(c["worldpoints"]) for c in got] == [1, 2]
+    bad = tmp_path / "bad.nvm"
+    bad.write_text("NVM_V3\n\n1\na.jpg 1000 1 0 0 0 0 0 0 0 0\n\n1\n0 0 5 1 2 3 1 4 0 1 1\n")   # camera 4 of 1
+    assert lib.l3d_nvm_open(str(bad).encode(), C.byref(h)) != 0 and b"malformed" in lib.l3d_last_error()
