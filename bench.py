@@ -119,7 +119,8 @@ def run_cpu_baseline(scene, args, pair_tests, kNN, l3d):
 def digest_parity(scene, args, l3d):
     """The HIP result of the FULL benchmarked scene against the stored record of a run of the reference's own code on
     it (tests/full_digest.py, written by tools/ref_digest.py): identical sets / order / phase-A fields through SHA-256
-    digests, float fields at REL_TOL when the float arrays are at hand."""
+    digests, float fields at REL_TOL against the full arrays beside oracle/_ref or, where those did not travel, their
+    committed strided sample (floats_checked: "full" | "sample"); with neither the block says ok: false."""
     from tests import full_digest as FD
     from tests import helpers as H
     meta, floats = FD.load_reference(args.config)
@@ -128,8 +129,13 @@ def digest_parity(scene, args, l3d):
                 "error": f"tests/golden/full/{args.config}.json is missing (tools/ref_digest.py {args.config})"}
     if meta["scene_sha256"] != FD.scene_hash(scene):
         return {"config": args.config, "checked": False, "ok": False, "error": "stored reference record is of another scene"}
+    if floats is None:   # neither the full float arrays nor their committed sample: no half-checked "ok"
+        return {"config": args.config, "checked": False, "ok": False,
+                "error": f"no float arrays for the stored record (oracle/_ref/cache/full_{args.config}.npz, "
+                         f"tests/golden/full/{args.config}_floats_sample.npz)"}
     exact, fl = FD.result_record(l3d, scene, False)
     r = FD.compare(exact, fl, meta["exact"], floats, H.REL_TOL)
+    r["ok"] = bool(r["ok"] and r["floats_checked"] and r["max_rel"] is not None)
     return {"config": args.config, "checked": True,
             "against": f"stored record of the reference's own code ({meta['reference_library']}, objects md5 {meta.get('reference_objects_md5')}, "
                        f"{meta['seconds']} s on {meta['threads']} threads, tools/ref_digest.py)",

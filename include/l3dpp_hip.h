@@ -94,6 +94,11 @@ typedef struct l3d_match_params {
 const char* l3d_last_error(void);
 /* build info: "gfx950;..." */
 const char* l3d_build_info(void);
+/* Device and pinned blocks that contexts release are kept in a process-wide cache for the next context (hipFree /
+ * hipHostMalloc cost milliseconds per scene otherwise): at most a quarter of the device's memory (L3D_CACHE_MAX_MB) and
+ * 1 GiB pinned; emptied automatically when an allocation fails.  l3d_trim_cache() hands everything cached back to the
+ * runtime now (returns the bytes freed) -- for a process that shares the device with other allocators. */
+uint64_t l3d_trim_cache(void);
 
 /* ---- (1) context layer ------------------------------------------------------------- */
 

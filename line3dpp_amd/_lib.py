@@ -57,6 +57,7 @@ EXPORTS = [
     "l3d_add_view_worldpoints", "l3d_get_visual_neighbors", "l3d_neighbors_from_worldpoints",
     "l3d_nvm_open", "l3d_nvm_num_cameras", "l3d_nvm_get_camera", "l3d_nvm_get_worldpoints", "l3d_nvm_close",
     "l3d_nvm_intrinsics", "l3d_segment_cache_name", "l3d_read_segment_cache", "l3d_write_segment_cache",
+    "l3d_trim_cache",
 ]
 
 _lib = None
@@ -75,6 +76,7 @@ def load():
     vp, u32, u64, i32, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_float
     L.l3d_last_error.restype = C.c_char_p
     L.l3d_build_info.restype = C.c_char_p
+    L.l3d_trim_cache.argtypes = []; L.l3d_trim_cache.restype = u64
     L.l3d_create.argtypes = [i32, vp]; L.l3d_create.restype = vp
     L.l3d_destroy.argtypes = [vp]; L.l3d_destroy.restype = None
     L.l3d_add_view.argtypes = [vp, u32, vp, u32, vp, vp, vp, u32, u32, f32, vp, u32]

@@ -228,8 +228,22 @@ std::mutex g_cache_mu;
 std::vector<CachedBlock> g_cache;
 size_t g_cache_bytes[2] = {0, 0};
 constexpr size_t kCacheMaxBlocks = 512;
-constexpr size_t kCacheMaxBytes[2] = {(size_t)96 << 30, (size_t)1 << 30};   // device / pinned
+constexpr size_t kCacheMaxPinned = (size_t)1 << 30;
+thread_local int g_release_synced = 0;   // > 0: inside a ReleaseSynced scope
+// device blocks: a quarter of the device's memory at most (the rest stays with the runtime: torch / RCCL live in the
+// same process), whatever the device: L3D_CACHE_MAX_MB overrides
+size_t cache_max_device_bytes() {
+    static const size_t cap = [] {
+        if (const char* e = std::getenv("L3D_CACHE_MAX_MB")) return (size_t)std::strtoull(e, nullptr, 10) << 20;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) { (void)hipGetLastError(); return (size_t)16 << 30; }
+        return tot / 4;
+    }();
+    return cap;
+}
 }  // namespace
+ReleaseSynced::ReleaseSynced() { ++g_release_synced; }
+ReleaseSynced::~ReleaseSynced() { --g_release_synced; }
 void* block_cache_take(bool pinned, size_t bytes, size_t* got_bytes) {
     if (!bytes) return nullptr;
     int dev = 0;
@@ -253,11 +267,42 @@ bool block_cache_give(bool pinned, void* p, size_t bytes) {
     if (off || !p || !bytes) return false;
     int dev = 0;
     (void)hipGetDevice(&dev);
+    const size_t cap = pinned ? kCacheMaxPinned : cache_max_device_bytes();
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if (g_cache.size() >= kCacheMaxBlocks || g_cache_bytes[pinned] + bytes > cap) return false;
+    }
+    // Kernels or copies of the releasing context may still be in flight on the block (a buffer that grows between two
+    // launches): the next owner -- another context, another stream, the host writing a pinned block -- must not meet
+    // them.  Same wait as the hipFree / hipHostFree this replaces.
+    if (!g_release_synced && hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return false; }
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    if (g_cache.size() >= kCacheMaxBlocks || g_cache_bytes[pinned] + bytes > kCacheMaxBytes[pinned]) return false;
+    if (g_cache.size() >= kCacheMaxBlocks || g_cache_bytes[pinned] + bytes > cap) return false;
     g_cache.push_back(CachedBlock{p, bytes, dev, pinned});
     g_cache_bytes[pinned] += bytes;
     return true;
+}
+size_t block_cache_trim(int kind) {
+    std::vector<CachedBlock> out;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (size_t i = 0; i < g_cache.size();) {
+            if (kind < 0 || (int)g_cache[i].pinned == kind) {
+                out.push_back(g_cache[i]); g_cache_bytes[g_cache[i].pinned] -= g_cache[i].bytes;
+                g_cache[i] = g_cache.back(); g_cache.pop_back();
+            } else ++i;
+        }
+    }
+    size_t freed = 0;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (const CachedBlock& b : out) {
+        if (b.pinned) (void)hipHostFree(b.p);
+        else { (void)hipSetDevice(b.device); (void)hipFree(b.p); }
+        freed += b.bytes;
+    }
+    if (!out.empty()) (void)hipSetDevice(cur);
+    return freed;
 }
 
 float ev_ms(hipEvent_t a, hipEvent_t b) {
@@ -278,6 +323,8 @@ const char* l3d_last_error(void) { return g_err.c_str(); }
 #endif
 const char* l3d_build_info(void) { return "libl3dpp_hip gfx950 hip fp-contract=off build=" L3D_BUILD_ID; }
 
+uint64_t l3d_trim_cache(void) { return (uint64_t)block_cache_trim(-1); }
+
 l3d_ctx* l3d_create(int device, void* stream) {
     if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed: no usable HIP device"); return nullptr; }
     auto* c = new l3d_ctx();
@@ -291,22 +338,30 @@ l3d_ctx* l3d_create(int device, void* stream) {
     // matchImages of the process: the code object of every translation unit with kernels (loaded at the first launch
     // of one of its kernels, ~0.6 ms each) and the copy paths of both directions (the first device-to-host
     // hipMemcpyAsync of a process took 7.3 ms -- of an 11 ms first call on a scene whose later calls take 0.3 ms).
-    // L3D_NO_WARMUP=1 leaves it to the first call (diagnostic).
-    if (!std::getenv("L3D_NO_WARMUP")) {
+    // L3D_NO_WARMUP=1 leaves it to the first call (diagnostic).  Once per process and device: later contexts find the
+    // code objects loaded and the copy paths set up.
+    static std::mutex warm_mu;
+    static std::set<int> warmed;
+    bool need_warm = !std::getenv("L3D_NO_WARMUP");
+    if (need_warm) { std::lock_guard<std::mutex> lk(warm_mu); need_warm = warmed.insert(device).second; }
+    if (need_warm) {
         hipStream_t st = c->stream;
         DevBuf<uint32_t> d; PinnedBuf<uint32_t> h;
-        // (a copy of a few bytes goes another way inside the runtime: it is the first copy of some KiB that pays)
-        constexpr size_t kWarmWords = 16384;
+        // (the runtime takes a different copy path per size class and sets each one up at its first use: measured on the
+        // first matchImages of a process, profiles/r03_first_call_of_a_process.txt -- 64 KiB + 64 B covered C1's 9 KiB view
+        // table but not C0's 3.7 KiB one (7.8 ms inside l3d_match_begin) nor C3's 147 KiB; one copy of 64 B, 4 KiB,
+        // 64 KiB and 1 MiB in each direction moves all of it here)
+        constexpr size_t kWarmWords = (1u << 20) / 4;
         bool ok = d.reserve(kWarmWords) == hipSuccess && h.reserve(kWarmWords) == hipSuccess;
         ok = ok && hipMemsetAsync(d.p, 0, kWarmWords * 4, st) == hipSuccess;
-        ok = ok && hipMemcpyAsync(h.p, d.p, kWarmWords * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
-        ok = ok && hipMemcpyAsync(d.p, h.p, kWarmWords * 4, hipMemcpyHostToDevice, st) == hipSuccess;
-        ok = ok && hipMemcpyAsync(h.p, d.p, 64, hipMemcpyDeviceToHost, st) == hipSuccess;
-        ok = ok && hipMemcpyAsync(d.p, h.p, 64, hipMemcpyHostToDevice, st) == hipSuccess;
+        for (size_t bytes : {(size_t)64, (size_t)4096, (size_t)65536, (size_t)1 << 20}) {
+            ok = ok && hipMemcpyAsync(h.p, d.p, bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+            ok = ok && hipMemcpyAsync(d.p, h.p, bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+        }
         ok = ok && warm_match(st) == hipSuccess && warm_lists(st) == hipSuccess && warm_scan(st) == hipSuccess &&
              warm_views(st) == hipSuccess && warm_affinity(st) == hipSuccess && warm_rdd(st) == hipSuccess;
         ok = ok && hipStreamSynchronize(st) == hipSuccess;
-        d.release(); h.release();
+        { const ReleaseSynced drained; d.release(); h.release(); }
         if (!ok) { set_error("start-up launches failed: no usable HIP device"); l3d_destroy(c); return nullptr; }
     }
     return c;
@@ -316,6 +371,8 @@ void l3d_destroy(l3d_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (auto& s2 : c->aux) if (s2) (void)hipStreamSynchronize(s2);
+    const ReleaseSynced drained;   // everything this context enqueued has been waited for: its blocks may change hands
     for (auto& kv : c->views) {
         HostView& v = *kv.second;
         v.d_seg4.release(); v.d_segf.release();

@@ -30,9 +30,22 @@ void set_error(const std::string& s);
 // Blocks released by a context (l3d_destroy, a buffer that grows) go to a process-wide cache and are handed to the next
 // reservation of similar size on the same device instead of back to the runtime: hipFree costs ~0.2 ms and
 // hipHostMalloc up to milliseconds on MI355X (tools/alloc_bench.hip), so a process that serves one Line3D object per
-// scene would otherwise pay ~10 ms per scene for memory it had a moment ago.  Bounded (blocks and bytes); l3d_api.hip.
+// scene would otherwise pay ~10 ms per scene for memory it had a moment ago.  Bounded (blocks; bytes: a quarter of the
+// device's memory at most, 1 GiB pinned); l3d_api.hip.
+//   * A block may only change hands when nothing is in flight on it.  hipFree / hipHostFree used to see to that (they
+//     synchronise the device); block_cache_give does the same unless the caller says the work that touched the block
+//     has been waited for (ReleaseSynced: l3d_destroy after it has drained its streams).  Growth is not part of the
+//     steady state -- a buffer grows on the first call of a scene larger than any before -- so the wait costs what
+//     the hipFree it replaces cost, minus the free.
+//   * An allocation that fails empties the cache of its kind (block_cache_trim) and is tried once more: cached blocks
+//     are only reused for requests of similar size, so a process that serves scenes of varying size could otherwise
+//     run out of memory the runtime still had before the cache existed.  l3d_trim_cache() does the same on demand.
 void* block_cache_take(bool pinned, size_t bytes, size_t* got_bytes);   // nullptr: nothing suitable cached
 bool block_cache_give(bool pinned, void* p, size_t bytes);              // false: cache full, caller frees
+size_t block_cache_trim(int kind);                                      // 0 device, 1 pinned, -1 both; returns bytes freed
+struct ReleaseSynced {   // RAII: releases on this thread inside the scope need no device synchronisation
+    ReleaseSynced(); ~ReleaseSynced();
+};
 
 // device buffer that grows but never shrinks (its block returns to the cache with the context)
 template <class T>
@@ -46,6 +59,7 @@ struct DevBuf {
         size_t got = 0;
         if (void* q = block_cache_take(false, n * sizeof(T), &got)) { p = (T*)q; bytes_ = got; cap = got / sizeof(T); return hipSuccess; }
         hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+        if (e != hipSuccess && block_cache_trim(0)) { (void)hipGetLastError(); e = hipMalloc((void**)&p, n * sizeof(T)); }
         if (e == hipSuccess) { cap = n; bytes_ = n * sizeof(T); } else p = nullptr;
         return e;
     }
@@ -73,6 +87,7 @@ struct PinnedBuf {
         size_t got = 0;
         if (void* q = block_cache_take(true, n * sizeof(T), &got)) { p = (T*)q; bytes_ = got; cap = got / sizeof(T); return hipSuccess; }
         hipError_t e = hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess && block_cache_trim(1)) { (void)hipGetLastError(); e = hipHostMalloc((void**)&p, n * sizeof(T), hipHostMallocDefault); }
         if (e == hipSuccess) { cap = n; bytes_ = n * sizeof(T); } else p = nullptr;
         return e;
     }

@@ -7,7 +7,11 @@ from the HIP context (line3dpp_amd.Line3D) and from the oracle (oracle.Oracle dr
                (tests/golden/full/<config>.json, committed, a few KB per config).
   float part   score3D of every surviving match, 3D end points / direction of every best hypothesis, affinity weights,
                view median depths, med_scene_depth_lines: compared at REL_TOL.  Stored as arrays in
-               oracle/_ref/cache/full_<config>.npz (git-ignored like oracle/_ref itself, travels with the snapshot).
+               oracle/_ref/cache/full_<config>.npz (git-ignored like oracle/_ref itself, travels with the snapshot) and,
+               so that the float half of the check can never silently drop out, as a COMMITTED strided sample of the
+               same arrays (tests/golden/full/<config>_floats_sample.npz: every n-th value, <= 16 384 per array, a few
+               hundred KB per configuration).  load_reference() hands back the full arrays when they are there, the
+               sample otherwise, and None only when neither exists -- which the callers treat as a FAILURE.
 
 tools/ref_digest.py writes both from a run of oracle/_ref on the full BASELINE configuration (minutes of CPU, done once
 per reference build); tests/test_gpu_full_size.py and bench.py --parity-digest compare the HIP result with them.
@@ -85,17 +89,38 @@ def _max_rel(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-30)))
 
 
+SAMPLE_CAP = {"score3D": 16384, "affinity_w": 16384, "best_geo": 4096}   # values / rows kept of each array
+
+
+def sample_floats(floats):
+    """the committed compact form: every n-th value of the large arrays (the strides travel with it)"""
+    out, strides = {}, {}
+    for k, a in floats.items():
+        a = np.asarray(a)
+        st = max(1, -(-len(a) // SAMPLE_CAP[k])) if k in SAMPLE_CAP else 1
+        out[k] = a[::st]; strides[k] = st
+    out["_strides"] = np.asarray([strides[k] for k in FLOAT_KEYS], np.int64)
+    return out
+
+
+FLOAT_KEYS = ("score3D", "median_depth", "best_geo", "affinity_w", "med_scene_depth_lines")
+
+
 def compare(exact, floats, ref_exact, ref_floats, tol):
-    """-> dict(ok, differing_views, ..., max_rel); ref_floats may be None (exact part only)"""
+    """-> dict(ok, differing_views, ..., max_rel); ref_floats: the full arrays or the committed sample (key "_strides");
+    None leaves only the exact part checked, and r["floats_checked"] False -- callers must treat that as a failure"""
     r = {"surviving": ref_exact["surviving"], "best": ref_exact["best"], "affinity_entries": ref_exact["affinity_entries"]}
     r["differing_views"] = sorted(int(c) for c in ref_exact["views"] if exact["views"].get(c) != ref_exact["views"][c])
     r["counts_equal"] = all(exact[k] == ref_exact[k] for k in ("surviving", "best", "affinity_entries"))
     r["best_equal"] = exact["best_digest"] == ref_exact["best_digest"]
     r["affinity_pairs_equal"] = exact["affinity_digest"] == ref_exact["affinity_digest"]
     r["exact_ok"] = bool(not r["differing_views"] and r["counts_equal"] and r["best_equal"] and r["affinity_pairs_equal"])
-    r["floats_checked"] = ref_floats is not None
+    r["floats_checked"] = False if ref_floats is None else ("sample" if "_strides" in ref_floats else "full")
     r["max_rel"] = None
     if ref_floats is not None and r["exact_ok"]:
+        if "_strides" in ref_floats:   # the candidate's arrays, sampled like the stored ones
+            st = dict(zip(FLOAT_KEYS, (int(x) for x in ref_floats["_strides"])))
+            floats = {k: np.asarray(floats[k])[::st[k]] for k in FLOAT_KEYS}
         rel = {k: _max_rel(floats[k], ref_floats[k]) for k in ("score3D", "median_depth", "affinity_w", "med_scene_depth_lines")}
         g, o = floats["best_geo"], np.asarray(ref_floats["best_geo"])
         err = 0.0
@@ -111,22 +136,36 @@ def compare(exact, floats, ref_exact, ref_floats, tol):
 
 
 def load_reference(config):
-    """(meta + exact digests, floats or None) of the stored reference run of `config`, or (None, None)"""
+    """(meta + exact digests, floats) of the stored reference run of `config`, or (None, None).  floats: the full arrays
+    beside oracle/_ref when present, else the committed strided sample (dict with "_strides"), else None"""
     p = os.path.join(DIGEST_DIR, f"{config}.json")
     if not os.path.exists(p):
         return None, None
     meta = json.load(open(p))
-    fp = os.path.join(CACHE_DIR, f"full_{config}.npz")
+    sha = _sha(json.dumps(meta["exact"], sort_keys=True).encode())
     floats = None
-    if os.path.exists(fp):
+    fp = os.path.join(CACHE_DIR, f"full_{config}.npz")
+    if os.path.exists(fp) and not os.environ.get("L3D_FLOATS_SAMPLE_ONLY"):
         z = np.load(fp)
-        if str(z["exact_sha"]) == _sha(json.dumps(meta["exact"], sort_keys=True).encode()):
-            floats = {k: z[k] for k in ("score3D", "median_depth", "best_geo", "affinity_w", "med_scene_depth_lines")}
+        if str(z["exact_sha"]) == sha:
+            floats = {k: z[k] for k in FLOAT_KEYS}
+    if floats is None:
+        sp = os.path.join(DIGEST_DIR, f"{config}_floats_sample.npz")
+        if os.path.exists(sp):
+            z = np.load(sp)
+            if str(z["exact_sha"]) == sha:
+                floats = {k: z[k] for k in FLOAT_KEYS + ("_strides",)}
     return meta, floats
 
 
 def store_reference(config, meta, floats):
     os.makedirs(DIGEST_DIR, exist_ok=True); os.makedirs(CACHE_DIR, exist_ok=True)
     json.dump(meta, open(os.path.join(DIGEST_DIR, f"{config}.json"), "w"), indent=0, sort_keys=True)
-    np.savez_compressed(os.path.join(CACHE_DIR, f"full_{config}.npz"),
-                        exact_sha=_sha(json.dumps(meta["exact"], sort_keys=True).encode()), **floats)
+    sha = _sha(json.dumps(meta["exact"], sort_keys=True).encode())
+    np.savez_compressed(os.path.join(CACHE_DIR, f"full_{config}.npz"), exact_sha=sha, **floats)
+    store_sample(config, sha, floats)
+
+
+def store_sample(config, sha, floats):
+    np.savez_compressed(os.path.join(DIGEST_DIR, f"{config}_floats_sample.npz"), exact_sha=sha,
+                        **sample_floats({k: floats[k] for k in FLOAT_KEYS}))

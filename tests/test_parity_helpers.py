@@ -67,3 +67,27 @@ def test_ring_slice_keeps_full_neighbour_sets_in_the_middle():
     assert all(len(v.neighbors) == 6 for v in mid)
     assert all(set(v.neighbors) <= set(range(5, 14)) for v in sl.views)
     assert len(sc.views[5].neighbors) == 6          # the source scene is untouched
+
+
+def test_committed_float_samples_belong_to_the_stored_records_and_catch_a_planted_error(monkeypatch):
+    """tests/golden/full/<config>_floats_sample.npz: the compact form of the reference's float fields that the full-size
+    checks fall back to where oracle/_ref/cache did not travel -- it must match the committed record of its
+    configuration, sample every array, and a value off by 1 % at a sampled position must fail the comparison."""
+    from tests import full_digest as FD
+    monkeypatch.setenv("L3D_FLOATS_SAMPLE_ONLY", "1")
+    for cfg in ("C1", "C2", "C4"):
+        meta, ref = FD.load_reference(cfg)
+        assert meta is not None and ref is not None and "_strides" in ref, cfg
+        st = dict(zip(FD.FLOAT_KEYS, (int(x) for x in ref["_strides"])))
+        assert len(ref["score3D"]) == -(-meta["exact"]["surviving"] // st["score3D"])
+        assert len(ref["best_geo"]) == -(-meta["exact"]["best"] // st["best_geo"])
+        # a candidate that IS the reference at the sampled positions (other positions never enter the comparison)
+        cand = {k: np.repeat(np.asarray(ref[k]), st[k], axis=0) for k in FD.FLOAT_KEYS}
+        r = FD.compare(meta["exact"], cand, meta["exact"], ref, H.REL_TOL)
+        assert r["ok"] and r["floats_checked"] == "sample" and r["max_rel"] == 0.0
+        bad = dict(cand); a = cand["affinity_w"].copy(); a[3 * st["affinity_w"]] *= 1.01; bad["affinity_w"] = a
+        r = FD.compare(meta["exact"], bad, meta["exact"], ref, H.REL_TOL)
+        assert not r["ok"] and r["max_rel"] > 5e-3
+        # no floats at all: the comparison says so and callers (test_gpu_full_size, bench.py) fail on it
+        r = FD.compare(meta["exact"], cand, meta["exact"], None, H.REL_TOL)
+        assert r["floats_checked"] is False and r["max_rel"] is None
