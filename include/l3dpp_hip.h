@@ -149,6 +149,29 @@ int l3d_nvm_get_camera(const l3d_nvm*, uint32_t index, l3d_nvm_camera* out);
 int l3d_nvm_get_worldpoints(const l3d_nvm*, uint32_t index, uint32_t* out, uint32_t cap);   /* = addImage's wps list */
 void l3d_nvm_close(l3d_nvm*);
 void l3d_nvm_intrinsics(float focal, uint32_t width, uint32_t height, double K[9]);          /* main_vsfm.cpp:272-282 */
+/* COLMAP text results (cameras.txt / images.txt / points3D.txt of a folder, main_colmap.cpp:136-348) and bundler files
+ * (bundle.rd.out, main_bundler.cpp:147-252) with what those front ends derive per image: K (COLMAP; bundler builds it
+ * from the image size: l3d_nvm_intrinsics), R, t, C = R^T (-t), the distortion coefficients handed to undistortImage,
+ * the worldpoint list and the median worldpoint distance handed to addImage.  Images in file order; `id` is the camID
+ * the front end passes to addImage (COLMAP: IMAGE_ID, bundler: the camera index); n_worldpoints == 0: skipped there. */
+typedef struct l3d_sfm l3d_sfm;
+typedef struct l3d_sfm_image {
+    uint32_t id, camera;              /* camID for addImage; COLMAP CAMERA_ID (bundler: = id) */
+    uint32_t width, height;           /* COLMAP: from cameras.txt (the reference takes the size from the image file); bundler: 0 */
+    const char* name;                 /* COLMAP image name (valid while the handle lives); bundler: "" */
+    float focal;                      /* bundler focal length (float there); COLMAP: (float)fx */
+    float median_depth;
+    uint32_t n_worldpoints;
+    double K[9];                      /* COLMAP; bundler: zeros */
+    double R[9], t[3], C[3];
+    double radial[3], tangential[2];  /* k1 k2 k3, p1 p2 */
+} l3d_sfm_image;
+int l3d_sfm_open_colmap(const char* folder, l3d_sfm** out);
+int l3d_sfm_open_bundler(const char* bundle_file, l3d_sfm** out);   /* L3D_ERR_NO_VIEWS: "No cameras and/or points in bundle file!" */
+uint32_t l3d_sfm_num_images(const l3d_sfm*);
+int l3d_sfm_get_image(const l3d_sfm*, uint32_t index, l3d_sfm_image* out);
+int l3d_sfm_get_worldpoints(const l3d_sfm*, uint32_t index, uint32_t* out, uint32_t cap);
+void l3d_sfm_close(l3d_sfm*);
 /* The segment cache Line3D::detectLineSegments loads / stores per image when load_segments is set (line3D.cc:295-309,
  * 362-366): "<data folder>/segments_L3D++_<camID>_<width>x<height>_<max segments>.bin", the boost binary archive of a
  * one-row L3DPP::DataArray<float4> (dataArray.h:352-374).  segs4 = n x (x1, y1, x2, y2). */
@@ -172,7 +195,8 @@ int l3d_match_begin(l3d_ctx*, const l3d_match_params*);
 int l3d_num_pairs(l3d_ctx*, uint32_t* n);
 int l3d_get_pairs(l3d_ctx*, uint32_t* src_cam, uint32_t* tgt_cam, uint64_t* slot_offset /* in slots */);
 int l3d_match_pairs(l3d_ctx*, uint32_t first, uint32_t count);
-int l3d_slot_buffer(l3d_ctx*, void** dev_ptr, uint64_t* n_slots);
+int l3d_slot_buffer(l3d_ctx*, void** dev_ptr, uint64_t* n_slots);   /* (halo form of a multi-GPU call: only the regions of
+                                                                       * the pairs this rank matched or received hold slots) */
 /* tell the context that the caller's exchange has filled in the slots of all other pairs */
 int l3d_slots_exchanged(l3d_ctx*);
 /* Compact form of the same exchange (kNN > 0): only the target index of every slot travels (4 B instead of 32);

@@ -34,6 +34,14 @@ class MatchParams(C.Structure):
                 ("epipolar_overlap", C.c_float), ("kNN", C.c_int32), ("const_regularization_depth", C.c_float)]
 
 
+class SfmImage(C.Structure):
+    """l3d_sfm_image (include/l3dpp_hip.h)"""
+    _fields_ = [("id", C.c_uint32), ("camera", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("name", C.c_char_p), ("focal", C.c_float), ("median_depth", C.c_float), ("n_worldpoints", C.c_uint32),
+                ("K", C.c_double * 9), ("R", C.c_double * 9), ("t", C.c_double * 3), ("C", C.c_double * 3),
+                ("radial", C.c_double * 3), ("tangential", C.c_double * 2)]
+
+
 class Timings(C.Structure):
     _fields_ = [("begin_ms", C.c_float), ("match_pairs_ms", C.c_float), ("finish_ms", C.c_float),
                 ("affinity_ms", C.c_float), ("match_kernel_launches", C.c_uint32), ("match_kernel_ms", C.c_float),
@@ -58,6 +66,8 @@ EXPORTS = [
     "l3d_nvm_open", "l3d_nvm_num_cameras", "l3d_nvm_get_camera", "l3d_nvm_get_worldpoints", "l3d_nvm_close",
     "l3d_nvm_intrinsics", "l3d_segment_cache_name", "l3d_read_segment_cache", "l3d_write_segment_cache",
     "l3d_trim_cache",
+    "l3d_sfm_open_colmap", "l3d_sfm_open_bundler", "l3d_sfm_num_images", "l3d_sfm_get_image", "l3d_sfm_get_worldpoints",
+    "l3d_sfm_close",
 ]
 
 _lib = None
@@ -83,6 +93,10 @@ def load():
     L.l3d_add_view_worldpoints.argtypes = [vp, u32, vp, u32, vp, vp, vp, u32, u32, f32, vp, u32]
     L.l3d_get_visual_neighbors.argtypes = [vp, u32, vp, u32, vp]
     L.l3d_neighbors_from_worldpoints.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, vp, vp, u64]
+    L.l3d_sfm_open_colmap.argtypes = [C.c_char_p, vp]; L.l3d_sfm_open_bundler.argtypes = [C.c_char_p, vp]
+    L.l3d_sfm_num_images.argtypes = [vp]; L.l3d_sfm_num_images.restype = u32
+    L.l3d_sfm_get_image.argtypes = [vp, u32, vp]; L.l3d_sfm_get_worldpoints.argtypes = [vp, u32, vp, u32]
+    L.l3d_sfm_close.argtypes = [vp]; L.l3d_sfm_close.restype = None
     L.l3d_nvm_open.argtypes = [C.c_char_p, vp]
     L.l3d_nvm_num_cameras.argtypes = [vp]; L.l3d_nvm_num_cameras.restype = u32
     L.l3d_nvm_get_camera.argtypes = [vp, u32, vp]

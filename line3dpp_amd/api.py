@@ -38,6 +38,7 @@ class Line3D:
         self.verbose = verbose
         self.last_status = 0
         self._M = {}
+        self.stream = int(stream)          # the hipStream_t every launch of this context goes to (dist.py: ordering of collectives)
         self.h = self.L.l3d_create(int(device), C.c_void_p(stream))
         if not self.h:
             raise RuntimeError("l3d_create failed: " + _lib.last_error())

@@ -1,7 +1,8 @@
 // k_lists.hip -- phase B, sparse form: the per-view part of Line3D::computeMatches (line3D.cc:745-773) =
 // scoringCPU (:1208-1294) + storeInverseMatches (:1672-1699) + filterMatches (:1586-1669) for ALL views.
 //
-//   k_inv_records   transposed index of the potential inverse hypotheses (24-byte records, CSR over segments)
+//   k_pair_csr      the potential inverse hypotheses of each directed pair, counting-sorted by target segment in LDS
+//                   (16-byte records + per-pair CSR offsets over the target view's segments; no device atomics)
 //   k_lists<WPL>    THE dense pass, one wave (long lists: one 4-wave workgroup) per 2D segment: gathers the segment's
 //                   hypotheses in canonical (= reference single-thread) order, sorts them by depth, finds the pairs
 //                   (i, j) with similarityForScoring(i, j) > 0.5 inside each hypothesis' depth window (conservative
@@ -16,6 +17,9 @@
 //   k_hyp_scores    score3D of every header from its edges (per-camera replace/subtract accumulation, :1255-1274)
 //   k_hyp_filter / k_seg_filter / k_seg_write   filterMatches: 10 % of the view's best score, first strict maximum,
 //                   0.75 gate; surviving matches_ lists, estimated_position3D_ entries, depths for the view medians
+#include <algorithm>
+#include <cstdlib>
+
 #include "l3d_dev.h"
 #include "l3d_kernels.h"
 #include "l3d_lists.h"
@@ -264,24 +268,22 @@ struct ListCfg {
     static constexpr uint32_t BYTES = CAP * 20 + NKEY * 8 + CAP * 2 + 64;   // LDS per list
 };
 
-// One list: its candidate pairs.  Returns 0 (done / nothing to do) or 1 (needs a larger kernel: nothing was written).
+// One list: its candidate pairs.  Returns 0 (done / nothing to do) or the list's length L > CAP (needs a larger kernel:
+// nothing was written).  The length is not known beforehand (round 4: no per-segment counters are kept): it is the number
+// of inverse records in the segment's rows of its incoming pairs' CSRs plus the alive fresh slots the pass finds.
 // Group-uniform control flow.
 template <int WPL, int BASE>
-__device__ __forceinline__ int process_list(uint32_t vi, uint32_t seg, uint32_t pool, L3D_LDS char* lds,
-                                            const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
-                                            const ListView* __restrict__ lviews, const OutPair* __restrict__ opairs,
-                                            const unsigned long long* __restrict__ off64,
-                                            const InvRec* __restrict__ inv, const Slot* __restrict__ slots,
-                                            uint32_t uniform_K, const ListPools lp) {
+__device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint32_t pool, L3D_LDS char* lds,
+                                                 const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+                                                 const ListView* __restrict__ lviews, const OutPair* __restrict__ opairs,
+                                                 const InPair* __restrict__ ipairs, const uint32_t* __restrict__ poff,
+                                                 const uint32_t* __restrict__ inv, const Slot* __restrict__ slots,
+                                                 uint32_t uniform_K, const ListPools lp) {
     typedef ListCfg<WPL, BASE> Cfg;
     constexpr uint32_t GS = Cfg::GS, CAP = Cfg::CAP, NKEY = Cfg::NKEY;
     const uint32_t t = WPL == 1 ? lane_id() : threadIdx.x;
     const ListView lv = lviews[vi];
     const uint32_t g = lv.seg_base + seg;
-    const unsigned long long o0 = off64[g], o1 = off64[g + 1];
-    const uint32_t L = (uint32_t)(o1 - o0);                             // low words: list offsets
-    if (L < 2) return 0;
-    if (L > CAP) return 1;
     L3D_LDS float* e_d1 = (L3D_LDS float*)lds;
     L3D_LDS float* e_d2 = e_d1 + CAP;
     L3D_LDS uint32_t* e_tv = (L3D_LDS uint32_t*)(e_d2 + CAP);
@@ -291,40 +293,74 @@ __device__ __forceinline__ int process_list(uint32_t vi, uint32_t seg, uint32_t 
     L3D_LDS uint16_t* pos_of = (L3D_LDS uint16_t*)(keys + NKEY);        // sorted position of hypothesis i
     uint32_t* red = (uint32_t*)(pos_of + CAP);                          // 16 words (generic pointer into LDS)
     const float vk = lv.k;
-    const uint32_t ib = (uint32_t)(o0 >> 32), n_inv = (uint32_t)(o1 >> 32) - ib;
-    // ---- inverse hypotheses, placed at their canonical rank: (source view, source segment) ascending ----
+    const uint32_t q0 = lv.q0, nq = lv.nq;
+    const uint32_t T = uniform_K ? nq * uniform_K : 0u;
+    // (measured and not adopted, profiles/r04_ab_list_pass.txt: requesting the fresh slots BEFORE the inverse chain and
+    // holding them in registers -- the two load chains side by side, and the list's length known before anything is
+    // staged -- took the one-wave tier from 32 to 70 VGPRs and made it 8 % slower)
+    // ---- inverse hypotheses: the segment's row of every incoming pair's CSR, pairs in ascending index (= ascending
+    // source view), the entries of a row in ascending slot index -- that IS the canonical order.  The rows' starts and
+    // their prefix within the list are staged in LDS (the keys array is not needed yet); an entry finds its row by a scan
+    // over the handful of incoming pairs and its place inside the row by counting the row's smaller slot indices (a row
+    // holds the few source segments of ONE view that matched this segment; until round 3 every record was ranked against
+    // all inverse records of the list) ----
+    uint32_t n_inv = 0;
     {
-        constexpr uint32_t kInvPer = (CAP + GS - 1) / GS;               // records per thread (n_inv <= L <= CAP)
-        // (rank by slot index = rank by (source view, source row), l3d_lists.h; the keys array is not needed yet)
+        // rows (incoming pairs) per round: a view has a handful.  Per row: [5q] first entry, [5q + 1] its place in the
+        // list, [5q + 2] its end, [5q + 3] source view, [5q + 4] pair; behind the table the slot indices of the round
+        constexpr uint32_t kRows = (2 * NKEY - CAP) / 5 >= 32 ? 32 : 16;
         L3D_LDS uint32_t* k32 = (L3D_LDS uint32_t*)keys;
-        InvRec mine[kInvPer];
-#pragma unroll
-        for (uint32_t c = 0; c < kInvPer; ++c) {
-            const uint32_t x = c * GS + t;
-            if (x < n_inv) {
-                mine[c] = inv[ib + x];
-                k32[x] = mine[c].ref;
+        L3D_LDS uint32_t* kref = k32 + 5 * kRows;
+        static_assert(5 * kRows + CAP <= 2 * NKEY, "LDS staging of the inverse hypotheses");
+        constexpr uint32_t kInvPer = (CAP + GS - 1) / GS;               // entries per thread and round
+        for (uint32_t qb = 0; qb < lv.ni; qb += kRows) {
+            const uint32_t nq_here = min(kRows, lv.ni - qb), q = qb + t;
+            uint32_t c = 0;
+            if (t < nq_here) {   // (three independent loads: the transposed offsets need nothing of the pair's table entry)
+                const uint32_t e0 = poff[lv.pbase + seg * lv.ni + q], e1 = poff[lv.pbase + (seg + 1) * lv.ni + q];
+                const InPair ip = ipairs[lv.i0 + q];
+                c = e1 - e0;
+                k32[5 * t] = ip.rec_base + e0; k32[5 * t + 3] = ip.src; k32[5 * t + 4] = ip.pair;
             }
-        }
-        group_barrier<WPL>();
+            uint32_t total;
+            const uint32_t ex = group_scan<WPL>(c, total, red);
+            if (t < nq_here) { k32[5 * t + 1] = ex; k32[5 * t + 2] = ex + c; }
+            group_barrier<WPL>();
+            if (n_inv + total > CAP) { n_inv += total; group_barrier<WPL>(); continue; }   // too long for this tier: only the length matters
+            uint32_t ref[kInvPer], row[kInvPer];
+            float2 dq[kInvPer];
 #pragma unroll
-        for (uint32_t c = 0; c < kInvPer; ++c) {
-            const uint32_t x = c * GS + t;
-            if (x < n_inv) {
-                const InvRec& r = mine[c];
-                uint32_t rank = 0;
-                for (uint32_t y = 0; y < n_inv; ++y) rank += (k32[y] < r.ref) ? 1u : 0u;
-                e_d1[rank] = r.dq1; e_d2[rank] = r.dq2; e_tv[rank] = pairs[r.pair].src; e_ref[rank] = r.ref; e_pf[rank] = r.pair | kHypInv;
+            for (uint32_t cc = 0; cc < kInvPer; ++cc) {
+                const uint32_t x = cc * GS + t;
+                if (x < total) {
+                    uint32_t r = 0;
+                    for (uint32_t j = 1; j < nq_here; ++j) r = k32[5 * j + 1] <= x ? j : r;   // prefixes ascend: the last row that starts at or before x
+                    row[cc] = r;
+                    ref[cc] = inv[k32[5 * r] + (x - k32[5 * r + 1])];
+                    kref[x] = ref[cc];
+                    dq[cc] = *(const float2*)&slots[ref[cc]].dq1;      // the depths of the target's end points = this hypothesis' own
+                }
             }
+            group_barrier<WPL>();
+#pragma unroll
+            for (uint32_t cc = 0; cc < kInvPer; ++cc) {
+                const uint32_t x = cc * GS + t;
+                if (x < total) {
+                    const uint32_t r = row[cc], r0 = k32[5 * r + 1], r1 = k32[5 * r + 2];
+                    uint32_t rank = r0;                                  // place among the entries of its own row (a handful)
+                    for (uint32_t y = r0; y < r1; ++y) rank += (kref[y] < ref[cc]) ? 1u : 0u;
+                    const uint32_t at = n_inv + rank;
+                    e_d1[at] = dq[cc].x; e_d2[at] = dq[cc].y; e_tv[at] = k32[5 * r + 3]; e_ref[at] = ref[cc]; e_pf[at] = k32[5 * r + 4] | kHypInv;
+                }
+            }
+            n_inv += total;
+            group_barrier<WPL>();   // the table is rebuilt / the keys array is overwritten (sort keys, below)
         }
-        group_barrier<WPL>();   // the ranks are taken: the keys array may be overwritten (sort keys, below)
     }
     // ---- fresh hypotheses: the alive slots of the view's outgoing pairs, ascending (target view, slot) ----
     uint32_t pos = n_inv;
     {
-        const uint32_t q0 = lv.q0, nq = lv.nq;
         if (uniform_K) {
-            const uint32_t T = nq * uniform_K;
             for (uint32_t t0 = 0; t0 < T; t0 += GS) {
                 const uint32_t x = t0 + t;
                 bool alive = false;
@@ -361,7 +397,12 @@ __device__ __forceinline__ int process_list(uint32_t vi, uint32_t seg, uint32_t 
         }
     }
     group_barrier<WPL>();
-    if (pos != L) { if (t == 0) atomicOr(&lp.flags[3], 1u); return 0; }   // counters and slots disagree: reported by the host
+    const uint32_t L = pos;
+    if (L > CAP) return L;                       // nothing written beyond the staging arrays: a larger tier takes the list
+    // (total list length of the pass = the reference's number of hypotheses: statistics, and the mean list length that
+    // picks the staging width of the next call)
+    if (t == 0 && L && lp.count_entries) atomicAdd(&lp.cnt[pool * 16 + 5], L);
+    if (L < 2) return 0;
     // ---- sort by the first depth: key = (order-preserving bits of dp1, canonical index) ----
     uint32_t N = 2;
     while (N < L) N <<= 1;
@@ -478,26 +519,113 @@ __device__ __forceinline__ int process_list(uint32_t vi, uint32_t seg, uint32_t 
 
 }  // namespace
 
-// ---- transposed index of the potential inverse hypotheses -------------------------------------------------------
-// grid = (slot blocks, pairs); one thread per slot; off64[g] high word = first record of segment g
-__global__ void k_inv_records(const PairDesc* __restrict__ pairs, uint32_t first_pair,
-                              const uint32_t* __restrict__ seg_base, const Slot* __restrict__ slots,
-                              const unsigned long long* __restrict__ off64, const uint32_t* __restrict__ inv_pos,
-                              InvRec* __restrict__ recs, uint32_t tgt_v0, uint32_t tgt_v1) {
-    const uint32_t pi = first_pair + blockIdx.y;
+// ---- the potential inverse hypotheses of a pair, sorted by target segment ------------------------------------------------
+// storeInverseMatches (line3D.cc:1672-1699) hands every scored match of view u to the view of its target segment.  Until
+// round 3 a slot took its place among the inverse references of its target with a device-scope atomic in the match
+// epilogue (5.5 M of them on C1, each with a returned value the wave waited for), a scan turned the counters into
+// offsets and k_inv_records scattered 16-byte records to them.  Now the match epilogue only writes the 4-byte stream
+// inv_tgt (target segment of a slot that hands an inverse match over, kEmpty otherwise) and ONE WORKGROUP PER PAIR
+// counting-sorts its slots by target segment: histogram over the target view's segments in LDS, scan, then every slot
+// takes the next place of its target's run from an LDS cursor and writes its index there.  A run holds the handful of
+// source rows that matched this target, in the order the LDS served the atomics; the list pass puts them into ascending
+// slot order (the canonical order) on the way.  Traffic: the 4-byte stream twice (the second time from the L2) and
+// 4 bytes per inverse hypothesis out -- a fifth of what the scatter of records moved.  Views beyond the LDS capacity (LDSCNT = false) keep the
+// cursors in the pair's own offset array.
+//   (first record of a pair: its slot_off -- a pair never has more records than slots)
+constexpr uint32_t kCsrBlock = 1024;
+constexpr uint32_t kCsrLdsSegs = 32768;        // up to 128 KiB of LDS cursors (+ the 64 dummy ones): gfx950 has 160 KiB per workgroup
+constexpr uint32_t kCsrChunk = 8;              // slots per thread whose memory operations are in flight together
+// The offsets are stored TRANSPOSED per target view: offT[pbase_v + t * ni_v + q] = first record of target segment t in
+// the q-th incoming pair of view v (t = 0 .. M_v; ni_v incoming pairs).  A list of segment t then reads the offsets of all
+// its incoming pairs with two coalesced loads whose addresses follow from the view table alone.
+// The loops are written WITHOUT data-dependent branches: a workgroup is the only one on its CU most of the time (a
+// handful of waves per SIMD), so what hides the latency of a load or of an LDS atomic is the next independent one of the
+// same wave -- slots that hand nothing over count on one of 64 dummy cursors instead of skipping the atomic (a branch
+// around each access serialised them: 0.11 ms on C1 where the batched form takes a fraction of that).
+template <bool LDSCNT>
+__global__ __launch_bounds__(kCsrBlock) void k_pair_csr(const PairDesc* __restrict__ pairs, uint32_t first_pair,
+                                                        const PairCsr* __restrict__ pair_csr,
+                                                        const uint32_t* __restrict__ inv_tgt,
+                                                        uint32_t* __restrict__ poff, uint32_t* __restrict__ refs,
+                                                        uint32_t* __restrict__ dummy, uint32_t tgt_v0, uint32_t tgt_v1,
+                                                        uint32_t lds_segs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t part[kCsrBlock];
+    const uint32_t pi = first_pair + blockIdx.x;
+    const PairCsr pcs = pair_csr[pi];
+    if (pcs.base == kEmpty) return;                                 // the pair hands nothing over (tgt < src)
     const PairDesc& pd = pairs[pi];
-    if (pd.tgt <= pd.src || pd.tgt < tgt_v0 || pd.tgt >= tgt_v1) return;   // only the target views of this pass
-    const uint64_t n = (uint64_t)pd.Ms * pd.K;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t ipos = inv_pos[pd.slot_off + i];
-    if (ipos == kEmpty) return;
-    const Slot s = slots[pd.slot_off + i];
-    const uint32_t g = seg_base[pd.tgt] + s.tgt_seg;
-    InvRec r;
-    r.ref = (uint32_t)(pd.slot_off + i); r.pair = pi;
-    r.dq1 = s.dq1; r.dq2 = s.dq2;
-    recs[(uint32_t)(off64[g] >> 32) + ipos] = r;
+    if (pd.tgt < tgt_v0 || pd.tgt >= tgt_v1) return;                // only the target views of this pass
+    const uint32_t Mt = pd.Mt, tid = threadIdx.x;
+    if ((Mt <= lds_segs) != LDSCNT) return;                         // the other instantiation takes this pair
+    const uint32_t S = pd.Ms * pd.K;                                // (< 2^32: l3d_match_begin limits the slot buffer)
+    const uint32_t* __restrict__ it = inv_tgt + pd.slot_off;
+    // end of run t = start of run t + 1 lives at row t + 1 of the transposed table, column q of this pair
+    uint32_t* __restrict__ offq = poff + pcs.base + pcs.q;
+    const uint32_t ni = pcs.ni;
+    // cursors: cur[t] runs from the start of run t to its end; [Mt, Mt + 64): dummies (global form: 64 words per workgroup)
+    L3D_LDS uint32_t* lcur = (L3D_LDS uint32_t*)smem;
+    uint32_t* gdum = dummy + (size_t)blockIdx.x * 64;
+    auto gcur = [&](uint32_t t) -> uint32_t* { return t < Mt ? offq + (size_t)(t + 1) * ni : gdum + (t - Mt); };
+    auto cur_get = [&](uint32_t t) -> uint32_t { return LDSCNT ? lcur[t] : *gcur(t); };
+    auto cur_set = [&](uint32_t t, uint32_t v) { if (LDSCNT) lcur[t] = v; else *gcur(t) = v; };
+    for (uint32_t t = tid; t < Mt + 64; t += kCsrBlock) cur_set(t, 0u);
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t dum = Mt + (tid & 63u);
+    // ---- histogram ----
+    for (uint32_t i0 = 0; i0 < S; i0 += kCsrChunk * kCsrBlock) {
+        uint32_t tv[kCsrChunk];
+#pragma unroll
+        for (uint32_t k = 0; k < kCsrChunk; ++k) { const uint32_t i = i0 + k * kCsrBlock + tid; tv[k] = it[min(i, S - 1)]; tv[k] = (i < S && tv[k] < Mt) ? tv[k] : dum; }
+#pragma unroll
+        for (uint32_t k = 0; k < kCsrChunk; ++k) {
+            if (LDSCNT) (void)__hip_atomic_fetch_add(&lcur[tv[k]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else atomicAdd(gcur(tv[k]), 1u);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- exclusive scan: thread x owns the segments [x * per, (x + 1) * per) ----
+    const uint32_t per = (Mt + kCsrBlock - 1) / kCsrBlock;
+    const uint32_t t0 = min(tid * per, Mt), t1 = min(t0 + per, Mt);
+    uint32_t sum = 0;
+    for (uint32_t t = t0; t < t1; ++t) sum += cur_get(t);
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < kCsrBlock; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    for (uint32_t t = t0; t < t1; ++t) { const uint32_t c = cur_get(t); cur_set(t, run); run += c; }
+    if (tid == 0) offq[0] = 0;
+    __threadfence_block();
+    __syncthreads();
+    // ---- scatter: a slot takes the next place of its target's run (cursor) and its INDEX goes there -- 4 bytes; the
+    // list pass reads the two depths it needs from the slot itself (a first version wrote 16-byte records here and read
+    // every slot's depths for them: one 32-byte sector per slot, 6.7 GB on C2 -- the whole slot buffer -- and ran at
+    // exactly the bandwidth-bound time of the k_inv_records it replaced).  Inside a run the order is the order in which
+    // the atomics were served: the list pass ranks the handful of entries of a run (the canonical order) ----
+    uint32_t* __restrict__ out = refs + pd.slot_off;
+    for (uint32_t i0 = 0; i0 < S; i0 += kCsrChunk * kCsrBlock) {
+        uint32_t tv[kCsrChunk], at[kCsrChunk];
+#pragma unroll
+        for (uint32_t k = 0; k < kCsrChunk; ++k) { const uint32_t i = i0 + k * kCsrBlock + tid; tv[k] = it[min(i, S - 1)]; tv[k] = (i < S && tv[k] < Mt) ? tv[k] : dum; }
+#pragma unroll
+        for (uint32_t k = 0; k < kCsrChunk; ++k)
+            at[k] = LDSCNT ? __hip_atomic_fetch_add(&lcur[tv[k]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                           : atomicAdd(gcur(tv[k]), 1u);
+#pragma unroll
+        for (uint32_t k = 0; k < kCsrChunk; ++k)
+            if (tv[k] < Mt) out[at[k]] = (uint32_t)pd.slot_off + i0 + k * kCsrBlock + tid;
+    }
+    if (LDSCNT) {                                                   // (LDSCNT = false: the cursors ARE the table entries)
+        __syncthreads();
+        for (uint32_t t = tid; t < Mt; t += kCsrBlock) *gcur(t) = lcur[t];
+    }
 }
 
 // WPL = 1: grid (segment blocks, views), one wave per segment; WPL = 4: fixed grid over the segments handed on
@@ -506,20 +634,19 @@ __global__ void k_inv_records(const PairDesc* __restrict__ pairs, uint32_t first
 template <int WPL, int BASE>
 __global__ __launch_bounds__(64 * WPL) void k_lists(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
                                                const ListView* __restrict__ lviews, const OutPair* __restrict__ opairs,
-                                               const uint32_t* __restrict__ gseg_view,
-                                               const unsigned long long* __restrict__ off64,
-                                               const InvRec* __restrict__ inv, const Slot* __restrict__ slots,
+                                               const InPair* __restrict__ ipairs, const uint32_t* __restrict__ gseg_view,
+                                               const uint32_t* __restrict__ poff,
+                                               const uint32_t* __restrict__ inv, const Slot* __restrict__ slots,
                                                uint32_t uniform_K, const ListPools lp, uint32_t view0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (WPL == 1) {
         const uint32_t vi = view0 + blockIdx.y, seg = blockIdx.x;
         if (seg >= lviews[vi].M) return;
         const uint32_t pool = lp.pool0 + ((blockIdx.y * gridDim.x + blockIdx.x) >> 2) % lp.npools;
-        const int rc = process_list<1, BASE>(vi, seg, pool, (L3D_LDS char*)smem, views, pairs, lviews, opairs,
-                                       off64, inv, slots, uniform_K, lp);
-        if (rc && lane_id() == 0) {
+        const uint32_t L = process_list<1, BASE>(vi, seg, pool, (L3D_LDS char*)smem, views, pairs, lviews, opairs,
+                                                 ipairs, poff, inv, slots, uniform_K, lp);
+        if (L && lane_id() == 0) {              // longer than one wave stages: handed to a larger tier
             const uint32_t g = lviews[vi].seg_base + seg;
-            const uint32_t L = (uint32_t)(off64[g + 1] - off64[g]);
             if (L > 65535u) atomicOr(&lp.flags[1], 1u);
             else if (L > ListCfg<4, BASE>::CAP) lp.listH[atomicAdd(&lp.flags[5], 1u)] = g;
             else if (L > ListCfg<2, BASE>::CAP) lp.list4[atomicAdd(&lp.flags[4], 1u)] = g;
@@ -532,7 +659,7 @@ __global__ __launch_bounds__(64 * WPL) void k_lists(const ViewDev* __restrict__ 
             const uint32_t g = list[idx];
             const uint32_t vi = gseg_view[g];
             (void)process_list<WPL, BASE>(vi, g - lviews[vi].seg_base, lp.pool0 + blockIdx.x % lp.npools, (L3D_LDS char*)smem, views, pairs,
-                                    lviews, opairs, off64, inv, slots, uniform_K, lp);
+                                          lviews, opairs, ipairs, poff, inv, slots, uniform_K, lp);
             __syncthreads();
         }
     }
@@ -546,41 +673,79 @@ struct HugeScratch {
 };
 __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
                                                     const ListView* __restrict__ lviews,
-                                                    const OutPair* __restrict__ opairs,
+                                                    const OutPair* __restrict__ opairs, const InPair* __restrict__ ipairs,
                                                     const uint32_t* __restrict__ gseg_view,
-                                                    const unsigned long long* __restrict__ off64,
-                                                    const InvRec* __restrict__ inv, const Slot* __restrict__ slots,
+                                                    const uint32_t* __restrict__ poff,
+                                                    const uint32_t* __restrict__ inv, const Slot* __restrict__ slots,
                                                     const ListPools lp, const HugeScratch hs) {
     __shared__ uint32_t red[16];
     __shared__ uint32_t s_base;
+    constexpr uint32_t kRows = 256;                 // incoming pairs staged per round
+    __shared__ uint32_t s_row[4 * kRows];           // [4q] first entry of row q, [4q + 1] its place in the list, [4q + 2] source view, [4q + 3] pair
     const uint32_t t = threadIdx.x;
     const uint32_t nH = lp.flags[5];
     for (uint32_t idx = blockIdx.x; idx < nH; idx += gridDim.x) {
         const uint32_t g = lp.listH[idx];
-        const uint32_t L = (uint32_t)(off64[g + 1] - off64[g]);
+        const uint32_t vi = gseg_view[g];
+        const ListView lv = lviews[vi];
+        const uint32_t seg = g - lv.seg_base;
+        const ViewDev& v = views[vi];
+        // ---- the list's length: inverse records (the segment's rows of the incoming pairs' CSRs) + alive fresh slots ----
+        uint32_t mine_n = 0;
+        for (uint32_t q = t; q < lv.ni; q += 256)
+            mine_n += poff[lv.pbase + (seg + 1) * lv.ni + q] - poff[lv.pbase + seg * lv.ni + q];
+        uint32_t n_inv;
+        (void)group_scan<4>(mine_n, n_inv, red);
+        mine_n = 0;
+        for (uint32_t q = lv.q0; q < lv.q0 + lv.nq; ++q) {
+            const OutPair op = opairs[q];
+            const uint64_t row0 = op.slot_off + (uint64_t)seg * op.K;
+            for (uint32_t j = t; j < op.K; j += 256) {
+                const Slot s = slots[row0 + j];
+                mine_n += (s.tgt_seg != kEmpty && (s.flags & kSlotAlive)) ? 1u : 0u;
+            }
+        }
+        uint32_t n_fresh;
+        (void)group_scan<4>(mine_n, n_fresh, red);
+        const uint32_t L = n_inv + n_fresh;
         __syncthreads();
-        if (t == 0) s_base = atomicAdd(&lp.flags[6], L);
+        if (t == 0) { s_base = atomicAdd(&lp.flags[6], L); atomicAdd(&lp.cnt[(lp.pool0 + blockIdx.x % lp.npools) * 16 + 5], L); }
         __syncthreads();
         const uint32_t base = s_base;
         if ((uint64_t)base + L > hs.cap) { if (t == 0) atomicOr(&lp.flags[2], 1u); continue; }
         float* e_d1 = hs.d1 + base; float* e_d2 = hs.d2 + base;
         uint32_t* e_tv = hs.tv + base; uint32_t* e_ref = hs.ref + base; uint32_t* e_pf = hs.pf + base;
         uint64_t* keys = hs.key + base;
-        const uint32_t vi = gseg_view[g];
-        const ListView lv = lviews[vi];
-        const uint32_t seg = g - lv.seg_base;
-        const ViewDev& v = views[vi];
-        const uint32_t ib = (uint32_t)(off64[g] >> 32), n_inv = (uint32_t)(off64[g + 1] >> 32) - ib;
-        for (uint32_t x = t; x < n_inv; x += 256) keys[x] = inv[ib + x].ref;
-        __threadfence_block();
-        __syncthreads();
-        for (uint32_t x = t; x < n_inv; x += 256) {
-            const InvRec r = inv[ib + x];
-            uint32_t rank = 0;
-            for (uint32_t y = 0; y < n_inv; ++y) rank += (keys[y] < (uint64_t)r.ref) ? 1u : 0u;
-            e_d1[rank] = r.dq1; e_d2[rank] = r.dq2; e_tv[rank] = pairs[r.pair].src; e_ref[rank] = r.ref; e_pf[rank] = r.pair | kHypInv;
+        // ---- inverse records in canonical order: incoming pairs ascending, a pair's row as k_pair_csr left it ----
+        uint32_t pos = 0;
+        for (uint32_t qb = 0; qb < lv.ni; qb += kRows) {
+            const uint32_t q = qb + t, nq_here = min(kRows, lv.ni - qb);
+            uint32_t c = 0, a = 0;
+            if (q < lv.ni) {
+                const uint32_t e0 = poff[lv.pbase + seg * lv.ni + q], e1 = poff[lv.pbase + (seg + 1) * lv.ni + q];
+                const InPair ip = ipairs[lv.i0 + q];
+                a = ip.rec_base + e0; c = e1 - e0;
+                s_row[4 * t + 2] = ip.src; s_row[4 * t + 3] = ip.pair;
+            }
+            uint32_t total;
+            const uint32_t ex = group_scan<4>(c, total, red);
+            if (q < lv.ni) { s_row[4 * t] = a; s_row[4 * t + 1] = ex; }
+            __syncthreads();
+            for (uint32_t x = t; x < total; x += 256) {
+                uint32_t lo = 0, hi = nq_here;                      // last row whose prefix is <= x
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (s_row[4 * mid + 1] <= x) lo = mid; else hi = mid; }
+                const uint32_t* rowp = inv + s_row[4 * lo];
+                const uint32_t r0 = s_row[4 * lo + 1], r1 = lo + 1 < nq_here ? s_row[4 * lo + 5] : total;
+                const uint32_t ref = rowp[x - r0];
+                uint32_t rank = r0;                                 // ascending slot index inside the row (k_pair_csr leaves a row unordered)
+                for (uint32_t y = 0; y < r1 - r0; ++y) rank += rowp[y] < ref ? 1u : 0u;
+                const float2 dq = *(const float2*)&slots[ref].dq1;
+                const uint32_t at = pos + rank;
+                e_d1[at] = dq.x; e_d2[at] = dq.y; e_tv[at] = s_row[4 * lo + 2]; e_ref[at] = ref; e_pf[at] = s_row[4 * lo + 3] | kHypInv;
+            }
+            pos += total;
+            __syncthreads();
         }
-        uint32_t pos = n_inv;
         for (uint32_t q = lv.q0; q < lv.q0 + lv.nq; ++q) {
             const OutPair op = opairs[q];
             const uint64_t row0 = op.slot_off + (uint64_t)seg * op.K;
@@ -596,7 +761,7 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
         }
         __threadfence_block();
         __syncthreads();
-        if (pos != L) { if (t == 0) atomicOr(&lp.flags[3], 1u); continue; }
+        if (pos != L) { if (t == 0) atomicOr(&lp.flags[3], 1u); continue; }   // (the two passes over the same data disagree: internal error)
         auto for_candidates = [&](uint32_t i, auto&& emit) {
             const float a1 = e_d1[i], a2 = e_d2[i];
             const uint32_t tvi = e_tv[i];
@@ -649,7 +814,10 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
 // candidate (one per lane, full lanes: this is where the fp64 unprojections, acos and exp live), then the accepted
 // ones as EDGES in (i, j) order with one HEADER per hypothesis i that has any.  The candidates arrive grouped by i
 // in canonical order (one contiguous run per i, j in walk order), so the order only has to be fixed inside a run.
-__global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+#ifndef L3D_EDGES_WAVES
+#define L3D_EDGES_WAVES 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L3D_EDGES_WAVES))) void k_edges(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
                                                const uint32_t* __restrict__ gseg_view, const Slot* __restrict__ slots,
                                                const SimConst sc, const ListPools lp, uint32_t* __restrict__ seg_of_g) {
     const uint32_t pool = lp.pool0 + blockIdx.y, wave = 0, lane = lane_id();   // one segment per workgroup (as k_lists)
@@ -831,7 +999,7 @@ constexpr uint32_t kMaxReplicas = 16;   // the view maxima are kept in 16 replic
 // replace/subtract accumulation (line3D.cc:1255-1274); the view's maximum for filterMatches
 __global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ positive,
                              const uint32_t* __restrict__ gseg_view, Slot* __restrict__ slots,
-                             uint32_t* __restrict__ max_score_bits) {
+                             const uint8_t* __restrict__ pair_present, uint32_t* __restrict__ max_score_bits) {
     const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = !(lp.flags[0] | lp.flags[2]) && k < min(lp.cnt[pool * 16 + 1], lp.hcap);
     float score3D = 0.0f;
@@ -854,7 +1022,10 @@ __global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ pos
             }
         h.score3D = score3D;
         h.state = exists ? kHypExists : 0u;
-        if (exists && !inv) slots[h.ref].score3D = score3D;
+        // (the slot's own copy of the score, for l3d_get_pair_slots.  A rank of a multi-GPU run holds the slots of the
+        // pairs that touch its views only: the headers of all ranks are here, the slot regions of the other pairs are not
+        // valid memory contents and are left alone -- pair_present, null on one GPU)
+        if (exists && !inv && (!pair_present || pair_present[h.pair_flags & 0x7FFFFFFFu])) slots[h.ref].score3D = score3D;
         view = gseg_view[h.g];
     }
     // the view's maximum: neighbouring headers mostly belong to one view -- one atomic per (wave, view), and none
@@ -972,15 +1143,21 @@ __global__ void k_seg_write(uint32_t G, const ViewDev* __restrict__ views, const
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------------
-hipError_t launch_inv_records(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
-                              const Slot* slots, const unsigned long long* off64, const uint32_t* inv_pos, InvRec* recs,
-                              uint32_t tgt_v0, uint32_t tgt_v1, hipStream_t st) {
-    if (!n_pairs || !max_slots) return hipSuccess;
-    for (uint32_t p0 = 0; p0 < n_pairs; p0 += 65535u) {
-        const uint32_t n = n_pairs - p0 < 65535u ? n_pairs - p0 : 65535u;
-        hipLaunchKernelGGL(k_inv_records, dim3((uint32_t)((max_slots + 255) / 256), n), dim3(256), 0, st, pairs, p0,
-                           seg_base, slots, off64, inv_pos, recs, tgt_v0, tgt_v1);
-    }
+hipError_t launch_pair_csr(const PairDesc* pairs, uint32_t n_pairs, uint32_t max_Mt, const PairCsr* pair_poff,
+                           const uint32_t* inv_tgt, uint32_t* poff, uint32_t* refs, uint32_t* dummy,
+                           uint32_t tgt_v0, uint32_t tgt_v1, hipStream_t st) {
+    if (!n_pairs) return hipSuccess;
+    // (L3D_CSR_GLOBAL=1, test hook: every pair takes the global-memory form that views beyond the LDS capacity need)
+    static const bool force_global = std::getenv("L3D_CSR_GLOBAL") != nullptr;
+    const uint32_t lds_segs = force_global ? 0u : kCsrLdsSegs;
+    const size_t lds = ((size_t)std::min(max_Mt, lds_segs) + 64) * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)k_pair_csr<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_pair_csr<true>, dim3(n_pairs), dim3(kCsrBlock), lds, st, pairs, 0u, pair_poff, inv_tgt,
+                       poff, refs, dummy, tgt_v0, tgt_v1, lds_segs);
+    if (max_Mt > lds_segs)   // views beyond the LDS capacity: cursors in global memory (dummy: 64 words per pair)
+        hipLaunchKernelGGL(k_pair_csr<false>, dim3(n_pairs), dim3(kCsrBlock), 0, st, pairs, 0u, pair_poff, inv_tgt,
+                           poff, refs, dummy, tgt_v0, tgt_v1, lds_segs);
     return hipGetLastError();
 }
 
@@ -1015,8 +1192,8 @@ hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, uint32
 }
 
 hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev* views, const PairDesc* pairs,
-                        const ListView* lviews, const OutPair* opairs, const uint32_t* gseg_view,
-                        const unsigned long long* off64, const InvRec* inv, const Slot* slots, uint32_t uniform_K,
+                        const ListView* lviews, const OutPair* opairs, const InPair* ipairs, const uint32_t* gseg_view,
+                        const uint32_t* poff, const uint32_t* inv, const Slot* slots, uint32_t uniform_K,
                         SimConst sc, ListPools lp, uint32_t* seg_of_g, HugeScratchArgs hsa, hipStream_t st) {
     if (!nv || !max_M) return hipSuccess;
     // the one-wave tier stages 128 hypotheses (8 waves per SIMD) unless the scene's lists are long on average
@@ -1032,14 +1209,14 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
         if (e != hipSuccess) return e;                                                                                     \
         for (uint32_t a = 0; a < nv; a += 65535u) { /* grid.y limit */                                                     \
             const uint32_t n = nv - a < 65535u ? nv - a : 65535u;                                                          \
-            hipLaunchKernelGGL((k_lists<1, B>), dim3(max_M, n), dim3(64), lds1, st, views, pairs, lviews, opairs,          \
-                               gseg_view, off64, inv, slots, uniform_K, lp, v0 + a);                                       \
+            hipLaunchKernelGGL((k_lists<1, B>), dim3(max_M, n), dim3(64), lds1, st, views, pairs, lviews, opairs, ipairs,  \
+                               gseg_view, poff, inv, slots, uniform_K, lp, v0 + a);                                        \
         }                                                                                                                  \
         /* lists beyond one wave's capacity: two waves up to 2x, four up to 4x (fixed grids over the hand-over lists) */   \
-        hipLaunchKernelGGL((k_lists<2, B>), dim3(16384), dim3(128), lds2, st, views, pairs, lviews, opairs, gseg_view,     \
-                           off64, inv, slots, uniform_K, lp, 0u);                                                          \
-        hipLaunchKernelGGL((k_lists<4, B>), dim3(2048), dim3(256), lds4, st, views, pairs, lviews, opairs, gseg_view,      \
-                           off64, inv, slots, uniform_K, lp, 0u);                                                          \
+        hipLaunchKernelGGL((k_lists<2, B>), dim3(16384), dim3(128), lds2, st, views, pairs, lviews, opairs, ipairs,        \
+                           gseg_view, poff, inv, slots, uniform_K, lp, 0u);                                                \
+        hipLaunchKernelGGL((k_lists<4, B>), dim3(2048), dim3(256), lds4, st, views, pairs, lviews, opairs, ipairs,         \
+                           gseg_view, poff, inv, slots, uniform_K, lp, 0u);                                                \
     } while (0)
     if (wide) L3D_LISTS(256); else L3D_LISTS(128);
 #undef L3D_LISTS
@@ -1050,8 +1227,8 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
     // lists beyond the four-wave tier: rare; when the previous pass over the same kind of scene handed none over the
     // launch is left out (a pass that then does hand one over is repeated with it: flags[5], l3d_api.hip check_pass)
     if (hsa.run_huge)
-        hipLaunchKernelGGL(k_lists_huge, dim3(256), dim3(256), 0, st, views, pairs, lviews, opairs, gseg_view, off64, inv,
-                           slots, lp, hs);
+        hipLaunchKernelGGL(k_lists_huge, dim3(256), dim3(256), 0, st, views, pairs, lviews, opairs, ipairs, gseg_view, poff,
+                           inv, slots, lp, hs);
     hipLaunchKernelGGL(k_edges, dim3(lp.scap, lp.npools), dim3(64), 0, st, views, pairs, gseg_view, slots, sc, lp,
                        seg_of_g);
     if (lp.npools < kListPools) hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, st, lp);   // sharded pass
@@ -1065,8 +1242,8 @@ hipError_t launch_chain_sweep(ListPools lp, uint8_t* positive, uint32_t* changed
     return hipGetLastError();
 }
 hipError_t launch_hyp_scores(ListPools lp, const uint8_t* positive, const uint32_t* gseg_view, Slot* slots,
-                             uint32_t* max_score_bits, hipStream_t st) {
-    hipLaunchKernelGGL(k_hyp_scores, hyp_grid(lp), dim3(256), 0, st, lp, positive, gseg_view, slots, max_score_bits);
+                             const uint8_t* pair_present, uint32_t* max_score_bits, hipStream_t st) {
+    hipLaunchKernelGGL(k_hyp_scores, hyp_grid(lp), dim3(256), 0, st, lp, positive, gseg_view, slots, pair_present, max_score_bits);
     return hipGetLastError();
 }
 hipError_t launch_hyp_filter(ListPools lp, uint32_t G, const uint32_t* gseg_view, const uint32_t* max_score_bits,

@@ -56,7 +56,7 @@ constexpr int kRing2 = 128;         // second ring (bounded kNN): candidates tha
 #define L3D_BALLOT(p) __builtin_amdgcn_ballot_w64(p)
 // diagnostics builds only (-DL3D_STATS: candidate counters, slow; -DL3D_CYCLES: per-work-item timeline)
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
-__device__ unsigned long long g_stats[12];   // 0 pre-filter tests, 1 candidates, 2 passed overlap, 3 accepted, 4 drains,
+__device__ unsigned long long g_stats[16];   // 0 pre-filter tests, 1 candidates, 2 passed overlap, 3 accepted, 4 drains,
                                             // 5 (row, target) pairs whose OWN bands intersect (what a per-row walk would
                                             // test), 6 slots kept, 7 work items, 8 stage-1 drains (depth decision), 9 candidates
                                             // that passed it (1 = candidates into stage 1, 4 = stage-2 drains (exact overlap))
@@ -70,6 +70,7 @@ __device__ unsigned long long g_cycles[1 << 16][8];   // per work item (its firs
 #define L3D_STAT(i, n) ((void)0)
 #endif
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 // IX16: target indices, row counts and slot positions fit 16 bits (every Mt and K below 65536 -- always true when
 // the pair is culled, kCullMaxSegs = 16384): 6.5 KiB of LDS per wave at K = 10 instead of 8 KiB, i.e. 24 resident
 // waves per CU (6 per SIMD) instead of 20
@@ -89,6 +90,10 @@ struct Lds {
     L3D_LDS volatile idx_t* top_ix;    // [kBlock*K]
     static constexpr idx_t kTie = (idx_t)((idx_t)1 << (8 * sizeof(idx_t) - 1));
 };
+
+// keep-all fill pass (MODE 2): staging area of the row sort behind the (table-less) carve: ring + four 64-entry arrays
+constexpr uint32_t kKeepSortCap = 512;
+__host__ __device__ constexpr uint32_t keep_sort_offset() { return (uint32_t)kRing * 4u + 4u * kBlock * 4u; }
 
 template <bool IX16>
 __device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K, uint32_t waves, bool two_rings) {
@@ -135,27 +140,18 @@ __device__ __forceinline__ bool prefilter(float e1x, float e1y, float e1z, float
 #endif
 }
 
-// an inverse-alive slot takes its position among the inverse refs of its target segment (global id g_tgt) from the
-// packed counter (low word: list length, high word: inverse refs), exactly as k_orient_all does
-__device__ __forceinline__ uint32_t take_inverse_position(const OrientFuse& of, uint32_t g_tgt) {
-    const unsigned long long old = atomicAdd(&of.cnt_pack[g_tgt], (1ull << 32) | 1ull);
-    return (uint32_t)(old >> 32);
-}
-
 // checkMatchOrientation (line3D.cc:811-858) of one freshly computed slot, in its source frame and -- for a pair that
 // hands inverse matches to its target (tgt processed later, :1680) -- in the target frame.  Returns the slot flags.
 __device__ __forceinline__ uint32_t fuse_orientation(const OrientFuse& of, const double* Cs, const double* Ct,
                                                      const SegX& sx, const SegX& tx, const PairResult& res,
-                                                     bool hands_inverse, uint32_t g_tgt, uint32_t& ipos) {
-    ipos = kEmpty;
+                                                     bool hands_inverse) {
     if (!orientation_ok_fast(Cs, sx, res.dp1, res.dp2, of.thr)) return 0u;
     uint32_t flags = kSlotAlive;
-    if (hands_inverse && orientation_ok_fast(Ct, tx, res.dq1, res.dq2, of.thr)) {
-        flags |= kSlotInvAlive;
-        ipos = take_inverse_position(of, g_tgt);
-    }
+    if (hands_inverse && orientation_ok_fast(Ct, tx, res.dq1, res.dq2, of.thr)) flags |= kSlotInvAlive;
     return flags;
 }
+// the 4-byte stream k_pair_csr sorts: target segment of a slot that hands an inverse match over, kEmpty otherwise
+__device__ __forceinline__ uint32_t inverse_target(const Slot& o) { return (o.flags & kSlotInvAlive) ? o.tgt_seg : kEmpty; }
 
 }  // namespace
 
@@ -217,8 +213,9 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     constexpr idx_t kTie = Lds<IX16>::kTie;
     L3D_LDS volatile uint32_t* ring = L.ring + q * kRingN;
     L3D_LDS volatile uint32_t* ring2 = L.ring2 + q * kRing2;
-    // epipolar-band culling (kNN mode only: the keep-all rows must be filled in ascending target order)
-    const PairCull* pc = (MODE == 0 && !BRUTE && cp.cull && cp.cull[wi.pair].enabled) ? &cp.cull[wi.pair] : nullptr;
+    // epipolar-band culling (round 4: in the keep-all mode as well -- its rows must come out in ascending target order,
+    // which the culled walk does not deliver: the fill pass sorts every row it has filled, epilogue below)
+    const PairCull* pc = (!BRUTE && cp.cull && cp.cull[wi.pair].enabled) ? &cp.cull[wi.pair] : nullptr;
     const bool cull = pc != nullptr;
     const bool active = wi.src0 + tid < Ms;
     uint32_t src = wi.src0 + tid;
@@ -310,9 +307,13 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     // original index)
     const bool sorted = cull && pc->sorted_copy != 0;
     const float4* __restrict__ ts4 = sorted ? cp.tgt_s4 + pc->t_off : vt.seg4;
-    const char* __restrict__ tsd = sorted ? (const char*)(cp.tgt_sd + pc->t_off) : (const char*)vt.segx;
-    const uint32_t tsd_stride = sorted ? (uint32_t)sizeof(SegD) : (uint32_t)sizeof(SegX);
+    const SegD32* __restrict__ tsd = sorted ? cp.tgt_sd + pc->t_off : vt.segd32;
     auto target_index = [&](uint32_t tp) -> uint32_t { return (cull && !sorted) ? tperm[tp] : tp; };
+    // (round 4: stage 1 decides in FLOAT on 48-byte records -- depths_positive32, l3d_dev.h: the decision is a matter of
+    // signs once the six dot products are clear of zero, which they are for all but a few candidates in a million;
+    // those go through the double-precision decision of round 3 on the spot.  Halves the gathered bytes of the stage
+    // and replaces ~60 fp64 instructions by ~35 fp32 ones at half the issue cost.)
+    const float Bx = pd.B[0], By = pd.B[1], Bz = pd.B[2], tolB = pd.tolB;
     auto stage1 = [&]() {
         const uint32_t n = min(64u, tail - head);
         const bool has = lane < n;
@@ -322,16 +323,21 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t sl = ent >> 23, tp = ent & 0x7FFFFFu;
         const uint32_t sg = __shfl(src, sl);   // the ring of a wave only holds rows of that wave
         bool pass = false;
-        // (A/B -DL3D_LAUNDER: the camera centres and, in stage 2, F fetched per drain through laundered pointers, in
-        // wave-uniform control flow so that they stay scalar loads: hoisted out of the walk they occupy 42 SGPRs there)
-        const ViewDev* pvs = &vs; const ViewDev* pvt = &vt;
-#if defined(L3D_LAUNDER) || defined(L3D_LAUNDER_C)
-        asm volatile("" : "+s"(pvs), "+s"(pvt));
-#endif
         if (has) {
-            const SegD& sd = *(const SegD*)&vs.segx[sg];                       // a SegX starts with its SegD
-            const SegD& td = *(const SegD*)(tsd + (size_t)target_index(tp) * tsd_stride);
-            pass = depths_positive(sd, td, pvs->C, pvt->C);
+            const SegD32 sd = vs.segd32[sg];
+            const SegD32 td = tsd[target_index(tp)];
+            const float B[3] = {Bx, By, Bz};
+            bool certain;
+            pass = depths_positive32(sd, td, B, tolB, certain);
+            if (!certain) {   // the sliver: the double-precision decision on the full records (by original target index)
+                const uint32_t to = cull ? tperm[tp] : tp;
+                // (the camera centres are fetched HERE, through laundered pointers: hoisted out of the walk they occupied
+                // 12 scalar registers of a loop that spills them -- this branch runs for a few candidates in a million)
+                const ViewDev* pvs = &vs; const ViewDev* pvt = &vt;
+                asm volatile("" : "+r"(pvs), "+r"(pvt));
+                pass = depths_positive(*(const SegD*)&pvs->segx[sg], *(const SegD*)&pvt->segx[to], pvs->C, pvt->C);
+                L3D_STAT(12, 1);                                // candidates decided in double (the float certificate failed)
+            }
         }
         const uint64_t m = L3D_BALLOT(pass);
         if (pass) ring2[(tail2 + prefix(m)) & (kRing2 - 1)] = ent;
@@ -670,17 +676,63 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
 
     // ---- epilogue ----
     if (MODE != 0) {
-        if (!active) return;
-        const uint32_t c = L.cnt[tid];
+        const uint32_t c = active ? (uint32_t)L.cnt[tid] : 0u;
         if (MODE == 1) {
-            row_counts[pd.row_off + src] = c;
+            if (active) row_counts[pd.row_off + src] = c;
             return;
         }
-        Slot* row = slots + pd.slot_off + (uint64_t)src * K;
-        Slot empty;
-        empty.tgt_seg = kEmpty; empty.overlap = 0; empty.dp1 = empty.dp2 = empty.dq1 = empty.dq2 = 0;
-        empty.score3D = 0; empty.flags = 0;
-        for (uint32_t j = min(c, K); j < K; ++j) row[j] = empty;
+        if (active) {
+            Slot* row = slots + pd.slot_off + (uint64_t)src * K;
+            Slot empty;
+            empty.tgt_seg = kEmpty; empty.overlap = 0; empty.dp1 = empty.dp2 = empty.dq1 = empty.dq2 = 0;
+            empty.score3D = 0; empty.flags = 0;
+            for (uint32_t j = min(c, K); j < K; ++j) row[j] = empty;
+        }
+        if (!cull) return;     // streamed unculled: a row's matches arrived in ascending target order (drain, lowest lane first)
+        // Culled walk (round 4): the matches of a row arrived in walk order; Line3D::matchingCPU pushes them in ascending
+        // target index (line3D.cc:987-992).  The wave sorts one row after the other: the row is staged in LDS (up to
+        // kKeepSortCap entries: 16 KiB), every entry counts the row's smaller targets and goes to that place.  A longer
+        // row is sorted in place by one lane (insertion sort: correct for any length, slow, practically never taken).
+        L3D_LDS uint32_t* stage = (L3D_LDS uint32_t*)(smem + keep_sort_offset());
+        const uint32_t n_rows = min((uint32_t)kBlock, Ms - wi.src0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // the rows were written by other lanes of this wave
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (uint32_t r = 0; r < n_rows; ++r) {
+            const uint32_t cr = min((uint32_t)__builtin_amdgcn_readlane(c, r), K);
+            if (cr < 2) continue;
+            Slot* row = slots + pd.slot_off + (uint64_t)__builtin_amdgcn_readlane(src, r) * K;
+            if (cr <= kKeepSortCap) {
+                for (uint32_t j = lane; j < cr; j += 64) {
+                    const v4u* p = (const v4u*)&row[j];
+                    const v4u a = p[0], b = p[1];
+                    L3D_LDS v4u* q = (L3D_LDS v4u*)(stage + 8 * j);
+                    q[0] = a; q[1] = b;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                for (uint32_t j = lane; j < cr; j += 64) {
+                    const uint32_t tgt = stage[8 * j];
+                    uint32_t rank = 0;
+                    for (uint32_t i = 0; i < cr; ++i) rank += stage[8 * i] < tgt ? 1u : 0u;   // (targets of a row are distinct)
+                    L3D_LDS const v4u* q = (L3D_LDS const v4u*)(stage + 8 * j);
+                    const v4u a = q[0], b = q[1];
+                    v4u* p = (v4u*)&row[rank];
+                    p[0] = a; p[1] = b;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            } else if (lane == 0) {
+                for (uint32_t x = 1; x < cr; ++x) {
+                    const Slot v = row[x];
+                    uint32_t y = x;
+                    while (y > 0 && row[y - 1].tgt_seg > v.tgt_seg) { row[y] = row[y - 1]; --y; }
+                    row[y] = v;
+                }
+            }
+        }
         return;
     }
     // MODE 0.  The wave writes its rows TOGETHER: item = (row, entry), one item per lane and pass, so that the K
@@ -706,9 +758,17 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     const uint32_t n_rows = min((uint32_t)kBlock, Ms - wi.src0);
-    const uint32_t gs = (uint32_t)(vs.segx - views[0].segx), gt = (uint32_t)(vt.segx - views[0].segx);
     const bool hands_inverse = pd.tgt > pd.src;   // inverse copy only towards a view processed later (:1680)
     const uint32_t n_items = n_rows * K;
+#ifndef L3D_NO_LAUNDER_EPILOGUE
+    // (the camera centres and the orientation thresholds are needed from here on only -- since round 4 the depth decision
+    // of stage 1 runs on floats and the baseline --: fetched through laundered pointers, so that they do not occupy 16
+    // scalar registers of the walk, whose loop spills scalars into vector lanes and reloads them every step)
+    const ViewDev* evs = &vs; const ViewDev* evt = &vt;
+    asm volatile("" : "+s"(evs), "+s"(evt));
+#else
+    const ViewDev* evs = &vs; const ViewDev* evt = &vt;
+#endif
     for (uint32_t base0 = 0; base0 < n_items; base0 += 64 * WPG) {
         const uint32_t base = base0 + q * 64;           // first item of this wave in this pass
         const uint32_t it = base + lane;
@@ -724,7 +784,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t c = (in && !tied) ? (uint32_t)L.cnt[r] : 0u;
         Slot o;
         o.tgt_seg = kEmpty; o.overlap = 0; o.dp1 = o.dp2 = o.dq1 = o.dq2 = 0; o.score3D = 0.0f; o.flags = 0;
-        uint32_t ipos = kEmpty, dst = j;
+        uint32_t dst = j;
         if (j < c) {
             L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)r * K;
             L3D_LDS const idx_t* ix = (L3D_LDS const idx_t*)L.top_ix + (size_t)r * K;
@@ -738,42 +798,30 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             // Three short stages that each fetch only the invariants they use (depths: rays + plane; orientation:
             // rays + mid ray).  The pointers are laundered between the stages so that the compiler does not keep both
             // 104-byte records live across them: that would cost the kernel a wave of occupancy for its epilogue.
-            const SegX* psx = vs.segx + rsrc;
-            const SegX* ptx = vt.segx + xj;
+            const SegX* psx = evs->segx + rsrc;
+            const SegX* ptx = evt->segx + xj;
             asm volatile("" : "+v"(psx), "+v"(ptx));
             PairResult res{};
-            exact_depths(*psx, *ptx, vs.C, vt.C, res, fastm);
+            exact_depths(*psx, *ptx, evs->C, evt->C, res, fastm);
             o.tgt_seg = xj; o.overlap = oj;
             o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
             asm volatile("" : "+v"(psx));
-            if (orientation_ok_fast(vs.C, *psx, res.dp1, res.dp2, of.thr)) {
+            if (orientation_ok_fast(evs->C, *psx, res.dp1, res.dp2, of.thr)) {
                 o.flags = kSlotAlive;
                 asm volatile("" : "+v"(ptx));
-                if (hands_inverse && orientation_ok_fast(vt.C, *ptx, res.dq1, res.dq2, of.thr)) {
-                    o.flags |= kSlotInvAlive;
-                    ipos = take_inverse_position(of, gt + xj);
-                }
+                if (hands_inverse && orientation_ok_fast(evt->C, *ptx, res.dq1, res.dq2, of.thr)) o.flags |= kSlotInvAlive;
             }
         }
+        // (round 4: nothing else leaves the epilogue -- no counters, no positions: the inverse hypotheses are sorted by
+        // target segment per pair afterwards (k_pair_csr) and the list pass counts its own fresh hypotheses)
         if (in && !tied) {
             const uint64_t at = pd.slot_off + (uint64_t)rsrc * K + dst;
             slots[at] = o;
-            of.inv_pos[at] = ipos;
+            of.inv_tgt[at] = inverse_target(o);
         }
 #ifdef L3D_STATS
         { const uint32_t nk = (uint32_t)__popcll(L3D_BALLOT(j < c)); if (lane == 0 && nk) L3D_STAT(6, nk); }
 #endif
-        // fresh alive hypotheses of the row: its items are neighbouring lanes, one counter update per (row, pass)
-        const uint64_t m = L3D_BALLOT((o.flags & kSlotAlive) != 0);
-        const uint32_t r0 = r * K;
-        const uint32_t lo = (r0 > base ? r0 : base) - base;
-        const uint32_t he = r0 + K < base + 64 ? r0 + K : base + 64;
-        const uint32_t hi = he - base;   // exclusive, <= 64
-        if (in && lane == lo) {
-            const uint64_t seg_mask = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-            const uint32_t n_alive = (uint32_t)__popcll(m & seg_mask);
-            if (n_alive) atomicAdd(&of.cnt_pack[gs + rsrc], (unsigned long long)n_alive);
-        }
     }
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
     if (threadIdx.x == 0 && w < (1u << 16)) {
@@ -797,6 +845,7 @@ bool match_staged(int mode, bool brute) {
 size_t match_lds_bytes(int mode, uint32_t K, bool ix16, uint32_t waves, bool brute) {
     const size_t ib = ix16 ? 2 : 4;
     const bool staged = match_staged(mode, brute);
+    if (mode == 2) return keep_sort_offset() + (size_t)kKeepSortCap * 32;   // (one wave, 32-bit indices: carve + row staging)
     return (size_t)waves * (ring_entries(staged, waves) + (staged ? kRing2 : 0)) * 4 + 2 * kBlock * 4 + 2 * kBlock * ib +
            (mode == 0 ? (size_t)kBlock * K * (4 + ib) : 0);
 }
@@ -817,7 +866,7 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
                               uint32_t* row_counts, float thr, CullPools pools, OrientFuse of, bool ix16,
                               hipStream_t stream) {
     if (nwork == 0) return hipSuccess;
-    if (mode == 0 && (!of.cnt_pack || !of.inv_pos || !of.tie_count || !of.tie_list)) return hipErrorInvalidValue;   // MODE 0 always fuses
+    if (mode == 0 && (!of.inv_tgt || !of.tie_count || !of.tie_list)) return hipErrorInvalidValue;   // MODE 0 always fuses
     const uint32_t grid = ((nwork + 7) / 8) * 8;
     if (!(mode == 0 && !brute)) ix16 = false;       // the compact layout is only instantiated for the hot variant
     const uint32_t wpg = match_waves_per_group(mode, brute, nwork);
@@ -864,10 +913,10 @@ __global__ __launch_bounds__(256) void k_expand_slot_idx(const ViewDev* __restri
     if (blockIdx.x * blockDim.x >= n) return;   // whole block past the end
     const uint32_t K = pd.K, row = s / K;
     const uint64_t at = pd.slot_off + s;
-    const uint32_t tg = s < n ? idx[at] : kEmpty;
+    if (s >= n) return;
+    const uint32_t tg = idx[at];
     Slot o;
     o.tgt_seg = tg; o.overlap = 0; o.dp1 = o.dp2 = o.dq1 = o.dq2 = 0; o.score3D = 0.0f; o.flags = 0;
-    uint32_t ipos = kEmpty;
     if (tg != kEmpty && tg < pd.Mt) {
         const ViewDev& vs = views[pd.src];
         const ViewDev& vt = views[pd.tgt];
@@ -880,25 +929,11 @@ __global__ __launch_bounds__(256) void k_expand_slot_idx(const ViewDev* __restri
         const SegX sx = vs.segx[row], tx = vt.segx[tg];
         exact_depths(sx, tx, vs.C, vt.C, res);
         o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
-        o.flags = fuse_orientation(of, vs.C, vt.C, sx, tx, res, pd.tgt > pd.src,
-                                   (uint32_t)(vt.segx - views[0].segx) + tg, ipos);
+        o.flags = fuse_orientation(of, vs.C, vt.C, sx, tx, res, pd.tgt > pd.src);
     } else {
         o.tgt_seg = kEmpty;
     }
-    const bool alive = (o.flags & kSlotAlive) != 0;
-    if (s < n) { slots[at] = o; of.inv_pos[at] = ipos; }
-    // the K slots of a source row are neighbouring lanes: one counter update per (row, wave), as in k_orient_all
-    const uint64_t m = __ballot(alive);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t base = s - lane, r0 = row * K;
-    const uint32_t lo = (r0 > base ? r0 : base) - base;
-    const uint32_t he = r0 + K < base + 64 ? r0 + K : base + 64;
-    const uint32_t hi = he - base;   // exclusive, <= 64
-    if (lane == lo && s < n) {
-        const uint64_t seg_mask = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-        const uint32_t cnt = (uint32_t)__popcll(m & seg_mask);
-        if (cnt) atomicAdd(&of.cnt_pack[(uint32_t)(views[pd.src].segx - views[0].segx) + row], (unsigned long long)cnt);
-    }
+    if (s < n) { slots[at] = o; of.inv_tgt[at] = inverse_target(o); }
 }
 
 hipError_t launch_pack_slot_idx(const Slot* slots, uint32_t* idx, uint64_t lo, uint64_t hi, hipStream_t stream) {
@@ -913,7 +948,7 @@ hipError_t launch_expand_slot_idx(const ViewDev* views, const PairDesc* pairs, u
                                   uint32_t max_row_slots, const uint32_t* idx, Slot* slots, OrientFuse of,
                                   hipStream_t stream) {
     if (!max_row_slots) return hipSuccess;
-    if (!of.cnt_pack || !of.inv_pos) return hipErrorInvalidValue;
+    if (!of.inv_tgt) return hipErrorInvalidValue;
     for (uint32_t p0 = 0; p0 < count; p0 += 65535u) {
         const uint32_t n = count - p0 < 65535u ? count - p0 : 65535u;
         hipLaunchKernelGGL(k_expand_slot_idx, dim3((max_row_slots + 255) / 256, n), dim3(256), 0, stream, views, pairs,
@@ -1245,9 +1280,16 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
     // either because every row band is unbounded)
     if (tid == 0) { span[0] = 0xFFFFFFFFu; span[1] = 0u; }
     __syncthreads();
-    for (uint32_t i = tid; i < Ms; i += kCullBlock) {
-        const Band b = src_band(pc, vs.seg4[i]);
-        if (b.cls) { atomicMin(&span[0], f2ord(b.lo)); atomicMax(&span[1], f2ord(b.hi)); }
+    {   // (one LDS atomic per wave: two per segment on the same two addresses serialised the whole pass -- a third of
+        // the kernel's time on C1)
+        uint32_t lo_o = 0xFFFFFFFFu, hi_o = 0u;
+        for (uint32_t i = tid; i < Ms; i += kCullBlock) {
+            const Band b = src_band(pc, vs.seg4[i]);
+            if (b.cls) { lo_o = min(lo_o, f2ord(b.lo)); hi_o = max(hi_o, f2ord(b.hi)); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo_o = min(lo_o, (uint32_t)__shfl_xor(lo_o, o)); hi_o = max(hi_o, (uint32_t)__shfl_xor(hi_o, o)); }
+        if ((tid & 63u) == 0) { atomicMin(&span[0], lo_o); atomicMax(&span[1], hi_o); }
     }
     __syncthreads();
     const float slo = ord2f(span[0]), shi = ord2f(span[1]);
@@ -1265,18 +1307,26 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
     }
     __syncthreads();
     cull_sort<KMAX>(keys, n2, !big);
-    for (uint32_t i = tid; i < Mt; i += kCullBlock) {
-        const uint32_t seg = (uint32_t)(keys[i] & 0xFFFFFFu);
-        const Band b = tgt_band(pc, vt.seg4[seg], slo, shi);
-        cp.tgt_perm[pc.t_off + i] = seg;
-        cp.tgt_sf[pc.t_off + i] = *(const float4*)&vt.segf[seg];
-        if (pc.sorted_copy) {
-            cp.tgt_s4[pc.t_off + i] = vt.seg4[seg];
-            cp.tgt_sd[pc.t_off + i] = *(const SegD*)&vt.segx[seg];
+    // (i = tid + k * 512: the 64 lanes of a wave hold exactly one 64-target chunk, so its band is a wave reduction and
+    // one plain store -- 128 LDS atomics per chunk on two addresses before)
+    for (uint32_t i0 = 0; i0 < Mt; i0 += kCullBlock) {
+        const uint32_t i = i0 + tid;
+        uint32_t lo_o = 0xFFFFFFFFu, hi_o = 0u;
+        if (i < Mt) {
+            const uint32_t seg = (uint32_t)(keys[i] & 0xFFFFFFu);
+            const Band b = tgt_band(pc, vt.seg4[seg], slo, shi);
+            cp.tgt_perm[pc.t_off + i] = seg;
+            cp.tgt_sf[pc.t_off + i] = *(const float4*)&vt.segf[seg];
+            if (pc.sorted_copy) {
+                cp.tgt_s4[pc.t_off + i] = vt.seg4[seg];
+                cp.tgt_sd[pc.t_off + i] = vt.segd32[seg];
+            }
+            cp.tgt_band[pc.t_off + i] = make_float2(b.lo, b.hi);
+            lo_o = f2ord(b.lo); hi_o = f2ord(b.hi);
         }
-        cp.tgt_band[pc.t_off + i] = make_float2(b.lo, b.hi);
-        atomicMin(&cb[2 * (i >> 6)], f2ord(b.lo));
-        atomicMax(&cb[2 * (i >> 6) + 1], f2ord(b.hi));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo_o = min(lo_o, (uint32_t)__shfl_xor(lo_o, o)); hi_o = max(hi_o, (uint32_t)__shfl_xor(hi_o, o)); }
+        if ((tid & 63u) == 0 && i < Mt) { cb[2 * (i >> 6)] = lo_o; cb[2 * (i >> 6) + 1] = hi_o; }
     }
     __syncthreads();
     for (uint32_t i = tid; i < nchunk; i += kCullBlock)
@@ -1355,7 +1405,7 @@ __global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __
     __shared__ uint32_t s_n;
     __shared__ uint32_t s_nwin, s_nvis;
     float* win_ov = (float*)smem;                 // [K] dynamic
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t tid = threadIdx.x;
     const uint32_t n_tied = min(*of.tie_count, of.tie_cap);
     uint64_t* glist = scratch + (size_t)blockIdx.x * 2 * scratch_stride;      // [2 stride]: list + sort buffer
     for (uint32_t t = blockIdx.x; t < n_tied; t += gridDim.x) {
@@ -1466,14 +1516,12 @@ __global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __
         if (tid == 0) s_nwin = w;
         __syncthreads();
         const uint32_t n_win = s_nwin;
-        const uint32_t gs = (uint32_t)(vs.segx - views[0].segx), gt = (uint32_t)(vt.segx - views[0].segx);
         const bool hands_inverse = pd.tgt > pd.src;
-        // ---- the row's K slots: depths, orientation filter, phase-B counters (as the match epilogue) ----
+        // ---- the row's K slots: depths, orientation filter (as the match epilogue) ----
         for (uint32_t j0 = 0; j0 < K; j0 += kTieBlock) {
             const uint32_t j = j0 + tid;
             Slot o;
             o.tgt_seg = kEmpty; o.overlap = 0; o.dp1 = o.dp2 = o.dq1 = o.dq2 = 0; o.score3D = 0.0f; o.flags = 0;
-            uint32_t ipos = kEmpty;
             if (j < n_win) {
                 const uint32_t xj = win_ix[j];
                 const SegX tx = vt.segx[xj];
@@ -1482,15 +1530,13 @@ __global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __
                 res.overlap = win_ov[j];
                 o.tgt_seg = xj; o.overlap = res.overlap;
                 o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
-                o.flags = fuse_orientation(of, vs.C, vt.C, sx, tx, res, hands_inverse, gt + xj, ipos);
+                o.flags = fuse_orientation(of, vs.C, vt.C, sx, tx, res, hands_inverse);
             }
             if (j < K) {
                 const uint64_t at = pd.slot_off + (uint64_t)src * K + j;
                 slots[at] = o;
-                of.inv_pos[at] = ipos;
+                of.inv_tgt[at] = inverse_target(o);
             }
-            const uint32_t n_alive = (uint32_t)__popcll(__ballot((o.flags & kSlotAlive) != 0));
-            if (lane == 0 && n_alive) atomicAdd(&of.cnt_pack[gs + src], (unsigned long long)n_alive);
         }
         __syncthreads();
     }
@@ -1546,13 +1592,10 @@ hipError_t launch_match_tied_rows(const ViewDev* views, const PairDesc* pairs, S
 }
 
 // ---- per-view precompute (after translate), all views in one launch: grid = (segment blocks, views) -----
-__global__ void k_prep_views(const ViewDev* __restrict__ views, unsigned long long* __restrict__ cnt_pack, uint32_t G) {
+__global__ void k_prep_views(const ViewDev* __restrict__ views) {
     const ViewDev& v = views[blockIdx.y];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cnt_pack && blockIdx.y == 0 && i == 0) cnt_pack[G] = 0;
     if (i >= v.M) return;
-    // the packed hypothesis counters of phase B (fed by the match epilogue) start from zero in every matchImages
-    if (cnt_pack) cnt_pack[(uint32_t)(v.segx - views[0].segx) + i] = 0;
     double A[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) A[k] = v.RtKinv[k];
@@ -1570,16 +1613,23 @@ __global__ void k_prep_views(const ViewDev* __restrict__ views, unsigned long lo
     o.cn = dot(C, n);
     o.rm[0] = rm.x; o.rm[1] = rm.y; o.rm[2] = rm.z;
     const_cast<SegX*>(v.segx)[i] = o;
+    if (v.segd32) {   // float copy of rays + plane normal: the depth DECISION of the match kernel (l3d_dev.h depths_positive32)
+        SegD32 q;
+        q.r1[0] = (float)r1.x; q.r1[1] = (float)r1.y; q.r1[2] = (float)r1.z;
+        q.r2[0] = (float)r2.x; q.r2[1] = (float)r2.y; q.r2[2] = (float)r2.z;
+        q.n[0] = (float)n.x; q.n[1] = (float)n.y; q.n[2] = (float)n.z;
+        q.pad[0] = q.pad[1] = q.pad[2] = 0.0f;
+        const_cast<SegD32*>(v.segd32)[i] = q;
+    }
     SegF f;
     f.qx = (float)(ax - (double)v.cx); f.qy = (float)(ay - (double)v.cy);
     f.dx = (float)(ax - bx); f.dy = (float)(ay - by);
     const_cast<SegF*>(v.segf)[i] = f;
 }
 
-hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, unsigned long long* cnt_pack,
-                             uint32_t G, hipStream_t stream) {
-    if (!n_views || !max_M) return cnt_pack ? hipMemsetAsync(cnt_pack, 0, ((size_t)G + 1) * 8, stream) : hipSuccess;
-    hipLaunchKernelGGL(k_prep_views, dim3((max_M + 255) / 256, n_views), dim3(256), 0, stream, views, cnt_pack, G);
+hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, hipStream_t stream) {
+    if (!n_views || !max_M) return hipSuccess;
+    hipLaunchKernelGGL(k_prep_views, dim3((max_M + 255) / 256, n_views), dim3(256), 0, stream, views);
     return hipGetLastError();
 }
 
@@ -1588,7 +1638,7 @@ hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t ma
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
 extern "C" void l3d_debug_stats(unsigned long long* out, int reset) {
     hipMemcpyFromSymbol(out, HIP_SYMBOL(l3d::g_stats), sizeof(l3d::g_stats));
-    if (reset) { unsigned long long z[12] = {}; hipMemcpyToSymbol(HIP_SYMBOL(l3d::g_stats), z, sizeof(z)); }
+    if (reset) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(l3d::g_stats), z, sizeof(z)); }
 }
 extern "C" void l3d_debug_cycles(unsigned long long* out, int n) {
     hipMemcpyFromSymbol(out, HIP_SYMBOL(l3d::g_cycles), (size_t)n * 64);

@@ -12,7 +12,7 @@
 // last tile to finish zeroes the state again: the work space is all-zero between launches (it is zeroed when it is
 // allocated, DevBuf::reserve_zeroed) and no launch needs a memset of its own.
 //
-// uint64 elements are two packed 32-bit counters (list length | inverse references, k_match.hip: cnt_pack), scanned
+// uint64 elements are two packed 32-bit counters (surviving matches | best hypotheses per segment, k_lists.hip: k_seg_filter), scanned
 // as two lanes at once; their totals stay below 2^32 (l3d_api.hip checks the slot count), so the halves never carry.
 #include "l3d_dev.h"
 #include "l3d_kernels.h"

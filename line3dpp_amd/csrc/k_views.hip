@@ -36,61 +36,35 @@ __device__ unsigned long long g_bstats[8];
 #endif
 
 // ---- pre-pass ---------------------------------------------------------------------------------------
-// grid = (slot blocks, pairs).  One thread per slot: orientation flags + list lengths.
-//   cnt_pack[g] low word:  hypotheses of global segment g (fresh alive + potential inverse) -> CSR of the lists
-//               high word: potential inverse hypotheses of g -> CSR of the transposed index
-//   inv_pos[slot] position of the slot among the inverse refs of its target segment (kEmpty: none)
+// grid = (slot blocks, pairs).  One thread per slot: orientation flags (checkMatchOrientation, line3D.cc:811-858) of
+// slots that do not carry them yet -- the keep-all mode and full records that arrived from another rank; the bounded-kNN
+// match epilogue does the same on the way -- and the 4-byte stream k_pair_csr sorts:
+//   inv_tgt[slot] target segment of a slot that hands an inverse match to its target view (kEmpty: none)
 __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
-                             const uint32_t* __restrict__ seg_base, Slot* __restrict__ slots,
-                             unsigned long long* __restrict__ cnt_pack, uint32_t* __restrict__ inv_pos,
-                             OrientThr othr) {
+                             Slot* __restrict__ slots, uint32_t* __restrict__ inv_tgt, OrientThr othr) {
     const PairDesc& pd = pairs[blockIdx.y];
     const uint64_t n = (uint64_t)pd.Ms * pd.K;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if ((uint64_t)blockIdx.x * blockDim.x >= n) return;   // whole block past the end
-    const uint32_t K = pd.K;
-    const uint32_t row = (uint32_t)(i / K);
-    bool alive = false;
-    if (i < n) {
-        uint32_t ipos = kEmpty;
-        Slot* sp = slots + pd.slot_off + i;
-        const Slot s = *sp;
-        if (s.tgt_seg != kEmpty) {
-            const ViewDev& vs = views[pd.src];
-            uint32_t flags = 0;
-            if (orientation_ok_fast(vs.C, vs.segx[row], s.dp1, s.dp2, othr)) {
-                flags = kSlotAlive;
-                alive = true;
-                // inverse copy: only towards a view that is processed later (line3D.cc:1680)
-                if (pd.tgt > pd.src) {
-                    const ViewDev& vt = views[pd.tgt];
-                    if (orientation_ok_fast(vt.C, vt.segx[s.tgt_seg], s.dq1, s.dq2, othr)) {
-                        flags |= kSlotInvAlive;
-                        // one 64-bit atomic: low word = list length, high word = number of inverse refs; the old
-                        // high word is this slot's position among the inverse refs of the target segment
-                        const unsigned long long old =
-                            atomicAdd(&cnt_pack[seg_base[pd.tgt] + s.tgt_seg], (1ull << 32) | 1ull);
-                        ipos = (uint32_t)(old >> 32);
-                    }
-                }
+    if (i >= n) return;
+    const uint32_t row = (uint32_t)(i / pd.K);
+    uint32_t itgt = kEmpty;
+    Slot* sp = slots + pd.slot_off + i;
+    const Slot s = *sp;
+    if (s.tgt_seg != kEmpty) {
+        const ViewDev& vs = views[pd.src];
+        uint32_t flags = 0;
+        if (orientation_ok_fast(vs.C, vs.segx[row], s.dp1, s.dp2, othr)) {
+            flags = kSlotAlive;
+            // inverse copy: only towards a view that is processed later (line3D.cc:1680)
+            if (pd.tgt > pd.src) {
+                const ViewDev& vt = views[pd.tgt];
+                if (orientation_ok_fast(vt.C, vt.segx[s.tgt_seg], s.dq1, s.dq2, othr)) { flags |= kSlotInvAlive; itgt = s.tgt_seg; }
             }
-            sp->flags = flags;
-            sp->score3D = 0.0f;
         }
-        inv_pos[pd.slot_off + i] = ipos;
+        sp->flags = flags;
+        sp->score3D = 0.0f;
     }
-    // the K slots of a source row are neighbouring lanes: one atomic per (row, wave) instead of one per slot
-    const uint64_t m = __ballot(alive);
-    const uint32_t lane = lane_id();
-    const uint64_t base = i - lane, r0 = (uint64_t)row * K;
-    const uint32_t lo = (uint32_t)((r0 > base ? r0 : base) - base);
-    const uint64_t he = r0 + K < base + 64 ? r0 + K : base + 64;
-    const uint32_t hi = (uint32_t)(he - base);   // exclusive, <= 64
-    if (lane == lo && i < n) {
-        const uint64_t seg_mask = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-        const uint32_t c = (uint32_t)__popcll(m & seg_mask);
-        if (c) atomicAdd(&cnt_pack[seg_base[pd.src] + row], (unsigned long long)c);
-    }
+    inv_tgt[pd.slot_off + i] = itgt;
 }
 
 
@@ -631,11 +605,10 @@ hipError_t launch_fill_gseg_view(const uint32_t* seg_base, uint32_t V, uint32_t 
     return hipGetLastError();
 }
 hipError_t launch_orient_pairs(const ViewDev* views, const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots,
-                               const uint32_t* seg_base, Slot* slots, unsigned long long* cnt_pack, uint32_t* inv_pos,
-                               double thr_lo, double thr_hi, hipStream_t st) {
+                               Slot* slots, uint32_t* inv_tgt, double thr_lo, double thr_hi, hipStream_t st) {
     if (!n_pairs || !max_slots) return hipSuccess;
     hipLaunchKernelGGL(k_orient_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, views,
-                       pairs, seg_base, slots, cnt_pack, inv_pos, OrientThr{thr_lo, thr_hi});
+                       pairs, slots, inv_tgt, OrientThr{thr_lo, thr_hi});
     return hipGetLastError();
 }
 hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, uint32_t* long_list, uint32_t* n_long,

@@ -129,6 +129,20 @@ void make_cull(const double F[9], double ws, double hs, double wt, double ht, Pa
     pc.enabled = 1;
 }
 
+// PairDesc::B / tolB (l3d_dev.h: depths_positive32): the baseline in float and the magnitude above which the float value
+// of n.B has the sign of the exact numerator of the depth test -- ten times the float error of the dot product
+// (kDepthTol32 |B|) plus what the double rounding of cn = C.n can add (1e-14 (|C_s| + |C_t|)); infinite -- the float
+// decision is never trusted -- for a baseline below 1e-3, beyond 1e30 or not finite.  L3D_NO_DEPTH32=1: always infinite.
+void pair_baseline(const d3& Cs, const d3& Ct, PairDesc& pd) {
+    static const bool off = std::getenv("L3D_NO_DEPTH32") != nullptr;
+    const d3 B = Ct - Cs;
+    const double nb = norm(B), nc = std::fabs(Cs.x) + std::fabs(Cs.y) + std::fabs(Cs.z) + std::fabs(Ct.x) + std::fabs(Ct.y) + std::fabs(Ct.z);
+    pd.B[0] = (float)B.x; pd.B[1] = (float)B.y; pd.B[2] = (float)B.z;
+    const double tol = (double)kDepthTol32 * nb * (1.0 + 1e-6) + 1e-14 * nc;
+    pd.tolB = (!off && std::isfinite(nb) && std::isfinite(nc) && nb >= 1e-3 && nb <= 1e30 && nc <= 1e30)
+                  ? std::nextafterf((float)tol, INFINITY) : INFINITY;
+}
+
 int upload_views(l3d_ctx& c) {
     const size_t V = c.order.size();
     L3D_HIP_CHECK(c.d_views.reserve(V));
@@ -140,6 +154,7 @@ int upload_views(l3d_ctx& c) {
     size_t Gtot = 0;
     for (size_t i = 0; i < V; ++i) Gtot += c.order[i]->M;
     L3D_HIP_CHECK(c.d_gsegx.reserve(std::max<size_t>(Gtot, 1)));
+    L3D_HIP_CHECK(c.d_gsegd32.reserve(std::max<size_t>(Gtot, 1)));
     std::memset((void*)hv, 0, V * sizeof(ViewDev));   // (padding bytes take part in the comparison of upload_table)
     size_t gbase = 0;
     for (size_t i = 0; i < V; ++i) {
@@ -147,16 +162,15 @@ int upload_views(l3d_ctx& c) {
         ViewDev& d = hv[i];
         d.C[0] = v.C.x; d.C[1] = v.C.y; d.C[2] = v.C.z;
         std::memcpy(d.RtKinv, v.RtKinv.m, 72);
-        d.seg4 = v.d_seg4.p; d.segf = v.d_segf.p; d.segx = c.d_gsegx.p + gbase;
+        d.seg4 = v.d_seg4.p; d.segf = v.d_segf.p; d.segx = c.d_gsegx.p + gbase; d.segd32 = c.d_gsegd32.p + gbase;
         gbase += v.M;
         d.M = v.M; d.cam = v.cam; d.k = v.k;
         d.cx = 0.5f * (float)v.width; d.cy = 0.5f * (float)v.height; d.pad = 0;
         max_M = std::max(max_M, v.M);
     }
     L3D_HIP_CHECK(upload_table(c.d_views, c.h_views, hv, V * sizeof(ViewDev), c.up_views, c.stream));
-    // per-segment invariants (k_prep_views), and the packed hypothesis counters of phase B zeroed on the way
-    L3D_HIP_CHECK(c.d_cnt_pack.reserve(Gtot + 1));
-    L3D_HIP_CHECK(launch_prep_views(c.d_views.p, (uint32_t)V, max_M, c.d_cnt_pack.p, (uint32_t)Gtot, c.stream));
+    // per-segment invariants (k_prep_views)
+    L3D_HIP_CHECK(launch_prep_views(c.d_views.p, (uint32_t)V, max_M, c.stream));
     return L3D_OK;
 }
 
@@ -380,8 +394,8 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_views.release(); c->d_pairs.release(); c->d_work.release(); c->d_slots.release(); c->d_slot_idx.release();
     c->h_views.release(); c->h_pairs.release(); c->h_cull.release(); c->h_work.release();
     c->h_segb.release(); c->h_cnt.release(); c->h_fin.release();
-    c->d_off64.release(); c->d_cnt64.release(); c->d_off64s.release(); c->d_scan_ws.release();
-    c->d_huge_u64.release(); c->d_inv_recs.release(); c->d_lzero.release(); c->d_list2.release(); c->d_list4.release(); c->d_listH.release();
+    c->d_poff.release(); c->d_csr_dummy.release(); c->d_pair_present.release(); c->d_cnt64.release(); c->d_off64s.release(); c->d_scan_ws.release();
+    c->d_huge_u64.release(); c->d_inv_refs.release(); c->d_lzero.release(); c->d_list2.release(); c->d_list4.release(); c->d_listH.release();
     c->d_seg_of_g.release(); c->d_huge_u32.release(); c->d_huge_f32.release(); c->d_ledges.release(); c->d_lhyps.release();
     c->d_lsegs.release(); c->d_lcands.release(); c->d_lchdrs.release(); c->d_ltab.release(); c->h_ltab.release();
     c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
@@ -391,7 +405,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_scal.release();
     c->d_surv_off.release(); c->d_hyp_off.release();
     c->d_surv_tg.release(); c->d_surv_sg.release();
-    c->d_cnt_pack.release(); c->d_inv_pos.release(); c->d_gsegx.release();
+    c->d_inv_tgt.release(); c->d_gsegx.release(); c->d_gsegd32.release();
     c->d_tie_count.release(); c->d_tie_list.release(); c->d_tie_heap.release(); c->d_item_bucket.release(); c->d_item_order.release(); c->d_order_done.release();
     c->d_coll_cnt.release(); c->d_coll_off.release(); c->d_coll_idx.release(); c->d_item_cnt.release();
     c->d_item_off.release(); c->d_item_seg.release(); c->d_item_sim.release();
@@ -606,6 +620,7 @@ static int match_begin_body(l3d_ctx* c) {
                 for (double cval : {v->C.x, v->C.y, v->C.z, t->C.x, t->C.y, t->C.z}) fm = fm && std::isfinite(cval) && std::fabs(cval) <= 1e30;
                 static const bool no_fast = std::getenv("L3D_NO_FASTMATH") != nullptr;   // diagnostic switch: the compiler's own expansions
                 pd.flags = (fm && !no_fast) ? kPairFastMath : 0u;
+                pair_baseline(v->C, t->C, pd);
             }
             slot_off += (uint64_t)pd.Ms * pd.K; row_off += pd.Ms;
             const uint32_t pi = (uint32_t)c->pairs.size();
@@ -613,7 +628,7 @@ static int match_begin_body(l3d_ctx* c) {
             if (t->index > v->index) t->in_pairs.push_back(pi);   // inverse only if tgt not yet processed (:1680)
             c->pairs.push_back(pd);
             PairCull pc{};
-            if (c->use_cull && c->kNN > 0 && pd.Ms <= kCullMaxSegs && pd.Mt <= kCullMaxSegs && pd.Ms && pd.Mt)
+            if (c->use_cull && pd.Ms <= kCullMaxSegs && pd.Mt <= kCullMaxSegs && pd.Ms && pd.Mt)
                 make_cull(pd.F, v->width, v->height, t->width, t->height, pc);
             pc.s_off = cs_off; pc.t_off = ct_off; pc.c_off = cc_off; pc.k_off = ~0ull;
             pc.w_item0 = w_item; pc.sorted_copy = pd.Mt >= kSortedCopyMinSegs ? 1u : 0u; w_item += (pd.Ms + kMatchRows - 1) / kMatchRows;
@@ -649,12 +664,8 @@ static int match_begin_body(l3d_ctx* c) {
     c->shard_world = 0; c->lists_ready = false; c->lists_prepared = false;
     int rc = upload_views(*c);
     if (rc) return rc;
-    {   // packed hypothesis counters of phase B: fed by the match epilogue (bounded kNN) or by k_orient_all
-        uint64_t G = 0;
-        for (auto* v : c->order) G += v->M;
-        (void)G;   // (d_cnt_pack: sized and zeroed by upload_views / k_prep_views)
-        if (c->kNN > 0) L3D_HIP_CHECK(c->d_inv_pos.reserve(std::max<uint64_t>(c->n_slots, 1)));
-    }
+    // the inverse-target stream of phase B: written by the match epilogue (bounded kNN) or by k_orient_all
+    if (c->kNN > 0) L3D_HIP_CHECK(c->d_inv_tgt.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(c->d_pairs.reserve(std::max<size_t>(c->pairs.size(), 1)));
     {
         bool sent = false;
@@ -673,7 +684,7 @@ static int match_begin_body(l3d_ctx* c) {
         bool any_sorted = false;
         for (const PairCull& pc : c->cull) any_sorted |= pc.enabled && pc.sorted_copy;
         L3D_HIP_CHECK(c->d_tgt_s4.reserve(any_sorted ? std::max<uint64_t>(ct_off, 1) : 1));
-        L3D_HIP_CHECK(c->d_tgt_sd.reserve(any_sorted ? std::max<uint64_t>(ct_off, 1) : 1));
+        L3D_HIP_CHECK(c->d_tgt_sd.reserve(any_sorted ? std::max<uint64_t>(ct_off, 1) : 1));   // (48-byte float records since round 4)
     }
     L3D_HIP_CHECK(c->d_tgt_band.reserve(std::max<uint64_t>(ct_off, 1)));
     L3D_HIP_CHECK(c->d_chunk_band.reserve(std::max<uint32_t>(cc_off, 1)));
@@ -752,7 +763,8 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     CullPools pools{c->d_cull.p, c->d_src_perm.p, c->d_src_band.p, c->d_tgt_perm.p, c->d_tgt_sf.p, c->d_tgt_band.p,
                     c->d_chunk_band.p, c->d_cull_keys.p};
     pools.tgt_s4 = c->d_tgt_s4.p; pools.tgt_sd = c->d_tgt_sd.p;
-    if (mode != 0 || c->brute || !maxM) pools.cull = nullptr;
+    const bool keep_all_unculled = std::getenv("L3D_KEEPALL_NO_CULL") != nullptr;   // diagnostic switch (A/B; read per call)
+    if (c->brute || !maxM || (mode != 0 && keep_all_unculled)) pools.cull = nullptr;
     else {
         static const int no_order = [] { const char* e = std::getenv("L3D_MATCH_ORDER"); return e && std::atoi(e) == 0; }();
         // longest-first launch order (k_order_items) where the launch has one to three items per wave slot (fewer: all
@@ -767,14 +779,16 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
             pools.order_done = c->d_order_done.p;
             pools.w_base = c->cull[first].w_item0; pools.cost_max = maxMt;
         }
-        L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
-        L3D_HIP_CHECK(launch_order_items(c->d_pairs.p, first, count, maxMt, pools, (uint32_t)n_work, c->stream));
+        // (keep-all mode: the fill pass walks what the count pass prepared)
+        if (mode != 2) {
+            L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
+            L3D_HIP_CHECK(launch_order_items(c->d_pairs.p, first, count, maxMt, pools, (uint32_t)n_work, c->stream));
+        }
     }
     L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
     const bool ix16 = maxMt < 65536u && maxK < 32768u;   // 16-bit indices in the kernel's LDS tables (top bit of a row's minpos: tie flag)
-    // bounded kNN: the orientation filter and the hypothesis counters of phase B are fused into the epilogue
-    OrientFuse of{mode == 0 ? c->d_cnt_pack.p : nullptr, mode == 0 ? c->d_inv_pos.p : nullptr,
-                  OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
+    // bounded kNN: the orientation filter of phase B is fused into the epilogue
+    OrientFuse of{mode == 0 ? c->d_inv_tgt.p : nullptr, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
     uint32_t tie_stride = 0;
     if (mode == 0) {   // rows with equal overlaps are collected here and replayed in the reference's heap order
         uint32_t mt = 0;
@@ -928,7 +942,7 @@ int l3d_expand_slot_indices(l3d_ctx* c, uint32_t first, uint32_t count) {
         max_row_slots = std::max<uint64_t>(max_row_slots, (uint64_t)c->pairs[p].Ms * c->pairs[p].K);
     for (uint32_t p = first; p < first + count; ++p)
         if (c->pair_done[p]) return fail(L3D_ERR_STATE, "l3d_expand_slot_indices: pair already present on this rank");
-    const OrientFuse of{c->d_cnt_pack.p, c->d_inv_pos.p, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
+    const OrientFuse of{c->d_inv_tgt.p, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
     L3D_HIP_CHECK(launch_expand_slot_idx(c->d_views.p, c->d_pairs.p, first, count, max_row_slots, c->d_slot_idx.p,
                                          c->d_slots.p, of, c->stream));
     for (uint32_t p = first; p < first + count; ++p) c->pair_done[p] = c->pair_counted[p] = 1;
@@ -1065,9 +1079,10 @@ int l3d_match_finish(l3d_ctx* c) {
 }
 
 // ---- phase B (sparse form, k_lists.hip) in three host stages -------------------------------------------------------
-//   lists_prepare  tables, list offsets (one scan of the packed counters): once per matchImages
+//   lists_prepare  tables (views, outgoing / incoming pairs, CSR bases): once per matchImages
 //   lists_run      the list pass for a range of views into a range of pools: zero the work arrays, inverse records of
-//                  those views' segments, candidates (k_lists), edges + headers (k_edges)
+//                  the pairs that hand matches to those views, sorted by target segment (k_pair_csr), candidates
+//                  (k_lists), edges + headers (k_edges)
 //   tail_run       chain sweeps, scores, filterMatches, outputs, view medians + the read-backs of the pass
 // One GPU runs prepare, lists_run(all views, all pools), tail_run.  With the list pass sharded over ranks
 // (l3d_lists_shard) every rank runs lists_run for ITS views into ITS pools, the pool slabs are all-gathered by the
@@ -1085,10 +1100,12 @@ static ListPools list_pools(l3d_ctx* c, uint32_t pool0 = 0, uint32_t npools = kL
     lp.flags = c->d_lzero.p + kListPools * 16;
     lp.list2 = c->d_list2.p; lp.list4 = c->d_list4.p; lp.listH = c->d_listH.p;
     lp.pool0 = pool0; lp.npools = npools;
+    static const bool no_stat = std::getenv("L3D_NO_LIST_STAT") != nullptr;   // diagnostic switch (A/B of the per-list counter)
+    lp.count_entries = no_stat ? 0u : 1u;
     return lp;
 }
 
-// d_medians = [tot64 x 4 (list entries | inverse records; survivors | hypotheses) | median depth of each view]
+// d_medians = [tot64 x 4 ([0] unused; [1] survivors | hypotheses) | median depth of each view]
 static unsigned long long* tot64_of(l3d_ctx* c) { return (unsigned long long*)c->d_medians.p; }
 static float* medians_of(l3d_ctx* c) { return c->d_medians.p + 8; }
 static size_t fin_b1(uint32_t V) { return ((size_t)8 + V + 3) & ~(size_t)3; }   // second part of h_fin (tail_run)
@@ -1132,12 +1149,12 @@ static int lists_prepare(l3d_ctx* c, int caps_mode) {
     L3D_HIP_CHECK(c->d_seg_base.reserve(V + 1)); L3D_HIP_CHECK(c->d_gseg_view.reserve(G + 1));
     L3D_HIP_CHECK(c->d_surv_off.reserve(G + 2)); L3D_HIP_CHECK(c->d_hyp_off.reserve(G + 2));
     L3D_HIP_CHECK(c->d_hyp_of_seg.reserve(G + 1)); L3D_HIP_CHECK(c->d_medians.reserve(V + 1 + 8));   // [two 64-bit totals + spare | medians]: read back together
-    L3D_HIP_CHECK(c->d_off64.reserve(G + 2)); L3D_HIP_CHECK(c->d_cnt64.reserve(G + 2)); L3D_HIP_CHECK(c->d_off64s.reserve(G + 2));
+    L3D_HIP_CHECK(c->d_cnt64.reserve(G + 2)); L3D_HIP_CHECK(c->d_off64s.reserve(G + 2));
     L3D_HIP_CHECK(c->d_scan_ws.reserve_zeroed(scan_ws_words(G, 8), st));
     L3D_HIP_CHECK(c->d_seg_of_g.reserve(G + 1)); L3D_HIP_CHECK(c->d_list2.reserve(G + 1)); L3D_HIP_CHECK(c->d_list4.reserve(G + 1)); L3D_HIP_CHECK(c->d_listH.reserve(G + 1));
     L3D_HIP_CHECK(c->d_hyps.reserve(std::max<uint32_t>(G, 1))); L3D_HIP_CHECK(c->d_depths.reserve(2 * (size_t)G + 2));
-    L3D_HIP_CHECK(c->d_inv_recs.reserve(std::max<uint64_t>(c->n_slots, 1)));
-    L3D_HIP_CHECK(c->d_inv_pos.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    L3D_HIP_CHECK(c->d_inv_refs.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    L3D_HIP_CHECK(c->d_inv_tgt.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(c->h_fin.reserve(fin_b1(V) + kListPools * 16 + 96));
     L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
     g_trace.mark("finish: reserves done");
@@ -1151,14 +1168,24 @@ static int lists_prepare(l3d_ctx* c, int caps_mode) {
             c->gseg_view_for = c->d_gseg_view.p;
         }
     }
-    // per-view / per-outgoing-pair tables of the list pass (l3d_lists.h), staged in one pinned buffer:
-    // [ListView x V | OutPair x P], outgoing pairs of a view in ascending target order
+    // per-view / per-pair tables of the list pass (l3d_lists.h), staged in one pinned buffer:
+    // [ListView x V | OutPair x P | InPair x P_in | PairCsr x P]: outgoing pairs of a view in ascending target order,
+    // incoming pairs (those that hand inverse matches over: src < tgt, line3D.cc:1680) in ascending pair index =
+    // ascending source view; the per-pair CSR offsets of a view's incoming pairs are one transposed table per view in
+    // d_poff (ListView::pbase, (M + 1) rows of ni columns), PairCsr tells k_pair_csr which column a pair fills
     {
-        static_assert(sizeof(ListView) == 32 && sizeof(OutPair) == 32, "table layout");
-        std::vector<char> table(((size_t)V + P + 1) * 32, 0);
+        static_assert(sizeof(ListView) == 32 && sizeof(OutPair) == 32 && sizeof(InPair) == 16 && sizeof(PairCsr) == 16, "table layout");
+        uint32_t n_in = 0;
+        for (uint32_t vi = 0; vi < V; ++vi) n_in += (uint32_t)c->order[vi]->in_pairs.size();
+        const size_t o_in = ((size_t)V + P) * 32, o_pp = o_in + (size_t)n_in * 16;
+        std::vector<char> table(o_pp + ((size_t)P + 1) * 16 + 32, 0);
         ListView* hv = (ListView*)table.data();
         OutPair* hp = (OutPair*)(table.data() + (size_t)V * 32);
-        uint32_t n = 0;
+        InPair* hi = (InPair*)(table.data() + o_in);
+        PairCsr* hpp = (PairCsr*)(table.data() + o_pp);
+        for (uint32_t p = 0; p < P; ++p) hpp[p] = PairCsr{kEmpty, 0u, 0u, 0u};
+        uint32_t n = 0, ni = 0;
+        uint64_t poff_total = 0;
         for (uint32_t vi = 0; vi < V; ++vi) {
             ListView& lv = hv[vi];
             lv = ListView{};
@@ -1170,26 +1197,37 @@ static int lists_prepare(l3d_ctx* c, int caps_mode) {
                 hp[n++] = op;
             }
             lv.nq = n - lv.q0;
+            lv.i0 = ni; lv.ni = (uint32_t)c->order[vi]->in_pairs.size(); lv.pbase = (uint32_t)poff_total;
+            uint32_t q = 0;
+            for (uint32_t p : c->order[vi]->in_pairs) {   // (built in pair order: ascending)
+                const PairDesc& pd = c->pairs[p];
+                InPair ip{};
+                ip.rec_base = (uint32_t)pd.slot_off; ip.src = pd.src; ip.pair = p;
+                hpp[p] = PairCsr{(uint32_t)poff_total, lv.ni, q++, 0u};
+                hi[ni++] = ip;
+            }
+            poff_total += ((uint64_t)lv.M + 1) * lv.ni;
+            if (poff_total >= (1ull << 32)) return fail(L3D_ERR_LIMIT, "more than 2^32 per-pair CSR offsets in phase B");
         }
-        L3D_HIP_CHECK(c->d_ltab.reserve(((size_t)V + P + 1) * 32));
-        L3D_HIP_CHECK(upload_table(c->d_ltab, c->h_ltab, table.data(), ((size_t)V + n) * 32, c->up_ltab, st));
+        c->poff_total = (uint32_t)poff_total; c->n_in_pairs = ni;
+        L3D_HIP_CHECK(c->d_poff.reserve(std::max<uint64_t>(poff_total, 1)));
+        L3D_HIP_CHECK(c->d_ltab.reserve(table.size()));
+        L3D_HIP_CHECK(upload_table(c->d_ltab, c->h_ltab, table.data(), o_pp + (size_t)P * 16, c->up_ltab, st));
     }
-    // ---- pre-pass: orientation flags and hypothesis counters of the pairs that do not carry them yet ----
+    // ---- pre-pass: orientation flags and inverse-target stream of the pairs that do not carry them yet ----
     // (bounded kNN: done by the match epilogue / the exchange expansion; what is left are the pairs of the keep-all
-    // mode and pairs whose full records arrived through l3d_slots_exchanged; d_cnt_pack was zeroed by l3d_match_begin)
+    // mode and pairs whose full records arrived through l3d_slots_exchanged)
     // (pairs that are not present on this rank -- a multi-GPU run keeps the pairs that touch the rank's views only --
     // are left alone: their slots are not valid)
     for (uint32_t p0 = 0; p0 < P;) {
         if (c->pair_counted[p0] || !c->pair_done[p0]) { ++p0; continue; }
         uint32_t p1 = p0;
         while (p1 < P && !c->pair_counted[p1] && c->pair_done[p1]) ++p1;
-        L3D_HIP_CHECK(launch_orient_pairs(c->d_views.p, c->d_pairs.p + p0, p1 - p0, max_slots, c->d_seg_base.p,
-                                          c->d_slots.p, c->d_cnt_pack.p, c->d_inv_pos.p, c->orient_lo, c->orient_hi, st));
+        L3D_HIP_CHECK(launch_orient_pairs(c->d_views.p, c->d_pairs.p + p0, p1 - p0, max_slots, c->d_slots.p, c->d_inv_tgt.p,
+                                          c->orient_lo, c->orient_hi, st));
         for (uint32_t p = p0; p < p1; ++p) c->pair_counted[p] = 1;
         p0 = p1;
     }
-    // list offsets (low words) and offsets of the inverse records (high words) in ONE scan of the packed counters
-    L3D_HIP_CHECK(launch_scan64(c->d_cnt_pack.p, G, c->d_off64.p, c->d_scan_ws.p, tot64_of(c), st));
     if (!c->lp_ecap) {
         // L3D_POOL_SCALE (diagnostic): scales the initial record pools; a small value makes the first list passes
         // overflow, so that the regrow path (check_pass) can be exercised at any scene size
@@ -1237,9 +1275,21 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
     // segments with surviving hypotheses, whose header this very pass has written)
     L3D_HIP_CHECK(hipMemsetAsync(c->d_lzero.p, 0, z.words * 4 + std::max<uint64_t>(c->n_slots, 1), st));
     g_trace.mark("zero block memset enqueued");
-    L3D_HIP_CHECK(launch_inv_records(c->d_pairs.p, P, max_slots, c->d_seg_base.p, c->d_slots.p, c->d_off64.p,
-                                     c->d_inv_pos.p, c->d_inv_recs.p, v0, v0 + nv, st));
-    g_trace.mark("inv_records enqueued");
+    const ListView* lviews = (const ListView*)c->d_ltab.p;
+    const OutPair* opairs = (const OutPair*)(c->d_ltab.p + (size_t)V * 32);
+    const InPair* ipairs = (const InPair*)(c->d_ltab.p + ((size_t)V + P) * 32);
+    const PairCsr* pair_poff = (const PairCsr*)(c->d_ltab.p + ((size_t)V + P) * 32 + (size_t)c->n_in_pairs * 16);
+    {   // the inverse hypotheses of the pairs that hand matches to these views, sorted by target segment
+        uint32_t max_Mt = 0;
+        for (auto& pd : c->pairs) if (pd.tgt > pd.src && pd.tgt >= v0 && pd.tgt < v0 + nv) max_Mt = std::max(max_Mt, pd.Mt);
+        if (max_Mt) {
+            // (views beyond the LDS capacity of k_pair_csr keep their cursors in global memory: 64 dummy words per pair)
+            if (max_Mt > 32768 || std::getenv("L3D_CSR_GLOBAL")) L3D_HIP_CHECK(c->d_csr_dummy.reserve((size_t)P * 64));
+            L3D_HIP_CHECK(launch_pair_csr(c->d_pairs.p, P, max_Mt, pair_poff, c->d_inv_tgt.p, c->d_poff.p, c->d_inv_refs.p,
+                                          c->d_csr_dummy.p, v0, v0 + nv, st));
+        }
+    }
+    g_trace.mark("pair CSRs enqueued");
     // mean list length: every alive slot is a hypothesis of its source segment and, towards a later view, of its target
     // segment too (~0.8 of the slots are alive, ~half of the pairs hand inverse matches over); exact after the first call
     const uint32_t mean_list = c->n_ents ? (uint32_t)(c->n_ents / std::max<uint32_t>(G, 1))
@@ -1249,10 +1299,8 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
     c->huge_ran = !c->huge_skip;
     uint32_t max_M = 0;
     for (uint32_t vi = v0; vi < v0 + nv; ++vi) max_M = std::max(max_M, c->order[vi]->M);
-    const ListView* lviews = (const ListView*)c->d_ltab.p;
-    const OutPair* opairs = (const OutPair*)(c->d_ltab.p + (size_t)V * 32);
-    L3D_HIP_CHECK(launch_lists(v0, nv, max_M, c->d_views.p, c->d_pairs.p, lviews, opairs, c->d_gseg_view.p, c->d_off64.p,
-                               c->d_inv_recs.p, c->d_slots.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, simc, lp,
+    L3D_HIP_CHECK(launch_lists(v0, nv, max_M, c->d_views.p, c->d_pairs.p, lviews, opairs, ipairs, c->d_gseg_view.p,
+                               c->d_poff.p, c->d_inv_refs.p, c->d_slots.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, simc, lp,
                                c->d_seg_of_g.p, hsa, st));
     L3D_HIP_CHECK(hipEventRecord(c->ev[9], st));
     g_trace.mark("list pass enqueued");
@@ -1279,7 +1327,14 @@ static int tail_run(l3d_ctx* c, bool fresh) {
     for (uint32_t s2 = 0; s2 < n_sweeps; ++s2)
         L3D_HIP_CHECK(launch_chain_sweep(lp, positive_of(c), changed, s2, st));
     g_trace.mark("chain sweeps enqueued");
-    L3D_HIP_CHECK(launch_hyp_scores(lp, positive_of(c), c->d_gseg_view.p, c->d_slots.p, max_score, st));
+    // which pairs' slots this rank holds (sharded calls only: on one GPU every pair is present)
+    const uint8_t* present = nullptr;
+    if (c->shard_world > 1) {
+        L3D_HIP_CHECK(c->d_pair_present.reserve(std::max<size_t>(c->pair_done.size(), 1)));
+        L3D_HIP_CHECK(hipMemcpyAsync(c->d_pair_present.p, c->pair_done.data(), c->pair_done.size(), hipMemcpyHostToDevice, st));
+        present = c->d_pair_present.p;
+    }
+    L3D_HIP_CHECK(launch_hyp_scores(lp, positive_of(c), c->d_gseg_view.p, c->d_slots.p, present, max_score, st));
     g_trace.mark("hyp_scores enqueued");
     L3D_HIP_CHECK(launch_hyp_filter(lp, G, c->d_gseg_view.p, max_score, kept, best, c->d_cnt64.p, st));
     g_trace.mark("hyp_filter enqueued");
@@ -1352,9 +1407,13 @@ static int finish_commit(l3d_ctx* c) {
     const uint32_t* h0 = c->h_fin.p;
     const uint32_t* h = h0 + fin_b1(V) - 128;                             // h[128 + ...]: pool counters
     const uint32_t* changed = h + 128 + kListPools * 16 + 32;
-    c->n_ents = h0[0];
     c->n_surv = h0[2]; c->n_hyps = h0[3];
-    c->tm.list_entries = h0[0];
+    {   // total length of the hypothesis lists: counted by the list pass per pool (k_lists.hip: cnt[pool * 16 + 5])
+        uint64_t ents = 0;
+        for (uint32_t q = 0; q < kListPools; ++q) ents += h[128 + q * 16 + 5];
+        c->n_ents = (uint32_t)std::min<uint64_t>(ents, 0xFFFFFFFFu);
+        c->tm.list_entries = c->n_ents;
+    }
     for (uint32_t s2 = 0; s2 < c->chain_enqueued; ++s2) c->tm.chain_sweeps += changed[s2] ? 1u : 0u;   // of the last round
     c->chain_need = c->tm.chain_extra_rounds ? kChainSweeps : c->tm.chain_sweeps;
     {

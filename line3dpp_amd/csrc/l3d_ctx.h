@@ -41,9 +41,8 @@ hipError_t launch_seam_entries(uint32_t n, const float4* m4, const float2* rt, c
 hipError_t launch_seam_all_present(uint32_t G, const uint32_t* off, const uint32_t* boff, uint64_t* bits, hipStream_t);
 hipError_t launch_seam_scores_out(uint32_t n, const DEntry*, float* scores, hipStream_t);
 hipError_t launch_fill_gseg_view(const uint32_t* seg_base, uint32_t V, uint32_t max_M, uint32_t* gseg_view, hipStream_t);
-hipError_t launch_orient_pairs(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots,
-                               const uint32_t* seg_base, Slot* slots, unsigned long long* cnt_pack, uint32_t* inv_pos,
-                               double thr_lo, double thr_hi, hipStream_t);
+hipError_t launch_orient_pairs(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots, Slot* slots,
+                               uint32_t* inv_tgt, double thr_lo, double thr_hi, hipStream_t);
 hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, uint32_t* long_list, uint32_t* n_long,
                            hipStream_t);
 hipError_t launch_support_long(uint32_t n_long, const uint32_t* long_list, const uint32_t* off, const uint32_t* boff,
@@ -84,6 +83,7 @@ void neighbors_from_worldpoints(const std::map<uint32_t, HostView*>& views, uint
 void translate(::l3d_ctx& c);      // Line3D::translate, line3D.cc:500-536
 void untranslate(::l3d_ctx& c);    // line3D.cc:539-545
 void make_cull(const double F[9], double ws, double hs, double wt, double ht, PairCull& pc);
+void pair_baseline(const d3& Cs, const d3& Ct, PairDesc& pd);
 void orientation_thresholds(double& lo, double& hi);
 SimConst sim_thresholds(float two_sigA_sqr);
 float ev_ms(hipEvent_t a, hipEvent_t b);
@@ -119,6 +119,7 @@ struct l3d_ctx {
     std::vector<PairDesc> pairs;
     std::vector<uint32_t> pair_src_cam, pair_tgt_cam;
     std::vector<char> pair_done;
+    DevBuf<uint8_t> d_pair_present;                 // pair_done on the device for the tail of a sharded call (k_hyp_scores)
     uint64_t n_slots = 0, pair_tests = 0;
     uint32_t n_rows_total = 0;
     // device
@@ -133,7 +134,7 @@ struct l3d_ctx {
     DevBuf<uint32_t> d_src_perm, d_tgt_perm;
     DevBuf<float2> d_src_band, d_chunk_band, d_tgt_band;
     DevBuf<float4> d_tgt_sf, d_tgt_s4;
-    DevBuf<SegD> d_tgt_sd;
+    DevBuf<SegD32> d_tgt_sd;
     DevBuf<uint32_t> d_item_bucket, d_item_order, d_order_done;   // longest-first launch order (k_order_items)
     DevBuf<uint64_t> d_cull_keys;   // sort scratch of pairs whose views exceed the LDS sort capacity
     bool use_cull = true;
@@ -148,6 +149,7 @@ struct l3d_ctx {
     std::vector<uint8_t> pair_counted;   // the pair's slots carry orientation flags and are in the phase-B counters
     hipEvent_t sev[5] = {};                         // prepared, half A done, half B done, memsets done, orient A done
     DevBuf<SegX> d_gsegx;                           // SegX of every segment, global segment order
+    DevBuf<SegD32> d_gsegd32;                       // float copy of rays + plane normal (stage 1 of the match kernel's pipeline)
     float collinearity_t = -1.0f;                   // collinearity_t_ (reconstruct3Dlines); > 0: collinear links
     DevBuf<uint32_t> d_coll_cnt, d_coll_off, d_coll_idx, d_item_cnt, d_item_off, d_item_seg;
     DevBuf<float> d_item_sim;
@@ -176,15 +178,16 @@ struct l3d_ctx {
     std::vector<uint32_t> seg_base;                 // [V+1]
     DevBuf<uint32_t> d_seg_base, d_gseg_view, d_scal;
     DevBuf<uint32_t> d_surv_off, d_hyp_off, d_surv_tg, d_surv_sg;
-    DevBuf<uint32_t> d_inv_pos;
-    DevBuf<unsigned long long> d_cnt_pack;
+    DevBuf<uint32_t> d_inv_tgt;                      // [n_slots] target segment of an inverse-alive slot, kEmpty otherwise
+    DevBuf<uint32_t> d_poff, d_csr_dummy;           // per-pair CSR offsets over the target's segments (k_pair_csr)
+    uint32_t poff_total = 0, n_in_pairs = 0;        // entries of d_poff / of the InPair table of the running call
     DevBuf<Match> d_surv;
     DevBuf<int32_t> d_hyp_of_seg;
     DevBuf<float> d_depths, d_medians;              // d_medians: 8 words of 64-bit totals, then [V] medians
     DevBuf<HypRec> d_hyps;
     // sparse phase B (k_lists.hip, l3d_lists.h)
-    DevBuf<unsigned long long> d_off64, d_cnt64, d_off64s, d_scan_ws, d_huge_u64;
-    DevBuf<InvRec> d_inv_recs;
+    DevBuf<unsigned long long> d_cnt64, d_off64s, d_scan_ws, d_huge_u64;
+    DevBuf<uint32_t> d_inv_refs;                    // inverse hypotheses of each pair sorted by target segment: slot indices
     DevBuf<uint32_t> d_lzero, d_list2, d_list4, d_listH, d_seg_of_g, d_huge_u32;
     DevBuf<float> d_huge_f32;
     DevBuf<EdgeRec> d_ledges;
@@ -207,7 +210,7 @@ struct l3d_ctx {
     bool lists_ready = false, lists_prepared = false;   // per-pool capacities (grow on overflow, kept across calls)
     PinnedBuf<uint32_t> h_fin;
     PinnedBuf<char> h_ltab;
-    DevBuf<char> d_ltab;   // [ListView x V | OutPair x P]
+    DevBuf<char> d_ltab;   // [ListView x V | OutPair x P | InPair x (pairs that hand inverse matches over) | pair_poff x P]
     std::vector<uint32_t> h_surv_off, h_hyp_off;    // lazily fetched for the accessors
     bool host_offsets_valid = false;
     // affinity

@@ -96,6 +96,13 @@ struct SegD {
 };  // 80 B
 static_assert(sizeof(SegD) == 80 && sizeof(SegX) == 104, "SegD is the prefix of SegX");
 
+// fp32 copy of what the depth DECISION needs (rays and plane normal: unit vectors, so their float roundings are absolute
+// errors of 6e-8 per component); depths_positive32 below.  48 bytes: three 16-byte loads instead of the five of a SegD.
+struct __attribute__((aligned(16))) SegD32 {
+    float r1[3], r2[3], n[3], pad[3];
+};
+static_assert(sizeof(SegD32) == 48, "SegD32 is 48 bytes");
+
 // fp32 pre-filter record of a segment in the target role: end point 1 relative to the image
 // centre and the end-point difference.
 struct __attribute__((aligned(16))) SegF {
@@ -128,6 +135,7 @@ struct ViewDev {
     const float4* seg4;  // raw segments
     const SegF* segf;
     const SegX* segx;
+    const SegD32* segd32;
     uint32_t M;
     uint32_t cam;
     float k;           // View::k_
@@ -145,7 +153,10 @@ struct PairDesc {
     uint64_t slot_off;  // first slot of this pair in the slot buffer
     float cc_dist;      // |C_src - C_tgt| rounded up: bounds |P - C_other| of a hypothesis from its depth (k_lists.hip)
     uint32_t flags;     // kPairFastMath
+    float B[3];         // C_tgt - C_src (double difference, rounded): the numerators of both triangulations are +-n.B
+    float tolB;         // |n.B| above this: the float evaluation has the sign of the exact numerator (inf: never trusted)
 };
+static_assert(sizeof(PairDesc) == 128, "PairDesc is 128 bytes");
 
 // ---- phase-B records ------------------------------------------------------------------------
 // transposed index entry: slot (pair, src_row, j) is a potential inverse hypothesis of its target segment
@@ -363,6 +374,28 @@ L3D_HD bool depths_positive(const S& sx, const T& tx, const double* Cs, const do
     tri_depths(Cs, sx.r1, sx.r2, tx.n, tx.cn, ds1, ds2);
     tri_depths(Ct, tx.r1, tx.r2, sx.n, sx.cn, dt1, dt2);
     return ds1 > kEps && ds2 > kEps && dt1 > kEps && dt2 > kEps;
+}
+
+// ---- the same DECISION in fp32, with a certificate ----------------------------------------------------------------------
+// num / da > L3D_EPS for the four (num, da) pairs of exact_depths, where num = cn_t - n_t.C_s = n_t.(C_t - C_s) for the
+// source rays against the target's plane and num' = cn_s - n_s.C_t = -n_s.(C_t - C_s) for the target rays against the
+// source's plane (up to the double rounding of cn, 1e-16 |C|).  Rays and normals are unit vectors and B = C_t - C_s is a
+// constant of the pair, so the float dot products carry ABSOLUTE errors below 3e-7 (three products of factors rounded
+// to 2^-24 each, two additions) resp. 3e-7 |B|.  When all six of them are at least ten times that far from zero
+// (kDepthTol32, PairDesc::tolB = kDepthTol32 |B| + what the cancellation in cn can add) every exact quantity has the
+// sign of its float value, |da| > 1e-6 is nowhere near the reference's |da| < L3D_EPS guard, and |num / da| >
+// 3e-6 |B| is nowhere near L3D_EPS (the host sets tolB = inf for a pair with |B| < 1e-3, which then never takes this
+// path): the decision is "num and da have the same sign", four multiplications.  Otherwise `certain` comes back false
+// and the caller runs depths_positive on the double records -- a few candidates in a million on the BASELINE scenes.
+// NaN anywhere fails the magnitude comparisons: uncertain.  tests/cpp/depth_sign.cpp pins certain => equal to exact_depths.
+constexpr float kDepthTol32 = 4.0e-6f;
+L3D_HD float dot3f(const float* a, const float* b) { return __builtin_fmaf(a[0], b[0], __builtin_fmaf(a[1], b[1], a[2] * b[2])); }
+L3D_HD bool depths_positive32(const SegD32& s, const SegD32& t, const float* B, float tolB, bool& certain) {
+    const float da = dot3f(s.r1, t.n), db = dot3f(s.r2, t.n), num = dot3f(t.n, B);
+    const float ea = dot3f(t.r1, s.n), eb = dot3f(t.r2, s.n), mun = dot3f(s.n, B);      // second numerator = -mun
+    certain = __builtin_fabsf(da) > kDepthTol32 && __builtin_fabsf(db) > kDepthTol32 && __builtin_fabsf(ea) > kDepthTol32 &&
+              __builtin_fabsf(eb) > kDepthTol32 && __builtin_fabsf(num) > tolB && __builtin_fabsf(mun) > tolB;
+    return num * da > 0.0f && num * db > 0.0f && mun * ea < 0.0f && mun * eb < 0.0f;
 }
 
 // full acceptance test of one (src seg, tgt seg) pair: line3D.cc:931-995

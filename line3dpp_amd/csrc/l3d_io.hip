@@ -111,6 +111,208 @@ void l3d_nvm_intrinsics(float focal, uint32_t width, uint32_t height, double K[9
     K[0] = focal; K[4] = focal; K[2] = px; K[5] = py; K[8] = 1.0;
 }
 
+// ---- COLMAP text result and bundler file: one handle type, one record per image ----------------------------------------
+// l3d_sfm_open_colmap: cameras.txt / images.txt / points3D.txt of a COLMAP result folder as main_colmap.cpp:136-348 reads
+// them -- lines that start with '#' are skipped in the first two files; camera models SIMPLE_PINHOLE, PINHOLE,
+// SIMPLE_RADIAL, RADIAL, OPENCV, FULL_OPENCV (:177-219, anything else is an error: -3 there); images.txt alternates an
+// image line (id, quaternion w x y z, t, camera id, name) with a line of 2D points (x y POINT3D_ID ...), of which the
+// non-negative ids are the worldpoint list handed to addImage; an image whose camera is unknown is dropped (:281);
+// R = rotationFromQ (line3D.cc:2730-2754: s = 2 / |q|^2, 0 for a vanishing quaternion), C = R^T (-t); points3D.txt: EVERY
+// line is parsed as "id X Y Z" (the comment test there looks at the last line of images.txt, :333 -- a line that does
+// not parse is left alone here); median depth = sorted float distances |C - X| [n / 2] over the image's list (:390-406,
+// a point without a points3D entry sits at the origin like in the reference's map); images are kept in file order
+// (img_seq), an image without worldpoints has n_worldpoints == 0 and is skipped by the caller like :389-410 does.
+// l3d_sfm_open_bundler: bundle.rd.out as main_bundler.cpp:147-252 reads it -- an ignored line, "num_cams num_points",
+// per camera focal / two radial coefficients, three rotation rows and the translation with the y and z rows / entries
+// negated (:192-212), C = R^T (-t); per point a position line, an ignored colour line and the view list
+// (count, then camera, key, x, y each); camera index = camID; median depth as above (:371-373).  K is built by the
+// caller from the image size (l3d_nvm_intrinsics: the same construction, :341-350).
+struct l3d_sfm {
+    struct Img {
+        uint32_t id = 0, cam = 0, width = 0, height = 0;
+        std::string name;
+        double K[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, R[9], t[3], C[3], radial[3] = {0, 0, 0}, tangential[2] = {0, 0};
+        float focal = 0, median_depth = 0;
+        std::vector<uint32_t> worldpoints;
+    };
+    std::vector<Img> imgs;
+};
+
+// Line3D::rotationFromQ, line3D.cc:2730-2754
+static void rotation_from_q(double w, double x, double y, double z, double R[9]) {
+    const double n = w * w + x * x + y * y + z * z;
+    const double s = std::fabs(n) < kEps ? 0.0 : 2.0 / n;
+    const double wx = s * w * x, wy = s * w * y, wz = s * w * z, xx = s * x * x, xy = s * x * y, xz = s * x * z;
+    const double yy = s * y * y, yz = s * y * z, zz = s * z * z;
+    R[0] = 1.0 - (yy + zz); R[1] = xy - wz; R[2] = xz + wy;
+    R[3] = xy + wz; R[4] = 1.0 - (xx + zz); R[5] = yz - wx;
+    R[6] = xz - wy; R[7] = yz + wx; R[8] = 1.0 - (xx + yy);
+}
+static void centre_from(const double R[9], const double t[3], double C[3]) {   // R^T (-1 t), Eigen's product order
+    const M3 Rm{{R[0], R[1], R[2], R[3], R[4], R[5], R[6], R[7], R[8]}};
+    const d3 c = mul33(m3_t(Rm).m, d3{-1.0 * t[0], -1.0 * t[1], -1.0 * t[2]});
+    C[0] = c.x; C[1] = c.y; C[2] = c.z;
+}
+static float median_of(std::vector<float>& d) { std::sort(d.begin(), d.end()); return d[d.size() / 2]; }
+
+
+int l3d_sfm_open_colmap(const char* folder, l3d_sfm** out) {
+    if (!folder || !out) return fail(L3D_ERR_ARG, "null argument");
+    *out = nullptr;
+    const std::string dir(folder);
+    std::ifstream fc(dir + "/cameras.txt"), fi(dir + "/images.txt"), fp(dir + "/points3D.txt");
+    if (!fc || !fi || !fp) return fail(L3D_ERR_ARG, "at least one of the colmap result files does not exist in sfm folder: " + dir);
+    struct Cam { double K[9], radial[3], tangential[2]; uint32_t w, h; };
+    std::map<uint32_t, Cam> cams;
+    std::string line;
+    while (std::getline(fc, line)) {
+        if (line.substr(0, 1) == "#") continue;
+        std::stringstream s(line);
+        uint32_t id = 0, w = 0, h = 0; std::string model;
+        s >> id >> model >> w >> h;
+        double fx = 0, fy = 0, cx = 0, cy = 0, k1 = 0, k2 = 0, k3 = 0, p1 = 0, p2 = 0;
+        if (model == "SIMPLE_PINHOLE") { s >> fx >> cx >> cy; fy = fx; }
+        else if (model == "PINHOLE") s >> fx >> fy >> cx >> cy;
+        else if (model == "SIMPLE_RADIAL") { s >> fx >> cx >> cy >> k1; fy = fx; }
+        else if (model == "RADIAL") { s >> fx >> cx >> cy >> k1 >> k2; fy = fx; }
+        else if (model == "OPENCV") s >> fx >> fy >> cx >> cy >> k1 >> k2 >> p1 >> p2;
+        else if (model == "FULL_OPENCV") s >> fx >> fy >> cx >> cy >> k1 >> k2 >> p1 >> p2 >> k3;
+        else return fail(L3D_ERR_ARG, "camera model " + model + " unknown!");
+        Cam c{{fx, 0, cx, 0, fy, cy, 0, 0, 1}, {k1, k2, k3}, {p1, p2}, w, h};
+        cams[id] = c;
+    }
+    auto sfm = std::make_unique<l3d_sfm>();
+    std::map<uint32_t, size_t> by_id;                          // image id -> record (a repeated id overwrites, like the maps there)
+    std::map<uint32_t, d3> wps;                                // worldpoints seen in images.txt (origin until points3D.txt says otherwise)
+    bool first = true;
+    uint32_t img_id = 0, cam_id = 0;
+    while (std::getline(fi, line)) {
+        if (line.substr(0, 1) == "#") continue;
+        std::stringstream s(line);
+        if (first) {
+            double qw = 0, qx = 0, qy = 0, qz = 0, tx = 0, ty = 0, tz = 0; std::string name;
+            s >> img_id >> qw >> qx >> qy >> qz >> tx >> ty >> tz >> cam_id >> name;
+            auto ci = cams.find(cam_id);
+            if (ci != cams.end()) {
+                l3d_sfm::Img im;
+                im.id = img_id; im.cam = cam_id; im.name = name; im.width = ci->second.w; im.height = ci->second.h;
+                std::memcpy(im.K, ci->second.K, 72); std::memcpy(im.radial, ci->second.radial, 24); std::memcpy(im.tangential, ci->second.tangential, 16);
+                rotation_from_q(qw, qx, qy, qz, im.R);
+                im.t[0] = tx; im.t[1] = ty; im.t[2] = tz;
+                centre_from(im.R, im.t, im.C);
+                im.focal = (float)im.K[0];
+                auto it = by_id.find(img_id);
+                if (it == by_id.end()) { by_id[img_id] = sfm->imgs.size(); sfm->imgs.push_back(im); }
+                else { im.worldpoints = sfm->imgs[it->second].worldpoints; sfm->imgs[it->second] = im; sfm->imgs.push_back(im); by_id[img_id] = sfm->imgs.size() - 1; }
+            }
+            first = false;
+        } else {
+            if (cams.count(cam_id)) {
+                std::vector<uint32_t> list;
+                for (;;) {
+                    double x, y; std::string wp;
+                    s >> x >> y >> wp;
+                    if (wp.empty()) break;
+                    const int id = std::atoi(wp.c_str());
+                    if (id >= 0) { list.push_back((uint32_t)id); wps[(uint32_t)id] = d3{0, 0, 0}; }
+                }
+                auto it = by_id.find(img_id);
+                if (it != by_id.end()) sfm->imgs[it->second].worldpoints = list;
+            }
+            first = true;
+        }
+    }
+    while (std::getline(fp, line)) {
+        std::stringstream s(line);
+        uint32_t id = 0; double X = 0, Y = 0, Z = 0;
+        s >> id >> X >> Y >> Z;
+        if (!s) continue;                                      // (a comment or malformed line)
+        auto it = wps.find(id);
+        if (it != wps.end()) it->second = d3{X, Y, Z};
+    }
+    // a repeated image id: img_seq holds it twice, both entries see the LAST pose and list (the maps are keyed by id)
+    for (auto& im : sfm->imgs) { const l3d_sfm::Img& last = sfm->imgs[by_id[im.id]]; if (&last != &im) im = last; }
+    for (auto& im : sfm->imgs) {
+        std::vector<float> depths;
+        for (uint32_t w : im.worldpoints) depths.push_back((float)norm(d3{im.C[0], im.C[1], im.C[2]} - wps[w]));
+        if (!depths.empty()) im.median_depth = median_of(depths);
+    }
+    *out = sfm.release();
+    return L3D_OK;
+}
+
+int l3d_sfm_open_bundler(const char* path, l3d_sfm** out) {
+    if (!path || !out) return fail(L3D_ERR_ARG, "null argument");
+    *out = nullptr;
+    std::ifstream f(path);
+    if (!f) return fail(L3D_ERR_ARG, std::string("bundle file '") + path + "' does not exist!");
+    std::string line;
+    std::getline(f, line); std::getline(f, line);             // first line ignored
+    uint32_t n_cams = 0, n_pts = 0;
+    { std::stringstream s(line); s >> n_cams >> n_pts; }
+    if (n_cams == 0 || n_pts == 0) return fail(L3D_ERR_NO_VIEWS, "No cameras and/or points in bundle file!");   // main_bundler.cpp:160-164
+    auto sfm = std::make_unique<l3d_sfm>();
+    sfm->imgs.resize(n_cams);
+    auto next = [&](std::stringstream& s) { std::getline(f, line); s.str(""); s.clear(); s.str(line); };
+    std::stringstream s;
+    for (uint32_t i = 0; i < n_cams; ++i) {
+        l3d_sfm::Img& im = sfm->imgs[i];
+        im.id = i; im.cam = i;
+        double focal = 0, d1 = 0, d2 = 0;
+        next(s); s >> focal >> d1 >> d2;
+        im.focal = (float)focal; im.radial[0] = (double)(float)d1; im.radial[1] = (double)(float)d2;   // (float pairs there, :170-176)
+        for (int j = 0; j < 3; ++j) { next(s); s >> im.R[3 * j] >> im.R[3 * j + 1] >> im.R[3 * j + 2]; }
+        for (int k = 3; k < 9; ++k) im.R[k] *= -1.0;          // flip 2nd and 3rd line
+        next(s); s >> im.t[0] >> im.t[1] >> im.t[2];
+        im.t[1] *= -1.0; im.t[2] *= -1.0;
+        centre_from(im.R, im.t, im.C);
+    }
+    std::vector<std::vector<float>> depths(n_cams);
+    for (uint32_t i = 0; i < n_pts; ++i) {
+        double px = 0, py = 0, pz = 0;
+        if (!std::getline(f, line)) break;
+        { std::istringstream p(line); p >> px >> py >> pz; }
+        std::getline(f, line);                                // colour
+        std::getline(f, line);
+        std::istringstream v(line);
+        uint32_t n_views = 0;
+        v >> n_views;
+        for (uint32_t j = 0; j < n_views; ++j) {
+            uint32_t cam = 0, key = 0; float x, y;
+            v >> cam >> key >> x >> y;
+            if (!v || cam >= n_cams) return fail(L3D_ERR_ARG, "malformed view list in bundle file");
+            sfm->imgs[cam].worldpoints.push_back(i);
+            depths[cam].push_back((float)norm(d3{px, py, pz} - d3{sfm->imgs[cam].C[0], sfm->imgs[cam].C[1], sfm->imgs[cam].C[2]}));
+        }
+    }
+    for (uint32_t i = 0; i < n_cams; ++i) if (!depths[i].empty()) sfm->imgs[i].median_depth = median_of(depths[i]);
+    *out = sfm.release();
+    return L3D_OK;
+}
+
+uint32_t l3d_sfm_num_images(const l3d_sfm* s) { return s ? (uint32_t)s->imgs.size() : 0u; }
+
+int l3d_sfm_get_image(const l3d_sfm* s, uint32_t i, l3d_sfm_image* out) {
+    if (!s || !out || i >= s->imgs.size()) return fail(L3D_ERR_ARG, "bad argument");
+    const l3d_sfm::Img& im = s->imgs[i];
+    out->id = im.id; out->camera = im.cam; out->width = im.width; out->height = im.height; out->name = im.name.c_str();
+    out->focal = im.focal; out->median_depth = im.median_depth; out->n_worldpoints = (uint32_t)im.worldpoints.size();
+    std::memcpy(out->K, im.K, 72); std::memcpy(out->R, im.R, 72); std::memcpy(out->t, im.t, 24); std::memcpy(out->C, im.C, 24);
+    std::memcpy(out->radial, im.radial, 24); std::memcpy(out->tangential, im.tangential, 16);
+    return L3D_OK;
+}
+
+int l3d_sfm_get_worldpoints(const l3d_sfm* s, uint32_t i, uint32_t* out, uint32_t cap) {
+    if (!s || i >= s->imgs.size() || (cap && !out)) return fail(L3D_ERR_ARG, "bad argument");
+    const auto& w = s->imgs[i].worldpoints;
+    if (cap && !w.empty()) std::memcpy(out, w.data(), 4 * (size_t)std::min<size_t>(cap, w.size()));
+    return w.size() > cap ? fail(L3D_ERR_LIMIT, "worldpoint buffer too small") : L3D_OK;
+}
+
+void l3d_sfm_close(l3d_sfm* s) { delete s; }
+
+
+
 // ---- segment cache ----------------------------------------------------------------------------------------------------
 static const char kArchiveSig[] = "serialization::archive";            // 22 characters
 static const unsigned char kPlatform[8] = {4, 8, 4, 8, 1, 0, 0, 0};   // sizes of int, long, float, double; endianness

@@ -51,7 +51,7 @@ struct CullPools {
     // what the exact tests read of a target, in sorted order as well (the candidates of a wave are neighbours in that
     // order: gathers by original index miss the L2s on large views -- C4 read 132 x its segment records)
     float4* tgt_s4;            // [sum Mt] raw segments (x1,y1,x2,y2)
-    SegD* tgt_sd;              // [sum Mt] rays, plane normal, plane offset (the depth test's share of SegX)
+    SegD32* tgt_sd;            // [sum Mt] rays and plane normal in float (the depth decision's share of SegX, l3d_dev.h SegD32)
 };
 constexpr uint32_t kOrderBuckets = 1024;
 constexpr uint32_t kCullLdsSegs = 16384;   // LDS sort capacity of k_cull_prepare (larger views sort in global memory)
@@ -59,8 +59,8 @@ constexpr uint32_t kCullMaxSegs = 1u << 20; // 20 index bits in the sort keys be
 
 // the orientation filter of phase B fused into whatever produces a slot (match epilogue, exchange expansion)
 struct OrientFuse {
-    unsigned long long* cnt_pack;   // [G] packed hypothesis counters of the global segments (k_orient_all)
-    uint32_t* inv_pos;              // [n_slots] position of a slot among the inverse refs of its target segment
+    uint32_t* inv_tgt;              // [n_slots] target segment of a slot that hands an inverse match to its target view
+                                    // (kSlotInvAlive), kEmpty otherwise: the 4-byte stream k_pair_csr sorts by target
     OrientThr thr;
     // rows in which the match kernel saw equal overlaps (the reference's heap order decides there): (pair, source row),
     // replayed by k_match_tied_rows
@@ -100,27 +100,28 @@ hipError_t launch_pack_slot_idx(const Slot* slots, uint32_t* idx, uint64_t lo, u
 hipError_t launch_expand_slot_idx(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
                                   uint32_t max_row_slots, const uint32_t* idx, Slot* slots, OrientFuse of,
                                   hipStream_t stream);
-// per-segment invariants of all views; cnt_pack (may be null): [G + 1] packed counters zeroed on the way
-hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, unsigned long long* cnt_pack,
-                             uint32_t G, hipStream_t stream);
+// per-segment invariants of all views
+hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, hipStream_t stream);
 
 // ---- k_lists.hip: the sparse phase B (l3d_lists.h) ----
-struct InvRec; struct ListPools;
+struct InvRec; struct ListPools; struct PairCsr;
 struct HugeScratchArgs { float* f32; uint32_t* u32; uint64_t* u64; uint32_t cap; uint32_t mean_list; uint32_t run_huge; };   // [2 cap] [3 cap] [cap]; mean list length (estimate)
 hipError_t launch_scan64(const unsigned long long* in, uint32_t n, unsigned long long* out, unsigned long long* tmp,
                          unsigned long long* total, hipStream_t st);
-hipError_t launch_inv_records(const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots, const uint32_t* seg_base,
-                              const Slot* slots, const unsigned long long* off64, const uint32_t* inv_pos, InvRec* recs,
-                              uint32_t tgt_v0, uint32_t tgt_v1, hipStream_t st);
+// the inverse hypotheses of every pair that hands matches to a later view, sorted by target segment (counting sort per
+// pair, one workgroup each): poff = per-pair CSR offsets over the target's segments, refs = the slot indices in that order
+hipError_t launch_pair_csr(const PairDesc* pairs, uint32_t n_pairs, uint32_t max_Mt, const PairCsr* pair_csr,
+                           const uint32_t* inv_tgt, uint32_t* poff, uint32_t* refs, uint32_t* dummy,
+                           uint32_t tgt_v0, uint32_t tgt_v1, hipStream_t st);
 hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, uint32_t world, hipStream_t st);
-struct ListView; struct OutPair;
+struct ListView; struct OutPair; struct InPair;
 hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev* views, const PairDesc* pairs,
-                        const ListView* lviews, const OutPair* opairs, const uint32_t* gseg_view,
-                        const unsigned long long* off64, const InvRec* inv, const Slot* slots, uint32_t uniform_K,
+                        const ListView* lviews, const OutPair* opairs, const InPair* ipairs, const uint32_t* gseg_view,
+                        const uint32_t* poff, const uint32_t* inv_refs, const Slot* slots, uint32_t uniform_K,
                         SimConst sc, ListPools lp, uint32_t* seg_of_g, HugeScratchArgs hsa, hipStream_t st);
 hipError_t launch_chain_sweep(ListPools lp, uint8_t* positive, uint32_t* changed, uint32_t sweep, hipStream_t st);
 hipError_t launch_hyp_scores(ListPools lp, const uint8_t* positive, const uint32_t* gseg_view, Slot* slots,
-                             uint32_t* max_score_bits, hipStream_t st);
+                             const uint8_t* pair_present, uint32_t* max_score_bits, hipStream_t st);
 hipError_t launch_hyp_filter(ListPools lp, uint32_t G, const uint32_t* gseg_view, const uint32_t* max_score_bits,
                              uint32_t* kept_cnt, unsigned long long* best_pack, unsigned long long* cnt64,
                              hipStream_t st);

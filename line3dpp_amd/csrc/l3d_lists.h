@@ -13,18 +13,15 @@
 
 namespace l3d {
 
-// slot (pair, src_row, j) as a potential inverse hypothesis of its target segment, with what the list pass needs
-// (the slot itself is only read again by k_edges if the hypothesis has a supporter): 16 bytes, 16-byte aligned (the
-// 24-byte record of round 2 straddled 32-byte sectors: 2.7 counted bytes per payload byte written), CSR over global
-// segments.  The canonical order of a segment's inverse hypotheses -- (source view, source segment) ascending -- is the
-// order of their slot indices (slots are laid out by pair = by source view, then source row; two slots of one row
-// never share a target), and the source view is pairs[pair].src.
-struct __attribute__((aligned(16))) InvRec {
-    uint32_t ref;        // slot index
-    uint32_t pair;       // directed pair the slot belongs to
-    float dq1, dq2;      // depths of the target segment's end points = this hypothesis' own depths
-};
-static_assert(sizeof(InvRec) == 16, "InvRec is 16 bytes");
+// A slot (pair, src_row, j) whose match survives both orientation tests is a potential INVERSE hypothesis of its target
+// segment (storeInverseMatches, line3D.cc:1672-1699).  Round 4: the slot indices of one directed pair are SORTED BY
+// TARGET SEGMENT (k_pair_csr: a counting sort per pair in LDS -- no device atomics, no position word per slot, no
+// 16-byte records) into `inv_refs`, with a CSR per pair over the target view's segments, stored transposed per target
+// view (`poff`, ListView::pbase).  The canonical order of a segment's inverse hypotheses -- (source view, source
+// segment) ascending -- is the order of their slot indices (slots are laid out by pair = by source view, then source
+// row; two slots of one row never share a target): the incoming pairs of a view in ascending pair index, and inside a
+// pair's run ascending slot index.  k_pair_csr leaves a run in the order its LDS atomics were served; the list pass
+// ranks an entry among the handful of entries of its run and reads the two depths it needs from the slot itself.
 
 // per view / per outgoing pair of a view: what the list pass needs of ViewDev / PairDesc, packed so that a wave gets
 // it with one or two loads instead of a chain of dependent ones (view -> pair list -> pair -> slot)
@@ -32,8 +29,24 @@ struct ListView {
     uint32_t seg_base, M;     // first global segment id, segments
     uint32_t q0, nq;          // outgoing pairs [q0, q0 + nq) in the OutPair table, ascending target view
     float k;                  // View::k_
-    uint32_t pad[3];
+    uint32_t i0, ni;          // incoming pairs that hand inverse matches over: [i0, i0 + ni) in the InPair table,
+                              // ascending pair index (= ascending source view)
+    uint32_t pbase;           // the view's transposed CSR offsets: poff[pbase + t * ni + q], t = 0 .. M, q = 0 .. ni - 1
 };
+// an incoming pair of a view: where its records start
+struct InPair {
+    uint32_t rec_base;        // first record of the pair (= its first slot: a pair never has more records than slots)
+    uint32_t src, pair;       // source view, pair index
+    uint32_t pad;
+};
+static_assert(sizeof(InPair) == 16, "InPair is 16 bytes");
+// per directed pair, for k_pair_csr: where its column of the target view's offset table is
+struct PairCsr {
+    uint32_t base;            // ListView::pbase of the target view (kEmpty: the pair hands nothing over)
+    uint32_t ni, q;           // incoming pairs of the target view, this pair's column
+    uint32_t pad;
+};
+static_assert(sizeof(PairCsr) == 16, "PairCsr is 16 bytes");
 struct OutPair {
     uint64_t slot_off;        // first slot of the pair
     uint32_t tgt, pair, K;    // target view, pair index, slots per source segment
@@ -116,6 +129,7 @@ struct ListPools {
     uint32_t* list2;       // [G] segments for the 2-wave kernel
     uint32_t* list4;       // [G] segments for the 4-wave kernel
     uint32_t* listH;       // [G] segments for the global-memory kernel
+    uint32_t count_entries; // 1: the list pass adds every list's length to cnt[pool * 16 + 5] (statistics; L3D_NO_LIST_STAT=1: off)
     uint32_t pool0, npools; // the pools this pass allocates from (all of them on one GPU; a rank's share when the list
                             // pass is sharded: the filled pools of all ranks are all-gathered slab by slab)
 };

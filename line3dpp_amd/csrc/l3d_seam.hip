@@ -121,7 +121,7 @@ int l3d_score_matches(int device, const float* lines4, uint32_t M, const float* 
         std::memcpy(hv.C, C, 24); std::memcpy(hv.RtKinv, RtKinv, 72);
         hv.seg4 = seg4.p; hv.segf = segf.p; hv.segx = segx.p; hv.M = M; hv.k = k;
         L3D_HIP_CHECK(hipMemcpy(dv.p, &hv, sizeof(hv), hipMemcpyHostToDevice));
-        L3D_HIP_CHECK(launch_prep_views(dv.p, 1, M, nullptr, 0, 0));
+        L3D_HIP_CHECK(launch_prep_views(dv.p, 1, M, 0));
         L3D_HIP_CHECK(launch_seam_entries(n, m4.p, rt.p, dv.p, k, dents.p, 0));
         L3D_HIP_CHECK(launch_bits_len(M, d_off.p, d_len.p, d_long.p, d_scal.p + 1, 0));
         L3D_HIP_CHECK(launch_scan(d_len.p, M, d_boff.p, d_tmp.p, d_scal.p + 0, 0));
@@ -157,14 +157,15 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
     const double* A[2] = {RtKinv_src, RtKinv_tgt};
     const double* Cc[2] = {C_src, C_tgt};
     DevBuf<float4> seg4[2]; DevBuf<SegF> segf[2];
+    DevBuf<SegD32> segd32;   // (float copy of rays + normals, same indexing)
     DevBuf<SegX> segx;   // one array for both views (source first), like the context's global array: the match kernel
                          // derives global segment ids from it for the phase-B counters it feeds
-    DevBuf<unsigned long long> cnt_pack; DevBuf<uint32_t> inv_pos, tie_count; DevBuf<uint2> tie_list; DevBuf<uint64_t> tie_heap;
+    DevBuf<uint32_t> inv_tgt, tie_count; DevBuf<uint2> tie_list; DevBuf<uint64_t> tie_heap;
     DevBuf<double> consts; DevBuf<ViewDev> dv; DevBuf<PairDesc> dp; DevBuf<WorkItem> dw; DevBuf<Slot> ds;
-    DevBuf<PairCull> dc; DevBuf<uint64_t> ckeys; DevBuf<uint32_t> sperm, tperm; DevBuf<float2> sband, tband, cband; DevBuf<float4> tsf, ts4; DevBuf<SegD> tsd;
+    DevBuf<PairCull> dc; DevBuf<uint64_t> ckeys; DevBuf<uint32_t> sperm, tperm; DevBuf<float2> sband, tband, cband; DevBuf<float4> tsf, ts4; DevBuf<SegD32> tsd;
     auto cleanup = [&]() {
         for (int i = 0; i < 2; ++i) { seg4[i].release(); segf[i].release(); }
-        segx.release(); cnt_pack.release(); inv_pos.release();
+        segx.release(); segd32.release(); inv_tgt.release();
         tie_count.release(); tie_list.release(); tie_heap.release();
         consts.release(); dv.release(); dp.release(); dw.release(); ds.release();
         dc.release(); ckeys.release(); sperm.release(); tperm.release(); sband.release(); tband.release(); cband.release(); tsf.release(); ts4.release(); tsd.release();
@@ -173,13 +174,13 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         ViewDev hv[2];
         double hc[24];
         L3D_HIP_CHECK(consts.reserve(24));
-        L3D_HIP_CHECK(segx.reserve((size_t)Ms + Mt));
+        L3D_HIP_CHECK(segx.reserve((size_t)Ms + Mt)); L3D_HIP_CHECK(segd32.reserve((size_t)Ms + Mt));
         for (int i = 0; i < 2; ++i) {
             L3D_HIP_CHECK(seg4[i].reserve(M[i])); L3D_HIP_CHECK(segf[i].reserve(M[i]));
             L3D_HIP_CHECK(hipMemcpy(seg4[i].p, lines[i], (size_t)M[i] * 16, hipMemcpyHostToDevice));
             std::memcpy(hc + 12 * i, A[i], 72); std::memcpy(hc + 12 * i + 9, Cc[i], 24);
             std::memcpy(hv[i].C, Cc[i], 24); std::memcpy(hv[i].RtKinv, A[i], 72);
-            hv[i].seg4 = seg4[i].p; hv[i].segf = segf[i].p; hv[i].segx = segx.p + (i ? Ms : 0u);
+            hv[i].seg4 = seg4[i].p; hv[i].segf = segf[i].p; hv[i].segx = segx.p + (i ? Ms : 0u); hv[i].segd32 = segd32.p + (i ? Ms : 0u);
             hv[i].M = M[i]; hv[i].cam = (uint32_t)i; hv[i].k = 0;
             hv[i].cx = 0.5f * (float)width; hv[i].cy = 0.5f * (float)height; hv[i].pad = 0;
         }
@@ -187,6 +188,7 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         std::memcpy(pd.F, F, 72);
         pd.src = 0; pd.tgt = 1; pd.Ms = Ms; pd.Mt = Mt; pd.K = (uint32_t)kNN; pd.row_off = 0; pd.slot_off = 0;
         pd.cc_dist = 0.0f; pd.flags = 0;   // (the seam entry keeps the compiler's own division / sqrt expansions)
+        pair_baseline(d3{C_src[0], C_src[1], C_src[2]}, d3{C_tgt[0], C_tgt[1], C_tgt[2]}, pd);
         std::vector<WorkItem> work;
         for (uint32_t s0 = 0; s0 < Ms; s0 += kMatchRows) work.push_back(WorkItem{0, s0});
         if (match_lds_bytes(0, pd.K, false, match_waves_per_group(0, false, (uint32_t)work.size())) > 160 * 1024)
@@ -194,7 +196,7 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         L3D_HIP_CHECK(dv.reserve(2)); L3D_HIP_CHECK(dp.reserve(1)); L3D_HIP_CHECK(dw.reserve(work.size()));
         L3D_HIP_CHECK(ds.reserve((size_t)Ms * pd.K));
         L3D_HIP_CHECK(hipMemcpy(dv.p, hv, sizeof(hv), hipMemcpyHostToDevice));
-        L3D_HIP_CHECK(launch_prep_views(dv.p, 2, std::max(Ms, Mt), nullptr, 0, 0));
+        L3D_HIP_CHECK(launch_prep_views(dv.p, 2, std::max(Ms, Mt), 0));
         L3D_HIP_CHECK(hipMemcpy(dp.p, &pd, sizeof(pd), hipMemcpyHostToDevice));
         L3D_HIP_CHECK(hipMemcpy(dw.p, work.data(), work.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
         const float thr = std::fmin(std::fabs(epi_overlap), 0.99f);
@@ -222,13 +224,12 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
             pools.tgt_s4 = ts4.p; pools.tgt_sd = tsd.p;
             L3D_HIP_CHECK(launch_cull_prepare(dv.p, dp.p, 0, 1, std::max(Ms, Mt), pools, 0));
         }
-        // the kernel also applies the orientation filter (slot flags) and feeds the phase-B counters: scratch here
-        L3D_HIP_CHECK(cnt_pack.reserve((size_t)Ms + Mt + 1)); L3D_HIP_CHECK(inv_pos.reserve((size_t)Ms * pd.K));
-        L3D_HIP_CHECK(hipMemset(cnt_pack.p, 0, ((size_t)Ms + Mt + 1) * 8));
+        // the kernel also applies the orientation filter (slot flags) and writes the inverse-target stream: scratch here
+        L3D_HIP_CHECK(inv_tgt.reserve((size_t)Ms * pd.K));
         L3D_HIP_CHECK(tie_count.reserve(4)); L3D_HIP_CHECK(tie_list.reserve(Ms));
         L3D_HIP_CHECK(tie_heap.reserve(2 * (size_t)match_tied_grid(Mt) * std::max(Mt, 1u)));   // (l3d_kernels.h: one scratch region per workgroup)
         L3D_HIP_CHECK(hipMemset(tie_count.p, 0, 16));
-        OrientFuse of{cnt_pack.p, inv_pos.p, OrientThr{-1.0, 1.0}, tie_count.p, tie_list.p, Ms, tie_count.p + 1, tie_count.p + 2};
+        OrientFuse of{inv_tgt.p, OrientThr{-1.0, 1.0}, tie_count.p, tie_list.p, Ms, tie_count.p + 1, tie_count.p + 2};
         orientation_thresholds(of.thr.lo, of.thr.hi);
         L3D_HIP_CHECK(launch_match_pairs(0, false, dv.p, dp.p, dw.p, (uint32_t)work.size(), pd.K, ds.p, nullptr, thr,
                                          pools, of, Mt < 65536u && pd.K < 65536u, 0));

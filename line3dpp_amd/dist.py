@@ -97,14 +97,38 @@ def device_tensor(ptr, nbytes, device):
     return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
 
 
-def _wait_for_exchange(buf, device):
-    """the collective runs on the backend's own stream: the library's stream must not touch `buf` before it is done"""
+def _wait_for_exchange(buf, device, l3d=None):
+    """The collective runs on the backend's own stream; the library's stream must not touch `buf` before it is done.
+    torch's NCCL (= RCCL) backend orders that by itself when the library launches on torch's CURRENT stream: a collective
+    starts after what that stream holds at the call, and Work.wait() (called by the synchronous collectives and by the
+    loops over batch_isend_irecv here) makes that stream -- not the host -- wait for it.  line3dpp_amd.Line3D runs on the
+    stream it was created with (default 0 = torch's default stream), so in the usual set-up nothing is left to do and
+    the host goes on enqueuing (round 3 synchronised the device at every phase boundary: five host round trips per
+    call).  Only a context on ANOTHER stream needs the device-wide wait."""
     if buf.is_cuda:
         import torch
-        torch.cuda.synchronize(device)
+        same = l3d is not None and int(getattr(l3d, "stream", -1)) == int(torch.cuda.current_stream(device).cuda_stream)
+        if not same:
+            torch.cuda.synchronize(device)
 
 
-def gather_slabs(slabs, rank, world_size, device, group=None):
+def _all_ok(ok, device, group):
+    """Every rank learns whether ANY rank failed locally (a HIP error in matchPairs / expandSlotIndices / listsShardViews,
+    an allocation): a rank that left the call on its own would leave its peers inside a collective for ever.  A failing
+    rank therefore keeps taking part in the communication pattern (with whatever its buffers hold) up to the next status
+    exchange, where all ranks give up together.  One int32 MIN all-reduce, placed where the host waits anyway (before
+    the record gather, after l3d_match_finish).  L3D_DIST_STATUS=0 leaves it out."""
+    if os.environ.get("L3D_DIST_STATUS", "1") == "0":
+        return ok
+    import torch
+    import torch.distributed as dist
+    on_gpu = device is not None and dist.get_backend(group) == "nccl"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
+def gather_slabs(slabs, rank, world_size, device, group=None, l3d=None):
     """Every rank's slab of every record array of the sharded list pass (Line3D.listsShard) lands at its place in every
     rank's array.  slabs = [(slab pointer, slab bytes, full-array pointer)]; equal slab sizes by construction.
 
@@ -127,6 +151,10 @@ def gather_slabs(slabs, rank, world_size, device, group=None):
             dist.all_gather_into_tensor(full, mine if full.is_cuda else mine.clone(), group=group)
             continue
         glob = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+        # (P2POp tags are IGNORED by the NCCL / RCCL backend: messages between two ranks are matched in the order in
+        # which both sides post them.  Every rank walks the arrays i and the peers q in the same order and posts, per
+        # (array, peer), its receive then its send, so the k-th transfer from a to b is array k on both sides.  The tag
+        # is what the gloo backend of the CPU tests matches by.)
         for q in range(world_size):       # disjoint slices of one array: sends read `mine`, receives fill the others
             if q != rank:
                 ops.append(dist.P2POp(dist.irecv, full[q * sb:(q + 1) * sb], glob(q), group, tag=i))   # tag = array
@@ -135,7 +163,7 @@ def gather_slabs(slabs, rank, world_size, device, group=None):
         for r in dist.batch_isend_irecv(ops):
             r.wait()
     if slabs:
-        _wait_for_exchange(device_tensor(slabs[0][2], 1, device), device)
+        _wait_for_exchange(device_tensor(slabs[0][2], 1, device), device, l3d)
 
 
 def plan_halo(pairs, M, world_size):
@@ -219,56 +247,65 @@ def match_images_halo(l3d, rank, world_size, device=None, group=None, **params):
     recv = [(r, f, n) for r in range(world_size) for (q, f, n) in runs[r] if q == rank]   # (source rank, first, count)
     halo_pairs = [p for (_, f, n) in send for p in range(f, f + n)]
     early, late = early_ranges(first, count, halo_pairs)
+    # A local failure from here on does NOT leave the call: the rank keeps posting what the plan says (its peers are
+    # inside the same exchanges) and all ranks give up together at the next status exchange (_all_ok).
+    ok = True
     for f, n in early:
-        if n and not l3d.matchPairs(f, n):
-            return give_up()
+        ok = ok and (not n or l3d.matchPairs(f, n))
     for _, f, n in send:
-        if not l3d.packSlotIndices(f, n):
-            return give_up()
+        ok = ok and l3d.packSlotIndices(f, n)
     lap("match_early")
     # ---- the halo: compact indices of whole pair runs, point to point, at the pairs' own places in the index buffer ----
     reqs = []
+    buf = None
     if send or recv:
         ptr, n_slots = l3d.slot_index_buffer()
-        if ptr is None:
-            return give_up()
+        if ptr is None:                # no buffer to exchange through: the one failure that cannot be carried along
+            raise RuntimeError("match_images_halo: the slot index buffer could not be allocated: " + str(getattr(l3d, "last_status", "")))
         buf = device_tensor(ptr, n_slots * 4, device)
         off = [int(o) for o in slot_off] + [int(n_slots)]
 
         def span(f, n):
             return buf[4 * off[f]:4 * off[f + n]]
         glob = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+        # (tags: ignored by NCCL / RCCL, which matches the messages of a pair of ranks in posting order.  Both sides list
+        # the runs between them in ascending pair order -- `recv` is built from the senders' `runs`, which are ascending --
+        # so the k-th send of rank a to rank b meets the k-th receive b posted for a.  gloo matches by the tag.)
         ops = [dist.P2POp(dist.irecv, span(f, n), glob(r), group, tag=f) for (r, f, n) in recv] + \
               [dist.P2POp(dist.isend, span(f, n), glob(q), group, tag=f) for (q, f, n) in send]
         reqs = dist.batch_isend_irecv(ops)
     # ---- the rest of this rank's pairs, matched while the halo travels ----
-    if late[1] and not l3d.matchPairs(late[0], late[1]):
-        for r in reqs:
-            r.wait()
-        return give_up()
+    ok = ok and (not late[1] or l3d.matchPairs(late[0], late[1]))
     lap("match")
     for r in reqs:
         r.wait()
     if reqs:
-        _wait_for_exchange(buf, device)
+        _wait_for_exchange(buf, device, l3d)
     lap("exchange_slots")
     for _, f, n in recv:
-        if not l3d.expandSlotIndices(f, n):
-            return give_up()
+        ok = ok and l3d.expandSlotIndices(f, n)
     for _ in range(8):
-        slabs = l3d.listsShardViews(rank, world_size, int(vb[rank]), int(vb[rank + 1]))
-        if slabs is None:
-            return give_up()
+        slabs = l3d.listsShardViews(rank, world_size, int(vb[rank]), int(vb[rank + 1])) if ok else None
+        ok = ok and slabs is not None
         lap("lists")
-        gather_slabs(slabs, rank, world_size, device, group)
+        if not _all_ok(ok, device, group):
+            return give_up()
+        gather_slabs(slabs, rank, world_size, device, group, l3d)
         lap("exchange_lists")
         rc = l3d.L.l3d_match_finish(l3d.h)
         l3d.last_status = rc
         lap("finish")
-        if rc == 0:
+        # (every rank sees every counter, so rc is the same everywhere unless a rank failed locally: the status exchange
+        # keeps a rank whose finish succeeded from leaving while another is about to repeat the exchange)
+        same = _all_ok(rc in (0, -10), device, group)
+        if rc == 0 and same:
             return True
-        if rc != -10:                  # L3D_ERR_RETRY
+        if not same:
+            if rc in (0, -10):
+                l3d.matchAbort()           # (rc == 0: the call is closed already -- a no-op; the results are discarded)
+                return False
             return l3d._check(rc, "matchFinish")
+        # rc == L3D_ERR_RETRY on every rank: the pools were enlarged alike, repeat the list pass and the exchange
     return give_up()
 
 
@@ -332,7 +369,7 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_l
         if n_slots:
             buf = device_tensor(ptr, n_slots * 4, device)
             exchange_slots(buf, slot_byte_ranges(ranges, slot_off, n_slots, slot_bytes=4), group)
-            _wait_for_exchange(buf, device)
+            _wait_for_exchange(buf, device, l3d)
         lap("exchange_slots")
         ok = (first == 0 or l3d.expandSlotIndices(0, first)) and \
              (first + count == n_pairs or l3d.expandSlotIndices(first + count, n_pairs - first - count))
@@ -344,7 +381,7 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_l
         if n_slots:
             buf = device_tensor(ptr, n_slots * 32, device)
             exchange_slots(buf, slot_byte_ranges(ranges, slot_off, n_slots), group)
-            _wait_for_exchange(buf, device)
+            _wait_for_exchange(buf, device, l3d)
         lap("exchange_slots")
         # every pair is now present on this rank
         l3d.L.l3d_slots_exchanged(l3d.h)
@@ -358,7 +395,7 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_l
                 return give_up()           # (l3d_lists_shard closes the call on every failing exit; matchAbort is a
                                            # no-op then, and the safety net for a binding that fails before the call)
             lap("lists")
-            gather_slabs(slabs, rank, world_size, device, group)
+            gather_slabs(slabs, rank, world_size, device, group, l3d)
             lap("exchange_lists")
             rc = l3d.L.l3d_match_finish(l3d.h)
             l3d.last_status = rc

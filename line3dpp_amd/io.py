@@ -297,3 +297,117 @@ def nvm_intrinsics(focal, width, height):
     """K as main_vsfm.cpp:272-282 builds it: principal point at the image centre (float arithmetic there)"""
     return np.array([[np.float32(focal), 0.0, np.float32(width) / np.float32(2.0)],
                      [0.0, np.float32(focal), np.float32(height) / np.float32(2.0)], [0.0, 0.0, 1.0]], np.float64)
+
+
+# ---- COLMAP text results and bundler files (the Python twin of l3d_sfm_open_colmap / l3d_sfm_open_bundler) --------------
+def rotation_from_q(qw, qx, qy, qz):
+    """Line3D::rotationFromQ, line3D.cc:2730-2754"""
+    n = qw * qw + qx * qx + qy * qy + qz * qz
+    s = 0.0 if abs(n) < 1e-12 else 2.0 / n
+    wx, wy, wz = s * qw * qx, s * qw * qy, s * qw * qz
+    xx, xy, xz = s * qx * qx, s * qx * qy, s * qx * qz
+    yy, yz, zz = s * qy * qy, s * qy * qz, s * qz * qz
+    return np.array([[1.0 - (yy + zz), xy - wz, xz + wy], [xy + wz, 1.0 - (xx + zz), yz - wx], [xz - wy, yz + wx, 1.0 - (xx + yy)]])
+
+
+_COLMAP_MODELS = {  # parameter order of cameras.txt -> (fx, fy, cx, cy, k1, k2, p1, p2, k3), main_colmap.cpp:177-219
+    "SIMPLE_PINHOLE": lambda p: (p[0], p[0], p[1], p[2], 0, 0, 0, 0, 0),
+    "PINHOLE": lambda p: (p[0], p[1], p[2], p[3], 0, 0, 0, 0, 0),
+    "SIMPLE_RADIAL": lambda p: (p[0], p[0], p[1], p[2], p[3], 0, 0, 0, 0),
+    "RADIAL": lambda p: (p[0], p[0], p[1], p[2], p[3], p[4], 0, 0, 0),
+    "OPENCV": lambda p: (p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], 0),
+    "FULL_OPENCV": lambda p: (p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]),
+}
+
+
+def _median_depth(C, pts):
+    d = sorted(np.float32(np.linalg.norm(C - p)) for p in pts)
+    return d[len(d) // 2] if d else None
+
+
+def read_colmap(folder):
+    """cameras.txt / images.txt / points3D.txt as main_colmap.cpp:136-348 reads them -> list of images in file order:
+    dict(id, camera, name, width, height, K, R, t, C, radial (k1, k2, k3), tangential (p1, p2), worldpoints,
+    median_depth or None).  An image whose camera is unknown is dropped; points3D.txt lines that do not parse as
+    "id X Y Z" are ignored; a worldpoint without an entry there sits at the origin (the reference's map default)."""
+    import os
+    cams = {}
+    for line in open(os.path.join(folder, "cameras.txt")).read().split("\n"):
+        if line[:1] == "#" or not line.split():
+            continue
+        tok = line.split()
+        if tok[1] not in _COLMAP_MODELS:
+            raise ValueError(f"camera model {tok[1]} unknown!")
+        fx, fy, cx, cy, k1, k2, p1, p2, k3 = (float(x) for x in _COLMAP_MODELS[tok[1]]([float(x) for x in tok[4:]] + [0.0] * 9))
+        cams[int(tok[0])] = dict(width=int(tok[2]), height=int(tok[3]), K=np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]]),
+                                 radial=np.array([k1, k2, k3]), tangential=np.array([p1, p2]))
+    imgs, by_id, wps = [], {}, {}
+    first, cur = True, None
+    for line in open(os.path.join(folder, "images.txt")).read().split("\n"):
+        if line[:1] == "#":
+            continue
+        tok = line.split()
+        if first:
+            cur = None
+            if len(tok) >= 9 and int(tok[8]) in cams:
+                cam = cams[int(tok[8])]
+                R = rotation_from_q(*(float(x) for x in tok[1:5]))
+                t = np.array([float(x) for x in tok[5:8]])
+                cur = dict(id=int(tok[0]), camera=int(tok[8]), name=tok[9] if len(tok) > 9 else "", R=R, t=t, C=R.T @ (-1.0 * t),
+                           worldpoints=[], **cam)
+                by_id[cur["id"]] = cur
+                imgs.append(cur)
+            first = False
+        else:
+            if cur is not None:
+                lst = []
+                for k in range(2, len(tok), 3):
+                    wp = int(tok[k])
+                    if wp >= 0:
+                        lst.append(wp); wps[wp] = np.zeros(3)
+                cur["worldpoints"] = lst
+            first = True
+    for line in open(os.path.join(folder, "points3D.txt")).read().split("\n"):
+        tok = line.split()
+        try:
+            pid, X, Y, Z = int(tok[0]), float(tok[1]), float(tok[2]), float(tok[3])
+        except (ValueError, IndexError):
+            continue
+        if pid in wps:
+            wps[pid] = np.array([X, Y, Z])
+    for im in imgs:
+        im["median_depth"] = _median_depth(im["C"], [wps[w] for w in im["worldpoints"]])
+    return imgs
+
+
+def read_bundler(path):
+    """bundle.rd.out as main_bundler.cpp:147-252 reads it -> list of cameras (index = camID): dict(id, focal, radial
+    (d1, d2, 0), R, t (second and third row / entry negated), C, worldpoints, median_depth or None)"""
+    lines = open(path).read().split("\n")
+    n_cams, n_pts = (int(x) for x in lines[1].split()[:2])
+    if n_cams == 0 or n_pts == 0:
+        raise ValueError("No cameras and/or points in bundle file!")
+    pos, cams = 2, []
+    for i in range(n_cams):
+        f, d1, d2 = (float(x) for x in lines[pos].split()[:3])
+        R = np.array([[float(x) for x in lines[pos + 1 + j].split()[:3]] for j in range(3)])
+        R[1] *= -1.0; R[2] *= -1.0
+        t = np.array([float(x) for x in lines[pos + 4].split()[:3]])
+        t[1] *= -1.0; t[2] *= -1.0
+        cams.append(dict(id=i, focal=np.float32(f), radial=np.array([np.float32(d1), np.float32(d2), 0.0]), R=R, t=t,
+                         C=R.T @ (-1.0 * t), worldpoints=[], _pts=[]))
+        pos += 5
+    for i in range(n_pts):
+        if pos + 2 >= len(lines):
+            break
+        p = np.array([float(x) for x in lines[pos].split()[:3]])
+        tok = lines[pos + 2].split()
+        for j in range(int(tok[0])):
+            cam = int(tok[1 + 4 * j])
+            if cam >= n_cams:
+                raise ValueError("malformed view list in bundle file")
+            cams[cam]["worldpoints"].append(i); cams[cam]["_pts"].append(p)
+        pos += 3
+    for c in cams:
+        c["median_depth"] = _median_depth(c["C"], c.pop("_pts"))
+    return cams

@@ -48,5 +48,54 @@ int main() {
             if (got != want) { if (++bad < 10) std::printf("MISMATCH mode %d it %d want %d got %d\n", mode, it, (int)want, (int)got); }
         }
     std::printf("%lu cases, %lu accepted, %lu through the fallback, %lu mismatches -> %s\n", n, accepted, sliver, bad, bad ? "FAILED" : "identical");
-    return bad ? 1 : 0;
+
+    // ---- the float decision of round 4 (depths_positive32): whenever it reports `certain`, it must equal exact_depths ----
+    // geometry as the match kernel sees it: unit rays / normals rounded to float, cn = C.n in double, B = C_t - C_s and
+    // tolB as l3d_api.hip: pair_baseline computes them.  Modes: random; a ray within 1e-5 .. 1e-8 of the other plane
+    // (da near zero); the baseline within 1e-5 .. 1e-9 of a plane (num near zero); camera centres of very different
+    // magnitude (cancellation in cn); tiny baselines (tolB infinite: never certain); NaN.
+    unsigned long n32 = 0, cert = 0, bad32 = 0, acc32 = 0;
+    auto f3 = [](const double* v, float* o) { o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; };
+    for (int mode = 0; mode < 6; ++mode)
+        for (int it = 0; it < 400000; ++it) {
+            SegX sx, tx; double Cs[3], Ct[3];
+            unit(sx.r1); unit(sx.r2); unit(sx.n); unit(tx.r1); unit(tx.r2); unit(tx.n); unit(sx.rm); unit(tx.rm);
+            const double scale = mode == 3 ? std::pow(10.0, 6 * U(rng)) : 10.0;
+            for (int k = 0; k < 3; ++k) { Cs[k] = scale * U(rng); Ct[k] = (mode == 3 ? 10.0 : scale) * U(rng); }
+            if (mode == 4) for (int k = 0; k < 3; ++k) Ct[k] = Cs[k] + std::pow(10.0, -2 - 4 * std::fabs(U(rng))) * U(rng);
+            auto tilt = [&](double* v, const double* n, double eps) {   // make v . n = eps (v stays unit up to eps^2)
+                const double d = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
+                for (int k = 0; k < 3; ++k) v[k] -= (d - eps) * n[k];
+                const double l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                for (int k = 0; k < 3; ++k) v[k] /= l;
+            };
+            if (mode == 1) tilt((it & 1) ? sx.r1 : tx.r2, (it & 1) ? tx.n : sx.n, std::pow(10.0, -5 - 3 * std::fabs(U(rng))) * (U(rng) > 0 ? 1 : -1));
+            if (mode == 2) {   // n_t (or n_s) nearly perpendicular to the baseline
+                double B[3] = {Ct[0] - Cs[0], Ct[1] - Cs[1], Ct[2] - Cs[2]};
+                const double l = std::sqrt(B[0] * B[0] + B[1] * B[1] + B[2] * B[2]);
+                for (int k = 0; k < 3; ++k) B[k] /= l;
+                tilt((it & 1) ? tx.n : sx.n, B, std::pow(10.0, -5 - 4 * std::fabs(U(rng))) * (U(rng) > 0 ? 1 : -1));
+            }
+            if (mode == 5 && (it % 5) == 0) tx.n[1] = NAN;
+            sx.cn = Cs[0] * sx.n[0] + (Cs[1] * sx.n[1] + Cs[2] * sx.n[2]);
+            tx.cn = Ct[0] * tx.n[0] + (Ct[1] * tx.n[1] + Ct[2] * tx.n[2]);
+            PairResult res{};
+            const bool want = exact_depths(sx, tx, Cs, Ct, res);
+            SegD32 s32{}, t32{};
+            f3(sx.r1, s32.r1); f3(sx.r2, s32.r2); f3(sx.n, s32.n); f3(tx.r1, t32.r1); f3(tx.r2, t32.r2); f3(tx.n, t32.n);
+            // pair_baseline (l3d_api.hip), restated
+            const double Bd[3] = {Ct[0] - Cs[0], Ct[1] - Cs[1], Ct[2] - Cs[2]};
+            const double nb = std::sqrt(Bd[0] * Bd[0] + (Bd[1] * Bd[1] + Bd[2] * Bd[2]));
+            double nc = 0; for (int k = 0; k < 3; ++k) nc += std::fabs(Cs[k]) + std::fabs(Ct[k]);
+            const float B[3] = {(float)Bd[0], (float)Bd[1], (float)Bd[2]};
+            const double tol = (double)kDepthTol32 * nb * (1.0 + 1e-6) + 1e-14 * nc;
+            const float tolB = (nb >= 1e-3 && nb <= 1e30 && nc <= 1e30) ? std::nextafterf((float)tol, INFINITY) : INFINITY;
+            bool certain = false;
+            const bool got = depths_positive32(s32, t32, B, tolB, certain);
+            ++n32; cert += certain; acc32 += want;
+            if (certain && got != want) { if (++bad32 < 10) std::printf("MISMATCH32 mode %d it %d want %d got %d\n", mode, it, (int)want, (int)got); }
+        }
+    std::printf("float decision: %lu cases, %lu accepted, %lu certain, %lu mismatches among the certain -> %s\n", n32, acc32, cert, bad32,
+                bad32 ? "FAILED" : "identical");
+    return (bad || bad32) ? 1 : 0;
 }

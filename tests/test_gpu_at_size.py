@@ -108,3 +108,69 @@ def test_slice_of_c2_c4_at_configured_size(config, count, mid):
     _assert_clean(r, 10_000, 1_000)
     n, ties = _phase_a_sample(g, sc, 32)
     assert n > 1_000_000
+
+
+def test_keep_all_mode_at_c1_size_through_the_culled_walk(monkeypatch):
+    """kNN <= 0 (every accepted match is kept, in ascending target order: line3D.cc:982-992).  Until round 3 this mode
+    streamed every pair unculled; it now takes the epipolar-band walk like the bounded mode and the fill pass sorts each
+    row by target afterwards.  Full C1 phase A: 32 sampled directed pairs bit for bit and in the reference's order
+    against matchingCPU of the restatement (pinned byte for byte on the reference's own code), culled and unculled
+    (L3D_KEEPALL_NO_CULL=1) giving the same slots, the culled passes several times faster; then the whole pipeline in
+    this mode against the reference's own code on a quarter-size scene (its scoring is quadratic in the list length)."""
+    from line3dpp_amd.api import Line3D
+    from line3dpp_amd.scene import make_scene
+    sc = make_config("C1")
+    out = {}
+    for name, env in (("culled", None), ("unculled", "1")):
+        if env:
+            monkeypatch.setenv("L3D_KEEPALL_NO_CULL", env)
+        else:
+            monkeypatch.delenv("L3D_KEEPALL_NO_CULL", raising=False)
+        g = Line3D()
+        g.add_scene(sc)
+        n_pairs = None
+        for rep in range(2):                                   # second call: warm pools, the time that counts
+            assert g.matchBegin(kNN=0)
+            n_pairs = len(g.pairs()[0])
+            assert g.matchPairs(0, n_pairs)
+            tm = g.timings()
+            if rep == 0:
+                assert g.matchAbort()
+        out[name] = (g, tm["match_pairs_ms"], tm["culled_pairs"])
+    (gc, ms_c, culled), (gu, ms_u, unculled) = out["culled"], out["unculled"]
+    assert culled == 2 * n_pairs and unculled == 0        # (both passes -- count and fill -- take the culled walk)
+    rng = np.random.default_rng(5)
+    sample = rng.choice(n_pairs, 32, replace=False)
+    for pi in sample:
+        a, b = gc.pair_slots(int(pi)), gu.pair_slots(int(pi))
+        assert a.shape == b.shape and np.array_equal(a["tgt_seg"], b["tgt_seg"]) and np.array_equal(a["overlap"], b["overlap"])
+        assert np.array_equal(a["d_p1"], b["d_p1"]) and np.array_equal(a["d_q2"], b["d_q2"])
+    from oracle import oracle as O
+    o = O.Oracle(threads=THREADS)
+    o.add_scene(sc)
+    o.begin_match(kNN=0)
+    pairs, _ = gc.pairs()
+    total = 0
+    for pi in sample:
+        om, _ = o.match_pair(int(pairs[pi][0]), int(pairs[pi][1]))
+        r = H.compare_pair_fast(gc.pair_slots(int(pi)), om)
+        assert r["set_diff"] == 0 and r["inexact_fields"] == 0 and r["order_rows"] == 0, (int(pi), r)
+        total += r["n_cpu"]
+    o.end_match()
+    assert total > 500_000
+    print(f"keep-all C1 phase A: culled {ms_c:.2f} ms, unculled {ms_u:.2f} ms ({ms_u / ms_c:.1f} x), {total} matches in 32 sampled pairs identical")
+    assert ms_u > 2.0 * ms_c, (ms_c, ms_u)
+    gc.matchAbort(); gu.matchAbort(); gc.close(); gu.close()
+    # the whole pipeline in this mode, against the reference's own code
+    monkeypatch.delenv("L3D_KEEPALL_NO_CULL", raising=False)
+    sq = make_scene(16, 1000, n_neighbors=6, seed=23)
+    g = Line3D()
+    g.add_scene(sq)
+    assert g.matchImages(kNN=0) and g.computeAffinity()
+    assert O.have_reference()
+    oq = O.Oracle(threads=THREADS, reference=True)
+    oq.add_scene(sq)
+    oq.match_images(kNN=0); oq.compute_affinity()
+    r = H.full_result_diff(g, oq, sq)
+    assert r["ok"] and r["set_diff"] == 0 and r["order_rows"] == 0 and r["inexact_phase_a_fields"] == 0, r
+    assert r["surviving"] > 10_000

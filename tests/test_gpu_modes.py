@@ -252,3 +252,16 @@ def test_worldpoint_lists_instead_of_neighbour_lists(num_neighbors):
     v = sc.views[0]
     g.addImage(999, (v.width, v.height), v.K, v.R, v.t, v.median_depth, [], v.segs)
     assert g.last_status == -4
+
+
+def test_inverse_hypotheses_sorted_with_global_cursors_equal_the_lds_form(monkeypatch):
+    """k_pair_csr (round 4: the inverse hypotheses of a pair counting-sorted by target segment) keeps its cursors in
+    LDS; views beyond the LDS capacity (more than 32 768 segments) keep them in the pair's own offset array.  The test
+    hook L3D_CSR_GLOBAL=1 sends every pair through that second form: same result as the reference's own code, on a scene
+    with ragged views and long lists (more neighbours than usual)."""
+    sc = make_scene(9, 420, n_neighbors=6, seed=31)
+    monkeypatch.setenv("L3D_CSR_GLOBAL", "1")
+    g = _gpu(sc)
+    assert g.matchImages() and g.computeAffinity()
+    r = _assert_same(g, _ref(sc, [{}]), sc)
+    assert r["surviving"] > 1000

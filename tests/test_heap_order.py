@@ -18,13 +18,17 @@ def test_division_free_depth_decision_equals_the_reference_arithmetic(tmp_path):
     """l3d_dev.h: depths_positive (stage 1 of the match kernel's candidate pipeline: the accept / reject decision of
     Line3D::triangulationDepths + line3D.cc:966-980 with one multiplication per depth, falling back to the division in
     the sliver where the two roundings could disagree) against exact_depths on 2.4 million cases incl. depths within a
-    few ulp of L3D_EPS, degenerate denominators, NaN and inf."""
+    few ulp of L3D_EPS, degenerate denominators, NaN and inf -- and, since round 4, the FLOAT decision on 48-byte records
+    (depths_positive32) on another 2.4 million cases incl. rays within 1e-5 .. 1e-8 of the other segment's plane,
+    baselines within 1e-5 .. 1e-9 of a plane, camera centres six orders of magnitude apart, tiny baselines and NaN: whenever
+    it reports `certain` it must equal exact_depths (uncertain candidates take the double-precision decision)."""
     exe = str(tmp_path / "depth_sign")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
                            os.path.join(ROOT, "tests", "cpp", "depth_sign.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "identical" in out.stdout and " 0 mismatches" in out.stdout
+    assert "float decision" in out.stdout and "0 mismatches among the certain" in out.stdout
 
 
 def test_division_free_orientation_decision_equals_the_reference_arithmetic(tmp_path):

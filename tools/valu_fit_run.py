@@ -19,7 +19,7 @@ sc = make_scene(16, 2000, n_neighbors=10, seed=7)
 g = Line3D(); g.add_scene(sc)
 L = _lib.load()
 stats = hasattr(L, "l3d_debug_stats")
-out = (C.c_ulonglong * 12)()
+out = (C.c_ulonglong * 16)()
 rows = []
 for thr, k in RUNS:
     if stats:
