@@ -203,10 +203,13 @@ def multi_gpu_model(pairs, M, kNN, phase, lists_ms, record_bytes):
     term, from THIS run's single-GPU phase times and the plan the N ranks would follow (l3d_plan_shards): no multi-GPU
     box has been available to measure it, so the terms are printed for whoever has one.  Assumptions stated in the
     output: 153 GB/s per xGMI link and direction, direct exchange of the record slabs (one slab per link of the full xGMI mesh; the ring figure is printed beside it), expansion of a received slot at the
-    round-2 measured 2.8e-5 us, 0.03 ms of host latency per synchronisation point (5 per call)."""
+    round-2 measured 2.8e-5 us, 0.03 ms of host latency per synchronisation point (3 per call since round 4: the exchanges
+    are ordered on the stream, dist.py) and 0.02 ms for each of the two status exchanges (dist.py: _all_ok)."""
     from line3dpp_amd import dist as l3d_dist
     cost = np.asarray([M[s] * M[t] for s, t in pairs], np.float64)
-    out = {"assumptions": {"link_GB_per_s": 153.0, "record_gather": "direct: one slab per link, all peers at once (full xGMI mesh); a ring would take (N-1) slab times", "expand_us_per_slot": 2.8e-5, "host_sync_ms": 0.03,
+    out = {"MODELLED_NOT_MEASURED": "no multi-GPU node has been available: every figure below is arithmetic on this run's single-GPU phase times",
+           "assumptions": {"link_GB_per_s": 153.0, "record_gather": "direct: one slab per link, all peers at once (full xGMI mesh); a ring would take (N-1) slab times", "expand_us_per_slot": 2.8e-5, "host_sync_ms": 0.03, "status_allreduce_ms": 0.02,
+                            "host_sync_points": "3 (pack, list pass, finish) + 2 status exchanges; round 3 synchronised the device at 5 points",
                             "record_bytes": int(record_bytes)}}
     tail_ms = max(phase["finish"] - lists_ms, 0.0)
     t1 = phase["begin"] + phase["match"] + phase["finish"] + phase["affinity"]
@@ -223,7 +226,7 @@ def multi_gpu_model(pairs, M, kNN, phase, lists_ms, record_bytes):
                  "halo_exchange_hidden_behind_matching_MB": round(4e-6 * halo_slots, 2),
                  "expand_received_pairs": 2.8e-5 * 1e-3 * halo_slots, "list_pass_own_views": lists_ms / n,
                  "gather_records_direct": 1e3 * record_bytes / n / 153e9, "gather_records_if_ring": 1e3 * (n - 1) / n * record_bytes / 153e9, "tail_replicated": tail_ms,
-                 "affinity_replicated": phase["affinity"], "host_syncs": 0.15}
+                 "affinity_replicated": phase["affinity"], "host_syncs": 3 * 0.03 + 2 * 0.02}
         total = sum(v for k, v in terms.items() if not k.endswith("_MB") and not k.endswith("_if_ring"))
         out[str(n)] = {"terms_ms": {k: round(v, 4) for k, v in terms.items()}, "total_ms": round(total, 4),
                        "speedup_over_1_gpu": round(t1 / total, 2), "largest_pair_share": round(share, 4)}

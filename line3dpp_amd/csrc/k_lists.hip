@@ -295,9 +295,9 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
     const float vk = lv.k;
     const uint32_t q0 = lv.q0, nq = lv.nq;
     const uint32_t T = uniform_K ? nq * uniform_K : 0u;
-    // (measured and not adopted, profiles/r04_ab_list_pass.txt: requesting the fresh slots BEFORE the inverse chain and
-    // holding them in registers -- the two load chains side by side, and the list's length known before anything is
-    // staged -- took the one-wave tier from 32 to 70 VGPRs and made it 8 % slower)
+    // (measured twice and not adopted, profiles/r04_ab_list_pass.txt: requesting the fresh slots BEFORE the inverse chain
+    // and holding them in registers so that the two load chains run side by side -- 8 % slower with eight registers per
+    // slot (70 VGPRs), 2-3 % slower in a lean form with five (56 VGPRs): the tier is bound by issue, not by the chains)
     // ---- inverse hypotheses: the segment's row of every incoming pair's CSR, pairs in ascending index (= ascending
     // source view), the entries of a row in ascending slot index -- that IS the canonical order.  The rows' starts and
     // their prefix within the list are staged in LDS (the keys array is not needed yet); an entry finds its row by a scan

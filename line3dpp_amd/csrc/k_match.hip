@@ -91,10 +91,6 @@ struct Lds {
     static constexpr idx_t kTie = (idx_t)((idx_t)1 << (8 * sizeof(idx_t) - 1));
 };
 
-// keep-all fill pass (MODE 2): staging area of the row sort behind the (table-less) carve: ring + four 64-entry arrays
-constexpr uint32_t kKeepSortCap = 512;
-__host__ __device__ constexpr uint32_t keep_sort_offset() { return (uint32_t)kRing * 4u + 4u * kBlock * 4u; }
-
 template <bool IX16>
 __device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K, uint32_t waves, bool two_rings) {
     typedef typename IdxT<IX16>::type idx_t;
@@ -213,9 +209,12 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     constexpr idx_t kTie = Lds<IX16>::kTie;
     L3D_LDS volatile uint32_t* ring = L.ring + q * kRingN;
     L3D_LDS volatile uint32_t* ring2 = L.ring2 + q * kRing2;
-    // epipolar-band culling (round 4: in the keep-all mode as well -- its rows must come out in ascending target order,
-    // which the culled walk does not deliver: the fill pass sorts every row it has filled, epilogue below)
-    const PairCull* pc = (!BRUTE && cp.cull && cp.cull[wi.pair].enabled) ? &cp.cull[wi.pair] : nullptr;
+    // epipolar-band culling.  Keep-all mode (round 4): the COUNT pass takes the culled walk as well (a count does not
+    // depend on the order); the FILL pass streams unculled, because a row must come out in ascending target order
+    // (line3D.cc:987-992) and that is the order in which an unculled row's matches arrive.  Measured on C1
+    // (profiles/r04_keepall.txt): count 1388 -> 660 us; a culled fill pass (1737 -> 1329 us) followed by a sort of every
+    // row (744 us as a kernel of its own, 3500 us inside the epilogue) was slower than streaming.
+    const PairCull* pc = (MODE != 2 && !BRUTE && cp.cull && cp.cull[wi.pair].enabled) ? &cp.cull[wi.pair] : nullptr;
     const bool cull = pc != nullptr;
     const bool active = wi.src0 + tid < Ms;
     uint32_t src = wi.src0 + tid;
@@ -354,12 +353,14 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t sg = __shfl(src, sl);
         bool pending = false;
         float ovv = 0.0f;
-#if defined(L3D_LAUNDER) || defined(L3D_LAUNDER_F)
+        // F is fetched per drain through a laundered pointer (wave-uniform control flow: scalar loads): hoisted out of the
+        // walk its 18 scalar registers -- with everything else the stages need -- made the walk's loop reload spilled
+        // scalars from vector lanes at every step (four v_readlane per two targets: the record base pointer and the lane
+        // mask).  Round 3 measured this switch as neutral; since the depth decision of stage 1 runs on floats (no camera
+        // centres in scalar registers either) it removes the reloads: C4 -8.7 %, C2 -3.5 %, C1 -1 % (profiles/r04_ab_match.txt).
+#ifndef L3D_NO_LAUNDER_F
         const double* Fp = pd.F;
         asm volatile("" : "+s"(Fp));
-#elif defined(L3D_LAUNDER_F2)
-        const double* Fp = F;
-        if (WPG == 2) { Fp = pd.F; asm volatile("" : "+s"(Fp)); }
 #else
         const double* Fp = F;
 #endif
@@ -688,52 +689,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             empty.score3D = 0; empty.flags = 0;
             for (uint32_t j = min(c, K); j < K; ++j) row[j] = empty;
         }
-        if (!cull) return;     // streamed unculled: a row's matches arrived in ascending target order (drain, lowest lane first)
-        // Culled walk (round 4): the matches of a row arrived in walk order; Line3D::matchingCPU pushes them in ascending
-        // target index (line3D.cc:987-992).  The wave sorts one row after the other: the row is staged in LDS (up to
-        // kKeepSortCap entries: 16 KiB), every entry counts the row's smaller targets and goes to that place.  A longer
-        // row is sorted in place by one lane (insertion sort: correct for any length, slow, practically never taken).
-        L3D_LDS uint32_t* stage = (L3D_LDS uint32_t*)(smem + keep_sort_offset());
-        const uint32_t n_rows = min((uint32_t)kBlock, Ms - wi.src0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // the rows were written by other lanes of this wave
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        for (uint32_t r = 0; r < n_rows; ++r) {
-            const uint32_t cr = min((uint32_t)__builtin_amdgcn_readlane(c, r), K);
-            if (cr < 2) continue;
-            Slot* row = slots + pd.slot_off + (uint64_t)__builtin_amdgcn_readlane(src, r) * K;
-            if (cr <= kKeepSortCap) {
-                for (uint32_t j = lane; j < cr; j += 64) {
-                    const v4u* p = (const v4u*)&row[j];
-                    const v4u a = p[0], b = p[1];
-                    L3D_LDS v4u* q = (L3D_LDS v4u*)(stage + 8 * j);
-                    q[0] = a; q[1] = b;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                for (uint32_t j = lane; j < cr; j += 64) {
-                    const uint32_t tgt = stage[8 * j];
-                    uint32_t rank = 0;
-                    for (uint32_t i = 0; i < cr; ++i) rank += stage[8 * i] < tgt ? 1u : 0u;   // (targets of a row are distinct)
-                    L3D_LDS const v4u* q = (L3D_LDS const v4u*)(stage + 8 * j);
-                    const v4u a = q[0], b = q[1];
-                    v4u* p = (v4u*)&row[rank];
-                    p[0] = a; p[1] = b;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            } else if (lane == 0) {
-                for (uint32_t x = 1; x < cr; ++x) {
-                    const Slot v = row[x];
-                    uint32_t y = x;
-                    while (y > 0 && row[y - 1].tgt_seg > v.tgt_seg) { row[y] = row[y - 1]; --y; }
-                    row[y] = v;
-                }
-            }
-        }
-        return;
+        return;                // (streamed unculled: a row's matches arrived in ascending target order -- drain, lowest lane first)
     }
     // MODE 0.  The wave writes its rows TOGETHER: item = (row, entry), one item per lane and pass, so that the K
     // 32-byte slots of a row (K*32 B contiguous, 64-byte aligned for even K) leave in one store instruction as whole
@@ -845,7 +801,6 @@ bool match_staged(int mode, bool brute) {
 size_t match_lds_bytes(int mode, uint32_t K, bool ix16, uint32_t waves, bool brute) {
     const size_t ib = ix16 ? 2 : 4;
     const bool staged = match_staged(mode, brute);
-    if (mode == 2) return keep_sort_offset() + (size_t)kKeepSortCap * 32;   // (one wave, 32-bit indices: carve + row staging)
     return (size_t)waves * (ring_entries(staged, waves) + (staged ? kRing2 : 0)) * 4 + 2 * kBlock * 4 + 2 * kBlock * ib +
            (mode == 0 ? (size_t)kBlock * K * (4 + ib) : 0);
 }

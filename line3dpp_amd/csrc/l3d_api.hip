@@ -764,7 +764,8 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
                     c->d_chunk_band.p, c->d_cull_keys.p};
     pools.tgt_s4 = c->d_tgt_s4.p; pools.tgt_sd = c->d_tgt_sd.p;
     const bool keep_all_unculled = std::getenv("L3D_KEEPALL_NO_CULL") != nullptr;   // diagnostic switch (A/B; read per call)
-    if (c->brute || !maxM || (mode != 0 && keep_all_unculled)) pools.cull = nullptr;
+    // (keep-all mode: the count pass takes the culled walk, the fill pass streams -- k_match.hip)
+    if (c->brute || !maxM || mode == 2 || (mode == 1 && keep_all_unculled)) pools.cull = nullptr;
     else {
         static const int no_order = [] { const char* e = std::getenv("L3D_MATCH_ORDER"); return e && std::atoi(e) == 0; }();
         // longest-first launch order (k_order_items) where the launch has one to three items per wave slot (fewer: all
@@ -779,11 +780,8 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
             pools.order_done = c->d_order_done.p;
             pools.w_base = c->cull[first].w_item0; pools.cost_max = maxMt;
         }
-        // (keep-all mode: the fill pass walks what the count pass prepared)
-        if (mode != 2) {
-            L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
-            L3D_HIP_CHECK(launch_order_items(c->d_pairs.p, first, count, maxMt, pools, (uint32_t)n_work, c->stream));
-        }
+        L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
+        L3D_HIP_CHECK(launch_order_items(c->d_pairs.p, first, count, maxMt, pools, (uint32_t)n_work, c->stream));
     }
     L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
     const bool ix16 = maxMt < 65536u && maxK < 32768u;   // 16-bit indices in the kernel's LDS tables (top bit of a row's minpos: tie flag)

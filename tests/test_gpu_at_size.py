@@ -112,11 +112,12 @@ def test_slice_of_c2_c4_at_configured_size(config, count, mid):
 
 def test_keep_all_mode_at_c1_size_through_the_culled_walk(monkeypatch):
     """kNN <= 0 (every accepted match is kept, in ascending target order: line3D.cc:982-992).  Until round 3 this mode
-    streamed every pair unculled; it now takes the epipolar-band walk like the bounded mode and the fill pass sorts each
-    row by target afterwards.  Full C1 phase A: 32 sampled directed pairs bit for bit and in the reference's order
-    against matchingCPU of the restatement (pinned byte for byte on the reference's own code), culled and unculled
-    (L3D_KEEPALL_NO_CULL=1) giving the same slots, the culled passes several times faster; then the whole pipeline in
-    this mode against the reference's own code on a quarter-size scene (its scoring is quadratic in the list length)."""
+    streamed every pair unculled in both of its passes; since round 4 the COUNT pass takes the epipolar-band walk (a
+    count does not depend on the order; the fill pass keeps streaming: its arrival order is the reference's order).  Full
+    C1 phase A: 32 sampled directed pairs bit for bit and in the reference's order against matchingCPU of the
+    restatement (pinned byte for byte on the reference's own code), with and without the culled count pass
+    (L3D_KEEPALL_NO_CULL=1) giving the same slots, the culled form faster; then the whole pipeline in this mode against
+    the reference's own code on a quarter-size scene (its scoring is quadratic in the list length)."""
     from line3dpp_amd.api import Line3D
     from line3dpp_amd.scene import make_scene
     sc = make_config("C1")
@@ -136,9 +137,11 @@ def test_keep_all_mode_at_c1_size_through_the_culled_walk(monkeypatch):
             tm = g.timings()
             if rep == 0:
                 assert g.matchAbort()
-        out[name] = (g, tm["match_pairs_ms"], tm["culled_pairs"])
+        # (GPU time of the two kernels -- count and fill -- and of the culling set-up; match_pairs_ms also spans the host's
+        # sizing of the rows between the two passes)
+        out[name] = (g, tm["match_kernel_ms"] + tm["cull_prepare_ms"], tm["culled_pairs"])
     (gc, ms_c, culled), (gu, ms_u, unculled) = out["culled"], out["unculled"]
-    assert culled == 2 * n_pairs and unculled == 0        # (both passes -- count and fill -- take the culled walk)
+    assert culled == n_pairs and unculled == 0            # (the count pass takes the culled walk, the fill pass streams)
     rng = np.random.default_rng(5)
     sample = rng.choice(n_pairs, 32, replace=False)
     for pi in sample:
@@ -158,8 +161,8 @@ def test_keep_all_mode_at_c1_size_through_the_culled_walk(monkeypatch):
         total += r["n_cpu"]
     o.end_match()
     assert total > 500_000
-    print(f"keep-all C1 phase A: culled {ms_c:.2f} ms, unculled {ms_u:.2f} ms ({ms_u / ms_c:.1f} x), {total} matches in 32 sampled pairs identical")
-    assert ms_u > 2.0 * ms_c, (ms_c, ms_u)
+    print(f"keep-all C1 phase A: culled count pass {ms_c:.2f} ms, both passes unculled {ms_u:.2f} ms ({ms_u / ms_c:.2f} x), {total} matches in 32 sampled pairs identical")
+    assert ms_u > 1.1 * ms_c, (ms_c, ms_u)
     gc.matchAbort(); gu.matchAbort(); gc.close(); gu.close()
     # the whole pipeline in this mode, against the reference's own code
     monkeypatch.delenv("L3D_KEEPALL_NO_CULL", raising=False)

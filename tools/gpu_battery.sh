@@ -4,7 +4,7 @@
 # rocprofv3 kernel statistics of C1 -> gpurun_out/<tag>/
 tag=$1; shift; tests=${1:-tests}; shift; cfgs=${@:-C1 C2 C4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$tag; mkdir -p $O; cd $R
-if [ "$tests" = tests ]; then ( time timeout 1500 python -m pytest tests -m gpu -q -x -s ) > $O/pytest.log 2>&1; tail -5 $O/pytest.log; fi
+if [ "$tests" = tests ]; then ( time timeout 1500 python -m pytest tests -m gpu -q -s ) > $O/pytest.log 2>&1; tail -5 $O/pytest.log; fi
 for c in $cfgs; do
   timeout 600 python bench.py --config $c --no-cpu-baseline --no-cold --steps 10 --warmup 3 2> $O/bench_$c.err > $O/bench_$c.json
   python - $O/bench_$c.json $c <<'PY'
