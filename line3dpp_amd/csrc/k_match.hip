@@ -46,8 +46,6 @@ constexpr int kRing1 = 128;         // the same for the staged one-wave-per-item
                                     // of 512 B, and 28 such waves fit a CU's 160 KiB (7 per SIMD; 6.3 KiB gave 6)
 __host__ __device__ constexpr int ring_entries(bool staged, uint32_t waves) { return (staged && waves == 1) ? kRing1 : kRing; }
 constexpr int kRing2 = 128;         // second ring (bounded kNN): candidates that passed the depth test; >= 63 + 64
-constexpr int kRing3 = 128;         // third ring (bounded kNN): candidates (and table entries) that need the exact overlap; a
-                                    // drain of stage 2 or 3 adds at most one entry per lane: >= 63 + 64
 
 // All LDS pointers carry the LDS address space in their TYPE: a generic pointer that travels through a struct
 // or a lambda capture loses it and every access becomes a flat_load/flat_store (plus, for volatile, sc0 sc1
@@ -83,9 +81,6 @@ struct Lds {
     typedef typename IdxT<IX16>::type idx_t;
     L3D_LDS volatile uint32_t* ring;   // [waves][ring_entries]
     L3D_LDS volatile uint32_t* ring2;  // [waves][kRing2] (bounded kNN only)
-    L3D_LDS volatile uint32_t* ring3;  // [waves][kRing3] (bounded kNN only)
-    L3D_LDS volatile uint32_t* inex;   // [kBlock] bit j: entry j of the row's table holds a LOWER BOUND of its overlap (float
-                                       // estimate - slack), not the exact value (bounded kNN only; written under the row's lock)
     L3D_LDS volatile float* minov;     // [kBlock]
     L3D_LDS volatile uint32_t* claim;  // [kBlock]
     L3D_LDS volatile float* top_ov;    // [kBlock*K]
@@ -102,8 +97,6 @@ __device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K, uint3
     Lds<IX16> l;
     l.ring = (L3D_LDS volatile uint32_t*)base; base += waves * ring_entries(two_rings, waves) * sizeof(uint32_t);
     l.ring2 = (L3D_LDS volatile uint32_t*)base; if (two_rings) base += waves * kRing2 * sizeof(uint32_t);
-    l.ring3 = (L3D_LDS volatile uint32_t*)base; if (two_rings) base += waves * kRing3 * sizeof(uint32_t);
-    l.inex = (L3D_LDS volatile uint32_t*)base; if (two_rings) base += kBlock * 4;
     l.minov = (L3D_LDS volatile float*)base; base += kBlock * 4;
     l.claim = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
     l.top_ov = (L3D_LDS volatile float*)base; base += (size_t)kBlock * K * 4;
@@ -216,7 +209,6 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     constexpr idx_t kTie = Lds<IX16>::kTie;
     L3D_LDS volatile uint32_t* ring = L.ring + q * kRingN;
     L3D_LDS volatile uint32_t* ring2 = L.ring2 + q * kRing2;
-    L3D_LDS volatile uint32_t* ring3 = L.ring3 + q * kRing3;
     // epipolar-band culling.  Keep-all mode (round 4): the COUNT pass takes the culled walk as well (a count does not
     // depend on the order); the FILL pass streams unculled, because a row must come out in ascending target order
     // (line3D.cc:987-992) and that is the order in which an unculled row's matches arrive.  Measured on C1
@@ -241,7 +233,6 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     float e1x = 0, e1y = 0, e1z = 0, e2x = 0, e2y = 0, e2z = 0;
     float thrL = thr;
     bool live = false;               // dead lane (row >= Ms or degenerate epipolar line): never a candidate
-    bool est_row = false;            // the float overlap estimate of this row may be relied on (l3d_dev.h overlap_estimate)
     if (active) {
         const float4 s = vs.seg4[src];
         d3 e1 = mul33(F, d3{(double)s.x, (double)s.y, 1.0});
@@ -256,7 +247,6 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             e2x = (float)(e2.x / n2); e2y = (float)(e2.y / n2);
             e2z = (float)((e2.z + (e2.x * cx + e2.y * cy)) / n2);
             live = true;
-            est_row = n1 >= 1e-9 && n2 >= 1e-9;   // (|x.z| = n |d|: with |d| >= kEstMinD far above the reference's L3D_EPS guard)
         }
     }
     if (q == 0) {
@@ -264,7 +254,6 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         L.minov[tid] = thr;
         L.claim[tid] = kEmpty;
         L.minpos[tid] = 0;
-        if (STAGED) L.inex[tid] = 0;
     }
     if (WPG > 1) __syncthreads();
     uint32_t head = 0, tail = 0;   // wave-uniform ring cursors
@@ -312,25 +301,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     // The depth VALUES are only computed for the winners (epilogue), as before.  What the exact tests read of a target
     // comes from the copies k_cull_prepare keeps in walk order (tgt_s4 / tgt_sd): a wave's candidates are neighbours
     // there.  Table entries are positions in that order; the epilogue translates the winners (tgt_perm).
-    uint32_t head2 = 0, tail2 = 0, head3 = 0, tail3 = 0;
-    // pre-filter records of the targets in the order the ring entries index them (walk order of a culled pair)
-    const v4f* __restrict__ tf = cull ? (const v4f*)(cp.tgt_sf + pc->t_off) : (const v4f*)vt.segf;
-    // Deferred exact evaluation (round 4).  Line3D::matchingCPU keeps the kNN best of a row (line3D.cc:982-1007); the
-    // candidates of a row arrive in a burst, so a table keyed by the exact overlap evaluated 2.3 candidates in double
-    // precision per slot it finally kept.  Stage 2 now ranks a candidate by a float ESTIMATE with a certified slack
-    // (l3d_dev.h overlap_estimate: |estimate - exact| <= slack): the table key of such an entry is the LOWER bound
-    // estimate - slack (bit j of inex[row]), a candidate whose UPPER bound lies below the row's K-th best key cannot be
-    // among the kNN best and is dropped without ever being evaluated, and the double-precision overlap is only computed
-    // (stage 3, full lanes again) for
-    //   * candidates the estimate cannot vouch for (near-parallel targets, tiny segments: `ok` false),
-    //   * candidates and evicted entries whose interval contains the K-th best key (they cannot be ordered without it),
-    //   * the entries that are still inexact when the walk is over (the winners: flush below).
-    // Every key is a lower bound of its entry's overlap, so the K-th best key never exceeds the true K-th best overlap:
-    // whatever is dropped is strictly below the kNN best, and the final table -- exact values throughout -- is the table
-    // the exact selection builds.  Ties are flagged as before (a flag only costs a replay).  kNN beyond 32 (bits of the
-    // mask), views beyond 2^22 segments and L3D_NO_DEFER=1 send every candidate to stage 3: the round-3 behaviour.
-    const bool defer = STAGED && K <= 32 && Mt < (1u << 22) && of.defer != 0;
-    constexpr uint32_t kWriteBack = 1u << 22;   // ring-3 entry: (row << 23) | kWriteBack | table position
+    uint32_t head2 = 0, tail2 = 0;
     // (walk-order copies only where k_cull_prepare keeps them: large target views; otherwise the view's own arrays, by
     // original index)
     const bool sorted = cull && pc->sorted_copy != 0;
@@ -372,13 +343,41 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         tail2 += (uint32_t)__popcll(m);
         if (lane == 0) L3D_STAT(9, __popcll(m));
     };
-    // kNN insertion of up to one candidate per lane (key = what the table is ordered by: the exact overlap, or the lower
-    // bound of an estimated one; ub = its upper bound).  Several candidates of one drain may belong to the same row: one
-    // at a time (compare-and-swap lock with two waves per row group; a wave's own contenders are serialised by the LDS
-    // atomic unit just the same).  On return `to3` says that the lane has an entry for stage 3 -- its own candidate when
-    // the interval cannot be ordered against the row's K-th best, or the entry it evicted when that one's interval still
-    // reaches the new K-th best -- and `pay` is that entry's target position.
-    auto table_insert = [&](bool pending, uint32_t sl, float key, float ub, bool inexact, uint32_t tg, bool& to3, uint32_t& pay) {
+    auto stage2 = [&]() {
+        const uint32_t n = min(64u, tail2 - head2);
+        const bool has = lane < n;
+        if (lane == 0) L3D_STAT(4, 1);
+        const uint32_t ent = ring2[(head2 + lane) & (kRing2 - 1)];
+        head2 += n;
+        const uint32_t sl = ent >> 23, tg = ent & 0x7FFFFFu;
+        const uint32_t sg = __shfl(src, sl);
+        bool pending = false;
+        float ovv = 0.0f;
+        // F is fetched per drain through a laundered pointer (wave-uniform control flow: scalar loads): hoisted out of the
+        // walk its 18 scalar registers -- with everything else the stages need -- made the walk's loop reload spilled
+        // scalars from vector lanes at every step (four v_readlane per two targets: the record base pointer and the lane
+        // mask).  Round 3 measured this switch as neutral; since the depth decision of stage 1 runs on floats (no camera
+        // centres in scalar registers either) it removes the reloads: C4 -8.7 %, C2 -3.5 %, C1 -1 % (profiles/r04_ab_match.txt).
+#ifndef L3D_NO_LAUNDER_F
+        const double* Fp = pd.F;
+        asm volatile("" : "+s"(Fp));
+#else
+        const double* Fp = F;
+#endif
+        if (has) {
+            const float4 s4 = vs.seg4[sg], t4 = ts4[target_index(tg)];
+            const float ov = exact_overlap(Fp, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w, fastm);
+            // a full row only admits overlaps that reach its K-th best (minov == thr while the row is not full); an overlap
+            // EQUAL to the K-th best goes on to the insertion: a tie at the kNN-th place flags the row for the exact replay
+            const float need = L.minov[sl];
+            if (ov > thr && ov >= need) { pending = true; ovv = ov; L3D_STAT(2, 1); L3D_STAT(3, 1); }
+#ifdef L3D_STATS
+            else if (!(ov > thr)) L3D_STAT(10, 1);          // not a match at all: what the pre-filter's slack lets through
+            else L3D_STAT(11, 1);                           // a match that no longer reaches the row's K-th best
+#endif
+        }
+        // several candidates of one drain may belong to the same row: one at a time (compare-and-swap lock with two waves
+        // per row group; a wave's own contenders are serialised by the LDS atomic unit just the same)
         while (L3D_BALLOT(pending)) {
             bool win;
             if (WPG > 1) {
@@ -400,26 +399,18 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                 L3D_LDS volatile float* ov = L.top_ov + (size_t)sl * K;
                 L3D_LDS volatile idx_t* ix = L.top_ix + (size_t)sl * K;
                 if (c < K) {
-                    ov[c] = key; ix[c] = tg;
-                    if (inexact) L.inex[sl] = L.inex[sl] | (1u << c);
+                    ov[c] = ovv; ix[c] = tg;
                     L.cnt[sl] = c + 1;
                     if (c + 1 == K) rescan_worst(sl);
                 } else {
                     const uint32_t wj = L.minpos[sl] & (idx_t)~kTie;
                     const float mo = L.minov[sl];
-                    if (key > mo) {
-                        const uint32_t old_ix = ix[wj], bits = L.inex[sl];
-                        ov[wj] = key; ix[wj] = tg;
-                        L.inex[sl] = inexact ? (bits | (1u << wj)) : (bits & ~(1u << wj));
+                    if (ovv > mo) {
+                        ov[wj] = ovv; ix[wj] = tg;
                         rescan_worst(sl);
-                        const float nmo = L.minov[sl];
-                        if (nmo == mo) flag_tie(sl);            // the evicted entry ties with the new K-th best
-                        // an evicted ESTIMATE may still belong to the kNN best: its overlap is at most mo + 2 slack
-                        if (((bits >> wj) & 1u) && !(mo + 2.0f * kEstSlackMax < nmo)) { to3 = true; pay = old_ix; }
-                    } else if (ub >= mo) {
-                        // cannot be placed below the K-th best: an exact overlap EQUAL to it is a tie at the K-th place
-                        // (whichever index would win: replay); an estimate needs its exact value first
-                        if (inexact) { to3 = true; pay = tg; } else flag_tie(sl);
+                        if (L.minov[sl] == mo) flag_tie(sl);    // the evicted entry ties with the new K-th best
+                    } else if (ovv == mo) {
+                        flag_tie(sl);                           // a tie at the K-th place (whichever index would win)
                     }
                 }
                 if (WPG > 1)
@@ -427,93 +418,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-    };
-    auto push3 = [&](bool to3, uint32_t ent) {
-        const uint64_t m = L3D_BALLOT(to3);
-        if (to3) ring3[(tail3 + prefix(m)) & (kRing3 - 1)] = ent;
-        tail3 += (uint32_t)__popcll(m);
-    };
-    // stage 2: the float estimate of 64 candidates, the certain rejections, the insertion of the certain ones by their
-    // lower bound; everything else on to stage 3
-    auto stage2 = [&]() {
-        const uint32_t n = min(64u, tail2 - head2);
-        const bool has = lane < n;
-        const uint32_t ent = ring2[(head2 + lane) & (kRing2 - 1)];
-        head2 += n;
-        const uint32_t sl = ent >> 23, tg = ent & 0x7FFFFFu;
-        bool pending = false, to3 = false;
-        uint32_t pay = tg;
-        float key = 0.0f, ub = 0.0f;
-        // the row's two epipolar lines live in the lane that owns the row
-        const float r1x = __shfl(e1x, sl), r1y = __shfl(e1y, sl), r1z = __shfl(e1z, sl);
-        const float r2x = __shfl(e2x, sl), r2y = __shfl(e2y, sl), r2z = __shfl(e2z, sl);
-        const bool row_ok = __shfl((int)est_row, sl) != 0;
-        if (has) {
-            bool ok = false;
-            float est = 0.0f, slack = 0.0f;
-            if (defer) {
-                const v4f qv = tf[tg];
-                ok = overlap_estimate(r1x, r1y, r1z, r2x, r2y, r2z, qv.x, qv.y, qv.z, qv.w, est, slack) && row_ok;
-            }
-            if (ok) {
-                const float need = L.minov[sl];           // (may lag behind under two waves: it only ever grows)
-                ub = est + slack; key = est - slack;
-                if (ub < need || !(ub > thr)) { L3D_STAT(13, 1); }                // certainly not among the kNN best / no match
-                else if (key > thr) pending = true;                               // certainly a match: ranked by its lower bound
-                else to3 = true;                                                  // the threshold lies inside its interval
-            } else to3 = true;
-        }
-        table_insert(pending, sl, key, ub, true, tg, to3, pay);
-        push3(to3, (sl << 23) | pay);
-        // feed the K-th best key back into the owning lane's pre-filter threshold
-        if (live) thrL = L.minov[tid];
-    };
-    // stage 3: the exact overlap of 64 entries -- candidates (then inserted by it) or table entries whose estimate is
-    // replaced by it in place (kWriteBack: the flush after the walk)
-    auto stage3 = [&]() {
-        const uint32_t n = min(64u, tail3 - head3);
-        const bool has = lane < n;
-        if (lane == 0) { L3D_STAT(4, 1); L3D_STAT(14, n); }
-        const uint32_t ent = ring3[(head3 + lane) & (kRing3 - 1)];
-        head3 += n;
-        const uint32_t sl = ent >> 23;
-        const bool wb = (ent & kWriteBack) != 0;
-        uint32_t tg = ent & (kWriteBack - 1u);
-        const uint32_t sg = __shfl(src, sl);
-        bool pending = false, to3 = false;
-        uint32_t pay = 0;
-        float ovv = 0.0f;
-        // F is fetched per drain through a laundered pointer (wave-uniform control flow: scalar loads): hoisted out of the
-        // walk its 18 scalar registers -- with everything else the stages need -- made the walk's loop reload spilled
-        // scalars from vector lanes at every step (four v_readlane per two targets: the record base pointer and the lane
-        // mask).  Round 3 measured this switch as neutral; since the depth decision of stage 1 runs on floats (no camera
-        // centres in scalar registers either) it removes the reloads: C4 -8.7 %, C2 -3.5 %, C1 -1 % (profiles/r04_ab_match.txt).
-#ifndef L3D_NO_LAUNDER_F
-        const double* Fp = pd.F;
-        asm volatile("" : "+s"(Fp));
-#else
-        const double* Fp = F;
-#endif
-        if (has) {
-            const uint32_t slot = sl * K + tg;                                   // (write-back: tg is the table position)
-            if (wb) tg = ((L3D_LDS const idx_t*)L.top_ix)[slot];
-            const float4 s4 = vs.seg4[sg], t4 = ts4[target_index(tg)];
-            const float ov = exact_overlap(Fp, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w, fastm);
-            if (wb) {
-                L.top_ov[slot] = ov;               // (its lower bound exceeded thr: a match for certain; no one else touches the entry now)
-            } else {
-                // a full row only admits overlaps that reach its K-th best key (minov == thr while the row is not full); an
-                // overlap EQUAL to it goes on to the insertion: a tie at the kNN-th place flags the row for the exact replay
-                const float need = L.minov[sl];
-                if (ov > thr && ov >= need) { pending = true; ovv = ov; L3D_STAT(2, 1); L3D_STAT(3, 1); }
-#ifdef L3D_STATS
-                else if (!(ov > thr)) L3D_STAT(10, 1);          // not a match at all: what the pre-filter's slack lets through
-                else L3D_STAT(11, 1);                           // a match that no longer reaches the row's K-th best
-#endif
-            }
-        }
-        table_insert(pending, sl, ovv, ovv, false, tg, to3, pay);
-        push3(to3, (sl << 23) | pay);
+        // feed the K-th best overlap back into the owning lane's pre-filter threshold
         if (live) thrL = L.minov[tid];
     };
 
@@ -608,50 +513,20 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     // ---- main loop: stream the target view through LDS ----
     // Branch-free per test: dead lanes evaluate the pre-filter on zeros and are masked out of the ballot;
     // the compaction prefix is v_mbcnt (population count of the ballot below this lane).
+    const v4f* __restrict__ tf = cull ? (const v4f*)(cp.tgt_sf + pc->t_off) : (const v4f*)vt.segf;
     const uint32_t ent_hi = tid << 23;
     const bool lane_on = BRUTE ? active : live;           // lanes that can produce candidates
     const uint64_t lanes_on = L3D_BALLOT(lane_on);
     // the candidate pipeline is run whenever the first ring holds a full drain (flush: until both rings are empty)
-    // the candidate pipeline inside the walk: run whenever a ring holds a full drain.  (A drain of stage 1 adds at most 64
-    // entries to ring 2, a drain of stage 2 or 3 at most 64 to ring 3, and a ring is drained as soon as it holds 64: no ring
-    // ever holds more than 127.)
-    auto pump = [&]() {
+    auto pump = [&](bool flush) {
         if (STAGED) {
-            for (;;) {
-                const uint32_t n1 = tail - head, n2 = tail2 - head2, n3 = tail3 - head3;
-                if (n3 >= 64) { L3D_TIC; stage3(); L3D_TOC(t_s2); }
-                else if (n2 >= 64) { L3D_TIC; stage2(); L3D_TOC(t_s2); }
-                else if (n1 >= 64) { L3D_TIC; stage1(); L3D_TOC(t_s1); }
-                else break;
+            while (tail - head >= (flush ? 1u : 64u)) {
+                { L3D_TIC; stage1(); L3D_TOC(t_s1); }
+                while (tail2 - head2 >= 64) { L3D_TIC; stage2(); L3D_TOC(t_s2); }
             }
+            if (flush) while (tail2 != head2) { L3D_TIC; stage2(); L3D_TOC(t_s2); }
         } else {
-            while (tail - head >= 64) drain();
-        }
-    };
-    // ... and after the walk (ONE loop, so that the stages are inlined here once): phase 0 empties the rings; then the
-    // winners that are still ranked by an estimate get their exact overlap (stage 3, write-back form) -- the epilogue and
-    // the tie checks see exact values only.  Two waves per row group: all candidates of both must be in the tables
-    // before the winners are read (barrier); wave q then takes the table positions j = q (mod 2).
-    auto finish_pipeline = [&]() {
-        if (STAGED) {
-            uint32_t phase = 0, j = q, bits = 0;
-            const uint32_t jn = K < 32u ? K : 32u;
-            for (;;) {
-                const uint32_t n1 = tail - head, n2 = tail2 - head2, n3 = tail3 - head3;
-                if (n3 >= 64 || (n3 && !n1 && !n2 && (phase == 0 || j >= jn))) { L3D_TIC; stage3(); L3D_TOC(t_s2); }
-                else if (n2 >= 64 || (n2 && !n1)) { L3D_TIC; stage2(); L3D_TOC(t_s2); }
-                else if (n1) { L3D_TIC; stage1(); L3D_TOC(t_s1); }
-                else if (phase == 0) {
-                    if (WPG > 1) __syncthreads();
-                    bits = live ? (uint32_t)L.inex[tid] : 0u;
-                    phase = 1;
-                } else if (j < jn) {
-                    push3(((bits >> j) & 1u) != 0, (tid << 23) | kWriteBack | j);
-                    j += WPG;
-                } else break;
-            }
-        } else {
-            while (tail != head) drain();
+            while (flush ? (tail != head) : (tail - head >= 64)) drain();
         }
     };
     // The target view is visited in chunks of 64 records.  With culling, 32 chunk bands are tested at once (one per
@@ -775,7 +650,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                     if (kRingN >= 63 + 2 * 64) {
                         if (m0) { if (c0b & lane_on) ring[(tail + prefix(m0)) & (kRingN - 1)] = ent_hi | (tb + j0); tail += __popcll(m0); }
                         if (m1) { if (c1b & lane_on) ring[(tail + prefix(m1)) & (kRingN - 1)] = ent_hi | (tb + j1); tail += __popcll(m1); }
-                        pump();
+                        pump(false);
                     } else {
                         // the short ring holds one push beyond a partial drain: push, pump, push, pump (a loop, so that the
                         // candidate pipeline is inlined once)
@@ -786,7 +661,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                             const uint32_t jh = h ? j1 : j0;
                             if (ch & lane_on) ring[(tail + prefix(mh)) & (kRingN - 1)] = ent_hi | (tb + jh);
                             tail += __popcll(mh);
-                            pump();
+                            pump(false);
                         }
                     }
                 }
@@ -794,7 +669,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         }
       }
     }
-    finish_pipeline();
+    pump(true);
 #if defined(L3D_STATS) || defined(L3D_CYCLES)
     const unsigned long long t_loop = clock64();
     if (threadIdx.x == 0) L3D_STAT(7, 1);
@@ -926,7 +801,7 @@ bool match_staged(int mode, bool brute) {
 size_t match_lds_bytes(int mode, uint32_t K, bool ix16, uint32_t waves, bool brute) {
     const size_t ib = ix16 ? 2 : 4;
     const bool staged = match_staged(mode, brute);
-    return (size_t)waves * (ring_entries(staged, waves) + (staged ? kRing2 + kRing3 : 0)) * 4 + (staged ? kBlock * 4 : 0) + 2 * kBlock * 4 + 2 * kBlock * ib +
+    return (size_t)waves * (ring_entries(staged, waves) + (staged ? kRing2 : 0)) * 4 + 2 * kBlock * 4 + 2 * kBlock * ib +
            (mode == 0 ? (size_t)kBlock * K * (4 + ib) : 0);
 }
 

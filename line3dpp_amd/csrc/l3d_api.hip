@@ -786,8 +786,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
     const bool ix16 = maxMt < 65536u && maxK < 32768u;   // 16-bit indices in the kernel's LDS tables (top bit of a row's minpos: tie flag)
     // bounded kNN: the orientation filter of phase B is fused into the epilogue
-    OrientFuse of{mode == 0 ? c->d_inv_tgt.p : nullptr, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr,
-                  std::getenv("L3D_NO_DEFER") ? 0u : 1u};   // (L3D_NO_DEFER=1, diagnostic / A-B switch: every candidate evaluated exactly)
+    OrientFuse of{mode == 0 ? c->d_inv_tgt.p : nullptr, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
     uint32_t tie_stride = 0;
     if (mode == 0) {   // rows with equal overlaps are collected here and replayed in the reference's heap order
         uint32_t mt = 0;
@@ -941,7 +940,7 @@ int l3d_expand_slot_indices(l3d_ctx* c, uint32_t first, uint32_t count) {
         max_row_slots = std::max<uint64_t>(max_row_slots, (uint64_t)c->pairs[p].Ms * c->pairs[p].K);
     for (uint32_t p = first; p < first + count; ++p)
         if (c->pair_done[p]) return fail(L3D_ERR_STATE, "l3d_expand_slot_indices: pair already present on this rank");
-    const OrientFuse of{c->d_inv_tgt.p, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr, 0u};
+    const OrientFuse of{c->d_inv_tgt.p, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
     L3D_HIP_CHECK(launch_expand_slot_idx(c->d_views.p, c->d_pairs.p, first, count, max_row_slots, c->d_slot_idx.p,
                                          c->d_slots.p, of, c->stream));
     for (uint32_t p = first; p < first + count; ++p) c->pair_done[p] = c->pair_counted[p] = 1;

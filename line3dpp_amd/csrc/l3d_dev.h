@@ -300,43 +300,6 @@ L3D_HD bool prefilter_products(float e1x, float e1y, float e1z, float e2x, float
     return !(u < 0.0f);
 }
 
-// ---- a float ESTIMATE of the overlap with a certified error (round 4: deferred exact evaluation, k_match.hip) -----------
-// Same quantities as the pre-filter: s_i = a_i / d_i, inner = |clamp(s1) - clamp(s2)|, union = |s1 - s2| + 1 - inner,
-// overlap ~ inner / union.  Against the reference's double-precision value (exact_overlap) the estimate is off by at most
-// 4e-4 / min|d_i| + 6e-6 on 9.6 million random and adversarial pairs (tests/cpp/estimate_cover.cpp: targets along the
-// band, nearly parallel to the pencil, end points on an epipolar line, F scaled over six orders of magnitude); `slack`
-// is ten times that (which also covers the 1-ulp v_rcp_f32 of the device).  `ok` = the bound may be relied on: both
-// |d_i| >= kEstMinD (no near-parallel target: there the reference's |x.z| > L3D_EPS guard and the float quotient part
-// ways), the target at least two pixels long (the reference returns 0 below a one-pixel extent, line3D.cc:1100-1105),
-// slack <= kEstSlackMax, everything finite.  The caller must also know that the row's epipolar lines have a norm of at
-// least 1e-9 before normalisation (the |x.z| guard again; k_match.hip prologue).  Not ok -> the exact value decides.
-constexpr float kEstKappa = 4.0e-3f, kEstKappa0 = 6.0e-5f, kEstSlackMax = 2.0e-3f, kEstMinD = 0.25f;
-L3D_HD bool overlap_estimate(float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
-                             float qx, float qy, float qz, float qw, float& est, float& slack) {
-    const float a1 = __builtin_fmaf(e1x, qx, __builtin_fmaf(e1y, qy, e1z));
-    const float a2 = __builtin_fmaf(e2x, qx, __builtin_fmaf(e2y, qy, e2z));
-    const float d1 = __builtin_fmaf(e1x, qz, e1y * qw);
-    const float d2 = __builtin_fmaf(e2x, qz, e2y * qw);
-#if defined(__HIP_DEVICE_COMPILE__)
-    const float s1 = a1 * __builtin_amdgcn_rcpf(d1), s2 = a2 * __builtin_amdgcn_rcpf(d2);
-#else
-    const float s1 = a1 / d1, s2 = a2 / d2;
-#endif
-    const float c1 = __builtin_fminf(__builtin_fmaxf(s1, 0.0f), 1.0f), c2 = __builtin_fminf(__builtin_fmaxf(s2, 0.0f), 1.0f);
-    const float inner = __builtin_fabsf(c1 - c2);
-    const float uni = __builtin_fabsf(s1 - s2) + 1.0f - inner;
-    const float dmin = __builtin_fminf(__builtin_fabsf(d1), __builtin_fabsf(d2));
-#if defined(__HIP_DEVICE_COMPILE__)
-    est = inner * __builtin_amdgcn_rcpf(uni);
-    slack = __builtin_fmaf(kEstKappa, __builtin_amdgcn_rcpf(dmin), kEstKappa0);
-#else
-    est = inner / uni;
-    slack = kEstKappa / dmin + kEstKappa0;
-#endif
-    // (NaN anywhere fails one of the comparisons)
-    return dmin >= kEstMinD && slack <= kEstSlackMax && __builtin_fmaf(qz, qz, qw * qw) >= 4.0f && est >= 0.0f && est <= 1.0f;
-}
-
 struct PairResult {
     float overlap;
     float dp1, dp2, dq1, dq2;

@@ -69,8 +69,6 @@ struct OrientFuse {
     uint32_t tie_cap;
     uint32_t* tie_next;             // the counter the next match launch will use (zeroed by k_match_tied_rows)
     uint32_t* tie_total;            // rows replayed so far (diagnostics)
-    uint32_t defer;                 // 1: stage 2 of k_match_pairs ranks candidates by the float estimate and defers the exact
-                                    // overlap (round 4); 0 (L3D_NO_DEFER=1): every candidate is evaluated exactly, as in round 3
 };
 
 // ---- k_match.hip ----

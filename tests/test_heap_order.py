@@ -55,17 +55,3 @@ def test_prefilter_without_reciprocals_never_rejects_an_accepted_pair(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "covered" in out.stdout and " 0 lost" in out.stdout
-
-
-def test_float_overlap_estimate_stays_inside_its_certified_slack(tmp_path):
-    """l3d_dev.h: overlap_estimate (round 4: k_match_pairs ranks a row's candidates by a float estimate of the epipolar
-    overlap and spends the double-precision evaluation on the winners and on what the estimate cannot separate) against
-    exact_overlap on 9.6 million pairs -- random, along the epipolar band, nearly parallel to the pencil, end points on
-    an epipolar line, F scaled over six orders of magnitude: whenever the estimate reports `ok`, it is within `slack` of
-    the reference's value (incl. the pairs for which the reference's guards return 0)."""
-    exe = str(tmp_path / "estimate_cover")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
-                           os.path.join(ROOT, "tests", "cpp", "estimate_cover.cpp"), "-o", exe])
-    out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout
-    assert "covered" in out.stdout and " 0 outside their bound" in out.stdout

@@ -23,7 +23,5 @@ print(json.dumps({"config": cfg, "build_info": L.l3d_build_info().decode(), "nom
                   "prefilter_tests": int(out[0]), "exact_tests": int(out[1]), "passed_overlap": int(out[2]),
                   "accepted": int(out[3]), "drains": int(out[4]), "band_pairs": int(out[5]), "kept_slots": int(out[6]),
                   "work_items": int(out[7]), "stage1_drains": int(out[8]), "depth_passed": int(out[9]),
-                  "stage2_not_a_match": int(out[10]), "stage2_below_kth_best": int(out[11]), "stage1_decided_in_double": int(out[12]),
-                  "stage2_dropped_on_the_estimate": int(out[13]), "exact_overlaps": int(out[14]),
-                  "exact_overlaps_per_kept_slot": (out[14] / out[6]) if out[6] else None, "prefilter_fraction_of_nominal": out[0] / nominal,
+                  "stage2_not_a_match": int(out[10]), "stage2_below_kth_best": int(out[11]), "stage1_decided_in_double": int(out[12]), "prefilter_fraction_of_nominal": out[0] / nominal,
                   "band_fraction_of_nominal": out[5] / nominal}))
