@@ -19,6 +19,7 @@
 //                   0.75 gate; surviving matches_ lists, estimated_position3D_ entries, depths for the view medians
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "l3d_dev.h"
 #include "l3d_kernels.h"
@@ -542,7 +543,7 @@ constexpr uint32_t kCsrChunk = 8;              // slots per thread whose memory 
 // handful of waves per SIMD), so what hides the latency of a load or of an LDS atomic is the next independent one of the
 // same wave -- slots that hand nothing over count on one of 64 dummy cursors instead of skipping the atomic (a branch
 // around each access serialised them: 0.11 ms on C1 where the batched form takes a fraction of that).
-template <bool LDSCNT>
+template <bool LDSCNT, bool TGT16>
 __global__ __launch_bounds__(kCsrBlock) void k_pair_csr(const PairDesc* __restrict__ pairs, uint32_t first_pair,
                                                         const PairCsr* __restrict__ pair_csr,
                                                         const uint32_t* __restrict__ inv_tgt,
@@ -559,7 +560,8 @@ __global__ __launch_bounds__(kCsrBlock) void k_pair_csr(const PairDesc* __restri
     const uint32_t Mt = pd.Mt, tid = threadIdx.x;
     if ((Mt <= lds_segs) != LDSCNT) return;                         // the other instantiation takes this pair
     const uint32_t S = pd.Ms * pd.K;                                // (< 2^32: l3d_match_begin limits the slot buffer)
-    const uint32_t* __restrict__ it = inv_tgt + pd.slot_off;
+    typedef typename std::conditional<TGT16, uint16_t, uint32_t>::type tgt_t;     // (0xFFFF / 0xFFFFFFFF: none -- both >= Mt)
+    const tgt_t* __restrict__ it = (const tgt_t*)inv_tgt + pd.slot_off;
     // end of run t = start of run t + 1 lives at row t + 1 of the transposed table, column q of this pair
     uint32_t* __restrict__ offq = poff + pcs.base + pcs.q;
     const uint32_t ni = pcs.ni;
@@ -965,7 +967,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L3D_EDGES_WA
 // Inside a launch an undecided header looks again a few times: all headers are resident at once, so a bit set by
 // another thread (device-scope store / load, the L2 is the meeting point) travels down a dependency chain within the
 // same launch instead of one launch per link.
-constexpr uint32_t kSweepLooks = 2;
+#ifndef L3D_SWEEP_LOOKS
+#define L3D_SWEEP_LOOKS 2
+#endif
+constexpr uint32_t kSweepLooks = L3D_SWEEP_LOOKS;
 __global__ void k_chain_sweep(const ListPools lp, uint8_t* __restrict__ positive, uint32_t* __restrict__ changed,
                               uint32_t sweep) {
     if (lp.flags[0] | lp.flags[2]) return;                    // an overflowed pass is discarded: its records are incomplete
@@ -1144,20 +1149,25 @@ __global__ void k_seg_write(uint32_t G, const ViewDev* __restrict__ views, const
 
 // ---- launchers --------------------------------------------------------------------------------------------------
 hipError_t launch_pair_csr(const PairDesc* pairs, uint32_t n_pairs, uint32_t max_Mt, const PairCsr* pair_poff,
-                           const uint32_t* inv_tgt, uint32_t* poff, uint32_t* refs, uint32_t* dummy,
+                           const uint32_t* inv_tgt, uint32_t tgt16, uint32_t* poff, uint32_t* refs, uint32_t* dummy,
                            uint32_t tgt_v0, uint32_t tgt_v1, hipStream_t st) {
     if (!n_pairs) return hipSuccess;
     // (L3D_CSR_GLOBAL=1, test hook: every pair takes the global-memory form that views beyond the LDS capacity need)
     static const bool force_global = std::getenv("L3D_CSR_GLOBAL") != nullptr;
     const uint32_t lds_segs = force_global ? 0u : kCsrLdsSegs;
     const size_t lds = ((size_t)std::min(max_Mt, lds_segs) + 64) * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)k_pair_csr<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_pair_csr<true>, dim3(n_pairs), dim3(kCsrBlock), lds, st, pairs, 0u, pair_poff, inv_tgt,
-                       poff, refs, dummy, tgt_v0, tgt_v1, lds_segs);
-    if (max_Mt > lds_segs)   // views beyond the LDS capacity: cursors in global memory (dummy: 64 words per pair)
-        hipLaunchKernelGGL(k_pair_csr<false>, dim3(n_pairs), dim3(kCsrBlock), 0, st, pairs, 0u, pair_poff, inv_tgt,
-                           poff, refs, dummy, tgt_v0, tgt_v1, lds_segs);
+#define L3D_CSR(T16)                                                                                                      \
+    do {                                                                                                                  \
+        hipError_t e = hipFuncSetAttribute((const void*)k_pair_csr<true, T16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                    \
+        hipLaunchKernelGGL((k_pair_csr<true, T16>), dim3(n_pairs), dim3(kCsrBlock), lds, st, pairs, 0u, pair_poff, inv_tgt, \
+                           poff, refs, dummy, tgt_v0, tgt_v1, lds_segs);                                                  \
+        if (max_Mt > lds_segs)   /* views beyond the LDS capacity: cursors in global memory (dummy: 64 words per pair) */ \
+            hipLaunchKernelGGL((k_pair_csr<false, T16>), dim3(n_pairs), dim3(kCsrBlock), 0, st, pairs, 0u, pair_poff, inv_tgt, \
+                               poff, refs, dummy, tgt_v0, tgt_v1, lds_segs);                                              \
+    } while (0)
+    if (tgt16) L3D_CSR(true); else L3D_CSR(false);
+#undef L3D_CSR
     return hipGetLastError();
 }
 

@@ -148,6 +148,11 @@ __device__ __forceinline__ uint32_t fuse_orientation(const OrientFuse& of, const
 }
 // the 4-byte stream k_pair_csr sorts: target segment of a slot that hands an inverse match over, kEmpty otherwise
 __device__ __forceinline__ uint32_t inverse_target(const Slot& o) { return (o.flags & kSlotInvAlive) ? o.tgt_seg : kEmpty; }
+__device__ __forceinline__ void store_inverse_target(const OrientFuse& of, uint64_t at, const Slot& o) {
+    const uint32_t t = inverse_target(o);
+    if (of.tgt16) ((uint16_t*)of.inv_tgt)[at] = (uint16_t)(t == kEmpty ? 0xFFFFu : t);   // (wave-uniform choice)
+    else of.inv_tgt[at] = t;
+}
 
 }  // namespace
 
@@ -773,7 +778,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         if (in && !tied) {
             const uint64_t at = pd.slot_off + (uint64_t)rsrc * K + dst;
             slots[at] = o;
-            of.inv_tgt[at] = inverse_target(o);
+            store_inverse_target(of, at, o);
         }
 #ifdef L3D_STATS
         { const uint32_t nk = (uint32_t)__popcll(L3D_BALLOT(j < c)); if (lane == 0 && nk) L3D_STAT(6, nk); }
@@ -888,7 +893,7 @@ __global__ __launch_bounds__(256) void k_expand_slot_idx(const ViewDev* __restri
     } else {
         o.tgt_seg = kEmpty;
     }
-    if (s < n) { slots[at] = o; of.inv_tgt[at] = inverse_target(o); }
+    if (s < n) { slots[at] = o; store_inverse_target(of, at, o); }
 }
 
 hipError_t launch_pack_slot_idx(const Slot* slots, uint32_t* idx, uint64_t lo, uint64_t hi, hipStream_t stream) {
@@ -1490,7 +1495,7 @@ __global__ __launch_bounds__(kTieBlock) void k_match_tied_rows(const ViewDev* __
             if (j < K) {
                 const uint64_t at = pd.slot_off + (uint64_t)src * K + j;
                 slots[at] = o;
-                of.inv_tgt[at] = inverse_target(o);
+                store_inverse_target(of, at, o);
             }
         }
         __syncthreads();

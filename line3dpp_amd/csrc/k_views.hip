@@ -41,7 +41,7 @@ __device__ unsigned long long g_bstats[8];
 // match epilogue does the same on the way -- and the 4-byte stream k_pair_csr sorts:
 //   inv_tgt[slot] target segment of a slot that hands an inverse match to its target view (kEmpty: none)
 __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
-                             Slot* __restrict__ slots, uint32_t* __restrict__ inv_tgt, OrientThr othr) {
+                             Slot* __restrict__ slots, uint32_t* __restrict__ inv_tgt, uint32_t tgt16, OrientThr othr) {
     const PairDesc& pd = pairs[blockIdx.y];
     const uint64_t n = (uint64_t)pd.Ms * pd.K;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,7 +64,8 @@ __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* 
         sp->flags = flags;
         sp->score3D = 0.0f;
     }
-    inv_tgt[pd.slot_off + i] = itgt;
+    if (tgt16) ((uint16_t*)inv_tgt)[pd.slot_off + i] = (uint16_t)(itgt == kEmpty ? 0xFFFFu : itgt);
+    else inv_tgt[pd.slot_off + i] = itgt;
 }
 
 
@@ -605,10 +606,10 @@ hipError_t launch_fill_gseg_view(const uint32_t* seg_base, uint32_t V, uint32_t 
     return hipGetLastError();
 }
 hipError_t launch_orient_pairs(const ViewDev* views, const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots,
-                               Slot* slots, uint32_t* inv_tgt, double thr_lo, double thr_hi, hipStream_t st) {
+                               Slot* slots, uint32_t* inv_tgt, uint32_t tgt16, double thr_lo, double thr_hi, hipStream_t st) {
     if (!n_pairs || !max_slots) return hipSuccess;
     hipLaunchKernelGGL(k_orient_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, views,
-                       pairs, slots, inv_tgt, OrientThr{thr_lo, thr_hi});
+                       pairs, slots, inv_tgt, tgt16, OrientThr{thr_lo, thr_hi});
     return hipGetLastError();
 }
 hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, uint32_t* long_list, uint32_t* n_long,

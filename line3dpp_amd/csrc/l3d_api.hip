@@ -664,7 +664,13 @@ static int match_begin_body(l3d_ctx* c) {
     c->shard_world = 0; c->lists_ready = false; c->lists_prepared = false;
     int rc = upload_views(*c);
     if (rc) return rc;
-    // the inverse-target stream of phase B: written by the match epilogue (bounded kNN) or by k_orient_all
+    // the inverse-target stream of phase B: written by the match epilogue (bounded kNN) or by k_orient_all; 16-bit entries
+    // when every view has fewer than 65 535 segments (L3D_INV_TGT32=1: always 32-bit, A/B switch)
+    {
+        uint32_t mx = 0;
+        for (auto* v : c->order) mx = std::max(mx, v->M);
+        c->tgt16 = (mx < 65535u && !std::getenv("L3D_INV_TGT32")) ? 1u : 0u;
+    }
     if (c->kNN > 0) L3D_HIP_CHECK(c->d_inv_tgt.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(c->d_pairs.reserve(std::max<size_t>(c->pairs.size(), 1)));
     {
@@ -786,7 +792,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
     const bool ix16 = maxMt < 65536u && maxK < 32768u;   // 16-bit indices in the kernel's LDS tables (top bit of a row's minpos: tie flag)
     // bounded kNN: the orientation filter of phase B is fused into the epilogue
-    OrientFuse of{mode == 0 ? c->d_inv_tgt.p : nullptr, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
+    OrientFuse of{mode == 0 ? c->d_inv_tgt.p : nullptr, c->tgt16, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
     uint32_t tie_stride = 0;
     if (mode == 0) {   // rows with equal overlaps are collected here and replayed in the reference's heap order
         uint32_t mt = 0;
@@ -940,7 +946,7 @@ int l3d_expand_slot_indices(l3d_ctx* c, uint32_t first, uint32_t count) {
         max_row_slots = std::max<uint64_t>(max_row_slots, (uint64_t)c->pairs[p].Ms * c->pairs[p].K);
     for (uint32_t p = first; p < first + count; ++p)
         if (c->pair_done[p]) return fail(L3D_ERR_STATE, "l3d_expand_slot_indices: pair already present on this rank");
-    const OrientFuse of{c->d_inv_tgt.p, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
+    const OrientFuse of{c->d_inv_tgt.p, c->tgt16, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
     L3D_HIP_CHECK(launch_expand_slot_idx(c->d_views.p, c->d_pairs.p, first, count, max_row_slots, c->d_slot_idx.p,
                                          c->d_slots.p, of, c->stream));
     for (uint32_t p = first; p < first + count; ++p) c->pair_done[p] = c->pair_counted[p] = 1;
@@ -1222,7 +1228,7 @@ static int lists_prepare(l3d_ctx* c, int caps_mode) {
         uint32_t p1 = p0;
         while (p1 < P && !c->pair_counted[p1] && c->pair_done[p1]) ++p1;
         L3D_HIP_CHECK(launch_orient_pairs(c->d_views.p, c->d_pairs.p + p0, p1 - p0, max_slots, c->d_slots.p, c->d_inv_tgt.p,
-                                          c->orient_lo, c->orient_hi, st));
+                                          c->tgt16, c->orient_lo, c->orient_hi, st));
         for (uint32_t p = p0; p < p1; ++p) c->pair_counted[p] = 1;
         p0 = p1;
     }
@@ -1283,7 +1289,7 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
         if (max_Mt) {
             // (views beyond the LDS capacity of k_pair_csr keep their cursors in global memory: 64 dummy words per pair)
             if (max_Mt > 32768 || std::getenv("L3D_CSR_GLOBAL")) L3D_HIP_CHECK(c->d_csr_dummy.reserve((size_t)P * 64));
-            L3D_HIP_CHECK(launch_pair_csr(c->d_pairs.p, P, max_Mt, pair_poff, c->d_inv_tgt.p, c->d_poff.p, c->d_inv_refs.p,
+            L3D_HIP_CHECK(launch_pair_csr(c->d_pairs.p, P, max_Mt, pair_poff, c->d_inv_tgt.p, c->tgt16, c->d_poff.p, c->d_inv_refs.p,
                                           c->d_csr_dummy.p, v0, v0 + nv, st));
         }
     }
@@ -1320,7 +1326,7 @@ static int tail_run(l3d_ctx* c, bool fresh) {
     if (!fresh) L3D_HIP_CHECK(hipMemsetAsync(changed, 0, (z.words - z.changed) * 4, st));
     // as many launches as the last call needed + 1 (a launch is a no-op once nothing changes; the last one enqueued
     // must report "no change", else the host keeps sweeping)
-    const uint32_t n_sweeps = std::min(kChainSweeps, std::max(3u, c->chain_need + 1));
+    const uint32_t n_sweeps = std::min(kChainSweeps, std::max(2u, c->chain_need + 1));
     c->chain_enqueued = n_sweeps;
     for (uint32_t s2 = 0; s2 < n_sweeps; ++s2)
         L3D_HIP_CHECK(launch_chain_sweep(lp, positive_of(c), changed, s2, st));

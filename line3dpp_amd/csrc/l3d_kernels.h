@@ -60,7 +60,9 @@ constexpr uint32_t kCullMaxSegs = 1u << 20; // 20 index bits in the sort keys be
 // the orientation filter of phase B fused into whatever produces a slot (match epilogue, exchange expansion)
 struct OrientFuse {
     uint32_t* inv_tgt;              // [n_slots] target segment of a slot that hands an inverse match to its target view
-                                    // (kSlotInvAlive), kEmpty otherwise: the 4-byte stream k_pair_csr sorts by target
+                                    // (kSlotInvAlive), kEmpty otherwise: the stream k_pair_csr sorts by target
+    uint32_t tgt16;                 // 1: the stream holds 16-bit entries (0xFFFF: none) -- every view of the scene has fewer
+                                    // than 65 535 segments: half the bytes the epilogue writes and k_pair_csr reads twice
     OrientThr thr;
     // rows in which the match kernel saw equal overlaps (the reference's heap order decides there): (pair, source row),
     // replayed by k_match_tied_rows
@@ -111,7 +113,7 @@ hipError_t launch_scan64(const unsigned long long* in, uint32_t n, unsigned long
 // the inverse hypotheses of every pair that hands matches to a later view, sorted by target segment (counting sort per
 // pair, one workgroup each): poff = per-pair CSR offsets over the target's segments, refs = the slot indices in that order
 hipError_t launch_pair_csr(const PairDesc* pairs, uint32_t n_pairs, uint32_t max_Mt, const PairCsr* pair_csr,
-                           const uint32_t* inv_tgt, uint32_t* poff, uint32_t* refs, uint32_t* dummy,
+                           const uint32_t* inv_tgt, uint32_t tgt16, uint32_t* poff, uint32_t* refs, uint32_t* dummy,
                            uint32_t tgt_v0, uint32_t tgt_v1, hipStream_t st);
 hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, uint32_t world, hipStream_t st);
 struct ListView; struct OutPair; struct InPair;
