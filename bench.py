@@ -369,9 +369,11 @@ def main():
         f, c = 0, len(pairs)
     my_pairs = pairs[f:f + c]
     # algorithmic bytes per launch (SURVEY.md §8d / DESIGN.md): per directed pair 16*(Ms+Mt) B of segment
-    # records read + (32 + 4)*kNN*Ms B written: the result slots and, since the orientation filter is fused into
-    # the kernel, the 4-byte inverse-list position of every slot (SURVEY's bound is 40*kNN*Ms)
-    algo_bytes = sum(16 * (M[s] + M[t]) + 36 * kNN * M[s] for s, t in my_pairs)
+    # records read + (32 + 2)*kNN*Ms B written: the result slots and, since the orientation filter is fused into
+    # the kernel, the 2-byte inverse target of every slot (round 4; 4 bytes for views of 65 535 segments and more;
+    # rounds 1-3: a 4-byte inverse-list position, 36 B per slot; SURVEY's bound is 40*kNN*Ms)
+    tgt_bytes = 2 if max(M.values()) < 65535 else 4
+    algo_bytes = sum(16 * (M[s] + M[t]) + (32 + tgt_bytes) * kNN * M[s] for s, t in my_pairs)
     my_tests = sum(M[s] * M[t] for s, t in my_pairs)
     # (one launch per step on one GPU; a rank of the halo form matches its pairs in two or three launches: the figures
     # below are per step, i.e. over all of a step's launches of the kernel)

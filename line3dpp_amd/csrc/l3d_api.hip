@@ -368,10 +368,24 @@ l3d_ctx* l3d_create(int device, void* stream) {
         constexpr size_t kWarmWords = (1u << 20) / 4;
         bool ok = d.reserve(kWarmWords) == hipSuccess && h.reserve(kWarmWords) == hipSuccess;
         ok = ok && hipMemsetAsync(d.p, 0, kWarmWords * 4, st) == hipSuccess;
-        for (size_t bytes : {(size_t)64, (size_t)4096, (size_t)65536, (size_t)1 << 20}) {
-            ok = ok && hipMemcpyAsync(h.p, d.p, bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
-            ok = ok && hipMemcpyAsync(d.p, h.p, bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+        // (round 4, profiles/r04_first_call.txt: the runtime sets its copy paths up lazily PER SIZE CLASS, DIRECTION AND
+        // STATE OF THE STREAM -- 8 ms at the first host-to-device copy of 16 KiB or more (tools/copy_probe.py); with
+        // start-up copies that all met an idle stream the first matchImages was fast and the SECOND paid 7.4 ms in a
+        // device-to-host read-back queued behind its kernels; with start-up copies that all met a busy stream the first
+        // upload of the first l3d_match_begin -- idle stream -- paid 8 ms again.  So both: every size class in both
+        // directions once on an idle stream and once right behind a fill that keeps it busy.)
+        const size_t sizes[] = {64, 1024, 4096, 16384, 65536, 262144, (size_t)1 << 20};
+        for (size_t bytes : sizes) {
+            ok = ok && hipMemcpyAsync(d.p, h.p, bytes, hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+            ok = ok && hipMemcpyAsync(h.p, d.p, bytes, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
         }
+        for (int rep = 0; rep < 2; ++rep)
+            for (size_t bytes : sizes) {
+                ok = ok && hipMemsetAsync(d.p, 0, kWarmWords * 4, st) == hipSuccess;
+                ok = ok && hipMemcpyAsync(h.p, d.p, bytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+                ok = ok && hipMemsetAsync(d.p, 0, kWarmWords * 4, st) == hipSuccess;
+                ok = ok && hipMemcpyAsync(d.p, h.p, bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+            }
         ok = ok && warm_match(st) == hipSuccess && warm_lists(st) == hipSuccess && warm_scan(st) == hipSuccess &&
              warm_views(st) == hipSuccess && warm_affinity(st) == hipSuccess && warm_rdd(st) == hipSuccess;
         ok = ok && hipStreamSynchronize(st) == hipSuccess;
@@ -1237,9 +1251,14 @@ static int lists_prepare(l3d_ctx* c, int caps_mode) {
         // overflow, so that the regrow path (check_pass) can be exercised at any scene size
         const double scale = [] { const char* e = std::getenv("L3D_POOL_SCALE"); const double v = e ? std::atof(e) : 1.0; return v > 0.0 ? v : 1.0; }();
         const double ns = scale * (double)c->n_slots;
-        c->lp_ecap = (uint32_t)std::max<double>(ns / 4 / kListPools, scale < 1.0 ? 16 : 512);
-        c->lp_hcap = (uint32_t)std::max<double>(ns / 8 / kListPools, scale < 1.0 ? 16 : 256);
-        c->lp_ccap = (uint32_t)std::max<double>(ns / 2 / kListPools, scale < 1.0 ? 32 : 1024);
+        // (first call of a scene: generous -- the strides are FITTED to what the scene needed afterwards, and a pass that
+        // outgrows its pools is repeated: the bundled testdata, C0, with its many supporters per slot, used to repeat its
+        // first list pass twice.  Four times the round-3 estimate while that stays below ~4 GiB of pools in all.)
+        const double bytes1 = ns * (sizeof(EdgeRec) / 4.0 + sizeof(HypHdr) / 8.0 + sizeof(CandRec) / 2.0);
+        const double gen = scale < 1.0 ? 1.0 : std::min(4.0, std::max(1.0, 4.0e9 / std::max(bytes1, 1.0)));
+        c->lp_ecap = (uint32_t)std::max<double>(gen * ns / 4 / kListPools, scale < 1.0 ? 16 : 512);
+        c->lp_hcap = (uint32_t)std::max<double>(gen * ns / 8 / kListPools, scale < 1.0 ? 16 : 256);
+        c->lp_ccap = (uint32_t)std::max<double>(gen * ns / 2 / kListPools, scale < 1.0 ? 32 : 1024);
     }
     c->lp_scap = std::max<uint32_t>(c->lp_scap, G / kListPools + 64);   // 30-50 % of the segments have candidates; grows on demand
     if (!c->huge_cap) c->huge_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->n_slots / 16, 1u << 20), 1u << 30);
