@@ -342,17 +342,30 @@ def main():
         step()
     kern_ms, kern_launches, phase = 0.0, 0, dict(begin=0.0, match=0.0, finish=0.0, affinity=0.0)
     lists_ms_sum, record_kbytes = 0.0, 0
+    # The timed steps record ONE pair of HIP events, the one around the dominant kernel (roofline.achieved is its live
+    # event time): an event between two kernels costs a ~6 us bubble on the stream, and a call has ten of them at the
+    # default level (l3d_set_timing_level).  The per-phase times come from separate steps, untimed, with all events on.
+    import ctypes as C
+    from line3dpp_amd import _lib
+    l3d.setTimingLevel(1)
+    tm_raw = _lib.Timings()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        l3d.L.l3d_get_timings(l3d.h, C.byref(tm_raw))
+        kern_ms += tm_raw.match_kernel_ms; kern_launches += tm_raw.match_kernel_launches
+    barrier()
+    dt = time.perf_counter() - t0
+    l3d.setTimingLevel(2)
+    phase_steps = max(1, min(args.steps, 5))
+    for _ in range(phase_steps):
+        step()
         tm = l3d.timings()
-        kern_ms += tm["match_kernel_ms"]; kern_launches += tm["match_kernel_launches"]
         phase["begin"] += tm["begin_ms"]; phase["match"] += tm["match_pairs_ms"]
         phase["finish"] += tm["finish_ms"]; phase["affinity"] += tm["affinity_ms"]
         lists_ms_sum += tm.get("lists_ms", 0.0); record_kbytes = tm.get("record_kbytes", 0)
     barrier()
-    dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -483,15 +496,17 @@ def main():
                                    f"epipolar_overlap=0.25; matchImages + affinity fill",
                        "pair_tests_per_step": pair_tests, "directed_pairs": len(pairs),
                        "parallelism": f"pair-sharded x{world}" if world > 1 else "single GPU"},
-            "phase_ms": {k: round(v / args.steps, 4) for k, v in phase.items()},
+            "phase_ms": {k: round(v / phase_steps, 4) for k, v in phase.items()},
             "cold_ms": cold["cold_ms"] if cold else None, "second_scene_ms": cold.get("second_scene_ms") if cold else None,
             "cold": cold,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }
         if world == 1:
-            out["phase_ms"]["lists_part_of_finish"] = round(lists_ms_sum / args.steps, 4)
-            out["multi_gpu_model"] = multi_gpu_model(pairs, M, kNN, {k: v / args.steps for k, v in phase.items()},
-                                                     lists_ms_sum / args.steps, 1024.0 * record_kbytes)
+            out["phase_ms"]["lists_part_of_finish"] = round(lists_ms_sum / phase_steps, 4)
+            out["phase_ms"]["measured_in"] = (f"{phase_steps} separate untimed steps with all ten HIP events of a call on "
+                                              "(l3d_set_timing_level 2); the timed steps record only the pair around the match kernel")
+            out["multi_gpu_model"] = multi_gpu_model(pairs, M, kNN, {k: v / phase_steps for k, v in phase.items()},
+                                                     lists_ms_sum / phase_steps, 1024.0 * record_kbytes)
         if world > 1 and getattr(l3d, "dist_ms", None):
             # rank 0's host wall time between the synchronisation points of the sharded call, per call (all calls incl.
             # warm-up): this rank's pairs | index all-gather | expansion + this rank's share of the list pass | all-gather

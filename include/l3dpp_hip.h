@@ -329,6 +329,12 @@ typedef struct l3d_timings {
                             * multi-GPU run all-gather */
 } l3d_timings;
 int l3d_get_timings(l3d_ctx*, l3d_timings*);
+/* How many of the context's HIP events a call records (they feed l3d_timings; the reference has no such thing: its
+ * timing is the wall clock of main_*.cpp).  2 (default): all ten -- every field above is filled; 1: only the pair around
+ * the pair-matching kernel (match_kernel_ms; the other times read 0); 0: none.  An event between two kernels costs a
+ * ~6 us bubble on the stream, which a 1.6 ms call notices: bench.py times its steps at level 1 and takes the phase
+ * breakdown from separate steps at level 2. */
+int l3d_set_timing_level(l3d_ctx*, int level);
 
 /* ---- (2) seam layer ------------------------------------------------------------------ */
 

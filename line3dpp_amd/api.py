@@ -287,6 +287,10 @@ class Line3D:
         self._check(self.L.l3d_get_sparse_matrix(self.h, int(sort_by_row), ptr(ent), ptr(start)), "sparse_matrix")
         return ent[:ne.value], start[:nr.value]
 
+    def setTimingLevel(self, level):
+        """l3d_set_timing_level: 2 = every phase timed with HIP events (default), 1 = the match kernel only, 0 = none"""
+        return self._check(self.L.l3d_set_timing_level(self.h, int(level)), "setTimingLevel")
+
     def timings(self):
         t = Timings()
         self.L.l3d_get_timings(self.h, C.byref(t))

@@ -2,13 +2,14 @@
 // scoringCPU (:1208-1294) + storeInverseMatches (:1672-1699) + filterMatches (:1586-1669) for ALL views.
 //
 //   k_pair_csr      the potential inverse hypotheses of each directed pair, counting-sorted by target segment in LDS
-//                   (16-byte records + per-pair CSR offsets over the target view's segments; no device atomics)
+//                   (slot indices + per-pair CSR offsets over the target view's segments; no device atomics)
 //   k_lists<WPL>    THE dense pass, one wave (long lists: one 4-wave workgroup) per 2D segment: gathers the segment's
 //                   hypotheses in canonical (= reference single-thread) order, sorts them by depth, finds the pairs
 //                   (i, j) with similarityForScoring(i, j) > 0.5 inside each hypothesis' depth window (conservative
-//                   window from slot data alone, then the reference's exact decision on the few candidates, full
-//                   lanes), evaluates their similarity and emits EDGES + one HEADER per supported hypothesis
-//                   (l3d_lists.h).  98 % of the hypotheses have no supporter and leave no trace.
+//                   window from slot data alone) and leaves them as CANDIDATES.  98 % of the hypotheses have none.
+//   k_cand_exact    the reference's exact decision and similarity for every candidate, one per thread, full waves
+//   k_edges         one wave per segment with candidates: the accepted ones as EDGES in (i, j) order + one HEADER per
+//                   supported hypothesis (l3d_lists.h)
 //   k_lists_huge    the same for lists beyond the LDS capacity of k_lists<4> (global-memory staging, all pairs)
 //   k_chain_sweep   the reference's chain (view v sees the inverse matches of views u < v whose score was > 0,
 //                   :1680) as a monotone fixed point over the headers: positive[slot] only ever gains bits and the
@@ -508,7 +509,7 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
                     CandRec r;
                     r.ij = (i << 16) | j; r.ref_i = e_ref[i]; r.ref_j = e_ref[j]; r.pf_i = e_pf[i];
                     r.tvj = e_tv[j] | (e_pf[j] & kHypInv);
-                    r.a1 = e_d1[i]; r.a2 = e_d2[i]; r.b1 = e_d1[j]; r.b2 = e_d2[j]; r.sim = -1.0f;
+                    r.a1 = e_d1[i]; r.a2 = e_d2[i]; r.b1 = e_d1[j]; r.b2 = e_d2[j]; r.sim = __uint_as_float(g);
                     lp.cands[w++] = r;
                 });
             }
@@ -804,7 +805,7 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
                 CandRec r;
                 r.ij = (i << 16) | j; r.ref_i = e_ref[i]; r.ref_j = e_ref[j]; r.pf_i = e_pf[i];
                 r.tvj = e_tv[j] | (e_pf[j] & kHypInv);
-                r.a1 = e_d1[i]; r.a2 = e_d2[i]; r.b1 = e_d1[j]; r.b2 = e_d2[j]; r.sim = -1.0f;
+                r.a1 = e_d1[i]; r.a2 = e_d2[i]; r.b1 = e_d1[j]; r.b2 = e_d2[j]; r.sim = __uint_as_float(g);
                 lp.cands[w++] = r;
             });
         }
@@ -812,16 +813,38 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
     }
 }
 
-// ---- candidates -> edges: one wave per segment with candidates.  The reference's decision and value for every
-// candidate (one per lane, full lanes: this is where the fp64 unprojections, acos and exp live), then the accepted
-// ones as EDGES in (i, j) order with one HEADER per hypothesis i that has any.  The candidates arrive grouped by i
-// in canonical order (one contiguous run per i, j in walk order), so the order only has to be fixed inside a run.
+// ---- the reference's decision and value for every candidate: ONE CANDIDATE PER THREAD over the pools ---------------
+// This is where the fp64 unprojections, acos and exp of phase B live.  Until round 4 k_edges did it with one wave per
+// segment -- a segment has ~17 candidates on C1, so three of four lanes idled through the most expensive code of the
+// pass (PMC: 4.2 active lanes per issue cycle against 10-11 in k_lists / k_match_pairs).  The candidates of a pool are
+// contiguous, so a flat launch over (pool, index) runs the same arithmetic with full waves; what was wave-uniform there
+// (the segment's view, its rays) is gathered per lane here -- neighbouring lanes mostly share it.  The list pass leaves
+// the segment in the record's `sim` word; this kernel replaces it by the similarity, or by -1.
 #ifndef L3D_EDGES_WAVES
 #define L3D_EDGES_WAVES 4
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L3D_EDGES_WAVES))) void k_edges(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(L3D_EDGES_WAVES))) void k_cand_exact(
+        const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ gseg_view,
+        const SimConst sc, const ListPools lp) {
+    if (lp.flags[0] | lp.flags[2]) return;   // the candidate pools overflowed: the pass is discarded
+    const uint32_t pool = lp.pool0 + blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= min(lp.cnt[pool * 16 + 3], lp.ccap)) return;
+    CandRec* cr = lp.cands + (size_t)pool * lp.ccap + x;
+    const CandRec r = *cr;
+    const uint32_t g = __float_as_uint(r.sim);
+    const PairDesc& pd = pairs[r.pf_i & 0x7FFFFFFFu];
+    const uint32_t tvi = (r.pf_i & kHypInv) ? pd.src : pd.tgt;
+    float sim = -1.0f;
+    const bool ok = exact_support(views[gseg_view[g]], views, views[0].segx[g], r.a1, r.a2, tvi, r.b1, r.b2, sc, sim);
+    cr->sim = ok ? sim : -1.0f;
+}
+
+// ---- candidates -> edges: one wave per segment with candidates.  The accepted ones (k_cand_exact) become EDGES in
+// (i, j) order with one HEADER per hypothesis i that has any.  The candidates arrive grouped by i in canonical order
+// (one contiguous run per i, j in walk order), so the order only has to be fixed inside a run.
+__global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
                                                const uint32_t* __restrict__ gseg_view, const Slot* __restrict__ slots,
-                                               const SimConst sc, const ListPools lp, uint32_t* __restrict__ seg_of_g) {
+                                               const ListPools lp, uint32_t* __restrict__ seg_of_g) {
     const uint32_t pool = lp.pool0 + blockIdx.y, wave = 0, lane = lane_id();   // one segment per workgroup (as k_lists)
     const uint32_t k = blockIdx.x;
     if (lp.flags[0] | lp.flags[2]) return;   // the candidate pools overflowed: headers beyond the last complete list are not valid
@@ -829,33 +852,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L3D_EDGES_WA
     const CandHdr ch = lp.chdrs[pool * lp.scap + k];
     const uint32_t g = ch.g, n = ch.cnt;
     CandRec* cand = lp.cands + ch.begin;
-    const ViewDev& v = views[gseg_view[g]];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    auto sync_wave = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    };
     // (ij, sim) of the list's candidates live in LDS for the order fixing below (lists beyond kEdgeLds entries walk
     // global memory instead: correct, slow, rare)
     constexpr uint32_t kEdgeLds = 512;
     __shared__ uint32_t s_ij[1][kEdgeLds];
     __shared__ float s_sim[1][kEdgeLds];
     const bool in_lds = n <= kEdgeLds;
-    // pass 1: the exact test
+    // pass 1: how many passed the exact test
     uint32_t n_acc = 0;
     for (uint32_t x0 = 0; x0 < n; x0 += 64) {
         const uint32_t x = x0 + lane;
         bool ok = false;
         if (x < n) {
-            const CandRec r = cand[x];
-            const PairDesc& pd = pairs[r.pf_i & 0x7FFFFFFFu];
-            const uint32_t tvi = (r.pf_i & kHypInv) ? pd.src : pd.tgt;
-            float sim = -1.0f;
-            ok = exact_support(v, views, views[0].segx[g], r.a1, r.a2, tvi, r.b1, r.b2, sc, sim);
-            if (!ok) sim = -1.0f;
-            if (in_lds) { s_ij[wave][x] = r.ij; s_sim[wave][x] = sim; }
-            else if (ok) cand[x].sim = sim;
+            const float sim = cand[x].sim;
+            ok = sim >= 0.0f;
+            if (in_lds) { s_ij[wave][x] = cand[x].ij; s_sim[wave][x] = sim; }
         }
         n_acc += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ok));
     }
@@ -864,9 +876,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L3D_EDGES_WA
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    } else {
-        sync_wave();
-    }
+    }   // (beyond the LDS capacity the passes below read the records k_cand_exact left: nothing of this wave's own)
     auto ij_of = [&](uint32_t y) -> uint32_t { return in_lds ? s_ij[wave][y] : cand[y].ij; };
     auto sim_of = [&](uint32_t y) -> float { return in_lds ? s_sim[wave][y] : cand[y].sim; };
     // inside its run: rank of an accepted pair by j, accepted pairs before it (0: it writes the header), run total
@@ -1239,8 +1249,8 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
     if (hsa.run_huge)
         hipLaunchKernelGGL(k_lists_huge, dim3(256), dim3(256), 0, st, views, pairs, lviews, opairs, ipairs, gseg_view, poff,
                            inv, slots, lp, hs);
-    hipLaunchKernelGGL(k_edges, dim3(lp.scap, lp.npools), dim3(64), 0, st, views, pairs, gseg_view, slots, sc, lp,
-                       seg_of_g);
+    hipLaunchKernelGGL(k_cand_exact, dim3((lp.ccap + 255) / 256, lp.npools), dim3(256), 0, st, views, pairs, gseg_view, sc, lp);
+    hipLaunchKernelGGL(k_edges, dim3(lp.scap, lp.npools), dim3(64), 0, st, views, pairs, gseg_view, slots, lp, seg_of_g);
     if (lp.npools < kListPools) hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, st, lp);   // sharded pass
     return hipGetLastError();
 }

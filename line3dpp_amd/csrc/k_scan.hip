@@ -4,10 +4,12 @@
 // scan of sums / down-sweep that was twelve launches of a few microseconds of work each.  Here a scan is a single
 // pass with decoupled look-back: a tile (1024 threads x 4 items) scans itself, publishes its aggregate at once, adds
 // up the aggregates of the tiles before it -- 64 of them per step, one per lane of its first wave, stopping at the
-// first one that already knows its inclusive prefix -- and publishes its own inclusive prefix.  A tile only ever
-// waits for tiles with a lower index, which were dispatched before it.
+// first one that already knows its inclusive prefix -- and publishes its own inclusive prefix.  A workgroup takes its
+// tile index from a ticket counter when it starts, so a tile only ever waits for tiles whose workgroups are already
+// running -- whatever order the hardware dispatches the workgroups of a launch in (until round 4 the tile index was
+// blockIdx.x, which relied on in-order dispatch).
 //
-// State: one 64-bit word per tile and 32-bit lane of the element type (kind << 32 | value; kind 0 = nothing yet,
+// Work space: [0] tiles finished, [1] tickets handed out, then the state: one 64-bit word per tile and 32-bit lane of the element type (kind << 32 | value; kind 0 = nothing yet,
 // 1 = aggregate, 2 = inclusive prefix), written and read whole with agent-scope atomics, so no fence is needed.  The
 // last tile to finish zeroes the state again: the work space is all-zero between launches (it is zeroed when it is
 // allocated, DevBuf::reserve_zeroed) and no launch needs a memset of its own.
@@ -51,15 +53,18 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-// ws: [0] tiles finished, [1 + tile * LANES + l] state of lane l of a tile
+// ws: [0] tiles finished, [1] next ticket, [2 + tile * LANES + l] state of lane l of a tile
 template <class T>
 __global__ __launch_bounds__(kScanBlock) void k_scan(const T* __restrict__ in, uint32_t n, T* __restrict__ out,
                                                      T* __restrict__ total_out, unsigned long long* __restrict__ ws) {
     constexpr uint32_t LANES = sizeof(T) / 4;
     __shared__ T wsum[17];
     __shared__ T s_prefix;
-    __shared__ uint32_t s_last;
-    const uint32_t tile = blockIdx.x, nb = gridDim.x, tid = threadIdx.x, lane = tid & 63u;
+    __shared__ uint32_t s_last, s_tile;
+    const uint32_t nb = gridDim.x, tid = threadIdx.x, lane = tid & 63u;
+    if (tid == 0) s_tile = (uint32_t)__hip_atomic_fetch_add(&ws[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t tile = s_tile;
     const uint32_t base = tile * kScanTile + tid * kScanItems;
     T a[kScanItems];
     T v = 0;
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(const T* __restrict__ in, u
     for (uint32_t k = 0; k < kScanItems; ++k) { a[k] = (base + k < n) ? in[base + k] : (T)0; v += a[k]; }
     T agg;
     T ex = block_exclusive_scan(v, wsum, agg);
-    unsigned long long* state = ws + 1;
+    unsigned long long* state = ws + 2;
     if (tid < 64) {
         if (lane < LANES)
             __hip_atomic_store(&state[(size_t)tile * LANES + lane],
@@ -124,7 +129,10 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(const T* __restrict__ in, u
     if (s_last) {
         for (uint32_t i = tid; i < nb * LANES; i += kScanBlock)
             __hip_atomic_store(&state[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0) __hip_atomic_store(&ws[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(&ws[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -138,7 +146,7 @@ hipError_t launch(const T* in, uint32_t n, T* out, unsigned long long* ws, T* to
 }  // namespace
 
 // 64-bit words of work space a scan of n elements needs (zeroed once: DevBuf::reserve_zeroed)
-size_t scan_ws_words(size_t n, uint32_t bytes_per_element) { return 2 + (n / kScanTile + 1) * (bytes_per_element / 4); }
+size_t scan_ws_words(size_t n, uint32_t bytes_per_element) { return 4 + (n / kScanTile + 1) * (bytes_per_element / 4); }
 
 // out[0..n] = exclusive scan of in[0..n) (out[n] = total, also stored to *total).  in and out may be the same array.
 hipError_t launch_scan(const uint32_t* in, uint32_t n, uint32_t* out, unsigned long long* ws, uint32_t* total, hipStream_t st) {

@@ -548,10 +548,14 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
 __global__ __launch_bounds__(1024) void k_median_all(const float* __restrict__ depths,
                                                      const uint32_t* __restrict__ hyp_off,
                                                      const uint32_t* __restrict__ seg_base,
+                                                     const uint32_t* __restrict__ tie_total, uint32_t* __restrict__ tie_out,
                                                      float* __restrict__ out_median) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_prefix, s_rank;
     const uint32_t v = blockIdx.x;
+    // the last kernel of a call's tail: the cumulative count of replayed rows (k_match_tied_rows) travels with the
+    // call's one read-back instead of a copy of its own
+    if (v == 0 && threadIdx.x == 0 && tie_total) *tie_out = *tie_total;
     const uint32_t h0 = hyp_off[seg_base[v]], h1 = hyp_off[seg_base[v + 1]];
     const uint32_t n = 2u * (h1 - h0);
     const float* dv = depths + 2u * h0;
@@ -700,9 +704,9 @@ hipError_t launch_score_all(uint32_t g0, uint32_t G, const uint32_t* off, const 
     return hipGetLastError();
 }
 hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base,
-                             float* out, hipStream_t st) {
+                             const uint32_t* tie_total, uint32_t* tie_out, float* out, hipStream_t st) {
     if (!V) return hipSuccess;
-    hipLaunchKernelGGL(k_median_all, dim3(V), dim3(1024), 0, st, depths, hyp_off, seg_base, out);
+    hipLaunchKernelGGL(k_median_all, dim3(V), dim3(1024), 0, st, depths, hyp_off, seg_base, tie_total, tie_out, out);
     return hipGetLastError();
 }
 

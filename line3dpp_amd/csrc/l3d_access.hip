@@ -145,16 +145,16 @@ int l3d_get_sparse_matrix(l3d_ctx* c, int sort_by_row, l3d_float4* entries, int3
     return L3D_OK;
 }
 
+int l3d_set_timing_level(l3d_ctx* c, int level) {
+    if (!c || level < 0 || level > 2) return fail(L3D_ERR_ARG, "l3d_set_timing_level: level 0, 1 or 2");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    c->timing_level = level;
+    return L3D_OK;
+}
+
 int l3d_get_timings(l3d_ctx* c, l3d_timings* t) {
     if (!c || !t) return fail(L3D_ERR_ARG, "null argument");
-    *t = c->tm;
-    if (c->d_tie_count.p) {   // rows replayed in the reference's priority_queue order, cumulative (diagnostics: read on demand)
-        uint32_t v[4] = {0, 0, 0, 0};
-        (void)hipSetDevice(c->device);
-        L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
-        L3D_HIP_CHECK(hipMemcpy(v, c->d_tie_count.p, 16, hipMemcpyDeviceToHost));
-        t->tied_rows = v[2];
-    }
+    *t = c->tm;   // (nothing here waits for the GPU: tied_rows arrives with the read-back of l3d_match_finish)
     return L3D_OK;
 }
 

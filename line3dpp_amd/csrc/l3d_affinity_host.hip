@@ -48,7 +48,7 @@ static int affinity_collinear(l3d_ctx* c) {
         L3D_HIP_CHECK(c->d_item_sim.reserve(std::max<uint32_t>(total, 1)));
         L3D_HIP_CHECK(launch_aff_coll_sim(mode, n, c->d_surv_sg.p, c->d_surv_tg.p, c->d_hyp_of_seg.p, c->d_hyps.p,
                                           c->d_views.p, c->d_seg_base.p, c->d_gseg_view.p, c->d_coll_off.p,
-                                          c->d_coll_idx.p, c->d_item_off.p, c->d_vaff.p, (c->d_medians.p + 8), (const float*)(c->d_vaff.p + V),
+                                          c->d_coll_idx.p, c->d_item_off.p, c->d_vaff.p, (c->d_med + 8), (const float*)(c->d_vaff.p + V),
                                           c->two_sigA_sqr, c->d_item_seg.p, c->d_item_sim.p, st));
         off[mode].resize((size_t)n + 1); seg[mode].resize(total); sim[mode].resize(total);
         L3D_HIP_CHECK(hipStreamSynchronize(st));
@@ -140,7 +140,7 @@ int affinity_core(l3d_ctx* c) {
     const uint32_t N = c->n_surv, H = c->n_hyps;
     L3D_HIP_CHECK(c->d_scal.reserve(16));
     L3D_HIP_CHECK(c->d_scan_ws.reserve_zeroed(scan_ws_words((size_t)c->G + 2 * (size_t)N, 4), st));
-    L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
+    if (c->ev_on(6)) L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
     if (N > 0 && H > 0) {
         L3D_HIP_CHECK(c->d_vaff.reserve(V + 1));
         L3D_HIP_CHECK(c->d_simv.reserve(N)); L3D_HIP_CHECK(c->d_ca.reserve(N)); L3D_HIP_CHECK(c->d_cb.reserve(N));
@@ -149,14 +149,14 @@ int affinity_core(l3d_ctx* c) {
         L3D_HIP_CHECK(c->d_scan_ws.reserve_zeroed(scan_ws_words(2 * (size_t)N, 4), st));
         L3D_HIP_CHECK(upload_table(c->d_vaff, c->h_vaff, va.data(), ((size_t)V + 1) * sizeof(ViewAff), c->up_vaff, st));
         L3D_HIP_CHECK(launch_aff_sim(N, c->d_surv_sg.p, c->d_surv_tg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_vaff.p,
-                                     (c->d_medians.p + 8), (const float*)(c->d_vaff.p + V), c->two_sigA_sqr, c->d_simv.p, c->d_ca.p, c->d_cb.p,
+                                     (c->d_med + 8), (const float*)(c->d_vaff.p + V), c->two_sigA_sqr, c->d_simv.p, c->d_ca.p, c->d_cb.p,
                                      st));
         if (c->collinearity_t > (float)kEps) {
             const int rc = affinity_collinear(c);
             if (rc) return rc;
-            L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
+            if (c->ev_on(7)) L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
             L3D_HIP_CHECK(hipStreamSynchronize(st));
-            c->tm.affinity_ms = ev_ms(c->ev[6], c->ev[7]);
+            c->tm.affinity_ms = ev_ms(c, 6, 7);
             c->affinity_done = true;
             return L3D_OK;
         }
@@ -183,10 +183,10 @@ int affinity_core(l3d_ctx* c) {
             counts_pending = true;
         }
     }
-    L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
+    if (c->ev_on(7)) L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
     L3D_HIP_CHECK(hipStreamSynchronize(st));
     if (counts_pending) { c->aff_n_edges = 2 * c->h_cnt.p[12]; c->aff_n_rows = c->h_cnt.p[13]; c->aff_host_valid = false; }
-    c->tm.affinity_ms = ev_ms(c->ev[6], c->ev[7]);
+    c->tm.affinity_ms = ev_ms(c, 6, 7);
     c->affinity_done = true;
     return L3D_OK;
 }

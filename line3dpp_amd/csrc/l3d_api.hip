@@ -324,6 +324,7 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
     (void)hipEventElapsedTime(&ms, a, b);
     return ms;
 }
+float ev_ms(const ::l3d_ctx* c, int a, int b) { return c->ev_on(a) && c->ev_on(b) ? ev_ms(c->ev[a], c->ev[b]) : 0.0f; }
 
 }  // namespace l3d
 
@@ -424,7 +425,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_coll_cnt.release(); c->d_coll_off.release(); c->d_coll_idx.release(); c->d_item_cnt.release();
     c->d_item_off.release(); c->d_item_seg.release(); c->d_item_sim.release();
     c->d_surv.release();
-    c->d_hyp_of_seg.release(); c->d_depths.release(); c->d_medians.release(); c->d_hyps.release();
+    c->d_hyp_of_seg.release(); c->d_depths.release(); c->d_med = nullptr; c->d_hyps.release();
     c->d_vaff.release(); c->d_simv.release(); c->h_vaff.release(); c->d_ca.release(); c->d_cb.release();
     c->d_flag.release(); c->d_epos.release(); c->d_first_touch.release(); c->d_touch_flag.release();
     c->d_touch_rank.release(); c->d_edges.release(); c->d_l2g.release();
@@ -568,7 +569,7 @@ int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
 }
 
 static int match_begin_body(l3d_ctx* c) {
-    L3D_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
+    if (c->ev_on(0)) L3D_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
     for (auto* v : c->order) {
         if (!c->fixed3Dregularizer) v->k = spatial_reg(*v, c->sigma_p);      // computeSpatialRegularizer
         else v->k = c->sigma_p / c->med_scene_depth;                          // update_k, view.h:124-127
@@ -709,7 +710,7 @@ static int match_begin_body(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_tgt_band.reserve(std::max<uint64_t>(ct_off, 1)));
     L3D_HIP_CHECK(c->d_chunk_band.reserve(std::max<uint32_t>(cc_off, 1)));
     L3D_HIP_CHECK(c->d_cull_keys.reserve(std::max<uint64_t>(ck_off, 1)));
-    L3D_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
+    if (c->ev_on(1)) L3D_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
     c->tm = l3d_timings{};
     c->state = l3d_ctx::BEGUN;
     return L3D_OK;
@@ -745,8 +746,8 @@ static int ensure_aux(l3d_ctx* c) {
 // reads the phase-A events of the last run_match_kernel (the stream must have passed ev[5])
 static void collect_match_timing(l3d_ctx* c) {
     if (!c->timing_pending) return;
-    c->tm.match_kernel_ms += ev_ms(c->ev[4], c->ev[5]);
-    c->tm.cull_prepare_ms += ev_ms(c->ev[8], c->ev[4]);
+    c->tm.match_kernel_ms += ev_ms(c, 4, 5);
+    c->tm.cull_prepare_ms += ev_ms(c, 8, 4);
     c->tm.match_kernel_launches += c->pending_launches;
     c->timing_pending = false; c->pending_launches = 0;
 }
@@ -779,7 +780,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         c->work_key.version = c->pairs_version; c->work_key.first = first; c->work_key.count = count;
         c->work_key.dev = c->d_work.p;
     }
-    L3D_HIP_CHECK(hipEventRecord(c->ev[8], c->stream));
+    if (c->ev_on(8)) L3D_HIP_CHECK(hipEventRecord(c->ev[8], c->stream));
     CullPools pools{c->d_cull.p, c->d_src_perm.p, c->d_src_band.p, c->d_tgt_perm.p, c->d_tgt_sf.p, c->d_tgt_band.p,
                     c->d_chunk_band.p, c->d_cull_keys.p};
     pools.tgt_s4 = c->d_tgt_s4.p; pools.tgt_sd = c->d_tgt_sd.p;
@@ -803,7 +804,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
         L3D_HIP_CHECK(launch_order_items(c->d_pairs.p, first, count, maxMt, pools, (uint32_t)n_work, c->stream));
     }
-    L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
+    if (c->ev_on(4)) L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
     const bool ix16 = maxMt < 65536u && maxK < 32768u;   // 16-bit indices in the kernel's LDS tables (top bit of a row's minpos: tie flag)
     // bounded kNN: the orientation filter of phase B is fused into the epilogue
     OrientFuse of{mode == 0 ? c->d_inv_tgt.p : nullptr, c->tgt16, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
@@ -830,7 +831,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     } else
     L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work, maxK,
                                      c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, of, ix16, c->stream));
-    L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));
+    if (c->ev_on(5)) L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));
     if (mode == 0) {
         L3D_HIP_CHECK(launch_match_tied_rows(c->d_views.p, c->d_pairs.p, c->d_slots.p, maxK, c->epipolar_overlap, of, pools,
                                              c->d_tie_heap.p, tie_stride, c->stream));
@@ -857,7 +858,7 @@ static int match_pairs_impl(l3d_ctx* c, uint32_t first, uint32_t count, bool syn
     for (uint32_t p = first; p < first + count; ++p)
         if (c->pair_done[p]) return fail(L3D_ERR_STATE, "l3d_match_pairs: pair already matched since l3d_match_begin");
     (void)hipSetDevice(c->device);
-    L3D_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
+    if (c->ev_on(2)) L3D_HIP_CHECK(hipEventRecord(c->ev[2], c->stream));
     int rc = L3D_OK;
     if (c->kNN > 0) {
         rc = run_match_kernel(c, 0, first, count);
@@ -888,11 +889,12 @@ static int match_pairs_impl(l3d_ctx* c, uint32_t first, uint32_t count, bool syn
         rc = run_match_kernel(c, 2, first, count);
     }
     if (rc) return rc;
-    L3D_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+    if (c->ev_on(3)) L3D_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
     if (sync) {
-        L3D_HIP_CHECK(hipEventSynchronize(c->ev[3]));
+        if (c->ev_on(3)) L3D_HIP_CHECK(hipEventSynchronize(c->ev[3]));
+        else L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
         collect_match_timing(c);
-        c->tm.match_pairs_ms += ev_ms(c->ev[2], c->ev[3]);
+        c->tm.match_pairs_ms += ev_ms(c, 2, 3);
     }
     for (uint32_t p = first; p < first + count; ++p) c->pair_done[p] = 1;
     return L3D_OK;
@@ -1123,14 +1125,17 @@ static ListPools list_pools(l3d_ctx* c, uint32_t pool0 = 0, uint32_t npools = kL
     return lp;
 }
 
-// d_medians = [tot64 x 4 ([0] unused; [1] survivors | hypotheses) | median depth of each view]
-static unsigned long long* tot64_of(l3d_ctx* c) { return (unsigned long long*)c->d_medians.p; }
-static float* medians_of(l3d_ctx* c) { return c->d_medians.p + 8; }
-static size_t fin_b1(uint32_t V) { return ((size_t)8 + V + 3) & ~(size_t)3; }   // second part of h_fin (tail_run)
+// d_med = [tot64 x 4 ([0] unused; [1] survivors | hypotheses) | median depth of each view], fin_med(V) words
+static unsigned long long* tot64_of(l3d_ctx* c) { return (unsigned long long*)c->d_med; }
+static float* medians_of(l3d_ctx* c) { return c->d_med + 8; }
+static size_t fin_med(uint32_t V) { return ((size_t)8 + V + 3) & ~(size_t)3; }
+static constexpr size_t kFinHead = (size_t)kListPools * 16 + 96;   // pool counters | flags (32) | changed (64)
 
-// layout of the zero block d_lzero (one memset per pass): pool counters | flags (32) | changed (64) | max_score (V+1)
-// | kept_cnt (G) | best_pack (G x u64, 8-byte aligned)
-struct ZeroLayout { size_t flags, changed, max_score, kept, best, words; };
+// layout of the zero block d_lzero (one memset per pass): pool counters | flags (32) | changed (64) | totals and
+// medians (fin_med(V): written at the end of the tail; the call's read-back is ONE copy of the block's first
+// kFinHead + fin_med(V) words -- two copies cost a second ~12 us bubble on the stream) | max_score (V+1) | kept_cnt (G)
+// | best_pack (G x u64, 8-byte aligned)
+struct ZeroLayout { size_t flags, changed, med, max_score, kept, best, words; };
 static ZeroLayout zero_layout(uint32_t V, uint32_t G);
 // positive[slot]: the hypothesis of that slot has a positive score (k_chain_sweep); lives behind the zero block
 static uint8_t* positive_of(l3d_ctx* c) {
@@ -1138,7 +1143,7 @@ static uint8_t* positive_of(l3d_ctx* c) {
 }
 static ZeroLayout zero_layout(uint32_t V, uint32_t G) {
     ZeroLayout z;
-    z.flags = (size_t)kListPools * 16; z.changed = z.flags + 32; z.max_score = z.changed + 64;
+    z.flags = (size_t)kListPools * 16; z.changed = z.flags + 32; z.med = z.changed + 64; z.max_score = z.med + fin_med(V);
     z.kept = z.max_score + ((size_t)V + 1) * 16;   // 16 replicas per view (k_lists.hip: kMaxReplicas)
     z.best = (z.kept + G + 1) & ~(size_t)1;
     z.words = z.best + 2 * (size_t)G + 2;
@@ -1166,15 +1171,15 @@ static int lists_prepare(l3d_ctx* c, int caps_mode) {
     if (2 * c->n_slots >= (1ull << 32)) return fail(L3D_ERR_LIMIT, "more than 2^32 hypotheses");
     L3D_HIP_CHECK(c->d_seg_base.reserve(V + 1)); L3D_HIP_CHECK(c->d_gseg_view.reserve(G + 1));
     L3D_HIP_CHECK(c->d_surv_off.reserve(G + 2)); L3D_HIP_CHECK(c->d_hyp_off.reserve(G + 2));
-    L3D_HIP_CHECK(c->d_hyp_of_seg.reserve(G + 1)); L3D_HIP_CHECK(c->d_medians.reserve(V + 1 + 8));   // [two 64-bit totals + spare | medians]: read back together
+    L3D_HIP_CHECK(c->d_hyp_of_seg.reserve(G + 1));
     L3D_HIP_CHECK(c->d_cnt64.reserve(G + 2)); L3D_HIP_CHECK(c->d_off64s.reserve(G + 2));
     L3D_HIP_CHECK(c->d_scan_ws.reserve_zeroed(scan_ws_words(G, 8), st));
     L3D_HIP_CHECK(c->d_seg_of_g.reserve(G + 1)); L3D_HIP_CHECK(c->d_list2.reserve(G + 1)); L3D_HIP_CHECK(c->d_list4.reserve(G + 1)); L3D_HIP_CHECK(c->d_listH.reserve(G + 1));
     L3D_HIP_CHECK(c->d_hyps.reserve(std::max<uint32_t>(G, 1))); L3D_HIP_CHECK(c->d_depths.reserve(2 * (size_t)G + 2));
     L3D_HIP_CHECK(c->d_inv_refs.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(c->d_inv_tgt.reserve(std::max<uint64_t>(c->n_slots, 1)));
-    L3D_HIP_CHECK(c->h_fin.reserve(fin_b1(V) + kListPools * 16 + 96));
-    L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
+    L3D_HIP_CHECK(c->h_fin.reserve(kFinHead + fin_med(V)));
+    if (c->ev_on(6)) L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
     g_trace.mark("finish: reserves done");
     {   // segment -> view table: a function of the view sizes alone, kept while they (and the array) are the same
         bool sent = false;
@@ -1270,6 +1275,7 @@ static int lists_reserve(l3d_ctx* c) {
     const uint32_t V = (uint32_t)c->order.size();
     const ZeroLayout z = zero_layout(V, c->G);
     L3D_HIP_CHECK(c->d_lzero.reserve(z.words + 2 + (c->n_slots + 3) / 4));   // zero block | positive[] (one byte per slot)
+    c->d_med = (float*)(c->d_lzero.p + z.med);
     L3D_HIP_CHECK(c->d_ledges.reserve((size_t)kListPools * c->lp_ecap));
     L3D_HIP_CHECK(c->d_lhyps.reserve((size_t)kListPools * c->lp_hcap));
     L3D_HIP_CHECK(c->d_lsegs.reserve((size_t)kListPools * c->lp_scap));
@@ -1325,7 +1331,7 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
     L3D_HIP_CHECK(launch_lists(v0, nv, max_M, c->d_views.p, c->d_pairs.p, lviews, opairs, ipairs, c->d_gseg_view.p,
                                c->d_poff.p, c->d_inv_refs.p, c->d_slots.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, simc, lp,
                                c->d_seg_of_g.p, hsa, st));
-    L3D_HIP_CHECK(hipEventRecord(c->ev[9], st));
+    if (c->ev_on(9)) L3D_HIP_CHECK(hipEventRecord(c->ev[9], st));
     g_trace.mark("list pass enqueued");
     return L3D_OK;
 }
@@ -1367,16 +1373,14 @@ static int tail_run(l3d_ctx* c, bool fresh) {
                                    c->d_seg_of_g.p, lp, c->d_slots.p, c->d_surv_off.p, c->d_hyp_off.p, c->d_surv.p,
                                    c->d_surv_tg.p, c->d_surv_sg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_depths.p, st));
     g_trace.mark("seg_write enqueued");
-    L3D_HIP_CHECK(launch_median_all(V, c->d_depths.p, c->d_hyp_off.p, c->d_seg_base.p, medians_of(c), st));
+    L3D_HIP_CHECK(launch_median_all(V, c->d_depths.p, c->d_hyp_off.p, c->d_seg_base.p, c->d_tie_count.p ? c->d_tie_count.p + 2 : nullptr,
+                                    (uint32_t*)tot64_of(c), medians_of(c), st));
     g_trace.mark("median enqueued");
-    // read-backs (pinned), two copies: [0..7] 64-bit totals, [8..8+V) medians | from fin_b1(V): pool counters, flags (32),
-    // changed (64) -- the head of the zero block
-    uint32_t* h = c->h_fin.p;
-    L3D_HIP_CHECK(hipMemcpyAsync(h, c->d_medians.p, (8 + (size_t)V) * 4, hipMemcpyDeviceToHost, st));
-    g_trace.mark("read-back 1 enqueued");
-    L3D_HIP_CHECK(hipMemcpyAsync(h + fin_b1(V), c->d_lzero.p, ((size_t)kListPools * 16 + 96) * 4, hipMemcpyDeviceToHost, st));
-    g_trace.mark("read-back 2 enqueued");
-    L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
+    // the read-back (pinned), one copy: the head of the zero block -- pool counters, flags (32), changed (64) -- and
+    // behind it [0..7] the 64-bit totals, [8..8+V) the medians
+    L3D_HIP_CHECK(hipMemcpyAsync(c->h_fin.p, c->d_lzero.p, (kFinHead + fin_med(V)) * 4, hipMemcpyDeviceToHost, st));
+    g_trace.mark("read-back enqueued");
+    if (c->ev_on(7)) L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
     g_trace.mark("tail enqueued");
     return L3D_OK;
 }
@@ -1385,17 +1389,16 @@ static int tail_run(l3d_ctx* c, bool fresh) {
 // L3D_OK, an error, or kRetry after the pools were enlarged
 static constexpr int kRetry = 1;
 static int check_pass(l3d_ctx* c) {
-    const uint32_t* h0 = c->h_fin.p;
-    const uint32_t* h = h0 + fin_b1((uint32_t)c->order.size()) - 128;   // h[128 + ...]: pool counters
-    const uint32_t* hf = h + 128 + kListPools * 16;                       // flags
+    const uint32_t* h = c->h_fin.p;                                       // h[...]: pool counters
+    const uint32_t* hf = h + kListPools * 16;                             // flags
     uint32_t fl[8];
     for (int k = 0; k < 8; ++k) fl[k] = hf[k];
     if (c->shard_world > 1) {
         const uint32_t ppr = kListPools / c->shard_world;
         for (uint32_t r = 0; r < c->shard_world; ++r)
-            for (int k = 0; k < 4; ++k) fl[k] |= h[128 + (size_t)r * ppr * 16 + 8 + k];
+            for (int k = 0; k < 4; ++k) fl[k] |= h[(size_t)r * ppr * 16 + 8 + k];
         fl[6] = 0;
-        for (uint32_t r = 0; r < c->shard_world; ++r) fl[6] = std::max(fl[6], h[128 + (size_t)r * ppr * 16 + 12]);
+        for (uint32_t r = 0; r < c->shard_world; ++r) fl[6] = std::max(fl[6], h[(size_t)r * ppr * 16 + 12]);
     }
     if (fl[1]) return fail(L3D_ERR_LIMIT, "a 2D segment has more than 65535 match hypotheses");
     // lists for the global-memory kernel although its launch was left out: repeat with it (and keep it from now on)
@@ -1410,8 +1413,8 @@ static int check_pass(l3d_ctx* c) {
             // (a pass that ran out of candidate space never reached the edges: those pools double)
             uint32_t me = 0, mh = 0, ms = 0, mc = 0;
             for (uint32_t q = 0; q < kListPools; ++q) {
-                me = std::max(me, h[128 + q * 16]); mh = std::max(mh, h[128 + q * 16 + 1]);
-                ms = std::max(ms, std::max(h[128 + q * 16 + 2], h[128 + q * 16 + 4])); mc = std::max(mc, h[128 + q * 16 + 3]);
+                me = std::max(me, h[q * 16]); mh = std::max(mh, h[q * 16 + 1]);
+                ms = std::max(ms, std::max(h[q * 16 + 2], h[q * 16 + 4])); mc = std::max(mc, h[q * 16 + 3]);
             }
             const bool cands_over = mc > c->lp_ccap || ms > c->lp_scap;
             c->lp_ccap = std::max(c->lp_ccap, mc + mc / 2 + 64); c->lp_scap = std::max(c->lp_scap, ms + ms / 2 + 64);
@@ -1427,13 +1430,14 @@ static int check_pass(l3d_ctx* c) {
 // results of the converged pass -> context; matchImages' epilogue (line3D.cc:493)
 static int finish_commit(l3d_ctx* c) {
     const uint32_t V = (uint32_t)c->order.size();
-    const uint32_t* h0 = c->h_fin.p;
-    const uint32_t* h = h0 + fin_b1(V) - 128;                             // h[128 + ...]: pool counters
-    const uint32_t* changed = h + 128 + kListPools * 16 + 32;
+    const uint32_t* h = c->h_fin.p;                                       // h[...]: pool counters
+    const uint32_t* h0 = h + kFinHead;                                    // totals and medians
+    const uint32_t* changed = h + kListPools * 16 + 32;
     c->n_surv = h0[2]; c->n_hyps = h0[3];
+    c->tm.tied_rows = h0[0];   // rows replayed in the reference's priority_queue order, cumulative (k_median_all hands it over)
     {   // total length of the hypothesis lists: counted by the list pass per pool (k_lists.hip: cnt[pool * 16 + 5])
         uint64_t ents = 0;
-        for (uint32_t q = 0; q < kListPools; ++q) ents += h[128 + q * 16 + 5];
+        for (uint32_t q = 0; q < kListPools; ++q) ents += h[q * 16 + 5];
         c->n_ents = (uint32_t)std::min<uint64_t>(ents, 0xFFFFFFFFu);
         c->tm.list_entries = c->n_ents;
     }
@@ -1443,9 +1447,9 @@ static int finish_commit(l3d_ctx* c) {
         uint64_t ne = 0;
         uint32_t me = 0, mh = 0, ms = 0, mc = 0;
         for (uint32_t q = 0; q < kListPools; ++q) {
-            ne += h[128 + q * 16];
-            me = std::max(me, h[128 + q * 16]); mh = std::max(mh, h[128 + q * 16 + 1]);
-            ms = std::max(ms, std::max(h[128 + q * 16 + 2], h[128 + q * 16 + 4])); mc = std::max(mc, h[128 + q * 16 + 3]);
+            ne += h[q * 16];
+            me = std::max(me, h[q * 16]); mh = std::max(mh, h[q * 16 + 1]);
+            ms = std::max(ms, std::max(h[q * 16 + 2], h[q * 16 + 4])); mc = std::max(mc, h[q * 16 + 3]);
         }
         c->tm.support_words = (uint32_t)ne;    // supporting (hypothesis, supporter) pairs
         // Pool strides fitted to what the scene needs (the allocations stay): the record slabs a multi-GPU run
@@ -1465,13 +1469,13 @@ static int finish_commit(l3d_ctx* c) {
     c->host_offsets_valid = false;
     if (c->timing_pending) {   // phase A ran unsynchronised (l3d_match_images)
         collect_match_timing(c);
-        c->tm.match_pairs_ms += ev_ms(c->ev[2], c->ev[3]);
+        c->tm.match_pairs_ms += ev_ms(c, 2, 3);
     }
-    c->tm.finish_ms = ev_ms(c->ev[6], c->ev[7]);
-    c->tm.lists_ms = ev_ms(c->ev[6], c->ev[9]);
+    c->tm.finish_ms = ev_ms(c, 6, 7);
+    c->tm.lists_ms = ev_ms(c, 6, 9);
     c->tm.record_kbytes = (uint32_t)(((uint64_t)kListPools * ((uint64_t)c->lp_ecap * sizeof(EdgeRec) + (uint64_t)c->lp_hcap * sizeof(HypHdr) +
                                                               (uint64_t)c->lp_scap * sizeof(SegHdr) + 64)) >> 10);
-    c->tm.begin_ms = ev_ms(c->ev[0], c->ev[1]);
+    c->tm.begin_ms = ev_ms(c, 0, 1);
     untranslate(*c);   // line3D.cc:493
     c->state = l3d_ctx::MATCHED;
     c->shard_world = 0; c->lists_ready = false; c->lists_prepared = false;
@@ -1488,7 +1492,7 @@ static int tail_until_converged(l3d_ctx* c) {
     g_trace.mark("phase B done");
     rc = check_pass(c);
     if (rc) return rc;
-    while (c->h_fin.p[fin_b1((uint32_t)c->order.size()) + kListPools * 16 + 32 + c->chain_enqueued - 1]) {
+    while (c->h_fin.p[kListPools * 16 + 32 + c->chain_enqueued - 1]) {
         rc = tail_run(c, false);
         if (rc) return rc;
         L3D_HIP_CHECK(hipStreamSynchronize(st));

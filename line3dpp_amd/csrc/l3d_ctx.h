@@ -53,7 +53,7 @@ hipError_t launch_support_all(uint32_t g0, uint32_t G, const uint32_t* off, cons
 hipError_t launch_score_all(uint32_t g0, uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view, DEntry*,
                             const uint64_t* bits, Slot*, uint32_t* max_score_bits, const ViewDev*, const uint32_t* seg_base,
                             SimConst, hipStream_t);
-hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base,
+hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base, const uint32_t* tie_total, uint32_t* tie_out,
                              float* out, hipStream_t);
 hipError_t launch_aff_sim(uint32_t N, const uint32_t* surv_sg, const uint32_t* surv_tg, const int32_t* hyp_of_seg,
                           const HypRec*, const ViewAff*, const float* medians, const float* msdl, float two_sigA_sqr,
@@ -87,6 +87,7 @@ void pair_baseline(const d3& Cs, const d3& Ct, PairDesc& pd);
 void orientation_thresholds(double& lo, double& hi);
 SimConst sim_thresholds(float two_sigA_sqr);
 float ev_ms(hipEvent_t a, hipEvent_t b);
+float ev_ms(const ::l3d_ctx* c, int a, int b);   // 0 when the timing level left one of the two events out
 int affinity_core(::l3d_ctx* c);           // l3d_affinity_host.hip
 int ensure_affinity_host(::l3d_ctx* c);    // l3d_affinity_host.hip
 std::string output_filename(::l3d_ctx* c, int max_image_width);   // l3d_output.hip
@@ -184,7 +185,9 @@ struct l3d_ctx {
     uint32_t poff_total = 0, n_in_pairs = 0;        // entries of d_poff / of the InPair table of the running call
     DevBuf<Match> d_surv;
     DevBuf<int32_t> d_hyp_of_seg;
-    DevBuf<float> d_depths, d_medians;              // d_medians: 8 words of 64-bit totals, then [V] medians
+    DevBuf<float> d_depths;
+    float* d_med = nullptr;                         // 8 words of 64-bit totals, then [V] medians: inside the zero block (d_lzero),
+                                                    // behind its head, so that ONE copy reads both back (l3d_api.hip: zero_layout)
     DevBuf<HypRec> d_hyps;
     // sparse phase B (k_lists.hip, l3d_lists.h)
     DevBuf<unsigned long long> d_cnt64, d_off64s, d_scan_ws, d_huge_u64;
@@ -226,7 +229,11 @@ struct l3d_ctx {
     std::vector<l3d_segment2d> l2g;
     std::vector<ReconLine> lines3D;                 // lines3D_ (original frame)
     bool lines_done = false;
-    // timings
+    // timings.  Every hipEventRecord between two kernels costs a ~6 us bubble on the stream (rocprofv3 kernel trace of C1:
+    // gaps exactly where the ten events of a call sit, none between other back-to-back kernels): timing_level 2 (default)
+    // records all of them, 1 only the pair around the match kernel (ev[4], ev[5]), 0 none (l3d_set_timing_level)
     hipEvent_t ev[10] = {};
+    int timing_level = 2;
+    bool ev_on(int k) const { return timing_level >= 2 || (timing_level == 1 && (k == 4 || k == 5)); }
     l3d_timings tm{};
 };

@@ -102,7 +102,8 @@ struct CandRec {
     uint32_t pf_i;       // pair | inverse << 31 of i
     uint32_t tvj;        // camera (view index) of j | j inverse << 31
     float a1, a2, b1, b2;   // depths of i and of j
-    float sim;           // k_edges: similarity if the pair passed the exact test, else -1
+    float sim;           // from the list pass: the bits of the segment's global index g; after k_cand_exact: the
+                         // similarity if the pair passed the exact test, else -1
 };
 static_assert(sizeof(CandRec) == 40, "CandRec is 40 bytes");
 struct CandHdr {
