@@ -842,22 +842,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(L3D_EDGES_W
 // ---- candidates -> edges: one wave per segment with candidates.  The accepted ones (k_cand_exact) become EDGES in
 // (i, j) order with one HEADER per hypothesis i that has any.  The candidates arrive grouped by i in canonical order
 // (one contiguous run per i, j in walk order), so the order only has to be fixed inside a run.
-__global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
-                                               const uint32_t* __restrict__ gseg_view, const Slot* __restrict__ slots,
-                                               const ListPools lp, uint32_t* __restrict__ seg_of_g) {
-    const uint32_t pool = lp.pool0 + blockIdx.y, wave = 0, lane = lane_id();   // one segment per workgroup (as k_lists)
-    const uint32_t k = blockIdx.x;
-    if (lp.flags[0] | lp.flags[2]) return;   // the candidate pools overflowed: headers beyond the last complete list are not valid
-    if (k >= min(lp.cnt[pool * 16 + 4], lp.scap)) return;
-    const CandHdr ch = lp.chdrs[pool * lp.scap + k];
+constexpr uint32_t kEdgeLds = 512;
+// the candidates of one segment, by one wave
+__device__ __forceinline__ void edges_of_segment(const PairDesc* __restrict__ pairs, const Slot* __restrict__ slots,
+                                                 const ListPools& lp, uint32_t* __restrict__ seg_of_g, const CandHdr ch,
+                                                 uint32_t opool, L3D_LDS uint32_t* s_ij_w, L3D_LDS float* s_sim_w,
+                                                 uint32_t lane) {
     const uint32_t g = ch.g, n = ch.cnt;
     CandRec* cand = lp.cands + ch.begin;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     // (ij, sim) of the list's candidates live in LDS for the order fixing below (lists beyond kEdgeLds entries walk
     // global memory instead: correct, slow, rare)
-    constexpr uint32_t kEdgeLds = 512;
-    __shared__ uint32_t s_ij[1][kEdgeLds];
-    __shared__ float s_sim[1][kEdgeLds];
     const bool in_lds = n <= kEdgeLds;
     // pass 1: how many passed the exact test
     uint32_t n_acc = 0;
@@ -867,7 +862,7 @@ __global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views,
         if (x < n) {
             const float sim = cand[x].sim;
             ok = sim >= 0.0f;
-            if (in_lds) { s_ij[wave][x] = cand[x].ij; s_sim[wave][x] = sim; }
+            if (in_lds) { s_ij_w[x] = cand[x].ij; s_sim_w[x] = sim; }
         }
         n_acc += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(ok));
     }
@@ -877,8 +872,8 @@ __global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views,
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }   // (beyond the LDS capacity the passes below read the records k_cand_exact left: nothing of this wave's own)
-    auto ij_of = [&](uint32_t y) -> uint32_t { return in_lds ? s_ij[wave][y] : cand[y].ij; };
-    auto sim_of = [&](uint32_t y) -> float { return in_lds ? s_sim[wave][y] : cand[y].sim; };
+    auto ij_of = [&](uint32_t y) -> uint32_t { return in_lds ? s_ij_w[y] : cand[y].ij; };
+    auto sim_of = [&](uint32_t y) -> float { return in_lds ? s_sim_w[y] : cand[y].sim; };
     // inside its run: rank of an accepted pair by j, accepted pairs before it (0: it writes the header), run total
     auto in_run = [&](uint32_t x, uint32_t& rank, uint32_t& earlier, uint32_t& mine) {
         const uint32_t ij = ij_of(x), i = ij >> 16;
@@ -909,10 +904,6 @@ __global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views,
         }
         n_h += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(first));
     }
-    // output pool: spread over ALL pools of the pass whatever the fill of the input pools (blockIdx.x only reaches the
-    // fullest input pool's count: on small scenes `(blockIdx.x >> 2) % npools` left most pools empty and overflowed the
-    // rest -- the one pool retry of a first C1 call)
-    const uint32_t opool = lp.pool0 + (blockIdx.x + 61u * blockIdx.y) % lp.npools;
     uint32_t eb = 0, hb = 0, sb = 0;
     if (lane == 0) {
         eb = atomicAdd(&lp.cnt[opool * 16 + 0], n_acc);
@@ -969,6 +960,29 @@ __global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views,
         const uint32_t si = opool * lp.scap + sb;
         lp.segs[si] = SegHdr{g, h0, n_h, 0u};
         seg_of_g[g] = si;
+    }
+}
+
+// grid (ceil(scap / L3D_EDGES_SPLIT), pools): a wave takes every gridDim.x-th segment header of its pool.  One wave per
+// header over the pools' CAPACITY launched 144 k waves on C1 of which 100 k found nothing to do.
+#ifndef L3D_EDGES_SPLIT
+#define L3D_EDGES_SPLIT 4
+#endif
+__global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+                                               const uint32_t* __restrict__ gseg_view, const Slot* __restrict__ slots,
+                                               const ListPools lp, uint32_t* __restrict__ seg_of_g) {
+    const uint32_t pool = lp.pool0 + blockIdx.y, lane = lane_id();
+    if (lp.flags[0] | lp.flags[2]) return;   // the candidate pools overflowed: headers beyond the last complete list are not valid
+    __shared__ uint32_t s_ij[kEdgeLds];
+    __shared__ float s_sim[kEdgeLds];
+    const uint32_t n_hdr = min(lp.cnt[pool * 16 + 4], lp.scap);
+    for (uint32_t k = blockIdx.x; k < n_hdr; k += gridDim.x) {
+        // output pool: spread over ALL pools of the pass whatever the fill of the input pools (on small scenes
+        // `(k >> 2) % npools` left most pools empty and overflowed the rest -- the one pool retry of a first C1 call)
+        const uint32_t opool = lp.pool0 + (k + 61u * blockIdx.y) % lp.npools;
+        edges_of_segment(pairs, slots, lp, seg_of_g, lp.chdrs[pool * lp.scap + k], opool, (L3D_LDS uint32_t*)s_ij, (L3D_LDS float*)s_sim, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the next segment reuses the LDS arrays
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1250,7 +1264,8 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
         hipLaunchKernelGGL(k_lists_huge, dim3(256), dim3(256), 0, st, views, pairs, lviews, opairs, ipairs, gseg_view, poff,
                            inv, slots, lp, hs);
     hipLaunchKernelGGL(k_cand_exact, dim3((lp.ccap + 255) / 256, lp.npools), dim3(256), 0, st, views, pairs, gseg_view, sc, lp);
-    hipLaunchKernelGGL(k_edges, dim3(lp.scap, lp.npools), dim3(64), 0, st, views, pairs, gseg_view, slots, lp, seg_of_g);
+    hipLaunchKernelGGL(k_edges, dim3((lp.scap + L3D_EDGES_SPLIT - 1) / L3D_EDGES_SPLIT, lp.npools), dim3(64), 0, st, views, pairs,
+                       gseg_view, slots, lp, seg_of_g);
     if (lp.npools < kListPools) hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, st, lp);   // sharded pass
     return hipGetLastError();
 }

@@ -545,55 +545,72 @@ __global__ __launch_bounds__(256) void k_score_all(uint32_t G, const uint32_t* _
 
 // median = sorted(depths)[n/2] by 4-pass radix select on the (positive) float bit patterns;
 // n == 0 -> L3D_EPS (line3D.cc:1658).  One workgroup per view.
+// This is the last kernel of a call's tail, and it hands the call's results to the host itself: the workgroup that
+// finishes last copies the head of the zero block -- pool counters, flags, chain state, totals, medians (l3d_api.hip:
+// zero_layout) -- into the pinned host buffer.  A copy command behind the kernel cost a 12 us bubble + 1.4 us on the
+// stream of a 1.5 ms call.  (Block 0 adds the cumulative count of replayed rows of k_match_tied_rows first.)
 __global__ __launch_bounds__(1024) void k_median_all(const float* __restrict__ depths,
                                                      const uint32_t* __restrict__ hyp_off,
                                                      const uint32_t* __restrict__ seg_base,
                                                      const uint32_t* __restrict__ tie_total, uint32_t* __restrict__ tie_out,
-                                                     float* __restrict__ out_median) {
+                                                     float* __restrict__ out_median, const uint32_t* rb_src,
+                                                     uint32_t* __restrict__ rb_host, uint32_t rb_words, uint32_t* rb_count) {
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_prefix, s_rank;
+    __shared__ uint32_t s_prefix, s_rank, s_last;
     const uint32_t v = blockIdx.x;
-    // the last kernel of a call's tail: the cumulative count of replayed rows (k_match_tied_rows) travels with the
-    // call's one read-back instead of a copy of its own
     if (v == 0 && threadIdx.x == 0 && tie_total) *tie_out = *tie_total;
     const uint32_t h0 = hyp_off[seg_base[v]], h1 = hyp_off[seg_base[v + 1]];
     const uint32_t n = 2u * (h1 - h0);
     const float* dv = depths + 2u * h0;
-    if (n == 0) {
-        if (threadIdx.x == 0) out_median[v] = (float)kEps;
-        return;
-    }
-    if (threadIdx.x == 0) { s_prefix = 0; s_rank = n / 2; }
-    __syncthreads();
-    for (int pass = 3; pass >= 0; --pass) {
-        const uint32_t shift = 8u * pass;
-        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_prefix = __float_as_uint((float)kEps); s_rank = n / 2; }
+    if (n != 0) {
+        if (threadIdx.x == 0) s_prefix = 0;
         __syncthreads();
-        const uint32_t prefix = s_prefix;
-        const uint32_t himask = pass == 3 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint32_t bits = __float_as_uint(dv[i]);
-            if ((bits & himask) == prefix) atomicAdd(&hist[(bits >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {   // one wave: bin d with cum(d-1) <= rank < cum(d)  (4 bins per lane, wave prefix)
-            const uint32_t l = threadIdx.x;
-            const uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
-            uint32_t x = h0 + h1 + h2 + h3;
-            const uint32_t mine = x;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (l >= (uint32_t)d) x += y; }
-            const uint32_t before = x - mine, r = s_rank;
-            if (r >= before && r < x) {
-                uint32_t acc = before, d = 4 * l;
-                if (acc + h0 <= r) { acc += h0; ++d; if (acc + h1 <= r) { acc += h1; ++d; if (acc + h2 <= r) { acc += h2; ++d; } } }
-                s_rank = r - acc;
-                s_prefix = prefix | (d << shift);
+        for (int pass = 3; pass >= 0; --pass) {
+            const uint32_t shift = 8u * pass;
+            if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix;
+            const uint32_t himask = pass == 3 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+                const uint32_t bits = __float_as_uint(dv[i]);
+                if ((bits & himask) == prefix) atomicAdd(&hist[(bits >> shift) & 255u], 1u);
             }
+            __syncthreads();
+            if (threadIdx.x < 64) {   // one wave: bin d with cum(d-1) <= rank < cum(d)  (4 bins per lane, wave prefix)
+                const uint32_t l = threadIdx.x;
+                const uint32_t c0 = hist[4 * l], c1 = hist[4 * l + 1], c2 = hist[4 * l + 2], c3 = hist[4 * l + 3];
+                uint32_t x = c0 + c1 + c2 + c3;
+                const uint32_t mine = x;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (l >= (uint32_t)d) x += y; }
+                const uint32_t before = x - mine, r = s_rank;
+                if (r >= before && r < x) {
+                    uint32_t acc = before, d = 4 * l;
+                    if (acc + c0 <= r) { acc += c0; ++d; if (acc + c1 <= r) { acc += c1; ++d; if (acc + c2 <= r) { acc += c2; ++d; } } }
+                    s_rank = r - acc;
+                    s_prefix = prefix | (d << shift);
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
-    if (threadIdx.x == 0) out_median[v] = __uint_as_float(s_prefix);
+    if (threadIdx.x == 0) {
+        out_median[v] = __uint_as_float(s_prefix);
+        s_last = 0;
+        if (rb_host) {
+            // release: this workgroup's median (workgroup 0: the replay count too) before its tick; every launch adds
+            // gridDim.x ticks to a counter zeroed once per list pass, so "last" is a multiple of gridDim.x
+            __threadfence();
+            s_last = (atomicAdd(rb_count, 1u) + 1u) % gridDim.x == 0 ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    if (s_last) {
+        __threadfence();   // acquire: the other workgroups' medians (written on other XCDs)
+        for (uint32_t i = threadIdx.x; i < rb_words; i += blockDim.x)
+            rb_host[i] = __hip_atomic_load(&rb_src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---- launchers --------------------------------------------------------------------------------------
@@ -704,9 +721,11 @@ hipError_t launch_score_all(uint32_t g0, uint32_t G, const uint32_t* off, const 
     return hipGetLastError();
 }
 hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base,
-                             const uint32_t* tie_total, uint32_t* tie_out, float* out, hipStream_t st) {
+                             const uint32_t* tie_total, uint32_t* tie_out, float* out, const uint32_t* rb_src,
+                             uint32_t* rb_host, uint32_t rb_words, uint32_t* rb_count, hipStream_t st) {
     if (!V) return hipSuccess;
-    hipLaunchKernelGGL(k_median_all, dim3(V), dim3(1024), 0, st, depths, hyp_off, seg_base, tie_total, tie_out, out);
+    hipLaunchKernelGGL(k_median_all, dim3(V), dim3(1024), 0, st, depths, hyp_off, seg_base, tie_total, tie_out, out, rb_src,
+                       rb_host, rb_words, rb_count);
     return hipGetLastError();
 }
 

@@ -583,9 +583,12 @@ static int match_begin_body(l3d_ctx* c) {
     // neighbours from the worldpoint overlap, line3D.cc:480-484 (every call anew, on the translated views)
     {
         bool any = false;
-        std::map<uint32_t, HostView*> vm;
-        for (auto& kv : c->views) { vm[kv.first] = kv.second.get(); any |= kv.second->by_worldpoints; }
-        if (any) neighbors_from_worldpoints(vm, (uint32_t)c->num_neighbors);
+        for (auto& kv : c->views) any |= kv.second->by_worldpoints;
+        if (any) {
+            std::map<uint32_t, HostView*> vm;
+            for (auto& kv : c->views) vm[kv.first] = kv.second.get();
+            neighbors_from_worldpoints(vm, (uint32_t)c->num_neighbors);
+        }
     }
     // The pair list, the fundamental matrices and the culling set-up are a function of the (translated) views, their
     // neighbour sets and kNN alone: when those are byte for byte what the previous call saw, the lists it built are
@@ -1373,13 +1376,15 @@ static int tail_run(l3d_ctx* c, bool fresh) {
                                    c->d_seg_of_g.p, lp, c->d_slots.p, c->d_surv_off.p, c->d_hyp_off.p, c->d_surv.p,
                                    c->d_surv_tg.p, c->d_surv_sg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_depths.p, st));
     g_trace.mark("seg_write enqueued");
+    // the read-back: the head of the zero block -- pool counters, flags (32), changed (64) -- and behind it [0..7] the
+    // 64-bit totals, [8..8+V) the medians, written into the pinned host buffer by the last workgroup of k_median_all
+    // (flags[16] counts its workgroups): no copy command on the stream
+    void* h_dev = nullptr;
+    L3D_HIP_CHECK(hipHostGetDevicePointer(&h_dev, c->h_fin.p, 0));
     L3D_HIP_CHECK(launch_median_all(V, c->d_depths.p, c->d_hyp_off.p, c->d_seg_base.p, c->d_tie_count.p ? c->d_tie_count.p + 2 : nullptr,
-                                    (uint32_t*)tot64_of(c), medians_of(c), st));
-    g_trace.mark("median enqueued");
-    // the read-back (pinned), one copy: the head of the zero block -- pool counters, flags (32), changed (64) -- and
-    // behind it [0..7] the 64-bit totals, [8..8+V) the medians
-    L3D_HIP_CHECK(hipMemcpyAsync(c->h_fin.p, c->d_lzero.p, (kFinHead + fin_med(V)) * 4, hipMemcpyDeviceToHost, st));
-    g_trace.mark("read-back enqueued");
+                                    (uint32_t*)tot64_of(c), medians_of(c), c->d_lzero.p, (uint32_t*)h_dev,
+                                    (uint32_t)(kFinHead + fin_med(V)), c->d_lzero.p + z.flags + 16, st));
+    g_trace.mark("median + read-back enqueued");
     if (c->ev_on(7)) L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
     g_trace.mark("tail enqueued");
     return L3D_OK;

@@ -53,8 +53,9 @@ hipError_t launch_support_all(uint32_t g0, uint32_t G, const uint32_t* off, cons
 hipError_t launch_score_all(uint32_t g0, uint32_t G, const uint32_t* off, const uint32_t* boff, const uint32_t* gseg_view, DEntry*,
                             const uint64_t* bits, Slot*, uint32_t* max_score_bits, const ViewDev*, const uint32_t* seg_base,
                             SimConst, hipStream_t);
-hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base, const uint32_t* tie_total, uint32_t* tie_out,
-                             float* out, hipStream_t);
+hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base,
+                             const uint32_t* tie_total, uint32_t* tie_out, float* out, const uint32_t* rb_src,
+                             uint32_t* rb_host, uint32_t rb_words, uint32_t* rb_count, hipStream_t);
 hipError_t launch_aff_sim(uint32_t N, const uint32_t* surv_sg, const uint32_t* surv_tg, const int32_t* hyp_of_seg,
                           const HypRec*, const ViewAff*, const float* medians, const float* msdl, float two_sigA_sqr,
                           float* simv, int32_t* ca, int32_t* cb, hipStream_t);
