@@ -265,3 +265,29 @@ def test_inverse_hypotheses_sorted_with_global_cursors_equal_the_lds_form(monkey
     assert g.matchImages() and g.computeAffinity()
     r = _assert_same(g, _ref(sc, [{}]), sc)
     assert r["surviving"] > 1000
+
+
+def test_timing_levels_change_what_is_timed_and_nothing_else():
+    """l3d_set_timing_level: 2 records every HIP event of a call (all of l3d_timings filled), 1 only the pair around the
+    pair-matching kernel, 0 none -- the results are those of the reference at every level, and l3d_get_timings itself
+    never waits for the GPU (tied_rows arrives with the call's one read-back, written by the last kernel of the tail)."""
+    sc = make_scene(6, 260, n_neighbors=3, seed=41)
+    o = _ref(sc, [dict()])
+    g = _gpu(sc)
+    seen = {}
+    for level in (2, 1, 0, 2):
+        assert g.setTimingLevel(level)
+        assert g.matchImages() and g.computeAffinity()
+        _assert_same(g, o, sc)
+        seen[level] = g.timings()
+    assert seen[2]["match_kernel_ms"] > 0 and seen[2]["finish_ms"] > 0 and seen[2]["begin_ms"] > 0 and seen[2]["affinity_ms"] > 0
+    assert seen[2]["lists_ms"] > 0 and seen[2]["match_pairs_ms"] >= seen[2]["match_kernel_ms"]
+    assert seen[1]["match_kernel_ms"] > 0 and seen[1]["match_kernel_launches"] == 1
+    assert seen[1]["finish_ms"] == 0 and seen[1]["begin_ms"] == 0 and seen[1]["affinity_ms"] == 0 and seen[1]["match_pairs_ms"] == 0
+    assert seen[0]["match_kernel_ms"] == 0 and seen[0]["finish_ms"] == 0
+    # the counters that travel with the read-back do not depend on the level
+    for level in (1, 0):
+        for k in ("list_entries", "support_words", "chain_sweeps", "culled_pairs"):
+            assert seen[level][k] == seen[2][k], (level, k)
+    from line3dpp_amd import _lib
+    assert not g.setTimingLevel(3) and "level" in _lib.last_error()
