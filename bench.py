@@ -19,6 +19,9 @@ Prints ONE JSON line with
                   instruction mix of the kernel (PMC, keyed by build id) and the per-class issue cycles measured on this
                   kind of box (profiles/*_valu_calibration.json); `useful_frac`; the HBM figure beside it
   `cpu_baseline`  the reference's own OpenMP CPU path (oracle/_ref), timed on this box, rank 0, N=1
+  `phase_ms`      GPU time of begin / phase A / phase B / affinity, from a few separate UNTIMED steps with all ten HIP
+                  events of a call on: the timed steps record only the pair around the match kernel (an event between
+                  two kernels is a ~6 us gap on the stream; l3d_set_timing_level)
   `parity`        the HIP result of the benchmarked scene against that very reference run -- or, with --parity-digest,
                   against the stored record of a reference run of the FULL configuration (tests/full_digest.py)
   `cold_ms` / `second_scene_ms`   the first matchImages + affinity of a fresh context (allocations, pool growth and
