@@ -1,8 +1,9 @@
 """Every kernel of the profiled steps from the PMC passes of tools/pmc_diag.sh (gpurun_out/pmcdiag_<tag>_<cfg>/):
-   python tools/pmc_all_kernels.py C1 > profiles/rNN_all_kernels_pmc_C1.txt   (edit the tag below for another round)"""
+   python tools/pmc_all_kernels.py C1 [tag] > profiles/rNN_all_kernels_pmc_C1.txt   (tag of the pmc_diag call, default r04_v2)"""
 import re, ast, subprocess, sys
 cfg=sys.argv[1]
-out=subprocess.run(["python","tools/pmc_summary.py",f"gpurun_out/pmcdiag_r04_v2_{cfg}","3"],capture_output=True,text=True).stdout
+tag=sys.argv[2] if len(sys.argv) > 2 else 'r04_v2'
+out=subprocess.run(["python","tools/pmc_summary.py",f"gpurun_out/pmcdiag_{tag}_{cfg}","3"],capture_output=True,text=True).stdout
 rows=[]
 for l in out.splitlines():
     m=re.match(r'(.+?) (\{.*\})$', l.strip())
