@@ -253,6 +253,13 @@ def nvm_rotation(qw, qx, qy, qz):
                      [2.0 * qx * qz - 2.0 * qy * qw, 2.0 * qy * qz + 2.0 * qx * qw, 1.0 - 2.0 * qx * qx - 2.0 * qy * qy]])
 
 
+def _mv3(M, v):
+    """M v for a 3x3 M in the evaluation order of the reference's fixed-size Eigen product (and of the C-ABI readers):
+    (M[i,0] v[0] + M[i,1] v[1]) + M[i,2] v[2] -- numpy's matmul may sum in another order or fuse the multiplies"""
+    M = np.asarray(M, np.float64); v = np.asarray(v, np.float64)
+    return (M[:, 0] * v[0] + M[:, 1] * v[1]) + M[:, 2] * v[2]
+
+
 def read_nvm(path):
     """-> list of cameras in file order (the reference uses the index as camID): dict(filename, focal, R, t, C,
     distortion, worldpoints = ids of the 3D points it sees, median_depth = sorted distances to them [n/2] as float32,
@@ -269,7 +276,7 @@ def read_nvm(path):
         focal, qw, qx, qy, qz, cx, cy, cz, dist = (float(x) for x in tok[1:10])
         R = nvm_rotation(qw, qx, qy, qz)
         Cc = np.array([cx, cy, cz])
-        cams.append(dict(filename=tok[0], focal=np.float32(focal), R=R, t=-R @ Cc, C=Cc, distortion=np.float32(dist),
+        cams.append(dict(filename=tok[0], focal=np.float32(focal), R=R, t=_mv3(-R, Cc), C=Cc, distortion=np.float32(dist),   # t = -R*C, :207
                          worldpoints=[], _depths=[]))
     pos += 1
     n_pts = int(lines[pos].split()[0]); pos += 1

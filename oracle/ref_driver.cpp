@@ -300,6 +300,12 @@ void lo_ref_fundamental(void* p, uint32_t src, uint32_t tgt, double* F9) {
     const Eigen::Matrix3d F = l->getFundamentalMatrix(l->views_[src], l->views_[tgt]);
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) F9[3 * i + j] = F(i, j);
 }
+// Line3D::rotationFromQ (line3D.cc:2730-2754), the reference's own: q = (w, x, y, z).  The front-end pin
+// (ref_front_driver.cpp) routes the rotationFromQ calls of main_colmap.cpp / main_vsfm.cpp here.
+void lo_ref_rotation_from_q(const double* q, double* R9) {
+    const Eigen::Matrix3d R = L3DPP::Line3D::rotationFromQ(q[0], q[1], q[2], q[3]);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R9[3 * i + j] = R(i, j);
+}
 // what get3DlineFromCluster (line3D.cc:2196-2211) does with its 3x3 scatter matrix: JacobiSVD, column of the largest
 // singular value, normalised
 void lo_ref_principal_direction(const double* S9, double* dir3) {

@@ -8,17 +8,12 @@ import numpy as np
 from line3dpp_amd.api import Line3D
 from line3dpp_amd.scene import make_scene
 from line3dpp_amd._lib import EMPTY
+from tests.stress.cases import culling_case
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 123)
 bad = 0; total = 0; culled = 0; npairs = 0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
-    nv = int(rng.integers(3, 14)); ns = int(rng.integers(50, 2500)); nn = int(rng.integers(2, min(nv, 8)))
-    radius = float(rng.uniform(8, 60)); knn = int(rng.choice([1, 3, 10, 20])); epi = float(rng.choice([0.1, 0.25, 0.5, 0.8]))
-    sc = make_scene(nv, ns, n_neighbors=nn, seed=int(rng.integers(1, 1 << 30)), radius=radius, noise_px=float(rng.uniform(0, 2)))
-    if rng.random() < 0.3:   # anisotropic rescale of the image
-        sx, sy = rng.uniform(0.5, 2.0, 2)
-        for v in sc.views:
-            v.segs = (v.segs * np.array([sx, sy, sx, sy])).astype(np.float32); v.K = v.K.copy(); v.K[0] *= sx; v.K[1] *= sy
-            v.width = int(v.width * sx); v.height = int(v.height * sy)
+    sc, knn, epi = culling_case(rng)
+    nv, ns, nn, radius = len(sc.views), len(sc.views[0].segs), len(sc.views[0].neighbors), 0.0
     out = []
     for brute in (0, 1):
         g = Line3D(); g.add_scene(sc); g.set_brute_force(brute)

@@ -10,20 +10,14 @@ from line3dpp_amd.api import Line3D
 from line3dpp_amd.scene import make_scene
 from oracle.oracle import Oracle
 from tests import helpers as H
+from tests.stress.cases import pipeline_case
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 321)
 bad = 0
 for it in range(n):
-    nv = int(rng.integers(3, 16)); ns = int(rng.integers(40, 700)); nn = int(rng.integers(2, min(nv, 12)))
-    knn = int(rng.choice([1, 5, 10, 25])); epi = float(rng.choice([0.1, 0.25, 0.5])); sa = float(rng.choice([5.0, 10.0, 20.0]))
-    sp = float(rng.choice([1.0, 2.5, 5.0, -0.05, -0.2])); radius = float(rng.uniform(10, 50))   # < 0: metric regulariser
-    if rng.random() < 0.15: knn = 0                                                         # keep-all mode
-    sc = make_scene(nv, ns, n_neighbors=nn, seed=int(rng.integers(1, 1 << 30)), radius=radius, noise_px=float(rng.uniform(0, 1.5)),
-                    real_fraction=float(rng.uniform(0.3, 0.9)))
-    if rng.random() < 0.5:    # ragged views and asymmetric neighbour lists
-        for v in sc.views:
-            v.segs = v.segs[:max(1, int(len(v.segs) * rng.uniform(0.3, 1.0)))].copy()
-            if len(v.neighbors) > 1 and rng.random() < 0.5: v.neighbors = v.neighbors[:-1]
+    sc, kw = pipeline_case(rng)
+    nv, ns, nn = len(sc.views), max(len(v.segs) for v in sc.views), max(len(v.neighbors) for v in sc.views)
+    knn, epi, sa, sp = kw['kNN'], kw['epi_overlap'], kw['sigma_a'], kw['sigma_p']
     g = Line3D(); g.add_scene(sc)
     assert g.matchImages(sigma_position=sp, sigma_angle=sa, kNN=knn, epipolar_overlap=epi) and g.computeAffinity()
     o = Oracle(threads=16); o.add_scene(sc)

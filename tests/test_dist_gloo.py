@@ -432,3 +432,77 @@ def test_halo_plan_balances_pairs_and_lists_every_crossing_pair_once():
             assert sum(k for _, k in early) + late[1] == counts[r]
             assert not any(late[0] <= p < late[0] + late[1] for p in halo)     # the stretch matched last sends nothing
         assert len(crossing) < 0.2 * len(pairs) * (world - 1) / world + 120
+
+
+# ---- a rank that fails locally does not strand the others (dist.py) --------------------------------------------
+class _FailingHaloContext(_HaloReplayContext):
+    """the halo context with ONE local failure on ONE rank: `where` = "match" (a matchPairs call returns False: a HIP error
+    in the pair kernel), "expand" (expandSlotIndices refuses what arrived) or "finish" (l3d_match_finish fails with an
+    error that is neither success nor RETRY on this rank only)"""
+
+    def __init__(self, scene, kNN, rank, world, fail_rank, where):
+        super().__init__(scene, kNN, rank, world)
+        self.failing = rank == fail_rank
+        self.where = where
+
+    def matchPairs(self, first, count):
+        ok = super().matchPairs(first, count)
+        return ok and not (self.failing and self.where == "match")
+
+    def expandSlotIndices(self, first, count):
+        ok = super().expandSlotIndices(first, count)
+        return ok and not (self.failing and self.where == "expand")
+
+    def l3d_match_finish(self, h):
+        rc = super().l3d_match_finish(h)
+        if self.failing and self.where == "finish" and rc in (0, -10):
+            self.matchAbort()              # (l3d_match_finish closes the call itself when it fails, l3d_api.hip)
+            return -4
+        return rc
+
+
+def _failing_worker(rank, world, port, q, fail_rank, where):
+    sys.path.insert(0, ROOT)
+    from line3dpp_amd import dist
+    from line3dpp_amd.scene import make_scene
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist_t.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        scene = make_scene(9, 40, n_neighbors=4, seed=6)
+        ctx = _FailingHaloContext(scene, 5, rank, world, fail_rank, where)
+        real = dist.device_tensor
+        dist.device_tensor = lambda arr, nbytes, device: torch.from_numpy(arr.view(np.uint8))[:nbytes]
+        try:
+            ok = dist.match_images_sharded(ctx, rank, world, device=None, kNN=5)
+        finally:
+            dist.device_tensor = real
+        # every rank gave up, together, and left its context idle (a later call starts clean)
+        q.put((rank, bool(ok), ctx.state, ctx.log[0], "finish" in ctx.log and ctx.state == "matched"))
+    finally:
+        dist_t.destroy_process_group()
+
+
+@pytest.mark.parametrize("where", ["match", "expand", "finish"])
+def test_a_rank_that_fails_locally_takes_all_ranks_out_of_the_call_together(where):
+    """round 3's early returns left the peers of a failing rank inside a collective for ever; now the failing rank keeps
+    posting what the plan says and all ranks give up at the next status exchange (dist._all_ok): nobody hangs, nobody
+    returns True, every context is idle again"""
+    world, fail_rank = 3, 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q, fail_rank, where)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))          # a hang is a timeout here
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [False] * world, res
+    assert all(r[3] == "begin" for r in res)
+    if where == "finish":
+        # the two healthy ranks had closed the call (rc 0 / RETRY) when they learnt of the failure: results discarded or
+        # context aborted; the failing one reports its own error -- nobody claims a result
+        assert all(r[2] in ("idle", "matched") for r in res), res
+    else:
+        assert all(r[2] == "idle" for r in res), res
