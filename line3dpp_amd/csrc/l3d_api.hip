@@ -1027,6 +1027,8 @@ static int lists_shard_impl(l3d_ctx* c, uint32_t rank, uint32_t world, int64_t v
         const uint32_t ppr = kListPools / world, pool0 = rank * ppr;
         r2 = lists_run(c, v0, v1 - v0, pool0, ppr);
         if (r2) return r2;
+        c->shard_rank = rank; c->shard_v0 = v0; c->shard_v1 = v1; c->shard_pool0 = pool0; c->shard_ppr = ppr;
+        c->tail_counted = false; c->tail_written = false;
         L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
         c->shard_world = world; c->lists_ready = true;
         slab_ptr[0] = c->d_ledges.p + (size_t)pool0 * c->lp_ecap; slab_bytes[0] = (uint64_t)ppr * c->lp_ecap * sizeof(EdgeRec); full_ptr[0] = c->d_ledges.p;
@@ -1339,14 +1341,19 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
     return L3D_OK;
 }
 
-// chain, scores, filterMatches, outputs, medians on the complete records (`fresh`: first tail after a list pass;
-// otherwise the chain continues from what earlier sweeps found and only the later stages start over)
-static int tail_run(l3d_ctx* c, bool fresh) {
+// The tail works on a SHARD of the scene: all of it on one GPU and in the replicated tail of a multi-GPU run; the views
+// [v0, v1) = segments [g0, g1) = pools [pool0, pool0 + npools) of this rank when the tail is sharded (l3d_tail_shard_*).
+struct TailShard { uint32_t v0, v1, g0, g1, pool0, npools; };
+static TailShard whole_tail(const l3d_ctx* c) { return TailShard{0u, (uint32_t)c->order.size(), 0u, c->G, 0u, kListPools}; }
+
+// phase 1: the chain on ALL records (a global fixed point), then scores, filterMatches and the per-segment counts of the
+// shard, scanned over its segments (tot64[1] = its surviving matches | its best hypotheses)
+static int tail_count_run(l3d_ctx* c, bool fresh, const TailShard& ts) {
     g_trace.mark("tail_run enter");
     hipStream_t st = c->stream;
     const uint32_t V = (uint32_t)c->order.size(), G = c->G;
     const ZeroLayout z = zero_layout(V, G);
-    const ListPools lp = list_pools(c);
+    const ListPools lp = list_pools(c), lps = list_pools(c, ts.pool0, ts.npools);
     uint32_t* changed = c->d_lzero.p + z.changed;
     uint32_t* max_score = c->d_lzero.p + z.max_score;
     uint32_t* kept = c->d_lzero.p + z.kept;
@@ -1366,26 +1373,49 @@ static int tail_run(l3d_ctx* c, bool fresh) {
         L3D_HIP_CHECK(hipMemcpyAsync(c->d_pair_present.p, c->pair_done.data(), c->pair_done.size(), hipMemcpyHostToDevice, st));
         present = c->d_pair_present.p;
     }
-    L3D_HIP_CHECK(launch_hyp_scores(lp, positive_of(c), c->d_gseg_view.p, c->d_slots.p, present, max_score, st));
+    L3D_HIP_CHECK(launch_hyp_scores(lps, positive_of(c), c->d_gseg_view.p, c->d_slots.p, present, max_score, st));
     g_trace.mark("hyp_scores enqueued");
-    L3D_HIP_CHECK(launch_hyp_filter(lp, G, c->d_gseg_view.p, max_score, kept, best, c->d_cnt64.p, st));
+    L3D_HIP_CHECK(launch_hyp_filter(lps, ts.g0, ts.g1, c->d_gseg_view.p, max_score, kept, best, c->d_cnt64.p, st));
     g_trace.mark("hyp_filter enqueued");
-    L3D_HIP_CHECK(launch_scan64(c->d_cnt64.p, G, c->d_off64s.p, c->d_scan_ws.p, tot64_of(c) + 1, st));
+    L3D_HIP_CHECK(launch_scan64(c->d_cnt64.p + ts.g0, ts.g1 - ts.g0, c->d_off64s.p + ts.g0, c->d_scan_ws.p, tot64_of(c) + 1, st));
     g_trace.mark("scan enqueued");
-    L3D_HIP_CHECK(launch_seg_write(G, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p, c->d_off64s.p, best,
-                                   c->d_seg_of_g.p, lp, c->d_slots.p, c->d_surv_off.p, c->d_hyp_off.p, c->d_surv.p,
-                                   c->d_surv_tg.p, c->d_surv_sg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_depths.p, st));
+    return L3D_OK;
+}
+
+// phase 2: the outputs of the shard's segments at their places in the full arrays (base64: what the shards before it
+// hold), the medians of its views; `publish`: the call's read-back, written by the last workgroup of k_median_all
+static int tail_write_run(l3d_ctx* c, const TailShard& ts, unsigned long long base64, bool publish) {
+    hipStream_t st = c->stream;
+    const uint32_t V = (uint32_t)c->order.size(), G = c->G;
+    const ZeroLayout z = zero_layout(V, G);
+    const ListPools lps = list_pools(c, ts.pool0, ts.npools);
+    unsigned long long* best = (unsigned long long*)(c->d_lzero.p + z.best);
+    L3D_HIP_CHECK(launch_seg_write(ts.g0, ts.g1, base64, c->d_views.p, c->d_pairs.p, c->d_seg_base.p, c->d_gseg_view.p,
+                                   c->d_off64s.p, best, c->d_seg_of_g.p, lps, c->d_slots.p, c->d_surv_off.p, c->d_hyp_off.p,
+                                   c->d_surv.p, c->d_surv_tg.p, c->d_surv_sg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_depths.p, st));
     g_trace.mark("seg_write enqueued");
     // the read-back: the head of the zero block -- pool counters, flags (32), changed (64) -- and behind it [0..7] the
     // 64-bit totals, [8..8+V) the medians, written into the pinned host buffer by the last workgroup of k_median_all
     // (flags[16] counts its workgroups): no copy command on the stream
     void* h_dev = nullptr;
     L3D_HIP_CHECK(hipHostGetDevicePointer(&h_dev, c->h_fin.p, 0));
-    L3D_HIP_CHECK(launch_median_all(V, c->d_depths.p, c->d_hyp_off.p, c->d_seg_base.p, c->d_tie_count.p ? c->d_tie_count.p + 2 : nullptr,
-                                    (uint32_t*)tot64_of(c), medians_of(c), c->d_lzero.p, (uint32_t*)h_dev,
-                                    (uint32_t)(kFinHead + fin_med(V)), c->d_lzero.p + z.flags + 16, st));
+    L3D_HIP_CHECK(launch_median_all(ts.v1 - ts.v0, c->d_depths.p, c->d_hyp_off.p, c->d_seg_base.p,
+                                    c->d_tie_count.p ? c->d_tie_count.p + 2 : nullptr, (uint32_t*)tot64_of(c), medians_of(c),
+                                    c->d_lzero.p, publish ? (uint32_t*)h_dev : nullptr, (uint32_t)(kFinHead + fin_med(V)),
+                                    c->d_lzero.p + z.flags + 16, st, ts.v0));
     g_trace.mark("median + read-back enqueued");
-    if (c->ev_on(7)) L3D_HIP_CHECK(hipEventRecord(c->ev[7], st));
+    return L3D_OK;
+}
+
+// chain, scores, filterMatches, outputs, medians on the complete records (`fresh`: first tail after a list pass;
+// otherwise the chain continues from what earlier sweeps found and only the later stages start over)
+static int tail_run(l3d_ctx* c, bool fresh) {
+    const TailShard ts = whole_tail(c);
+    int rc = tail_count_run(c, fresh, ts);
+    if (rc) return rc;
+    rc = tail_write_run(c, ts, 0ull, true);
+    if (rc) return rc;
+    if (c->ev_on(7)) L3D_HIP_CHECK(hipEventRecord(c->ev[7], c->stream));
     g_trace.mark("tail enqueued");
     return L3D_OK;
 }
@@ -1533,6 +1563,131 @@ static int match_finish_impl(l3d_ctx* c) {
         break;
     }
     return finish_commit(c);
+}
+
+// ---- the tail of phase B sharded by views (N > 1 ranks) ---------------------------------------------------------------
+// After l3d_lists_shard* and the exchange of the record slabs every rank holds ALL records.  The chain is a global fixed
+// point over them and is run by every rank; scores, filterMatches, the outputs and the medians are per view and are
+// computed by the rank that owns the view:
+//   l3d_tail_shard_count   chain + scores + filterMatches + counts of this rank's views  -> its two counts
+//   (the caller all-gathers the counts)
+//   l3d_tail_shard_layout  this rank's outputs, written at their places in the full arrays; where every rank's parts are
+//   (the caller exchanges the parts, in place)
+//   l3d_tail_shard_commit  medians of all views to the host, totals: the call is closed like l3d_match_finish closes it
+static int tail_count_until_converged(l3d_ctx* c, const TailShard& ts) {
+    hipStream_t st = c->stream;
+    const uint32_t V = (uint32_t)c->order.size();
+    auto run = [&](bool fresh) -> int {
+        const int rc = tail_count_run(c, fresh, ts);
+        if (rc) return rc;
+        L3D_HIP_CHECK(hipMemcpyAsync(c->h_fin.p, c->d_lzero.p, (kFinHead + fin_med(V)) * 4, hipMemcpyDeviceToHost, st));
+        L3D_HIP_CHECK(hipStreamSynchronize(st));
+        return L3D_OK;
+    };
+    int rc = run(true);
+    if (rc) return rc;
+    rc = check_pass(c);
+    if (rc) return rc;
+    while (c->h_fin.p[kListPools * 16 + 32 + c->chain_enqueued - 1]) {
+        rc = run(false);
+        if (rc) return rc;
+        ++c->tm.chain_extra_rounds;
+    }
+    return L3D_OK;
+}
+
+static int close_failed_call(l3d_ctx* c, int rc) {   // as l3d_match_finish: a defined state, the error text kept
+    if (rc != L3D_OK && rc != L3D_ERR_RETRY) {
+        const std::string why = l3d_last_error();
+        abort_match(c);
+        set_error(why);
+    }
+    return rc;
+}
+
+int l3d_tail_shard_count(l3d_ctx* c, uint32_t counts[2]) {
+    if (!c || !counts) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (c->state != l3d_ctx::BEGUN || !c->lists_ready || c->shard_world < 2)
+        return fail(L3D_ERR_STATE, "l3d_tail_shard_count follows l3d_lists_shard* and the exchange of its slabs (world > 1)");
+    (void)hipSetDevice(c->device);
+    const int rc = [&]() -> int {
+        const ListPools lp = list_pools(c);
+        L3D_HIP_CHECK(launch_seg_index(lp, c->d_seg_of_g.p, c->G, c->shard_world, c->stream));
+        const TailShard ts{c->shard_v0, c->shard_v1, c->seg_base[c->shard_v0], c->seg_base[c->shard_v1], c->shard_pool0, c->shard_ppr};
+        const int r = tail_count_until_converged(c, ts);
+        if (r == kRetry) { c->lists_ready = false; return fail(L3D_ERR_RETRY, "phase-B pools enlarged: repeat l3d_lists_shard and the exchange"); }
+        if (r) return r;
+        const uint32_t* med = c->h_fin.p + kFinHead;
+        counts[0] = med[2]; counts[1] = med[3];
+        c->tail_counted = true; c->tail_written = false;
+        return L3D_OK;
+    }();
+    return close_failed_call(c, rc);
+}
+
+int l3d_tail_shard_layout(l3d_ctx* c, uint32_t world, const uint32_t* counts_all, const uint32_t* view_bounds, void* base_ptr[9],
+                          uint64_t elt_bytes[9], uint64_t* first, uint64_t* count) {
+    if (!c || !counts_all || !view_bounds || !base_ptr || !elt_bytes || !first || !count) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (c->state != l3d_ctx::BEGUN || !c->tail_counted || world != c->shard_world)
+        return fail(L3D_ERR_STATE, "l3d_tail_shard_layout follows l3d_tail_shard_count (same world size)");
+    (void)hipSetDevice(c->device);
+    const int rc = [&]() -> int {
+        const uint32_t V = (uint32_t)c->order.size();
+        if (view_bounds[0] != 0 || view_bounds[world] != V || view_bounds[c->shard_rank] != c->shard_v0 ||
+            view_bounds[c->shard_rank + 1] != c->shard_v1)
+            return fail(L3D_ERR_ARG, "view bounds do not match the list pass of this rank");
+        c->tail_base_n.assign(world + 1, 0); c->tail_base_h.assign(world + 1, 0);
+        uint64_t n = 0, h = 0;
+        for (uint32_t r = 0; r < world; ++r) {
+            if (view_bounds[r + 1] < view_bounds[r]) return fail(L3D_ERR_ARG, "view bounds are not ascending");
+            c->tail_base_n[r] = (uint32_t)n; c->tail_base_h[r] = (uint32_t)h;
+            n += counts_all[2 * r]; h += counts_all[2 * r + 1];
+        }
+        if (n >= (1ull << 32) || n > (uint64_t)kListPools * c->lp_hcap || h > c->G)
+            return fail(L3D_ERR_LIMIT, "the ranks' counts exceed the output arrays");
+        c->tail_base_n[world] = (uint32_t)n; c->tail_base_h[world] = (uint32_t)h;
+        const uint32_t me = c->shard_rank;
+        const TailShard ts{c->shard_v0, c->shard_v1, c->seg_base[c->shard_v0], c->seg_base[c->shard_v1], c->shard_pool0, c->shard_ppr};
+        const int r2 = tail_write_run(c, ts, (unsigned long long)c->tail_base_n[me] | ((unsigned long long)c->tail_base_h[me] << 32), false);
+        if (r2) return r2;
+        void* bp[9] = {c->d_surv.p, c->d_surv_tg.p, c->d_surv_sg.p, c->d_hyps.p, c->d_depths.p, c->d_surv_off.p, c->d_hyp_off.p,
+                       c->d_hyp_of_seg.p, medians_of(c)};
+        const uint64_t eb[9] = {sizeof(Match), 4, 4, sizeof(HypRec), 8, 4, 4, 4, 4};
+        for (int k = 0; k < 9; ++k) { base_ptr[k] = bp[k]; elt_bytes[k] = eb[k]; }
+        for (uint32_t r = 0; r < world; ++r) {
+            const uint64_t g0 = c->seg_base[view_bounds[r]], g1 = c->seg_base[view_bounds[r + 1]], end = r + 1 == world ? 1 : 0;
+            const uint64_t f[9] = {c->tail_base_n[r], c->tail_base_n[r], c->tail_base_n[r], c->tail_base_h[r], c->tail_base_h[r],
+                                   g0, g0, g0, view_bounds[r]};
+            const uint64_t m[9] = {counts_all[2 * r], counts_all[2 * r], counts_all[2 * r], counts_all[2 * r + 1], counts_all[2 * r + 1],
+                                   g1 - g0 + end, g1 - g0 + end, g1 - g0, (uint64_t)view_bounds[r + 1] - view_bounds[r]};
+            for (int k = 0; k < 9; ++k) { first[9 * r + k] = f[k]; count[9 * r + k] = m[k]; }
+        }
+        c->tail_written = true;
+        return L3D_OK;
+    }();
+    return close_failed_call(c, rc);
+}
+
+int l3d_tail_shard_commit(l3d_ctx* c) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (c->state != l3d_ctx::BEGUN || !c->tail_written)
+        return fail(L3D_ERR_STATE, "l3d_tail_shard_commit follows l3d_tail_shard_layout and the exchange of the parts");
+    (void)hipSetDevice(c->device);
+    const int rc = [&]() -> int {
+        const uint32_t V = (uint32_t)c->order.size(), world = c->shard_world;
+        uint32_t* med = c->h_fin.p + kFinHead;
+        if (c->ev_on(7)) L3D_HIP_CHECK(hipEventRecord(c->ev[7], c->stream));
+        // totals' words and the medians of ALL views (the other ranks' have arrived with the exchange)
+        L3D_HIP_CHECK(hipMemcpyAsync(med, c->d_med, (8 + (size_t)V) * 4, hipMemcpyDeviceToHost, c->stream));
+        L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
+        med[2] = c->tail_base_n[world]; med[3] = c->tail_base_h[world];
+        c->tail_counted = false; c->tail_written = false;
+        return finish_commit(c);
+    }();
+    return close_failed_call(c, rc);
 }
 
 int l3d_match_images(l3d_ctx* c, const l3d_match_params* p) {

@@ -55,7 +55,7 @@ hipError_t launch_score_all(uint32_t g0, uint32_t G, const uint32_t* off, const 
                             SimConst, hipStream_t);
 hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base,
                              const uint32_t* tie_total, uint32_t* tie_out, float* out, const uint32_t* rb_src,
-                             uint32_t* rb_host, uint32_t rb_words, uint32_t* rb_count, hipStream_t);
+                             uint32_t* rb_host, uint32_t rb_words, uint32_t* rb_count, hipStream_t, uint32_t v0 = 0);
 hipError_t launch_aff_sim(uint32_t N, const uint32_t* surv_sg, const uint32_t* surv_tg, const int32_t* hyp_of_seg,
                           const HypRec*, const ViewAff*, const float* medians, const float* msdl, float two_sigA_sqr,
                           float* simv, int32_t* ca, int32_t* cb, hipStream_t);
@@ -212,6 +212,11 @@ struct l3d_ctx {
     uint32_t chain_need = 8, chain_enqueued = 10;   // chain launches that changed something last time / enqueued this time
     // list pass sharded over ranks (l3d_lists_shard): world size of the running call, slabs received
     uint32_t shard_world = 0;
+    // this rank's share of a sharded list pass (l3d_lists_shard*): views [shard_v0, shard_v1), pools [shard_pool0, + shard_ppr)
+    uint32_t shard_rank = 0, shard_v0 = 0, shard_v1 = 0, shard_pool0 = 0, shard_ppr = 0;
+    // sharded tail (l3d_tail_shard_*): counts of all ranks -> where every rank's outputs start in the full arrays
+    std::vector<uint32_t> tail_base_n, tail_base_h;
+    bool tail_counted = false, tail_written = false;
     bool lists_ready = false, lists_prepared = false;   // per-pool capacities (grow on overflow, kept across calls)
     PinnedBuf<uint32_t> h_fin;
     PinnedBuf<char> h_ltab;
