@@ -87,6 +87,22 @@ void make_cull(const double F[9], double ws, double hs, double wt, double ht, Pa
 void pair_baseline(const d3& Cs, const d3& Ct, PairDesc& pd);
 void orientation_thresholds(double& lo, double& hi);
 SimConst sim_thresholds(float two_sigA_sqr);
+// L3D_TRACE=1: host-side wall-clock checkpoints of matchImages on stderr (diagnostics)
+struct HostTrace {
+    bool on = std::getenv("L3D_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::vector<std::pair<double, const char*>> marks;   // printed by flush(): printing inside the timeline distorts it
+    void mark(const char* what) {
+        if (!on) return;
+        marks.emplace_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what);
+    }
+    void flush() {
+        for (auto& m : marks) std::fprintf(stderr, "[l3d trace] %9.1f us  %s\n", m.first, m.second);
+        marks.clear();
+    }
+};
+extern HostTrace g_trace;   // l3d_api.hip
+
 float ev_ms(hipEvent_t a, hipEvent_t b);
 float ev_ms(const ::l3d_ctx* c, int a, int b);   // 0 when the timing level left one of the two events out
 int affinity_core(::l3d_ctx* c);           // l3d_affinity_host.hip
@@ -94,6 +110,10 @@ int ensure_affinity_host(::l3d_ctx* c);    // l3d_affinity_host.hip
 std::string output_filename(::l3d_ctx* c, int max_image_width);   // l3d_output.hip
 
 }  // namespace l3d
+
+// shared by l3d_api.hip and l3d_phase_b.hip (C linkage: defined inside their extern "C" blocks)
+extern "C" void abort_match(::l3d_ctx* c);
+extern "C" void collect_match_timing(::l3d_ctx* c);
 
 using namespace l3d;   // host-side translation units of this library only (never included by users of the C-ABI)
 
