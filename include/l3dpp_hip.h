@@ -230,6 +230,24 @@ int l3d_lists_shard(l3d_ctx*, uint32_t rank, uint32_t world, void* slab_ptr[4], 
  * replicated remainder of phase B works on the records alone. */
 int l3d_lists_shard_views(l3d_ctx*, uint32_t rank, uint32_t world, uint32_t view0, uint32_t view1, void* slab_ptr[4],
                           uint64_t slab_bytes[4], void* full_ptr[4]);
+/* The tail of phase B sharded by views as well (optional, instead of l3d_match_finish after l3d_lists_shard_views and the
+ * exchange of its slabs).  The chain of storeInverseMatches (line3D.cc:1672-1699) is a global fixed point over the
+ * records of all ranks and every rank runs it; scoringCPU's scores, filterMatches (:1586-1669), the surviving matches_
+ * lists, estimated_position3D_ and the view medians are per view and are computed by the rank that owns the view:
+ *   l3d_tail_shard_count   chain + scores + filterMatches + counts of this rank's views: counts[0] = its surviving
+ *                          matches, counts[1] = its best hypotheses (L3D_ERR_RETRY as l3d_match_finish gives it)
+ *   -- the caller all-gathers the two counts of every rank --
+ *   l3d_tail_shard_layout  this rank's outputs, written at their places in the full arrays, and where every rank's parts
+ *                          are: nine arrays (Match, target / source segment of a match, HypRec, depth pairs, the three
+ *                          per-segment arrays, the view medians): base_ptr[k] device pointer, elt_bytes[k] element size,
+ *                          first[9 r + k] / count[9 r + k] the elements of rank r.  view_bounds[world + 1]: the view
+ *                          ranges of the ranks (those of the list pass)
+ *   -- the caller exchanges the parts: rank r's part of array k to every other rank, in place --
+ *   l3d_tail_shard_commit  closes the call as l3d_match_finish does (medians to the host, totals, views untranslated) */
+int l3d_tail_shard_count(l3d_ctx*, uint32_t counts[2]);
+int l3d_tail_shard_layout(l3d_ctx*, uint32_t world, const uint32_t* counts_all, const uint32_t* view_bounds, void* base_ptr[9],
+                          uint64_t elt_bytes[9], uint64_t* first, uint64_t* count);
+int l3d_tail_shard_commit(l3d_ctx*);
 /* Partition of a call over `world` ranks (host only; a function of the pair list of l3d_get_pairs): contiguous view
  * ranges whose outgoing pairs carry equal shares of the cost (pair_cost[p], e.g. Ms * Mt); pair_src_view[p] = index of
  * the pair's source view (the list is ordered by it).  view_bounds / pair_bounds receive world + 1 entries: rank r owns

@@ -65,7 +65,7 @@ EXPORTS = [
     "l3d_add_view_worldpoints", "l3d_get_visual_neighbors", "l3d_neighbors_from_worldpoints",
     "l3d_nvm_open", "l3d_nvm_num_cameras", "l3d_nvm_get_camera", "l3d_nvm_get_worldpoints", "l3d_nvm_close",
     "l3d_nvm_intrinsics", "l3d_segment_cache_name", "l3d_read_segment_cache", "l3d_write_segment_cache",
-    "l3d_trim_cache", "l3d_set_timing_level",
+    "l3d_trim_cache", "l3d_set_timing_level", "l3d_tail_shard_count", "l3d_tail_shard_layout", "l3d_tail_shard_commit",
     "l3d_sfm_open_colmap", "l3d_sfm_open_bundler", "l3d_sfm_num_images", "l3d_sfm_get_image", "l3d_sfm_get_worldpoints",
     "l3d_sfm_close",
 ]
@@ -131,6 +131,9 @@ def load():
     L.l3d_get_sparse_matrix.argtypes = [vp, i32, vp, vp]
     L.l3d_get_timings.argtypes = [vp, C.POINTER(Timings)]
     L.l3d_set_timing_level.argtypes = [vp, C.c_int]
+    L.l3d_tail_shard_count.argtypes = [vp, vp]
+    L.l3d_tail_shard_layout.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
+    L.l3d_tail_shard_commit.argtypes = [vp]
     L.l3d_match_lines.argtypes = [i32, vp, u32, vp, u32, vp, vp, vp, vp, vp, u32, u32, f32, C.c_int32, vp,
                                   C.POINTER(u64)]
     L.l3d_set_brute_force.argtypes = [vp, i32]

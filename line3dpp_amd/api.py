@@ -132,6 +132,29 @@ class Line3D:
             return None
         return [(sp[k], int(sb[k]), fp[k]) for k in range(4)]
 
+    # the tail of phase B sharded by views (see line3dpp_amd/dist.py: match_images_halo)
+    def tailShardCount(self):
+        """l3d_tail_shard_count -> (status, surviving matches, best hypotheses of this rank's views)"""
+        c = (C.c_uint32 * 2)()
+        rc = self.L.l3d_tail_shard_count(self.h, c)
+        self.last_status = rc
+        return rc, int(c[0]), int(c[1])
+
+    def tailShardLayout(self, world, counts_all, view_bounds):
+        """l3d_tail_shard_layout -> [(device pointer of the full array, element bytes, [(first, count) per rank])] x 9, or None"""
+        ca = (C.c_uint32 * (2 * world))(*[int(x) for pair in counts_all for x in pair])
+        vb = (C.c_uint32 * (world + 1))(*[int(x) for x in view_bounds])
+        bp = (C.c_void_p * 9)(); eb = (C.c_uint64 * 9)()
+        first = (C.c_uint64 * (9 * world))(); count = (C.c_uint64 * (9 * world))()
+        if not self._check(self.L.l3d_tail_shard_layout(self.h, int(world), ca, vb, bp, eb, first, count), "tailShardLayout"):
+            return None
+        return [(bp[k], int(eb[k]), [(int(first[9 * r + k]), int(count[9 * r + k])) for r in range(world)]) for k in range(9)]
+
+    def tailShardCommit(self):
+        rc = self.L.l3d_tail_shard_commit(self.h)
+        self.last_status = rc
+        return rc
+
     def matchAbort(self):
         """closes an open matchBegin without results (views untranslated, context idle); no-op otherwise"""
         return self.L.l3d_match_abort(self.h) == 0

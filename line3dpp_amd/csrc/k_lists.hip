@@ -999,7 +999,7 @@ __global__ void k_chain_sweep(const ListPools lp, uint8_t* __restrict__ positive
                               uint32_t sweep) {
     if (lp.flags[0] | lp.flags[2]) return;                    // an overflowed pass is discarded: its records are incomplete
     if (sweep && !changed[sweep - 1]) return;
-    const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t pool = lp.pool0 + blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;   // (grid.y = lp.npools: all pools)
     if (k >= min(lp.cnt[pool * 16 + 1], lp.hcap)) return;
     const HypHdr& h = lp.hyps[pool * lp.hcap + k];
     if (h.pair_flags & kHypInv) return;                       // an inverse hypothesis exists iff its SOURCE is positive
@@ -1029,7 +1029,7 @@ constexpr uint32_t kMaxReplicas = 16;   // the view maxima are kept in 16 replic
 __global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ positive,
                              const uint32_t* __restrict__ gseg_view, Slot* __restrict__ slots,
                              const uint8_t* __restrict__ pair_present, uint32_t* __restrict__ max_score_bits) {
-    const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t pool = lp.pool0 + blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;   // (grid.y = lp.npools)
     const bool active = !(lp.flags[0] | lp.flags[2]) && k < min(lp.cnt[pool * 16 + 1], lp.hcap);
     float score3D = 0.0f;
     uint32_t view = kEmpty;
@@ -1080,7 +1080,7 @@ __global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ pos
 __global__ void k_hyp_filter(const ListPools lp, const uint32_t* __restrict__ gseg_view,
                              const uint32_t* __restrict__ max_score_bits, uint32_t* __restrict__ kept_cnt,
                              unsigned long long* __restrict__ best_pack) {
-    const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t pool = lp.pool0 + blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;   // (grid.y = lp.npools)
     if ((lp.flags[0] | lp.flags[2]) || k >= min(lp.cnt[pool * 16 + 1], lp.hcap)) return;
     HypHdr& h = lp.hyps[pool * lp.hcap + k];
     uint32_t mx = 0;
@@ -1099,10 +1099,10 @@ __global__ void k_hyp_filter(const ListPools lp, const uint32_t* __restrict__ gs
 }
 
 // per segment: the 0.75 gate; cnt64[g] = surviving matches (low word) | has a best hypothesis (high word)
-__global__ void k_seg_filter(uint32_t G, const uint32_t* __restrict__ kept_cnt,
+__global__ void k_seg_filter(uint32_t g0, uint32_t g1, const uint32_t* __restrict__ kept_cnt,
                              const unsigned long long* __restrict__ best_pack, unsigned long long* __restrict__ cnt64) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G) return;
+    const uint32_t g = g0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= g1) return;
     const bool ok = __uint_as_float((uint32_t)(best_pack[g] >> 32)) > kMinBestScore3D;
     cnt64[g] = ok ? ((1ull << 32) | kept_cnt[g]) : 0ull;
 }
@@ -1123,52 +1123,66 @@ __device__ __forceinline__ void make_match(const ViewDev* views, const PairDesc*
 }
 
 // offsets of all segments + the outputs of the segments that keep a best hypothesis: surviving matches (reference
-// Match layout, canonical order), the estimated_position3D_ entry, the two depths for the view's median
-__global__ void k_seg_write(uint32_t G, const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+// Match layout, canonical order), the estimated_position3D_ entry, the two depths for the view's median.
+// Thread t serves segment t (offsets, hyp_of_seg) AND header slot t (pool t / hcap, index t % hcap): a kept header finds
+// its place among the surviving matches of its segment by counting the kept headers before it (a segment's headers are
+// contiguous and in canonical order).  One thread per SEGMENT walking its headers, as until round 4, ran ~950
+// instructions per wave on 6 of 64 lanes (profiles/r04_all_kernels_pmc_C1.txt).
+// A rank of a multi-GPU run with a SHARDED tail serves the segments [g0, g1) of its views and the headers of its pools
+// (lp.pool0, lp.npools); off64s holds the scan over ITS segments and base64 what the ranks before it hold (surviving
+// matches | best hypotheses << 32), so that everything is written at its place in the full arrays.  One GPU: g0 = 0,
+// g1 = G, all pools, base64 = 0.
+__global__ void k_seg_write(uint32_t g0, uint32_t g1, unsigned long long base64, const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
                             const uint32_t* __restrict__ seg_base, const uint32_t* __restrict__ gseg_view,
                             const unsigned long long* __restrict__ off64s, const unsigned long long* __restrict__ best_pack,
                             const uint32_t* __restrict__ seg_of_g, const ListPools lp, const Slot* __restrict__ slots,
                             uint32_t* __restrict__ surv_off, uint32_t* __restrict__ hyp_off, Match* __restrict__ surv,
                             uint32_t* __restrict__ surv_tg, uint32_t* __restrict__ surv_sg,
                             int32_t* __restrict__ hyp_of_seg, HypRec* __restrict__ hyps, float* __restrict__ depths) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g > G) return;
-    const unsigned long long o = off64s[g];
-    surv_off[g] = (uint32_t)o; hyp_off[g] = (uint32_t)(o >> 32);
-    if (g == G) return;
-    const bool ok = (off64s[g + 1] >> 32) != (o >> 32) && !(lp.flags[0] | lp.flags[2]);
-    if (!ok) { hyp_of_seg[g] = -1; return; }
-    const uint32_t view = gseg_view[g], seg = g - seg_base[view];
-    const ViewDev& v = views[view];
-    const SegHdr sh = lp.segs[seg_of_g[g]];
-    const uint32_t best_canon = 0xFFFFFFFFu - (uint32_t)best_pack[g];
-    uint32_t w = (uint32_t)o;
-    const uint32_t hx = (uint32_t)(o >> 32);
-    for (uint32_t k = 0; k < sh.hyp_cnt; ++k) {
-        const HypHdr& h = lp.hyps[sh.hyp_begin + k];
-        if (!(h.state & kHypKeep)) continue;
-        Match m; uint32_t tv, tseg;
-        make_match(views, pairs, view, seg, h, m, tv, tseg);
-        surv_tg[w] = seg_base[tv] + tseg;
-        surv_sg[w] = g;
-        surv[w++] = m;
-        if (h.canon == best_canon) {
-            HypRec r;
-            const SegX& sx = v.segx[seg];
-            const Seg3 s3 = unproject(v.C, sx.r1, sx.r2, h.dp1, h.dp2);   // unprojectMatch(best,true), :1638
-            r.P1[0] = s3.P1.x; r.P1[1] = s3.P1.y; r.P1[2] = s3.P1.z;
-            r.P2[0] = s3.P2.x; r.P2[1] = s3.P2.y; r.P2[2] = s3.P2.z;
-            r.dir[0] = s3.dir.x; r.dir[1] = s3.dir.y; r.dir[2] = s3.dir.z;
-            r.length = s3.length;
-            r.valid = s3.length > 0.0f ? 1u : 0u;
-            r.m = m;
-            r.view = view; r.pad = 0;
-            hyps[hx] = r;
-            depths[2 * hx] = h.dp1;
-            depths[2 * hx + 1] = h.dp2;
-        }
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool pass_ok = !(lp.flags[0] | lp.flags[2]);
+    if (t <= g1 - g0) {   // ---- the segment (and the end of the range) ----
+        const uint32_t gs = g0 + t;
+        const unsigned long long o = off64s[gs] + base64;
+        surv_off[gs] = (uint32_t)o; hyp_off[gs] = (uint32_t)(o >> 32);
+        if (gs < g1) hyp_of_seg[gs] = ((off64s[gs + 1] >> 32) != (off64s[gs] >> 32) && pass_ok) ? (int32_t)(uint32_t)(o >> 32) : -1;
     }
-    hyp_of_seg[g] = (int32_t)hx;
+    // ---- the header ----
+    if (!pass_ok) return;
+    const uint32_t pq = t / lp.hcap, k = t - pq * lp.hcap, pool = lp.pool0 + pq;
+    if (pq >= lp.npools || k >= min(lp.cnt[pool * 16 + 1], lp.hcap)) return;
+    const uint32_t hi = pool * lp.hcap + k;
+    const HypHdr& h = lp.hyps[hi];
+    if (!(h.state & kHypKeep)) return;
+    const uint32_t g = h.g;
+    if ((off64s[g + 1] >> 32) == (off64s[g] >> 32)) return;  // the segment keeps no best hypothesis: nothing of it is written
+    const unsigned long long o = off64s[g] + base64;
+    const uint32_t view = gseg_view[g], seg = g - seg_base[view];
+    const SegHdr sh = lp.segs[seg_of_g[g]];
+    uint32_t w = (uint32_t)o;
+    for (uint32_t y = sh.hyp_begin; y < hi; ++y) w += (lp.hyps[y].state & kHypKeep) ? 1u : 0u;
+    Match m; uint32_t tv, tseg;
+    make_match(views, pairs, view, seg, h, m, tv, tseg);
+    surv_tg[w] = seg_base[tv] + tseg;
+    surv_sg[w] = g;
+    surv[w] = m;
+    if (h.canon == 0xFFFFFFFFu - (uint32_t)best_pack[g]) {
+        const uint32_t hx = (uint32_t)(o >> 32);
+        const ViewDev& v = views[view];
+        HypRec r;
+        const SegX& sx = v.segx[seg];
+        const Seg3 s3 = unproject(v.C, sx.r1, sx.r2, h.dp1, h.dp2);   // unprojectMatch(best,true), :1638
+        r.P1[0] = s3.P1.x; r.P1[1] = s3.P1.y; r.P1[2] = s3.P1.z;
+        r.P2[0] = s3.P2.x; r.P2[1] = s3.P2.y; r.P2[2] = s3.P2.z;
+        r.dir[0] = s3.dir.x; r.dir[1] = s3.dir.y; r.dir[2] = s3.dir.z;
+        r.length = s3.length;
+        r.valid = s3.length > 0.0f ? 1u : 0u;
+        r.m = m;
+        r.view = view; r.pad = 0;
+        hyps[hx] = r;
+        depths[2 * hx] = h.dp1;
+        depths[2 * hx + 1] = h.dp2;
+    }
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------------
@@ -1249,7 +1263,7 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
         /* lists beyond one wave's capacity: two waves up to 2x, four up to 4x (fixed grids over the hand-over lists) */   \
         hipLaunchKernelGGL((k_lists<2, B>), dim3(16384), dim3(128), lds2, st, views, pairs, lviews, opairs, ipairs,        \
                            gseg_view, poff, inv, slots, uniform_K, lp, 0u);                                                \
-        hipLaunchKernelGGL((k_lists<4, B>), dim3(2048), dim3(256), lds4, st, views, pairs, lviews, opairs, ipairs,         \
+        hipLaunchKernelGGL((k_lists<4, B>), dim3(512), dim3(256), lds4, st, views, pairs, lviews, opairs, ipairs,          \
                            gseg_view, poff, inv, slots, uniform_K, lp, 0u);                                                \
     } while (0)
     if (wide) L3D_LISTS(256); else L3D_LISTS(128);
@@ -1270,7 +1284,7 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
     return hipGetLastError();
 }
 
-static dim3 hyp_grid(const ListPools& lp) { return dim3((lp.hcap + 255) / 256, kListPools); }
+static dim3 hyp_grid(const ListPools& lp) { return dim3((lp.hcap + 255) / 256, lp.npools); }   // the pools of lp: pool0 + blockIdx.y
 
 hipError_t launch_chain_sweep(ListPools lp, uint8_t* positive, uint32_t* changed, uint32_t sweep, hipStream_t st) {
     hipLaunchKernelGGL(k_chain_sweep, hyp_grid(lp), dim3(256), 0, st, lp, positive, changed, sweep);
@@ -1281,19 +1295,20 @@ hipError_t launch_hyp_scores(ListPools lp, const uint8_t* positive, const uint32
     hipLaunchKernelGGL(k_hyp_scores, hyp_grid(lp), dim3(256), 0, st, lp, positive, gseg_view, slots, pair_present, max_score_bits);
     return hipGetLastError();
 }
-hipError_t launch_hyp_filter(ListPools lp, uint32_t G, const uint32_t* gseg_view, const uint32_t* max_score_bits,
+hipError_t launch_hyp_filter(ListPools lp, uint32_t g0, uint32_t g1, const uint32_t* gseg_view, const uint32_t* max_score_bits,
                              uint32_t* kept_cnt, unsigned long long* best_pack, unsigned long long* cnt64,
                              hipStream_t st) {
     hipLaunchKernelGGL(k_hyp_filter, hyp_grid(lp), dim3(256), 0, st, lp, gseg_view, max_score_bits, kept_cnt, best_pack);
-    if (G) hipLaunchKernelGGL(k_seg_filter, dim3((G + 255) / 256), dim3(256), 0, st, G, kept_cnt, best_pack, cnt64);
+    if (g1 > g0) hipLaunchKernelGGL(k_seg_filter, dim3((g1 - g0 + 255) / 256), dim3(256), 0, st, g0, g1, kept_cnt, best_pack, cnt64);
     return hipGetLastError();
 }
-hipError_t launch_seg_write(uint32_t G, const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base,
+hipError_t launch_seg_write(uint32_t g0, uint32_t g1, unsigned long long base64, const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base,
                             const uint32_t* gseg_view, const unsigned long long* off64s,
                             const unsigned long long* best_pack, const uint32_t* seg_of_g, ListPools lp,
                             const Slot* slots, uint32_t* surv_off, uint32_t* hyp_off, Match* surv, uint32_t* surv_tg,
                             uint32_t* surv_sg, int32_t* hyp_of_seg, HypRec* hyps, float* depths, hipStream_t st) {
-    hipLaunchKernelGGL(k_seg_write, dim3((G + 1 + 127) / 128), dim3(128), 0, st, G, views, pairs, seg_base, gseg_view,
+    const uint64_t n_thr = std::max<uint64_t>((uint64_t)(g1 - g0) + 1, (uint64_t)lp.npools * lp.hcap);
+    hipLaunchKernelGGL(k_seg_write, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, g0, g1, base64, views, pairs, seg_base, gseg_view,
                        off64s, best_pack, seg_of_g, lp, slots, surv_off, hyp_off, surv, surv_tg, surv_sg, hyp_of_seg,
                        hyps, depths);
     return hipGetLastError();

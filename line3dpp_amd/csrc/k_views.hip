@@ -554,11 +554,12 @@ __global__ __launch_bounds__(1024) void k_median_all(const float* __restrict__ d
                                                      const uint32_t* __restrict__ seg_base,
                                                      const uint32_t* __restrict__ tie_total, uint32_t* __restrict__ tie_out,
                                                      float* __restrict__ out_median, const uint32_t* rb_src,
-                                                     uint32_t* __restrict__ rb_host, uint32_t rb_words, uint32_t* rb_count) {
+                                                     uint32_t* __restrict__ rb_host, uint32_t rb_words, uint32_t* rb_count,
+                                                     uint32_t v0) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_prefix, s_rank, s_last;
-    const uint32_t v = blockIdx.x;
-    if (v == 0 && threadIdx.x == 0 && tie_total) *tie_out = *tie_total;
+    const uint32_t v = v0 + blockIdx.x;             // (a rank with a sharded tail serves the views [v0, v0 + gridDim.x))
+    if (blockIdx.x == 0 && threadIdx.x == 0 && tie_total) *tie_out = *tie_total;
     const uint32_t h0 = hyp_off[seg_base[v]], h1 = hyp_off[seg_base[v + 1]];
     const uint32_t n = 2u * (h1 - h0);
     const float* dv = depths + 2u * h0;
@@ -722,10 +723,10 @@ hipError_t launch_score_all(uint32_t g0, uint32_t G, const uint32_t* off, const 
 }
 hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base,
                              const uint32_t* tie_total, uint32_t* tie_out, float* out, const uint32_t* rb_src,
-                             uint32_t* rb_host, uint32_t rb_words, uint32_t* rb_count, hipStream_t st) {
+                             uint32_t* rb_host, uint32_t rb_words, uint32_t* rb_count, hipStream_t st, uint32_t v0) {
     if (!V) return hipSuccess;
     hipLaunchKernelGGL(k_median_all, dim3(V), dim3(1024), 0, st, depths, hyp_off, seg_base, tie_total, tie_out, out, rb_src,
-                       rb_host, rb_words, rb_count);
+                       rb_host, rb_words, rb_count, v0);
     return hipGetLastError();
 }
 

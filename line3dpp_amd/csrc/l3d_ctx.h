@@ -55,7 +55,7 @@ hipError_t launch_score_all(uint32_t g0, uint32_t G, const uint32_t* off, const 
                             SimConst, hipStream_t);
 hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base,
                              const uint32_t* tie_total, uint32_t* tie_out, float* out, const uint32_t* rb_src,
-                             uint32_t* rb_host, uint32_t rb_words, uint32_t* rb_count, hipStream_t);
+                             uint32_t* rb_host, uint32_t rb_words, uint32_t* rb_count, hipStream_t, uint32_t v0 = 0);
 hipError_t launch_aff_sim(uint32_t N, const uint32_t* surv_sg, const uint32_t* surv_tg, const int32_t* hyp_of_seg,
                           const HypRec*, const ViewAff*, const float* medians, const float* msdl, float two_sigA_sqr,
                           float* simv, int32_t* ca, int32_t* cb, hipStream_t);
@@ -87,6 +87,22 @@ void make_cull(const double F[9], double ws, double hs, double wt, double ht, Pa
 void pair_baseline(const d3& Cs, const d3& Ct, PairDesc& pd);
 void orientation_thresholds(double& lo, double& hi);
 SimConst sim_thresholds(float two_sigA_sqr);
+// L3D_TRACE=1: host-side wall-clock checkpoints of matchImages on stderr (diagnostics)
+struct HostTrace {
+    bool on = std::getenv("L3D_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::vector<std::pair<double, const char*>> marks;   // printed by flush(): printing inside the timeline distorts it
+    void mark(const char* what) {
+        if (!on) return;
+        marks.emplace_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what);
+    }
+    void flush() {
+        for (auto& m : marks) std::fprintf(stderr, "[l3d trace] %9.1f us  %s\n", m.first, m.second);
+        marks.clear();
+    }
+};
+extern HostTrace g_trace;   // l3d_api.hip
+
 float ev_ms(hipEvent_t a, hipEvent_t b);
 float ev_ms(const ::l3d_ctx* c, int a, int b);   // 0 when the timing level left one of the two events out
 int affinity_core(::l3d_ctx* c);           // l3d_affinity_host.hip
@@ -94,6 +110,10 @@ int ensure_affinity_host(::l3d_ctx* c);    // l3d_affinity_host.hip
 std::string output_filename(::l3d_ctx* c, int max_image_width);   // l3d_output.hip
 
 }  // namespace l3d
+
+// shared by l3d_api.hip and l3d_phase_b.hip (C linkage: defined inside their extern "C" blocks)
+extern "C" void abort_match(::l3d_ctx* c);
+extern "C" void collect_match_timing(::l3d_ctx* c);
 
 using namespace l3d;   // host-side translation units of this library only (never included by users of the C-ABI)
 
@@ -212,6 +232,11 @@ struct l3d_ctx {
     uint32_t chain_need = 8, chain_enqueued = 10;   // chain launches that changed something last time / enqueued this time
     // list pass sharded over ranks (l3d_lists_shard): world size of the running call, slabs received
     uint32_t shard_world = 0;
+    // this rank's share of a sharded list pass (l3d_lists_shard*): views [shard_v0, shard_v1), pools [shard_pool0, + shard_ppr)
+    uint32_t shard_rank = 0, shard_v0 = 0, shard_v1 = 0, shard_pool0 = 0, shard_ppr = 0;
+    // sharded tail (l3d_tail_shard_*): counts of all ranks -> where every rank's outputs start in the full arrays
+    std::vector<uint32_t> tail_base_n, tail_base_h;
+    bool tail_counted = false, tail_written = false;
     bool lists_ready = false, lists_prepared = false;   // per-pool capacities (grow on overflow, kept across calls)
     PinnedBuf<uint32_t> h_fin;
     PinnedBuf<char> h_ltab;

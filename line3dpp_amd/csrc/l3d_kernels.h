@@ -124,10 +124,10 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
 hipError_t launch_chain_sweep(ListPools lp, uint8_t* positive, uint32_t* changed, uint32_t sweep, hipStream_t st);
 hipError_t launch_hyp_scores(ListPools lp, const uint8_t* positive, const uint32_t* gseg_view, Slot* slots,
                              const uint8_t* pair_present, uint32_t* max_score_bits, hipStream_t st);
-hipError_t launch_hyp_filter(ListPools lp, uint32_t G, const uint32_t* gseg_view, const uint32_t* max_score_bits,
+hipError_t launch_hyp_filter(ListPools lp, uint32_t g0, uint32_t g1, const uint32_t* gseg_view, const uint32_t* max_score_bits,
                              uint32_t* kept_cnt, unsigned long long* best_pack, unsigned long long* cnt64,
                              hipStream_t st);
-hipError_t launch_seg_write(uint32_t G, const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base,
+hipError_t launch_seg_write(uint32_t g0, uint32_t g1, unsigned long long base64, const ViewDev* views, const PairDesc* pairs, const uint32_t* seg_base,
                             const uint32_t* gseg_view, const unsigned long long* off64s,
                             const unsigned long long* best_pack, const uint32_t* seg_of_g, ListPools lp,
                             const Slot* slots, uint32_t* surv_off, uint32_t* hyp_off, Match* surv, uint32_t* surv_tg,

@@ -166,6 +166,48 @@ def gather_slabs(slabs, rank, world_size, device, group=None, l3d=None):
         _wait_for_exchange(device_tensor(slabs[0][2], 1, device), device, l3d)
 
 
+def exchange_parts(layout, rank, world_size, device, group=None, l3d=None):
+    """The outputs of a sharded tail (Line3D.tailShardLayout): rank r's part of every array goes to all other ranks, in
+    place -- variable sizes, known to every rank from the all-gathered counts; one send and one receive per peer and
+    array in a single group, like the record slabs (one transfer per xGMI link and array).  Empty parts are skipped on
+    both sides.  Order: arrays ascending, peers ascending, on both sides (NCCL / RCCL match the messages of a pair of ranks
+    in posting order; the tag is what gloo matches by)."""
+    import torch.distributed as dist
+    glob = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
+    recvs, sends, last = [], [], None
+    for k, (ptr, elt, parts) in enumerate(layout):
+        total = max(f + n for f, n in parts) * elt
+        if total == 0:
+            continue
+        full = device_tensor(ptr, total, device)
+        f_me, n_me = parts[rank]
+        for q in range(world_size):
+            if q == rank:
+                continue
+            f_q, n_q = parts[q]
+            if n_q:
+                recvs.append(dist.P2POp(dist.irecv, full[f_q * elt:(f_q + n_q) * elt], glob(q), group, tag=100 + k))
+            if n_me:
+                sends.append(dist.P2POp(dist.isend, full[f_me * elt:(f_me + n_me) * elt], glob(q), group, tag=100 + k))
+        last = full
+    if recvs or sends:
+        for r in dist.batch_isend_irecv(recvs + sends):
+            r.wait()
+        _wait_for_exchange(last, device, l3d)
+
+
+def _gather_counts(n_r, h_r, world_size, device, group):
+    """the two counts of every rank's part of a sharded tail -> [(n, h)] x world"""
+    import torch
+    import torch.distributed as dist
+    on_gpu = device is not None and dist.get_backend(group) == "nccl"
+    dev = device if on_gpu else "cpu"
+    mine = torch.tensor([n_r, h_r], dtype=torch.int64, device=dev)
+    out = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world_size)]
+    dist.all_gather(out, mine, group=group)
+    return [(int(t[0].item()), int(t[1].item())) for t in out]
+
+
 def plan_halo(pairs, M, world_size):
     """The partition of a call over `world_size` ranks (l3d_plan_shards) and what follows from it for every rank:
     view_bounds, pair_bounds, and per rank the runs of consecutive pairs it sends (pairs it owns whose TARGET view another
@@ -284,6 +326,7 @@ def match_images_halo(l3d, rank, world_size, device=None, group=None, **params):
     lap("exchange_slots")
     for _, f, n in recv:
         ok = ok and l3d.expandSlotIndices(f, n)
+    shard_tail = os.environ.get("L3D_SHARD_TAIL", "1") != "0" and hasattr(l3d, "tailShardCount")
     for _ in range(8):
         slabs = l3d.listsShardViews(rank, world_size, int(vb[rank]), int(vb[rank + 1])) if ok else None
         ok = ok and slabs is not None
@@ -292,12 +335,30 @@ def match_images_halo(l3d, rank, world_size, device=None, group=None, **params):
             return give_up()
         gather_slabs(slabs, rank, world_size, device, group, l3d)
         lap("exchange_lists")
-        rc = l3d.L.l3d_match_finish(l3d.h)
+        # the tail: sharded by views as well (chain on every rank, scores / filterMatches / outputs / medians by the owner
+        # of the view, the outputs exchanged in place), or replicated on the records of all ranks (L3D_SHARD_TAIL=0)
+        n_r = h_r = 0
+        if shard_tail:
+            rc, n_r, h_r = l3d.tailShardCount()
+        else:
+            rc = l3d.L.l3d_match_finish(l3d.h)
         l3d.last_status = rc
         lap("finish")
         # (every rank sees every counter, so rc is the same everywhere unless a rank failed locally: the status exchange
         # keeps a rank whose finish succeeded from leaving while another is about to repeat the exchange)
         same = _all_ok(rc in (0, -10), device, group)
+        if rc == 0 and same and shard_tail:
+            counts = _gather_counts(n_r, h_r, world_size, device, group)
+            layout = l3d.tailShardLayout(world_size, counts, [int(v) for v in vb])
+            if not _all_ok(layout is not None, device, group):
+                return give_up()                     # (a rank whose layout failed has closed its call already: a no-op there)
+            exchange_parts(layout, rank, world_size, device, group, l3d)
+            rc = l3d.tailShardCommit()
+            l3d.last_status = rc
+            lap("finish")
+            if not _all_ok(rc == 0, device, group):
+                return give_up() if rc == 0 else l3d._check(rc, "tailShardCommit")
+            return True
         if rc == 0 and same:
             return True
         if not same:

@@ -351,8 +351,70 @@ class _HaloReplayContext(_ReplayContext):
         self.last_status = rc
         return rc == 0
 
+    # ---- the sharded tail (l3d_tail_shard_count / _layout / _commit): nine arrays with parts of rank-dependent size
+    # (one rank's are empty), every part carrying a signature that the commit checks for all ranks ----
+    ELT = [40, 4, 4, 128, 8, 4, 4, 4, 4]
 
-def _halo_worker(rank, world, port, q):
+    def _counts(self, r):
+        return (0, 0) if r == self.world - 1 and self.world > 2 else (10 + 3 * r, 2 + r)
+
+    def _part_sig(self, r, k, nbytes):
+        import hashlib
+        d = hashlib.sha256(f"part:{r}:{k}:{self.attempt}".encode()).digest()
+        return np.frombuffer((d * (nbytes // len(d) + 1))[:nbytes], np.uint8)
+
+    def _slabs_arrived(self):
+        vb = self.halo_plan["view_bounds"]
+        return all(np.array_equal(self.full[k][r * self.SLAB:(r + 1) * self.SLAB], self._sig(r, int(vb[r]), int(vb[r + 1]), self.attempt, k))
+                   for r in range(self.world) for k in range(4))
+
+    def tailShardCount(self):
+        if not self._slabs_arrived():
+            self.last_status = -8
+            return -8, 0, 0
+        if self.attempt == 0:                        # "pools enlarged on every rank alike": repeat list pass + gather
+            self.attempt = 1; self.log.append("retry")
+            return -10, 0, 0
+        self.log.append("tail_count")
+        return (0,) + self._counts(self.rank)
+
+    def tailShardLayout(self, world, counts_all, view_bounds):
+        assert world == self.world and list(counts_all) == [self._counts(r) for r in range(world)]
+        assert [int(v) for v in view_bounds] == [int(v) for v in self.halo_plan["view_bounds"]]
+        base_n = np.concatenate([[0], np.cumsum([c[0] for c in counts_all])]); base_h = np.concatenate([[0], np.cumsum([c[1] for c in counts_all])])
+        seg = np.concatenate([[0], np.cumsum([5] * world)])                       # 5 "segments" and one "view" per rank
+        self.parts = []
+        for k, elt in enumerate(self.ELT):
+            if k < 3:
+                rng_ = [(int(base_n[r]), int(counts_all[r][0])) for r in range(world)]
+            elif k < 5:
+                rng_ = [(int(base_h[r]), int(counts_all[r][1])) for r in range(world)]
+            elif k < 8:
+                rng_ = [(int(seg[r]), 5 + (1 if k < 7 and r == world - 1 else 0)) for r in range(world)]
+            else:
+                rng_ = [(r, 1) for r in range(world)]
+            total = max(f + n for f, n in rng_) * elt
+            arr = np.full(max(total, 1), 0xEE, np.uint8)
+            f, n = rng_[self.rank]
+            arr[f * elt:(f + n) * elt] = self._part_sig(self.rank, k, n * elt)
+            self.parts.append((arr, elt, rng_))
+        self.log.append("tail_layout")
+        return list(self.parts)
+
+    def tailShardCommit(self):
+        for k, (arr, elt, rng_) in enumerate(self.parts):
+            for r, (f, n) in enumerate(rng_):
+                if not np.array_equal(arr[f * elt:(f + n) * elt], self._part_sig(r, k, n * elt)):
+                    self.last_status = -8
+                    return -8                        # a part that did not arrive
+        self.o.end_match()
+        self.o.match_images(kNN=self.kNN); self.o.compute_affinity()
+        self.state = "matched"; self.log.append("finish")
+        self.last_status = 0
+        return 0
+
+
+def _halo_worker(rank, world, port, q, shard_tail=True):
     sys.path.insert(0, ROOT)
     from line3dpp_amd import dist
     from line3dpp_amd.scene import make_scene
@@ -361,6 +423,7 @@ def _halo_worker(rank, world, port, q):
     try:
         scene = make_scene(9, 60, n_neighbors=4, seed=6)
         ctx = _HaloReplayContext(scene, 5, rank, world)
+        os.environ["L3D_SHARD_TAIL"] = "1" if shard_tail else "0"
         real = dist.device_tensor
         dist.device_tensor = lambda arr, nbytes, device: torch.from_numpy(arr.view(np.uint8))[:nbytes]
         try:
@@ -371,7 +434,7 @@ def _halo_worker(rank, world, port, q):
         pb, vb, runs = plan["pair_bounds"], plan["view_bounds"], plan["runs"]
         mine = set(range(int(pb[rank]), int(pb[rank + 1])))
         incoming = {p for r in range(world) for (qq, f, n) in runs[r] if qq == rank for p in range(f, f + n)}
-        ok = bool(ok) and ctx.log == ["begin", "retry", "finish"]
+        ok = bool(ok) and ctx.log == (["begin", "retry", "tail_count", "tail_layout", "finish"] if shard_tail else ["begin", "retry", "finish"])
         ok = ok and set(ctx.own) == mine                                   # a rank matches exactly the pairs it owns
         ok = ok and set(np.nonzero(ctx.present)[0].tolist()) == mine | incoming   # and holds those plus its halo, nothing else
         ok = ok and ctx.ranges_seen == (int(vb[rank]), int(vb[rank + 1]))
@@ -382,12 +445,12 @@ def _halo_worker(rank, world, port, q):
         dist_t.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 4, 8])
-def test_halo_form_over_gloo(world):
+@pytest.mark.parametrize("world,shard_tail", [(2, True), (3, True), (4, True), (8, True), (3, False)])
+def test_halo_form_over_gloo(world, shard_tail):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q, shard_tail)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]
@@ -460,6 +523,20 @@ class _FailingHaloContext(_HaloReplayContext):
             return -4
         return rc
 
+    def tailShardCount(self):              # the sharded tail: the same two failure points
+        rc, n, h = super().tailShardCount()
+        if self.failing and self.where == "tail_count" and rc in (0, -10):
+            self.matchAbort()
+            return -4, 0, 0
+        return rc, n, h
+
+    def tailShardCommit(self):
+        if self.failing and self.where == "finish":
+            self.matchAbort()
+            self.last_status = -4
+            return -4
+        return super().tailShardCommit()
+
 
 def _failing_worker(rank, world, port, q, fail_rank, where):
     sys.path.insert(0, ROOT)
@@ -482,7 +559,7 @@ def _failing_worker(rank, world, port, q, fail_rank, where):
         dist_t.destroy_process_group()
 
 
-@pytest.mark.parametrize("where", ["match", "expand", "finish"])
+@pytest.mark.parametrize("where", ["match", "expand", "tail_count", "finish"])
 def test_a_rank_that_fails_locally_takes_all_ranks_out_of_the_call_together(where):
     """round 3's early returns left the peers of a failing rank inside a collective for ever; now the failing rank keeps
     posting what the plan says and all ranks give up at the next status exchange (dist._all_ok): nobody hangs, nobody
@@ -500,7 +577,7 @@ def test_a_rank_that_fails_locally_takes_all_ranks_out_of_the_call_together(wher
         assert p.exitcode == 0
     assert [r[1] for r in res] == [False] * world, res
     assert all(r[3] == "begin" for r in res)
-    if where == "finish":
+    if where in ("finish", "tail_count"):
         # the two healthy ranks had closed the call (rc 0 / RETRY) when they learnt of the failure: results discarded or
         # context aborted; the failing one reports its own error -- nobody claims a result
         assert all(r[2] in ("idle", "matched") for r in res), res

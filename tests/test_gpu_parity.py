@@ -912,6 +912,98 @@ def test_halo_form_emulated_on_one_gpu_at_c2_slice_size(world):
     assert g.matchImages()                           # the failed call left a clean context
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_tail_emulated_on_one_gpu_at_c2_slice_size(world):
+    """The same halo form with the TAIL of phase B sharded by views as well (l3d_tail_shard_count / _layout / _commit):
+    after the record slabs have been copied where the all-gather would put them, every context runs the chain on all
+    records, computes scores, filterMatches, outputs and medians of ITS views only and writes them at their places in the
+    full arrays; the parts are copied where the exchange would put them; the commit closes the call.  Everything a user
+    can read back must equal a single context's result byte for byte."""
+    import torch
+    from line3dpp_amd import dist
+    from line3dpp_amd.scene import make_config
+    sc = H.ring_slice(make_config("C2", max_views=24), 0, 24)
+    ref = _gpu(sc)
+    assert ref.matchImages() and ref.computeAffinity()
+    dev = torch.device("cuda", 0)
+    ctxs = [_gpu(sc) for _ in range(world)]
+    for g in ctxs:
+        assert g.matchBegin()
+    pairs, slot_off = ctxs[0].pairs()
+    plan = dist.plan_halo(pairs, ctxs[0]._M, world)
+    vb, pb, runs = plan["view_bounds"], plan["pair_bounds"], plan["runs"]
+    bufs = []
+    for r, g in enumerate(ctxs):
+        assert g.matchPairs(int(pb[r]), int(pb[r + 1] - pb[r]))
+        for _, f, n in runs[r]:
+            assert g.packSlotIndices(f, n)
+        ptr, n_slots = g.slot_index_buffer()
+        bufs.append(dist.device_tensor(ptr, n_slots * 4, dev))
+    off = [int(o) for o in slot_off] + [int(n_slots)]
+    for r in range(world):
+        for q, f, n in runs[r]:
+            bufs[q][4 * off[f]:4 * off[f + n]].copy_(bufs[r][4 * off[f]:4 * off[f + n]])
+    torch.cuda.synchronize()
+    for q, g in enumerate(ctxs):
+        for r in range(world):
+            for qq, f, n in runs[r]:
+                if qq == q:
+                    assert g.expandSlotIndices(f, n)
+    for attempt in range(8):
+        slabs = []
+        for r, g in enumerate(ctxs):
+            sl = g.listsShardViews(r, world, int(vb[r]), int(vb[r + 1]))
+            assert sl is not None and len(sl) == 4
+            slabs.append(sl)
+        for k in range(4):
+            sb = slabs[0][k][1]
+            fulls = [dist.device_tensor(sl[k][2], sb * world, dev) for sl in slabs]
+            for r in range(world):
+                for q in range(world):
+                    if q != r:
+                        fulls[q][r * sb:(r + 1) * sb].copy_(fulls[r][r * sb:(r + 1) * sb])
+        torch.cuda.synchronize()
+        res = [g.tailShardCount() for g in ctxs]
+        assert len({rc for rc, _, _ in res}) == 1, "every rank takes the same decision (all of them see all pool counters)"
+        if res[0][0] == 0:
+            break
+        assert res[0][0] == -10, res
+    else:
+        raise AssertionError("the pools never became large enough")
+    counts = [(n, h) for _, n, h in res]
+    assert sum(n for n, _ in counts) == sum(len(ref.matches(v.cam)[0]) for v in sc.views) and all(n > 0 for n, _ in counts)
+    layouts = [g.tailShardLayout(world, counts, [int(v) for v in vb]) for g in ctxs]
+    assert all(l is not None and len(l) == 9 for l in layouts)
+    moved = 0
+    for k in range(9):
+        elt, parts = layouts[0][k][1], layouts[0][k][2]
+        assert all(l[k][1] == elt and l[k][2] == parts for l in layouts), "every rank derives the same layout"
+        total = max(f + n for f, n in parts) * elt
+        fulls = [dist.device_tensor(l[k][0], total, dev) for l in layouts]
+        for r, (f, n) in enumerate(parts):
+            for q in range(world):
+                if q != r and n:
+                    fulls[q][f * elt:(f + n) * elt].copy_(fulls[r][f * elt:(f + n) * elt])
+                    moved += n * elt
+    torch.cuda.synchronize()
+    assert moved > 0
+    assert [g.tailShardCommit() for g in ctxs] == [0] * world
+    for g in ctxs:
+        assert g.computeAffinity()
+        for v in sc.views:
+            a, ao = g.matches(v.cam); b, bo = ref.matches(v.cam)
+            assert np.array_equal(ao, bo) and a.tobytes() == b.tobytes()
+            assert g.view_info(v.cam) == ref.view_info(v.cam)
+        for x, y in zip(g.best(), ref.best()):
+            assert x.tobytes() == y.tobytes()
+        ge, gl, _ = g.affinity(); re_, rl, _ = ref.affinity()
+        assert ge.tobytes() == re_.tobytes() and gl.tobytes() == rl.tobytes()
+    # out of order: a commit without a layout, a layout with another world size
+    g = ctxs[0]
+    assert g.matchBegin() and g.tailShardCommit() != 0
+    assert g.matchImages()                           # the failed call left a clean context
+
+
 def test_txt_writer_matches_accessor_and_reference_writer(tmp_path):
     """l3d_save_3d_lines_txt (Line3D::save3DLinesAsTXT): file name and content against get3Dlines() and against
     the file the reference's own writer produces for the same scene (oracle/_ref)."""
