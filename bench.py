@@ -8,11 +8,15 @@ of Ms*Mt, divided by the wall time of the step, whole job over all ranks.  Segme
 in HBM before the timed region (uploaded at addImage).  Workload at N=1: BASELINE config C1
 (synthetic 64 views x 2000 segments/view, 10 visual neighbours).
 
-N>1 (torchrun, one rank per GPU): the halo form of line3dpp_amd/dist.py -- views cut into contiguous ranges, a rank
-matches the pairs of its views, the pairs across a cut travel point to point in compact form while the rest is being
-matched, the list pass of phase B is sharded by views, its records are all-gathered over RCCL, the tail of phase B runs
-on every rank ("scaling": "strong": same scene at every N).  No multi-GPU box has been available: at N = 1 the line
-carries `multi_gpu_model`, the expected N-GPU time term by term from this run's phase times.
+N>1 (one rank per GPU over RCCL; `python bench.py --gpus N` without WORLD_SIZE starts the N ranks itself through
+torch.distributed.run, under torchrun it is a rank): the halo form of line3dpp_amd/dist.py -- views cut into contiguous
+ranges, a rank matches the pairs of its views, the pairs across a cut travel point to point in compact form while the
+rest is being matched, the list pass, the tail of phase B and the affinity fill are sharded by the same views, their
+records / outputs / similarities are exchanged in place over xGMI and every rank ends with the complete result.
+"scaling": "weak" (default for N > 1; SURVEY.md 8e: pairs are independent units): the scene of N ranks is N neighbourhood
+rings of the configuration's size in one scene (N x 64 views x 2000 segments for C1: per-GPU work fixed, at N = 1 exactly
+the configuration); `--scaling strong` runs the SAME scene at every N.  No multi-GPU box has been available to the
+builder: at N = 1 the line carries `multi_gpu_model`, the expected N-GPU time term by term from this run's phase times.
 
 Prints ONE JSON line with
   `roofline`      the pair-matching kernel, timed with HIP events on its launch stream; VALU-issue roof priced with the
@@ -201,21 +205,30 @@ def load_json_newest(pattern, pred=lambda d: True):
     return None
 
 
-def multi_gpu_model(pairs, M, kNN, phase, lists_ms, record_bytes):
+def multi_gpu_model(pairs, M, kNN, phase, lists_ms, record_bytes, tail_bytes=0.0, sim_bytes=0.0):
     """What the halo form of the multi-GPU call (line3dpp_amd/dist.py) is expected to take on N GPUs of one node, term by
     term, from THIS run's single-GPU phase times and the plan the N ranks would follow (l3d_plan_shards): no multi-GPU
-    box has been available to measure it, so the terms are printed for whoever has one.  Assumptions stated in the
-    output: 153 GB/s per xGMI link and direction, direct exchange of the record slabs (one slab per link of the full xGMI mesh; the ring figure is printed beside it), expansion of a received slot at the
-    round-2 measured 2.8e-5 us, 0.03 ms of host latency per synchronisation point (3 per call since round 4: the exchanges
-    are ordered on the stream, dist.py) and 0.02 ms for each of the two status exchanges (dist.py: _all_ok)."""
+    box has been available to measure it, so the terms are printed for whoever has one.  Two readings per N:
+    `strong` -- this very scene cut into N view ranges; `weak` -- N rings of this scene's size in one scene (what
+    `bench.py --gpus N` runs by default), per-rank work as on one GPU plus what grows with N (the records, outputs and
+    similarities of N - 1 peers arrive; the chain of inverse matches runs over the records of all ranks).
+    Assumptions stated in the output: 153 GB/s per xGMI link and direction, direct exchanges (one part per link of the full
+    xGMI mesh), expansion of a received slot at the round-2 measured 2.8e-5 us, 0.03 ms of host latency per
+    synchronisation point, 0.02 ms per status / count exchange; of the tail of phase B (finish - list pass) the part that
+    is per view (scores, filterMatches, outputs, medians: divided by N since round 5, l3d_tail_shard_*) is taken as 0.55,
+    the rest (the chain: a fixed point over all records) as replicated -- the split of profiles/r04_final_kernel_stats."""
     from line3dpp_amd import dist as l3d_dist
     cost = np.asarray([M[s] * M[t] for s, t in pairs], np.float64)
+    per_view = 0.55
     out = {"MODELLED_NOT_MEASURED": "no multi-GPU node has been available: every figure below is arithmetic on this run's single-GPU phase times",
-           "assumptions": {"link_GB_per_s": 153.0, "record_gather": "direct: one slab per link, all peers at once (full xGMI mesh); a ring would take (N-1) slab times", "expand_us_per_slot": 2.8e-5, "host_sync_ms": 0.03, "status_allreduce_ms": 0.02,
-                            "host_sync_points": "3 (pack, list pass, finish) + 2 status exchanges; round 3 synchronised the device at 5 points",
-                            "record_bytes": int(record_bytes)}}
+           "assumptions": {"link_GB_per_s": 153.0, "exchanges": "direct: one part per link, all peers at once (full xGMI mesh); a ring would take (N-1) part times",
+                            "expand_us_per_slot": 2.8e-5, "host_sync_ms": 0.03, "status_or_count_exchange_ms": 0.02,
+                            "host_sync_points": "4 (pack, list pass, tail count, commit) + 4 status / count exchanges + 1 for the sharded affinity fill",
+                            "tail_per_view_fraction": per_view, "record_bytes": int(record_bytes), "tail_output_bytes": int(tail_bytes),
+                            "similarity_bytes": int(sim_bytes)}}
     tail_ms = max(phase["finish"] - lists_ms, 0.0)
     t1 = phase["begin"] + phase["match"] + phase["finish"] + phase["affinity"]
+    syncs = 4 * 0.03 + 5 * 0.02
     for n in (2, 4, 8):
         plan = l3d_dist.plan_halo(pairs, M, n)
         pb = plan["pair_bounds"].astype(np.int64)
@@ -225,13 +238,28 @@ def multi_gpu_model(pairs, M, kNN, phase, lists_ms, record_bytes):
             for (q, f, k) in plan["runs"][r]:
                 halo_in[q] += sum(M[pairs[p][0]] * kNN for p in range(f, f + k))
         halo_slots = max(halo_in)
+        link = 153e9
         terms = {"begin": phase["begin"], "match_own_pairs": phase["match"] * share,
                  "halo_exchange_hidden_behind_matching_MB": round(4e-6 * halo_slots, 2),
                  "expand_received_pairs": 2.8e-5 * 1e-3 * halo_slots, "list_pass_own_views": lists_ms / n,
-                 "gather_records_direct": 1e3 * record_bytes / n / 153e9, "gather_records_if_ring": 1e3 * (n - 1) / n * record_bytes / 153e9, "tail_replicated": tail_ms,
-                 "affinity_replicated": phase["affinity"], "host_syncs": 3 * 0.03 + 2 * 0.02}
+                 "gather_records_direct": 1e3 * record_bytes / n / link, "gather_records_if_ring": 1e3 * (n - 1) / n * record_bytes / link,
+                 "tail_chain_replicated": tail_ms * (1 - per_view), "tail_own_views": tail_ms * per_view / n,
+                 "exchange_tail_outputs": 1e3 * tail_bytes / n / link,
+                 "affinity_similarities_own_views": 0.6 * phase["affinity"] / n, "affinity_bookkeeping_replicated": 0.4 * phase["affinity"],
+                 "exchange_similarities": 1e3 * sim_bytes / n / link, "host_syncs": syncs}
         total = sum(v for k, v in terms.items() if not k.endswith("_MB") and not k.endswith("_if_ring"))
-        out[str(n)] = {"terms_ms": {k: round(v, 4) for k, v in terms.items()}, "total_ms": round(total, 4),
+        # weak: every rank does one GPU's work; what arrives from N - 1 peers and what is replicated grows with N
+        weak = {"own_work_as_on_one_gpu": t1, "gather_records_direct": 1e3 * record_bytes / link,
+                "exchange_tail_outputs": 1e3 * tail_bytes / link, "exchange_similarities": 1e3 * sim_bytes / link,
+                "tail_chain_over_all_ranks_records": (n - 1) * tail_ms * (1 - per_view),
+                "affinity_bookkeeping_over_all_ranks": (n - 1) * 0.4 * phase["affinity"], "host_syncs": syncs}
+        wtotal = sum(weak.values())
+        out[str(n)] = {"strong": {"terms_ms": {k: round(v, 4) for k, v in terms.items()}, "total_ms": round(total, 4),
+                                  "speedup_over_1_gpu": round(t1 / total, 2), "largest_pair_share": round(share, 4)},
+                       "weak": {"terms_ms": {k: round(v, 4) for k, v in weak.items()}, "total_ms": round(wtotal, 4),
+                                "throughput_over_1_gpu": round(n * t1 / wtotal, 2), "efficiency": round(t1 / wtotal, 3)},
+                       # (kept at the top level for readers of earlier rounds' lines: the strong reading)
+                       "terms_ms": {k: round(v, 4) for k, v in terms.items()}, "total_ms": round(total, 4),
                        "speedup_over_1_gpu": round(t1 / total, 2), "largest_pair_share": round(share, 4)}
     return out
 
@@ -277,6 +305,44 @@ def process_cold(config, device_index, kNN):
         return {"error": repr(e)[:200]}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE): start N ranks of this script, one per GPU, through
+    torch.distributed.run on 127.0.0.1 -- the form the driver itself uses for N > 1 -- and return its exit code.
+    Fails loudly when the box has fewer than N GPUs (never a silent N = 1 run)."""
+    import socket
+    import subprocess
+    if not args.launcher_selftest:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this box "
+                             f"(one rank per GPU; refusing to run fewer ranks than asked for)")
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def weak_scene(config, n):
+    """The scene of a weak-scaling run on n ranks: n neighbourhood rings of the configuration's size in ONE scene (camIDs
+    and neighbour lists offset ring by ring, each ring its own seeded instance of the configuration: ring 0 is the
+    configuration itself), so that a contiguous, cost-balanced cut into n view ranges (l3d_plan_shards) gives every rank
+    one GPU's work.  n = 1: the configuration."""
+    from line3dpp_amd.scene import CONFIGS, Scene, make_config
+    if n == 1:
+        return make_config(config)
+    base = 0x4C334450 + list(CONFIGS).index(config)
+    views = []
+    for r in range(n):
+        sub = make_config(config, seed=base + 7919 * r) if config != "C0" else make_config(config)
+        off = len(views)
+        for v in sub.views:
+            v.cam += off
+            v.neighbors = [int(x) + off for x in v.neighbors]
+            views.append(v)
+    return Scene(views, f"{config}x{n}rings")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,16 +356,46 @@ def main():
     ap.add_argument("--parity-digest", action="store_true",
                     help="parity of the full scene against the stored reference record (tests/golden/full) instead of a live run")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-call / second-scene measurement")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = N rings of the configuration's size in one scene (per-GPU work fixed, default); "
+                         "strong = the same scene at every N")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="start the ranks as --gpus N would, over gloo on the CPU, report them and exit (no GPU work): the "
+                         "CPU test of the launcher")
     args = ap.parse_args()
 
+    # ---- one process per GPU.  Under torchrun / torch.distributed.run (WORLD_SIZE set) this process IS a rank; started
+    # plainly with --gpus N > 1 it starts the N ranks itself -- `python bench.py --gpus 8` must never run one rank and
+    # print "n_gpus": 1 (round 4 did) ----
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or under "
+                         f"torch.distributed.run with --nproc-per-node equal to --gpus")
+    import torch.distributed as dist
+    if args.launcher_selftest:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            seen = [None] * world
+            dist.all_gather_object(seen, rank)
+            n_backend, backend = dist.get_world_size(), dist.get_backend()
+            dist.destroy_process_group()
+        else:
+            seen, n_backend, backend = [0], 1, "none"
+        if rank == 0:
+            print(json.dumps({"launcher_selftest": True, "n_gpus": world, "ranks": sorted(seen),
+                              "ranks_reported_by_backend": n_backend, "backend": backend}))
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU, no oversubscription)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -308,7 +404,8 @@ def main():
     from line3dpp_amd.api import Line3D
     from line3dpp_amd.scene import CONFIGS, make_config, make_scene
 
-    scene = make_config(args.config)
+    weak = world > 1 and args.scaling == "weak"
+    scene = weak_scene(args.config, world) if weak else make_config(args.config)
     cfg = CONFIGS[args.config]
     pair_tests, pairs = scene.pair_tests()
     kNN = 10
@@ -322,7 +419,7 @@ def main():
         def step():
             ok = l3d_dist.match_images_sharded(ctx, rank, world, device=device, kNN=kNN)
             assert ok, "matchImages failed"
-            assert ctx.computeAffinity(), "affinity failed"
+            assert l3d_dist.compute_affinity_sharded(ctx, rank, world, device=device), "affinity failed"
         return step
 
     # ---- cold call: the FIRST matchImages + affinity of a fresh context (a user of Line3D::matchImages pays this once per
@@ -345,12 +442,12 @@ def main():
         step()
     kern_ms, kern_launches, phase = 0.0, 0, dict(begin=0.0, match=0.0, finish=0.0, affinity=0.0)
     lists_ms_sum, record_kbytes = 0.0, 0
-    # The timed steps record ONE pair of HIP events, the one around the dominant kernel (roofline.achieved is its live
-    # event time): an event between two kernels costs a ~6 us bubble on the stream, and a call has ten of them at the
-    # default level (l3d_set_timing_level).  The per-phase times come from separate steps, untimed, with all events on.
+    # The timed steps run the library AS SHIPPED: its default timing level (1 since round 5) records one pair of HIP events,
+    # the one around the dominant kernel (roofline.achieved is its live event time), which is all this loop reads.  An
+    # event between two kernels costs a ~6 us bubble on the stream and a call has ten of them at the profiling level
+    # (l3d_set_timing_level 2): the per-phase times come from separate steps, untimed, at that level.
     import ctypes as C
     from line3dpp_amd import _lib
-    l3d.setTimingLevel(1)
     tm_raw = _lib.Timings()
     barrier()
     t0 = time.perf_counter()
@@ -368,6 +465,7 @@ def main():
         phase["begin"] += tm["begin_ms"]; phase["match"] += tm["match_pairs_ms"]
         phase["finish"] += tm["finish_ms"]; phase["affinity"] += tm["affinity_ms"]
         lists_ms_sum += tm.get("lists_ms", 0.0); record_kbytes = tm.get("record_kbytes", 0)
+    l3d.setTimingLevel(1)
     barrier()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -488,17 +586,23 @@ def main():
     if rank == 0:
         out = {
             "metric": "M segment-pair scores/sec", "value": round(value, 2), "unit": "M segment-pair scores/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "n_gpus": world, "ranks_reported_by_backend": dist.get_world_size() if world > 1 else 1,
+            "backend": dist.get_backend() if world > 1 else "none",
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if args.config != "C0" else "reference testdata (recovered cameras)",
-            "config": {"workload": (f"{args.config}: synthetic {cfg['n_views']} views x {cfg['n_segs']} segments/view, "
+            "config": {"workload": ((f"{world} rings of " if weak else "") +
+                                    f"{args.config}: synthetic {cfg['n_views']} views x {cfg['n_segs']} segments/view, "
                                     if args.config != "C0" else
                                     "C0: the reference's bundled testdata (26 images, cameras recovered from its result "
                                     "fixture, the 406-919 LSD segments per view that occur in it), ") +
                                    f"{cfg['n_neighbors']} visual neighbours, kNN=10, sigma_p=2.5px, sigma_a=10deg, "
                                    f"epipolar_overlap=0.25; matchImages + affinity fill",
                        "pair_tests_per_step": pair_tests, "directed_pairs": len(pairs),
-                       "parallelism": f"pair-sharded x{world}" if world > 1 else "single GPU"},
+                       "views": scene.n_views,
+                       "parallelism": (f"views / pairs sharded x{world} (halo form, tail and affinity fill sharded by views; "
+                                       f"{'weak: one ring of the configuration per rank' if weak else 'strong: the same scene at every N'})")
+                                      if world > 1 else "single GPU"},
             "phase_ms": {k: round(v / phase_steps, 4) for k, v in phase.items()},
             "cold_ms": cold["cold_ms"] if cold else None, "second_scene_ms": cold.get("second_scene_ms") if cold else None,
             "cold": cold,
@@ -508,8 +612,14 @@ def main():
             out["phase_ms"]["lists_part_of_finish"] = round(lists_ms_sum / phase_steps, 4)
             out["phase_ms"]["measured_in"] = (f"{phase_steps} separate untimed steps with all ten HIP events of a call on "
                                               "(l3d_set_timing_level 2); the timed steps record only the pair around the match kernel")
+            # what the sharded tail / affinity fill exchange: the surviving matches (Match 40 B + two segment ids), the best
+            # hypotheses (HypRec 128 B + a depth pair), three per-segment words; one float per surviving match
+            n_surv = sum(int(l3d.matches(v.cam)[1][-1]) for v in scene.views)
+            n_best = len(l3d.best()[0])
             out["multi_gpu_model"] = multi_gpu_model(pairs, M, kNN, {k: v / phase_steps for k, v in phase.items()},
-                                                     lists_ms_sum / phase_steps, 1024.0 * record_kbytes)
+                                                     lists_ms_sum / phase_steps, 1024.0 * record_kbytes,
+                                                     tail_bytes=48.0 * n_surv + 136.0 * n_best + 12.0 * sum(M.values()),
+                                                     sim_bytes=4.0 * n_surv)
         if world > 1 and getattr(l3d, "dist_ms", None):
             # rank 0's host wall time between the synchronisation points of the sharded call, per call (all calls incl.
             # warm-up): this rank's pairs | index all-gather | expansion + this rank's share of the list pass | all-gather

@@ -248,6 +248,16 @@ int l3d_tail_shard_count(l3d_ctx*, uint32_t counts[2]);
 int l3d_tail_shard_layout(l3d_ctx*, uint32_t world, const uint32_t* counts_all, const uint32_t* view_bounds, void* base_ptr[9],
                           uint64_t elt_bytes[9], uint64_t* first, uint64_t* count);
 int l3d_tail_shard_commit(l3d_ctx*);
+/* The affinity fill of Line3D::reconstruct3Dlines (computingAffinityMatrix, line3D.cc:1852-1979) sharded by the same
+ * views, for a call that was closed by l3d_tail_shard_commit (the similarity of a candidate depends on its
+ * two hypotheses alone).  Instead of l3d_compute_affinity:
+ *   l3d_affinity_shard_begin   similarity (line3D.cc:1467-1553) of the surviving matches of this rank's views, written at
+ *                              their places in the full float array *simv; first[r] / count[r]: the elements of rank r
+ *   -- the caller exchanges the parts: rank r's part to every other rank, in place --
+ *   l3d_affinity_shard_finish  used_ / local ids / CLEdge pairs from all similarities (every rank: same A_ everywhere)
+ * Not with collinearity_t > 0 (line3D.cc:1904-1974 is sequential by definition): L3D_ERR_LIMIT, use l3d_compute_affinity. */
+int l3d_affinity_shard_begin(l3d_ctx*, uint32_t rank, uint32_t world, void** simv, uint64_t* first, uint64_t* count);
+int l3d_affinity_shard_finish(l3d_ctx*);
 /* Partition of a call over `world` ranks (host only; a function of the pair list of l3d_get_pairs): contiguous view
  * ranges whose outgoing pairs carry equal shares of the cost (pair_cost[p], e.g. Ms * Mt); pair_src_view[p] = index of
  * the pair's source view (the list is ordered by it).  view_bounds / pair_bounds receive world + 1 entries: rank r owns
@@ -348,11 +358,16 @@ typedef struct l3d_timings {
 } l3d_timings;
 int l3d_get_timings(l3d_ctx*, l3d_timings*);
 /* How many of the context's HIP events a call records (they feed l3d_timings; the reference has no such thing: its
- * timing is the wall clock of main_*.cpp).  2 (default): all ten -- every field above is filled; 1: only the pair around
- * the pair-matching kernel (match_kernel_ms; the other times read 0); 0: none.  An event between two kernels costs a
- * ~6 us bubble on the stream, which a 1.6 ms call notices: bench.py times its steps at level 1 and takes the phase
- * breakdown from separate steps at level 2. */
+ * timing is the wall clock of main_*.cpp).  1 (DEFAULT since round 5: the fast setting is what a drop-in user gets): only
+ * the pair around the pair-matching kernel (match_kernel_ms; the other times read 0); 2 (profiling, opt-in): all ten --
+ * every field above is filled; 0: none.  An event between two kernels costs a ~6 us bubble on the stream, which a
+ * 1.4 ms call notices: bench.py times the library as shipped (level 1) and takes the phase breakdown from separate
+ * untimed steps at level 2. */
 int l3d_set_timing_level(l3d_ctx*, int level);
+/* Test hook (no reference counterpart): process-wide counters that tell a test which form of a kernel ran.
+ * "csr_global_launches": launches of the global-cursor form of k_pair_csr (views beyond 32 768 segments, or
+ * L3D_CSR_GLOBAL=1).  Unknown name: ~0. */
+unsigned long long l3d_debug_counter(const char* name);
 
 /* ---- (2) seam layer ------------------------------------------------------------------ */
 

@@ -67,7 +67,7 @@ EXPORTS = [
     "l3d_nvm_intrinsics", "l3d_segment_cache_name", "l3d_read_segment_cache", "l3d_write_segment_cache",
     "l3d_trim_cache", "l3d_set_timing_level", "l3d_tail_shard_count", "l3d_tail_shard_layout", "l3d_tail_shard_commit",
     "l3d_sfm_open_colmap", "l3d_sfm_open_bundler", "l3d_sfm_num_images", "l3d_sfm_get_image", "l3d_sfm_get_worldpoints",
-    "l3d_sfm_close",
+    "l3d_sfm_close", "l3d_debug_counter", "l3d_affinity_shard_begin", "l3d_affinity_shard_finish",
 ]
 
 _lib = None
@@ -131,9 +131,13 @@ def load():
     L.l3d_get_sparse_matrix.argtypes = [vp, i32, vp, vp]
     L.l3d_get_timings.argtypes = [vp, C.POINTER(Timings)]
     L.l3d_set_timing_level.argtypes = [vp, C.c_int]
+    L.l3d_debug_counter.argtypes = [C.c_char_p]
+    L.l3d_debug_counter.restype = C.c_ulonglong
     L.l3d_tail_shard_count.argtypes = [vp, vp]
     L.l3d_tail_shard_layout.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     L.l3d_tail_shard_commit.argtypes = [vp]
+    L.l3d_affinity_shard_begin.argtypes = [vp, u32, u32, vp, vp, vp]
+    L.l3d_affinity_shard_finish.argtypes = [vp]
     L.l3d_match_lines.argtypes = [i32, vp, u32, vp, u32, vp, vp, vp, vp, vp, u32, u32, f32, C.c_int32, vp,
                                   C.POINTER(u64)]
     L.l3d_set_brute_force.argtypes = [vp, i32]

@@ -163,6 +163,19 @@ class Line3D:
     def computeAffinity(self):
         return self._check(self.L.l3d_compute_affinity(self.h), "computeAffinity")
 
+    def affinityShardBegin(self, rank, world):
+        """l3d_affinity_shard_begin -> (device pointer of the similarity array, 4, [(first, count) per rank]) in the form
+        dist.exchange_parts takes, or None (not after a sharded tail / collinearity links asked for / an error)"""
+        p = C.c_void_p(); first = (C.c_uint64 * world)(); count = (C.c_uint64 * world)()
+        rc = self.L.l3d_affinity_shard_begin(self.h, int(rank), int(world), C.byref(p), first, count)
+        self.last_status = rc
+        if rc != 0:
+            return None
+        return (p.value, 4, [(int(first[r]), int(count[r])) for r in range(world)])
+
+    def affinityShardFinish(self):
+        return self._check(self.L.l3d_affinity_shard_finish(self.h), "affinityShardFinish")
+
     # Line3D::reconstruct3Dlines, line3D.h:162-166 (defaults commons.h:63-70)
     def reconstruct3Dlines(self, visibility_t=L3D_DEF_MIN_VISIBILITY_T, perform_diffusion=False, collinearity_t=-1.0,
                            use_CERES=False, max_iter_CERES=250):
@@ -311,7 +324,7 @@ class Line3D:
         return ent[:ne.value], start[:nr.value]
 
     def setTimingLevel(self, level):
-        """l3d_set_timing_level: 2 = every phase timed with HIP events (default), 1 = the match kernel only, 0 = none"""
+        """l3d_set_timing_level: 1 = the match kernel only (default), 2 = every phase timed with HIP events (profiling), 0 = none"""
         return self._check(self.L.l3d_set_timing_level(self.h, int(level)), "setTimingLevel")
 
     def timings(self):

@@ -62,7 +62,11 @@ __device__ __forceinline__ float sim_affinity(const HypRec& h1, const HypRec& h2
 }  // namespace
 
 // candidate c = surviving match c of the global pool (views ascending, segments ascending, list order)
-__global__ void k_aff_sim(uint32_t N, const uint32_t* __restrict__ surv_sg, const uint32_t* __restrict__ surv_tg,
+// [lo, hi): the candidates whose similarity THIS launch computes -- all of them on one GPU; with the affinity fill
+// sharded by views (l3d_affinity_shard_begin) the surviving matches of this rank's views, the other ranks' values arriving
+// by exchange.  The two hypothesis ids of a candidate are two table look-ups and are written for all N everywhere.
+__global__ void k_aff_sim(uint32_t N, uint32_t lo, uint32_t hi, const uint32_t* __restrict__ surv_sg,
+                          const uint32_t* __restrict__ surv_tg,
                           const int32_t* __restrict__ hyp_of_seg, const HypRec* __restrict__ hyps,
                           const ViewAff* __restrict__ va, const float* __restrict__ medians,
                           const float* __restrict__ msdl_ptr, float two_sigA_sqr, float* __restrict__ simv,
@@ -70,14 +74,15 @@ __global__ void k_aff_sim(uint32_t N, const uint32_t* __restrict__ surv_sg, cons
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= N) return;
     const int32_t ha = hyp_of_seg[surv_sg[c]], hb = hyp_of_seg[surv_tg[c]];
+    cand_a[c] = ha;
+    cand_b[c] = hb;
+    if (c < lo || c >= hi) return;
     float sim = 0.0f;
     if (ha >= 0 && hb >= 0) {
         const uint32_t v1 = hyps[ha].view, v2 = hyps[hb].view;
         sim = sim_affinity(hyps[ha], hyps[hb], va[v1].k, medians[v1], va[v2].k, medians[v2], *msdl_ptr, two_sigA_sqr);
     }
     simv[c] = sim;
-    cand_a[c] = ha;
-    cand_b[c] = hb;
 }
 
 __global__ void k_aff_flag(uint32_t N, const uint32_t* __restrict__ surv_off, const uint32_t* __restrict__ surv_sg,
@@ -252,11 +257,11 @@ __global__ void k_aff_coll_sim(uint32_t n_items, const uint32_t* __restrict__ su
 // ---- launchers ---------------------------------------------------------------------------------
 static inline dim3 grid1(uint32_t n, uint32_t b = 256) { return dim3((n + b - 1) / b); }
 
-hipError_t launch_aff_sim(uint32_t N, const uint32_t* surv_sg, const uint32_t* surv_tg, const int32_t* hyp_of_seg,
+hipError_t launch_aff_sim(uint32_t N, uint32_t lo, uint32_t hi, const uint32_t* surv_sg, const uint32_t* surv_tg, const int32_t* hyp_of_seg,
                           const HypRec* hyps, const ViewAff* va, const float* medians, const float* msdl,
                           float two_sigA_sqr, float* simv, int32_t* ca, int32_t* cb, hipStream_t st) {
     if (!N) return hipSuccess;
-    hipLaunchKernelGGL(k_aff_sim, grid1(N, 128), dim3(128), 0, st, N, surv_sg, surv_tg, hyp_of_seg, hyps, va, medians,
+    hipLaunchKernelGGL(k_aff_sim, grid1(N, 128), dim3(128), 0, st, N, lo, hi, surv_sg, surv_tg, hyp_of_seg, hyps, va, medians,
                        msdl, two_sigA_sqr, simv, ca, cb);
     return hipGetLastError();
 }

@@ -1186,23 +1186,36 @@ __global__ void k_seg_write(uint32_t g0, uint32_t g1, unsigned long long base64,
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------------
+std::atomic<uint64_t> g_csr_global_launches{0};   // test hook (l3d_debug_counter): launches of the global-cursor k_pair_csr<false>
+
 hipError_t launch_pair_csr(const PairDesc* pairs, uint32_t n_pairs, uint32_t max_Mt, const PairCsr* pair_poff,
                            const uint32_t* inv_tgt, uint32_t tgt16, uint32_t* poff, uint32_t* refs, uint32_t* dummy,
                            uint32_t tgt_v0, uint32_t tgt_v1, hipStream_t st) {
     if (!n_pairs) return hipSuccess;
-    // (L3D_CSR_GLOBAL=1, test hook: every pair takes the global-memory form that views beyond the LDS capacity need)
-    static const bool force_global = std::getenv("L3D_CSR_GLOBAL") != nullptr;
+    // (L3D_CSR_GLOBAL=1, test hook: every pair takes the global-memory form that views beyond the LDS capacity need.  Read
+    // PER CALL, as lists_run reads it when it sizes `dummy`: a process-wide static here was latched by whichever test ran
+    // first, and the hook then tested nothing -- ADVICE round 4.  g_csr_global_launches lets the test see that the form ran.)
+    const bool force_global = std::getenv("L3D_CSR_GLOBAL") != nullptr;
     const uint32_t lds_segs = force_global ? 0u : kCsrLdsSegs;
     const size_t lds = ((size_t)std::min(max_Mt, lds_segs) + 64) * 4;
+    // the dynamic-LDS attribute is process-global state of the function: set ONCE to the largest size any launch asks for
+    // (contexts on different threads would otherwise race with different sizes)
+    static const hipError_t attr_rc = [] {
+        const int mx = (int)(((size_t)kCsrLdsSegs + 64) * 4);
+        hipError_t e = hipFuncSetAttribute((const void*)k_pair_csr<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_pair_csr<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        return e;
+    }();
+    if (attr_rc != hipSuccess) return attr_rc;
 #define L3D_CSR(T16)                                                                                                      \
     do {                                                                                                                  \
-        hipError_t e = hipFuncSetAttribute((const void*)k_pair_csr<true, T16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e != hipSuccess) return e;                                                                                    \
         hipLaunchKernelGGL((k_pair_csr<true, T16>), dim3(n_pairs), dim3(kCsrBlock), lds, st, pairs, 0u, pair_poff, inv_tgt, \
                            poff, refs, dummy, tgt_v0, tgt_v1, lds_segs);                                                  \
-        if (max_Mt > lds_segs)   /* views beyond the LDS capacity: cursors in global memory (dummy: 64 words per pair) */ \
+        if (max_Mt > lds_segs) { /* views beyond the LDS capacity: cursors in global memory (dummy: 64 words per pair) */ \
             hipLaunchKernelGGL((k_pair_csr<false, T16>), dim3(n_pairs), dim3(kCsrBlock), 0, st, pairs, 0u, pair_poff, inv_tgt, \
                                poff, refs, dummy, tgt_v0, tgt_v1, lds_segs);                                              \
+            g_csr_global_launches.fetch_add(1, std::memory_order_relaxed);                                                \
+        }                                                                                                                 \
     } while (0)
     if (tgt16) L3D_CSR(true); else L3D_CSR(false);
 #undef L3D_CSR

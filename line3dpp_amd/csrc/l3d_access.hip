@@ -145,6 +145,13 @@ int l3d_get_sparse_matrix(l3d_ctx* c, int sort_by_row, l3d_float4* entries, int3
     return L3D_OK;
 }
 
+// test hook: process-wide counters that let a test see WHICH form of a kernel ran (the global-cursor form
+// of k_pair_csr was selected by an environment variable that had been latched before the test set it)
+unsigned long long l3d_debug_counter(const char* name) {
+    if (name && std::string(name) == "csr_global_launches") return g_csr_global_launches.load(std::memory_order_relaxed);
+    return ~0ull;
+}
+
 int l3d_set_timing_level(l3d_ctx* c, int level) {
     if (!c || level < 0 || level > 2) return fail(L3D_ERR_ARG, "l3d_set_timing_level: level 0, 1 or 2");
     std::lock_guard<std::recursive_mutex> lk(c->mu);

@@ -120,14 +120,18 @@ static int affinity_collinear(l3d_ctx* c) {
     return L3D_OK;
 }
 
-// med_scene_depth_lines_ + computingAffinityMatrix (line3D.cc:1759-1778) in the CURRENT (translated) frame
-int affinity_core(l3d_ctx* c) {
+// med_scene_depth_lines_ + computingAffinityMatrix (line3D.cc:1759-1778) in the CURRENT (translated) frame, in three
+// pieces so that the similarity pass -- the arithmetic of the step -- can be sharded by views over the ranks of a
+// multi-GPU run (l3d_affinity_shard_begin / _finish below; SURVEY.md 8e "Affinity"):
+//   affinity_prepare   med_scene_depth_lines_, the per-view table, the buffers
+//   affinity_sim       similarity of the candidates [lo, hi) (all of them on one GPU)
+//   affinity_rest      used_ / local ids / CLEdge pairs from the similarities of ALL candidates, the one read-back
+static int affinity_prepare(l3d_ctx* c) {
     (void)hipSetDevice(c->device);
     hipStream_t st = c->stream;
     const uint32_t V = (uint32_t)c->order.size();
     c->edges.clear(); c->l2g.clear();
     c->aff_n_edges = 0; c->aff_n_rows = 0; c->aff_host_valid = true;
-    bool counts_pending = false;
     // med_scene_depth_lines_, line3D.cc:1759-1774
     std::vector<float> sd;
     for (auto* v : c->order) if (v->median_depth > kEps) sd.push_back(v->median_depth);
@@ -148,9 +152,24 @@ int affinity_core(l3d_ctx* c) {
         L3D_HIP_CHECK(c->d_first_touch.reserve(H));
         L3D_HIP_CHECK(c->d_scan_ws.reserve_zeroed(scan_ws_words(2 * (size_t)N, 4), st));
         L3D_HIP_CHECK(upload_table(c->d_vaff, c->h_vaff, va.data(), ((size_t)V + 1) * sizeof(ViewAff), c->up_vaff, st));
-        L3D_HIP_CHECK(launch_aff_sim(N, c->d_surv_sg.p, c->d_surv_tg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_vaff.p,
-                                     (c->d_med + 8), (const float*)(c->d_vaff.p + V), c->two_sigA_sqr, c->d_simv.p, c->d_ca.p, c->d_cb.p,
-                                     st));
+    }
+    return L3D_OK;
+}
+
+static int affinity_sim(l3d_ctx* c, uint32_t lo, uint32_t hi) {
+    const uint32_t V = (uint32_t)c->order.size(), N = c->n_surv, H = c->n_hyps;
+    if (!(N > 0 && H > 0)) return L3D_OK;
+    L3D_HIP_CHECK(launch_aff_sim(N, lo, hi, c->d_surv_sg.p, c->d_surv_tg.p, c->d_hyp_of_seg.p, c->d_hyps.p, c->d_vaff.p,
+                                 (c->d_med + 8), (const float*)(c->d_vaff.p + V), c->two_sigA_sqr, c->d_simv.p, c->d_ca.p, c->d_cb.p,
+                                 c->stream));
+    return L3D_OK;
+}
+
+static int affinity_rest(l3d_ctx* c) {
+    hipStream_t st = c->stream;
+    const uint32_t N = c->n_surv, H = c->n_hyps;
+    bool counts_pending = false;
+    if (N > 0 && H > 0) {
         if (c->collinearity_t > (float)kEps) {
             const int rc = affinity_collinear(c);
             if (rc) return rc;
@@ -191,6 +210,13 @@ int affinity_core(l3d_ctx* c) {
     return L3D_OK;
 }
 
+int affinity_core(l3d_ctx* c) {
+    int rc = affinity_prepare(c);
+    if (rc == L3D_OK) rc = affinity_sim(c, 0u, c->n_surv);
+    if (rc == L3D_OK) rc = affinity_rest(c);
+    return rc;
+}
+
 // host copies of A_ / local2global_ (fetched on first use)
 int ensure_affinity_host(l3d_ctx* c) {
     if (c->aff_host_valid) return L3D_OK;
@@ -220,6 +246,42 @@ int l3d_compute_affinity(l3d_ctx* c) {
     // read; they are applied to keep the host state identical to the reference's.
     translate(*c);
     const int rc = affinity_core(c);
+    untranslate(*c);
+    return rc;
+}
+
+// ---- the affinity fill sharded by views (N > 1 ranks; SURVEY.md 8e "Affinity": independent per hypothesis) ----------------
+// After a call closed by l3d_tail_shard_commit every rank knows where every rank's views' surviving matches lie in the
+// (replicated) arrays: tail_base_n.  The similarity of a candidate (line3D.cc:1467-1553: the fp64 acos / exp arithmetic
+// of the step) is computed by the rank that owns the candidate's source view; the float values are exchanged in place
+// (the caller: line3dpp_amd/dist.py compute_affinity_sharded), and the bookkeeping that follows (used_, local ids,
+// CLEdge pairs: a few small passes over flags) runs on every rank, so every rank ends with the same A_.
+int l3d_affinity_shard_begin(l3d_ctx* c, uint32_t rank, uint32_t world, void** simv, uint64_t* first, uint64_t* count) {
+    if (!c || !simv || !first || !count) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (c->state != l3d_ctx::MATCHED) return fail(L3D_ERR_STATE, "matchImages must precede the affinity step");
+    if (world < 2 || rank >= world || c->aff_parts_world != world || c->tail_base_n.size() != (size_t)world + 1 ||
+        c->tail_base_n[world] != c->n_surv)
+        return fail(L3D_ERR_STATE, "l3d_affinity_shard_begin follows a call closed by l3d_tail_shard_commit with the same world size");
+    if (c->collinearity_t > (float)kEps)
+        return fail(L3D_ERR_LIMIT, "the links to collinear segments are sequential by definition (line3D.cc:1904-1974): use l3d_compute_affinity");
+    translate(*c);
+    int rc = affinity_prepare(c);
+    if (rc == L3D_OK) rc = affinity_sim(c, c->tail_base_n[rank], c->tail_base_n[rank + 1]);
+    if (rc != L3D_OK) { untranslate(*c); return rc; }
+    *simv = c->d_simv.p;
+    for (uint32_t r = 0; r < world; ++r) { first[r] = c->tail_base_n[r]; count[r] = c->tail_base_n[r + 1] - c->tail_base_n[r]; }
+    c->aff_shard_open = true;
+    return L3D_OK;
+}
+
+int l3d_affinity_shard_finish(l3d_ctx* c) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (c->state != l3d_ctx::MATCHED || !c->aff_shard_open)
+        return fail(L3D_ERR_STATE, "l3d_affinity_shard_finish follows l3d_affinity_shard_begin and the exchange of the similarities");
+    c->aff_shard_open = false;
+    const int rc = affinity_rest(c);
     untranslate(*c);
     return rc;
 }

@@ -344,7 +344,9 @@ l3d_ctx* l3d_create(int device, void* stream) {
     static std::mutex warm_mu;
     static std::set<int> warmed;
     bool need_warm = !std::getenv("L3D_NO_WARMUP");
-    if (need_warm) { std::lock_guard<std::mutex> lk(warm_mu); need_warm = warmed.insert(device).second; }
+    // (`warmed` holds a device only once its warm-up has SUCCEEDED -- ADVICE round 4: after a transient failure every later
+    // context would have skipped it; two contexts created concurrently may both warm up, which is harmless)
+    if (need_warm) { std::lock_guard<std::mutex> lk(warm_mu); need_warm = warmed.count(device) == 0; }
     if (need_warm) {
         hipStream_t st = c->stream;
         DevBuf<uint32_t> d; PinnedBuf<uint32_t> h;
@@ -375,9 +377,13 @@ l3d_ctx* l3d_create(int device, void* stream) {
             }
         ok = ok && warm_match(st) == hipSuccess && warm_lists(st) == hipSuccess && warm_scan(st) == hipSuccess &&
              warm_views(st) == hipSuccess && warm_affinity(st) == hipSuccess && warm_rdd(st) == hipSuccess;
-        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        // (waited for UNCONDITIONALLY: on a failure the short-circuit above would have skipped it, and the blocks below are
+        // handed to the cache as "drained")
+        const bool drained_ok = hipStreamSynchronize(st) == hipSuccess;
+        ok = ok && drained_ok;
         { const ReleaseSynced drained; d.release(); h.release(); }
         if (!ok) { set_error("start-up launches failed: no usable HIP device"); l3d_destroy(c); return nullptr; }
+        { std::lock_guard<std::mutex> lk(warm_mu); warmed.insert(device); }
     }
     return c;
 }
@@ -544,6 +550,9 @@ int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
         c->med_scene_depth = c->views_avg_depths[c->views_avg_depths.size() / 2];
     }
     c->state = l3d_ctx::IDLE;
+    // (a sharded affinity fill left open -- begin without finish -- holds the views translated: closed here)
+    if (c->aff_shard_open) { untranslate(*c); c->aff_shard_open = false; }
+    c->aff_parts_world = 0;
     translate(*c);
     const int rc = match_begin_body(c);
     if (rc != L3D_OK) {

@@ -56,7 +56,7 @@ hipError_t launch_score_all(uint32_t g0, uint32_t G, const uint32_t* off, const 
 hipError_t launch_median_all(uint32_t V, const float* depths, const uint32_t* hyp_off, const uint32_t* seg_base,
                              const uint32_t* tie_total, uint32_t* tie_out, float* out, const uint32_t* rb_src,
                              uint32_t* rb_host, uint32_t rb_words, uint32_t* rb_count, hipStream_t, uint32_t v0 = 0);
-hipError_t launch_aff_sim(uint32_t N, const uint32_t* surv_sg, const uint32_t* surv_tg, const int32_t* hyp_of_seg,
+hipError_t launch_aff_sim(uint32_t N, uint32_t lo, uint32_t hi, const uint32_t* surv_sg, const uint32_t* surv_tg, const int32_t* hyp_of_seg,
                           const HypRec*, const ViewAff*, const float* medians, const float* msdl, float two_sigA_sqr,
                           float* simv, int32_t* ca, int32_t* cb, hipStream_t);
 hipError_t launch_aff_flag(uint32_t N, const uint32_t* surv_off, const uint32_t* surv_sg, const uint32_t* surv_tg,
@@ -237,6 +237,8 @@ struct l3d_ctx {
     // sharded tail (l3d_tail_shard_*): counts of all ranks -> where every rank's outputs start in the full arrays
     std::vector<uint32_t> tail_base_n, tail_base_h;
     bool tail_counted = false, tail_written = false;
+    uint32_t aff_parts_world = 0;                    // world size of the last call closed by l3d_tail_shard_commit (tail_base_n valid), else 0
+    bool aff_shard_open = false;                    // between l3d_affinity_shard_begin and _finish (views translated)
     bool lists_ready = false, lists_prepared = false;   // per-pool capacities (grow on overflow, kept across calls)
     PinnedBuf<uint32_t> h_fin;
     PinnedBuf<char> h_ltab;
@@ -256,10 +258,11 @@ struct l3d_ctx {
     std::vector<ReconLine> lines3D;                 // lines3D_ (original frame)
     bool lines_done = false;
     // timings.  Every hipEventRecord between two kernels costs a ~6 us bubble on the stream (rocprofv3 kernel trace of C1:
-    // gaps exactly where the ten events of a call sit, none between other back-to-back kernels): timing_level 2 (default)
-    // records all of them, 1 only the pair around the match kernel (ev[4], ev[5]), 0 none (l3d_set_timing_level)
+    // gaps exactly where the ten events of a call sit, none between other back-to-back kernels): timing_level 2 records
+    // all of them (profiling, opt-in), 1 -- THE DEFAULT since round 5: what a facade user of matchImages gets is the fast
+    // setting -- only the pair around the match kernel (ev[4], ev[5]), 0 none (l3d_set_timing_level)
     hipEvent_t ev[10] = {};
-    int timing_level = 2;
+    int timing_level = 1;
     bool ev_on(int k) const { return timing_level >= 2 || (timing_level == 1 && (k == 4 || k == 5)); }
     l3d_timings tm{};
 };

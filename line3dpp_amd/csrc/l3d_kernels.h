@@ -1,10 +1,14 @@
 // l3d_kernels.h -- launch prototypes shared by the .hip translation units of libl3dpp_hip.so
 #pragma once
+#include <atomic>
+
 #include "l3d_dev.h"
 
 struct l3d_cledge;
 
 namespace l3d {
+
+extern std::atomic<uint64_t> g_csr_global_launches;   // k_lists.hip, test hook read through l3d_debug_counter
 
 constexpr int kMatchRows = 64;   // source rows per work item of k_match_pairs (one wave64)
 struct WorkItem {

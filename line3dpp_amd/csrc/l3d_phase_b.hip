@@ -719,7 +719,9 @@ int l3d_tail_shard_commit(l3d_ctx* c) {
         L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
         med[2] = c->tail_base_n[world]; med[3] = c->tail_base_h[world];
         c->tail_counted = false; c->tail_written = false;
-        return finish_commit(c);
+        const int fr = finish_commit(c);
+        if (fr == L3D_OK) c->aff_parts_world = world;   // tail_base_n: where every rank's surviving matches lie (l3d_affinity_shard_begin)
+        return fr;
     }();
     return close_failed_call(c, rc);
 }

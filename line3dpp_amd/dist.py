@@ -97,18 +97,20 @@ def device_tensor(ptr, nbytes, device):
     return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
 
 
-def _wait_for_exchange(buf, device, l3d=None):
+def _wait_for_exchange(buf, device, l3d=None, group=None):
     """The collective runs on the backend's own stream; the library's stream must not touch `buf` before it is done.
     torch's NCCL (= RCCL) backend orders that by itself when the library launches on torch's CURRENT stream: a collective
     starts after what that stream holds at the call, and Work.wait() (called by the synchronous collectives and by the
     loops over batch_isend_irecv here) makes that stream -- not the host -- wait for it.  line3dpp_amd.Line3D runs on the
     stream it was created with (default 0 = torch's default stream), so in the usual set-up nothing is left to do and
     the host goes on enqueuing (round 3 synchronised the device at every phase boundary: five host round trips per
-    call).  Only a context on ANOTHER stream needs the device-wide wait."""
+    call).  Only a context on ANOTHER stream needs the device-wide wait -- and any backend other than NCCL / RCCL, whose
+    Work.wait() promises nothing about streams: the shortcut is taken for backend "nccl" only."""
     if buf.is_cuda:
         import torch
+        import torch.distributed as dist
         same = l3d is not None and int(getattr(l3d, "stream", -1)) == int(torch.cuda.current_stream(device).cuda_stream)
-        if not same:
+        if not (same and dist.get_backend(group) == "nccl"):
             torch.cuda.synchronize(device)
 
 
@@ -163,7 +165,7 @@ def gather_slabs(slabs, rank, world_size, device, group=None, l3d=None):
         for r in dist.batch_isend_irecv(ops):
             r.wait()
     if slabs:
-        _wait_for_exchange(device_tensor(slabs[0][2], 1, device), device, l3d)
+        _wait_for_exchange(device_tensor(slabs[0][2], 1, device), device, l3d, group)
 
 
 def exchange_parts(layout, rank, world_size, device, group=None, l3d=None):
@@ -193,7 +195,7 @@ def exchange_parts(layout, rank, world_size, device, group=None, l3d=None):
     if recvs or sends:
         for r in dist.batch_isend_irecv(recvs + sends):
             r.wait()
-        _wait_for_exchange(last, device, l3d)
+        _wait_for_exchange(last, device, l3d, group)
 
 
 def _gather_counts(n_r, h_r, world_size, device, group):
@@ -300,10 +302,14 @@ def match_images_halo(l3d, rank, world_size, device=None, group=None, **params):
     # ---- the halo: compact indices of whole pair runs, point to point, at the pairs' own places in the index buffer ----
     reqs = []
     buf = None
+    # (the index buffer is asked for on EVERY rank of a call that exchanges anything -- whether a rank has halo pairs is a
+    # function of the plan, identical everywhere -- so that a failing allocation, the one failure that cannot be carried
+    # through the exchange, takes all ranks out together instead of leaving the peers inside batch_isend_irecv for ever)
+    if any(runs):
+        ptr, n_slots = l3d.slot_index_buffer() if ok else (None, 0)
+        if not _all_ok(ptr is not None, device, group):
+            return give_up()
     if send or recv:
-        ptr, n_slots = l3d.slot_index_buffer()
-        if ptr is None:                # no buffer to exchange through: the one failure that cannot be carried along
-            raise RuntimeError("match_images_halo: the slot index buffer could not be allocated: " + str(getattr(l3d, "last_status", "")))
         buf = device_tensor(ptr, n_slots * 4, device)
         off = [int(o) for o in slot_off] + [int(n_slots)]
 
@@ -322,7 +328,7 @@ def match_images_halo(l3d, rank, world_size, device=None, group=None, **params):
     for r in reqs:
         r.wait()
     if reqs:
-        _wait_for_exchange(buf, device, l3d)
+        _wait_for_exchange(buf, device, l3d, group)
     lap("exchange_slots")
     for _, f, n in recv:
         ok = ok and l3d.expandSlotIndices(f, n)
@@ -430,7 +436,7 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_l
         if n_slots:
             buf = device_tensor(ptr, n_slots * 4, device)
             exchange_slots(buf, slot_byte_ranges(ranges, slot_off, n_slots, slot_bytes=4), group)
-            _wait_for_exchange(buf, device, l3d)
+            _wait_for_exchange(buf, device, l3d, group)
         lap("exchange_slots")
         ok = (first == 0 or l3d.expandSlotIndices(0, first)) and \
              (first + count == n_pairs or l3d.expandSlotIndices(first + count, n_pairs - first - count))
@@ -442,7 +448,7 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_l
         if n_slots:
             buf = device_tensor(ptr, n_slots * 32, device)
             exchange_slots(buf, slot_byte_ranges(ranges, slot_off, n_slots), group)
-            _wait_for_exchange(buf, device, l3d)
+            _wait_for_exchange(buf, device, l3d, group)
         lap("exchange_slots")
         # every pair is now present on this rank
         l3d.L.l3d_slots_exchanged(l3d.h)
@@ -469,3 +475,21 @@ def match_images_sharded(l3d, rank, world_size, device=None, group=None, shard_l
     ok = l3d.matchFinish()                 # a failing matchFinish restores the context itself
     lap("finish")
     return ok
+
+
+def compute_affinity_sharded(l3d, rank, world_size, device=None, group=None):
+    """The affinity fill (Line3D.computeAffinity) over `world_size` ranks: after a matchImages whose tail was sharded by
+    views (match_images_halo), every rank computes the similarities of its views' surviving matches
+    (l3d_affinity_shard_begin), the float values are exchanged in place (one send and one receive per peer, like the
+    tail's parts) and the bookkeeping runs on every rank (l3d_affinity_shard_finish): same A_ everywhere.  Falls back to
+    the replicated computeAffinity on ALL ranks together when any rank cannot shard (tail not sharded, collinearity
+    links, a local failure of begin): the ranks agree through one status exchange, so none is left inside the exchange."""
+    if world_size == 1 or os.environ.get("L3D_SHARD_AFFINITY", "1") == "0" or not hasattr(l3d, "affinityShardBegin"):
+        return l3d.computeAffinity()
+    part = l3d.affinityShardBegin(rank, world_size)
+    if not _all_ok(part is not None, device, group):
+        if part is not None and not l3d.affinityShardFinish():     # (closes the open shard: its similarities are complete
+            return False                                             # only for this rank's views, the result is discarded)
+        return l3d.computeAffinity()
+    exchange_parts([part], rank, world_size, device, group, l3d)
+    return l3d.affinityShardFinish()

@@ -414,6 +414,47 @@ class _HaloReplayContext(_ReplayContext):
         return 0
 
 
+def _aff_methods():
+    """the sharded affinity fill (l3d_affinity_shard_begin / _finish) on the replay context: a float array whose parts
+    have rank-dependent sizes (one rank's is empty), each carrying a signature that finish checks for ALL ranks; only after
+    a sharded tail (as the library: the parts are the tail's), else None -> every rank falls back to computeAffinity"""
+    def counts(self, r):
+        return 0 if r == self.world - 1 and self.world > 2 else 7 + 2 * r
+
+    def sig(self, r, n):
+        import hashlib
+        d = hashlib.sha256(f"aff:{r}".encode()).digest()
+        return np.frombuffer((d * (4 * n // len(d) + 1))[:4 * n], np.uint8)
+
+    def begin(self, rank, world):
+        assert (rank, world) == (self.rank, self.world) and self.state == "matched"
+        if "tail_count" not in self.log:
+            self.last_status = -3
+            return None
+        base = np.concatenate([[0], np.cumsum([counts(self, r) for r in range(world)])])
+        self.aff = np.full(4 * max(int(base[-1]), 1), 0xEE, np.uint8)
+        self.aff_parts = [(int(base[r]), counts(self, r)) for r in range(world)]
+        f, n = self.aff_parts[rank]
+        self.aff[4 * f:4 * (f + n)] = sig(self, rank, n)
+        self.log.append("aff_begin")
+        return (self.aff, 4, list(self.aff_parts))
+
+    def finish(self):
+        for r, (f, n) in enumerate(self.aff_parts):
+            if not np.array_equal(self.aff[4 * f:4 * (f + n)], sig(self, r, n)):
+                return False                      # a part that did not arrive
+        self.log.append("aff_finish")
+        return True
+
+    def whole(self):
+        self.log.append("affinity")
+        return True
+    return begin, finish, whole
+
+
+_HaloReplayContext.affinityShardBegin, _HaloReplayContext.affinityShardFinish, _HaloReplayContext.computeAffinity = _aff_methods()
+
+
 def _halo_worker(rank, world, port, q, shard_tail=True):
     sys.path.insert(0, ROOT)
     from line3dpp_amd import dist
@@ -428,13 +469,17 @@ def _halo_worker(rank, world, port, q, shard_tail=True):
         dist.device_tensor = lambda arr, nbytes, device: torch.from_numpy(arr.view(np.uint8))[:nbytes]
         try:
             ok = dist.match_images_sharded(ctx, rank, world, device=None, kNN=5)
+            # the affinity fill sharded by the same views (every rank's similarities arrive everywhere), or -- the tail was
+            # not sharded -- the replicated fill on every rank, decided together
+            ok = ok and dist.compute_affinity_sharded(ctx, rank, world, device=None)
         finally:
             dist.device_tensor = real
         plan = ctx.halo_plan
         pb, vb, runs = plan["pair_bounds"], plan["view_bounds"], plan["runs"]
         mine = set(range(int(pb[rank]), int(pb[rank + 1])))
         incoming = {p for r in range(world) for (qq, f, n) in runs[r] if qq == rank for p in range(f, f + n)}
-        ok = bool(ok) and ctx.log == (["begin", "retry", "tail_count", "tail_layout", "finish"] if shard_tail else ["begin", "retry", "finish"])
+        ok = bool(ok) and ctx.log == (["begin", "retry", "tail_count", "tail_layout", "finish", "aff_begin", "aff_finish"] if shard_tail
+                                      else ["begin", "retry", "finish", "affinity"])
         ok = ok and set(ctx.own) == mine                                   # a rank matches exactly the pairs it owns
         ok = ok and set(np.nonzero(ctx.present)[0].tolist()) == mine | incoming   # and holds those plus its halo, nothing else
         ok = ok and ctx.ranges_seen == (int(vb[rank]), int(vb[rank + 1]))

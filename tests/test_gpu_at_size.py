@@ -129,6 +129,7 @@ def test_keep_all_mode_at_c1_size_through_the_culled_walk(monkeypatch):
             monkeypatch.delenv("L3D_KEEPALL_NO_CULL", raising=False)
         g = Line3D()
         g.add_scene(sc)
+        assert g.setTimingLevel(2)                             # cull_prepare_ms is a profiling-level time
         n_pairs = None
         for rep in range(2):                                   # second call: warm pools, the time that counts
             assert g.matchBegin(kNN=0)

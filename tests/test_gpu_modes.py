@@ -260,9 +260,15 @@ def test_inverse_hypotheses_sorted_with_global_cursors_equal_the_lds_form(monkey
     hook L3D_CSR_GLOBAL=1 sends every pair through that second form: same result as the reference's own code, on a scene
     with ragged views and long lists (more neighbours than usual)."""
     sc = make_scene(9, 420, n_neighbors=6, seed=31)
+    from line3dpp_amd import _lib
+    L = _lib.load()
     monkeypatch.setenv("L3D_CSR_GLOBAL", "1")
+    before = L.l3d_debug_counter(b"csr_global_launches")
     g = _gpu(sc)
     assert g.matchImages() and g.computeAffinity()
+    # the hook is read per call (round 4 latched it at the first launch of the process and this test then ran the LDS form):
+    # the global-cursor form must actually have been launched
+    assert L.l3d_debug_counter(b"csr_global_launches") > before
     r = _assert_same(g, _ref(sc, [{}]), sc)
     assert r["surviving"] > 1000
 
