@@ -467,6 +467,9 @@ def main():
         lists_ms_sum += tm.get("lists_ms", 0.0); record_kbytes = tm.get("record_kbytes", 0)
     l3d.setTimingLevel(1)
     barrier()
+    # (for multi_gpu_model: what the sharded tail / affinity fill would exchange -- read before the context is closed)
+    n_surv = sum(int(l3d.matches(v.cam)[1][-1]) for v in scene.views) if world == 1 and rank == 0 else 0
+    n_best = len(l3d.best()[0]) if world == 1 and rank == 0 else 0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -614,8 +617,6 @@ def main():
                                               "(l3d_set_timing_level 2); the timed steps record only the pair around the match kernel")
             # what the sharded tail / affinity fill exchange: the surviving matches (Match 40 B + two segment ids), the best
             # hypotheses (HypRec 128 B + a depth pair), three per-segment words; one float per surviving match
-            n_surv = sum(int(l3d.matches(v.cam)[1][-1]) for v in scene.views)
-            n_best = len(l3d.best()[0])
             out["multi_gpu_model"] = multi_gpu_model(pairs, M, kNN, {k: v / phase_steps for k, v in phase.items()},
                                                      lists_ms_sum / phase_steps, 1024.0 * record_kbytes,
                                                      tail_bytes=48.0 * n_surv + 136.0 * n_best + 12.0 * sum(M.values()),

@@ -366,7 +366,8 @@ int l3d_get_timings(l3d_ctx*, l3d_timings*);
 int l3d_set_timing_level(l3d_ctx*, int level);
 /* Test hook (no reference counterpart): process-wide counters that tell a test which form of a kernel ran.
  * "csr_global_launches": launches of the global-cursor form of k_pair_csr (views beyond 32 768 segments, or
- * L3D_CSR_GLOBAL=1).  Unknown name: ~0. */
+ * L3D_CSR_GLOBAL=1); "knn_replay_calls": l3d_match_begin calls whose kNN exceeded the LDS tables of the match kernel
+ * (every row then takes the exact replay path).  Unknown name: ~0. */
 unsigned long long l3d_debug_counter(const char* name);
 
 /* ---- (2) seam layer ------------------------------------------------------------------ */

@@ -1276,6 +1276,9 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
         /* lists beyond one wave's capacity: two waves up to 2x, four up to 4x (fixed grids over the hand-over lists) */   \
         hipLaunchKernelGGL((k_lists<2, B>), dim3(16384), dim3(128), lds2, st, views, pairs, lviews, opairs, ipairs,        \
                            gseg_view, poff, inv, slots, uniform_K, lp, 0u);                                                \
+        /* (the four-wave tier is left out while the passes hand it no list -- C1: an empty grid of 16 us --, like      */    \
+        /* k_lists_huge below: a pass that then does hand one over is repeated with it, flags[4], check_pass)           */    \
+        if (hsa.run_tier4)                                                                                                 \
         hipLaunchKernelGGL((k_lists<4, B>), dim3(512), dim3(256), lds4, st, views, pairs, lviews, opairs, ipairs,          \
                            gseg_view, poff, inv, slots, uniform_K, lp, 0u);                                                \
     } while (0)

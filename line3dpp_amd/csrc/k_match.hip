@@ -46,6 +46,7 @@ constexpr int kRing1 = 128;         // the same for the staged one-wave-per-item
                                     // of 512 B, and 28 such waves fit a CU's 160 KiB (7 per SIMD; 6.3 KiB gave 6)
 __host__ __device__ constexpr int ring_entries(bool staged, uint32_t waves) { return (staged && waves == 1) ? kRing1 : kRing; }
 constexpr int kRing2 = 128;         // second ring (bounded kNN): candidates that passed the depth test; >= 63 + 64
+constexpr int kFifo = 128;          // tile form: FIFO of in-band target records (>= 64 / R - 1 left over + 64 of a chunk)
 
 // All LDS pointers carry the LDS address space in their TYPE: a generic pointer that travels through a struct
 // or a lambda capture loses it and every access becomes a flat_load/flat_store (plus, for volatile, sc0 sc1
@@ -88,21 +89,28 @@ struct Lds {
     L3D_LDS volatile idx_t* minpos;    // [kBlock] slot of the worst entry of a full row; top bit (kTie): the row saw equal
                                        // overlaps where the reference's heap order decides (written under the row's lock)
     L3D_LDS volatile idx_t* top_ix;    // [kBlock*K]
+    L3D_LDS v4f* fifo_rec;             // tile form: [kFifo] records of the targets whose band meets the wave's rows' hull
+    L3D_LDS uint32_t* fifo_pos;        // tile form: [kFifo] their walk-order positions
     static constexpr idx_t kTie = (idx_t)((idx_t)1 << (8 * sizeof(idx_t) - 1));
 };
 
+// rows: rows of a work item (kBlock in the row form, R in the tile form); fifo: the tile form's record FIFO (first: the
+// base of the dynamic LDS is 16-byte aligned, and so are its 16-byte records)
 template <bool IX16>
-__device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K, uint32_t waves, bool two_rings) {
+__device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K, uint32_t waves, bool two_rings, uint32_t rows = kBlock,
+                                           bool fifo = false) {
     typedef typename IdxT<IX16>::type idx_t;
     Lds<IX16> l;
+    l.fifo_rec = (L3D_LDS v4f*)base; if (fifo) base += kFifo * sizeof(v4f);
+    l.fifo_pos = (L3D_LDS uint32_t*)base; if (fifo) base += kFifo * sizeof(uint32_t);
     l.ring = (L3D_LDS volatile uint32_t*)base; base += waves * ring_entries(two_rings, waves) * sizeof(uint32_t);
     l.ring2 = (L3D_LDS volatile uint32_t*)base; if (two_rings) base += waves * kRing2 * sizeof(uint32_t);
-    l.minov = (L3D_LDS volatile float*)base; base += kBlock * 4;
-    l.claim = (L3D_LDS volatile uint32_t*)base; base += kBlock * 4;
-    l.top_ov = (L3D_LDS volatile float*)base; base += (size_t)kBlock * K * 4;
-    l.cnt = (L3D_LDS volatile idx_t*)base; base += kBlock * sizeof(idx_t);
-    l.minpos = (L3D_LDS volatile idx_t*)base; base += kBlock * sizeof(idx_t);
-    l.top_ix = (L3D_LDS volatile idx_t*)base; base += (size_t)kBlock * K * sizeof(idx_t);
+    l.minov = (L3D_LDS volatile float*)base; base += rows * 4;
+    l.claim = (L3D_LDS volatile uint32_t*)base; base += rows * 4;
+    l.top_ov = (L3D_LDS volatile float*)base; base += (size_t)rows * K * 4;
+    l.cnt = (L3D_LDS volatile idx_t*)base; base += rows * sizeof(idx_t);
+    l.minpos = (L3D_LDS volatile idx_t*)base; base += rows * sizeof(idx_t);
+    l.top_ix = (L3D_LDS volatile idx_t*)base; base += (size_t)rows * K * sizeof(idx_t);
     return l;
 }
 
@@ -170,10 +178,32 @@ __device__ __forceinline__ void store_inverse_target(const OrientFuse& of, uint6
 // 0.754 ms).  One wave per item (the large scenes) is limited to 6 per SIMD by its LDS (6.3 KiB per wave) whatever the
 // registers: there the 84-register budget without the spill is the faster one (C2 13.88 against 14.26 ms, C4 25.6
 // against 26.2; profiles/r03_v2_ab_target_delivery.txt, rows sl6 / sl7).
+// TILE (round 5; 0 = the row form above, 16 / 32 = rows per work item): the tile form of the bounded-kNN kernel.
+//   * a work item is R = TILE source rows of ONE width class in band order (k_cull_prepare pads every class to a multiple
+//     of R), handled by one wave64; lane l = (row l % R, target slot l / R): a step of the walk tests 64 / R targets against
+//     R rows.  The wave visits the targets whose band meets the hull of ITS R rows -- a quarter (an eighth) of the rows of
+//     the row form, all of one width class: on C1 the pre-filter tests 1.5 x the (row, target) pairs whose own bands
+//     intersect instead of 2.9 x (tools/hull_sim.py; C2 1.4 x instead of 2.1 x, C4 1.24 x instead of 1.7 x);
+//   * the target records no longer come through the scalar cache one s_load_dwordx4 each (a 16-byte record stream misses
+//     it on every fourth load by construction, and half of a wave's life was waiting): in a visited chunk lane l fetches
+//     record l and band l (one coalesced 1 KiB + 512 B load per chunk), the in-band records are compacted into an LDS
+//     FIFO (v_mbcnt), and a step reads its 64 / R records back as ds_read_b128 -- one address per R lanes, broadcast.
+//     The FIFO carries what is left over (< 64 / R records) to the next chunk, so sparse chunks cost no partial steps;
+//   * one ballot + one compaction per 64 lane-tests (two per 128 in the row form), no scalar bit scan, no record address
+//     arithmetic on the scalar unit.
 #ifndef L3D_MATCH_WAVES
-#define L3D_MATCH_WAVES (WPG == 2 ? 7 : 6)
+#define L3D_MATCH_WAVES (TILE ? L3D_TILE_WAVES : (WPG == 2 ? 7 : 6))
 #endif
-template <int MODE, bool BRUTE, bool IX16, int WPG, bool STAGED>
+#ifndef L3D_TILE_WAVES
+#define L3D_TILE_WAVES 6
+#endif
+#ifndef L3D_ROW_CLASSES_DEFAULT
+#define L3D_ROW_CLASSES_DEFAULT 1   // row form: padded class layout (1) or the legacy layout (0)
+#endif
+#ifndef L3D_TILE_DEFAULT
+#define L3D_TILE_DEFAULT 0    // rows per work item of the tile form (0: the row form is the default)
+#endif
+template <int MODE, bool BRUTE, bool IX16, int WPG, bool STAGED, int TILE = 0>
 __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3D_MATCH_WAVES))) void k_match_pairs(const ViewDev* __restrict__ views,
                                                            const PairDesc* __restrict__ pairs,
                                                            const WorkItem* __restrict__ work, uint32_t nwork,
@@ -205,11 +235,16 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     const bool fastm = (pd.flags & kPairFastMath) != 0;     // l3d_dev.h: IEEE division / sqrt without operand scaling
     typedef typename IdxT<IX16>::type idx_t;
     static_assert(!STAGED || (MODE == 0 && !BRUTE), "the two-stage candidate pipeline exists for the bounded-kNN variant");
-    Lds<IX16> L = carve<IX16>((L3D_LDS char*)smem, MODE == 0 ? K : 0, WPG, STAGED);
+    static_assert(TILE == 0 || ((TILE == 16 || TILE == 32) && STAGED && WPG == 1), "the tile form: bounded kNN, staged, one wave per item");
+    constexpr uint32_t ROWS = TILE ? (uint32_t)TILE : (uint32_t)kBlock;   // rows of a work item
+    constexpr uint32_t TPS = 64u / ROWS;                                  // targets per step of the tile form's walk
+    Lds<IX16> L = carve<IX16>((L3D_LDS char*)smem, MODE == 0 ? K : 0, WPG, STAGED, ROWS, TILE != 0);
     // wave of the workgroup -- through readfirstlane: the compiler must know it is wave-uniform, or the chunk loop
     // below (its mask depends on q) is compiled as a divergent loop with vector addresses
     const uint32_t q = WPG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
-    const uint32_t tid = threadIdx.x & 63u, lane = tid;          // row of the work item = lane
+    const uint32_t tid = threadIdx.x & 63u, lane = tid;          // row of the work item = lane (row form)
+    const uint32_t rs = TILE ? (tid & (ROWS - 1u)) : tid;        // this lane's row of the work item
+    const uint32_t grp = TILE ? tid / ROWS : 0u;                 // tile form: which of a step's TPS targets this lane tests
     constexpr uint32_t kRingN = (uint32_t)ring_entries(STAGED, WPG);
     constexpr idx_t kTie = Lds<IX16>::kTie;
     L3D_LDS volatile uint32_t* ring = L.ring + q * kRingN;
@@ -221,14 +256,25 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     // row (744 us as a kernel of its own, 3500 us inside the epilogue) was slower than streaming.
     const PairCull* pc = (MODE != 2 && !BRUTE && cp.cull && cp.cull[wi.pair].enabled) ? &cp.cull[wi.pair] : nullptr;
     const bool cull = pc != nullptr;
-    const bool active = wi.src0 + tid < Ms;
-    uint32_t src = wi.src0 + tid;
+    bool active = wi.src0 + rs < Ms;
+    uint32_t src = wi.src0 + rs;
     float blo = __builtin_inff(), bhi = -__builtin_inff();   // this lane's tau band (empty for a dead lane)
-    if (cull && active) {
+    // padded class layout of the source rows (the tile form always; the row form when k_cull_prepare laid the launch's
+    // rows out that way, CullPools::padded_rows): the pair's region holds tile_src_cap(Ms, R) positions, every width class
+    // padded to a multiple of R with kEmpty rows
+    const bool pad = TILE != 0 || cp.padded_rows != 0;
+    if (pad && cull) {
+        src = cp.src_perm[pc->s_off + wi.src0 + rs];
+        active = src != kEmpty;
+        if (active) { const float2 b = cp.src_band[pc->s_off + wi.src0 + rs]; blo = b.x; bhi = b.y; }
+    } else if (cull && active) {
         src = cp.src_perm[pc->s_off + wi.src0 + tid];
         const float2 b = cp.src_band[pc->s_off + wi.src0 + tid];
         blo = b.x; bhi = b.y;
     }
+    if (pad && !active) src = kEmpty;                         // (the epilogue skips such rows)
+    if (pad && L3D_BALLOT(active) == 0) return;               // an item of padding only (every wave of the workgroup holds
+                                                              // the same rows: uniform, before any barrier / LDS use)
 
     double F[9];
 #pragma unroll
@@ -254,7 +300,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             live = true;
         }
     }
-    if (q == 0) {
+    if (q == 0 && tid < ROWS) {
         L.cnt[tid] = 0;
         L.minov[tid] = thr;
         L.claim[tid] = kEmpty;
@@ -424,7 +470,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             }
         }
         // feed the K-th best overlap back into the owning lane's pre-filter threshold
-        if (live) thrL = L.minov[tid];
+        if (live) thrL = L.minov[rs];
     };
 
     // one exact test per lane on up to 64 queued candidates, then kNN insertion
@@ -512,14 +558,14 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             }
         }
         // feed the K-th best overlap back into the owning lane's pre-filter threshold
-        if (MODE == 0 && live) thrL = L.minov[tid];
+        if (MODE == 0 && live) thrL = L.minov[rs];
     };
 
     // ---- main loop: stream the target view through LDS ----
     // Branch-free per test: dead lanes evaluate the pre-filter on zeros and are masked out of the ballot;
     // the compaction prefix is v_mbcnt (population count of the ballot below this lane).
     const v4f* __restrict__ tf = cull ? (const v4f*)(cp.tgt_sf + pc->t_off) : (const v4f*)vt.segf;
-    const uint32_t ent_hi = tid << 23;
+    const uint32_t ent_hi = rs << 23;
     const bool lane_on = BRUTE ? active : live;           // lanes that can produce candidates
     const uint64_t lanes_on = L3D_BALLOT(lane_on);
     // the candidate pipeline is run whenever the first ring holds a full drain (flush: until both rings are empty)
@@ -552,14 +598,117 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     // exact test.  The result does not depend on the order (total order of the insertion; ties are replayed).
     uint32_t cc = 0;
     if (cull) {
-        const uint32_t n_rows = min((uint32_t)kBlock, Ms - wi.src0);
+        // (tile form: the item's rows are lanes 0 .. R-1, the padding of its class -- if any -- at the end)
+        const uint64_t row_lanes = ROWS == 64u ? ~0ull : ((1ull << (ROWS & 63u)) - 1ull);
+        const uint32_t n_rows = pad ? (uint32_t)__popcll(L3D_BALLOT(active) & row_lanes) : min((uint32_t)kBlock, Ms - wi.src0);
         const float mid = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(blo), n_rows / 2));
         for (uint32_t c0 = 0; c0 < nch; c0 += 64) {
             const uint32_t c = c0 + lane;
             cc += (uint32_t)__popcll(L3D_BALLOT(c < nch && cband[c].x < mid));
         }
     }
+    // ---- tile form: the FIFO of in-band target records and one step of the walk ----
+    uint32_t fh = 0, ft = 0;             // wave-uniform FIFO cursors (records fh .. ft-1 are queued)
+    auto tile_step = [&]() {
+        // lane (row rs, slot grp) tests record fh + grp; a slot beyond the queue (the flush at the end of the walk) idles
+        const uint32_t p = fh + grp;
+        const bool valid = p < ft;
+        const uint32_t ix = p & (uint32_t)(kFifo - 1);
+        const v4f q = L.fifo_rec[ix];                 // ds_read_b128, one address per R lanes
+        const uint32_t tp = L.fifo_pos[ix];
+        fh = min(fh + TPS, ft);
+        const bool cb = prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q, thrL);
+        // (lane masks from the comparisons themselves, combined by scalar ANDs)
+        const uint64_t mm = L3D_BALLOT(cb) & L3D_BALLOT(valid) & lanes_on;
+        if (lane == 0) L3D_STAT(0, 64);
+#ifdef L3D_STATS
+        {   // the row's own band against the target's: the pairs a walk without the hull would test
+            uint32_t nb = (uint32_t)__popcll(L3D_BALLOT(valid) & lanes_on);
+            if (cull) { const float2 b0 = tband[valid ? tp : 0u]; nb = (uint32_t)__popcll(L3D_BALLOT(valid && !(b0.y < blo || b0.x > bhi)) & lanes_on); }
+            if (lane == 0) L3D_STAT(5, nb);
+        }
+#endif
+        if (mm) {
+            if ((mm >> lane) & 1ull) ring[(tail + prefix(mm)) & (kRingN - 1)] = ent_hi | tp;
+            tail += (uint32_t)__popcll(mm);
+            pump(false);
+        }
+    };
     const uint32_t ngrp = (nch + 31) / 32, gc = cc / 32;
+    if constexpr (TILE != 0) {
+        // ---- the tile form's walk: the same chunk order (centre-out), one chunk AHEAD ----
+        // A work item of R rows meets a handful of targets per chunk (C1, R = 16: 7.5 steps per visited chunk, R = 64: 35), so
+        // the latency of a chunk's two loads -- record l and band l per lane, L2 hits -- is no longer small against the work
+        // between them: the loads of the NEXT visited chunk are issued before the current one is compacted and walked (six
+        // registers across the candidate pipeline; loads return in order, so waiting for the current chunk leaves them in
+        // flight).
+        uint32_t it_pass = 0, it_gi = 0, it_wm = 0, it_g0 = 0, it_dir = 0;
+        const uint32_t n_pass = cull ? 2u : 1u;
+        auto next_chunk = [&]() -> uint32_t {          // first target of the next visited chunk, kEmpty at the end (wave-uniform)
+            while (!it_wm) {
+                if (it_pass >= n_pass) return kEmpty;
+                const uint32_t n_g = it_pass == 0 ? ngrp - min(gc, ngrp) : gc + 1;
+                if (it_gi >= n_g) { ++it_pass; it_gi = 0; continue; }
+                const uint32_t g0 = (it_pass == 0 ? gc + it_gi : gc - it_gi) * 32;
+                uint32_t wm;
+                if (cull) {
+                    bool vis = false;
+                    const uint32_t c = g0 + lane;
+                    if (lane < 32 && c < nch) {
+                        const float2 cb = cband[c];
+                        vis = !(cb.y < wlo || cb.x > whi);
+                    }
+                    wm = (uint32_t)L3D_BALLOT(vis);
+                    if (it_gi == 0) { const uint32_t below = (1u << (cc & 31u)) - 1u; wm &= it_pass == 0 ? ~below : below; }
+                } else {
+                    wm = (nch - g0 >= 32) ? 0xFFFFFFFFu : ((1u << (nch - g0)) - 1u);
+                }
+                ++it_gi;
+                it_wm = wm; it_g0 = g0; it_dir = it_pass;
+            }
+            const uint32_t bit = it_dir == 0 ? (uint32_t)__builtin_ctz(it_wm) : 31u - (uint32_t)__builtin_clz(it_wm);
+            it_wm &= ~(1u << bit);
+            return (it_g0 + bit) * 64;
+        };
+        // record and band of target tb + lane (an empty band for a lane beyond the view; without culling every target is in)
+        auto fetch = [&](uint32_t tb, v4f& rec, float& lo, float& hi) {
+            const uint32_t ti = tb + lane;
+            rec = v4f{0.0f, 0.0f, 0.0f, 0.0f}; lo = __builtin_inff(); hi = -__builtin_inff();
+            if (ti < Mt) {
+                rec = tf[ti];
+                if (cull) { const float2 b = tband[ti]; lo = b.x; hi = b.y; }
+                else { lo = -__builtin_inff(); hi = __builtin_inff(); }
+            }
+        };
+        uint32_t tb_c = next_chunk();
+        v4f rec_c; float lo_c, hi_c;
+        if (tb_c != kEmpty) fetch(tb_c, rec_c, lo_c, hi_c);
+        while (tb_c != kEmpty) {
+            const uint32_t tb_n = next_chunk();
+            v4f rec_n = {0.0f, 0.0f, 0.0f, 0.0f}; float lo_n = __builtin_inff(), hi_n = -__builtin_inff();
+            if (tb_n != kEmpty) fetch(tb_n, rec_n, lo_n, hi_n);
+            // the records whose band meets the hull of the wave's rows are appended to the FIFO, and the walk advances while
+            // a full step's worth is queued
+            // (the range test is explicit: an item of unbounded rows -- hull (-inf, inf) -- would take the empty band of a lane
+            // beyond the view for a hit; unculled: wlo = +inf, whi = -inf never reject the (-inf, inf) band of a real target)
+            const bool in = tb_c + lane < Mt && !(hi_c < wlo || lo_c > whi);
+            const uint64_t m = L3D_BALLOT(in);
+            if (m) {
+                if (in) {
+                    const uint32_t ix = (ft + prefix(m)) & (uint32_t)(kFifo - 1);
+                    L.fifo_rec[ix] = rec_c;
+                    L.fifo_pos[ix] = tb_c + lane;
+                }
+                ft += (uint32_t)__popcll(m);
+                // (LDS operations of a wave complete in order: the reads of tile_step see these writes; the compiler must
+                // not move them across)
+                asm volatile("" ::: "memory");
+                while (ft - fh >= TPS) tile_step();
+            }
+            tb_c = tb_n; rec_c = rec_n; lo_c = lo_n; hi_c = hi_n;
+        }
+        while (ft != fh) tile_step();                         // what is left in the FIFO (fewer than TPS records)
+    } else
     for (uint32_t pass = 0; pass < (cull ? 2u : 1u); ++pass) {
       const uint32_t n_g = pass == 0 ? ngrp - min(gc, ngrp) : gc + 1;
       for (uint32_t gi = 0; gi < n_g; ++gi) {
@@ -706,19 +855,21 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     if (WPG > 1) __syncthreads();                       // every wave's candidates are in the tables
     {   // equal overlaps INSIDE a row's table: their order is the reference's heap order as well (every wave of the
         // group checks all 64 rows itself: same flags, no further barrier)
-        const uint32_t c = min((uint32_t)L.cnt[tid], K);
-        L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)tid * K;
+        // (tile form: lanes R .. 63 repeat the rows of lanes 0 .. R-1 -- same table, same flag, same value written)
+        const uint32_t c = min((uint32_t)L.cnt[rs], K);
+        L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)rs * K;
         bool t = false;
         for (uint32_t i = 1; i < c; ++i) {
             const float oi = ov[i];
             for (uint32_t j = 0; j < i; ++j) t |= ov[j] == oi;
         }
-        if (t) flag_tie(tid);
+        if (t && tid < ROWS) flag_tie(tid);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    const uint32_t n_rows = min((uint32_t)kBlock, Ms - wi.src0);
+    // (tile form: all R rows of the item are walked; padding rows -- src == kEmpty -- are skipped item by item)
+    const uint32_t n_rows = pad ? ROWS : min((uint32_t)kBlock, Ms - wi.src0);
     const bool hands_inverse = pd.tgt > pd.src;   // inverse copy only towards a view processed later (:1680)
     const uint32_t n_items = n_rows * K;
 #ifndef L3D_NO_LAUNDER_EPILOGUE
@@ -733,9 +884,10 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     for (uint32_t base0 = 0; base0 < n_items; base0 += 64 * WPG) {
         const uint32_t base = base0 + q * 64;           // first item of this wave in this pass
         const uint32_t it = base + lane;
-        const bool in = it < n_items;
-        const uint32_t r = in ? it / K : 0u, j = it - r * K;
+        const bool in_range = it < n_items;
+        const uint32_t r = in_range ? it / K : 0u, j = it - r * K;
         const uint32_t rsrc = __shfl(src, r);           // every wave of the group holds the same 64 rows, row = lane
+        const bool in = in_range && (!pad || rsrc != kEmpty);
         // a flagged row is left to k_match_tied_rows entirely (slots, orientation flags, counters)
         const bool tied = in && (L.minpos[r] & kTie) != 0;
         if (tied && j == 0) {
@@ -803,11 +955,30 @@ bool match_staged(int mode, bool brute) {
     static const bool off = [] { const char* e = std::getenv("L3D_MATCH_STAGED"); return e && std::atoi(e) == 0; }();
     return mode == 0 && !brute && !off;
 }
-size_t match_lds_bytes(int mode, uint32_t K, bool ix16, uint32_t waves, bool brute) {
+size_t match_lds_bytes(int mode, uint32_t K, bool ix16, uint32_t waves, bool brute, uint32_t tile_rows) {
     const size_t ib = ix16 ? 2 : 4;
     const bool staged = match_staged(mode, brute);
+    if (tile_rows)   // (one wave per item: FIFO + the two rings + the tables of R rows)
+        return (size_t)kFifo * (sizeof(v4f) + 4) + (size_t)(ring_entries(true, 1) + kRing2) * 4 + 2 * (size_t)tile_rows * 4 +
+               2 * (size_t)tile_rows * ib + (size_t)tile_rows * K * (4 + ib);
     return (size_t)waves * (ring_entries(staged, waves) + (staged ? kRing2 : 0)) * 4 + 2 * kBlock * 4 + 2 * kBlock * ib +
            (mode == 0 ? (size_t)kBlock * K * (4 + ib) : 0);
+}
+
+// The tile form serves the bounded-kNN launches of the two-stage pipeline (everything else -- keep-all passes, the
+// brute-force hook, the single-stage A/B switch -- keeps the row form).  L3D_MATCH_TILE = 0 | 16 | 32 overrides.
+uint32_t match_tile_rows(int mode, bool brute) {
+    if (!match_staged(mode, brute)) return 0;
+    static const int forced = [] { const char* e = std::getenv("L3D_MATCH_TILE"); return e ? std::atoi(e) : -1; }();
+    if (forced == 0 || forced == 16 || forced == 32) return (uint32_t)forced;
+    return L3D_TILE_DEFAULT;
+}
+uint32_t match_layout_rows(int mode, bool brute) {
+    if (mode != 0 || brute) return 0;
+    const uint32_t t = match_tile_rows(mode, brute);
+    if (t) return t;
+    static const int classes = [] { const char* e = std::getenv("L3D_MATCH_CLASSES"); return e ? std::atoi(e) : L3D_ROW_CLASSES_DEFAULT; }();
+    return classes ? (uint32_t)kMatchRows : 0u;
 }
 
 // Two waves per work item pay off while the launch has few items for the machine (C0: kernel 0.34 -> 0.24 ms, C1 with
@@ -824,29 +995,33 @@ uint32_t match_waves_per_group(int mode, bool brute, uint32_t nwork) {
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,
                               const WorkItem* work, uint32_t nwork, uint32_t maxK, Slot* slots,
                               uint32_t* row_counts, float thr, CullPools pools, OrientFuse of, bool ix16,
-                              hipStream_t stream) {
+                              uint32_t tile_rows, hipStream_t stream) {
     if (nwork == 0) return hipSuccess;
     if (mode == 0 && (!of.inv_tgt || !of.tie_count || !of.tie_list)) return hipErrorInvalidValue;   // MODE 0 always fuses
     const uint32_t grid = ((nwork + 7) / 8) * 8;
     if (!(mode == 0 && !brute)) ix16 = false;       // the compact layout is only instantiated for the hot variant
-    const uint32_t wpg = match_waves_per_group(mode, brute, nwork);
-    const size_t lds = match_lds_bytes(mode, maxK, ix16, wpg, brute);
-#define L3D_LAUNCH(M, B, X, W, S)                                                                             \
+    if (tile_rows && tile_rows != match_tile_rows(mode, brute)) return hipErrorInvalidValue;   // (the work list was cut for it)
+    const uint32_t wpg = tile_rows ? 1u : match_waves_per_group(mode, brute, nwork);
+    const size_t lds = match_lds_bytes(mode, maxK, ix16, wpg, brute, tile_rows);
+#define L3D_LAUNCH(M, B, X, W, S, T)                                                                          \
     do {                                                                                                      \
-        hipError_t e = hipFuncSetAttribute((const void*)k_match_pairs<M, B, X, W, S>,                         \
+        hipError_t e = hipFuncSetAttribute((const void*)k_match_pairs<M, B, X, W, S, T>,                      \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
         if (e != hipSuccess) return e;                                                                        \
-        hipLaunchKernelGGL((k_match_pairs<M, B, X, W, S>), dim3(grid), dim3(kBlock * W), lds, stream, views,  \
+        hipLaunchKernelGGL((k_match_pairs<M, B, X, W, S, T>), dim3(grid), dim3(kBlock * W), lds, stream, views, \
                            pairs, work, nwork, slots, row_counts, thr, pools, of);                            \
     } while (0)
-#define L3D_LAUNCH_HOT(X, W) do { if (match_staged(mode, brute)) L3D_LAUNCH(0, false, X, W, true); else L3D_LAUNCH(0, false, X, W, false); } while (0)
-    if (mode == 0) {
-        if (brute) L3D_LAUNCH(0, true, false, 1, false);
+#define L3D_LAUNCH_HOT(X, W) do { if (match_staged(mode, brute)) L3D_LAUNCH(0, false, X, W, true, 0); else L3D_LAUNCH(0, false, X, W, false, 0); } while (0)
+    if (mode == 0 && tile_rows) {
+        if (tile_rows == 16) { if (ix16) L3D_LAUNCH(0, false, true, 1, true, 16); else L3D_LAUNCH(0, false, false, 1, true, 16); }
+        else { if (ix16) L3D_LAUNCH(0, false, true, 1, true, 32); else L3D_LAUNCH(0, false, false, 1, true, 32); }
+    } else if (mode == 0) {
+        if (brute) L3D_LAUNCH(0, true, false, 1, false, 0);
         else if (ix16) { if (wpg == 2) L3D_LAUNCH_HOT(true, 2); else L3D_LAUNCH_HOT(true, 1); }
         else { if (wpg == 2) L3D_LAUNCH_HOT(false, 2); else L3D_LAUNCH_HOT(false, 1); }
     }
-    else if (mode == 1) { if (brute) L3D_LAUNCH(1, true, false, 1, false); else L3D_LAUNCH(1, false, false, 1, false); }
-    else { if (brute) L3D_LAUNCH(2, true, false, 1, false); else L3D_LAUNCH(2, false, false, 1, false); }
+    else if (mode == 1) { if (brute) L3D_LAUNCH(1, true, false, 1, false, 0); else L3D_LAUNCH(1, false, false, 1, false, 0); }
+    else { if (brute) L3D_LAUNCH(2, true, false, 1, false, 0); else L3D_LAUNCH(2, false, false, 1, false, 0); }
 #undef L3D_LAUNCH_HOT
 #undef L3D_LAUNCH
     return hipGetLastError();
@@ -1097,7 +1272,8 @@ __global__ __launch_bounds__(kCullBlock) void k_order_items(const PairDesc* __re
         const float2* src = by_target ? cp.tgt_band + pc.t_off : cp.chunk_band + pc.c_off;
         for (uint32_t i = tid; i < n_bands; i += kCullBlock) bands[i] = src[i];
         __syncthreads();
-        const uint32_t n_items = (Ms + 63) / 64;
+        const uint32_t n_rows_tot = cp.padded_rows ? tile_src_cap(Ms, 64u) : Ms;   // (padded class layout: kEmpty rows carry an empty band)
+        const uint32_t n_items = (n_rows_tot + 63) / 64;
         uint32_t* bucket = cp.item_bucket + (pc.w_item0 - cp.w_base);
         const uint64_t cmax = cp.cost_max ? cp.cost_max : 1u;
         for (uint32_t it = wave; it < n_items; it += n_waves) {
@@ -1105,7 +1281,7 @@ __global__ __launch_bounds__(kCullBlock) void k_order_items(const PairDesc* __re
             if (pc.enabled) {
                 const uint32_t r = it * 64 + lane;
                 float lo = __builtin_inff(), hi = -__builtin_inff();
-                if (r < Ms) { const float2 b = cp.src_band[pc.s_off + r]; lo = b.x; hi = b.y; }
+                if (r < n_rows_tot) { const float2 b = cp.src_band[pc.s_off + r]; lo = b.x; hi = b.y; }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
                 uint32_t n = 0;
@@ -1176,10 +1352,13 @@ hipError_t launch_order_items(const PairDesc* pairs, uint32_t first, uint32_t co
     return hipGetLastError();
 }
 
+// tile_rows: 0 = the row form's layout (Ms positions, at most two width classes from 4096 segments on); R = 16 / 32 = the
+// tile form's: kTileClasses width classes at every view size, each padded with kEmpty rows to a multiple of R, in a region
+// of tile_src_cap(Ms, R) positions
 template <int KMAX>
 __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __restrict__ views,
                                                              const PairDesc* __restrict__ pairs, uint32_t first,
-                                                             const CullPools cp) {
+                                                             const CullPools cp, const uint32_t tile_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t p = first + blockIdx.x;
     const PairCull& pc = cp.cull[p];
@@ -1221,13 +1400,61 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
                 // order: unbounded, widest, wide, plain -- the row groups with the largest hulls are the longest work
                 // items and must start first (ordered last they lengthen the ramp-down tail of the launch)
                 uint32_t cls = b.cls;   // 0: unbounded, 2: bounded
-                if (cls == 2) { const float w = b.hi - b.lo; cls = w > w1 ? ((two && w > w2) ? 1u : 2u) : 3u; }
+                if (cls == 2) {
+                    const float w = b.hi - b.lo;
+                    // (padded layout: how many width classes pay depends on how many items a class is cut into -- with few
+                    // items per class 64 consecutive rows of a class spread further in tau than the class saves in width;
+                    // tools/hull_sim.py on C1 / C2 / C4 for R = 16 / 32 / 64: one cut at 1/16 of the image below 48 items per
+                    // pair, 1/64 and 1/16 below 192, 1/64, 1/32 and 1/16 from there on)
+                    if (tile_rows) {
+                        const uint32_t items = Ms / tile_rows;
+                        const float c16 = ref * (1.0f / 16.0f), c32 = items >= 192u ? ref * (1.0f / 32.0f) : c16,
+                                    c64 = items >= 48u ? ref * (1.0f / 64.0f) : c16;
+                        cls = w > c16 ? 1u : w > c32 ? 2u : w > c64 ? 3u : 4u;
+                    }
+                    else cls = w > w1 ? ((two && w > w2) ? 1u : 2u) : 3u;
+                }
                 key = ((uint64_t)cls << 56) | ((uint64_t)f2ord(b.lo) << 24) | i;
             }
             keys[i] = key;
         }
         __syncthreads();
         cull_sort<KMAX>(keys, n2, !big);
+        if (tile_rows) {
+            // Tile form (k_match_pairs<..., TILE>): a work item is R consecutive positions, and its hull must not straddle
+            // two classes (the last rows of one class and the first of the next are far apart in tau: such an item would
+            // walk the whole view) -- so every class starts at a multiple of R; the gap is padded with kEmpty rows, which
+            // the match kernel skips.  The class sizes are only known here, so the host cuts tile_src_cap(Ms, R) positions
+            // into items and the positions beyond the last class stay kEmpty as well.
+            __shared__ uint32_t cstart[kTileClasses + 1], cbase[kTileClasses + 1];
+            const uint32_t R = tile_rows, cap = tile_src_cap(Ms, R);
+            for (uint32_t i = tid; i < cap; i += kCullBlock) {
+                cp.src_perm[pc.s_off + i] = kEmpty;
+                cp.src_band[pc.s_off + i] = make_float2(__builtin_inff(), -__builtin_inff());
+            }
+            if (tid <= kTileClasses) {          // first sorted position of class tid (binary search; padding keys sort last)
+                const uint64_t want = (uint64_t)tid << 56;
+                uint32_t lo = 0, hi = Ms;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
+                cstart[tid] = lo;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t base = 0;
+                for (uint32_t k = 0; k < kTileClasses; ++k) { cbase[k] = base; base += ((cstart[k + 1] - cstart[k] + R - 1) / R) * R; }
+                cbase[kTileClasses] = base;
+            }
+            __syncthreads();                    // (also: the kEmpty fill above is complete before the rows are placed)
+            for (uint32_t i = tid; i < Ms; i += kCullBlock) {
+                const uint64_t key = keys[i];
+                const uint32_t row = (uint32_t)(key & 0xFFFFFFu), k = (uint32_t)(key >> 56);
+                const Band b = src_band(pc, vs.seg4[row]);
+                const uint32_t at = cbase[k] + (i - cstart[k]);
+                cp.src_perm[pc.s_off + at] = row;
+                cp.src_band[pc.s_off + at] = make_float2(b.lo, b.hi);
+            }
+            return;
+        }
         for (uint32_t i = tid; i < Ms; i += kCullBlock) {
             const uint32_t row = (uint32_t)(keys[i] & 0xFFFFFFu);
             const Band b = src_band(pc, vs.seg4[row]);
@@ -1294,7 +1521,7 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
 }
 
 hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
-                               uint32_t max_M, CullPools pools, hipStream_t stream) {
+                               uint32_t max_M, CullPools pools, uint32_t tile_rows, hipStream_t stream) {
     if (!count || !pools.cull) return hipSuccess;
     uint32_t n2 = kCullBlock;
     while (n2 < max_M) n2 <<= 1;
@@ -1306,7 +1533,8 @@ hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint
         hipError_t e = hipFuncSetAttribute((const void*)k_cull_prepare<K>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                            (int)lds);                                                                      \
         if (e != hipSuccess) return e;                                                                                     \
-        hipLaunchKernelGGL(k_cull_prepare<K>, dim3(count, 2), dim3(kCullBlock), lds, stream, views, pairs, first, pools);  \
+        hipLaunchKernelGGL(k_cull_prepare<K>, dim3(count, 2), dim3(kCullBlock), lds, stream, views, pairs, first, pools,   \
+                           tile_rows);                                                                                     \
     } while (0)
     const uint32_t kmax = std::min(n2, kCullLdsSegs) / kCullBlock;
     if (kmax <= 1) L3D_CULL(1); else if (kmax == 2) L3D_CULL(2); else if (kmax == 4) L3D_CULL(4);

@@ -149,6 +149,7 @@ int l3d_get_sparse_matrix(l3d_ctx* c, int sort_by_row, l3d_float4* entries, int3
 // of k_pair_csr was selected by an environment variable that had been latched before the test set it)
 unsigned long long l3d_debug_counter(const char* name) {
     if (name && std::string(name) == "csr_global_launches") return g_csr_global_launches.load(std::memory_order_relaxed);
+    if (name && std::string(name) == "knn_replay_calls") return g_knn_replay_calls.load(std::memory_order_relaxed);
     return ~0ull;
 }
 

@@ -310,6 +310,8 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
     (void)hipEventElapsedTime(&ms, a, b);
     return ms;
 }
+std::atomic<uint64_t> g_knn_replay_calls{0};   // test hook (l3d_debug_counter): calls whose kNN exceeded the LDS tables of k_match_pairs
+
 float ev_ms(const ::l3d_ctx* c, int a, int b) { return c->ev_on(a) && c->ev_on(b) ? ev_ms(c->ev[a], c->ev[b]) : 0.0f; }
 
 }  // namespace l3d
@@ -563,6 +565,12 @@ int l3d_match_begin(l3d_ctx* c, const l3d_match_params* p) {
     return rc;
 }
 
+// work items of a pair with Ms source rows in the bounded-kNN launch of this context (row form: 64 rows each; tile form: R
+// positions of the padded class layout each)
+static uint32_t match_items(const l3d_ctx* c, uint32_t Ms) {
+    return c->layout_rows ? tile_src_cap(Ms, c->layout_rows) / c->layout_rows : (Ms + kMatchRows - 1) / kMatchRows;
+}
+
 static int match_begin_body(l3d_ctx* c) {
     if (c->ev_on(0)) L3D_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
     for (auto* v : c->order) {
@@ -591,7 +599,10 @@ static int match_begin_body(l3d_ctx* c) {
     std::vector<unsigned char> sig;
     {
         auto put = [&](const void* q, size_t n) { const unsigned char* b = (const unsigned char*)q; sig.insert(sig.end(), b, b + n); };
-        const int32_t head[3] = {c->kNN, c->use_cull ? 1 : 0, c->brute ? 1 : 0};
+        // tile form of the bounded-kNN kernel (k_match.hip): R rows per work item, the source pools laid out for it
+        c->tile_rows = c->kNN > 0 ? match_tile_rows(0, c->brute) : 0u;
+        c->layout_rows = c->kNN > 0 ? match_layout_rows(0, c->brute) : 0u;   // padded class layout of the source rows (k_cull_prepare)
+        const int32_t head[5] = {c->kNN, c->use_cull ? 1 : 0, c->brute ? 1 : 0, (int32_t)c->tile_rows, (int32_t)c->layout_rows};
         put(head, sizeof(head));
         for (auto* v : c->order) {
             const uint32_t iv[5] = {v->cam, v->index, v->M, (uint32_t)v->width, (uint32_t)v->height};
@@ -644,14 +655,15 @@ static int match_begin_body(l3d_ctx* c) {
             if (c->use_cull && pd.Ms <= kCullMaxSegs && pd.Mt <= kCullMaxSegs && pd.Ms && pd.Mt)
                 make_cull(pd.F, v->width, v->height, t->width, t->height, pc);
             pc.s_off = cs_off; pc.t_off = ct_off; pc.c_off = cc_off; pc.k_off = ~0ull;
-            pc.w_item0 = w_item; pc.sorted_copy = pd.Mt >= kSortedCopyMinSegs ? 1u : 0u; w_item += (pd.Ms + kMatchRows - 1) / kMatchRows;
+            pc.w_item0 = w_item; pc.sorted_copy = pd.Mt >= kSortedCopyMinSegs ? 1u : 0u; w_item += match_items(c, pd.Ms);
             if (pc.enabled && std::max(pd.Ms, pd.Mt) > kCullLdsSegs) {   // sort keys of this pair in global scratch
                 uint32_t a = 64, b = 64;
                 while (a < pd.Ms) a <<= 1;
                 while (b < pd.Mt) b <<= 1;
                 pc.k_off = ck_off; ck_off += (uint64_t)a + b;
             }
-            if (pc.enabled) { cs_off += pd.Ms; ct_off += pd.Mt; cc_off += (pd.Mt + 63) / 64; }
+            // (tile form: the rows of a pair take tile_src_cap positions -- every width class padded to a multiple of R)
+            if (pc.enabled) { cs_off += c->layout_rows ? tile_src_cap(pd.Ms, c->layout_rows) : pd.Ms; ct_off += pd.Mt; cc_off += (pd.Mt + 63) / 64; }
             c->cull.push_back(pc);
             c->pair_src_cam.push_back(v->cam); c->pair_tgt_cam.push_back(tcam);
             c->pair_tests += (uint64_t)pd.Ms * pd.Mt;
@@ -663,11 +675,12 @@ static int match_begin_body(l3d_ctx* c) {
     if (c->kNN > 0 && !c->pairs.empty()) {
         // bounded kNN keeps the per-row top-K tables of 64 rows in LDS (k_match.hip): the real limit of this build
         size_t n_work = 0; uint32_t maxMt = 0;
-        for (auto& pd : c->pairs) { n_work += (pd.Ms + kMatchRows - 1) / kMatchRows; maxMt = std::max(maxMt, pd.Mt); }
+        for (auto& pd : c->pairs) { n_work += match_items(c, pd.Ms); maxMt = std::max(maxMt, pd.Mt); }
         const uint32_t wpg = match_waves_per_group(0, c->brute, (uint32_t)std::min<size_t>(n_work, 0xFFFFFFFFu));
-        auto fits = [&](uint32_t K) { return match_lds_bytes(0, K, maxMt < 65536u && K < 32768u && !c->brute, wpg, c->brute) <= 160 * 1024; };
+        auto fits = [&](uint32_t K) { return match_lds_bytes(0, K, maxMt < 65536u && K < 32768u && !c->brute, wpg, c->brute, c->tile_rows) <= 160 * 1024; };
         // beyond that, every row takes the exact replay path (k_match_tied_rows): slower per row, any kNN <= 4096
         c->knn_replay = !fits((uint32_t)c->kNN);
+        if (c->knn_replay) l3d::g_knn_replay_calls.fetch_add(1, std::memory_order_relaxed);
     } else c->knn_replay = false;
     c->cull_tot[0] = cs_off; c->cull_tot[1] = ct_off; c->cull_tot[2] = ck_off; c->cull_tot[3] = cc_off;
     c->begin_sig.swap(sig); c->begin_sig_valid = true;
@@ -754,7 +767,12 @@ void collect_match_timing(l3d_ctx* c) {   // (declared in l3d_ctx.h: l3d_phase_b
 static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count) {
     size_t n_work = 0;
     uint32_t maxK = 0, maxM = 0, maxMt = 0;
-    for (uint32_t p = first; p < first + count; ++p) n_work += (c->pairs[p].Ms + kMatchRows - 1) / kMatchRows;
+    const bool hot = mode == 0 && !c->brute && !c->knn_replay;
+    const uint32_t tile = hot ? c->tile_rows : 0u;          // kernel form (keep-all passes, brute force: the row form)
+    const uint32_t layout = hot ? c->layout_rows : 0u;      // padded class layout of the source rows (0: Ms rows per pair)
+    const uint32_t rows_per_item = layout ? layout : (uint32_t)kMatchRows;
+    auto items_of = [&](uint32_t Ms) { return layout ? tile_src_cap(Ms, layout) / layout : (Ms + kMatchRows - 1) / kMatchRows; };
+    for (uint32_t p = first; p < first + count; ++p) n_work += items_of(c->pairs[p].Ms);
     if (!n_work) return L3D_OK;
     for (uint32_t p = first; p < first + count; ++p) {
         const PairDesc& pd = c->pairs[p];
@@ -763,25 +781,25 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         maxMt = std::max(maxMt, pd.Mt);
     }
     const bool replay_all = mode == 0 && c->knn_replay;   // kNN beyond the LDS tables: every row through k_match_tied_rows
-    if (!replay_all && match_lds_bytes(mode, maxK, false, match_waves_per_group(mode, c->brute, (uint32_t)n_work), c->brute) > 160 * 1024)
+    if (!replay_all && match_lds_bytes(mode, maxK, false, match_waves_per_group(mode, c->brute, (uint32_t)n_work), c->brute, tile) > 160 * 1024)
         return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
     L3D_HIP_CHECK(c->d_work.reserve(n_work));
     // the work list of these pairs is on the device already when the pair list has not changed since it was sent
     if (!(c->work_key.version == c->pairs_version && c->work_key.first == first && c->work_key.count == count &&
-          c->work_key.dev == (const void*)c->d_work.p)) {
+          c->work_key.dev == (const void*)c->d_work.p && c->work_key.rows == rows_per_item)) {
         L3D_HIP_CHECK(c->h_work.reserve(n_work));
         WorkItem* work = c->h_work.p;
         size_t w = 0;
         for (uint32_t p = first; p < first + count; ++p)
-            for (uint32_t s0 = 0; s0 < c->pairs[p].Ms; s0 += kMatchRows) work[w++] = WorkItem{p, s0};
+            for (uint32_t k = 0, n = items_of(c->pairs[p].Ms); k < n; ++k) work[w++] = WorkItem{p, k * rows_per_item};
         L3D_HIP_CHECK(hipMemcpyAsync(c->d_work.p, work, n_work * sizeof(WorkItem), hipMemcpyHostToDevice, c->stream));
         c->work_key.version = c->pairs_version; c->work_key.first = first; c->work_key.count = count;
-        c->work_key.dev = c->d_work.p;
+        c->work_key.dev = c->d_work.p; c->work_key.rows = rows_per_item;
     }
     if (c->ev_on(8)) L3D_HIP_CHECK(hipEventRecord(c->ev[8], c->stream));
     CullPools pools{c->d_cull.p, c->d_src_perm.p, c->d_src_band.p, c->d_tgt_perm.p, c->d_tgt_sf.p, c->d_tgt_band.p,
                     c->d_chunk_band.p, c->d_cull_keys.p};
-    pools.tgt_s4 = c->d_tgt_s4.p; pools.tgt_sd = c->d_tgt_sd.p;
+    pools.tgt_s4 = c->d_tgt_s4.p; pools.tgt_sd = c->d_tgt_sd.p; pools.padded_rows = layout;
     const bool keep_all_unculled = std::getenv("L3D_KEEPALL_NO_CULL") != nullptr;   // diagnostic switch (A/B; read per call)
     // (keep-all mode: the count pass takes the culled walk, the fill pass streams -- k_match.hip)
     if (c->brute || !maxM || mode == 2 || (mode == 1 && keep_all_unculled)) pools.cull = nullptr;
@@ -789,7 +807,8 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         static const int no_order = [] { const char* e = std::getenv("L3D_MATCH_ORDER"); return e && std::atoi(e) == 0; }();
         // longest-first launch order (k_order_items) where the launch has one to three items per wave slot (fewer: all
         // start at once; more: the tail is short against the whole) -- C1: kernel 1.08 -> 1.03 ms; C2 / C4: +6 % with it
-        if (!no_order && n_work > kMatchOrderMinItems && n_work <= kMatchOrderMaxItems) {
+        // (tile form: four to eight times as many, shorter items, the widest class of every pair first: list order)
+        if (!tile && !no_order && n_work > kMatchOrderMinItems && n_work <= kMatchOrderMaxItems) {
             L3D_HIP_CHECK(c->d_item_bucket.reserve(n_work)); L3D_HIP_CHECK(c->d_item_order.reserve(n_work));
             if (!c->d_order_done.p) {            // zeroed once: the kernel re-arms it
                 L3D_HIP_CHECK(c->d_order_done.reserve(1));
@@ -799,7 +818,8 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
             pools.order_done = c->d_order_done.p;
             pools.w_base = c->cull[first].w_item0; pools.cost_max = maxMt;
         }
-        L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, c->stream));
+        // (the source pools are laid out for the form this launch takes: pools.padded_rows)
+        L3D_HIP_CHECK(launch_cull_prepare(c->d_views.p, c->d_pairs.p, first, count, maxM, pools, layout, c->stream));
         L3D_HIP_CHECK(launch_order_items(c->d_pairs.p, first, count, maxMt, pools, (uint32_t)n_work, c->stream));
     }
     if (c->ev_on(4)) L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
@@ -828,7 +848,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         L3D_HIP_CHECK(launch_queue_all_rows(c->d_pairs.p, first, count, maxMs, c->pairs[first].row_off, of, c->stream));
     } else
     L3D_HIP_CHECK(launch_match_pairs(mode, c->brute, c->d_views.p, c->d_pairs.p, c->d_work.p, (uint32_t)n_work, maxK,
-                                     c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, of, ix16, c->stream));
+                                     c->d_slots.p, c->d_row_counts.p, c->epipolar_overlap, pools, of, ix16, tile, c->stream));
     if (c->ev_on(5)) L3D_HIP_CHECK(hipEventRecord(c->ev[5], c->stream));
     if (mode == 0) {
         L3D_HIP_CHECK(launch_match_tied_rows(c->d_views.p, c->d_pairs.p, c->d_slots.p, maxK, c->epipolar_overlap, of, pools,

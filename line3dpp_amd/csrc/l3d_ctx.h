@@ -183,8 +183,10 @@ struct l3d_ctx {
     UploadTag up_views, up_pairs, up_cull, up_seg_base, up_ltab;   // what the device tables hold (upload_table)
     std::vector<unsigned char> begin_sig; bool begin_sig_valid = false;   // what the pair list was built from (l3d_match_begin)
     uint64_t cull_tot[4] = {0, 0, 0, 0};            // pool sizes of the culling set-up of that list
+    uint32_t layout_rows = 0;                       // padded class layout of the source pools: rows per work item (0: Ms rows per pair, legacy)
+    uint32_t tile_rows = 0;                         // rows per work item of the bounded-kNN launches of this call (0: the row form; k_match.hip)
     uint64_t pairs_version = 0;                     // bumped whenever the pair list on the device changes
-    struct { uint64_t version = ~0ull; uint32_t first = 0, count = 0; const void* dev = nullptr; } work_key;   // d_work holds the items of these pairs
+    struct { uint64_t version = ~0ull; uint32_t first = 0, count = 0, rows = 0; const void* dev = nullptr; } work_key;   // d_work holds the items of these pairs
     PinnedBuf<uint32_t> h_segb;
     const void* gseg_view_for = nullptr;            // d_gseg_view was filled for the seg_base the device holds
     bool timing_pending = false;                    // phase-A events recorded but not read yet
@@ -223,11 +225,12 @@ struct l3d_ctx {
     uint32_t lp_ecap = 0, lp_hcap = 0, lp_scap = 0, lp_ccap = 0, huge_cap = 0;
     uint32_t lp_attempts = 0;
     bool huge_skip = false, huge_ran = true;        // k_lists_huge left out while the passes hand it no lists
+    bool list4_skip = false, list4_ran = true;      // the same for the four-wave tier k_lists<4>
     // The pool capacities (and huge_skip) are kept across calls, separately for unsharded calls [0] and for calls whose
     // list pass is sharded over ranks [1]: the slabs the ranks all-gather must have one size on every rank, and the
     // sharded set only ever changes by decisions every rank takes alike (check_pass sees all ranks' counters), whatever
     // unsharded calls a rank's context has served in between.  caps_mode = the set the members above hold.
-    struct PoolCaps { uint32_t e = 0, h = 0, s = 0, c = 0, huge = 0; bool huge_skip = false; } caps_saved[2];
+    struct PoolCaps { uint32_t e = 0, h = 0, s = 0, c = 0, huge = 0; bool huge_skip = false, list4_skip = false; } caps_saved[2];
     int caps_mode = 0;
     uint32_t chain_need = 8, chain_enqueued = 10;   // chain launches that changed something last time / enqueued this time
     // list pass sharded over ranks (l3d_lists_shard): world size of the running call, slabs received

@@ -8,9 +8,23 @@ struct l3d_cledge;
 
 namespace l3d {
 
+extern std::atomic<uint64_t> g_knn_replay_calls;      // l3d_api.hip
 extern std::atomic<uint64_t> g_csr_global_launches;   // k_lists.hip, test hook read through l3d_debug_counter
 
-constexpr int kMatchRows = 64;   // source rows per work item of k_match_pairs (one wave64)
+constexpr int kMatchRows = 64;   // source rows per work item of k_match_pairs (one wave64): the ROW form (keep-all modes, brute-force
+                                 // hook, the accelerator seam, L3D_MATCH_TILE=0)
+// The TILE form of the bounded-kNN kernel (round 5): a work item is R = 16 or 32 source rows of ONE width class, a lane is
+// a (row, target) pair -- 64 / R targets per step -- and the targets come out of an LDS FIFO of the records whose band
+// meets the hull of the R rows (k_match.hip).  k_cull_prepare lays the rows of a pair out class by class, every class
+// padded to a multiple of R (kEmpty rows), in a region of tile_src_cap(Ms, R) positions: the host's work list is that
+// region cut into items of R positions, whatever the class sizes turn out to be on the device.
+constexpr uint32_t kTileClasses = 5;   // unbounded band | width beyond 1/16, 1/32, 1/64 of the target image | narrow
+__host__ __device__ constexpr uint32_t tile_src_cap(uint32_t Ms, uint32_t R) {
+    return ((Ms + kTileClasses * (R - 1) + R - 1) / R) * R;
+}
+uint32_t match_tile_rows(int mode, bool brute);   // 0: row form; 16 / 32: tile form (L3D_MATCH_TILE overrides)
+uint32_t match_layout_rows(int mode, bool brute); // rows per work item of the padded class layout: the tile form's R, 64 for the
+                                                  // row form (L3D_MATCH_CLASSES=0: 0 = its legacy layout without padding)
 struct WorkItem {
     uint32_t pair;  // index into the pair array
     uint32_t src0;  // first source row (position in the pair's row order) of the work item
@@ -39,7 +53,7 @@ struct PairCull {
 constexpr uint32_t kSortedCopyMinSegs = 4096;
 struct CullPools {
     const PairCull* cull;      // [n_pairs] or nullptr
-    uint32_t* src_perm;        // [sum Ms] source row visited at sorted position i
+    uint32_t* src_perm;        // [sum Ms] source row visited at sorted position i (tile form: [sum tile_src_cap], kEmpty = padding)
     float2* src_band;          // [sum Ms] its tau band (lo, hi)
     uint32_t* tgt_perm;        // [sum Mt] target segment at sorted position i
     float4* tgt_sf;            // [sum Mt] SegF records in sorted order
@@ -56,6 +70,8 @@ struct CullPools {
     // order: gathers by original index miss the L2s on large views -- C4 read 132 x its segment records)
     float4* tgt_s4;            // [sum Mt] raw segments (x1,y1,x2,y2)
     SegD32* tgt_sd;            // [sum Mt] rays and plane normal in float (the depth decision's share of SegX, l3d_dev.h SegD32)
+    uint32_t padded_rows;      // 0: src_perm / src_band hold Ms rows per pair (row form, legacy classes); R: the padded class layout
+                               // of tile_src_cap(Ms, R) positions per pair (tile form: R = 16 / 32; row form with classes: 64)
 };
 constexpr uint32_t kOrderBuckets = 1024;
 constexpr uint32_t kCullLdsSegs = 16384;   // LDS sort capacity of k_cull_prepare (larger views sort in global memory)
@@ -78,18 +94,18 @@ struct OrientFuse {
 };
 
 // ---- k_match.hip ----
-size_t match_lds_bytes(int mode, uint32_t K, bool ix16 = false, uint32_t waves = 1, bool brute = false);
+size_t match_lds_bytes(int mode, uint32_t K, bool ix16 = false, uint32_t waves = 1, bool brute = false, uint32_t tile_rows = 0);
 constexpr uint32_t kMatchOrderMaxItems = 16384;   // launches up to this many work items: two waves per item
 constexpr uint32_t kMatchOrderMinItems = 3584;    // ... and, from this many on (more waves than wave slots), longest-first order
 uint32_t match_waves_per_group(int mode, bool brute, uint32_t nwork);   // waves that share one 64-row work item of k_match_pairs
 hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
-                               uint32_t max_M, CullPools pools, hipStream_t stream);
+                               uint32_t max_M, CullPools pools, uint32_t tile_rows, hipStream_t stream);
 hipError_t launch_order_items(const PairDesc* pairs, uint32_t first, uint32_t count, uint32_t max_Mt, CullPools pools,
                               uint32_t nwork, hipStream_t stream);
 hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const PairDesc* pairs,
                               const WorkItem* work, uint32_t nwork, uint32_t maxK, Slot* slots,
                               uint32_t* row_counts, float thr, CullPools pools, OrientFuse of, bool ix16,
-                              hipStream_t stream);
+                              uint32_t tile_rows, hipStream_t stream);
 // rows flagged by the match kernel (equal overlaps): the reference's priority_queue order, replayed; scratch = one
 // region of 2 * scratch_stride (stride >= max Mt) packed entries per workgroup of match_tied_grid(stride); cp: the culling pools of the
 // match launch (cp.cull == nullptr: every target is visited)
@@ -111,7 +127,7 @@ hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t ma
 
 // ---- k_lists.hip: the sparse phase B (l3d_lists.h) ----
 struct InvRec; struct ListPools; struct PairCsr;
-struct HugeScratchArgs { float* f32; uint32_t* u32; uint64_t* u64; uint32_t cap; uint32_t mean_list; uint32_t run_huge; };   // [2 cap] [3 cap] [cap]; mean list length (estimate)
+struct HugeScratchArgs { float* f32; uint32_t* u32; uint64_t* u64; uint32_t cap; uint32_t mean_list; uint32_t run_huge; uint32_t run_tier4; };   // [2 cap] [3 cap] [cap]; mean list length (estimate); which of the rarely needed tiers are launched
 hipError_t launch_scan64(const unsigned long long* in, uint32_t n, unsigned long long* out, unsigned long long* tmp,
                          unsigned long long* total, hipStream_t st);
 // the inverse hypotheses of every pair that hands matches to a later view, sorted by target segment (counting sort per

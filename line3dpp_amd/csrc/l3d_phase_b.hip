@@ -191,14 +191,15 @@ static ZeroLayout zero_layout(uint32_t V, uint32_t G) {
 
 static int lists_prepare(l3d_ctx* c, int caps_mode) {
     if (caps_mode != c->caps_mode) {   // the capacities of the other kind of call (l3d_ctx.h: caps_saved)
-        c->caps_saved[c->caps_mode] = l3d_ctx::PoolCaps{c->lp_ecap, c->lp_hcap, c->lp_scap, c->lp_ccap, c->huge_cap, c->huge_skip};
+        c->caps_saved[c->caps_mode] = l3d_ctx::PoolCaps{c->lp_ecap, c->lp_hcap, c->lp_scap, c->lp_ccap, c->huge_cap, c->huge_skip, c->list4_skip};
         const l3d_ctx::PoolCaps& pc = c->caps_saved[caps_mode];
         c->lp_ecap = pc.e; c->lp_hcap = pc.h; c->lp_scap = pc.s; c->lp_ccap = pc.c; c->huge_cap = pc.huge; c->huge_skip = pc.huge_skip;
+        c->list4_skip = pc.list4_skip;
         c->caps_mode = caps_mode;
     }
     // a sharded list pass always runs k_lists_huge: whether a rank's views hold a list for it is not known to the other
     // ranks before the pass, and a rank that had to repeat the pass alone would leave the collectives of the others
-    if (caps_mode == 1) c->huge_skip = false;
+    if (caps_mode == 1) { c->huge_skip = false; c->list4_skip = false; }
     hipStream_t st = c->stream;
     const uint32_t V = (uint32_t)c->order.size(), P = (uint32_t)c->pairs.size();
     // global segment ids
@@ -363,8 +364,8 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
     const uint32_t mean_list = c->n_ents ? (uint32_t)(c->n_ents / std::max<uint32_t>(G, 1))
                                          : (uint32_t)(1.5 * (double)c->n_slots / std::max<uint32_t>(G, 1));
     const HugeScratchArgs hsa{c->d_huge_f32.p, c->d_huge_u32.p, (uint64_t*)c->d_huge_u64.p, c->huge_cap, mean_list,
-                              c->huge_skip ? 0u : 1u};
-    c->huge_ran = !c->huge_skip;
+                              c->huge_skip ? 0u : 1u, c->list4_skip ? 0u : 1u};
+    c->huge_ran = !c->huge_skip; c->list4_ran = !c->list4_skip;
     uint32_t max_M = 0;
     for (uint32_t vi = v0; vi < v0 + nv; ++vi) max_M = std::max(max_M, c->order[vi]->M);
     L3D_HIP_CHECK(launch_lists(v0, nv, max_M, c->d_views.p, c->d_pairs.p, lviews, opairs, ipairs, c->d_gseg_view.p,
@@ -471,8 +472,9 @@ static int check_pass(l3d_ctx* c) {
     }
     if (fl[1]) return fail(L3D_ERR_LIMIT, "a 2D segment has more than 65535 match hypotheses");
     // lists for the global-memory kernel although its launch was left out: repeat with it (and keep it from now on)
-    const bool huge_missed = fl[5] && !c->huge_ran;
+    const bool huge_missed = (fl[5] && !c->huge_ran) || (fl[4] && !c->list4_ran);   // (the same for the four-wave tier: flags[4])
     c->huge_skip = fl[5] == 0 && c->shard_world <= 1;
+    c->list4_skip = fl[4] == 0 && c->shard_world <= 1;
     if (huge_missed) { ++c->tm.pool_retries; return kRetry; }
     if (fl[3]) return fail(L3D_ERR_HIP, "internal error: hypothesis counters and slot flags disagree");
     if (fl[0] || fl[2]) {

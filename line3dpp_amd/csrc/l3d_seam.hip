@@ -222,7 +222,7 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
             L3D_HIP_CHECK(ts4.reserve(Mt)); L3D_HIP_CHECK(tsd.reserve(Mt));
             pools = CullPools{dc.p, sperm.p, sband.p, tperm.p, tsf.p, tband.p, cband.p, ckeys.p};
             pools.tgt_s4 = ts4.p; pools.tgt_sd = tsd.p;
-            L3D_HIP_CHECK(launch_cull_prepare(dv.p, dp.p, 0, 1, std::max(Ms, Mt), pools, 0));
+            L3D_HIP_CHECK(launch_cull_prepare(dv.p, dp.p, 0, 1, std::max(Ms, Mt), pools, 0u, 0));   // (the seam keeps the row form of the kernel)
         }
         // the kernel also applies the orientation filter (slot flags) and writes the inverse-target stream: scratch here
         L3D_HIP_CHECK(inv_tgt.reserve((size_t)Ms * pd.K));
@@ -232,7 +232,7 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         OrientFuse of{inv_tgt.p, 0u, OrientThr{-1.0, 1.0}, tie_count.p, tie_list.p, Ms, tie_count.p + 1, tie_count.p + 2};
         orientation_thresholds(of.thr.lo, of.thr.hi);
         L3D_HIP_CHECK(launch_match_pairs(0, false, dv.p, dp.p, dw.p, (uint32_t)work.size(), pd.K, ds.p, nullptr, thr,
-                                         pools, of, Mt < 65536u && pd.K < 65536u, 0));
+                                         pools, of, Mt < 65536u && pd.K < 65536u, 0u, 0));
         // rows with equal overlaps: the reference's priority_queue order (line3D.cc:982-1007)
         L3D_HIP_CHECK(launch_match_tied_rows(dv.p, dp.p, ds.p, pd.K, thr, of, pools, tie_heap.p, std::max(Mt, 1u), 0));
         L3D_HIP_CHECK(hipDeviceSynchronize());

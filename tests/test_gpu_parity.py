@@ -988,8 +988,25 @@ def test_sharded_tail_emulated_on_one_gpu_at_c2_slice_size(world):
     torch.cuda.synchronize()
     assert moved > 0
     assert [g.tailShardCommit() for g in ctxs] == [0] * world
+    # the affinity fill sharded by the same views (l3d_affinity_shard_begin / _finish): every context computes the
+    # similarities of ITS views' surviving matches, the float parts are copied where the exchange would put them
+    aparts = [g.affinityShardBegin(r, world) for r, g in enumerate(ctxs)]
+    assert all(a is not None and a[1] == 4 and a[2] == aparts[0][2] for a in aparts), "every rank derives the same parts"
+    assert [n for _, n in aparts[0][2]] == [n for n, _ in counts]
+    n_all = sum(n for _, n in aparts[0][2])
+    sims = [dist.device_tensor(a[0], 4 * n_all, dev) for a in aparts]
+    for q in range(world):                           # poison what a rank did not compute: a part that never arrives shows
+        for r, (f, n) in enumerate(aparts[0][2]):
+            if q != r and n:
+                sims[q][4 * f:4 * (f + n)].fill_(0xFF)
+    for r, (f, n) in enumerate(aparts[0][2]):
+        for q in range(world):
+            if q != r and n:
+                sims[q][4 * f:4 * (f + n)].copy_(sims[r][4 * f:4 * (f + n)])
+    torch.cuda.synchronize()
+    assert all(g.affinityShardFinish() for g in ctxs)
+    assert ctxs[0].affinityShardBegin(0, world + 1) is None and ctxs[0].affinityShardFinish() is False   # wrong world; no open shard
     for g in ctxs:
-        assert g.computeAffinity()
         for v in sc.views:
             a, ao = g.matches(v.cam); b, bo = ref.matches(v.cam)
             assert np.array_equal(ao, bo) and a.tobytes() == b.tobytes()
@@ -1002,6 +1019,8 @@ def test_sharded_tail_emulated_on_one_gpu_at_c2_slice_size(world):
     g = ctxs[0]
     assert g.matchBegin() and g.tailShardCommit() != 0
     assert g.matchImages()                           # the failed call left a clean context
+    assert g.affinityShardBegin(0, world) is None    # (a single-context call has no sharded tail behind it)
+    assert g.computeAffinity()
 
 
 def test_txt_writer_matches_accessor_and_reference_writer(tmp_path):
