@@ -988,11 +988,13 @@ __global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views,
 
 // ---- the chain as a monotone fixed point ------------------------------------------------------------------------
 // grid (header blocks, pools).  Launch s runs only if launch s-1 changed something (changed[] is zeroed by the host).
-// Inside a launch an undecided header looks again a few times: all headers are resident at once, so a bit set by
-// another thread (device-scope store / load, the L2 is the meeting point) travels down a dependency chain within the
-// same launch instead of one launch per link.
+// Inside a launch an undecided header may look again (L3D_SWEEP_LOOKS): all headers are resident at once, so a bit set by
+// another thread (device-scope store / load, the L2 is the meeting point) can travel down a dependency chain within the
+// same launch.  Measured in round 5 (profiles/r05_ab_phase_b.txt): it does not pay -- `finish` of C1 0.571 / 0.580 / 0.641 /
+// 0.717 ms with 1 / 2 / 6 / 16 looks (a look re-reads the edges of every undecided header and sleeps): one look, and the
+// launches the last call needed + 1.
 #ifndef L3D_SWEEP_LOOKS
-#define L3D_SWEEP_LOOKS 2
+#define L3D_SWEEP_LOOKS 1
 #endif
 constexpr uint32_t kSweepLooks = L3D_SWEEP_LOOKS;
 __global__ void k_chain_sweep(const ListPools lp, uint8_t* __restrict__ positive, uint32_t* __restrict__ changed,
@@ -1252,13 +1254,18 @@ hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, uint32
     return hipGetLastError();
 }
 
+#ifndef L3D_LISTS2_GRID
+#define L3D_LISTS2_GRID 16384   // fixed grid of the two-wave tier (its workgroups stride over the hand-over list)
+#endif
 hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev* views, const PairDesc* pairs,
                         const ListView* lviews, const OutPair* opairs, const InPair* ipairs, const uint32_t* gseg_view,
                         const uint32_t* poff, const uint32_t* inv, const Slot* slots, uint32_t uniform_K,
                         SimConst sc, ListPools lp, uint32_t* seg_of_g, HugeScratchArgs hsa, hipStream_t st) {
     if (!nv || !max_M) return hipSuccess;
     // the one-wave tier stages 128 hypotheses (8 waves per SIMD) unless the scene's lists are long on average
-    const bool wide = hsa.mean_list > 96;
+    // (L3D_LISTS_WIDE=0|1: A/B switch of the staging width, read per launch)
+    const char* wide_env = std::getenv("L3D_LISTS_WIDE");
+    const bool wide = wide_env ? std::atoi(wide_env) != 0 : hsa.mean_list > 96;
 #define L3D_LISTS(B)                                                                                                       \
     do {                                                                                                                   \
         const size_t lds1 = ListCfg<1, B>::BYTES, lds2 = ListCfg<2, B>::BYTES, lds4 = ListCfg<4, B>::BYTES;                \
@@ -1274,7 +1281,7 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
                                gseg_view, poff, inv, slots, uniform_K, lp, v0 + a);                                        \
         }                                                                                                                  \
         /* lists beyond one wave's capacity: two waves up to 2x, four up to 4x (fixed grids over the hand-over lists) */   \
-        hipLaunchKernelGGL((k_lists<2, B>), dim3(16384), dim3(128), lds2, st, views, pairs, lviews, opairs, ipairs,        \
+        hipLaunchKernelGGL((k_lists<2, B>), dim3(L3D_LISTS2_GRID), dim3(128), lds2, st, views, pairs, lviews, opairs, ipairs, \
                            gseg_view, poff, inv, slots, uniform_K, lp, 0u);                                                \
         /* (the four-wave tier is left out while the passes hand it no list -- C1: an empty grid of 16 us --, like      */    \
         /* k_lists_huge below: a pass that then does hand one over is repeated with it, flags[4], check_pass)           */    \

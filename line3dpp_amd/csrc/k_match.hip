@@ -91,6 +91,8 @@ struct Lds {
     L3D_LDS volatile idx_t* top_ix;    // [kBlock*K]
     L3D_LDS v4f* fifo_rec;             // tile form: [kFifo] records of the targets whose band meets the wave's rows' hull
     L3D_LDS uint32_t* fifo_pos;        // tile form: [kFifo] their walk-order positions
+    L3D_LDS v4f* row_sd;               // row cache: [rows][3] = SegD32 of the item's source rows, seg4.xyz in its padding
+    L3D_LDS float* row_w;              // row cache: [rows] seg4.w
     static constexpr idx_t kTie = (idx_t)((idx_t)1 << (8 * sizeof(idx_t) - 1));
 };
 
@@ -98,10 +100,12 @@ struct Lds {
 // base of the dynamic LDS is 16-byte aligned, and so are its 16-byte records)
 template <bool IX16>
 __device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K, uint32_t waves, bool two_rings, uint32_t rows = kBlock,
-                                           bool fifo = false) {
+                                           bool fifo = false, bool row_cache = false) {
     typedef typename IdxT<IX16>::type idx_t;
     Lds<IX16> l;
     l.fifo_rec = (L3D_LDS v4f*)base; if (fifo) base += kFifo * sizeof(v4f);
+    l.row_sd = (L3D_LDS v4f*)base; if (row_cache) base += (size_t)rows * 3 * sizeof(v4f);
+    l.row_w = (L3D_LDS float*)base; if (row_cache) base += (size_t)rows * sizeof(float);
     l.fifo_pos = (L3D_LDS uint32_t*)base; if (fifo) base += kFifo * sizeof(uint32_t);
     l.ring = (L3D_LDS volatile uint32_t*)base; base += waves * ring_entries(two_rings, waves) * sizeof(uint32_t);
     l.ring2 = (L3D_LDS volatile uint32_t*)base; if (two_rings) base += waves * kRing2 * sizeof(uint32_t);
@@ -194,6 +198,9 @@ __device__ __forceinline__ void store_inverse_target(const OrientFuse& of, uint6
 #ifndef L3D_MATCH_WAVES
 #define L3D_MATCH_WAVES (TILE ? L3D_TILE_WAVES : (WPG == 2 ? 7 : 6))
 #endif
+#ifndef L3D_ROW_CACHE
+#define L3D_ROW_CACHE 1   // 0: never stage the source rows' records in LDS (A/B)
+#endif
 #ifndef L3D_TILE_WAVES
 #define L3D_TILE_WAVES 6
 #endif
@@ -238,7 +245,14 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     static_assert(TILE == 0 || ((TILE == 16 || TILE == 32) && STAGED && WPG == 1), "the tile form: bounded kNN, staged, one wave per item");
     constexpr uint32_t ROWS = TILE ? (uint32_t)TILE : (uint32_t)kBlock;   // rows of a work item
     constexpr uint32_t TPS = 64u / ROWS;                                  // targets per step of the tile form's walk
-    Lds<IX16> L = carve<IX16>((L3D_LDS char*)smem, MODE == 0 ? K : 0, WPG, STAGED, ROWS, TILE != 0);
+    // row cache (two waves per item only: with one wave per item its 3.3 KiB would cost a wave of occupancy): what the two
+    // candidate stages read of a SOURCE row -- the float depth record and the raw segment -- is staged in LDS once per
+    // work item instead of being gathered from the view's arrays by every candidate
+    // (C1: kernel 0.601 -> 0.585 ms; not for launches that do not fill the machine -- C0 0.179 -> 0.182: the launcher sets
+    // CullPools::row_cache by the number of work items; profiles/r05_ab_match_forms.txt)
+    constexpr bool ROWCACHE_BUILT = L3D_ROW_CACHE != 0 && STAGED && WPG == 2 && TILE == 0;
+    const bool ROWCACHE = ROWCACHE_BUILT && cp.row_cache != 0;
+    Lds<IX16> L = carve<IX16>((L3D_LDS char*)smem, MODE == 0 ? K : 0, WPG, STAGED, ROWS, TILE != 0, ROWCACHE);
     // wave of the workgroup -- through readfirstlane: the compiler must know it is wave-uniform, or the chunk loop
     // below (its mask depends on q) is compiled as a divergent loop with vector addresses
     const uint32_t q = WPG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;
@@ -284,6 +298,14 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     float e1x = 0, e1y = 0, e1z = 0, e2x = 0, e2y = 0, e2z = 0;
     float thrL = thr;
     bool live = false;               // dead lane (row >= Ms or degenerate epipolar line): never a candidate
+    if (ROWCACHE && q == 0) {        // lane = row: its float depth record and raw segment (zeros for a dead row: never read)
+        SegD32 sd{}; float4 s4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (active) { sd = vs.segd32[src]; s4 = vs.seg4[src]; }
+        L.row_sd[3 * tid + 0] = v4f{sd.r1[0], sd.r1[1], sd.r1[2], sd.r2[0]};
+        L.row_sd[3 * tid + 1] = v4f{sd.r2[1], sd.r2[2], sd.n[0], sd.n[1]};
+        L.row_sd[3 * tid + 2] = v4f{sd.n[2], s4.x, s4.y, s4.z};
+        L.row_w[tid] = s4.w;
+    }
     if (active) {
         const float4 s = vs.seg4[src];
         d3 e1 = mul33(F, d3{(double)s.x, (double)s.y, 1.0});
@@ -374,7 +396,12 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t sg = __shfl(src, sl);   // the ring of a wave only holds rows of that wave
         bool pass = false;
         if (has) {
-            const SegD32 sd = vs.segd32[sg];
+            SegD32 sd;
+            if (ROWCACHE) {
+                const v4f a = L.row_sd[3 * sl + 0], b = L.row_sd[3 * sl + 1], c = L.row_sd[3 * sl + 2];
+                sd.r1[0] = a.x; sd.r1[1] = a.y; sd.r1[2] = a.z; sd.r2[0] = a.w; sd.r2[1] = b.x; sd.r2[2] = b.y;
+                sd.n[0] = b.z; sd.n[1] = b.w; sd.n[2] = c.x;
+            } else sd = vs.segd32[sg];
             const SegD32 td = tsd[target_index(tp)];
             const float B[3] = {Bx, By, Bz};
             bool certain;
@@ -416,7 +443,10 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const double* Fp = F;
 #endif
         if (has) {
-            const float4 s4 = vs.seg4[sg], t4 = ts4[target_index(tg)];
+            float4 s4;
+            if (ROWCACHE) { const v4f c = L.row_sd[3 * sl + 2]; s4 = make_float4(c.y, c.z, c.w, L.row_w[sl]); }
+            else s4 = vs.seg4[sg];
+            const float4 t4 = ts4[target_index(tg)];
             const float ov = exact_overlap(Fp, s4.x, s4.y, s4.z, s4.w, t4.x, t4.y, t4.z, t4.w, fastm);
             // a full row only admits overlaps that reach its K-th best (minov == thr while the row is not full); an overlap
             // EQUAL to the K-th best goes on to the insertion: a tie at the kNN-th place flags the row for the exact replay
@@ -955,13 +985,18 @@ bool match_staged(int mode, bool brute) {
     static const bool off = [] { const char* e = std::getenv("L3D_MATCH_STAGED"); return e && std::atoi(e) == 0; }();
     return mode == 0 && !brute && !off;
 }
-size_t match_lds_bytes(int mode, uint32_t K, bool ix16, uint32_t waves, bool brute, uint32_t tile_rows) {
+bool match_row_cache(int mode, bool brute, uint32_t nwork, uint32_t tile_rows) {
+    return L3D_ROW_CACHE != 0 && match_staged(mode, brute) && !tile_rows && match_waves_per_group(mode, brute, nwork) == 2 &&
+           nwork > kMatchOrderMinItems;
+}
+size_t match_lds_bytes(int mode, uint32_t K, bool ix16, uint32_t waves, bool brute, uint32_t tile_rows, bool row_cache) {
     const size_t ib = ix16 ? 2 : 4;
     const bool staged = match_staged(mode, brute);
     if (tile_rows)   // (one wave per item: FIFO + the two rings + the tables of R rows)
         return (size_t)kFifo * (sizeof(v4f) + 4) + (size_t)(ring_entries(true, 1) + kRing2) * 4 + 2 * (size_t)tile_rows * 4 +
                2 * (size_t)tile_rows * ib + (size_t)tile_rows * K * (4 + ib);
-    return (size_t)waves * (ring_entries(staged, waves) + (staged ? kRing2 : 0)) * 4 + 2 * kBlock * 4 + 2 * kBlock * ib +
+    const size_t rc_bytes = (row_cache && staged && waves == 2) ? (size_t)kBlock * (3 * sizeof(v4f) + 4) : 0;
+    return rc_bytes + (size_t)waves * (ring_entries(staged, waves) + (staged ? kRing2 : 0)) * 4 + 2 * kBlock * 4 + 2 * kBlock * ib +
            (mode == 0 ? (size_t)kBlock * K * (4 + ib) : 0);
 }
 
@@ -969,7 +1004,9 @@ size_t match_lds_bytes(int mode, uint32_t K, bool ix16, uint32_t waves, bool bru
 // brute-force hook, the single-stage A/B switch -- keeps the row form).  L3D_MATCH_TILE = 0 | 16 | 32 overrides.
 uint32_t match_tile_rows(int mode, bool brute) {
     if (!match_staged(mode, brute)) return 0;
-    static const int forced = [] { const char* e = std::getenv("L3D_MATCH_TILE"); return e ? std::atoi(e) : -1; }();
+    // (read per call -- once per l3d_match_begin --, not latched: a test switches forms inside one process)
+    const char* e = std::getenv("L3D_MATCH_TILE");
+    const int forced = e ? std::atoi(e) : -1;
     if (forced == 0 || forced == 16 || forced == 32) return (uint32_t)forced;
     return L3D_TILE_DEFAULT;
 }
@@ -977,7 +1014,8 @@ uint32_t match_layout_rows(int mode, bool brute) {
     if (mode != 0 || brute) return 0;
     const uint32_t t = match_tile_rows(mode, brute);
     if (t) return t;
-    static const int classes = [] { const char* e = std::getenv("L3D_MATCH_CLASSES"); return e ? std::atoi(e) : L3D_ROW_CLASSES_DEFAULT; }();
+    const char* e = std::getenv("L3D_MATCH_CLASSES");
+    const int classes = e ? std::atoi(e) : L3D_ROW_CLASSES_DEFAULT;
     return classes ? (uint32_t)kMatchRows : 0u;
 }
 
@@ -1000,9 +1038,11 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
     if (mode == 0 && (!of.inv_tgt || !of.tie_count || !of.tie_list)) return hipErrorInvalidValue;   // MODE 0 always fuses
     const uint32_t grid = ((nwork + 7) / 8) * 8;
     if (!(mode == 0 && !brute)) ix16 = false;       // the compact layout is only instantiated for the hot variant
-    if (tile_rows && tile_rows != match_tile_rows(mode, brute)) return hipErrorInvalidValue;   // (the work list was cut for it)
+    if (tile_rows && (tile_rows != 16u && tile_rows != 32u)) return hipErrorInvalidValue;
+    if (tile_rows && !match_staged(mode, brute)) return hipErrorInvalidValue;   // (the tile form exists for the staged bounded-kNN kernel)
     const uint32_t wpg = tile_rows ? 1u : match_waves_per_group(mode, brute, nwork);
-    const size_t lds = match_lds_bytes(mode, maxK, ix16, wpg, brute, tile_rows);
+    pools.row_cache = match_row_cache(mode, brute, nwork, tile_rows) ? 1u : 0u;
+    const size_t lds = match_lds_bytes(mode, maxK, ix16, wpg, brute, tile_rows, pools.row_cache != 0);
 #define L3D_LAUNCH(M, B, X, W, S, T)                                                                          \
     do {                                                                                                      \
         hipError_t e = hipFuncSetAttribute((const void*)k_match_pairs<M, B, X, W, S, T>,                      \

@@ -677,7 +677,8 @@ static int match_begin_body(l3d_ctx* c) {
         size_t n_work = 0; uint32_t maxMt = 0;
         for (auto& pd : c->pairs) { n_work += match_items(c, pd.Ms); maxMt = std::max(maxMt, pd.Mt); }
         const uint32_t wpg = match_waves_per_group(0, c->brute, (uint32_t)std::min<size_t>(n_work, 0xFFFFFFFFu));
-        auto fits = [&](uint32_t K) { return match_lds_bytes(0, K, maxMt < 65536u && K < 32768u && !c->brute, wpg, c->brute, c->tile_rows) <= 160 * 1024; };
+        auto fits = [&](uint32_t K) { return match_lds_bytes(0, K, maxMt < 65536u && K < 32768u && !c->brute, wpg, c->brute, c->tile_rows,
+                                                           match_row_cache(0, c->brute, (uint32_t)std::min<size_t>(n_work, 0xFFFFFFFFu), c->tile_rows)) <= 160 * 1024; };
         // beyond that, every row takes the exact replay path (k_match_tied_rows): slower per row, any kNN <= 4096
         c->knn_replay = !fits((uint32_t)c->kNN);
         if (c->knn_replay) l3d::g_knn_replay_calls.fetch_add(1, std::memory_order_relaxed);
@@ -781,12 +782,13 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         maxMt = std::max(maxMt, pd.Mt);
     }
     const bool replay_all = mode == 0 && c->knn_replay;   // kNN beyond the LDS tables: every row through k_match_tied_rows
-    if (!replay_all && match_lds_bytes(mode, maxK, false, match_waves_per_group(mode, c->brute, (uint32_t)n_work), c->brute, tile) > 160 * 1024)
+    if (!replay_all && match_lds_bytes(mode, maxK, false, match_waves_per_group(mode, c->brute, (uint32_t)n_work), c->brute, tile,
+                                       match_row_cache(mode, c->brute, (uint32_t)n_work, tile)) > 160 * 1024)
         return fail(L3D_ERR_LIMIT, "kNN too large for the LDS top-K table");
     L3D_HIP_CHECK(c->d_work.reserve(n_work));
     // the work list of these pairs is on the device already when the pair list has not changed since it was sent
     if (!(c->work_key.version == c->pairs_version && c->work_key.first == first && c->work_key.count == count &&
-          c->work_key.dev == (const void*)c->d_work.p && c->work_key.rows == rows_per_item)) {
+          c->work_key.dev == (const void*)c->d_work.p && c->work_key.rows == rows_per_item && c->work_key.items == n_work)) {
         L3D_HIP_CHECK(c->h_work.reserve(n_work));
         WorkItem* work = c->h_work.p;
         size_t w = 0;
@@ -794,7 +796,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
             for (uint32_t k = 0, n = items_of(c->pairs[p].Ms); k < n; ++k) work[w++] = WorkItem{p, k * rows_per_item};
         L3D_HIP_CHECK(hipMemcpyAsync(c->d_work.p, work, n_work * sizeof(WorkItem), hipMemcpyHostToDevice, c->stream));
         c->work_key.version = c->pairs_version; c->work_key.first = first; c->work_key.count = count;
-        c->work_key.dev = c->d_work.p; c->work_key.rows = rows_per_item;
+        c->work_key.dev = c->d_work.p; c->work_key.rows = rows_per_item; c->work_key.items = n_work;
     }
     if (c->ev_on(8)) L3D_HIP_CHECK(hipEventRecord(c->ev[8], c->stream));
     CullPools pools{c->d_cull.p, c->d_src_perm.p, c->d_src_band.p, c->d_tgt_perm.p, c->d_tgt_sf.p, c->d_tgt_band.p,

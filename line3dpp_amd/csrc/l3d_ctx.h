@@ -186,7 +186,7 @@ struct l3d_ctx {
     uint32_t layout_rows = 0;                       // padded class layout of the source pools: rows per work item (0: Ms rows per pair, legacy)
     uint32_t tile_rows = 0;                         // rows per work item of the bounded-kNN launches of this call (0: the row form; k_match.hip)
     uint64_t pairs_version = 0;                     // bumped whenever the pair list on the device changes
-    struct { uint64_t version = ~0ull; uint32_t first = 0, count = 0, rows = 0; const void* dev = nullptr; } work_key;   // d_work holds the items of these pairs
+    struct { uint64_t version = ~0ull; uint32_t first = 0, count = 0, rows = 0; size_t items = 0; const void* dev = nullptr; } work_key;   // d_work holds the items of these pairs
     PinnedBuf<uint32_t> h_segb;
     const void* gseg_view_for = nullptr;            // d_gseg_view was filled for the seg_base the device holds
     bool timing_pending = false;                    // phase-A events recorded but not read yet

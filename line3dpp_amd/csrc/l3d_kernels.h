@@ -70,6 +70,7 @@ struct CullPools {
     // order: gathers by original index miss the L2s on large views -- C4 read 132 x its segment records)
     float4* tgt_s4;            // [sum Mt] raw segments (x1,y1,x2,y2)
     SegD32* tgt_sd;            // [sum Mt] rays and plane normal in float (the depth decision's share of SegX, l3d_dev.h SegD32)
+    uint32_t row_cache;        // set by launch_match_pairs: the work items stage their source rows' records in LDS
     uint32_t padded_rows;      // 0: src_perm / src_band hold Ms rows per pair (row form, legacy classes); R: the padded class layout
                                // of tile_src_cap(Ms, R) positions per pair (tile form: R = 16 / 32; row form with classes: 64)
 };
@@ -94,7 +95,9 @@ struct OrientFuse {
 };
 
 // ---- k_match.hip ----
-size_t match_lds_bytes(int mode, uint32_t K, bool ix16 = false, uint32_t waves = 1, bool brute = false, uint32_t tile_rows = 0);
+size_t match_lds_bytes(int mode, uint32_t K, bool ix16 = false, uint32_t waves = 1, bool brute = false, uint32_t tile_rows = 0,
+                       bool row_cache = false);
+bool match_row_cache(int mode, bool brute, uint32_t nwork, uint32_t tile_rows);   // the source rows' records staged in LDS (k_match.hip)
 constexpr uint32_t kMatchOrderMaxItems = 16384;   // launches up to this many work items: two waves per item
 constexpr uint32_t kMatchOrderMinItems = 3584;    // ... and, from this many on (more waves than wave slots), longest-first order
 uint32_t match_waves_per_group(int mode, bool brute, uint32_t nwork);   // waves that share one 64-row work item of k_match_pairs

@@ -338,13 +338,19 @@ def read_colmap(folder):
     median_depth or None).  An image whose camera is unknown is dropped; points3D.txt lines that do not parse as
     "id X Y Z" are ignored; a worldpoint without an entry there sits at the origin (the reference's map default)."""
     import os
+    def getlines(path):      # std::getline's view of a file: no extra empty line behind a final newline
+        text = open(path).read()
+        lines = text.split("\n")
+        return lines[:-1] if lines and lines[-1] == "" else lines
     cams = {}
-    for line in open(os.path.join(folder, "cameras.txt")).read().split("\n"):
-        if line[:1] == "#" or not line.split():
+    for line in getlines(os.path.join(folder, "cameras.txt")):
+        if line[:1] == "#":
             continue
         tok = line.split()
-        if tok[1] not in _COLMAP_MODELS:
-            raise ValueError(f"camera model {tok[1]} unknown!")
+        # (a blank line is NOT skipped: the reference and l3d_sfm_open_colmap parse it and fail on its empty model name)
+        model = tok[1] if len(tok) > 1 else ""
+        if model not in _COLMAP_MODELS:
+            raise ValueError(f"camera model {model} unknown!")
         fx, fy, cx, cy, k1, k2, p1, p2, k3 = (float(x) for x in _COLMAP_MODELS[tok[1]]([float(x) for x in tok[4:]] + [0.0] * 9))
         cams[int(tok[0])] = dict(width=int(tok[2]), height=int(tok[3]), K=np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]]),
                                  radial=np.array([k1, k2, k3]), tangential=np.array([p1, p2]))
@@ -374,6 +380,9 @@ def read_colmap(folder):
                         lst.append(wp); wps[wp] = np.zeros(3)
                 cur["worldpoints"] = lst
             first = True
+    # a repeated IMAGE_ID: the reference's maps are keyed by the id, so BOTH entries of the image sequence see the last pose
+    # and the last worldpoint list (l3d_sfm_open_colmap does the same fix-up)
+    imgs = [im if by_id[im["id"]] is im else dict(by_id[im["id"]]) for im in imgs]
     for line in open(os.path.join(folder, "points3D.txt")).read().split("\n"):
         tok = line.split()
         try:

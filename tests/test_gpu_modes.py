@@ -303,3 +303,30 @@ def test_timing_levels_change_what_is_timed_and_nothing_else():
             assert seen[level][k] == seen[2][k], (level, k)
     from line3dpp_amd import _lib
     assert not g.setTimingLevel(3) and "level" in _lib.last_error()
+
+
+def test_forms_of_the_match_kernel_give_the_same_bytes(monkeypatch):
+    """k_match_pairs has three forms for the bounded-kNN launch (k_match.hip): the row form on the padded width-class
+    layout of the source rows (the default of round 5), the row form on the legacy layout (L3D_MATCH_CLASSES=0), and the
+    tile form with 16 / 32 rows per work item and the LDS FIFO of target records (L3D_MATCH_TILE=16|32).  The switches are
+    read at every l3d_match_begin, so ONE context runs all of them in turn: every slot of phase A, every surviving list,
+    best hypothesis and affinity entry must be the same bytes, and equal the reference's own code.  The scene has ragged
+    views (classes of very different sizes, views smaller than one work item) and a kNN that leaves rows unfilled."""
+    sc = make_scene(9, 1100, n_neighbors=4, seed=97)
+    rng = np.random.default_rng(5)
+    for i, v in enumerate(sc.views):
+        v.segs = v.segs[:max(5, int(len(v.segs) * (0.02 if i == 3 else rng.uniform(0.4, 1.0))))].copy()
+    g = _gpu(sc)
+    o = _ref(sc, [dict(kNN=7)])
+    first = None
+    for tile, classes in (("0", "1"), ("0", "0"), ("16", "1"), ("32", "1"), ("0", "1")):
+        monkeypatch.setenv("L3D_MATCH_TILE", tile); monkeypatch.setenv("L3D_MATCH_CLASSES", classes)
+        assert g.matchImages(kNN=7) and g.computeAffinity()
+        assert g.timings()["culled_pairs"] > 0
+        _assert_same(g, o, sc)
+        n_pairs = len(g.pairs()[0])
+        snap = [g.pair_slots(p).tobytes() for p in range(n_pairs)] + [g.matches(v.cam)[0].tobytes() for v in sc.views] + \
+               [x.tobytes() for x in g.best()] + [g.affinity()[0].tobytes()]
+        if first is None:
+            first = snap
+        assert snap == first, (tile, classes)

@@ -361,6 +361,31 @@ def test_c_abi_colmap_reader_equals_the_python_twin(tmp_path):
     assert lib.l3d_sfm_open_colmap(str(tmp_path / "nowhere").encode(), C.byref(h)) != 0 and b"does not exist" in lib.l3d_last_error()
     _write_colmap(tmp_path / "bad", [(1, "THIN_PRISM_FISHEYE", 100, 100, [1.0] * 12)], [], [])
     assert lib.l3d_sfm_open_colmap(str(tmp_path / "bad").encode(), C.byref(h)) != 0 and b"unknown" in lib.l3d_last_error()
+    # two quirks of main_colmap.cpp that both readers must share:
+    # (1) a repeated IMAGE_ID -- the reference's maps are keyed by the id, so both entries of the image sequence end up
+    #     with the LAST pose and the LAST worldpoint list
+    cams, images, points = _colmap_scene(rng, n_img=5)
+    iid0 = images[0][0]
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    images.append((iid0, q, rng.normal(size=3) * 6, 2, "again.jpg", [(7.0, 8.0, points[3][0]), (9.0, 10.0, points[5][0])]))
+    folder = tmp_path / "dup"
+    _write_colmap(folder, cams, images, points)
+    want = io.read_colmap(str(folder))
+    assert [w["id"] for w in want].count(iid0) == 2
+    a, b = [w for w in want if w["id"] == iid0]
+    assert a["name"] == b["name"] == "again.jpg" and a["worldpoints"] == b["worldpoints"] == [points[3][0], points[5][0]]
+    assert np.array_equal(a["R"], b["R"]) and a["camera"] == b["camera"] == 2
+    assert lib.l3d_sfm_open_colmap(str(folder).encode(), C.byref(h)) == 0
+    _check_sfm_handle(L, lib, h, want, True)
+    lib.l3d_sfm_close(h)
+    # (2) a blank line in cameras.txt is parsed like any other line and fails on its empty model name, in both
+    folder = tmp_path / "blank"
+    _write_colmap(folder, cams, images[:2], points)
+    txt = (folder / "cameras.txt").read_text().split("\n")
+    (folder / "cameras.txt").write_text("\n".join(txt[:3] + [""] + txt[3:]))
+    with pytest.raises(ValueError, match="unknown"):
+        io.read_colmap(str(folder))
+    assert lib.l3d_sfm_open_colmap(str(folder).encode(), C.byref(h)) != 0 and b"unknown" in lib.l3d_last_error()
 
 
 def _write_bundler(path, cams, points):
