@@ -28,7 +28,8 @@ out = {
     "_comment": "rocprofv3 PMC passes of `bench.py --config %s --steps 2 --warmup 1` (tools/pmc_bench.sh), per launch of %s. "
                 "SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs; "
                 "FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE counts half of a 16 B/lane stream on gfx950 (read bytes = 2 x "
-                "FETCH_SIZE x 1024, MI355X_MICROARCH.md); WRITE_SIZE is uncalibrated there -- see profiles/%s_write_size_calibration.json" % (cfg, name, tag),
+                "FETCH_SIZE x 1024, MI355X_MICROARCH.md); WRITE_SIZE is uncalibrated there -- see profiles/r02_write_size_calibration.json "
+                "(the calibration of round 2: the one that exists)" % (cfg, name),
     "build_info": build, "config": cfg, "kernel": name, "counters_per_launch": {k: round(v) for k, v in sorted(m.items())},
     "kernel_cycles": round(cycles),
     "valu_busy_fraction": round(4.0 * m["SQ_ACTIVE_INST_VALU"] / (cycles * simds), 4),
