@@ -26,6 +26,14 @@
 #include "l3d_kernels.h"
 #include "l3d_lists.h"
 
+// A/B switches of the list tiers (profiles/r05_ab_phase_b.txt)
+#ifndef L3D_LISTS_NO_TIER2
+#define L3D_LISTS_NO_TIER2 0   // 1: lists beyond one wave's capacity go straight to the four-wave tier
+#endif
+#ifndef L3D_LISTS4_GRID
+#define L3D_LISTS4_GRID 512     // fixed grid of the four-wave tier
+#endif
+
 namespace l3d {
 
 namespace {
@@ -652,7 +660,7 @@ __global__ __launch_bounds__(64 * WPL) void k_lists(const ViewDev* __restrict__ 
             const uint32_t g = lviews[vi].seg_base + seg;
             if (L > 65535u) atomicOr(&lp.flags[1], 1u);
             else if (L > ListCfg<4, BASE>::CAP) lp.listH[atomicAdd(&lp.flags[5], 1u)] = g;
-            else if (L > ListCfg<2, BASE>::CAP) lp.list4[atomicAdd(&lp.flags[4], 1u)] = g;
+            else if (L > ListCfg<2, BASE>::CAP || L3D_LISTS_NO_TIER2) lp.list4[atomicAdd(&lp.flags[4], 1u)] = g;   // (L3D_LISTS_NO_TIER2: A/B switch)
             else lp.list2[atomicAdd(&lp.flags[7], 1u)] = g;
         }
     } else {
@@ -1286,7 +1294,7 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
         /* (the four-wave tier is left out while the passes hand it no list -- C1: an empty grid of 16 us --, like      */    \
         /* k_lists_huge below: a pass that then does hand one over is repeated with it, flags[4], check_pass)           */    \
         if (hsa.run_tier4)                                                                                                 \
-        hipLaunchKernelGGL((k_lists<4, B>), dim3(512), dim3(256), lds4, st, views, pairs, lviews, opairs, ipairs,          \
+        hipLaunchKernelGGL((k_lists<4, B>), dim3(L3D_LISTS4_GRID), dim3(256), lds4, st, views, pairs, lviews, opairs, ipairs, \
                            gseg_view, poff, inv, slots, uniform_K, lp, 0u);                                                \
     } while (0)
     if (wide) L3D_LISTS(256); else L3D_LISTS(128);

@@ -12,7 +12,14 @@
 //                64-target chunks, and inside them only the targets, whose band meets its rows' bands
 //                (exact culling), centre-out from where the targets' bands begin where its rows' do;
 //                a target record reaches all lanes as scalar operands (s_load through the constant address space:
-//                the record index is wave-uniform) -- no LDS tile, no barrier, no lane broadcast
+//                the record index is wave-uniform) -- no LDS tile, no barrier, no lane broadcast.
+//                Round 5: the source rows are laid out by WIDTH CLASS of their bands, every class padded to a multiple
+//                of the item size, so that a work item's hull never straddles two classes (C4 -8.8 %, C2 -3.9 %, C1
+//                -2.6 %); with two waves per item the rows' own records are staged in LDS once per item (row cache).
+//                The TILE form (template parameter TILE = 16 | 32: R rows x 64/R targets per step, the records through
+//                an LDS FIFO instead of the scalar cache) is kept as a tested A/B variant: it halves the pre-filter's
+//                lane-tests and takes the scalar-cache misses from 27 % to 4 %, and is 20 % slower on C1 because every
+//                wave carries fixed work (profiles/r05_ab_match_forms.txt)
 //   k_order_items (launches with few items per wave slot) starts the longest work items first
 //   fp32 pre-filter (conservative) -> __ballot -> popcount-prefix compaction of
 //                the few survivors into a per-wave LDS ring
@@ -1444,12 +1451,12 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
                     const float w = b.hi - b.lo;
                     // (padded layout: how many width classes pay depends on how many items a class is cut into -- with few
                     // items per class 64 consecutive rows of a class spread further in tau than the class saves in width;
-                    // tools/hull_sim.py on C1 / C2 / C4 for R = 16 / 32 / 64: one cut at 1/16 of the image below 48 items per
-                    // pair, 1/64 and 1/16 below 192, 1/64, 1/32 and 1/16 from there on)
+                    // tools/hull_sim.py on C1 / C2 / C4 for R = 16 / 32 / 64: no cut below 24 items per pair (tile_classes), one at 1/16 of
+                    // the image below 48, 1/64 and 1/16 below 192, 1/64, 1/32 and 1/16 from there on)
                     if (tile_rows) {
                         const uint32_t items = Ms / tile_rows;
-                        const float c16 = ref * (1.0f / 16.0f), c32 = items >= 192u ? ref * (1.0f / 32.0f) : c16,
-                                    c64 = items >= 48u ? ref * (1.0f / 64.0f) : c16;
+                        const float c16 = items >= kTileMinItems ? ref * (1.0f / 16.0f) : __builtin_inff(),   // (few items: one class)
+                                    c32 = items >= 192u ? ref * (1.0f / 32.0f) : c16, c64 = items >= 48u ? ref * (1.0f / 64.0f) : c16;
                         cls = w > c16 ? 1u : w > c32 ? 2u : w > c64 ? 3u : 4u;
                     }
                     else cls = w > w1 ? ((two && w > w2) ? 1u : 2u) : 3u;

@@ -19,8 +19,13 @@ constexpr int kMatchRows = 64;   // source rows per work item of k_match_pairs (
 // padded to a multiple of R (kEmpty rows), in a region of tile_src_cap(Ms, R) positions: the host's work list is that
 // region cut into items of R positions, whatever the class sizes turn out to be on the device.
 constexpr uint32_t kTileClasses = 5;   // unbounded band | width beyond 1/16, 1/32, 1/64 of the target image | narrow
+// Width classes only pay where a class is cut into enough items: a view of 1000 segments (C3) has 16 items of 64 rows per
+// pair, and splitting them into classes that each end in a partially filled item cost its match kernel 10 % (3.11 against
+// 2.81 ms), while C1's 31 items gain.  Below 24 items per pair: the unbounded rows and ONE class of bounded rows.
+constexpr uint32_t kTileMinItems = 24;
+__host__ __device__ constexpr uint32_t tile_classes(uint32_t Ms, uint32_t R) { return Ms / R < kTileMinItems ? 2u : kTileClasses; }
 __host__ __device__ constexpr uint32_t tile_src_cap(uint32_t Ms, uint32_t R) {
-    return ((Ms + kTileClasses * (R - 1) + R - 1) / R) * R;
+    return ((Ms + tile_classes(Ms, R) * (R - 1) + R - 1) / R) * R;
 }
 uint32_t match_tile_rows(int mode, bool brute);   // 0: row form; 16 / 32: tile form (L3D_MATCH_TILE overrides)
 uint32_t match_layout_rows(int mode, bool brute); // rows per work item of the padded class layout: the tile form's R, 64 for the

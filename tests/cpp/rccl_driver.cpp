@@ -11,8 +11,14 @@
 //   l3d_expand_slot_indices             received pairs -> slots (re-derived bit-identically)
 //   l3d_lists_shard_views               phase B's list pass for the rank's views
 //   ncclSend/ncclRecv per peer x 4 arrays, one group (in place)   record slabs of the list pass
-//   l3d_match_finish                    tail of phase B on the records of all ranks (L3D_ERR_RETRY: pools enlarged, repeat)
-//   l3d_compute_affinity
+//   world > 1 (round 5: tail and affinity fill sharded by the same views):
+//   l3d_tail_shard_count                chain on all records; scores / filterMatches / counts of the rank's views
+//                                       (L3D_ERR_RETRY: pools enlarged, repeat the list pass and its exchange)
+//   ncclAllGather of the two counts     -> l3d_tail_shard_layout: the rank's outputs at their places, every rank's parts
+//   ncclSend/ncclRecv per peer x 9 arrays, one group (in place)   -> l3d_tail_shard_commit
+//   l3d_affinity_shard_begin            similarities of the rank's views' surviving matches
+//   ncclSend/ncclRecv per peer, one group (in place)              -> l3d_affinity_shard_finish
+//   world == 1:  l3d_match_finish, l3d_compute_affinity
 //
 // usage:  rccl_driver <scene.bin> <rank> <world> <id file>     (scene.bin as tests/cpp/facade_smoke.cpp reads it; rank 0
 //         writes the ncclUniqueId to <id file>, the others wait for it; device = rank)
@@ -156,10 +162,51 @@ int main(int argc, char** argv) {
             }
         NCCL(ncclGroupEnd());
         HIP(hipStreamSynchronize(comm_stream));
-        rc = l3d_match_finish(c);
+        if (world == 1) { rc = l3d_match_finish(c); continue; }
+        // ---- the tail sharded by views: counts -> layout -> parts in place -> commit ----
+        uint32_t mine[2] = {0, 0};
+        rc = l3d_tail_shard_count(c, mine);
+        if (rc != 0) continue;                                   // (L3D_ERR_RETRY on every rank alike; anything else ends the loop)
+        uint32_t *d_cnt = nullptr;
+        HIP(hipMalloc(&d_cnt, (size_t)(2 + 2 * world) * 4));
+        HIP(hipMemcpy(d_cnt, mine, 8, hipMemcpyHostToDevice));
+        NCCL(ncclAllGather(d_cnt, d_cnt + 2, 2, ncclUint32, comm, comm_stream));
+        HIP(hipStreamSynchronize(comm_stream));
+        std::vector<uint32_t> counts(2 * (size_t)world);
+        HIP(hipMemcpy(counts.data(), d_cnt + 2, counts.size() * 4, hipMemcpyDeviceToHost));
+        HIP(hipFree(d_cnt));
+        void* base[9]; uint64_t elt[9];
+        std::vector<uint64_t> pfirst(9 * (size_t)world), pcount(9 * (size_t)world);
+        L3D(l3d_tail_shard_layout(c, (uint32_t)world, counts.data(), vb.data(), base, elt, pfirst.data(), pcount.data()));
+        NCCL(ncclGroupStart());
+        for (int k = 0; k < 9; ++k)
+            for (int q = 0; q < world; ++q) {
+                if (q == rank) continue;
+                const uint64_t fq = pfirst[9 * q + k], nq = pcount[9 * q + k], fm = pfirst[9 * rank + k], nm = pcount[9 * rank + k];
+                if (nq) NCCL(ncclRecv((char*)base[k] + fq * elt[k], (size_t)(nq * elt[k]), ncclUint8, q, comm, comm_stream));
+                if (nm) NCCL(ncclSend((char*)base[k] + fm * elt[k], (size_t)(nm * elt[k]), ncclUint8, q, comm, comm_stream));
+            }
+        NCCL(ncclGroupEnd());
+        HIP(hipStreamSynchronize(comm_stream));
+        rc = l3d_tail_shard_commit(c);
     }
-    if (rc != 0) { std::fprintf(stderr, "l3d_match_finish -> %d: %s\n", rc, l3d_last_error()); return 13; }
-    L3D(l3d_compute_affinity(c));
+    if (rc != 0) { std::fprintf(stderr, "phase B -> %d: %s\n", rc, l3d_last_error()); return 13; }
+    if (world == 1) L3D(l3d_compute_affinity(c));
+    else {
+        void* simv = nullptr;
+        std::vector<uint64_t> afirst(world), acount(world);
+        L3D(l3d_affinity_shard_begin(c, (uint32_t)rank, (uint32_t)world, &simv, afirst.data(), acount.data()));
+        HIP(hipDeviceSynchronize());                             // the similarities of this rank's views are written
+        NCCL(ncclGroupStart());
+        for (int q = 0; q < world; ++q) {
+            if (q == rank) continue;
+            if (acount[q]) NCCL(ncclRecv((float*)simv + afirst[q], (size_t)acount[q], ncclFloat, q, comm, comm_stream));
+            if (acount[rank]) NCCL(ncclSend((float*)simv + afirst[rank], (size_t)acount[rank], ncclFloat, q, comm, comm_stream));
+        }
+        NCCL(ncclGroupEnd());
+        HIP(hipStreamSynchronize(comm_stream));
+        L3D(l3d_affinity_shard_finish(c));
+    }
 
     // ---- what every rank must hold: the complete result ----
     uint64_t n_matches = 0; double score_sum = 0.0;
