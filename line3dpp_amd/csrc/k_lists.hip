@@ -27,6 +27,12 @@
 #include "l3d_lists.h"
 
 // A/B switches of the list tiers (profiles/r05_ab_phase_b.txt)
+#ifndef L3D_CHAIN_BATCH
+#define L3D_CHAIN_BATCH 0   // 1: k_chain_sweep fetches four edges per round trip (loses the exit at the first satisfied edge)
+#endif
+#ifndef L3D_LISTS_BATCH
+#define L3D_LISTS_BATCH 1   // 1: the row look-up and the rank of an inverse record read four LDS words per round trip
+#endif
 #ifndef L3D_LISTS_NO_TIER2
 #define L3D_LISTS_NO_TIER2 0   // 1: lists beyond one wave's capacity go straight to the four-wave tier
 #endif
@@ -344,7 +350,19 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
                 const uint32_t x = cc * GS + t;
                 if (x < total) {
                     uint32_t r = 0;
+#if L3D_LISTS_BATCH
+                    {   // (four table words per LDS round trip: the trip count is a run-time value and the loop was one
+                        // dependent read after the other)
+                        uint32_t j = 1;
+                        for (; j + 4 <= nq_here; j += 4) {
+                            const uint32_t s0 = k32[5 * j + 1], s1 = k32[5 * j + 6], s2 = k32[5 * j + 11], s3 = k32[5 * j + 16];
+                            r = s0 <= x ? j : r; r = s1 <= x ? j + 1 : r; r = s2 <= x ? j + 2 : r; r = s3 <= x ? j + 3 : r;
+                        }
+                        for (; j < nq_here; ++j) r = k32[5 * j + 1] <= x ? j : r;
+                    }
+#else
                     for (uint32_t j = 1; j < nq_here; ++j) r = k32[5 * j + 1] <= x ? j : r;   // prefixes ascend: the last row that starts at or before x
+#endif
                     row[cc] = r;
                     ref[cc] = inv[k32[5 * r] + (x - k32[5 * r + 1])];
                     kref[x] = ref[cc];
@@ -358,7 +376,18 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
                 if (x < total) {
                     const uint32_t r = row[cc], r0 = k32[5 * r + 1], r1 = k32[5 * r + 2];
                     uint32_t rank = r0;                                  // place among the entries of its own row (a handful)
+#if L3D_LISTS_BATCH
+                    {
+                        uint32_t y = r0;
+                        for (; y + 4 <= r1; y += 4) {
+                            const uint32_t k0 = kref[y], k1 = kref[y + 1], k2 = kref[y + 2], k3 = kref[y + 3];
+                            rank += (k0 < ref[cc] ? 1u : 0u) + (k1 < ref[cc] ? 1u : 0u) + (k2 < ref[cc] ? 1u : 0u) + (k3 < ref[cc] ? 1u : 0u);
+                        }
+                        for (; y < r1; ++y) rank += (kref[y] < ref[cc]) ? 1u : 0u;
+                    }
+#else
                     for (uint32_t y = r0; y < r1; ++y) rank += (kref[y] < ref[cc]) ? 1u : 0u;
+#endif
                     const uint32_t at = n_inv + rank;
                     e_d1[at] = dq[cc].x; e_d2[at] = dq[cc].y; e_tv[at] = k32[5 * r + 3]; e_ref[at] = ref[cc]; e_pf[at] = k32[5 * r + 4] | kHypInv;
                 }
@@ -459,6 +488,22 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
         const uint32_t p = pos_of[i];
         const float a1 = e_d1[i], a2 = e_d2[i];
         const uint32_t tvi = e_tv[i];
+#if L3D_LISTS_BATCH
+        // (98 % of the hypotheses have nobody inside their window: both first neighbours are requested together, so that the
+        // usual walk is one LDS round trip instead of two)
+        const uint64_t kd0 = p > 0 ? keys[p - 1] : 0ull, ku0 = p + 1 < L ? keys[p + 1] : 0ull;
+        auto test = [&](uint64_t kq) -> bool {            // false: outside the window -- the walk in this direction ends
+            const float d = a1 - ord2f((uint32_t)(kq >> 32));
+            if (!(d * d <= R1)) return false;
+            const uint32_t j = (uint32_t)kq & 0xFFFFu;
+            const float d2 = a2 - e_d2[j];
+            if (e_tv[j] != tvi && d2 * d2 <= R2) emit(j);
+            return true;
+        };
+        if (p > 0 && test(kd0)) for (uint32_t q = p - 1; q-- > 0;) if (!test(keys[q])) break;
+        if (p + 1 < L && test(ku0)) for (uint32_t q = p + 2; q < L; ++q) if (!test(keys[q])) break;
+        return;
+#endif
         for (uint32_t q = p; q-- > 0;) {
             const uint64_t kq = keys[q];
             const float d = a1 - ord2f((uint32_t)(kq >> 32));
@@ -1015,6 +1060,32 @@ __global__ void k_chain_sweep(const ListPools lp, uint8_t* __restrict__ positive
     if (h.pair_flags & kHypInv) return;                       // an inverse hypothesis exists iff its SOURCE is positive
     if (__hip_atomic_load(&positive[h.ref], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const uint32_t n = h.edge_cnt, e0 = h.edge_begin;
+#if L3D_CHAIN_BATCH
+    if (kSweepLooks == 1) {
+        // (a header has a handful of edges, each an edge record and -- for an inverse supporter -- its existence byte: two
+        // dependent global round trips per edge, one edge after the other.  Four edges and their bytes per round trip; any
+        // satisfied edge decides, whichever comes first.)
+        bool any_inverse = false;
+        for (uint32_t e = 0; e < n; e += 4) {
+            EdgeRec ed[4]; uint8_t ok[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) ed[i] = lp.edges[e0 + min(e + i, n - 1)];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const bool inv = (ed[i].j_cam & kEdgeInv) != 0;
+                any_inverse |= inv;
+                ok[i] = inv ? __hip_atomic_load(&positive[ed[i].ref_j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)1;
+            }
+            if (ok[0] | ok[1] | ok[2] | ok[3]) {
+                __hip_atomic_store(&positive[h.ref], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                changed[sweep] = 1;
+                return;
+            }
+        }
+        (void)any_inverse;
+        return;
+    }
+#endif
     for (uint32_t look = 0; look < kSweepLooks; ++look) {
         bool any_inverse = false;
         for (uint32_t e = 0; e < n; ++e) {
@@ -1049,6 +1120,28 @@ __global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ pos
         const bool exists = !inv || positive[h.ref] != 0;
         float cur = 0.0f;
         uint32_t cur_cam = kEmpty;
+#if L3D_LISTS_BATCH
+        if (exists) {
+            // (four edge records, then their existence bytes, per global round trip; accumulated in the list's order)
+            const uint32_t n = h.edge_cnt, e0 = h.edge_begin;
+            for (uint32_t e = 0; e < n; e += 4) {
+                EdgeRec ed[4]; bool ok[4];
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) ed[i] = lp.edges[e0 + min(e + i, n - 1)];
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) ok[i] = e + i < n && (!(ed[i].j_cam & kEdgeInv) || positive[ed[i].ref_j] != 0);
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) {
+                    if (!ok[i]) continue;
+                    if (ed[i].tv_j == cur_cam) {
+                        if (ed[i].sim > cur) { score3D -= cur; score3D += ed[i].sim; cur = ed[i].sim; }
+                    } else {
+                        score3D += ed[i].sim; cur = ed[i].sim; cur_cam = ed[i].tv_j;
+                    }
+                }
+            }
+        }
+#else
         if (exists)
             for (uint32_t e = 0; e < h.edge_cnt; ++e) {
                 const EdgeRec ed = lp.edges[h.edge_begin + e];
@@ -1059,6 +1152,7 @@ __global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ pos
                     score3D += ed.sim; cur = ed.sim; cur_cam = ed.tv_j;
                 }
             }
+#endif
         h.score3D = score3D;
         h.state = exists ? kHypExists : 0u;
         // (the slot's own copy of the score, for l3d_get_pair_slots.  A rank of a multi-GPU run holds the slots of the

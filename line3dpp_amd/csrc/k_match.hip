@@ -205,6 +205,12 @@ __device__ __forceinline__ void store_inverse_target(const OrientFuse& of, uint6
 #ifndef L3D_MATCH_WAVES
 #define L3D_MATCH_WAVES (TILE ? L3D_TILE_WAVES : (WPG == 2 ? 7 : 6))
 #endif
+#ifndef L3D_INS_BATCH
+#define L3D_INS_BATCH 1   // 0: one LDS round trip per table entry (rounds 2-4); 1: the reads of the top-K insertion and of the
+                          // epilogue's rank requested four at a time (C1 -5.9 %, C2 -3.8 %, C4 -1.7 %); 2: eight at a time with clamped
+                          // indices, one write per table word, no source-row shuffle in a row-cached item (SLOWER: C1 0.62
+                          // against 0.55 ms); 3: as 2 with the four-wide scan
+#endif
 #ifndef L3D_ROW_CACHE
 #define L3D_ROW_CACHE 1   // 0: never stage the source rows' records in LDS (A/B)
 #endif
@@ -360,14 +366,66 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     auto rescan_worst = [&](uint32_t sl) {
         L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)sl * K;
         uint32_t wj = 0; float wo = ov[0];
+#if L3D_INS_BATCH
+        // (K is a run-time value, so the loop is not unrolled and every entry was its own LDS round trip -- ten dependent
+        // ~100-cycle waits per insertion into a full row; four reads are requested together, compared in the same order)
+        const idx_t mp = L.minpos[sl];
+        uint32_t j = 1;
+        for (; j + 4 <= K; j += 4) {
+            const float o0 = ov[j], o1 = ov[j + 1], o2 = ov[j + 2], o3 = ov[j + 3];
+            if (o0 < wo) { wo = o0; wj = j; }
+            if (o1 < wo) { wo = o1; wj = j + 1; }
+            if (o2 < wo) { wo = o2; wj = j + 2; }
+            if (o3 < wo) { wo = o3; wj = j + 3; }
+        }
+        for (; j < K; ++j) {
+            const float o = ov[j];
+            if (o < wo) { wo = o; wj = j; }
+        }
+        L.minov[sl] = wo;
+        L.minpos[sl] = (idx_t)(wj | (mp & kTie));
+#else
         for (uint32_t j = 1; j < K; ++j) {
             const float o = ov[j];
             if (o < wo) { wo = o; wj = j; }
         }
         L.minov[sl] = wo;
         L.minpos[sl] = (idx_t)(wj | (L.minpos[sl] & kTie));
+#endif
     };
     auto flag_tie = [&](uint32_t sl) { L.minpos[sl] = (idx_t)(L.minpos[sl] | kTie); };
+#if L3D_INS_BATCH >= 2
+    // smallest overlap of a full row's table and its slot, the first among equals (as rescan_worst): eight entries per LDS
+    // round trip, indices clamped to the last entry (a repeated entry never beats itself under the strict comparison)
+    auto scan_worst8 = [&](uint32_t sl, float& wo, uint32_t& wj) {
+        L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)sl * K;
+#if L3D_INS_BATCH == 2
+        const uint32_t last = K - 1;
+        wo = __builtin_inff(); wj = 0;
+        for (uint32_t j = 0; j < K; j += 8) {
+            float o[8];
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i) o[i] = ov[min(j + i, last)];
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i) if (o[i] < wo) { wo = o[i]; wj = min(j + i, last); }
+        }
+#else
+        wo = ov[0]; wj = 0;
+        uint32_t j = 1;
+        for (; j + 4 <= K; j += 4) {
+            const float o0 = ov[j], o1 = ov[j + 1], o2 = ov[j + 2], o3 = ov[j + 3];
+            if (o0 < wo) { wo = o0; wj = j; }
+            if (o1 < wo) { wo = o1; wj = j + 1; }
+            if (o2 < wo) { wo = o2; wj = j + 2; }
+            if (o3 < wo) { wo = o3; wj = j + 3; }
+        }
+        for (; j < K; ++j) {
+            const float o = ov[j];
+            if (o < wo) { wo = o; wj = j; }
+        }
+#endif
+    };
+#endif
 
     auto prefix = [&](uint64_t m) -> uint32_t {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -400,8 +458,15 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t ent = ring[(head + lane) & (kRingN - 1)];
         head += n;
         const uint32_t sl = ent >> 23, tp = ent & 0x7FFFFFu;
+#if L3D_INS_BATCH >= 2
+        // (the source row of an entry comes from its lane by a shuffle -- an LDS round trip at the head of every drain; a
+        // row-cached item only needs it in the double-precision fallback, a few candidates in a million: fetched there)
+        uint32_t sg = 0;
+        if (!ROWCACHE) sg = __shfl(src, sl);
+#else
         const uint32_t sg = __shfl(src, sl);   // the ring of a wave only holds rows of that wave
-        bool pass = false;
+#endif
+        bool pass = false, fallback = false;
         if (has) {
             SegD32 sd;
             if (ROWCACHE) {
@@ -413,8 +478,14 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             const float B[3] = {Bx, By, Bz};
             bool certain;
             pass = depths_positive32(sd, td, B, tolB, certain);
-            if (!certain) {   // the sliver: the double-precision decision on the full records (by original target index)
-                const uint32_t to = cull ? tperm[tp] : tp;
+            fallback = !certain;
+        }
+        if (L3D_BALLOT(fallback)) {   // the sliver (wave-uniform test): the double-precision decision on the full records
+#if L3D_INS_BATCH >= 2
+            if (ROWCACHE) sg = __shfl(src, sl);
+#endif
+            if (fallback) {
+                const uint32_t to = cull ? tperm[tp] : tp;    // (by original target index)
                 // (the camera centres are fetched HERE, through laundered pointers: hoisted out of the walk they occupied
                 // 12 scalar registers of a loop that spills them -- this branch runs for a few candidates in a million)
                 const ViewDev* pvs = &vs; const ViewDev* pvt = &vt;
@@ -435,7 +506,12 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t ent = ring2[(head2 + lane) & (kRing2 - 1)];
         head2 += n;
         const uint32_t sl = ent >> 23, tg = ent & 0x7FFFFFu;
+#if L3D_INS_BATCH >= 2
+        uint32_t sg = 0;
+        if (!ROWCACHE) sg = __shfl(src, sl);     // (wave-uniform branch; a row-cached item reads the row's record from LDS)
+#else
         const uint32_t sg = __shfl(src, sl);
+#endif
         bool pending = false;
         float ovv = 0.0f;
         // F is fetched per drain through a laundered pointer (wave-uniform control flow: scalar loads): hoisted out of the
@@ -484,15 +560,50 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                 if (WPG == 1) L.claim[sl] = kEmpty;
                 pending = false;
                 const uint32_t c = L.cnt[sl];
+#if L3D_INS_BATCH
+                const idx_t mp_now = L.minpos[sl];      // (requested with the count: one wait instead of three)
+                const float mo_now = L.minov[sl];
+#endif
                 L3D_LDS volatile float* ov = L.top_ov + (size_t)sl * K;
                 L3D_LDS volatile idx_t* ix = L.top_ix + (size_t)sl * K;
+#if L3D_INS_BATCH >= 2
+                // (every table word is written once, from values this lane holds: no read-back of what it has just written)
+                if (c < K) {
+                    ov[c] = ovv; ix[c] = tg;
+                    L.cnt[sl] = c + 1;
+                    if (c + 1 == K) {
+                        float wo; uint32_t wj2;
+                        scan_worst8(sl, wo, wj2);
+                        L.minov[sl] = wo;
+                        L.minpos[sl] = (idx_t)(wj2 | (mp_now & kTie));
+                    }
+                } else {
+                    const uint32_t wj = mp_now & (idx_t)~kTie;
+                    const float mo = mo_now;
+                    if (ovv > mo) {
+                        ov[wj] = ovv; ix[wj] = tg;
+                        float wo; uint32_t wj2;
+                        scan_worst8(sl, wo, wj2);
+                        L.minov[sl] = wo;
+                        // (wo == mo: the evicted entry ties with the new K-th best)
+                        L.minpos[sl] = (idx_t)(wj2 | (mp_now & kTie) | (wo == mo ? kTie : (idx_t)0));
+                    } else if (ovv == mo) {
+                        L.minpos[sl] = (idx_t)(mp_now | kTie);     // a tie at the K-th place (whichever index would win)
+                    }
+                }
+#else
                 if (c < K) {
                     ov[c] = ovv; ix[c] = tg;
                     L.cnt[sl] = c + 1;
                     if (c + 1 == K) rescan_worst(sl);
                 } else {
+#if L3D_INS_BATCH
+                    const uint32_t wj = mp_now & (idx_t)~kTie;
+                    const float mo = mo_now;
+#else
                     const uint32_t wj = L.minpos[sl] & (idx_t)~kTie;
                     const float mo = L.minov[sl];
+#endif
                     if (ovv > mo) {
                         ov[wj] = ovv; ix[wj] = tg;
                         rescan_worst(sl);
@@ -501,6 +612,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                         flag_tie(sl);                           // a tie at the K-th place (whichever index would win)
                     }
                 }
+#endif
                 if (WPG > 1)
                     __hip_atomic_store((L3D_LDS uint32_t*)&L.claim[sl], kEmpty, __ATOMIC_RELEASE,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -896,6 +1008,27 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t c = min((uint32_t)L.cnt[rs], K);
         L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)rs * K;
         bool t = false;
+#if L3D_INS_BATCH
+        if (K <= 16) {
+            // (the usual kNN: the row's entries are fetched four per LDS round trip and compared in registers; entries beyond
+            // the row's count read as distinct NaN-free sentinels that equal nothing)
+            float o[16];
+#pragma unroll
+            for (uint32_t b = 0; b < 16; b += 4) {
+                if (b < c) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) o[b + i] = (b + i < c) ? ov[b + i] : -1.0f - (float)(b + i);
+                } else {
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) o[b + i] = -1.0f - (float)(b + i);
+                }
+            }
+#pragma unroll
+            for (uint32_t i = 1; i < 16; ++i)
+#pragma unroll
+                for (uint32_t j = 0; j < i; ++j) t |= o[j] == o[i];
+        } else
+#endif
         for (uint32_t i = 1; i < c; ++i) {
             const float oi = ov[i];
             for (uint32_t j = 0; j < i; ++j) t |= ov[j] == oi;
@@ -943,7 +1076,18 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             // (a row that gets here has no two equal overlaps -- the pass above flagged those --, so the order
             // (overlap desc, target asc) is the order by overlap)
             uint32_t rank = 0;
+#if L3D_INS_BATCH
+            {
+                uint32_t i = 0;
+                for (; i + 4 <= c; i += 4) {
+                    const float o0 = ov[i], o1 = ov[i + 1], o2 = ov[i + 2], o3 = ov[i + 3];
+                    rank += (o0 > oj ? 1u : 0u) + (o1 > oj ? 1u : 0u) + (o2 > oj ? 1u : 0u) + (o3 > oj ? 1u : 0u);
+                }
+                for (; i < c; ++i) rank += ov[i] > oj ? 1u : 0u;
+            }
+#else
             for (uint32_t i = 0; i < c; ++i) rank += ov[i] > oj ? 1u : 0u;
+#endif
             dst = rank;
             // Three short stages that each fetch only the invariants they use (depths: rays + plane; orientation:
             // rays + mid ray).  The pointers are laundered between the stages so that the compiler does not keep both
