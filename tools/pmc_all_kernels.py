@@ -12,7 +12,7 @@ for l in out.splitlines():
     if not d.get('SQ_WAVES') or not d.get('SQ_ACTIVE_INST_VALU'): continue
     rows.append((d['GRBM_GUI_ACTIVE'], n, d))
 rows.sort(reverse=True)
-print(f"# {cfg}: every kernel of the 3 profiled steps (2 timed + 1 warm-up) of bench.py, PMC passes of tools/pmc_diag.sh (final build 9e9c22fcc982),")
+print(f"# {cfg}: every kernel of the 3 profiled steps (2 timed + 1 warm-up) of bench.py, PMC passes of tools/pmc_diag.sh (build of the pmc_diag call),")
 print("# sums over the 3 steps.  lanes = SQ_THREAD_CYCLES_VALU / (4 x SQ_ACTIVE_INST_VALU) (relative measure: k_match_pairs ~11-14 = its")
 print("# ~45-55 of 64 lanes); wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES; valu/wave = SQ_INSTS_VALU / SQ_WAVES; sqc_miss = scalar data cache")
 print(f"{'kernel':44s} {'waves':>9s} {'valu/wave':>9s} {'lanes':>6s} {'wait':>5s} {'sqc_miss':>8s} {'lds_conf':>8s}")
