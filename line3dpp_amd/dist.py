@@ -97,7 +97,17 @@ def device_tensor(ptr, nbytes, device):
     return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
 
 
-def _wait_for_exchange(buf, device, l3d=None, group=None):
+def _issue_stream(buf, device):
+    """torch's current stream at the moment a collective is ISSUED (the backend orders the collective behind what that stream
+    holds then): handed to _wait_for_exchange, so that a caller who changes the stream context between issue and wait cannot
+    make the shortcut look valid"""
+    if buf is None or not getattr(buf, "is_cuda", False):
+        return None
+    import torch
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _wait_for_exchange(buf, device, l3d=None, group=None, issued_on=None):
     """The collective runs on the backend's own stream; the library's stream must not touch `buf` before it is done.
     torch's NCCL (= RCCL) backend orders that by itself when the library launches on torch's CURRENT stream: a collective
     starts after what that stream holds at the call, and Work.wait() (called by the synchronous collectives and by the
@@ -109,7 +119,10 @@ def _wait_for_exchange(buf, device, l3d=None, group=None):
     if buf.is_cuda:
         import torch
         import torch.distributed as dist
-        same = l3d is not None and int(getattr(l3d, "stream", -1)) == int(torch.cuda.current_stream(device).cuda_stream)
+        now = int(torch.cuda.current_stream(device).cuda_stream)
+        ctx_stream = int(getattr(l3d, "stream", -1)) if l3d is not None else -1
+        # (the context's stream must be the stream the collective was issued on AND still torch's current one)
+        same = l3d is not None and ctx_stream == now and (issued_on is None or issued_on == now)
         if not (same and dist.get_backend(group) == "nccl"):
             torch.cuda.synchronize(device)
 
@@ -141,6 +154,7 @@ def gather_slabs(slabs, rank, world_size, device, group=None, l3d=None):
     whoever has a node to compare them on."""
     import torch.distributed as dist
     collective = bool(os.environ.get("L3D_GATHER_COLLECTIVE"))
+    issued_on = _issue_stream(device_tensor(slabs[0][2], 1, device), device) if slabs else None
     ops = []
     for i, (sp, sb, fp) in enumerate(slabs):
         if not sb:
@@ -165,7 +179,7 @@ def gather_slabs(slabs, rank, world_size, device, group=None, l3d=None):
         for r in dist.batch_isend_irecv(ops):
             r.wait()
     if slabs:
-        _wait_for_exchange(device_tensor(slabs[0][2], 1, device), device, l3d, group)
+        _wait_for_exchange(device_tensor(slabs[0][2], 1, device), device, l3d, group, issued_on)
 
 
 def exchange_parts(layout, rank, world_size, device, group=None, l3d=None):
@@ -177,11 +191,14 @@ def exchange_parts(layout, rank, world_size, device, group=None, l3d=None):
     import torch.distributed as dist
     glob = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
     recvs, sends, last = [], [], None
+    issued_on = None
     for k, (ptr, elt, parts) in enumerate(layout):
         total = max(f + n for f, n in parts) * elt
         if total == 0:
             continue
         full = device_tensor(ptr, total, device)
+        if issued_on is None:
+            issued_on = _issue_stream(full, device)
         f_me, n_me = parts[rank]
         for q in range(world_size):
             if q == rank:
@@ -195,7 +212,7 @@ def exchange_parts(layout, rank, world_size, device, group=None, l3d=None):
     if recvs or sends:
         for r in dist.batch_isend_irecv(recvs + sends):
             r.wait()
-        _wait_for_exchange(last, device, l3d, group)
+        _wait_for_exchange(last, device, l3d, group, issued_on)
 
 
 def _gather_counts(n_r, h_r, world_size, device, group):
@@ -321,6 +338,7 @@ def match_images_halo(l3d, rank, world_size, device=None, group=None, **params):
         # so the k-th send of rank a to rank b meets the k-th receive b posted for a.  gloo matches by the tag.)
         ops = [dist.P2POp(dist.irecv, span(f, n), glob(r), group, tag=f) for (r, f, n) in recv] + \
               [dist.P2POp(dist.isend, span(f, n), glob(q), group, tag=f) for (q, f, n) in send]
+        issued_on = _issue_stream(buf, device)
         reqs = dist.batch_isend_irecv(ops)
     # ---- the rest of this rank's pairs, matched while the halo travels ----
     ok = ok and (not late[1] or l3d.matchPairs(late[0], late[1]))
@@ -328,7 +346,7 @@ def match_images_halo(l3d, rank, world_size, device=None, group=None, **params):
     for r in reqs:
         r.wait()
     if reqs:
-        _wait_for_exchange(buf, device, l3d, group)
+        _wait_for_exchange(buf, device, l3d, group, issued_on)
     lap("exchange_slots")
     for _, f, n in recv:
         ok = ok and l3d.expandSlotIndices(f, n)
