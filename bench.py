@@ -264,6 +264,62 @@ def multi_gpu_model(pairs, M, kNN, phase, lists_ms, record_bytes, tail_bytes=0.0
     return out
 
 
+def phase_b_roofline(tm, lists_ms, pairs, M, kNN, build, config, world):
+    """The second roofline block (round 6): the LIST PASS of phase B -- k_pair_csr, the k_lists tiers, k_cand_exact, k_edges --,
+    the bandwidth-style part of the path (scoringCPU + storeInverseMatches, line3D.cc:1208-1294, 1672-1699, in sparse form).
+    `achieved` = algorithmic bytes of the pass / its live HIP-event time (events around the pass at timing level 2, the
+    zero-block memset included); per kernel the counted traffic and the issue counters of the PMC summary of THIS build
+    (tools/pmc_phase_b.sh -> profiles/*_pmc_lists_<config>.json), when there is one.
+    Algorithmic bytes, from the counts the library reports for the timed scene:
+      k_pair_csr    2 B (4 B from 65 535 segments per view on) of the inverse-target stream per slot of a pair that hands matches
+                    over + 4 B per inverse hypothesis written + the per-pair offsets (4 B per target segment and pair)
+      k_lists       per hypothesis of a list 8 B of depths + 4 B of identity, fresh and inverse alike; 40 B per candidate written
+      k_cand_exact  40 B per candidate read, 4 B written
+      k_edges       40 B per candidate read; 16 B per edge, 64 B per header written"""
+    n_ent, n_inv, n_cand, n_hdr, n_edge = (tm.get(k, 0) for k in ("list_entries", "list_inverse", "list_candidates", "list_headers", "support_words"))
+    tgt_b = 2 if max(M.values()) < 65535 else 4
+    inv_pairs = [(s_, t_) for s_, t_ in pairs if t_ > s_]
+    csr = sum(tgt_b * M[s_] * kNN + 4 * (M[t_] + 1) for s_, t_ in inv_pairs) + 4 * n_inv
+    algo = {"k_pair_csr": csr, "k_lists": 12 * n_ent + 40 * n_cand, "k_cand_exact": 44 * n_cand, "k_edges": 40 * n_cand + 16 * n_edge + 64 * n_hdr}
+    total = sum(algo.values())
+    out = {"scope": "list pass of phase B: k_pair_csr + k_lists<1|2|4> + k_cand_exact + k_edges", "bound": "hbm",
+           "achieved": round(total / (lists_ms * 1e-3) / 1e9, 2) if lists_ms > 0 else None, "peak": 8000.0, "unit": "GB/s",
+           "frac": round(total / (lists_ms * 1e-3) / 1e9 / 8000.0, 5) if lists_ms > 0 else None,
+           "live_ms": round(lists_ms, 4), "timed_with": "HIP events around the pass on its launch stream (l3d_set_timing_level 2), separate untimed steps",
+           "algorithmic_bytes": dict(algo, total=total),
+           "counts": {"hypotheses_in_lists": n_ent, "of_which_inverse": n_inv, "candidate_pairs": n_cand, "supported_hypotheses": n_hdr,
+                      "supporting_pairs": n_edge, "slots": tm.get("slots_lo", 0) + (tm.get("slots_hi", 0) << 32)}}
+    pmc = load_json_newest("*_pmc_lists_%s.json" % config, lambda d: d.get("build_info") == build) if world == 1 else None
+    if pmc:
+        ks = {}
+        groups = {"k_pair_csr": "k_pair_csr", "k_lists": "k_lists<", "k_cand_exact": "k_cand_exact", "k_edges": "k_edges"}
+        for name, prefix in groups.items():
+            sel = [v for k, v in pmc["kernels"].items() if k.startswith(prefix) and not k.startswith("k_lists_huge") and v.get("avg_us")]
+            if not sel:
+                continue
+            us = sum(v["avg_us"] * (v.get("calls_per_step") or 1) for v in sel)
+            rd = sum(v.get("fetch_bytes_x2", 0) * (v.get("calls_per_step") or 1) for v in sel)
+            rd_raw = sum(v.get("fetch_bytes_raw", 0) * (v.get("calls_per_step") or 1) for v in sel)
+            wr = sum(v.get("write_bytes", 0) * (v.get("calls_per_step") or 1) for v in sel)
+            big = max(sel, key=lambda v: v["avg_us"])
+            ks[name] = {"us_per_step": round(us, 2), "algorithmic_bytes": algo[name],
+                        "achieved_GB_per_s": round(algo[name] / (us * 1e-6) / 1e9, 1), "frac_of_8_TB_per_s": round(algo[name] / (us * 1e-6) / 8e12, 4),
+                        "counted_read_bytes_x2": int(rd), "counted_read_bytes_raw": int(rd_raw), "counted_write_bytes": int(wr),
+                        "counted_GB_per_s_x2": round((rd + wr) / (us * 1e-6) / 1e9, 1),
+                        "traffic_over_algorithmic_x2": round((rd + wr) / max(algo[name], 1), 2),
+                        "traffic_over_algorithmic_raw": round((rd_raw + wr) / max(algo[name], 1), 2),
+                        "valu_busy_fraction": big.get("valu_busy_fraction"), "wait_share_of_wave_life": big.get("wait_share_of_wave_life"),
+                        "l2_hit_rate": big.get("l2_hit_rate")}
+        out["kernels"] = ks
+        out["pmc_source"] = pmc["_file"] + " (rocprofv3 --pmc passes + an undisturbed --kernel-trace run, same build id)"
+        out["reading"] = ("FETCH_SIZE x 2 is the guide's gfx950 correction for wide coalesced streams and an upper bound for the 8-byte "
+                          "gathers of the list pass (`raw` = as counted). k_lists is bound by VALU issue (valu_busy_fraction), not by HBM: "
+                          "see DESIGN.md 5.2")
+    else:
+        out["pmc_source"] = "no PMC summary under profiles/ for this build and workload (tools/pmc_phase_b.sh)"
+    return out
+
+
 def cold_call(scene, kNN, device_index, step_fn_factory):
     """first matchImages + affinity of a fresh context: (ms, timings dict, context)"""
     from line3dpp_amd.api import Line3D
@@ -473,6 +529,7 @@ def main():
         phase["begin"] += tm["begin_ms"]; phase["match"] += tm["match_pairs_ms"]
         phase["finish"] += tm["finish_ms"]; phase["affinity"] += tm["affinity_ms"]
         lists_ms_sum += tm.get("lists_ms", 0.0); record_kbytes = tm.get("record_kbytes", 0)
+    tm_last = dict(tm)
     l3d.setTimingLevel(1)
     barrier()
     # (for multi_gpu_model: what the sharded tail / affinity fill would exchange -- read before the context is closed)
@@ -622,6 +679,8 @@ def main():
             "cold": cold,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }
+        if world == 1:
+            out["roofline_phase_b"] = phase_b_roofline(tm_last, lists_ms_sum / phase_steps, pairs, M, kNN, build, args.config, world)
         if world == 1:
             out["phase_ms"]["lists_part_of_finish"] = round(lists_ms_sum / phase_steps, 4)
             out["phase_ms"]["measured_in"] = (f"{phase_steps} separate untimed steps with all ten HIP events of a call on "

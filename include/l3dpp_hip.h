@@ -355,6 +355,11 @@ typedef struct l3d_timings {
                             * multi-GPU run shards by views; the rest of finish_ms is the tail every rank runs */
     uint32_t record_kbytes;/* phase B: size of the four record arrays at their current pool strides, KiB: what the ranks of a
                             * multi-GPU run all-gather */
+    /* round 6: what the roofline of phase B is computed from (bench.py: roofline_phase_b) */
+    uint32_t list_inverse; /* phase B: of list_entries, the inverse hypotheses (storeInverseMatches, line3D.cc:1672-1699) */
+    uint32_t list_candidates; /* phase B: candidate pairs the list pass handed to the exact test (similarityForScoring) */
+    uint32_t list_headers; /* phase B: hypotheses with at least one supporter (headers of the sparse form) */
+    uint32_t slots_lo, slots_hi; /* phase A: slots of the call = sum over directed pairs of Ms x kNN (64 bits) */
 } l3d_timings;
 int l3d_get_timings(l3d_ctx*, l3d_timings*);
 /* How many of the context's HIP events a call records (they feed l3d_timings; the reference has no such thing: its

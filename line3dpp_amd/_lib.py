@@ -48,7 +48,9 @@ class Timings(C.Structure):
                 ("cull_prepare_ms", C.c_float), ("culled_pairs", C.c_uint32),
                 ("list_entries", C.c_uint32), ("support_words", C.c_uint32), ("tied_rows", C.c_uint32), ("chain_sweeps", C.c_uint32),
                 ("chain_extra_rounds", C.c_uint32), ("pool_retries", C.c_uint32),
-                ("lists_ms", C.c_float), ("record_kbytes", C.c_uint32)]
+                ("lists_ms", C.c_float), ("record_kbytes", C.c_uint32),
+                ("list_inverse", C.c_uint32), ("list_candidates", C.c_uint32), ("list_headers", C.c_uint32),
+                ("slots_lo", C.c_uint32), ("slots_hi", C.c_uint32)]
 
 
 EXPORTS = [

@@ -293,8 +293,8 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
                                                  const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
                                                  const ListView* __restrict__ lviews, const OutPair* __restrict__ opairs,
                                                  const InPair* __restrict__ ipairs, const uint32_t* __restrict__ poff,
-                                                 const uint32_t* __restrict__ inv, const Slot* __restrict__ slots,
-                                                 uint32_t uniform_K, const ListPools lp) {
+                                                 const uint32_t* __restrict__ inv, const float2* __restrict__ hyp_p,
+                                                 const float2* __restrict__ hyp_q, uint32_t uniform_K, const ListPools lp) {
     typedef ListCfg<WPL, BASE> Cfg;
     constexpr uint32_t GS = Cfg::GS, CAP = Cfg::CAP, NKEY = Cfg::NKEY;
     const uint32_t t = WPL == 1 ? lane_id() : threadIdx.x;
@@ -366,7 +366,7 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
                     row[cc] = r;
                     ref[cc] = inv[k32[5 * r] + (x - k32[5 * r + 1])];
                     kref[x] = ref[cc];
-                    dq[cc] = *(const float2*)&slots[ref[cc]].dq1;      // the depths of the target's end points = this hypothesis' own
+                    dq[cc] = hyp_q[ref[cc]];                            // the depths of the target's end points = this hypothesis' own
                 }
             }
             group_barrier<WPL>();
@@ -403,17 +403,17 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
             for (uint32_t t0 = 0; t0 < T; t0 += GS) {
                 const uint32_t x = t0 + t;
                 bool alive = false;
-                Slot s; uint32_t ref = 0, pi = 0, tv = 0;
+                float2 s = make_float2(0.0f, 0.0f); uint32_t ref = 0, pi = 0, tv = 0;
                 if (x < T) {
                     const OutPair op = opairs[q0 + x / uniform_K];
                     pi = op.pair; tv = op.tgt;
                     ref = (uint32_t)(op.slot_off + (uint64_t)seg * uniform_K + x % uniform_K);
-                    s = slots[ref];
-                    alive = s.tgt_seg != kEmpty && (s.flags & kSlotAlive);
+                    s = hyp_p[ref];              // 8 bytes of the stream beside the slots: NaN = empty slot or filtered by orientation
+                    alive = s.x == s.x;
                 }
                 uint32_t total;
                 const uint32_t at = pos + group_count<WPL>(alive, total, red);
-                if (alive && at < CAP) { e_d1[at] = s.dp1; e_d2[at] = s.dp2; e_tv[at] = tv; e_ref[at] = ref; e_pf[at] = pi; }
+                if (alive && at < CAP) { e_d1[at] = s.x; e_d2[at] = s.y; e_tv[at] = tv; e_ref[at] = ref; e_pf[at] = pi; }
                 pos += total;
             }
         } else {
@@ -422,14 +422,14 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
                 const uint64_t row0 = op.slot_off + (uint64_t)seg * op.K;
                 for (uint32_t j0 = 0; j0 < op.K; j0 += GS) {
                     bool alive = false;
-                    Slot s;
+                    float2 s = make_float2(0.0f, 0.0f);
                     if (j0 + t < op.K) {
-                        s = slots[row0 + j0 + t];
-                        alive = s.tgt_seg != kEmpty && (s.flags & kSlotAlive);
+                        s = hyp_p[row0 + j0 + t];
+                        alive = s.x == s.x;
                     }
                     uint32_t total;
                     const uint32_t at = pos + group_count<WPL>(alive, total, red);
-                    if (alive && at < CAP) { e_d1[at] = s.dp1; e_d2[at] = s.dp2; e_tv[at] = op.tgt; e_ref[at] = (uint32_t)(row0 + j0 + t); e_pf[at] = op.pair; }
+                    if (alive && at < CAP) { e_d1[at] = s.x; e_d2[at] = s.y; e_tv[at] = op.tgt; e_ref[at] = (uint32_t)(row0 + j0 + t); e_pf[at] = op.pair; }
                     pos += total;
                 }
             }
@@ -440,7 +440,7 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
     if (L > CAP) return L;                       // nothing written beyond the staging arrays: a larger tier takes the list
     // (total list length of the pass = the reference's number of hypotheses: statistics, and the mean list length that
     // picks the staging width of the next call)
-    if (t == 0 && L && lp.count_entries) atomicAdd(&lp.cnt[pool * 16 + 5], L);
+    if (t == 0 && L && lp.count_entries) { atomicAdd(&lp.cnt[pool * 16 + 5], L); if (n_inv) atomicAdd(&lp.cnt[pool * 16 + 6], n_inv); }
     if (L < 2) return 0;
     // ---- sort by the first depth: key = (order-preserving bits of dp1, canonical index) ----
     uint32_t N = 2;
@@ -597,13 +597,20 @@ constexpr uint32_t kCsrChunk = 8;              // slots per thread whose memory 
 // handful of waves per SIMD), so what hides the latency of a load or of an LDS atomic is the next independent one of the
 // same wave -- slots that hand nothing over count on one of 64 dummy cursors instead of skipping the atomic (a branch
 // around each access serialised them: 0.11 ms on C1 where the batched form takes a fraction of that).
-template <bool LDSCNT, bool TGT16>
+// STAGED (round 6, LDS cursors and 16-bit targets): the sorted order is assembled in LDS and leaves as COALESCED stores.  What
+// the direct form waits for is its scattered stores (a scattered 4-byte store dirties a 32-byte sector: 48 bytes of counted
+// write traffic per entry; halving the LDS atomics -- ranks kept in registers -- changed nothing, profiles/r06_ab_pair_csr.txt).
+// The targets are cut into ranges whose entries fit the stage: per range one pass over the pair's 2-byte target stream
+// (L2-resident), a slot of the range takes its place with the cursor atomic and leaves its index in the stage; then the stage
+// goes out back to back.  C2: 0.68 -> 0.45 ms.
+__host__ __device__ constexpr uint32_t lds_segs_round(uint32_t Mt) { return (Mt + 3u) & ~3u; }   // (the stage behind the cursors stays 16-byte aligned)
+template <bool LDSCNT, bool TGT16, bool STAGED>
 __global__ __launch_bounds__(kCsrBlock) void k_pair_csr(const PairDesc* __restrict__ pairs, uint32_t first_pair,
                                                         const PairCsr* __restrict__ pair_csr,
                                                         const uint32_t* __restrict__ inv_tgt,
                                                         uint32_t* __restrict__ poff, uint32_t* __restrict__ refs,
                                                         uint32_t* __restrict__ dummy, uint32_t tgt_v0, uint32_t tgt_v1,
-                                                        uint32_t lds_segs) {
+                                                        uint32_t lds_segs, uint32_t stage_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t part[kCsrBlock];
     const uint32_t pi = first_pair + blockIdx.x;
@@ -661,11 +668,48 @@ __global__ __launch_bounds__(kCsrBlock) void k_pair_csr(const PairDesc* __restri
     __threadfence_block();
     __syncthreads();
     // ---- scatter: a slot takes the next place of its target's run (cursor) and its INDEX goes there -- 4 bytes; the
-    // list pass reads the two depths it needs from the slot itself (a first version wrote 16-byte records here and read
-    // every slot's depths for them: one 32-byte sector per slot, 6.7 GB on C2 -- the whole slot buffer -- and ran at
-    // exactly the bandwidth-bound time of the k_inv_records it replaced).  Inside a run the order is the order in which
-    // the atomics were served: the list pass ranks the handful of entries of a run (the canonical order) ----
+    // list pass gathers the two depths it needs by that index (round 6: from the 8-byte stream hyp_q; 16-byte entries that
+    // carry the depths through the sort were measured twice and lose: in round 3 reading them from the 32-byte slots, in
+    // round 6 from hyp_q -- coalesced in slot order or gathered in sorted order, profiles/r06_ab_pair_csr.txt).  Inside a run
+    // the order is the order in which the atomics were served: the list pass ranks the handful of entries of a run (the
+    // canonical order) ----
     uint32_t* __restrict__ out = refs + pd.slot_off;
+    if (STAGED) {
+        L3D_LDS uint32_t* stage = lcur + (lds_segs_round(Mt) + 64);       // [stage_cap] slot indices (within the pair) in sorted order
+        const uint32_t total = part[kCsrBlock - 1];
+        const uint32_t window = stage_cap - min(stage_cap / 8, 1024u);     // records a range aims at (the rest of the stage: its last run's overhang)
+        uint32_t t_lo = 0, base = 0;
+        while (base < total) {                                              // (uniform)
+            // first target whose run starts at or beyond base + window: every thread searches the pristine starts [t_lo, Mt)
+            uint32_t lo = t_lo + 1, hi = Mt;                                // (at least one target per range)
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (lcur[mid] < base + window) lo = mid + 1; else hi = mid; }
+            const uint32_t t_hi = lo, end = t_hi < Mt ? lcur[t_hi] : total;
+            __syncthreads();                                                // (all have read the starts before a cursor moves)
+            for (uint32_t i0 = 0; i0 < S; i0 += kCsrChunk * kCsrBlock) {
+                uint32_t tv[kCsrChunk], at[kCsrChunk];
+#pragma unroll
+                for (uint32_t k = 0; k < kCsrChunk; ++k) { const uint32_t i = i0 + k * kCsrBlock + tid; tv[k] = it[min(i, S - 1)]; tv[k] = (i < S && tv[k] >= t_lo && tv[k] < t_hi) ? tv[k] : kEmpty; }
+#pragma unroll
+                for (uint32_t k = 0; k < kCsrChunk; ++k)
+                    at[k] = tv[k] != kEmpty ? __hip_atomic_fetch_add(&lcur[tv[k]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < kCsrChunk; ++k) {
+                    if (tv[k] == kEmpty) continue;
+                    const uint32_t i = i0 + k * kCsrBlock + tid, x = at[k] - base;
+                    if (x < stage_cap) stage[x] = i;
+                    else out[at[k]] = (uint32_t)pd.slot_off + i;       // (a run beyond the stage: rare)
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            const uint32_t n_here = min(end - base, stage_cap);
+            for (uint32_t x = tid; x < n_here; x += kCsrBlock) out[base + x] = (uint32_t)pd.slot_off + stage[x];
+            __syncthreads();                                                // (the stage is reused)
+            t_lo = t_hi; base = end;
+        }
+        for (uint32_t t = tid; t < Mt; t += kCsrBlock) *gcur(t) = lcur[t];   // (the cursors have reached the ends of their runs)
+        return;
+    }
     for (uint32_t i0 = 0; i0 < S; i0 += kCsrChunk * kCsrBlock) {
         uint32_t tv[kCsrChunk], at[kCsrChunk];
 #pragma unroll
@@ -692,15 +736,15 @@ __global__ __launch_bounds__(64 * WPL) void k_lists(const ViewDev* __restrict__ 
                                                const ListView* __restrict__ lviews, const OutPair* __restrict__ opairs,
                                                const InPair* __restrict__ ipairs, const uint32_t* __restrict__ gseg_view,
                                                const uint32_t* __restrict__ poff,
-                                               const uint32_t* __restrict__ inv, const Slot* __restrict__ slots,
-                                               uint32_t uniform_K, const ListPools lp, uint32_t view0) {
+                                               const uint32_t* __restrict__ inv, const float2* __restrict__ hyp_p,
+                                               const float2* __restrict__ hyp_q, uint32_t uniform_K, const ListPools lp, uint32_t view0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (WPL == 1) {
         const uint32_t vi = view0 + blockIdx.y, seg = blockIdx.x;
         if (seg >= lviews[vi].M) return;
         const uint32_t pool = lp.pool0 + ((blockIdx.y * gridDim.x + blockIdx.x) >> 2) % lp.npools;
         const uint32_t L = process_list<1, BASE>(vi, seg, pool, (L3D_LDS char*)smem, views, pairs, lviews, opairs,
-                                                 ipairs, poff, inv, slots, uniform_K, lp);
+                                                 ipairs, poff, inv, hyp_p, hyp_q, uniform_K, lp);
         if (L && lane_id() == 0) {              // longer than one wave stages: handed to a larger tier
             const uint32_t g = lviews[vi].seg_base + seg;
             if (L > 65535u) atomicOr(&lp.flags[1], 1u);
@@ -715,7 +759,7 @@ __global__ __launch_bounds__(64 * WPL) void k_lists(const ViewDev* __restrict__ 
             const uint32_t g = list[idx];
             const uint32_t vi = gseg_view[g];
             (void)process_list<WPL, BASE>(vi, g - lviews[vi].seg_base, lp.pool0 + blockIdx.x % lp.npools, (L3D_LDS char*)smem, views, pairs,
-                                          lviews, opairs, ipairs, poff, inv, slots, uniform_K, lp);
+                                          lviews, opairs, ipairs, poff, inv, hyp_p, hyp_q, uniform_K, lp);
             __syncthreads();
         }
     }
@@ -732,8 +776,8 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
                                                     const OutPair* __restrict__ opairs, const InPair* __restrict__ ipairs,
                                                     const uint32_t* __restrict__ gseg_view,
                                                     const uint32_t* __restrict__ poff,
-                                                    const uint32_t* __restrict__ inv, const Slot* __restrict__ slots,
-                                                    const ListPools lp, const HugeScratch hs) {
+                                                    const uint32_t* __restrict__ inv, const float2* __restrict__ hyp_p,
+                                                    const float2* __restrict__ hyp_q, const ListPools lp, const HugeScratch hs) {
     __shared__ uint32_t red[16];
     __shared__ uint32_t s_base;
     constexpr uint32_t kRows = 256;                 // incoming pairs staged per round
@@ -757,15 +801,18 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
             const OutPair op = opairs[q];
             const uint64_t row0 = op.slot_off + (uint64_t)seg * op.K;
             for (uint32_t j = t; j < op.K; j += 256) {
-                const Slot s = slots[row0 + j];
-                mine_n += (s.tgt_seg != kEmpty && (s.flags & kSlotAlive)) ? 1u : 0u;
+                const float2 s = hyp_p[row0 + j];
+                mine_n += s.x == s.x ? 1u : 0u;
             }
         }
         uint32_t n_fresh;
         (void)group_scan<4>(mine_n, n_fresh, red);
         const uint32_t L = n_inv + n_fresh;
         __syncthreads();
-        if (t == 0) { s_base = atomicAdd(&lp.flags[6], L); atomicAdd(&lp.cnt[(lp.pool0 + blockIdx.x % lp.npools) * 16 + 5], L); }
+        if (t == 0) {
+            s_base = atomicAdd(&lp.flags[6], L);
+            atomicAdd(&lp.cnt[(lp.pool0 + blockIdx.x % lp.npools) * 16 + 5], L); atomicAdd(&lp.cnt[(lp.pool0 + blockIdx.x % lp.npools) * 16 + 6], n_inv);
+        }
         __syncthreads();
         const uint32_t base = s_base;
         if ((uint64_t)base + L > hs.cap) { if (t == 0) atomicOr(&lp.flags[2], 1u); continue; }
@@ -795,7 +842,7 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
                 const uint32_t ref = rowp[x - r0];
                 uint32_t rank = r0;                                 // ascending slot index inside the row (k_pair_csr leaves a row unordered)
                 for (uint32_t y = 0; y < r1 - r0; ++y) rank += rowp[y] < ref ? 1u : 0u;
-                const float2 dq = *(const float2*)&slots[ref].dq1;
+                const float2 dq = hyp_q[ref];
                 const uint32_t at = pos + rank;
                 e_d1[at] = dq.x; e_d2[at] = dq.y; e_tv[at] = s_row[4 * lo + 2]; e_ref[at] = ref; e_pf[at] = s_row[4 * lo + 3] | kHypInv;
             }
@@ -807,11 +854,11 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
             const uint64_t row0 = op.slot_off + (uint64_t)seg * op.K;
             for (uint32_t j0 = 0; j0 < op.K; j0 += 256) {
                 bool alive = false;
-                Slot s;
-                if (j0 + t < op.K) { s = slots[row0 + j0 + t]; alive = s.tgt_seg != kEmpty && (s.flags & kSlotAlive); }
+                float2 s = make_float2(0.0f, 0.0f);
+                if (j0 + t < op.K) { s = hyp_p[row0 + j0 + t]; alive = s.x == s.x; }
                 uint32_t total;
                 const uint32_t at = pos + group_scan<4>(alive ? 1u : 0u, total, red);
-                if (alive && at < L) { e_d1[at] = s.dp1; e_d2[at] = s.dp2; e_tv[at] = op.tgt; e_ref[at] = (uint32_t)(row0 + j0 + t); e_pf[at] = op.pair; }
+                if (alive && at < L) { e_d1[at] = s.x; e_d2[at] = s.y; e_tv[at] = op.tgt; e_ref[at] = (uint32_t)(row0 + j0 + t); e_pf[at] = op.pair; }
                 pos += total;
             }
         }
@@ -1293,8 +1340,8 @@ __global__ void k_seg_write(uint32_t g0, uint32_t g1, unsigned long long base64,
 std::atomic<uint64_t> g_csr_global_launches{0};   // test hook (l3d_debug_counter): launches of the global-cursor k_pair_csr<false>
 
 hipError_t launch_pair_csr(const PairDesc* pairs, uint32_t n_pairs, uint32_t max_Mt, const PairCsr* pair_poff,
-                           const uint32_t* inv_tgt, uint32_t tgt16, uint32_t* poff, uint32_t* refs, uint32_t* dummy,
-                           uint32_t tgt_v0, uint32_t tgt_v1, hipStream_t st) {
+                           const uint32_t* inv_tgt, uint32_t tgt16, uint32_t* poff, uint32_t* refs,
+                           uint32_t* dummy, uint32_t tgt_v0, uint32_t tgt_v1, uint64_t max_pair_slots, hipStream_t st) {
     if (!n_pairs) return hipSuccess;
     // (L3D_CSR_GLOBAL=1, test hook: every pair takes the global-memory form that views beyond the LDS capacity need.  Read
     // PER CALL, as lists_run reads it when it sizes `dummy`: a process-wide static here was latched by whichever test ran
@@ -1306,18 +1353,38 @@ hipError_t launch_pair_csr(const PairDesc* pairs, uint32_t n_pairs, uint32_t max
     // (contexts on different threads would otherwise race with different sizes)
     static const hipError_t attr_rc = [] {
         const int mx = (int)(((size_t)kCsrLdsSegs + 64) * 4);
-        hipError_t e = hipFuncSetAttribute((const void*)k_pair_csr<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_pair_csr<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        hipError_t e = hipFuncSetAttribute((const void*)k_pair_csr<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_pair_csr<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
         return e;
     }();
     if (attr_rc != hipSuccess) return attr_rc;
+    // The staged form (LDS cursors, 16-bit targets).  Stage size: room for the entries of the largest pair in ONE range (about
+    // 0.6 of its slots hand an inverse match over) -- beside the cursors inside 78 KiB if that fits (two workgroups per CU: C1,
+    // C3), else inside one workgroup's whole LDS (C2: 0.26 against 0.35 ms with two ranges at 78 KiB); pairs beyond that take
+    // several ranges (C4: 0.64 ms with 4 or with 27 of them).  L3D_CSR_STAGED=0: the direct form; L3D_CSR_STAGE_KB: the budget (A/B).
+    const char* st_env = std::getenv("L3D_CSR_STAGED");
+    if (tgt16 && !force_global && max_Mt <= lds_segs && !(st_env && std::atoi(st_env) == 0)) {
+        const size_t cur_bytes = ((size_t)lds_segs_round(max_Mt) + 64) * 4;
+        const char* kb_env = std::getenv("L3D_CSR_STAGE_KB");
+        const size_t two = 78 * 1024, one = 156 * 1024 - 4096;
+        const size_t want = (size_t)(0.6 * (double)max_pair_slots) * 4 + 4096;
+        size_t budget = cur_bytes + want <= two ? two : one;
+        if (kb_env) budget = std::min<size_t>(std::max<size_t>((size_t)std::atoi(kb_env) * 1024, cur_bytes + 4096), one);
+        size_t cap = (budget - cur_bytes) / 4;
+        cap = std::min<size_t>(cap, (size_t)std::max<uint64_t>(max_pair_slots, 1024));   // (never more entries than slots)
+        static const hipError_t attr2 = hipFuncSetAttribute((const void*)k_pair_csr<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        if (attr2 != hipSuccess) return attr2;
+        hipLaunchKernelGGL((k_pair_csr<true, true, true>), dim3(n_pairs), dim3(kCsrBlock), cur_bytes + cap * 4, st, pairs, 0u, pair_poff, inv_tgt,
+                           poff, refs, dummy, tgt_v0, tgt_v1, lds_segs, (uint32_t)cap);
+        return hipGetLastError();
+    }
 #define L3D_CSR(T16)                                                                                                      \
     do {                                                                                                                  \
-        hipLaunchKernelGGL((k_pair_csr<true, T16>), dim3(n_pairs), dim3(kCsrBlock), lds, st, pairs, 0u, pair_poff, inv_tgt, \
-                           poff, refs, dummy, tgt_v0, tgt_v1, lds_segs);                                                  \
+        hipLaunchKernelGGL((k_pair_csr<true, T16, false>), dim3(n_pairs), dim3(kCsrBlock), lds, st, pairs, 0u, pair_poff, inv_tgt, \
+                           poff, refs, dummy, tgt_v0, tgt_v1, lds_segs, 0u);                                              \
         if (max_Mt > lds_segs) { /* views beyond the LDS capacity: cursors in global memory (dummy: 64 words per pair) */ \
-            hipLaunchKernelGGL((k_pair_csr<false, T16>), dim3(n_pairs), dim3(kCsrBlock), 0, st, pairs, 0u, pair_poff, inv_tgt, \
-                               poff, refs, dummy, tgt_v0, tgt_v1, lds_segs);                                              \
+            hipLaunchKernelGGL((k_pair_csr<false, T16, false>), dim3(n_pairs), dim3(kCsrBlock), 0, st, pairs, 0u, pair_poff, inv_tgt, \
+                               poff, refs, dummy, tgt_v0, tgt_v1, lds_segs, 0u);                                          \
             g_csr_global_launches.fetch_add(1, std::memory_order_relaxed);                                                \
         }                                                                                                                 \
     } while (0)
@@ -1361,7 +1428,7 @@ hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, uint32
 #endif
 hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev* views, const PairDesc* pairs,
                         const ListView* lviews, const OutPair* opairs, const InPair* ipairs, const uint32_t* gseg_view,
-                        const uint32_t* poff, const uint32_t* inv, const Slot* slots, uint32_t uniform_K,
+                        const uint32_t* poff, const uint32_t* inv, const float2* hyp_p, const float2* hyp_q, const Slot* slots, uint32_t uniform_K,
                         SimConst sc, ListPools lp, uint32_t* seg_of_g, HugeScratchArgs hsa, hipStream_t st) {
     if (!nv || !max_M) return hipSuccess;
     // the one-wave tier stages 128 hypotheses (8 waves per SIMD) unless the scene's lists are long on average
@@ -1380,16 +1447,16 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
         for (uint32_t a = 0; a < nv; a += 65535u) { /* grid.y limit */                                                     \
             const uint32_t n = nv - a < 65535u ? nv - a : 65535u;                                                          \
             hipLaunchKernelGGL((k_lists<1, B>), dim3(max_M, n), dim3(64), lds1, st, views, pairs, lviews, opairs, ipairs,  \
-                               gseg_view, poff, inv, slots, uniform_K, lp, v0 + a);                                        \
+                               gseg_view, poff, inv, hyp_p, hyp_q, uniform_K, lp, v0 + a);                                        \
         }                                                                                                                  \
         /* lists beyond one wave's capacity: two waves up to 2x, four up to 4x (fixed grids over the hand-over lists) */   \
         hipLaunchKernelGGL((k_lists<2, B>), dim3(L3D_LISTS2_GRID), dim3(128), lds2, st, views, pairs, lviews, opairs, ipairs, \
-                           gseg_view, poff, inv, slots, uniform_K, lp, 0u);                                                \
+                           gseg_view, poff, inv, hyp_p, hyp_q, uniform_K, lp, 0u);                                                \
         /* (the four-wave tier is left out while the passes hand it no list -- C1: an empty grid of 16 us --, like      */    \
         /* k_lists_huge below: a pass that then does hand one over is repeated with it, flags[4], check_pass)           */    \
         if (hsa.run_tier4)                                                                                                 \
         hipLaunchKernelGGL((k_lists<4, B>), dim3(L3D_LISTS4_GRID), dim3(256), lds4, st, views, pairs, lviews, opairs, ipairs, \
-                           gseg_view, poff, inv, slots, uniform_K, lp, 0u);                                                \
+                           gseg_view, poff, inv, hyp_p, hyp_q, uniform_K, lp, 0u);                                                \
     } while (0)
     if (wide) L3D_LISTS(256); else L3D_LISTS(128);
 #undef L3D_LISTS
@@ -1401,7 +1468,7 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
     // launch is left out (a pass that then does hand one over is repeated with it: flags[5], l3d_api.hip check_pass)
     if (hsa.run_huge)
         hipLaunchKernelGGL(k_lists_huge, dim3(256), dim3(256), 0, st, views, pairs, lviews, opairs, ipairs, gseg_view, poff,
-                           inv, slots, lp, hs);
+                           inv, hyp_p, hyp_q, lp, hs);
     hipLaunchKernelGGL(k_cand_exact, dim3((lp.ccap + 255) / 256, lp.npools), dim3(256), 0, st, views, pairs, gseg_view, sc, lp);
     hipLaunchKernelGGL(k_edges, dim3((lp.scap + L3D_EDGES_SPLIT - 1) / L3D_EDGES_SPLIT, lp.npools), dim3(64), 0, st, views, pairs,
                        gseg_view, slots, lp, seg_of_g);

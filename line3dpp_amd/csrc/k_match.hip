@@ -171,6 +171,13 @@ __device__ __forceinline__ void store_inverse_target(const OrientFuse& of, uint6
     const uint32_t t = inverse_target(o);
     if (of.tgt16) ((uint16_t*)of.inv_tgt)[at] = (uint16_t)(t == kEmpty ? 0xFFFFu : t);   // (wave-uniform choice)
     else of.inv_tgt[at] = t;
+    // the hypothesis streams of phase B (l3d_kernels.h: OrientFuse): what the list pass reads of a slot, 8 bytes each
+    if (of.hyp_p) {
+        const float nan = __builtin_nanf("");
+        const bool alive = o.tgt_seg != kEmpty && (o.flags & kSlotAlive);
+        of.hyp_p[at] = alive ? make_float2(o.dp1, o.dp2) : make_float2(nan, nan);
+        of.hyp_q[at] = make_float2(o.dq1, o.dq2);
+    }
 }
 
 }  // namespace

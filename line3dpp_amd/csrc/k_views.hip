@@ -41,7 +41,8 @@ __device__ unsigned long long g_bstats[8];
 // match epilogue does the same on the way -- and the 4-byte stream k_pair_csr sorts:
 //   inv_tgt[slot] target segment of a slot that hands an inverse match to its target view (kEmpty: none)
 __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
-                             Slot* __restrict__ slots, uint32_t* __restrict__ inv_tgt, uint32_t tgt16, OrientThr othr) {
+                             Slot* __restrict__ slots, uint32_t* __restrict__ inv_tgt, uint32_t tgt16,
+                             float2* __restrict__ hyp_p, float2* __restrict__ hyp_q, OrientThr othr) {
     const PairDesc& pd = pairs[blockIdx.y];
     const uint64_t n = (uint64_t)pd.Ms * pd.K;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,9 +51,9 @@ __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* 
     uint32_t itgt = kEmpty;
     Slot* sp = slots + pd.slot_off + i;
     const Slot s = *sp;
+    uint32_t flags = 0;
     if (s.tgt_seg != kEmpty) {
         const ViewDev& vs = views[pd.src];
-        uint32_t flags = 0;
         if (orientation_ok_fast(vs.C, vs.segx[row], s.dp1, s.dp2, othr)) {
             flags = kSlotAlive;
             // inverse copy: only towards a view that is processed later (line3D.cc:1680)
@@ -66,6 +67,10 @@ __global__ void k_orient_all(const ViewDev* __restrict__ views, const PairDesc* 
     }
     if (tgt16) ((uint16_t*)inv_tgt)[pd.slot_off + i] = (uint16_t)(itgt == kEmpty ? 0xFFFFu : itgt);
     else inv_tgt[pd.slot_off + i] = itgt;
+    // the hypothesis streams the list pass reads (l3d_kernels.h: OrientFuse)
+    const float nan = __builtin_nanf("");
+    hyp_p[pd.slot_off + i] = (flags & kSlotAlive) ? make_float2(s.dp1, s.dp2) : make_float2(nan, nan);
+    hyp_q[pd.slot_off + i] = make_float2(s.dq1, s.dq2);
 }
 
 
@@ -628,10 +633,11 @@ hipError_t launch_fill_gseg_view(const uint32_t* seg_base, uint32_t V, uint32_t 
     return hipGetLastError();
 }
 hipError_t launch_orient_pairs(const ViewDev* views, const PairDesc* pairs, uint32_t n_pairs, uint64_t max_slots,
-                               Slot* slots, uint32_t* inv_tgt, uint32_t tgt16, double thr_lo, double thr_hi, hipStream_t st) {
+                               Slot* slots, uint32_t* inv_tgt, uint32_t tgt16, float2* hyp_p, float2* hyp_q, double thr_lo,
+                               double thr_hi, hipStream_t st) {
     if (!n_pairs || !max_slots) return hipSuccess;
     hipLaunchKernelGGL(k_orient_all, dim3((uint32_t)((max_slots + 255) / 256), n_pairs), dim3(256), 0, st, views,
-                       pairs, slots, inv_tgt, tgt16, OrientThr{thr_lo, thr_hi});
+                       pairs, slots, inv_tgt, tgt16, hyp_p, hyp_q, OrientThr{thr_lo, thr_hi});
     return hipGetLastError();
 }
 hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, uint32_t* long_list, uint32_t* n_long,

@@ -414,7 +414,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_scal.release();
     c->d_surv_off.release(); c->d_hyp_off.release();
     c->d_surv_tg.release(); c->d_surv_sg.release();
-    c->d_inv_tgt.release(); c->d_gsegx.release(); c->d_gsegd32.release();
+    c->d_inv_tgt.release(); c->d_hyp_p.release(); c->d_hyp_q.release(); c->d_gsegx.release(); c->d_gsegd32.release();
     c->d_tie_count.release(); c->d_tie_list.release(); c->d_tie_heap.release(); c->d_item_bucket.release(); c->d_item_order.release(); c->d_order_done.release();
     c->d_coll_cnt.release(); c->d_coll_off.release(); c->d_coll_idx.release(); c->d_item_cnt.release();
     c->d_item_off.release(); c->d_item_seg.release(); c->d_item_sim.release();
@@ -698,7 +698,11 @@ static int match_begin_body(l3d_ctx* c) {
         for (auto* v : c->order) mx = std::max(mx, v->M);
         c->tgt16 = (mx < 65535u && !std::getenv("L3D_INV_TGT32")) ? 1u : 0u;
     }
-    if (c->kNN > 0) L3D_HIP_CHECK(c->d_inv_tgt.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    if (c->kNN > 0) {
+        L3D_HIP_CHECK(c->d_inv_tgt.reserve(std::max<uint64_t>(c->n_slots, 1)));
+        L3D_HIP_CHECK(c->d_hyp_p.reserve(std::max<uint64_t>(c->n_slots, 1)));
+        L3D_HIP_CHECK(c->d_hyp_q.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    }
     L3D_HIP_CHECK(c->d_pairs.reserve(std::max<size_t>(c->pairs.size(), 1)));
     {
         bool sent = false;
@@ -827,7 +831,8 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     if (c->ev_on(4)) L3D_HIP_CHECK(hipEventRecord(c->ev[4], c->stream));
     const bool ix16 = maxMt < 65536u && maxK < 32768u;   // 16-bit indices in the kernel's LDS tables (top bit of a row's minpos: tie flag)
     // bounded kNN: the orientation filter of phase B is fused into the epilogue
-    OrientFuse of{mode == 0 ? c->d_inv_tgt.p : nullptr, c->tgt16, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
+    OrientFuse of{mode == 0 ? c->d_inv_tgt.p : nullptr, c->tgt16, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr,
+                  mode == 0 ? c->d_hyp_p.p : nullptr, mode == 0 ? c->d_hyp_q.p : nullptr};
     uint32_t tie_stride = 0;
     if (mode == 0) {   // rows with equal overlaps are collected here and replayed in the reference's heap order
         uint32_t mt = 0;
@@ -982,7 +987,8 @@ int l3d_expand_slot_indices(l3d_ctx* c, uint32_t first, uint32_t count) {
         max_row_slots = std::max<uint64_t>(max_row_slots, (uint64_t)c->pairs[p].Ms * c->pairs[p].K);
     for (uint32_t p = first; p < first + count; ++p)
         if (c->pair_done[p]) return fail(L3D_ERR_STATE, "l3d_expand_slot_indices: pair already present on this rank");
-    const OrientFuse of{c->d_inv_tgt.p, c->tgt16, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr};
+    const OrientFuse of{c->d_inv_tgt.p, c->tgt16, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr,
+                        c->d_hyp_p.p, c->d_hyp_q.p};
     L3D_HIP_CHECK(launch_expand_slot_idx(c->d_views.p, c->d_pairs.p, first, count, max_row_slots, c->d_slot_idx.p,
                                          c->d_slots.p, of, c->stream));
     for (uint32_t p = first; p < first + count; ++p) c->pair_done[p] = c->pair_counted[p] = 1;

@@ -42,7 +42,7 @@ hipError_t launch_seam_all_present(uint32_t G, const uint32_t* off, const uint32
 hipError_t launch_seam_scores_out(uint32_t n, const DEntry*, float* scores, hipStream_t);
 hipError_t launch_fill_gseg_view(const uint32_t* seg_base, uint32_t V, uint32_t max_M, uint32_t* gseg_view, hipStream_t);
 hipError_t launch_orient_pairs(const ViewDev*, const PairDesc*, uint32_t n_pairs, uint64_t max_slots, Slot* slots,
-                               uint32_t* inv_tgt, uint32_t tgt16, double thr_lo, double thr_hi, hipStream_t);
+                               uint32_t* inv_tgt, uint32_t tgt16, float2* hyp_p, float2* hyp_q, double thr_lo, double thr_hi, hipStream_t);
 hipError_t launch_bits_len(uint32_t G, const uint32_t* off, uint32_t* len, uint32_t* long_list, uint32_t* n_long,
                            hipStream_t);
 hipError_t launch_support_long(uint32_t n_long, const uint32_t* long_list, const uint32_t* off, const uint32_t* boff,
@@ -203,6 +203,9 @@ struct l3d_ctx {
     DevBuf<uint32_t> d_seg_base, d_gseg_view, d_scal;
     DevBuf<uint32_t> d_surv_off, d_hyp_off, d_surv_tg, d_surv_sg;
     DevBuf<uint32_t> d_inv_tgt;                      // [n_slots] target segment of an inverse-alive slot, kEmpty otherwise
+    // the compact hypothesis streams of phase B (round 6; l3d_kernels.h: OrientFuse): 8 bytes per slot each, written beside
+    // the slots
+    DevBuf<float2> d_hyp_p, d_hyp_q;
     uint32_t tgt16 = 0;                             // ... as 16-bit entries (every view below 65 535 segments; set by l3d_match_begin)
     DevBuf<uint32_t> d_poff, d_csr_dummy;           // per-pair CSR offsets over the target's segments (k_pair_csr)
     uint32_t poff_total = 0, n_in_pairs = 0;        // entries of d_poff / of the InPair table of the running call

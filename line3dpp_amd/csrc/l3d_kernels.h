@@ -97,6 +97,12 @@ struct OrientFuse {
     uint32_t tie_cap;
     uint32_t* tie_next;             // the counter the next match launch will use (zeroed by k_match_tied_rows)
     uint32_t* tie_total;            // rows replayed so far (diagnostics)
+    // The compact hypothesis streams of phase B (round 6), written beside the slots by whatever produces a slot (nullptr: not
+    // kept -- the accelerator seam): the list pass of phase B reads 8 bytes per slot where it read the 32-byte record for 8.
+    float2* hyp_p;                  // [n_slots] (depth_p1, depth_p2) of an ALIVE slot (kSlotAlive), NaN otherwise: the fresh
+                                    // hypotheses of the source segment
+    float2* hyp_q;                  // [n_slots] (depth_q1, depth_q2): the depths of a slot's INVERSE hypothesis (read where
+                                    // inv_tgt names a target); k_pair_csr carries them into the sorted order of its records
 };
 
 // ---- k_match.hip ----
@@ -141,13 +147,14 @@ hipError_t launch_scan64(const unsigned long long* in, uint32_t n, unsigned long
 // the inverse hypotheses of every pair that hands matches to a later view, sorted by target segment (counting sort per
 // pair, one workgroup each): poff = per-pair CSR offsets over the target's segments, refs = the slot indices in that order
 hipError_t launch_pair_csr(const PairDesc* pairs, uint32_t n_pairs, uint32_t max_Mt, const PairCsr* pair_csr,
-                           const uint32_t* inv_tgt, uint32_t tgt16, uint32_t* poff, uint32_t* refs, uint32_t* dummy,
-                           uint32_t tgt_v0, uint32_t tgt_v1, hipStream_t st);
+                           const uint32_t* inv_tgt, uint32_t tgt16, uint32_t* poff, uint32_t* refs,
+                           uint32_t* dummy, uint32_t tgt_v0, uint32_t tgt_v1, uint64_t max_pair_slots, hipStream_t st);
 hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, uint32_t world, hipStream_t st);
 struct ListView; struct OutPair; struct InPair;
 hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev* views, const PairDesc* pairs,
                         const ListView* lviews, const OutPair* opairs, const InPair* ipairs, const uint32_t* gseg_view,
-                        const uint32_t* poff, const uint32_t* inv_refs, const Slot* slots, uint32_t uniform_K,
+                        const uint32_t* poff, const uint32_t* inv_refs, const float2* hyp_p, const float2* hyp_q,
+                        const Slot* slots, uint32_t uniform_K,
                         SimConst sc, ListPools lp, uint32_t* seg_of_g, HugeScratchArgs hsa, hipStream_t st);
 hipError_t launch_chain_sweep(ListPools lp, uint8_t* positive, uint32_t* changed, uint32_t sweep, hipStream_t st);
 hipError_t launch_hyp_scores(ListPools lp, const uint8_t* positive, const uint32_t* gseg_view, Slot* slots,

@@ -23,6 +23,13 @@ namespace l3d {
 // pair's run ascending slot index.  k_pair_csr leaves a run in the order its LDS atomics were served; the list pass
 // ranks an entry among the handful of entries of its run and reads the two depths it needs from the slot itself.
 
+// Round 6: the depths a hypothesis needs no longer come out of the 32-byte slots but out of two 8-byte streams written beside
+// them (l3d_kernels.h: OrientFuse): hyp_p[slot] = (dp1, dp2) of an alive slot (NaN otherwise) for the fresh hypotheses, read in
+// slot order; hyp_q[slot] = (dq1, dq2) for the inverse ones, gathered by the slot index of the sorted entry.  Carrying the two
+// depths through the sort (16-byte entries, one contiguous load per run in the list pass) was built and measured: the list pass
+// read 0.32 x the bytes and gained 5 %, the sort lost more than that whichever way the depths reached it
+// (profiles/r06_ab_pair_csr.txt).
+
 // per view / per outgoing pair of a view: what the list pass needs of ViewDev / PairDesc, packed so that a wave gets
 // it with one or two loads instead of a chain of dependent ones (view -> pair list -> pair -> slot)
 struct ListView {

@@ -218,6 +218,7 @@ static int lists_prepare(l3d_ctx* c, int caps_mode) {
     L3D_HIP_CHECK(c->d_hyps.reserve(std::max<uint32_t>(G, 1))); L3D_HIP_CHECK(c->d_depths.reserve(2 * (size_t)G + 2));
     L3D_HIP_CHECK(c->d_inv_refs.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(c->d_inv_tgt.reserve(std::max<uint64_t>(c->n_slots, 1)));
+    L3D_HIP_CHECK(c->d_hyp_p.reserve(std::max<uint64_t>(c->n_slots, 1))); L3D_HIP_CHECK(c->d_hyp_q.reserve(std::max<uint64_t>(c->n_slots, 1)));
     L3D_HIP_CHECK(c->h_fin.reserve(kFinHead + fin_med(V)));
     if (c->ev_on(6)) L3D_HIP_CHECK(hipEventRecord(c->ev[6], st));
     g_trace.mark("finish: reserves done");
@@ -287,7 +288,7 @@ static int lists_prepare(l3d_ctx* c, int caps_mode) {
         uint32_t p1 = p0;
         while (p1 < P && !c->pair_counted[p1] && c->pair_done[p1]) ++p1;
         L3D_HIP_CHECK(launch_orient_pairs(c->d_views.p, c->d_pairs.p + p0, p1 - p0, max_slots, c->d_slots.p, c->d_inv_tgt.p,
-                                          c->tgt16, c->orient_lo, c->orient_hi, st));
+                                          c->tgt16, c->d_hyp_p.p, c->d_hyp_q.p, c->orient_lo, c->orient_hi, st));
         for (uint32_t p = p0; p < p1; ++p) c->pair_counted[p] = 1;
         p0 = p1;
     }
@@ -355,7 +356,7 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
             // (views beyond the LDS capacity of k_pair_csr keep their cursors in global memory: 64 dummy words per pair)
             if (max_Mt > 32768 || std::getenv("L3D_CSR_GLOBAL")) L3D_HIP_CHECK(c->d_csr_dummy.reserve((size_t)P * 64));
             L3D_HIP_CHECK(launch_pair_csr(c->d_pairs.p, P, max_Mt, pair_poff, c->d_inv_tgt.p, c->tgt16, c->d_poff.p, c->d_inv_refs.p,
-                                          c->d_csr_dummy.p, v0, v0 + nv, st));
+                                          c->d_csr_dummy.p, v0, v0 + nv, max_slots, st));
         }
     }
     g_trace.mark("pair CSRs enqueued");
@@ -369,7 +370,7 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
     uint32_t max_M = 0;
     for (uint32_t vi = v0; vi < v0 + nv; ++vi) max_M = std::max(max_M, c->order[vi]->M);
     L3D_HIP_CHECK(launch_lists(v0, nv, max_M, c->d_views.p, c->d_pairs.p, lviews, opairs, ipairs, c->d_gseg_view.p,
-                               c->d_poff.p, c->d_inv_refs.p, c->d_slots.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, simc, lp,
+                               c->d_poff.p, c->d_inv_refs.p, c->d_hyp_p.p, c->d_hyp_q.p, c->d_slots.p, c->kNN > 0 ? (uint32_t)c->kNN : 0u, simc, lp,
                                c->d_seg_of_g.p, hsa, st));
     if (c->ev_on(9)) L3D_HIP_CHECK(hipEventRecord(c->ev[9], st));
     g_trace.mark("list pass enqueued");
@@ -507,10 +508,14 @@ static int finish_commit(l3d_ctx* c) {
     c->n_surv = h0[2]; c->n_hyps = h0[3];
     c->tm.tied_rows = h0[0];   // rows replayed in the reference's priority_queue order, cumulative (k_median_all hands it over)
     {   // total length of the hypothesis lists: counted by the list pass per pool (k_lists.hip: cnt[pool * 16 + 5])
-        uint64_t ents = 0;
-        for (uint32_t q = 0; q < kListPools; ++q) ents += h[q * 16 + 5];
+        uint64_t ents = 0, inv = 0, cands = 0, hdrs = 0;
+        for (uint32_t q = 0; q < kListPools; ++q) { ents += h[q * 16 + 5]; inv += h[q * 16 + 6]; cands += h[q * 16 + 3]; hdrs += h[q * 16 + 1]; }
         c->n_ents = (uint32_t)std::min<uint64_t>(ents, 0xFFFFFFFFu);
         c->tm.list_entries = c->n_ents;
+        c->tm.list_inverse = (uint32_t)std::min<uint64_t>(inv, 0xFFFFFFFFu);
+        c->tm.list_candidates = (uint32_t)std::min<uint64_t>(cands, 0xFFFFFFFFu);
+        c->tm.list_headers = (uint32_t)std::min<uint64_t>(hdrs, 0xFFFFFFFFu);
+        c->tm.slots_lo = (uint32_t)c->n_slots; c->tm.slots_hi = (uint32_t)(c->n_slots >> 32);
     }
     for (uint32_t s2 = 0; s2 < c->chain_enqueued; ++s2) c->tm.chain_sweeps += changed[s2] ? 1u : 0u;   // of the last round
     c->chain_need = c->tm.chain_extra_rounds ? kChainSweeps : c->tm.chain_sweeps;

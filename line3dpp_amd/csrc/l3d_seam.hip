@@ -229,7 +229,7 @@ int l3d_match_lines(int device, const float* lines_src4, uint32_t Ms, const floa
         L3D_HIP_CHECK(tie_count.reserve(4)); L3D_HIP_CHECK(tie_list.reserve(Ms));
         L3D_HIP_CHECK(tie_heap.reserve(2 * (size_t)match_tied_grid(Mt) * std::max(Mt, 1u)));   // (l3d_kernels.h: one scratch region per workgroup)
         L3D_HIP_CHECK(hipMemset(tie_count.p, 0, 16));
-        OrientFuse of{inv_tgt.p, 0u, OrientThr{-1.0, 1.0}, tie_count.p, tie_list.p, Ms, tie_count.p + 1, tie_count.p + 2};
+        OrientFuse of{inv_tgt.p, 0u, OrientThr{-1.0, 1.0}, tie_count.p, tie_list.p, Ms, tie_count.p + 1, tie_count.p + 2, nullptr, nullptr};
         orientation_thresholds(of.thr.lo, of.thr.hi);
         L3D_HIP_CHECK(launch_match_pairs(0, false, dv.p, dp.p, dw.p, (uint32_t)work.size(), pd.K, ds.p, nullptr, thr,
                                          pools, of, Mt < 65536u && pd.K < 65536u, 0u, 0));
