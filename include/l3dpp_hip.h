@@ -258,6 +258,9 @@ int l3d_tail_shard_commit(l3d_ctx*);
  * Not with collinearity_t > 0 (line3D.cc:1904-1974 is sequential by definition): L3D_ERR_LIMIT, use l3d_compute_affinity. */
 int l3d_affinity_shard_begin(l3d_ctx*, uint32_t rank, uint32_t world, void** simv, uint64_t* first, uint64_t* count);
 int l3d_affinity_shard_finish(l3d_ctx*);
+/* closes an open sharded fill without the bookkeeping pass (a peer failed, its similarities never arrived: the caller goes
+ * on to l3d_compute_affinity on every rank): views untranslated, nothing else touched.  L3D_OK also when none is open. */
+int l3d_affinity_shard_abort(l3d_ctx*);
 /* Partition of a call over `world` ranks (host only; a function of the pair list of l3d_get_pairs): contiguous view
  * ranges whose outgoing pairs carry equal shares of the cost (pair_cost[p], e.g. Ms * Mt); pair_src_view[p] = index of
  * the pair's source view (the list is ordered by it).  view_bounds / pair_bounds receive world + 1 entries: rank r owns

@@ -176,6 +176,10 @@ class Line3D:
     def affinityShardFinish(self):
         return self._check(self.L.l3d_affinity_shard_finish(self.h), "affinityShardFinish")
 
+    def affinityShardAbort(self):
+        """l3d_affinity_shard_abort: close an open sharded fill without its bookkeeping pass (a peer could not shard)"""
+        return self._check(self.L.l3d_affinity_shard_abort(self.h), "affinityShardAbort")
+
     # Line3D::reconstruct3Dlines, line3D.h:162-166 (defaults commons.h:63-70)
     def reconstruct3Dlines(self, visibility_t=L3D_DEF_MIN_VISIBILITY_T, perform_diffusion=False, collinearity_t=-1.0,
                            use_CERES=False, max_iter_CERES=250):

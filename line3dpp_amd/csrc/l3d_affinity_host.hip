@@ -242,6 +242,7 @@ int l3d_compute_affinity(l3d_ctx* c) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (c->state != l3d_ctx::MATCHED) return fail(L3D_ERR_STATE, "matchImages must precede the affinity step");
+    if (c->aff_shard_open) return fail(L3D_ERR_STATE, "a sharded affinity fill is open: l3d_affinity_shard_finish (or _abort) first");
     // translate()/untranslate() (line3D.cc:1749,1820) only move camera centres, which the affinity terms never
     // read; they are applied to keep the host state identical to the reference's.
     translate(*c);
@@ -260,6 +261,7 @@ int l3d_affinity_shard_begin(l3d_ctx* c, uint32_t rank, uint32_t world, void** s
     if (!c || !simv || !first || !count) return fail(L3D_ERR_ARG, "null argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (c->state != l3d_ctx::MATCHED) return fail(L3D_ERR_STATE, "matchImages must precede the affinity step");
+    if (c->aff_shard_open) return fail(L3D_ERR_STATE, "l3d_affinity_shard_begin: a sharded affinity fill is already open (views translated)");
     if (world < 2 || rank >= world || c->aff_parts_world != world || c->tail_base_n.size() != (size_t)world + 1 ||
         c->tail_base_n[world] != c->n_surv)
         return fail(L3D_ERR_STATE, "l3d_affinity_shard_begin follows a call closed by l3d_tail_shard_commit with the same world size");
@@ -268,6 +270,9 @@ int l3d_affinity_shard_begin(l3d_ctx* c, uint32_t rank, uint32_t world, void** s
     translate(*c);
     int rc = affinity_prepare(c);
     if (rc == L3D_OK) rc = affinity_sim(c, c->tail_base_n[rank], c->tail_base_n[rank + 1]);
+    // (the caller posts the exchange of the similarities right away, possibly on another stream or through a backend that
+    // does not order itself after this stream: the part must be complete in device memory on return -- ADVICE round 5)
+    if (rc == L3D_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(L3D_ERR_HIP, "l3d_affinity_shard_begin: stream synchronisation failed");
     if (rc != L3D_OK) { untranslate(*c); return rc; }
     *simv = c->d_simv.p;
     for (uint32_t r = 0; r < world; ++r) { first[r] = c->tail_base_n[r]; count[r] = c->tail_base_n[r + 1] - c->tail_base_n[r]; }
@@ -286,6 +291,18 @@ int l3d_affinity_shard_finish(l3d_ctx* c) {
     return rc;
 }
 
+// closes an open sharded fill WITHOUT the bookkeeping pass (a rank whose peer failed: the other ranks' similarities never
+// arrived, the caller goes on to l3d_compute_affinity): views untranslated, nothing else touched
+int l3d_affinity_shard_abort(l3d_ctx* c) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (!c->aff_shard_open) return L3D_OK;
+    c->aff_shard_open = false;
+    (void)hipStreamSynchronize(c->stream);
+    untranslate(*c);
+    return L3D_OK;
+}
+
 // Line3D::reconstruct3Dlines, line3D.cc:1702-1824
 int l3d_reconstruct_3d_lines(l3d_ctx* c, uint32_t visibility_t, int perform_diffusion, float collinearity_t,
                              int use_CERES, uint32_t max_iter_CERES) {
@@ -294,6 +311,7 @@ int l3d_reconstruct_3d_lines(l3d_ctx* c, uint32_t visibility_t, int perform_diff
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (c->state != l3d_ctx::MATCHED || c->n_hyps == 0)
         return fail(L3D_ERR_STATE, "no clusterable segments! forgot to match lines?");   // line3D.cc:1712-1718
+    if (c->aff_shard_open) return fail(L3D_ERR_STATE, "a sharded affinity fill is open: l3d_affinity_shard_finish (or _abort) first");
     c->collinearity_t = collinearity_t;                                                          // :1725-1726
     if (use_CERES) set_error("CERES not available, no optimization will be performed");             // :1741-1743
     const unsigned vis = std::max<unsigned>(visibility_t, 3);

@@ -814,7 +814,9 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
         // longest-first launch order (k_order_items) where the launch has one to three items per wave slot (fewer: all
         // start at once; more: the tail is short against the whole) -- C1: kernel 1.08 -> 1.03 ms; C2 / C4: +6 % with it
         // (tile form: four to eight times as many, shorter items, the widest class of every pair first: list order)
-        if (!tile && !no_order && n_work > kMatchOrderMinItems && n_work <= kMatchOrderMaxItems) {
+        // (not for the exact-replay path of a kNN beyond the LDS tables: its launch is unpadded while PairCull::w_item0 counts
+        // the padded class layout -- k_order_items would file items past the end of d_item_bucket)
+        if (!tile && !no_order && !replay_all && n_work > kMatchOrderMinItems && n_work <= kMatchOrderMaxItems) {
             L3D_HIP_CHECK(c->d_item_bucket.reserve(n_work)); L3D_HIP_CHECK(c->d_item_order.reserve(n_work));
             if (!c->d_order_done.p) {            // zeroed once: the kernel re-arms it
                 L3D_HIP_CHECK(c->d_order_done.reserve(1));

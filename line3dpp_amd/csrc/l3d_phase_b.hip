@@ -693,6 +693,10 @@ int l3d_tail_shard_layout(l3d_ctx* c, uint32_t world, const uint32_t* counts_all
         const TailShard ts{c->shard_v0, c->shard_v1, c->seg_base[c->shard_v0], c->seg_base[c->shard_v1], c->shard_pool0, c->shard_ppr};
         const int r2 = tail_write_run(c, ts, (unsigned long long)c->tail_base_n[me] | ((unsigned long long)c->tail_base_h[me] << 32), false);
         if (r2) return r2;
+        // (the caller exchanges the parts right away, possibly on another stream or through a backend that does not order
+        // itself after this stream: they must be complete in device memory on return, as the slabs of l3d_lists_shard* are --
+        // ADVICE round 5)
+        L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
         void* bp[9] = {c->d_surv.p, c->d_surv_tg.p, c->d_surv_sg.p, c->d_hyps.p, c->d_depths.p, c->d_surv_off.p, c->d_hyp_off.p,
                        c->d_hyp_of_seg.p, medians_of(c)};
         const uint64_t eb[9] = {sizeof(Match), 4, 4, sizeof(HypRec), 8, 4, 4, 4, 4};

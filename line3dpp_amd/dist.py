@@ -506,8 +506,8 @@ def compute_affinity_sharded(l3d, rank, world_size, device=None, group=None):
         return l3d.computeAffinity()
     part = l3d.affinityShardBegin(rank, world_size)
     if not _all_ok(part is not None, device, group):
-        if part is not None and not l3d.affinityShardFinish():     # (closes the open shard: its similarities are complete
-            return False                                             # only for this rank's views, the result is discarded)
+        if part is not None:               # this rank's shard is open, a peer's is not: close it WITHOUT the bookkeeping pass
+            l3d.affinityShardAbort()       # (the other ranks' similarities never arrived)
         return l3d.computeAffinity()
     exchange_parts([part], rank, world_size, device, group, l3d)
     return l3d.affinityShardFinish()

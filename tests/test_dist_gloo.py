@@ -447,12 +447,18 @@ def _aff_methods():
         return True
 
     def whole(self):
+        assert "aff_begin" not in self.log or "aff_finish" in self.log or "aff_abort" in self.log, "computeAffinity inside an open shard"
         self.log.append("affinity")
         return True
-    return begin, finish, whole
+
+    def abort(self):
+        self.log.append("aff_abort")
+        return True
+    return begin, finish, whole, abort
 
 
-_HaloReplayContext.affinityShardBegin, _HaloReplayContext.affinityShardFinish, _HaloReplayContext.computeAffinity = _aff_methods()
+(_HaloReplayContext.affinityShardBegin, _HaloReplayContext.affinityShardFinish, _HaloReplayContext.computeAffinity,
+ _HaloReplayContext.affinityShardAbort) = _aff_methods()
 
 
 def _halo_worker(rank, world, port, q, shard_tail=True):

@@ -1006,6 +1006,12 @@ def test_sharded_tail_emulated_on_one_gpu_at_c2_slice_size(world):
     torch.cuda.synchronize()
     assert all(g.affinityShardFinish() for g in ctxs)
     assert ctxs[0].affinityShardBegin(0, world + 1) is None and ctxs[0].affinityShardFinish() is False   # wrong world; no open shard
+    # an open shard refuses a second begin and the unsharded fill (the views are translated: ADVICE round 5); abort closes it
+    # without the bookkeeping pass, after which the replicated fill gives the same A_
+    assert ctxs[0].affinityShardBegin(0, world) is not None
+    assert ctxs[0].affinityShardBegin(0, world) is None and ctxs[0].computeAffinity() is False
+    assert ctxs[0].affinityShardAbort() and ctxs[0].affinityShardAbort()
+    assert ctxs[0].computeAffinity()
     for g in ctxs:
         for v in sc.views:
             a, ao = g.matches(v.cam); b, bo = ref.matches(v.cam)
