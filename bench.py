@@ -676,6 +676,9 @@ def main():
                                       if world > 1 else "single GPU"},
             "phase_ms": {k: round(v / phase_steps, 4) for k, v in phase.items()},
             "cold_ms": cold["cold_ms"] if cold else None, "second_scene_ms": cold.get("second_scene_ms") if cold else None,
+            # the call a user of Line3D::matchImages makes ONCE per scene, in a warm process: the second headline (round 6)
+            "value_second_scene": round(pair_tests / (cold["second_scene_ms"] * 1e-3) / 1e6, 2) if cold and cold.get("second_scene_ms") else None,
+            "second_scene_over_steady": round(cold["second_scene_ms"] / ms_per_step, 3) if cold and cold.get("second_scene_ms") else None,
             "cold": cold,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }

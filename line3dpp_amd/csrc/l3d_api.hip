@@ -1,6 +1,8 @@
 // l3d_api.hip -- context layer of libl3dpp_hip.so (include/l3dpp_hip.h): the host-side driver that mirrors
 // Line3D::addImage / matchImages (line3D.cc:112-227, 375-497, 702-778).  No CPU fallback exists: every compute step
 // is a HIP kernel launch; without a usable device the calls fail with L3D_ERR_HIP.
+#include <thread>
+
 #include "l3d_ctx.h"
 
 namespace l3d {
@@ -572,17 +574,23 @@ static uint32_t match_items(const l3d_ctx* c, uint32_t Ms) {
 }
 
 static int match_begin_body(l3d_ctx* c) {
+    g_trace.mark("begin: enter (views translated)");
     if (c->ev_on(0)) L3D_HIP_CHECK(hipEventRecord(c->ev[0], c->stream));
     for (auto* v : c->order) {
         if (!c->fixed3Dregularizer) v->k = spatial_reg(*v, c->sigma_p);      // computeSpatialRegularizer
         else v->k = c->sigma_p / c->med_scene_depth;                          // update_k, view.h:124-127
         v->median_depth = 0.0f;
     }
+    g_trace.mark("begin: regularisers");
     // fixed neighbours, line3D.cc:467-479 (sets persist across calls like visual_neighbors_)
+    // (camIDs of the context, ascending: c->order is ordered by camID -- searched instead of the std::map of views)
+    std::vector<uint32_t> cams(c->order.size());
+    for (size_t i = 0; i < c->order.size(); ++i) cams[i] = c->order[i]->cam;
     for (auto* v : c->order)
         if (!v->by_worldpoints && v->visual_nbrs.empty())
             for (uint32_t n : v->fixed_nbrs)
-                if (c->views.count(n)) v->visual_nbrs.insert(n);
+                if (std::binary_search(cams.begin(), cams.end(), n)) v->visual_nbrs.insert(n);
+    g_trace.mark("begin: fixed neighbours");
     // neighbours from the worldpoint overlap, line3D.cc:480-484 (every call anew, on the translated views)
     {
         bool any = false;
@@ -613,28 +621,78 @@ static int match_begin_body(l3d_ctx* c) {
             for (uint32_t n : v->visual_nbrs) put(&n, 4);
         }
     }
+    g_trace.mark("begin: regularisers, neighbours, scene signature");
     const bool same_scene = c->begin_sig_valid && sig == c->begin_sig;
     uint64_t cs_off = c->cull_tot[0], ct_off = c->cull_tot[1], ck_off = c->cull_tot[2]; uint32_t cc_off = (uint32_t)c->cull_tot[3];
     if (!same_scene) {
     c->begin_sig_valid = false;
     for (auto* v : c->order) { v->out_pairs.clear(); v->in_pairs.clear(); }
     cs_off = ct_off = ck_off = 0; cc_off = 0;
-    // directed pair list, line3D.cc:704-741
+    // directed pair list, line3D.cc:704-741.  Round 6: in two steps -- the ENUMERATION (which pairs, in which order, where their
+    // slots / rows / culling pools start: sequential by definition, no arithmetic) and the per-pair ARITHMETIC (fundamental
+    // matrix, baseline, culling descriptor: independent per pair, spread over a few host threads from 1 024 pairs on).  The
+    // first matchImages of a scene of 1 024 views spent 2-5 ms here before its first kernel could be enqueued
+    // (profiles/r06_first_call.txt).
     c->pairs.clear(); c->pair_src_cam.clear(); c->pair_tgt_cam.clear(); c->cull.clear();
     uint32_t w_item = 0;
-    std::map<uint32_t, std::set<uint32_t>> matched;
     uint64_t slot_off = 0; uint32_t row_off = 0;
     c->pair_tests = 0;
+    {
+        size_t n_guess = 0;
+        for (auto* v : c->order) n_guess += v->visual_nbrs.size();
+        c->pairs.reserve(n_guess); c->cull.reserve(n_guess); c->pair_src_cam.reserve(n_guess); c->pair_tgt_cam.reserve(n_guess);
+    }
+    std::vector<std::pair<HostView*, HostView*>> ends;
+    // camID -> view: c->order is ascending in camID
+    auto view_of = [&](uint32_t cam) -> HostView* {
+        auto it = std::lower_bound(cams.begin(), cams.end(), cam);
+        return it != cams.end() && *it == cam ? c->order[(size_t)(it - cams.begin())] : nullptr;
+    };
     for (auto* v : c->order)
         for (uint32_t tcam : v->visual_nbrs) {
-            if (matched[v->cam].count(tcam)) continue;
-            HostView* t = c->views[tcam].get();
-            PairDesc pd;
-            fundamental(*v, *t, pd.F);
+            HostView* t = view_of(tcam);
+            if (!t) t = c->views[tcam].get();   // (never: a neighbour set only holds views of the context)
+            // `matched_[src]` of the reference holds tcam already iff the pair was created from the other side: tcam comes
+            // earlier in the order and lists this view among its neighbours (a set holds a neighbour once)
+            if (t->index < v->index && t->visual_nbrs.count(v->cam)) continue;
+            PairDesc pd{};
             pd.src = v->index; pd.tgt = t->index; pd.Ms = v->M; pd.Mt = t->M;
             pd.K = c->kNN > 0 ? (uint32_t)c->kNN : 0u;
             pd.row_off = row_off; pd.slot_off = slot_off;
-            {   // |C_src - C_tgt|, rounded up (k_lists.hip: window_sq)
+            slot_off += (uint64_t)pd.Ms * pd.K; row_off += pd.Ms;
+            const uint32_t pi = (uint32_t)c->pairs.size();
+            v->out_pairs.push_back(pi);
+            if (t->index > v->index) t->in_pairs.push_back(pi);   // inverse only if tgt not yet processed (:1680)
+            c->pairs.push_back(pd);
+            PairCull pc{};
+            // (the pools of a pair are reserved whether or not its geometry turns out to suit culling: the offsets must not
+            // depend on the arithmetic below)
+            const bool may_cull = c->use_cull && pd.Ms <= kCullMaxSegs && pd.Mt <= kCullMaxSegs && pd.Ms && pd.Mt;
+            pc.s_off = cs_off; pc.t_off = ct_off; pc.c_off = cc_off; pc.k_off = ~0ull;
+            pc.w_item0 = w_item; pc.sorted_copy = pd.Mt >= kSortedCopyMinSegs ? 1u : 0u; w_item += match_items(c, pd.Ms);
+            if (may_cull && std::max(pd.Ms, pd.Mt) > kCullLdsSegs) {   // sort keys of this pair in global scratch
+                uint32_t a = 64, b = 64;
+                while (a < pd.Ms) a <<= 1;
+                while (b < pd.Mt) b <<= 1;
+                pc.k_off = ck_off; ck_off += (uint64_t)a + b;
+            }
+            // (tile form: the rows of a pair take tile_src_cap positions -- every width class padded to a multiple of R)
+            if (may_cull) { cs_off += c->layout_rows ? tile_src_cap(pd.Ms, c->layout_rows) : pd.Ms; ct_off += pd.Mt; cc_off += (pd.Mt + 63) / 64; }
+            c->cull.push_back(pc);
+            ends.emplace_back(v, t);
+            c->pair_src_cam.push_back(v->cam); c->pair_tgt_cam.push_back(tcam);
+            c->pair_tests += (uint64_t)pd.Ms * pd.Mt;
+        }
+    g_trace.mark("begin: pair list enumerated");
+    {
+        static const bool no_fast = std::getenv("L3D_NO_FASTMATH") != nullptr;   // diagnostic switch: the compiler's own expansions
+        const bool use_cull = c->use_cull;
+        auto fill = [&](size_t p0, size_t p1) {
+            for (size_t p = p0; p < p1; ++p) {
+                const HostView* v = ends[p].first; const HostView* t = ends[p].second;
+                PairDesc& pd = c->pairs[p];
+                fundamental(*v, *t, pd.F);
+                // |C_src - C_tgt|, rounded up (k_lists.hip: window_sq)
                 const double d = norm(v->C - t->C);
                 pd.cc_dist = std::nextafterf((float)(d * (1.0 + 1e-6)), INFINITY);
                 // kPairFastMath (l3d_dev.h): everything that enters the pair's exact arithmetic is finite and far from the
@@ -642,33 +700,23 @@ static int match_begin_body(l3d_ctx* c) {
                 bool fm = v->coord_max <= 1e7 && t->coord_max <= 1e7;
                 for (int k = 0; k < 9 && fm; ++k) { const double a = std::fabs(pd.F[k]); fm = std::isfinite(a) && (a == 0.0 || (a >= 1e-30 && a <= 1e30)); }
                 for (double cval : {v->C.x, v->C.y, v->C.z, t->C.x, t->C.y, t->C.z}) fm = fm && std::isfinite(cval) && std::fabs(cval) <= 1e30;
-                static const bool no_fast = std::getenv("L3D_NO_FASTMATH") != nullptr;   // diagnostic switch: the compiler's own expansions
                 pd.flags = (fm && !no_fast) ? kPairFastMath : 0u;
                 pair_baseline(v->C, t->C, pd);
+                PairCull& pc = c->cull[p];
+                if (use_cull && pd.Ms <= kCullMaxSegs && pd.Mt <= kCullMaxSegs && pd.Ms && pd.Mt)
+                    make_cull(pd.F, v->width, v->height, t->width, t->height, pc);
             }
-            slot_off += (uint64_t)pd.Ms * pd.K; row_off += pd.Ms;
-            const uint32_t pi = (uint32_t)c->pairs.size();
-            v->out_pairs.push_back(pi);
-            if (t->index > v->index) t->in_pairs.push_back(pi);   // inverse only if tgt not yet processed (:1680)
-            c->pairs.push_back(pd);
-            PairCull pc{};
-            if (c->use_cull && pd.Ms <= kCullMaxSegs && pd.Mt <= kCullMaxSegs && pd.Ms && pd.Mt)
-                make_cull(pd.F, v->width, v->height, t->width, t->height, pc);
-            pc.s_off = cs_off; pc.t_off = ct_off; pc.c_off = cc_off; pc.k_off = ~0ull;
-            pc.w_item0 = w_item; pc.sorted_copy = pd.Mt >= kSortedCopyMinSegs ? 1u : 0u; w_item += match_items(c, pd.Ms);
-            if (pc.enabled && std::max(pd.Ms, pd.Mt) > kCullLdsSegs) {   // sort keys of this pair in global scratch
-                uint32_t a = 64, b = 64;
-                while (a < pd.Ms) a <<= 1;
-                while (b < pd.Mt) b <<= 1;
-                pc.k_off = ck_off; ck_off += (uint64_t)a + b;
-            }
-            // (tile form: the rows of a pair take tile_src_cap positions -- every width class padded to a multiple of R)
-            if (pc.enabled) { cs_off += c->layout_rows ? tile_src_cap(pd.Ms, c->layout_rows) : pd.Ms; ct_off += pd.Mt; cc_off += (pd.Mt + 63) / 64; }
-            c->cull.push_back(pc);
-            c->pair_src_cam.push_back(v->cam); c->pair_tgt_cam.push_back(tcam);
-            c->pair_tests += (uint64_t)pd.Ms * pd.Mt;
-            matched[v->cam].insert(tcam); matched[tcam].insert(v->cam);
-        }
+        };
+        const size_t P = c->pairs.size();
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t n_thr = P >= 1024 ? std::min<size_t>({8, hw / 2 ? hw / 2 : 1, P / 256}) : 1;
+        if (n_thr > 1) {
+            std::vector<std::thread> th;
+            for (size_t k = 1; k < n_thr; ++k) th.emplace_back(fill, P * k / n_thr, P * (k + 1) / n_thr);
+            fill(0, P / n_thr);
+            for (auto& x : th) x.join();
+        } else fill(0, P);
+    }
     c->n_slots = slot_off; c->n_rows_total = row_off;
     if (c->n_slots >= (1ull << 32) || c->pairs.size() >= (1u << 24))
         return fail(L3D_ERR_LIMIT, "slot buffer / pair list exceed the 32-bit slot and 24-bit pair indices of phase B");
@@ -686,11 +734,13 @@ static int match_begin_body(l3d_ctx* c) {
     c->cull_tot[0] = cs_off; c->cull_tot[1] = ct_off; c->cull_tot[2] = ck_off; c->cull_tot[3] = cc_off;
     c->begin_sig.swap(sig); c->begin_sig_valid = true;
     }
+    g_trace.mark(same_scene ? "begin: pair list kept" : "begin: pair list, fundamental matrices, cull descriptors built");
     c->pair_done.assign(c->pairs.size(), 0);
     c->pair_counted.assign(c->pairs.size(), 0);
     c->shard_world = 0; c->lists_ready = false; c->lists_prepared = false;
     int rc = upload_views(*c);
     if (rc) return rc;
+    g_trace.mark("begin: views uploaded / k_prep_views enqueued");
     // the inverse-target stream of phase B: written by the match epilogue (bounded kNN) or by k_orient_all; 16-bit entries
     // when every view has fewer than 65 535 segments (L3D_INV_TGT32=1: always 32-bit, A/B switch)
     {
@@ -727,6 +777,7 @@ static int match_begin_body(l3d_ctx* c) {
     L3D_HIP_CHECK(c->d_chunk_band.reserve(std::max<uint32_t>(cc_off, 1)));
     L3D_HIP_CHECK(c->d_cull_keys.reserve(std::max<uint64_t>(ck_off, 1)));
     if (c->ev_on(1)) L3D_HIP_CHECK(hipEventRecord(c->ev[1], c->stream));
+    g_trace.mark("begin: tables uploaded, pools reserved");
     c->tm = l3d_timings{};
     c->state = l3d_ctx::BEGUN;
     return L3D_OK;

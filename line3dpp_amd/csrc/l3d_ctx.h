@@ -236,6 +236,7 @@ struct l3d_ctx {
     struct PoolCaps { uint32_t e = 0, h = 0, s = 0, c = 0, huge = 0; bool huge_skip = false, list4_skip = false; } caps_saved[2];
     int caps_mode = 0;
     uint32_t chain_need = 8, chain_enqueued = 10;   // chain launches that changed something last time / enqueued this time
+    uint32_t chain_hist[4] = {6, 6, 6, 6}, chain_hist_at = 0;   // ... in the last four calls (a fresh context: 6 + 2 launches)
     // list pass sharded over ranks (l3d_lists_shard): world size of the running call, slabs received
     uint32_t shard_world = 0;
     // this rank's share of a sharded list pass (l3d_lists_shard*): views [shard_v0, shard_v1), pools [shard_pool0, + shard_ppr)

@@ -146,6 +146,25 @@ inline M3 m3_inv(const M3& A) {  // cofactor formula (Eigen compute_inverse_size
 }
 
 // L3DPP::View (view.h:49-223), hot-path members only
+// a set of camera ids as a sorted vector: the neighbour sets are walked and searched for every pair of the list, and a
+// std::set is one heap node per element (the first matchImages of a scene of 1 024 views spent 2 ms chasing them)
+struct FlatSet {
+    std::vector<uint32_t> v;
+    bool insert(uint32_t x) {
+        auto it = std::lower_bound(v.begin(), v.end(), x);
+        if (it != v.end() && *it == x) return false;
+        v.insert(it, x);
+        return true;
+    }
+    size_t count(uint32_t x) const { return std::binary_search(v.begin(), v.end(), x) ? 1 : 0; }
+    size_t size() const { return v.size(); }
+    bool empty() const { return v.empty(); }
+    void clear() { v.clear(); }
+    std::vector<uint32_t>::const_iterator begin() const { return v.begin(); }
+    std::vector<uint32_t>::const_iterator end() const { return v.end(); }
+    FlatSet& operator=(const std::set<uint32_t>& s) { v.assign(s.begin(), s.end()); return *this; }
+};
+
 struct HostView {
     uint32_t cam = 0, M = 0, index = 0;
     std::vector<float> segs;
@@ -157,7 +176,7 @@ struct HostView {
     std::vector<uint32_t> fixed_nbrs;   // fixed_visual_neighbors_[cam]
     bool by_worldpoints = false;        // added with a worldpoint list (neighbors_by_worldpoints_): neighbours are found
     std::vector<uint32_t> worldpoints;  // from the worldpoint overlap at every matchImages (views2worldpoints_[cam])
-    std::set<uint32_t> visual_nbrs;     // visual_neighbors_[cam]
+    FlatSet visual_nbrs;                // visual_neighbors_[cam]
     // device
     DevBuf<float4> d_seg4;
     DevBuf<SegF> d_segf;

@@ -395,9 +395,13 @@ static int tail_count_run(l3d_ctx* c, bool fresh, const TailShard& ts) {
     uint32_t* kept = c->d_lzero.p + z.kept;
     unsigned long long* best = (unsigned long long*)(c->d_lzero.p + z.best);
     if (!fresh) L3D_HIP_CHECK(hipMemsetAsync(changed, 0, (z.words - z.changed) * 4, st));
-    // as many launches as the last call needed + 1 (a launch is a no-op once nothing changes; the last one enqueued
-    // must report "no change", else the host keeps sweeping)
-    const uint32_t n_sweeps = std::min(kChainSweeps, std::max(2u, c->chain_need + 1));
+    // as many launches as the last calls needed + 3 (a launch is a no-op once nothing changes; the last one enqueued must
+    // report "no change", else the host keeps sweeping -- a second host round trip, 0.16 ms on C1).  How many sweeps a
+    // scene needs varies by one or two from call to call: whether a bit set in a launch is seen by a later thread of the
+    // SAME launch is a race the fixed point is indifferent to, its depth is not.  Round 5 enqueued the last call's count
+    // + 1 and the SECOND call of most scenes paid the extra round (profiles/r06_first_call.txt).
+    const uint32_t need = std::max(std::max(c->chain_hist[0], c->chain_hist[1]), std::max(c->chain_hist[2], c->chain_hist[3]));
+    const uint32_t n_sweeps = std::min(kChainSweeps, std::max(4u, need + 3));
     c->chain_enqueued = n_sweeps;
     for (uint32_t s2 = 0; s2 < n_sweeps; ++s2)
         L3D_HIP_CHECK(launch_chain_sweep(lp, positive_of(c), changed, s2, st));
@@ -519,6 +523,7 @@ static int finish_commit(l3d_ctx* c) {
     }
     for (uint32_t s2 = 0; s2 < c->chain_enqueued; ++s2) c->tm.chain_sweeps += changed[s2] ? 1u : 0u;   // of the last round
     c->chain_need = c->tm.chain_extra_rounds ? kChainSweeps : c->tm.chain_sweeps;
+    c->chain_hist[c->chain_hist_at++ & 3u] = c->chain_need;
     {
         uint64_t ne = 0;
         uint32_t me = 0, mh = 0, ms = 0, mc = 0;
