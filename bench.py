@@ -565,6 +565,9 @@ def main():
     def items_of(ms):
         return (ms + (2 if ms // 64 < 24 else 5) * 63 + 63) // 64
     wpg = 2 if sum(items_of(M[s]) for s, _ in my_pairs) <= 16384 else 1
+    # launches of up to 2 048 row-form items take the tile form (16 rows per item, one wave each; l3d_kernels.h: kMatchTileMaxItems)
+    tile_env = os.environ.get("L3D_MATCH_TILE")
+    tile = int(tile_env) if tile_env in ("0", "16") else (16 if sum((M[s] + 63) // 64 for s, _ in pairs) <= 2048 else 0)
     hbm_achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # What binds this kernel is VALU issue, not HBM (< 0.2 B per pair test): the primary roofline is the VALU one.
     # Its inputs are PMC counters, which cannot be read from inside this process: tools/pmc_bench.sh collects them
@@ -582,7 +585,7 @@ def main():
     hbm = {"achieved": round(hbm_achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(hbm_achieved / 8000.0, 6),
            "algorithmic_bytes": algo_bytes, "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
            "traffic_over_algorithmic": round(pmc["traffic_bytes_per_launch"] / algo_bytes, 2) if pmc else None}
-    common = {"kernel": f"k_match_pairs<0,false,true,{wpg},true,0>", "kernel_ms": round(avg_ms, 4),
+    common = {"kernel": f"k_match_pairs<0,false,true,{1 if tile else wpg},true,{tile}>", "kernel_ms": round(avg_ms, 4),
               "nominal_pair_tests_per_s": round(my_tests / (avg_ms * 1e-3), 1) if avg_ms > 0 else 0.0,
               "pmc_source": pmc_note, "build": build}
     if pmc:

@@ -16,10 +16,12 @@
 //                Round 5: the source rows are laid out by WIDTH CLASS of their bands, every class padded to a multiple
 //                of the item size, so that a work item's hull never straddles two classes (C4 -8.8 %, C2 -3.9 %, C1
 //                -2.6 %); with two waves per item the rows' own records are staged in LDS once per item (row cache).
-//                The TILE form (template parameter TILE = 16 | 32: R rows x 64/R targets per step, the records through
-//                an LDS FIFO instead of the scalar cache) is kept as a tested A/B variant: it halves the pre-filter's
-//                lane-tests and takes the scalar-cache misses from 27 % to 4 %, and is 20 % slower on C1 because every
-//                wave carries fixed work (profiles/r05_ab_match_forms.txt)
+//                The TILE form (template parameter TILE = 16: 16 rows x 4 targets per step, the records through an LDS
+//                FIFO instead of the scalar cache) halves the pre-filter's lane-tests and takes the scalar-cache misses
+//                from 27 % to 4 %; it is 20 % slower on C1 and C3 because every wave carries fixed work
+//                (profiles/r05_ab_match_forms.txt) and 7 % FASTER where the row form's launch leaves the machine
+//                half empty (C0, the reference's testdata: 1 430 items; profiles/r06_ab_small_views.txt): the form of
+//                launches of up to kMatchTileMaxItems row-form items (round 6).  R = 32 lost everywhere and is gone.
 //   k_order_items (launches with few items per wave slot) starts the longest work items first
 //   fp32 pre-filter (conservative) -> __ballot -> popcount-prefix compaction of
 //                the few survivors into a per-wave LDS ring
@@ -125,34 +127,16 @@ __device__ __forceinline__ Lds<IX16> carve(L3D_LDS char* base, uint32_t K, uint3
     return l;
 }
 
-// conservative fp32 test "could overlap(src, tgt) exceed thr?" (l3d_dev.h: prefilter_products, the form without
-// reciprocals).  -DL3D_PREFILTER_RCP restores the round-2 form (two v_rcp_f32, clamp output modifier) for A/B runs.
+// conservative fp32 test "could overlap(src, tgt) exceed thr?": l3d_dev.h prefilter_products, the form without reciprocals
+// (the round-2 form with two v_rcp_f32 and the batch levels / delivery variants of rounds 3-5 that lost their A/Bs are
+// documented in profiles/r03_v3_ab_prefilter.txt, r03_v2_ab_target_delivery.txt, r05_ab_match_forms.txt -- and no longer built)
 // scalar-unit bit operations the compiler does not select by itself (wave-uniform operands)
 __device__ __forceinline__ uint32_t s_ff1(uint64_t m) { uint32_t r; asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(m)); return r; }
 __device__ __forceinline__ uint64_t s_bitset0(uint64_t m, uint32_t bit) { asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit)); return m; }
 
 __device__ __forceinline__ bool prefilter(float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
                                           const v4f q, float thr) {
-#ifndef L3D_PREFILTER_RCP
     return prefilter_products(e1x, e1y, e1z, e2x, e2y, e2z, q.x, q.y, q.z, q.w, thr);
-#else
-    float a1 = __builtin_fmaf(e1x, q.x, __builtin_fmaf(e1y, q.y, e1z));
-    float a2 = __builtin_fmaf(e2x, q.x, __builtin_fmaf(e2y, q.y, e2z));
-    float d1 = __builtin_fmaf(e1x, q.z, e1y * q.w);
-    float d2 = __builtin_fmaf(e2x, q.z, e2y * q.w);
-    float r1 = __builtin_amdgcn_rcpf(d1);
-    float r2 = __builtin_amdgcn_rcpf(d2);
-    float s1 = a1 * r1, s2 = a2 * r2;
-    float c1, c2;
-    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(c1) : "v"(a1), "v"(r1));
-    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(c2) : "v"(a2), "v"(r2));
-    float inner = fabsf(c1 - c2);
-    float w = fabsf(s1 - s2) + 1.0f;                      // inner + outer
-    float rmax = fmaxf(fabsf(r1), fabsf(r2));
-    float t = __builtin_fmaf(-kKappa, rmax, thr - kKappa0);
-    float u = __builtin_fmaf(inner, 1.0f + t, -(t * w));  // inner - t * outer
-    return !(u <= 0.0f);
-#endif
 }
 
 // checkMatchOrientation (line3D.cc:811-858) of one freshly computed slot, in its source frame and -- for a pair that
@@ -196,7 +180,7 @@ __device__ __forceinline__ void store_inverse_target(const OrientFuse& of, uint6
 // 0.754 ms).  One wave per item (the large scenes) is limited to 6 per SIMD by its LDS (6.3 KiB per wave) whatever the
 // registers: there the 84-register budget without the spill is the faster one (C2 13.88 against 14.26 ms, C4 25.6
 // against 26.2; profiles/r03_v2_ab_target_delivery.txt, rows sl6 / sl7).
-// TILE (round 5; 0 = the row form above, 16 / 32 = rows per work item): the tile form of the bounded-kNN kernel.
+// TILE (round 5; 0 = the row form above, 16 = rows per work item): the tile form of the bounded-kNN kernel.
 //   * a work item is R = TILE source rows of ONE width class in band order (k_cull_prepare pads every class to a multiple
 //     of R), handled by one wave64; lane l = (row l % R, target slot l / R): a step of the walk tests 64 / R targets against
 //     R rows.  The wave visits the targets whose band meets the hull of ITS R rows -- a quarter (an eighth) of the rows of
@@ -212,12 +196,6 @@ __device__ __forceinline__ void store_inverse_target(const OrientFuse& of, uint6
 #ifndef L3D_MATCH_WAVES
 #define L3D_MATCH_WAVES (TILE ? L3D_TILE_WAVES : (WPG == 2 ? 7 : 6))
 #endif
-#ifndef L3D_INS_BATCH
-#define L3D_INS_BATCH 1   // 0: one LDS round trip per table entry (rounds 2-4); 1: the reads of the top-K insertion and of the
-                          // epilogue's rank requested four at a time (C1 -5.9 %, C2 -3.8 %, C4 -1.7 %); 2: eight at a time with clamped
-                          // indices, one write per table word, no source-row shuffle in a row-cached item (SLOWER: C1 0.62
-                          // against 0.55 ms); 3: as 2 with the four-wide scan
-#endif
 #ifndef L3D_ROW_CACHE
 #define L3D_ROW_CACHE 1   // 0: never stage the source rows' records in LDS (A/B)
 #endif
@@ -226,9 +204,6 @@ __device__ __forceinline__ void store_inverse_target(const OrientFuse& of, uint6
 #endif
 #ifndef L3D_ROW_CLASSES_DEFAULT
 #define L3D_ROW_CLASSES_DEFAULT 1   // row form: padded class layout (1) or the legacy layout (0)
-#endif
-#ifndef L3D_TILE_DEFAULT
-#define L3D_TILE_DEFAULT 0    // rows per work item of the tile form (0: the row form is the default)
 #endif
 template <int MODE, bool BRUTE, bool IX16, int WPG, bool STAGED, int TILE = 0>
 __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3D_MATCH_WAVES))) void k_match_pairs(const ViewDev* __restrict__ views,
@@ -262,7 +237,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     const bool fastm = (pd.flags & kPairFastMath) != 0;     // l3d_dev.h: IEEE division / sqrt without operand scaling
     typedef typename IdxT<IX16>::type idx_t;
     static_assert(!STAGED || (MODE == 0 && !BRUTE), "the two-stage candidate pipeline exists for the bounded-kNN variant");
-    static_assert(TILE == 0 || ((TILE == 16 || TILE == 32) && STAGED && WPG == 1), "the tile form: bounded kNN, staged, one wave per item");
+    static_assert(TILE == 0 || (TILE == 16 && STAGED && WPG == 1), "the tile form: bounded kNN, staged, one wave per item");
     constexpr uint32_t ROWS = TILE ? (uint32_t)TILE : (uint32_t)kBlock;   // rows of a work item
     constexpr uint32_t TPS = 64u / ROWS;                                  // targets per step of the tile form's walk
     // row cache (two waves per item only: with one wave per item its 3.3 KiB would cost a wave of occupancy): what the two
@@ -373,7 +348,6 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     auto rescan_worst = [&](uint32_t sl) {
         L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)sl * K;
         uint32_t wj = 0; float wo = ov[0];
-#if L3D_INS_BATCH
         // (K is a run-time value, so the loop is not unrolled and every entry was its own LDS round trip -- ten dependent
         // ~100-cycle waits per insertion into a full row; four reads are requested together, compared in the same order)
         const idx_t mp = L.minpos[sl];
@@ -391,48 +365,8 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         }
         L.minov[sl] = wo;
         L.minpos[sl] = (idx_t)(wj | (mp & kTie));
-#else
-        for (uint32_t j = 1; j < K; ++j) {
-            const float o = ov[j];
-            if (o < wo) { wo = o; wj = j; }
-        }
-        L.minov[sl] = wo;
-        L.minpos[sl] = (idx_t)(wj | (L.minpos[sl] & kTie));
-#endif
     };
     auto flag_tie = [&](uint32_t sl) { L.minpos[sl] = (idx_t)(L.minpos[sl] | kTie); };
-#if L3D_INS_BATCH >= 2
-    // smallest overlap of a full row's table and its slot, the first among equals (as rescan_worst): eight entries per LDS
-    // round trip, indices clamped to the last entry (a repeated entry never beats itself under the strict comparison)
-    auto scan_worst8 = [&](uint32_t sl, float& wo, uint32_t& wj) {
-        L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)sl * K;
-#if L3D_INS_BATCH == 2
-        const uint32_t last = K - 1;
-        wo = __builtin_inff(); wj = 0;
-        for (uint32_t j = 0; j < K; j += 8) {
-            float o[8];
-#pragma unroll
-            for (uint32_t i = 0; i < 8; ++i) o[i] = ov[min(j + i, last)];
-#pragma unroll
-            for (uint32_t i = 0; i < 8; ++i) if (o[i] < wo) { wo = o[i]; wj = min(j + i, last); }
-        }
-#else
-        wo = ov[0]; wj = 0;
-        uint32_t j = 1;
-        for (; j + 4 <= K; j += 4) {
-            const float o0 = ov[j], o1 = ov[j + 1], o2 = ov[j + 2], o3 = ov[j + 3];
-            if (o0 < wo) { wo = o0; wj = j; }
-            if (o1 < wo) { wo = o1; wj = j + 1; }
-            if (o2 < wo) { wo = o2; wj = j + 2; }
-            if (o3 < wo) { wo = o3; wj = j + 3; }
-        }
-        for (; j < K; ++j) {
-            const float o = ov[j];
-            if (o < wo) { wo = o; wj = j; }
-        }
-#endif
-    };
-#endif
 
     auto prefix = [&](uint64_t m) -> uint32_t {
         return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -465,14 +399,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t ent = ring[(head + lane) & (kRingN - 1)];
         head += n;
         const uint32_t sl = ent >> 23, tp = ent & 0x7FFFFFu;
-#if L3D_INS_BATCH >= 2
-        // (the source row of an entry comes from its lane by a shuffle -- an LDS round trip at the head of every drain; a
-        // row-cached item only needs it in the double-precision fallback, a few candidates in a million: fetched there)
-        uint32_t sg = 0;
-        if (!ROWCACHE) sg = __shfl(src, sl);
-#else
         const uint32_t sg = __shfl(src, sl);   // the ring of a wave only holds rows of that wave
-#endif
         bool pass = false, fallback = false;
         if (has) {
             SegD32 sd;
@@ -488,9 +415,6 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             fallback = !certain;
         }
         if (L3D_BALLOT(fallback)) {   // the sliver (wave-uniform test): the double-precision decision on the full records
-#if L3D_INS_BATCH >= 2
-            if (ROWCACHE) sg = __shfl(src, sl);
-#endif
             if (fallback) {
                 const uint32_t to = cull ? tperm[tp] : tp;    // (by original target index)
                 // (the camera centres are fetched HERE, through laundered pointers: hoisted out of the walk they occupied
@@ -513,12 +437,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t ent = ring2[(head2 + lane) & (kRing2 - 1)];
         head2 += n;
         const uint32_t sl = ent >> 23, tg = ent & 0x7FFFFFu;
-#if L3D_INS_BATCH >= 2
-        uint32_t sg = 0;
-        if (!ROWCACHE) sg = __shfl(src, sl);     // (wave-uniform branch; a row-cached item reads the row's record from LDS)
-#else
         const uint32_t sg = __shfl(src, sl);
-#endif
         bool pending = false;
         float ovv = 0.0f;
         // F is fetched per drain through a laundered pointer (wave-uniform control flow: scalar loads): hoisted out of the
@@ -526,12 +445,8 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         // scalars from vector lanes at every step (four v_readlane per two targets: the record base pointer and the lane
         // mask).  Round 3 measured this switch as neutral; since the depth decision of stage 1 runs on floats (no camera
         // centres in scalar registers either) it removes the reloads: C4 -8.7 %, C2 -3.5 %, C1 -1 % (profiles/r04_ab_match.txt).
-#ifndef L3D_NO_LAUNDER_F
         const double* Fp = pd.F;
         asm volatile("" : "+s"(Fp));
-#else
-        const double* Fp = F;
-#endif
         if (has) {
             float4 s4;
             if (ROWCACHE) { const v4f c = L.row_sd[3 * sl + 2]; s4 = make_float4(c.y, c.z, c.w, L.row_w[sl]); }
@@ -567,50 +482,17 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                 if (WPG == 1) L.claim[sl] = kEmpty;
                 pending = false;
                 const uint32_t c = L.cnt[sl];
-#if L3D_INS_BATCH
                 const idx_t mp_now = L.minpos[sl];      // (requested with the count: one wait instead of three)
                 const float mo_now = L.minov[sl];
-#endif
                 L3D_LDS volatile float* ov = L.top_ov + (size_t)sl * K;
                 L3D_LDS volatile idx_t* ix = L.top_ix + (size_t)sl * K;
-#if L3D_INS_BATCH >= 2
-                // (every table word is written once, from values this lane holds: no read-back of what it has just written)
-                if (c < K) {
-                    ov[c] = ovv; ix[c] = tg;
-                    L.cnt[sl] = c + 1;
-                    if (c + 1 == K) {
-                        float wo; uint32_t wj2;
-                        scan_worst8(sl, wo, wj2);
-                        L.minov[sl] = wo;
-                        L.minpos[sl] = (idx_t)(wj2 | (mp_now & kTie));
-                    }
-                } else {
-                    const uint32_t wj = mp_now & (idx_t)~kTie;
-                    const float mo = mo_now;
-                    if (ovv > mo) {
-                        ov[wj] = ovv; ix[wj] = tg;
-                        float wo; uint32_t wj2;
-                        scan_worst8(sl, wo, wj2);
-                        L.minov[sl] = wo;
-                        // (wo == mo: the evicted entry ties with the new K-th best)
-                        L.minpos[sl] = (idx_t)(wj2 | (mp_now & kTie) | (wo == mo ? kTie : (idx_t)0));
-                    } else if (ovv == mo) {
-                        L.minpos[sl] = (idx_t)(mp_now | kTie);     // a tie at the K-th place (whichever index would win)
-                    }
-                }
-#else
                 if (c < K) {
                     ov[c] = ovv; ix[c] = tg;
                     L.cnt[sl] = c + 1;
                     if (c + 1 == K) rescan_worst(sl);
                 } else {
-#if L3D_INS_BATCH
                     const uint32_t wj = mp_now & (idx_t)~kTie;
                     const float mo = mo_now;
-#else
-                    const uint32_t wj = L.minpos[sl] & (idx_t)~kTie;
-                    const float mo = L.minov[sl];
-#endif
                     if (ovv > mo) {
                         ov[wj] = ovv; ix[wj] = tg;
                         rescan_worst(sl);
@@ -619,7 +501,6 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                         flag_tie(sl);                           // a tie at the K-th place (whichever index would win)
                     }
                 }
-#endif
                 if (WPG > 1)
                     __hip_atomic_store((L3D_LDS uint32_t*)&L.claim[sl], kEmpty, __ATOMIC_RELEASE,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -889,15 +770,6 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             wm &= ~(1u << bit);
             const uint32_t ti = tb + lane;
             bool in = ti < Mt;
-#ifdef L3D_TARGETS_BY_READLANE
-            // Lane l fetches record l of the chunk (one coalesced 1 KiB load per chunk, requested together with the band);
-            // the record of the target being tested then reaches all lanes as scalar operands through v_readlane.  The
-            // round-2 form fetched every record with its own s_load_dwordx4: a stream of 16-byte records misses the scalar
-            // cache on every fourth load (25 % measured) and the wave sat on s_waitcnt at every step -- half of a wave's
-            // life was spent waiting.  Four v_readlane per target cost 17 issue cycles on a VALU that was ~60 % busy.
-            v4f rec = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (in) rec = tf[ti];
-#endif
             if (cull && in) {
                 const float2 b = tband[ti];
                 in = !(b.y < wlo || b.x > whi);
@@ -910,35 +782,12 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                 // (scalar-unit economy: the walk costs ~30 scalar instructions per step at 4.3 issue cycles each, more than
                 // its vector instructions -- s_bitset0 instead of the three-instruction m &= m - 1; an empty m gives bit
                 // index -1, which clears bit 63 of zero)
-#ifndef L3D_NO_BITSET
                 const uint32_t j0 = s_ff1(m); m = s_bitset0(m, j0);
                 const bool v1 = m != 0; const uint32_t j1r = s_ff1(m); m = s_bitset0(m, j1r);
                 const uint32_t j1 = v1 ? j1r : j0;
-#else
-                const uint32_t j0 = __builtin_ctzll(m); m &= m - 1;
-                const bool v1 = m != 0; const uint32_t j1 = v1 ? __builtin_ctzll(m) : j0; m &= m - 1;
-#endif
-#ifdef L3D_TARGETS_BY_READLANE
-                auto bcast = [&](uint32_t j) -> v4f {
-                    v4f q;
-                    q.x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rec.x), j));
-                    q.y = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rec.y), j));
-                    q.z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rec.z), j));
-                    q.w = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rec.w), j));
-                    return q;
-                };
-                const v4f q0 = bcast(j0), q1 = bcast(j1);
-#else
                 // (32-bit byte offsets: s_load_dwordx4 base, offset -- no 64-bit address arithmetic on the scalar unit)
-#ifndef L3D_NO_OFF32
                 v4f q0 = *(RecPtr)(tfb + ((tb + j0) << 4)), q1 = *(RecPtr)(tfb + ((tb + j1) << 4));
-#else
-                v4f q0 = ((RecPtr)tfb)[tb + j0], q1 = ((RecPtr)tfb)[tb + j1];
-#endif
-#ifndef L3D_NO_LOADS_FIRST
                 asm volatile("" : "+s"(q0), "+s"(q1));   // both records requested before the first is used (C2 / C4 -1 %)
-#endif
-#endif
                 // (the lane masks are built from the comparison itself and the uniform masks by scalar ANDs: a ballot of
                 // `live & test` would first turn the flag into 0/1 in a VGPR)
                 const bool c0b = BRUTE || prefilter(e1x, e1y, e1z, e2x, e2y, e2z, q0, thrL);
@@ -1015,7 +864,6 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         const uint32_t c = min((uint32_t)L.cnt[rs], K);
         L3D_LDS const float* ov = (L3D_LDS const float*)L.top_ov + (size_t)rs * K;
         bool t = false;
-#if L3D_INS_BATCH
         if (K <= 16) {
             // (the usual kNN: the row's entries are fetched four per LDS round trip and compared in registers; entries beyond
             // the row's count read as distinct NaN-free sentinels that equal nothing)
@@ -1035,7 +883,6 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
 #pragma unroll
                 for (uint32_t j = 0; j < i; ++j) t |= o[j] == o[i];
         } else
-#endif
         for (uint32_t i = 1; i < c; ++i) {
             const float oi = ov[i];
             for (uint32_t j = 0; j < i; ++j) t |= ov[j] == oi;
@@ -1049,15 +896,11 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
     const uint32_t n_rows = pad ? ROWS : min((uint32_t)kBlock, Ms - wi.src0);
     const bool hands_inverse = pd.tgt > pd.src;   // inverse copy only towards a view processed later (:1680)
     const uint32_t n_items = n_rows * K;
-#ifndef L3D_NO_LAUNDER_EPILOGUE
     // (the camera centres and the orientation thresholds are needed from here on only -- since round 4 the depth decision
     // of stage 1 runs on floats and the baseline --: fetched through laundered pointers, so that they do not occupy 16
     // scalar registers of the walk, whose loop spills scalars into vector lanes and reloads them every step)
     const ViewDev* evs = &vs; const ViewDev* evt = &vt;
     asm volatile("" : "+s"(evs), "+s"(evt));
-#else
-    const ViewDev* evs = &vs; const ViewDev* evt = &vt;
-#endif
     for (uint32_t base0 = 0; base0 < n_items; base0 += 64 * WPG) {
         const uint32_t base = base0 + q * 64;           // first item of this wave in this pass
         const uint32_t it = base + lane;
@@ -1083,7 +926,6 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             // (a row that gets here has no two equal overlaps -- the pass above flagged those --, so the order
             // (overlap desc, target asc) is the order by overlap)
             uint32_t rank = 0;
-#if L3D_INS_BATCH
             {
                 uint32_t i = 0;
                 for (; i + 4 <= c; i += 4) {
@@ -1092,9 +934,6 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                 }
                 for (; i < c; ++i) rank += ov[i] > oj ? 1u : 0u;
             }
-#else
-            for (uint32_t i = 0; i < c; ++i) rank += ov[i] > oj ? 1u : 0u;
-#endif
             dst = rank;
             // Three short stages that each fetch only the invariants they use (depths: rays + plane; orientation:
             // rays + mid ray).  The pointers are laundered between the stages so that the compiler does not keep both
@@ -1159,18 +998,20 @@ size_t match_lds_bytes(int mode, uint32_t K, bool ix16, uint32_t waves, bool bru
 }
 
 // The tile form serves the bounded-kNN launches of the two-stage pipeline (everything else -- keep-all passes, the
-// brute-force hook, the single-stage A/B switch -- keeps the row form).  L3D_MATCH_TILE = 0 | 16 | 32 overrides.
-uint32_t match_tile_rows(int mode, bool brute) {
+// brute-force hook, the single-stage A/B switch -- keeps the row form) whose row form would leave the machine half empty:
+// up to kMatchTileMaxItems items of 64 rows (est_row_items: what the caller expects the launch to hold).  L3D_MATCH_TILE = 0 | 16
+// overrides.
+uint32_t match_tile_rows(int mode, bool brute, uint64_t est_row_items) {
     if (!match_staged(mode, brute)) return 0;
     // (read per call -- once per l3d_match_begin --, not latched: a test switches forms inside one process)
     const char* e = std::getenv("L3D_MATCH_TILE");
     const int forced = e ? std::atoi(e) : -1;
-    if (forced == 0 || forced == 16 || forced == 32) return (uint32_t)forced;
-    return L3D_TILE_DEFAULT;
+    if (forced == 0 || forced == 16) return (uint32_t)forced;
+    return est_row_items && est_row_items <= kMatchTileMaxItems ? 16u : 0u;
 }
-uint32_t match_layout_rows(int mode, bool brute) {
+uint32_t match_layout_rows(int mode, bool brute, uint32_t tile_rows) {
     if (mode != 0 || brute) return 0;
-    const uint32_t t = match_tile_rows(mode, brute);
+    const uint32_t t = tile_rows;
     if (t) return t;
     const char* e = std::getenv("L3D_MATCH_CLASSES");
     const int classes = e ? std::atoi(e) : L3D_ROW_CLASSES_DEFAULT;
@@ -1196,7 +1037,7 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
     if (mode == 0 && (!of.inv_tgt || !of.tie_count || !of.tie_list)) return hipErrorInvalidValue;   // MODE 0 always fuses
     const uint32_t grid = ((nwork + 7) / 8) * 8;
     if (!(mode == 0 && !brute)) ix16 = false;       // the compact layout is only instantiated for the hot variant
-    if (tile_rows && (tile_rows != 16u && tile_rows != 32u)) return hipErrorInvalidValue;
+    if (tile_rows && tile_rows != 16u) return hipErrorInvalidValue;
     if (tile_rows && !match_staged(mode, brute)) return hipErrorInvalidValue;   // (the tile form exists for the staged bounded-kNN kernel)
     const uint32_t wpg = tile_rows ? 1u : match_waves_per_group(mode, brute, nwork);
     pools.row_cache = match_row_cache(mode, brute, nwork, tile_rows) ? 1u : 0u;
@@ -1211,8 +1052,7 @@ hipError_t launch_match_pairs(int mode, bool brute, const ViewDev* views, const 
     } while (0)
 #define L3D_LAUNCH_HOT(X, W) do { if (match_staged(mode, brute)) L3D_LAUNCH(0, false, X, W, true, 0); else L3D_LAUNCH(0, false, X, W, false, 0); } while (0)
     if (mode == 0 && tile_rows) {
-        if (tile_rows == 16) { if (ix16) L3D_LAUNCH(0, false, true, 1, true, 16); else L3D_LAUNCH(0, false, false, 1, true, 16); }
-        else { if (ix16) L3D_LAUNCH(0, false, true, 1, true, 32); else L3D_LAUNCH(0, false, false, 1, true, 32); }
+        if (ix16) L3D_LAUNCH(0, false, true, 1, true, 16); else L3D_LAUNCH(0, false, false, 1, true, 16);
     } else if (mode == 0) {
         if (brute) L3D_LAUNCH(0, true, false, 1, false, 0);
         else if (ix16) { if (wpg == 2) L3D_LAUNCH_HOT(true, 2); else L3D_LAUNCH_HOT(true, 1); }

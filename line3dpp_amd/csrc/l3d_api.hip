@@ -396,7 +396,6 @@ void l3d_destroy(l3d_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (auto& s2 : c->aux) if (s2) (void)hipStreamSynchronize(s2);
     const ReleaseSynced drained;   // everything this context enqueued has been waited for: its blocks may change hands
     for (auto& kv : c->views) {
         HostView& v = *kv.second;
@@ -426,9 +425,6 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_flag.release(); c->d_epos.release(); c->d_first_touch.release(); c->d_touch_flag.release();
     c->d_touch_rank.release(); c->d_edges.release(); c->d_l2g.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
-    for (auto& e : c->pipe_ev) (void)hipEventDestroy(e);
-    for (auto& e : c->sev) if (e) (void)hipEventDestroy(e);
-    for (auto& s2 : c->aux) if (s2) (void)hipStreamDestroy(s2);
     delete c;
 }
 
@@ -507,7 +503,6 @@ static int add_view(l3d_ctx* c, uint32_t camID, const float* segs4, uint32_t M, 
 // (matchImages translates them, line3D.cc:436/493) and a new l3d_match_begin is required
 void abort_match(l3d_ctx* c) {   // (declared in l3d_ctx.h: l3d_phase_b.hip closes failed calls with it)
     (void)hipStreamSynchronize(c->stream);
-    for (auto& s2 : c->aux) if (s2) (void)hipStreamSynchronize(s2);
     untranslate(*c);
     c->timing_pending = false; c->pending_launches = 0;
     c->state = l3d_ctx::IDLE;
@@ -608,8 +603,12 @@ static int match_begin_body(l3d_ctx* c) {
     {
         auto put = [&](const void* q, size_t n) { const unsigned char* b = (const unsigned char*)q; sig.insert(sig.end(), b, b + n); };
         // tile form of the bounded-kNN kernel (k_match.hip): R rows per work item, the source pools laid out for it
-        c->tile_rows = c->kNN > 0 ? match_tile_rows(0, c->brute) : 0u;
-        c->layout_rows = c->kNN > 0 ? match_layout_rows(0, c->brute) : 0u;   // padded class layout of the source rows (k_cull_prepare)
+        // (the launch the row form would make: every unordered neighbour pair is matched once, ceil(M / 64) items per pair)
+        uint64_t est_items = 0;
+        for (auto* v : c->order) est_items += (uint64_t)v->visual_nbrs.size() * ((v->M + kMatchRows - 1) / kMatchRows);
+        est_items = (est_items + 1) / 2;
+        c->tile_rows = c->kNN > 0 ? match_tile_rows(0, c->brute, est_items) : 0u;
+        c->layout_rows = c->kNN > 0 ? match_layout_rows(0, c->brute, c->tile_rows) : 0u;   // padded class layout of the source rows (k_cull_prepare)
         const int32_t head[5] = {c->kNN, c->use_cull ? 1 : 0, c->brute ? 1 : 0, (int32_t)c->tile_rows, (int32_t)c->layout_rows};
         put(head, sizeof(head));
         for (auto* v : c->order) {
@@ -796,17 +795,6 @@ int l3d_get_pairs(l3d_ctx* c, uint32_t* s, uint32_t* t, uint64_t* off) {
         if (t) t[i] = c->pair_tgt_cam[i];
         if (off) off[i] = c->pairs[i].slot_off;
     }
-    return L3D_OK;
-}
-
-static int ensure_aux(l3d_ctx* c) {
-    if (!c->aux[0]) {   // highest priority: its kernels must not queue behind thousands of other workgroups
-        int lo_p = 0, hi_p = 0;
-        L3D_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-        L3D_HIP_CHECK(hipStreamCreateWithPriority(&c->aux[0], hipStreamNonBlocking, hi_p));
-    }
-    if (!c->aux[1]) L3D_HIP_CHECK(hipStreamCreateWithFlags(&c->aux[1], hipStreamNonBlocking));
-    for (auto& e : c->sev) if (!e) L3D_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return L3D_OK;
 }
 

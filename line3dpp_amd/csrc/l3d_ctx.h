@@ -166,10 +166,7 @@ struct l3d_ctx {
     uint32_t aff_n_edges = 0, aff_n_rows = 0;
     bool aff_host_valid = true;
     PinnedBuf<uint32_t> h_cnt;
-    hipStream_t aux[2] = {nullptr, nullptr};        // aux[0] high priority (phase-A first half, the chain), aux[1]
-    std::vector<hipEvent_t> pipe_ev;
     std::vector<uint8_t> pair_counted;   // the pair's slots carry orientation flags and are in the phase-B counters
-    hipEvent_t sev[5] = {};                         // prepared, half A done, half B done, memsets done, orient A done
     DevBuf<SegX> d_gsegx;                           // SegX of every segment, global segment order
     DevBuf<SegD32> d_gsegd32;                       // float copy of rays + plane normal (stage 1 of the match kernel's pipeline)
     float collinearity_t = -1.0f;                   // collinearity_t_ (reconstruct3Dlines); > 0: collinear links

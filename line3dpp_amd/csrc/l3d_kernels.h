@@ -27,8 +27,10 @@ __host__ __device__ constexpr uint32_t tile_classes(uint32_t Ms, uint32_t R) { r
 __host__ __device__ constexpr uint32_t tile_src_cap(uint32_t Ms, uint32_t R) {
     return ((Ms + tile_classes(Ms, R) * (R - 1) + R - 1) / R) * R;
 }
-uint32_t match_tile_rows(int mode, bool brute);   // 0: row form; 16 / 32: tile form (L3D_MATCH_TILE overrides)
-uint32_t match_layout_rows(int mode, bool brute); // rows per work item of the padded class layout: the tile form's R, 64 for the
+constexpr uint64_t kMatchTileMaxItems = 2048;     // launches of up to this many 64-row items take the tile form (C0: 1 430 items,
+                                                  // kernel -7 %; C1's 10 560 and C3's 81 920 lose 20 % in it)
+uint32_t match_tile_rows(int mode, bool brute, uint64_t est_row_items);   // 0: row form; 16: tile form (L3D_MATCH_TILE overrides)
+uint32_t match_layout_rows(int mode, bool brute, uint32_t tile_rows); // rows per work item of the padded class layout: the tile form's R, 64 for the
                                                   // row form (L3D_MATCH_CLASSES=0: 0 = its legacy layout without padding)
 struct WorkItem {
     uint32_t pair;  // index into the pair array

@@ -308,7 +308,8 @@ def test_timing_levels_change_what_is_timed_and_nothing_else():
 def test_forms_of_the_match_kernel_give_the_same_bytes(monkeypatch):
     """k_match_pairs has three forms for the bounded-kNN launch (k_match.hip): the row form on the padded width-class
     layout of the source rows (the default of round 5), the row form on the legacy layout (L3D_MATCH_CLASSES=0), and the
-    tile form with 16 / 32 rows per work item and the LDS FIFO of target records (L3D_MATCH_TILE=16|32).  The switches are
+    tile form with 16 rows per work item and the LDS FIFO of target records (L3D_MATCH_TILE=16; since round 6 what launches
+    of up to 2 048 row-form items take by themselves: the last pass below lets the library choose).  The switches are
     read at every l3d_match_begin, so ONE context runs all of them in turn: every slot of phase A, every surviving list,
     best hypothesis and affinity entry must be the same bytes, and equal the reference's own code.  The scene has ragged
     views (classes of very different sizes, views smaller than one work item) and a kNN that leaves rows unfilled."""
@@ -319,8 +320,12 @@ def test_forms_of_the_match_kernel_give_the_same_bytes(monkeypatch):
     g = _gpu(sc)
     o = _ref(sc, [dict(kNN=7)])
     first = None
-    for tile, classes in (("0", "1"), ("0", "0"), ("16", "1"), ("32", "1"), ("0", "1")):
-        monkeypatch.setenv("L3D_MATCH_TILE", tile); monkeypatch.setenv("L3D_MATCH_CLASSES", classes)
+    for tile, classes in (("0", "1"), ("0", "0"), ("16", "1"), ("0", "1"), (None, "1")):
+        if tile is None:
+            monkeypatch.delenv("L3D_MATCH_TILE")
+        else:
+            monkeypatch.setenv("L3D_MATCH_TILE", tile)
+        monkeypatch.setenv("L3D_MATCH_CLASSES", classes)
         assert g.matchImages(kNN=7) and g.computeAffinity()
         assert g.timings()["culled_pairs"] > 0
         _assert_same(g, o, sc)
