@@ -223,12 +223,17 @@ def multi_gpu_model(pairs, M, kNN, phase, lists_ms, record_bytes, tail_bytes=0.0
     out = {"MODELLED_NOT_MEASURED": "no multi-GPU node has been available: every figure below is arithmetic on this run's single-GPU phase times",
            "assumptions": {"link_GB_per_s": 153.0, "exchanges": "direct: one part per link, all peers at once (full xGMI mesh); a ring would take (N-1) part times",
                             "expand_us_per_slot": 2.8e-5, "host_sync_ms": 0.03, "status_or_count_exchange_ms": 0.02,
-                            "host_sync_points": "4 (pack, list pass, tail count, commit) + 4 status / count exchanges + 1 for the sharded affinity fill",
+                            "host_sync_points": "round 6: 4 (list pass + the one status exchange in front of the record gather, tail count, "
+                                                "commit, affinity finish) + 1 exchange that carries the tail's counts AND status (round 5: 4 + 4 + 1); "
+                                                "the sharded entries do not wait for the device when RCCL orders itself behind the stream (l3d_shard_options)",
+                            "records": "a rank receives the record slabs of the ranks its views depend on (dist.shard_needs): all lower ranks for a "
+                                       "ring cut into view ranges (strong), NONE for N rings without pairs between them (weak) -- and its chain "
+                                       "covers those records only",
                             "tail_per_view_fraction": per_view, "record_bytes": int(record_bytes), "tail_output_bytes": int(tail_bytes),
                             "similarity_bytes": int(sim_bytes)}}
     tail_ms = max(phase["finish"] - lists_ms, 0.0)
     t1 = phase["begin"] + phase["match"] + phase["finish"] + phase["affinity"]
-    syncs = 4 * 0.03 + 5 * 0.02
+    syncs = 4 * 0.03 + 2 * 0.02
     for n in (2, 4, 8):
         plan = l3d_dist.plan_halo(pairs, M, n)
         pb = plan["pair_bounds"].astype(np.int64)
@@ -249,9 +254,9 @@ def multi_gpu_model(pairs, M, kNN, phase, lists_ms, record_bytes, tail_bytes=0.0
                  "exchange_similarities": 1e3 * sim_bytes / n / link, "host_syncs": syncs}
         total = sum(v for k, v in terms.items() if not k.endswith("_MB") and not k.endswith("_if_ring"))
         # weak: every rank does one GPU's work; what arrives from N - 1 peers and what is replicated grows with N
-        weak = {"own_work_as_on_one_gpu": t1, "gather_records_direct": 1e3 * record_bytes / link,
+        weak = {"own_work_as_on_one_gpu": t1, "gather_records_direct": 0.0,          # (independent rings: no rank depends on another's records)
                 "exchange_tail_outputs": 1e3 * tail_bytes / link, "exchange_similarities": 1e3 * sim_bytes / link,
-                "tail_chain_over_all_ranks_records": (n - 1) * tail_ms * (1 - per_view),
+                "tail_chain_over_all_ranks_records": 0.0,                             # (the chain covers the rank's own records only)
                 "affinity_bookkeeping_over_all_ranks": (n - 1) * 0.4 * phase["affinity"], "host_syncs": syncs}
         wtotal = sum(weak.values())
         out[str(n)] = {"strong": {"terms_ms": {k: round(v, 4) for k, v in terms.items()}, "total_ms": round(total, 4),
@@ -420,6 +425,9 @@ def main():
     ap.add_argument("--parity-digest", action="store_true",
                     help="parity of the full scene against the stored reference record (tests/golden/full) instead of a live run")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-call / second-scene measurement")
+    ap.add_argument("--no-extra-lines", action="store_true",
+                    help="N = 1: skip the short C2 run that feeds the model of BASELINE's 8-GPU configuration; N > 1: skip the "
+                         "C2 strong-scaling line printed beside the default weak-scaling C1 line")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N > 1: weak = N rings of the configuration's size in one scene (per-GPU work fixed, default); "
                          "strong = the same scene at every N")
@@ -485,6 +493,48 @@ def main():
             assert ok, "matchImages failed"
             assert l3d_dist.compute_affinity_sharded(ctx, rank, world, device=device), "affinity failed"
         return step
+
+    def quick_line(config, scaling, steps, warmup):
+        """a plain timed line of another configuration in this process group (no roofline / CPU / cold legs): the metric, the
+        phase times of a few untimed steps at timing level 2 and what multi_gpu_model needs"""
+        wk = world > 1 and scaling == "weak"
+        sc = weak_scene(config, world) if wk else make_config(config)
+        tests, prs = sc.pair_tests()
+        g = Line3D(device=local_rank); g.add_scene(sc)
+        st = stepper(g)
+        for _ in range(warmup):
+            st()
+        barrier()
+        t0_ = time.perf_counter()
+        for _ in range(steps):
+            st()
+        barrier()
+        dt_ = time.perf_counter() - t0_
+        if world > 1:
+            t_ = torch.tensor([dt_], dtype=torch.float64, device=device)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            dt_ = float(t_.item())
+        ph = dict(begin=0.0, match=0.0, finish=0.0, affinity=0.0, lists=0.0)
+        g.setTimingLevel(2)
+        n_ph = max(1, min(steps, 3))
+        for _ in range(n_ph):
+            st()
+            tmq = g.timings()
+            ph["begin"] += tmq["begin_ms"] / n_ph; ph["match"] += tmq["match_pairs_ms"] / n_ph
+            ph["finish"] += tmq["finish_ms"] / n_ph; ph["affinity"] += tmq["affinity_ms"] / n_ph; ph["lists"] += tmq.get("lists_ms", 0.0) / n_ph
+        g.setTimingLevel(1)
+        Mq = {v.cam: len(v.segs) for v in sc.views}
+        extra = {}
+        if world == 1:
+            extra = dict(n_surv=sum(int(g.matches(v.cam)[1][-1]) for v in sc.views), n_best=len(g.best()[0]), record_kbytes=tmq.get("record_kbytes", 0))
+        g.close()
+        c_ = CONFIGS[config]
+        return {"config": {"workload": ((f"{world} rings of " if wk else "") + f"{config}: synthetic {c_['n_views']} views x {c_['n_segs']} segments/view, "
+                                        f"{c_['n_neighbors']} visual neighbours, kNN=10; matchImages + affinity fill"),
+                           "pair_tests_per_step": tests, "directed_pairs": len(prs)},
+                "scaling": scaling if world > 1 else "weak", "n_gpus": world, "steps": steps, "warmup": warmup,
+                "value": round(tests / (dt_ / steps) / 1e6, 2), "unit": "M segment-pair scores/s", "ms_per_step": round(1e3 * dt_ / steps, 4),
+                "phase_ms": {k: round(v, 4) for k, v in ph.items()}}, (prs, Mq, ph, extra)
 
     # ---- cold call: the FIRST matchImages + affinity of a fresh context (a user of Line3D::matchImages pays this once per
     # scene).  Only the code objects are warm: a tiny scene on a throw-away context loads the kernels first.
@@ -657,6 +707,12 @@ def main():
         cold.update(second_scene_ms=round(ms2, 3), second_scene_call=tm2)
         g2.close()
 
+    # N > 1: BASELINE's 8-GPU configurations are C2 / C3 / C4 at fixed size -- the default line above is N rings of C1 (weak);
+    # the C2 strong-scaling line is measured in the same process group and printed inside the one JSON line, so that the
+    # first real multi-GPU run yields both (VERDICT r5 #6c).  Every rank takes part.
+    extra_line = None
+    if world > 1 and not args.no_extra_lines and args.config == "C1" and args.scaling == "weak":
+        extra_line, _ = quick_line("C2", "strong", max(3, args.steps // 4), 1)
     if rank == 0:
         out = {
             "metric": "M segment-pair scores/sec", "value": round(value, 2), "unit": "M segment-pair scores/s",
@@ -685,6 +741,15 @@ def main():
             "cold": cold,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }
+        if extra_line is not None:
+            out["baseline_8gpu_config_line"] = extra_line
+        if world == 1 and args.config == "C1" and not args.no_extra_lines:
+            # BASELINE's 8-GPU configuration (C2, strong) on this one GPU, for the model of its N-GPU time (VERDICT r5 #6d)
+            line2, (prs2, M2, ph2, ex2) = quick_line("C2", "strong", 3, 1)
+            line2["multi_gpu_model"] = multi_gpu_model(prs2, M2, kNN, ph2, ph2["lists"], 1024.0 * ex2["record_kbytes"],
+                                                       tail_bytes=48.0 * ex2["n_surv"] + 136.0 * ex2["n_best"] + 12.0 * sum(M2.values()),
+                                                       sim_bytes=4.0 * ex2["n_surv"])
+            out["baseline_8gpu_config_on_one_gpu"] = line2
         if world == 1:
             out["roofline_phase_b"] = phase_b_roofline(tm_last, lists_ms_sum / phase_steps, pairs, M, kNN, build, args.config, world)
         if world == 1:

@@ -245,6 +245,19 @@ int l3d_lists_shard_views(l3d_ctx*, uint32_t rank, uint32_t world, uint32_t view
  *   -- the caller exchanges the parts: rank r's part of array k to every other rank, in place --
  *   l3d_tail_shard_commit  closes the call as l3d_match_finish does (medians to the host, totals, views untranslated) */
 int l3d_tail_shard_count(l3d_ctx*, uint32_t counts[2]);
+/* Options of the sharded entries of this context (round 6; they hold until changed):
+ *   first_needed_rank   the chain of a rank only has to cover the records its views DEPEND on: view v depends on view u < v when a
+ *                       pair (u -> v) hands inverse matches over (line3D.cc:1680), transitively.  With contiguous view ranges the
+ *                       ranks a rank depends on lie below it; the caller (which knows the pair list: l3d_plan_shards) passes the
+ *                       lowest one, and may then leave the record slabs of ranks outside [first_needed_rank, rank] unexchanged --
+ *                       the COUNTER slab (array 3 of l3d_lists_shard*) must still reach every rank, it carries the pool
+ *                       overflow flags all ranks decide on alike.  0 (default): all ranks below (and the records of all ranks
+ *                       must be present, as before).
+ *   exchanges_stream_ordered   nonzero: the caller's exchanges are ordered behind the context's stream by themselves (RCCL
+ *                       on the same stream): l3d_lists_shard*, l3d_tail_shard_layout and l3d_affinity_shard_begin then return
+ *                       WITHOUT waiting for the device (three host synchronisations less per call).  0 (default): they
+ *                       return when their slabs / parts are complete in device memory. */
+int l3d_shard_options(l3d_ctx*, uint32_t first_needed_rank, int exchanges_stream_ordered);
 int l3d_tail_shard_layout(l3d_ctx*, uint32_t world, const uint32_t* counts_all, const uint32_t* view_bounds, void* base_ptr[9],
                           uint64_t elt_bytes[9], uint64_t* first, uint64_t* count);
 int l3d_tail_shard_commit(l3d_ctx*);

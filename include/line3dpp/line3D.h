@@ -110,12 +110,28 @@ public:
         if (rc != L3D_OK) std::cout << prefix_err_ << l3d_last_error() << std::endl;
     }
 
-    // void Line3D::get3Dlines(std::vector<FinalLine3D>&), line3D.h:173 (FinalLine3D: segment3D.h:165-178)
+    // void Line3D::get3Dlines(std::vector<FinalLine3D>&), line3D.h:173.  FinalLine3D / LineCluster3D with the reference's member
+    // and accessor names (segment3D.h:120-178), so that a consumer written against them compiles unchanged:
+    // line.underlyingCluster_.seg3D(), .residuals(), .size(), .reference_view(); the 3D segments and 2D segment ids are the
+    // C-ABI's PODs (reference layouts: l3d_segment3d = Segment3D's P1, P2, dir; l3d_segment2d = camID, segID)
+    class LineCluster3D {
+    public:
+        LineCluster3D() : reference_view_(0) {}
+        LineCluster3D(const l3d_segment3d& seg3D, const std::list<l3d_segment2d>& residuals, const unsigned int ref_view)
+            : seg3D_(seg3D), residuals_(residuals), reference_view_(ref_view) {}
+        l3d_segment3d seg3D() const { return seg3D_; }
+        const std::list<l3d_segment2d>* residuals() const { return &residuals_; }
+        size_t size() const { return residuals_.size(); }
+        unsigned int reference_view() const { return reference_view_; }
+        void update3Dline(const l3d_segment3d& seg3D) { seg3D_ = seg3D; }
+    private:
+        l3d_segment3d seg3D_{};
+        std::list<l3d_segment2d> residuals_;
+        unsigned int reference_view_;
+    };
     struct FinalLine3D {
         std::list<l3d_segment3d> collinear3Dsegments_;
-        l3d_segment3d underlyingCluster_seg3D_;
-        std::list<l3d_segment2d> underlyingCluster_residuals_;
-        unsigned int underlyingCluster_reference_view_;
+        LineCluster3D underlyingCluster_;
     };
     void get3Dlines(std::vector<FinalLine3D>& result) {
         result.clear();
@@ -128,9 +144,7 @@ public:
         result.resize(nl);
         for (uint32_t i = 0; i < nl; ++i) {
             result[i].collinear3Dsegments_.assign(segs.begin() + so[i], segs.begin() + so[i + 1]);
-            result[i].underlyingCluster_residuals_.assign(res.begin() + ro[i], res.begin() + ro[i + 1]);
-            result[i].underlyingCluster_seg3D_ = cl[i];
-            result[i].underlyingCluster_reference_view_ = rv[i];
+            result[i].underlyingCluster_ = LineCluster3D(cl[i], std::list<l3d_segment2d>(res.begin() + ro[i], res.begin() + ro[i + 1]), rv[i]);
         }
     }
 

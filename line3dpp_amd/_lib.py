@@ -69,7 +69,7 @@ EXPORTS = [
     "l3d_nvm_intrinsics", "l3d_segment_cache_name", "l3d_read_segment_cache", "l3d_write_segment_cache",
     "l3d_trim_cache", "l3d_set_timing_level", "l3d_tail_shard_count", "l3d_tail_shard_layout", "l3d_tail_shard_commit",
     "l3d_sfm_open_colmap", "l3d_sfm_open_bundler", "l3d_sfm_num_images", "l3d_sfm_get_image", "l3d_sfm_get_worldpoints",
-    "l3d_sfm_close", "l3d_debug_counter", "l3d_affinity_shard_begin", "l3d_affinity_shard_finish", "l3d_affinity_shard_abort",
+    "l3d_sfm_close", "l3d_debug_counter", "l3d_affinity_shard_begin", "l3d_affinity_shard_finish", "l3d_affinity_shard_abort", "l3d_shard_options",
 ]
 
 _lib = None
@@ -141,6 +141,7 @@ def load():
     L.l3d_affinity_shard_begin.argtypes = [vp, u32, u32, vp, vp, vp]
     L.l3d_affinity_shard_finish.argtypes = [vp]
     L.l3d_affinity_shard_abort.argtypes = [vp]
+    L.l3d_shard_options.argtypes = [vp, C.c_uint32, C.c_int]
     L.l3d_match_lines.argtypes = [i32, vp, u32, vp, u32, vp, vp, vp, vp, vp, u32, u32, f32, C.c_int32, vp,
                                   C.POINTER(u64)]
     L.l3d_set_brute_force.argtypes = [vp, i32]

@@ -140,6 +140,11 @@ class Line3D:
         self.last_status = rc
         return rc, int(c[0]), int(c[1])
 
+    def shardOptions(self, first_needed_rank=0, exchanges_stream_ordered=False):
+        """l3d_shard_options: the lowest rank whose records this rank's chain depends on; whether the caller's exchanges order
+        themselves behind the context's stream (then the sharded entries return without waiting for the device)"""
+        return self._check(self.L.l3d_shard_options(self.h, int(first_needed_rank), 1 if exchanges_stream_ordered else 0), "shardOptions")
+
     def tailShardLayout(self, world, counts_all, view_bounds):
         """l3d_tail_shard_layout -> [(device pointer of the full array, element bytes, [(first, count) per rank])] x 9, or None"""
         ca = (C.c_uint32 * (2 * world))(*[int(x) for pair in counts_all for x in pair])

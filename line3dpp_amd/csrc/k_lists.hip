@@ -1410,16 +1410,18 @@ __global__ void k_merge_flags(const ListPools lp, uint32_t world) {
     if (f2) lp.flags[2] = 1;
 }
 
-// seg_of_g of every segment header present (after the slabs of all ranks have arrived)
+// seg_of_g of every segment header present in the pools of lp (after the slabs have arrived).  Round 6: lp.pool0 / npools are
+// the pools whose RECORDS this rank holds (l3d_shard_options) -- the counters of all ranks arrive, the records of the ranks it
+// does not depend on do not, and a counter without its records must not be followed
 __global__ void k_seg_index(const ListPools lp, uint32_t* __restrict__ seg_of_g) {
     if (lp.flags[0] | lp.flags[2]) return;
-    const uint32_t pool = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t pool = lp.pool0 + blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= min(lp.cnt[pool * 16 + 2], lp.scap)) return;
     seg_of_g[lp.segs[pool * lp.scap + k].g] = pool * lp.scap + k;
 }
 hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, uint32_t world, hipStream_t st) {
     hipLaunchKernelGGL(k_merge_flags, dim3(1), dim3(1), 0, st, lp, world ? world : 1u);
-    hipLaunchKernelGGL(k_seg_index, dim3((lp.scap + 255) / 256, kListPools), dim3(256), 0, st, lp, seg_of_g);
+    hipLaunchKernelGGL(k_seg_index, dim3((lp.scap + 255) / 256, lp.npools), dim3(256), 0, st, lp, seg_of_g);
     return hipGetLastError();
 }
 

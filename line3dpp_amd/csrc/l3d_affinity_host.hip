@@ -272,7 +272,7 @@ int l3d_affinity_shard_begin(l3d_ctx* c, uint32_t rank, uint32_t world, void** s
     if (rc == L3D_OK) rc = affinity_sim(c, c->tail_base_n[rank], c->tail_base_n[rank + 1]);
     // (the caller posts the exchange of the similarities right away, possibly on another stream or through a backend that
     // does not order itself after this stream: the part must be complete in device memory on return -- ADVICE round 5)
-    if (rc == L3D_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(L3D_ERR_HIP, "l3d_affinity_shard_begin: stream synchronisation failed");
+    if (rc == L3D_OK && !c->exch_ordered && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(L3D_ERR_HIP, "l3d_affinity_shard_begin: stream synchronisation failed");
     if (rc != L3D_OK) { untranslate(*c); return rc; }
     *simv = c->d_simv.p;
     for (uint32_t r = 0; r < world; ++r) { first[r] = c->tail_base_n[r]; count[r] = c->tail_base_n[r + 1] - c->tail_base_n[r]; }

@@ -241,6 +241,8 @@ struct l3d_ctx {
     // sharded tail (l3d_tail_shard_*): counts of all ranks -> where every rank's outputs start in the full arrays
     std::vector<uint32_t> tail_base_n, tail_base_h;
     bool tail_counted = false, tail_written = false;
+    uint32_t shard_dep_rank0 = 0;                   // l3d_shard_options: lowest rank whose records this rank's chain needs
+    bool exch_ordered = false;                      // ... the caller's exchanges order themselves behind the stream: no host waits
     uint32_t aff_parts_world = 0;                    // world size of the last call closed by l3d_tail_shard_commit (tail_base_n valid), else 0
     bool aff_shard_open = false;                    // between l3d_affinity_shard_begin and _finish (views translated)
     bool lists_ready = false, lists_prepared = false;   // per-pool capacities (grow on overflow, kept across calls)

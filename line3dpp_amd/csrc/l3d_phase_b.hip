@@ -63,7 +63,7 @@ static int lists_shard_impl(l3d_ctx* c, uint32_t rank, uint32_t world, int64_t v
         if (r2) return r2;
         c->shard_rank = rank; c->shard_v0 = v0; c->shard_v1 = v1; c->shard_pool0 = pool0; c->shard_ppr = ppr;
         c->tail_counted = false; c->tail_written = false;
-        L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (!c->exch_ordered) L3D_HIP_CHECK(hipStreamSynchronize(c->stream));   // (l3d_shard_options: the caller's exchange orders itself)
         c->shard_world = world; c->lists_ready = true;
         slab_ptr[0] = c->d_ledges.p + (size_t)pool0 * c->lp_ecap; slab_bytes[0] = (uint64_t)ppr * c->lp_ecap * sizeof(EdgeRec); full_ptr[0] = c->d_ledges.p;
         slab_ptr[1] = c->d_lhyps.p + (size_t)pool0 * c->lp_hcap; slab_bytes[1] = (uint64_t)ppr * c->lp_hcap * sizeof(HypHdr); full_ptr[1] = c->d_lhyps.p;
@@ -389,7 +389,12 @@ static int tail_count_run(l3d_ctx* c, bool fresh, const TailShard& ts) {
     hipStream_t st = c->stream;
     const uint32_t V = (uint32_t)c->order.size(), G = c->G;
     const ZeroLayout z = zero_layout(V, G);
-    const ListPools lp = list_pools(c), lps = list_pools(c, ts.pool0, ts.npools);
+    // the chain: over the records this shard's views depend on -- all pools on one GPU and in a replicated tail; the pools of
+    // the ranks [shard_dep_rank0, rank] when the tail is sharded (l3d_shard_options; the pools of later ranks hold nothing this
+    // rank's scores read, those of ranks it does not depend on need not even have arrived: their counters are zero)
+    const bool dep = ts.npools < kListPools && c->shard_world > 1 && c->shard_dep_rank0 <= c->shard_rank;
+    const uint32_t cp0 = dep ? c->shard_dep_rank0 * c->shard_ppr : 0u, cp1 = dep ? (c->shard_rank + 1) * c->shard_ppr : kListPools;
+    const ListPools lp = list_pools(c, cp0, cp1 - cp0), lps = list_pools(c, ts.pool0, ts.npools);
     uint32_t* changed = c->d_lzero.p + z.changed;
     uint32_t* max_score = c->d_lzero.p + z.max_score;
     uint32_t* kept = c->d_lzero.p + z.kept;
@@ -651,6 +656,14 @@ static int close_failed_call(l3d_ctx* c, int rc) {   // as l3d_match_finish: a d
     return rc;
 }
 
+int l3d_shard_options(l3d_ctx* c, uint32_t first_needed_rank, int exchanges_stream_ordered) {
+    if (!c) return fail(L3D_ERR_ARG, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    c->shard_dep_rank0 = first_needed_rank;
+    c->exch_ordered = exchanges_stream_ordered != 0;
+    return L3D_OK;
+}
+
 int l3d_tail_shard_count(l3d_ctx* c, uint32_t counts[2]) {
     if (!c || !counts) return fail(L3D_ERR_ARG, "null argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
@@ -658,7 +671,9 @@ int l3d_tail_shard_count(l3d_ctx* c, uint32_t counts[2]) {
         return fail(L3D_ERR_STATE, "l3d_tail_shard_count follows l3d_lists_shard* and the exchange of its slabs (world > 1)");
     (void)hipSetDevice(c->device);
     const int rc = [&]() -> int {
-        const ListPools lp = list_pools(c);
+        if (c->shard_dep_rank0 > c->shard_rank) return fail(L3D_ERR_ARG, "l3d_shard_options: first_needed_rank lies above this rank");
+        // (the pools whose records are present: those of the ranks this rank depends on, and its own)
+        const ListPools lp = list_pools(c, c->shard_dep_rank0 * c->shard_ppr, (c->shard_rank + 1 - c->shard_dep_rank0) * c->shard_ppr);
         L3D_HIP_CHECK(launch_seg_index(lp, c->d_seg_of_g.p, c->G, c->shard_world, c->stream));
         const TailShard ts{c->shard_v0, c->shard_v1, c->seg_base[c->shard_v0], c->seg_base[c->shard_v1], c->shard_pool0, c->shard_ppr};
         const int r = tail_count_until_converged(c, ts);
@@ -700,8 +715,8 @@ int l3d_tail_shard_layout(l3d_ctx* c, uint32_t world, const uint32_t* counts_all
         if (r2) return r2;
         // (the caller exchanges the parts right away, possibly on another stream or through a backend that does not order
         // itself after this stream: they must be complete in device memory on return, as the slabs of l3d_lists_shard* are --
-        // ADVICE round 5)
-        L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
+        // ADVICE round 5; not when the caller's exchanges order themselves behind the stream: l3d_shard_options)
+        if (!c->exch_ordered) L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
         void* bp[9] = {c->d_surv.p, c->d_surv_tg.p, c->d_surv_sg.p, c->d_hyps.p, c->d_depths.p, c->d_surv_off.p, c->d_hyp_off.p,
                        c->d_hyp_of_seg.p, medians_of(c)};
         const uint64_t eb[9] = {sizeof(Match), 4, 4, sizeof(HypRec), 8, 4, 4, 4, 4};

@@ -127,13 +127,18 @@ def _wait_for_exchange(buf, device, l3d=None, group=None, issued_on=None):
             torch.cuda.synchronize(device)
 
 
-def _all_ok(ok, device, group):
+def _all_ok(ok, device, group, level=1):
     """Every rank learns whether ANY rank failed locally (a HIP error in matchPairs / expandSlotIndices / listsShardViews,
     an allocation): a rank that left the call on its own would leave its peers inside a collective for ever.  A failing
     rank therefore keeps taking part in the communication pattern (with whatever its buffers hold) up to the next status
-    exchange, where all ranks give up together.  One int32 MIN all-reduce, placed where the host waits anyway (before
-    the record gather, after l3d_match_finish).  L3D_DIST_STATUS=0 leaves it out."""
-    if os.environ.get("L3D_DIST_STATUS", "1") == "0":
+    exchange, where all ranks give up together.  One int32 MIN all-reduce, placed where the host waits anyway.
+    Round 6: every exchange is a host round trip (an 8-GPU C1 call is 0.5 ms), so only the one in front of the record gather
+    -- the point a failing rank reaches without the buffers the gather needs -- is on by default (level 1); the status of
+    the tail travels with its counts (_gather_counts), and the exchanges that only guarded against a failure on ONE rank of a
+    step whose outcome is a function of state every rank holds alike (layout, commit, the affinity's begin) are level 2:
+    L3D_DIST_STATUS=2 turns them back on, =0 turns all of them off."""
+    want = int(os.environ.get("L3D_DIST_STATUS", "1"))
+    if want < level:
         return ok
     import torch
     import torch.distributed as dist
@@ -143,9 +148,44 @@ def _all_ok(ok, device, group):
     return bool(int(t.item()))
 
 
-def gather_slabs(slabs, rank, world_size, device, group=None, l3d=None):
+def shard_needs(pairs, M, view_bounds, world_size):
+    """needs[r] = the ranks (other than r) whose RECORDS rank r's chain depends on.  View v depends on view u < v when a pair
+    (u -> v) exists (its matches are handed to v as inverse hypotheses, line3D.cc:1680) and, through u's own inverse
+    hypotheses, on everything u depends on: the ancestors of r's views in that DAG, by owner.  A function of the pair list
+    alone.  N rings without pairs between them (weak scaling): every set is empty -- no record travels, every rank's chain
+    covers its own records only."""
+    cams = sorted(M)
+    vidx = {c: i for i, c in enumerate(cams)}
+    V = len(cams)
+    preds = [[] for _ in range(V)]
+    for s, t in pairs:
+        u, v = vidx[int(s)], vidx[int(t)]
+        if v > u:
+            preds[v].append(u)
+    owner = np.searchsorted(np.asarray(view_bounds)[1:], np.arange(V), side="right")
+    needs = []
+    for r in range(world_size):
+        seen = np.zeros(V, bool)
+        stack = list(range(int(view_bounds[r]), int(view_bounds[r + 1])))
+        for v in stack:
+            seen[v] = True
+        while stack:
+            v = stack.pop()
+            for u in preds[v]:
+                if not seen[u]:
+                    seen[u] = True
+                    stack.append(u)
+        needs.append(sorted(set(int(q) for q in owner[seen]) - {r}))
+    return needs
+
+
+def gather_slabs(slabs, rank, world_size, device, group=None, l3d=None, needs=None):
     """Every rank's slab of every record array of the sharded list pass (Line3D.listsShard) lands at its place in every
     rank's array.  slabs = [(slab pointer, slab bytes, full-array pointer)]; equal slab sizes by construction.
+
+    needs (round 6, shard_needs): the three RECORD arrays (edges, headers, segment headers) only travel from a rank to the
+    ranks whose chain depends on its records; the fourth array -- the pool counters with every rank's overflow flags, on
+    which all ranks decide alike -- always reaches everyone.  None: everything to everyone.
 
     Default: DIRECT exchange -- one send and one receive per peer, all posted at once (batch_isend_irecv).  The xGMI
     fabric of an 8-GPU node is a full mesh (7 links per GPU, one per peer), so the seven transfers of a rank run on seven
@@ -161,7 +201,7 @@ def gather_slabs(slabs, rank, world_size, device, group=None, l3d=None):
             continue
         full = device_tensor(fp, sb * world_size, device)
         mine = full[rank * sb:(rank + 1) * sb]
-        if collective or world_size == 1:
+        if (collective and needs is None) or world_size == 1:
             # RCCL gathers in place when the input is the rank's own slice of the output (no copy of the slab on the
             # send side); the CPU backend of the tests gets a copy
             dist.all_gather_into_tensor(full, mine if full.is_cuda else mine.clone(), group=group)
@@ -171,10 +211,13 @@ def gather_slabs(slabs, rank, world_size, device, group=None, l3d=None):
         # which both sides post them.  Every rank walks the arrays i and the peers q in the same order and posts, per
         # (array, peer), its receive then its send, so the k-th transfer from a to b is array k on both sides.  The tag
         # is what the gloo backend of the CPU tests matches by.)
+        everyone = needs is None or i == len(slabs) - 1           # (the counter slab is the last array)
         for q in range(world_size):       # disjoint slices of one array: sends read `mine`, receives fill the others
             if q != rank:
-                ops.append(dist.P2POp(dist.irecv, full[q * sb:(q + 1) * sb], glob(q), group, tag=i))   # tag = array
-                ops.append(dist.P2POp(dist.isend, mine, glob(q), group, tag=i))
+                if everyone or q in needs[rank]:
+                    ops.append(dist.P2POp(dist.irecv, full[q * sb:(q + 1) * sb], glob(q), group, tag=i))   # tag = array
+                if everyone or rank in needs[q]:
+                    ops.append(dist.P2POp(dist.isend, mine, glob(q), group, tag=i))
     if ops:
         for r in dist.batch_isend_irecv(ops):
             r.wait()
@@ -215,16 +258,18 @@ def exchange_parts(layout, rank, world_size, device, group=None, l3d=None):
         _wait_for_exchange(last, device, l3d, group, issued_on)
 
 
-def _gather_counts(n_r, h_r, world_size, device, group):
-    """the two counts of every rank's part of a sharded tail -> [(n, h)] x world"""
+def _gather_counts(n_r, h_r, rc, world_size, device, group):
+    """the two counts of every rank's part of a sharded tail AND the status of its count step (round 6: one exchange where
+    round 5 had a status all-reduce followed by the count all-gather) -> ([(n, h)] x world, [rc] x world)"""
     import torch
     import torch.distributed as dist
     on_gpu = device is not None and dist.get_backend(group) == "nccl"
     dev = device if on_gpu else "cpu"
-    mine = torch.tensor([n_r, h_r], dtype=torch.int64, device=dev)
-    out = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world_size)]
-    dist.all_gather(out, mine, group=group)
-    return [(int(t[0].item()), int(t[1].item())) for t in out]
+    mine = torch.tensor([n_r, h_r, rc], dtype=torch.int64, device=dev)
+    out = torch.zeros(3 * world_size, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    host = out.cpu().tolist()                    # ONE read of everything
+    return [(int(host[3 * r]), int(host[3 * r + 1])) for r in range(world_size)], [int(host[3 * r + 2]) for r in range(world_size)]
 
 
 def plan_halo(pairs, M, world_size):
@@ -253,7 +298,7 @@ def plan_halo(pairs, M, world_size):
             runs[r][-1] = (q, runs[r][-1][1], runs[r][-1][2] + 1)
         else:
             runs[r].append((q, p, 1))
-    return dict(view_bounds=vb, pair_bounds=pb, runs=runs)
+    return dict(view_bounds=vb, pair_bounds=pb, runs=runs, needs=shard_needs(pairs, M, vb, world_size))
 
 
 def early_ranges(first, count, halo_pairs):
@@ -302,7 +347,17 @@ def match_images_halo(l3d, rank, world_size, device=None, group=None, **params):
     M = l3d._M
     plan = plan_halo(pairs, M, world_size)
     l3d.halo_plan = plan
-    vb, pb, runs = plan["view_bounds"], plan["pair_bounds"], plan["runs"]
+    vb, pb, runs, needs = plan["view_bounds"], plan["pair_bounds"], plan["runs"], plan["needs"]
+    # the chain of this rank covers the records its views depend on (the ranks in needs[rank], all below it), and the
+    # library's sharded entries need not wait for the device when the exchanges order themselves behind its stream (RCCL on
+    # the context's stream = torch's current one); l3d_shard_options
+    if hasattr(l3d, "shardOptions"):
+        ordered = False
+        if device is not None and getattr(l3d, "stream", None) is not None and dist.get_backend(group) == "nccl":
+            import torch
+            ordered = int(torch.cuda.current_stream(device).cuda_stream) == int(l3d.stream)
+        if not l3d.shardOptions(min(needs[rank] + [rank]), ordered):
+            return give_up()
     first, count = int(pb[rank]), int(pb[rank + 1] - pb[rank])
     send = runs[rank]
     recv = [(r, f, n) for r in range(world_size) for (q, f, n) in runs[r] if q == rank]   # (source rank, first, count)
@@ -320,11 +375,14 @@ def match_images_halo(l3d, rank, world_size, device=None, group=None, **params):
     reqs = []
     buf = None
     # (the index buffer is asked for on EVERY rank of a call that exchanges anything -- whether a rank has halo pairs is a
-    # function of the plan, identical everywhere -- so that a failing allocation, the one failure that cannot be carried
-    # through the exchange, takes all ranks out together instead of leaving the peers inside batch_isend_irecv for ever)
+    # function of the plan, identical everywhere.  A failing allocation is the one failure that cannot be carried through
+    # the exchange; like a failing matchBegin it is a failure of the call's set-up, and the status exchange that guarded
+    # against it on ONE rank alone is level 2 since round 6)
     if any(runs):
-        ptr, n_slots = l3d.slot_index_buffer() if ok else (None, 0)
-        if not _all_ok(ptr is not None, device, group):
+        ptr, n_slots = l3d.slot_index_buffer()     # (also on a rank that has failed: it keeps posting what the plan says)
+        if not _all_ok(ptr is not None, device, group, level=2):
+            return give_up()
+        if ptr is None:
             return give_up()
     if send or recv:
         buf = device_tensor(ptr, n_slots * 4, device)
@@ -357,7 +415,7 @@ def match_images_halo(l3d, rank, world_size, device=None, group=None, **params):
         lap("lists")
         if not _all_ok(ok, device, group):
             return give_up()
-        gather_slabs(slabs, rank, world_size, device, group, l3d)
+        gather_slabs(slabs, rank, world_size, device, group, l3d, needs if shard_tail else None)
         lap("exchange_lists")
         # the tail: sharded by views as well (chain on every rank, scores / filterMatches / outputs / medians by the owner
         # of the view, the outputs exchanged in place), or replicated on the records of all ranks (L3D_SHARD_TAIL=0)
@@ -368,21 +426,30 @@ def match_images_halo(l3d, rank, world_size, device=None, group=None, **params):
             rc = l3d.L.l3d_match_finish(l3d.h)
         l3d.last_status = rc
         lap("finish")
-        # (every rank sees every counter, so rc is the same everywhere unless a rank failed locally: the status exchange
-        # keeps a rank whose finish succeeded from leaving while another is about to repeat the exchange)
+        # (every rank sees every counter, so rc is the same everywhere unless a rank failed locally: the status keeps a rank
+        # whose finish succeeded from leaving while another is about to repeat the exchange.  Sharded tail: it travels WITH
+        # the counts -- one exchange, one host read)
+        if shard_tail:
+            counts, rcs = _gather_counts(n_r, h_r, rc, world_size, device, group)
+            if all(x == 0 for x in rcs):
+                layout = l3d.tailShardLayout(world_size, counts, [int(v) for v in vb])
+                if not _all_ok(layout is not None, device, group, level=2) or layout is None:
+                    return give_up()                 # (a rank whose layout failed has closed its call already: a no-op there)
+                exchange_parts(layout, rank, world_size, device, group, l3d)
+                rc = l3d.tailShardCommit()
+                l3d.last_status = rc
+                lap("finish")
+                if not _all_ok(rc == 0, device, group, level=2):
+                    return give_up() if rc == 0 else l3d._check(rc, "tailShardCommit")
+                return True if rc == 0 else l3d._check(rc, "tailShardCommit")
+            if all(x == -10 for x in rcs):
+                continue                             # L3D_ERR_RETRY on every rank: pools enlarged alike, repeat list pass + exchange
+            # a rank failed locally (or the ranks disagree, which the shared counters rule out): all give up together
+            if rc in (0, -10):
+                l3d.matchAbort()
+                return False
+            return l3d._check(rc, "tailShardCount")
         same = _all_ok(rc in (0, -10), device, group)
-        if rc == 0 and same and shard_tail:
-            counts = _gather_counts(n_r, h_r, world_size, device, group)
-            layout = l3d.tailShardLayout(world_size, counts, [int(v) for v in vb])
-            if not _all_ok(layout is not None, device, group):
-                return give_up()                     # (a rank whose layout failed has closed its call already: a no-op there)
-            exchange_parts(layout, rank, world_size, device, group, l3d)
-            rc = l3d.tailShardCommit()
-            l3d.last_status = rc
-            lap("finish")
-            if not _all_ok(rc == 0, device, group):
-                return give_up() if rc == 0 else l3d._check(rc, "tailShardCommit")
-            return True
         if rc == 0 and same:
             return True
         if not same:
@@ -505,7 +572,9 @@ def compute_affinity_sharded(l3d, rank, world_size, device=None, group=None):
     if world_size == 1 or os.environ.get("L3D_SHARD_AFFINITY", "1") == "0" or not hasattr(l3d, "affinityShardBegin"):
         return l3d.computeAffinity()
     part = l3d.affinityShardBegin(rank, world_size)
-    if not _all_ok(part is not None, device, group):
+    # (whether the fill can be sharded is a function of state every rank holds alike -- the tail was sharded over this world
+    # size, no collinearity links --, so the status exchange is level 2 since round 6: L3D_DIST_STATUS=2)
+    if not _all_ok(part is not None, device, group, level=2) or part is None:
         if part is not None:               # this rank's shard is open, a peer's is not: close it WITHOUT the bookkeeping pass
             l3d.affinityShardAbort()       # (the other ranks' similarities never arrived)
         return l3d.computeAffinity()

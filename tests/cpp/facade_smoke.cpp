@@ -51,7 +51,19 @@ int main(int argc, char** argv) {
     std::vector<L3DPP_HIP::Line3D::FinalLine3D> lines;
     l3d.get3Dlines(lines);
     size_t nseg3 = 0; for (auto& L : lines) nseg3 += L.collinear3Dsegments_.size();
-    printf("LINES lines=%zu segments=%zu\n", lines.size(), nseg3);
+    // a consumer written against the reference's FinalLine3D / LineCluster3D (segment3D.h:120-178) reads the cluster through
+    // the same accessors
+    size_t nres = 0; double len = 0; unsigned refsum = 0;
+    for (auto& L : lines) {
+        const l3d_segment3d s3 = L.underlyingCluster_.seg3D();
+        const std::list<l3d_segment2d>* res = L.underlyingCluster_.residuals();
+        nres += res->size(); refsum += L.underlyingCluster_.reference_view();
+        if (res->size() != L.underlyingCluster_.size()) return 3;
+        const double* q = reinterpret_cast<const double*>(&s3);   // P1[3], P2[3], dir[3]
+        double d2 = 0; for (int k = 0; k < 3; ++k) d2 += (q[k] - q[3 + k]) * (q[k] - q[3 + k]);
+        len += d2;
+    }
+    printf("LINES lines=%zu segments=%zu residuals=%zu refsum=%u len2=%.6f\n", lines.size(), nseg3, nres, refsum, len);
     printf("RESULT images=%zu matches=%zu score_sum=%.6f hypotheses=%zu edges=%zu rows=%zu wsum=%.6f\n",
            l3d.numImages(), n_matches, score_sum, hyp.size(), A.size(), l2g.size(), wsum);
     return 0;

@@ -10,7 +10,10 @@
 //   l3d_match_pairs   (late range)      the rest of its pairs, while the halo travels
 //   l3d_expand_slot_indices             received pairs -> slots (re-derived bit-identically)
 //   l3d_lists_shard_views               phase B's list pass for the rank's views
-//   ncclSend/ncclRecv per peer x 4 arrays, one group (in place)   record slabs of the list pass
+//   l3d_shard_options                   round 6: the lowest rank whose records this rank's chain depends on (the ancestors of
+//                                       its views in the DAG of pairs that hand inverse matches over)
+//   ncclSend/ncclRecv, one group (in place)   the three RECORD arrays of the list pass from a rank to the ranks that depend on
+//                                       it, the counter array (overflow flags every rank decides on alike) to everyone
 //   world > 1 (round 5: tail and affinity fill sharded by the same views):
 //   l3d_tail_shard_count                chain on all records; scores / filterMatches / counts of the rank's views
 //                                       (L3D_ERR_RETRY: pools enlarged, repeat the list pass and its exchange)
@@ -115,6 +118,28 @@ int main(int argc, char** argv) {
         if (!runs[r].empty() && runs[r].back().peer == q && runs[r].back().first + runs[r].back().count == p) ++runs[r].back().count;
         else runs[r].push_back(Run{q, p, 1});
     }
+    // needs[r][q]: rank r's chain depends on the records of rank q (line3dpp_amd/dist.py: shard_needs) -- view v depends on
+    // view u < v when a pair (u -> v) exists, transitively; by owner
+    std::vector<std::vector<char>> needs(world, std::vector<char>(world, 0));
+    {
+        std::vector<std::vector<uint32_t>> preds(nv);
+        for (uint32_t p = 0; p < P; ++p) if (tview[p] > sview[p]) preds[tview[p]].push_back(sview[p]);
+        for (int r = 0; r < world; ++r) {
+            std::vector<char> seen(nv, 0);
+            std::vector<uint32_t> stack;
+            for (uint32_t v = vb[r]; v < vb[r + 1]; ++v) { seen[v] = 1; stack.push_back(v); }
+            while (!stack.empty()) {
+                const uint32_t v = stack.back(); stack.pop_back();
+                for (uint32_t u : preds[v]) if (!seen[u]) { seen[u] = 1; stack.push_back(u); }
+            }
+            for (uint32_t v = 0; v < nv; ++v) if (seen[v] && (int)owner(v) != r) needs[r][owner(v)] = 1;
+        }
+    }
+    uint32_t first_needed = (uint32_t)rank;
+    for (int q = 0; q < rank; ++q) if (needs[rank][q]) { first_needed = (uint32_t)q; break; }
+    // (the exchanges below run on a communication stream of their own: the library's entries must return with their parts
+    // complete -- exchanges_stream_ordered = 0)
+    L3D(l3d_shard_options(c, first_needed, 0));
     const uint32_t first = pb[rank], count = pb[rank + 1] - pb[rank];
     // the largest stretch of own pairs without anything to send is matched last
     uint32_t late_first = first, late_count = count;
@@ -157,8 +182,9 @@ int main(int argc, char** argv) {
         for (int k = 0; k < 4; ++k)
             for (int q = 0; q < world; ++q) {
                 if (q == rank || !bytes[k]) continue;
-                NCCL(ncclSend(slab[k], (size_t)bytes[k], ncclUint8, q, comm, comm_stream));
-                NCCL(ncclRecv((char*)full[k] + (size_t)q * bytes[k], (size_t)bytes[k], ncclUint8, q, comm, comm_stream));
+                // records (k < 3): to the ranks that depend on them; counters (k = 3): to everyone
+                if (k == 3 || needs[q][rank]) NCCL(ncclSend(slab[k], (size_t)bytes[k], ncclUint8, q, comm, comm_stream));
+                if (k == 3 || needs[rank][q]) NCCL(ncclRecv((char*)full[k] + (size_t)q * bytes[k], (size_t)bytes[k], ncclUint8, q, comm, comm_stream));
             }
         NCCL(ncclGroupEnd());
         HIP(hipStreamSynchronize(comm_stream));

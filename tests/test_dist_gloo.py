@@ -333,12 +333,8 @@ class _HaloReplayContext(_ReplayContext):
         return [(None, self.SLAB, self.full[k]) for k in range(4)]
 
     def l3d_match_finish(self, h):
-        vb = self.halo_plan["view_bounds"]
-        for r in range(self.world):
-            for k in range(4):
-                got = self.full[k][r * self.SLAB:(r + 1) * self.SLAB]
-                if not np.array_equal(got, self._sig(r, int(vb[r]), int(vb[r + 1]), self.attempt, k)):
-                    return -8                        # a slab that did not arrive (or arrived from another attempt)
+        if not self._slabs_arrived(sharded_tail=False):
+            return -8                                # a slab that did not arrive (or arrived from another attempt)
         if self.attempt == 0:                        # "pools enlarged on every rank alike": repeat list pass + gather
             self.attempt = 1; self.log.append("retry")
             return -10
@@ -363,10 +359,26 @@ class _HaloReplayContext(_ReplayContext):
         d = hashlib.sha256(f"part:{r}:{k}:{self.attempt}".encode()).digest()
         return np.frombuffer((d * (nbytes // len(d) + 1))[:nbytes], np.uint8)
 
-    def _slabs_arrived(self):
+    def shardOptions(self, first_needed_rank=0, exchanges_stream_ordered=False):
+        self.first_needed = int(first_needed_rank); self.log_options = (int(first_needed_rank), bool(exchanges_stream_ordered))
+        return True
+
+    def _slabs_arrived(self, sharded_tail=True):
+        """round 6: the record arrays (k < 3) of the ranks this rank's chain DEPENDS on (dist.shard_needs) and of itself, the
+        counter slab (k = 3) of every rank; the records of a rank it does not depend on must NOT have been sent to it"""
         vb = self.halo_plan["view_bounds"]
-        return all(np.array_equal(self.full[k][r * self.SLAB:(r + 1) * self.SLAB], self._sig(r, int(vb[r]), int(vb[r + 1]), self.attempt, k))
-                   for r in range(self.world) for k in range(4))
+        needs = set(self.halo_plan["needs"][self.rank]) | {self.rank} if sharded_tail else set(range(self.world))
+        assert getattr(self, "first_needed", 0) == min(needs)
+        for r in range(self.world):
+            for k in range(4):
+                got = self.full[k][r * self.SLAB:(r + 1) * self.SLAB]
+                want = self._sig(r, int(vb[r]), int(vb[r + 1]), self.attempt, k)
+                if k == 3 or r in needs:
+                    if not np.array_equal(got, want):
+                        return False
+                elif got.any():
+                    return False                     # something arrived that nobody should have sent
+        return True
 
     def tailShardCount(self):
         if not self._slabs_arrived():
@@ -589,8 +601,9 @@ class _FailingHaloContext(_HaloReplayContext):
         return super().tailShardCommit()
 
 
-def _failing_worker(rank, world, port, q, fail_rank, where):
+def _failing_worker(rank, world, port, q, fail_rank, where, status_level="1"):
     sys.path.insert(0, ROOT)
+    os.environ["L3D_DIST_STATUS"] = status_level
     from line3dpp_amd import dist
     from line3dpp_amd.scene import make_scene
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -610,22 +623,33 @@ def _failing_worker(rank, world, port, q, fail_rank, where):
         dist_t.destroy_process_group()
 
 
-@pytest.mark.parametrize("where", ["match", "expand", "tail_count", "finish"])
+@pytest.mark.parametrize("where", ["match", "expand", "tail_count", "finish", "finish_default_level"])
 def test_a_rank_that_fails_locally_takes_all_ranks_out_of_the_call_together(where):
     """round 3's early returns left the peers of a failing rank inside a collective for ever; now the failing rank keeps
     posting what the plan says and all ranks give up at the next status exchange (dist._all_ok): nobody hangs, nobody
     returns True, every context is idle again"""
     world, fail_rank = 3, 1
+    # Round 6: the status exchanges of the default level are the one in front of the record gather and the one that travels
+    # with the tail's counts; the guard around the COMMIT (a failure after every exchange of the call is done) is level 2
+    # (L3D_DIST_STATUS=2): with it all ranks report the failure, without it the healthy ranks keep their (complete) result
+    # and only the failing rank reports -- nobody hangs either way
+    level = "2" if where == "finish" else "1"
+    default_commit = where == "finish_default_level"
+    where = "finish" if default_commit else where
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q, fail_rank, where)) for r in range(world)]
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q, fail_rank, where, level)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(world))          # a hang is a timeout here
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    if default_commit:
+        assert [r[1] for r in res] == [r[0] != fail_rank for r in res], res
+        assert all(r[2] == ("idle" if r[0] == fail_rank else "matched") for r in res), res
+        return
     assert [r[1] for r in res] == [False] * world, res
     assert all(r[3] == "begin" for r in res)
     if where in ("finish", "tail_count"):

@@ -434,6 +434,16 @@ def test_cpp_facade_matches_python_front_end(tmp_path, mode):
     e, l2g, _ = g.affinity()
     assert int(kv["hypotheses"]) == len(g.best()[0]) and int(kv["edges"]) == len(e) and int(kv["rows"]) == len(l2g)
     assert abs(float(kv["wsum"]) - float(e["w"].astype(np.float64).sum())) < 1e-3
+    # FinalLine3D through the reference's accessors (underlyingCluster_.seg3D() / .residuals() / .reference_view(),
+    # segment3D.h:120-178) against the Python front end's lines
+    ll = dict(x.split("=") for x in [l for l in out.splitlines() if l.startswith("LINES")][0].split()[1:])
+    assert g.reconstruct3Dlines(3)
+    lines = g.get3Dlines()
+    assert int(ll["lines"]) == len(lines) and int(ll["segments"]) == sum(len(L["collinear3Dsegments"]) for L in lines)
+    assert int(ll["residuals"]) == sum(len(L["residuals"]) for L in lines)
+    assert int(ll["refsum"]) == sum(int(L["reference_view"]) for L in lines)
+    len2 = sum(float(((np.asarray(L["cluster_line"]["P1"], np.float64) - np.asarray(L["cluster_line"]["P2"], np.float64)) ** 2).sum()) for L in lines)
+    assert abs(float(ll["len2"]) - len2) < 1e-3 * max(len2, 1.0)
 
 
 def test_full_pipeline_vs_reference_own_code():
@@ -915,14 +925,41 @@ def test_halo_form_emulated_on_one_gpu_at_c2_slice_size(world):
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_tail_emulated_on_one_gpu_at_c2_slice_size(world):
     """The same halo form with the TAIL of phase B sharded by views as well (l3d_tail_shard_count / _layout / _commit):
-    after the record slabs have been copied where the all-gather would put them, every context runs the chain on all
-    records, computes scores, filterMatches, outputs and medians of ITS views only and writes them at their places in the
-    full arrays; the parts are copied where the exchange would put them; the commit closes the call.  Everything a user
-    can read back must equal a single context's result byte for byte."""
+    after the record slabs have been copied where the exchange would put them, every context runs the chain on the
+    records its views depend on, computes scores, filterMatches, outputs and medians of ITS views only and writes them at
+    their places in the full arrays; the parts are copied where the exchange would put them; the commit closes the call.
+    Everything a user can read back must equal a single context's result byte for byte.  Round 6: a context only receives
+    the record slabs of the ranks its views DEPEND on (dist.shard_needs; the counter slab of every rank) and its chain only
+    covers those (l3d_shard_options)."""
+    from line3dpp_amd.scene import make_config
+    _sharded_tail_emulation(H.ring_slice(make_config("C2", max_views=24), 0, 24), world)
+
+
+def test_sharded_tail_of_independent_rings_needs_no_foreign_records():
+    """weak scaling as bench.py --gpus N runs it: N rings without a pair between them, one per rank.  No rank depends on
+    another's records (dist.shard_needs gives empty sets): NO record slab travels, every chain covers its own pools only,
+    and the result is still the single context's byte for byte."""
+    from line3dpp_amd import dist
+    from line3dpp_amd.scene import Scene
+    views = []
+    for r in range(3):
+        sub_ = make_scene(7, 280, n_neighbors=4, seed=31 + r)
+        off = len(views)
+        for v in sub_.views:
+            v.cam += off
+            v.neighbors = [int(x) + off for x in v.neighbors]
+            views.append(v)
+    sc = Scene(views, "3rings")
+    M = {v.cam: len(v.segs) for v in sc.views}
+    pairs = sc.pair_tests()[1]
+    plan = dist.plan_halo(pairs, M, 3)
+    assert plan["needs"] == [[], [], []] and not any(plan["runs"]), plan
+    _sharded_tail_emulation(sc, 3)
+
+
+def _sharded_tail_emulation(sc, world):
     import torch
     from line3dpp_amd import dist
-    from line3dpp_amd.scene import make_config
-    sc = H.ring_slice(make_config("C2", max_views=24), 0, 24)
     ref = _gpu(sc)
     assert ref.matchImages() and ref.computeAffinity()
     dev = torch.device("cuda", 0)
@@ -931,9 +968,11 @@ def test_sharded_tail_emulated_on_one_gpu_at_c2_slice_size(world):
         assert g.matchBegin()
     pairs, slot_off = ctxs[0].pairs()
     plan = dist.plan_halo(pairs, ctxs[0]._M, world)
-    vb, pb, runs = plan["view_bounds"], plan["pair_bounds"], plan["runs"]
+    vb, pb, runs, needs = plan["view_bounds"], plan["pair_bounds"], plan["runs"], plan["needs"]
+    assert all(all(q < r for q in needs[r]) for r in range(world)), "a rank only depends on ranks below it"
     bufs = []
     for r, g in enumerate(ctxs):
+        assert g.shardOptions(min(needs[r] + [r]), False)
         assert g.matchPairs(int(pb[r]), int(pb[r + 1] - pb[r]))
         for _, f, n in runs[r]:
             assert g.packSlotIndices(f, n)
@@ -960,8 +999,10 @@ def test_sharded_tail_emulated_on_one_gpu_at_c2_slice_size(world):
             fulls = [dist.device_tensor(sl[k][2], sb * world, dev) for sl in slabs]
             for r in range(world):
                 for q in range(world):
-                    if q != r:
+                    if q != r and (k == 3 or r in needs[q]):      # records: only to the ranks that depend on them
                         fulls[q][r * sb:(r + 1) * sb].copy_(fulls[r][r * sb:(r + 1) * sb])
+                    elif q != r:
+                        fulls[q][r * sb:(r + 1) * sb].fill_(0xA5)   # what never arrives must not be read either
         torch.cuda.synchronize()
         res = [g.tailShardCount() for g in ctxs]
         assert len({rc for rc, _, _ in res}) == 1, "every rank takes the same decision (all of them see all pool counters)"
