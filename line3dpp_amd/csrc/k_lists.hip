@@ -185,31 +185,33 @@ __device__ __forceinline__ float window_sq(float dp, float k, float kt, float cc
 
 // ---- compare-exchange steps of the sorting networks with SCALAR direction logic ---------------------------------------
 // In a bitonic network, which lanes keep the smaller key of a pair is a fixed pattern of the lane index per stage.
-// Written as `keep_min ? min : max` it costs two comparisons and four selects per 64-bit key and stage; here the pattern
+// Written as `keep_min ? min : max` it costs two comparisons and selects per key and stage; here the pattern
 // is a 64-bit constant, the comparison result is taken as a lane mask (ballot), the two are combined on the scalar unit
-// and the key is selected by that mask: one VALU comparison + two v_cndmask per key and stage (the sort was ~45 % of
+// and the key is selected by that mask: one VALU comparison + one v_cndmask per 32-bit key and stage (the sort was ~45 % of
 // the list pass's VALU instructions, and the pass is VALU-bound: 1 030 instructions x 128 k lists = its 0.2 ms).
 // bit t of the result: (t & d) == 0 for a power of two d < 64; all lanes for d >= 64 of a one-wave index
 __device__ __forceinline__ uint64_t lanes_bit_clear(uint32_t d) {
     return d == 1 ? 0x5555555555555555ull : d == 2 ? 0x3333333333333333ull : d == 4 ? 0x0F0F0F0F0F0F0F0Full :
            d == 8 ? 0x00FF00FF00FF00FFull : d == 16 ? 0x0000FFFF0000FFFFull : d == 32 ? 0x00000000FFFFFFFFull : ~0ull;
 }
-// per lane: mask bit set -> a, else b
-__device__ __forceinline__ uint64_t select_lanes(uint64_t mask_in, uint64_t a, uint64_t b) {
-    // (the mask is wave-uniform by construction; readfirstlane makes the compiler keep it in SGPRs, which the "s"
-    // constraint alone does not enforce for a 64-bit operand)
+// Round 6: 32-BIT SORT KEYS.  A key is the order-preserving image of the first depth with its low bits replaced by the
+// canonical index (kKeyIdxBits: as many as the tier's capacity needs), so that a compare-exchange is ONE lane exchange, one
+// comparison and one select where the 64-bit key (depth << 32 | index) took two, a 64-bit comparison and two -- the sort is
+// 40 % of the list pass's VALU instructions on long lists (C2) and the pass is bound by them (valu_busy 0.6-0.9,
+// profiles/r06_pmc_lists_C*.json).  The order is that of the TRUNCATED depth: the walk along the sorted keys allows for the
+// truncation (process_list: R1w) and decides on the exact depths, so the candidate set is what the 64-bit keys gave.
+__device__ __forceinline__ uint32_t select_lanes32(uint64_t mask_in, uint32_t a, uint32_t b) {
     const uint64_t mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(mask_in >> 32)) << 32) |
-                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)mask_in);   // (the builtin returns int)
-    uint32_t lo, hi;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"((uint32_t)b), "v"((uint32_t)a), "s"(mask));
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"((uint32_t)(b >> 32)), "v"((uint32_t)(a >> 32)), "s"(mask));
-    return ((uint64_t)hi << 32) | lo;
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)mask_in);
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
 }
-// own key v, partner's key o (distinct, or both the padding value); keep_min: lanes that end up with the smaller one
-__device__ __forceinline__ uint64_t cmp_exchange(uint64_t v, uint64_t o, uint64_t keep_min) {
+__device__ __forceinline__ uint32_t cmp_exchange(uint32_t v, uint32_t o, uint64_t keep_min) {
     const uint64_t own_less = __builtin_amdgcn_ballot_w64(v < o);
-    return select_lanes(~(own_less ^ keep_min), v, o);
+    return select_lanes32(~(own_less ^ keep_min), v, o);
 }
+__device__ __forceinline__ uint32_t make_key(float d1, uint32_t idx, uint32_t idx_mask) { return (f2ord(d1) & ~idx_mask) | idx; }
 
 // Bitonic sort of the list's depth keys with the keys in REGISTERS (thread t owns the KPT consecutive elements
 // t*KPT ..): partner distance below KPT = register exchange, below 64 threads = lane exchange, and only the partners in
@@ -217,13 +219,13 @@ __device__ __forceinline__ uint64_t cmp_exchange(uint64_t v, uint64_t o, uint64_
 // none at all instead of 28 LDS round trips, for 256 keys on two waves one barrier stage instead of 36.  The keys are
 // distinct (the canonical index is part of them).  Leaves the sorted keys in keys[0 .. 64*WPL*KPT).
 template <int WPL, int KPT>
-__device__ __forceinline__ void list_sort_regs(L3D_LDS uint64_t* keys, L3D_LDS const float* e_d1, uint32_t L, uint32_t t) {
+__device__ __forceinline__ void list_sort_regs(L3D_LDS uint32_t* keys, L3D_LDS const float* e_d1, uint32_t L, uint32_t t, uint32_t idx_mask) {
     constexpr uint32_t GS = 64 * WPL, N = GS * KPT;
-    uint64_t v[KPT];
+    uint32_t v[KPT];
 #pragma unroll
     for (int r = 0; r < KPT; ++r) {
         const uint32_t x = t * KPT + r;
-        v[r] = x < L ? (((uint64_t)f2ord(e_d1[x]) << 32) | x) : ~0ull;
+        v[r] = x < L ? make_key(e_d1[x], x, idx_mask) : ~0u;
     }
     const uint32_t wave_t = __builtin_amdgcn_readfirstlane(t) & ~63u;   // first thread index of this wave (uniform)
     // lanes whose element t*KPT + r has bit k clear ("ascending" half of the k-merge)
@@ -250,7 +252,7 @@ __device__ __forceinline__ void list_sort_regs(L3D_LDS uint64_t* keys, L3D_LDS c
             const uint32_t d = j / KPT;
 #pragma unroll
             for (int r = 0; r < KPT; ++r) {
-                const uint64_t o = __shfl_xor((unsigned long long)v[r], (int)d);
+                const uint32_t o = __shfl_xor(v[r], (int)d);
                 v[r] = cmp_exchange(v[r], o, ~(lanes_bit_clear(d) ^ up_mask(k, r)));
             }
         }
@@ -260,10 +262,10 @@ __device__ __forceinline__ void list_sort_regs(L3D_LDS uint64_t* keys, L3D_LDS c
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
                     if ((r & jj) == 0) {
-                        const uint64_t a = v[r], b = v[r | jj];
+                        const uint32_t a = v[r], b = v[r | jj];
                         // swap where (a > b) == ascending
                         const uint64_t sw = ~(__builtin_amdgcn_ballot_w64(a > b) ^ up_mask(k, r));
-                        v[r] = select_lanes(sw, b, a); v[r | jj] = select_lanes(sw, a, b);
+                        v[r] = select_lanes32(sw, b, a); v[r | jj] = select_lanes32(sw, a, b);
                     }
                 }
             }
@@ -305,8 +307,12 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
     L3D_LDS uint32_t* e_tv = (L3D_LDS uint32_t*)(e_d2 + CAP);
     L3D_LDS uint32_t* e_ref = e_tv + CAP;
     L3D_LDS uint32_t* e_pf = e_ref + CAP;
-    L3D_LDS uint64_t* keys = (L3D_LDS uint64_t*)(e_pf + CAP);
-    L3D_LDS uint16_t* pos_of = (L3D_LDS uint16_t*)(keys + NKEY);        // sorted position of hypothesis i
+    // (32-bit sort keys in the first half of the 8-byte-per-key area, whose full size the staging of the inverse hypotheses
+    // below still uses as scratch)
+    L3D_LDS uint32_t* keys = (L3D_LDS uint32_t*)(e_pf + CAP);
+    L3D_LDS uint16_t* pos_of = (L3D_LDS uint16_t*)(keys + 2 * NKEY);    // sorted position of hypothesis i
+    constexpr uint32_t kIdxMask = NKEY - 1;                             // low bits of a key: the canonical index
+    static_assert((NKEY & (NKEY - 1)) == 0 && CAP <= NKEY, "the index bits of a sort key cover the tier's capacity");
     uint32_t* red = (uint32_t*)(pos_of + CAP);                          // 16 words (generic pointer into LDS)
     const float vk = lv.k;
     const uint32_t q0 = lv.q0, nq = lv.nq;
@@ -447,35 +453,35 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
     while (N < L) N <<= 1;
     if (WPL == 1 && N <= 64) {
         // one key per lane: the bitonic network runs on lane exchanges, no LDS round trip per stage
-        uint64_t key = t < L ? (((uint64_t)f2ord(e_d1[t]) << 32) | t) : ~0ull;
+        uint32_t key = t < L ? make_key(e_d1[t], t, kIdxMask) : ~0u;
 #pragma unroll
         for (uint32_t k = 2; k <= 64; k <<= 1)
 #pragma unroll
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                const uint64_t other = __shfl_xor(key, (int)j);
+                const uint32_t other = __shfl_xor(key, (int)j);
                 // lanes that keep the smaller key: ((t & j) == 0) == ((t & k) == 0)
                 key = cmp_exchange(key, other, ~(lanes_bit_clear(j) ^ lanes_bit_clear(k)));
             }
         keys[t] = key;
     } else if (N == 2 * GS) {
-        list_sort_regs<WPL, 2>(keys, e_d1, L, t);
+        list_sort_regs<WPL, 2>(keys, e_d1, L, t, kIdxMask);
     } else if (CAP >= 4 * GS && N == 4 * GS) {
-        list_sort_regs<WPL, (CAP >= 4 * GS ? 4 : 2)>(keys, e_d1, L, t);
+        list_sort_regs<WPL, (CAP >= 4 * GS ? 4 : 2)>(keys, e_d1, L, t, kIdxMask);
     } else {
-    for (uint32_t x = t; x < N; x += GS) keys[x] = x < L ? (((uint64_t)f2ord(e_d1[x]) << 32) | x) : ~0ull;
+    for (uint32_t x = t; x < N; x += GS) keys[x] = x < L ? make_key(e_d1[x], x, kIdxMask) : ~0u;
     for (uint32_t k = 2; k <= N; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             group_barrier<WPL>();
             for (uint32_t px = t; px < N / 2; px += GS) {
                 const uint32_t lo = ((px & ~(j - 1)) << 1) | (px & (j - 1)), hi = lo | j;
-                const uint64_t a = keys[lo], b = keys[hi];
+                const uint32_t a = keys[lo], b = keys[hi];
                 const bool up = (lo & k) == 0;
                 if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
             }
         }
     }
     group_barrier<WPL>();
-    for (uint32_t p = t; p < L; p += GS) pos_of[(uint32_t)keys[p] & 0xFFFFu] = (uint16_t)p;
+    for (uint32_t p = t; p < L; p += GS) pos_of[keys[p] & kIdxMask] = (uint16_t)p;
     group_barrier<WPL>();
     // ---- candidate pairs: every hypothesis walks outwards from its sorted position while the first depths differ by
     // no more than its window; a candidate also has another camera and its second depth inside the second window.
@@ -483,43 +489,28 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
     // Two passes: count (-> one reservation for the whole list), then write the records ----
     constexpr uint32_t kPer = (CAP + GS - 1) / GS;                      // hypotheses per thread
     uint32_t my_cnt[kPer], my_total = 0;
-    float my_R1[kPer], my_R2[kPer];                                      // squared windows of my hypotheses
-    auto walk = [&](uint32_t i, float R1, float R2, auto&& emit) {
+    float my_R1[kPer], my_R2[kPer], my_R1w[kPer];                        // squared windows of my hypotheses; R1w: the walk's
+    // The sorted keys carry the first depth TRUNCATED to its upper bits (t_j <= d_j < t_j (1 + kKeySlack)): the walk ends where
+    // (a1 - t_j)^2 exceeds R1w = (r1 + (a1 + r1) kKeySlack)^2, r1 = sqrt(R1) -- beyond that no entry's true depth is within r1
+    // of a1 in either direction --, and an entry inside is a candidate on its EXACT depths, as with the 64-bit keys.
+    constexpr float kKeySlack = (float)NKEY * 1.1920929e-7f * 1.001f;   // 2^kKeyIdxBits ulps, relative
+    auto walk = [&](uint32_t i, float R1, float R1w, float R2, auto&& emit) {
         const uint32_t p = pos_of[i];
         const float a1 = e_d1[i], a2 = e_d2[i];
         const uint32_t tvi = e_tv[i];
-#if L3D_LISTS_BATCH
         // (98 % of the hypotheses have nobody inside their window: both first neighbours are requested together, so that the
         // usual walk is one LDS round trip instead of two)
-        const uint64_t kd0 = p > 0 ? keys[p - 1] : 0ull, ku0 = p + 1 < L ? keys[p + 1] : 0ull;
-        auto test = [&](uint64_t kq) -> bool {            // false: outside the window -- the walk in this direction ends
-            const float d = a1 - ord2f((uint32_t)(kq >> 32));
-            if (!(d * d <= R1)) return false;
-            const uint32_t j = (uint32_t)kq & 0xFFFFu;
-            const float d2 = a2 - e_d2[j];
-            if (e_tv[j] != tvi && d2 * d2 <= R2) emit(j);
+        const uint32_t kd0 = p > 0 ? keys[p - 1] : 0u, ku0 = p + 1 < L ? keys[p + 1] : 0u;
+        auto test = [&](uint32_t kq) -> bool {            // false: outside the window -- the walk in this direction ends
+            const float d = a1 - ord2f(kq & ~kIdxMask);
+            if (!(d * d <= R1w)) return false;
+            const uint32_t j = kq & kIdxMask;
+            const float d1 = a1 - e_d1[j], d2 = a2 - e_d2[j];
+            if (d1 * d1 <= R1 && e_tv[j] != tvi && d2 * d2 <= R2) emit(j);
             return true;
         };
         if (p > 0 && test(kd0)) for (uint32_t q = p - 1; q-- > 0;) if (!test(keys[q])) break;
         if (p + 1 < L && test(ku0)) for (uint32_t q = p + 2; q < L; ++q) if (!test(keys[q])) break;
-        return;
-#endif
-        for (uint32_t q = p; q-- > 0;) {
-            const uint64_t kq = keys[q];
-            const float d = a1 - ord2f((uint32_t)(kq >> 32));
-            if (!(d * d <= R1)) break;
-            const uint32_t j = (uint32_t)kq & 0xFFFFu;
-            const float d2 = a2 - e_d2[j];
-            if (e_tv[j] != tvi && d2 * d2 <= R2) emit(j);
-        }
-        for (uint32_t q = p + 1; q < L; ++q) {
-            const uint64_t kq = keys[q];
-            const float d = a1 - ord2f((uint32_t)(kq >> 32));
-            if (!(d * d <= R1)) break;
-            const uint32_t j = (uint32_t)kq & 0xFFFFu;
-            const float d2 = a2 - e_d2[j];
-            if (e_tv[j] != tvi && d2 * d2 <= R2) emit(j);
-        }
     };
     // hypothesis i = c * GS + t: canonical order = ascending (c, t), so the offsets are one group scan per c
     uint32_t H = 0;
@@ -527,12 +518,17 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
     for (uint32_t c = 0; c < kPer; ++c) {
         const uint32_t i = c * GS + t;
         uint32_t cnt = 0;
-        my_R1[c] = my_R2[c] = -1.0f;
+        my_R1[c] = my_R2[c] = my_R1w[c] = -1.0f;
         if (c * GS < L) {
             if (i < L) {
                 const float kt = views[e_tv[i]].k, D = pairs[e_pf[i] & 0x7FFFFFFFu].cc_dist;
                 my_R1[c] = window_sq(e_d1[i], vk, kt, D); my_R2[c] = window_sq(e_d2[i], vk, kt, D);
-                walk(i, my_R1[c], my_R2[c], [&](uint32_t) { ++cnt; });
+                {   // (inf stays inf: the whole list is the window; the factor covers the rounding of the root and the square)
+                    const float r1 = __builtin_sqrtf(my_R1[c]);
+                    const float rw = r1 + (__builtin_fabsf(e_d1[i]) + r1) * kKeySlack;
+                    my_R1w[c] = rw * rw * 1.00001f;
+                }
+                walk(i, my_R1[c], my_R1w[c], my_R2[c], [&](uint32_t) { ++cnt; });
             }
             uint32_t total;
             my_cnt[c] = H + group_scan<WPL>(cnt, total, red);          // offset of my records within the list
@@ -558,7 +554,7 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
             const uint32_t i = c * GS + t;
             if (i < L) {
                 uint32_t w = c0 + my_cnt[c];
-                walk(i, my_R1[c], my_R2[c], [&](uint32_t j) {
+                walk(i, my_R1[c], my_R1w[c], my_R2[c], [&](uint32_t j) {
                     CandRec r;
                     r.ij = (i << 16) | j; r.ref_i = e_ref[i]; r.ref_j = e_ref[j]; r.pf_i = e_pf[i];
                     r.tvj = e_tv[j] | (e_pf[j] & kHypInv);
