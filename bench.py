@@ -743,7 +743,9 @@ def main():
         }
         if extra_line is not None:
             out["baseline_8gpu_config_line"] = extra_line
-        if world == 1 and args.config == "C1" and not args.no_extra_lines:
+        # (not in the profiling / A-B invocations, which all pass --no-cpu-baseline: a second configuration in the process would
+        # mix its kernels into their per-kernel summaries)
+        if world == 1 and args.config == "C1" and not args.no_extra_lines and not args.no_cpu_baseline:
             # BASELINE's 8-GPU configuration (C2, strong) on this one GPU, for the model of its N-GPU time (VERDICT r5 #6d)
             line2, (prs2, M2, ph2, ex2) = quick_line("C2", "strong", 3, 1)
             line2["multi_gpu_model"] = multi_gpu_model(prs2, M2, kNN, ph2, ph2["lists"], 1024.0 * ex2["record_kbytes"],

@@ -26,19 +26,8 @@
 #include "l3d_kernels.h"
 #include "l3d_lists.h"
 
-// A/B switches of the list tiers (profiles/r05_ab_phase_b.txt)
-#ifndef L3D_CHAIN_BATCH
-#define L3D_CHAIN_BATCH 0   // 1: k_chain_sweep fetches four edges per round trip (loses the exit at the first satisfied edge)
-#endif
-#ifndef L3D_LISTS_BATCH
-#define L3D_LISTS_BATCH 1   // 1: the row look-up and the rank of an inverse record read four LDS words per round trip
-#endif
-#ifndef L3D_LISTS_NO_TIER2
-#define L3D_LISTS_NO_TIER2 0   // 1: lists beyond one wave's capacity go straight to the four-wave tier
-#endif
-#ifndef L3D_LISTS4_GRID
-#define L3D_LISTS4_GRID 512     // fixed grid of the four-wave tier
-#endif
+// grids of the multi-wave list tiers (every alternative measured is slower: profiles/r05_ab_phase_b.txt)
+constexpr uint32_t kLists4Grid = 512;      // fixed grid of the four-wave tier
 
 namespace l3d {
 
@@ -356,7 +345,6 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
                 const uint32_t x = cc * GS + t;
                 if (x < total) {
                     uint32_t r = 0;
-#if L3D_LISTS_BATCH
                     {   // (four table words per LDS round trip: the trip count is a run-time value and the loop was one
                         // dependent read after the other)
                         uint32_t j = 1;
@@ -366,9 +354,6 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
                         }
                         for (; j < nq_here; ++j) r = k32[5 * j + 1] <= x ? j : r;
                     }
-#else
-                    for (uint32_t j = 1; j < nq_here; ++j) r = k32[5 * j + 1] <= x ? j : r;   // prefixes ascend: the last row that starts at or before x
-#endif
                     row[cc] = r;
                     ref[cc] = inv[k32[5 * r] + (x - k32[5 * r + 1])];
                     kref[x] = ref[cc];
@@ -382,7 +367,6 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
                 if (x < total) {
                     const uint32_t r = row[cc], r0 = k32[5 * r + 1], r1 = k32[5 * r + 2];
                     uint32_t rank = r0;                                  // place among the entries of its own row (a handful)
-#if L3D_LISTS_BATCH
                     {
                         uint32_t y = r0;
                         for (; y + 4 <= r1; y += 4) {
@@ -391,9 +375,6 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
                         }
                         for (; y < r1; ++y) rank += (kref[y] < ref[cc]) ? 1u : 0u;
                     }
-#else
-                    for (uint32_t y = r0; y < r1; ++y) rank += (kref[y] < ref[cc]) ? 1u : 0u;
-#endif
                     const uint32_t at = n_inv + rank;
                     e_d1[at] = dq[cc].x; e_d2[at] = dq[cc].y; e_tv[at] = k32[5 * r + 3]; e_ref[at] = ref[cc]; e_pf[at] = k32[5 * r + 4] | kHypInv;
                 }
@@ -745,7 +726,7 @@ __global__ __launch_bounds__(64 * WPL) void k_lists(const ViewDev* __restrict__ 
             const uint32_t g = lviews[vi].seg_base + seg;
             if (L > 65535u) atomicOr(&lp.flags[1], 1u);
             else if (L > ListCfg<4, BASE>::CAP) lp.listH[atomicAdd(&lp.flags[5], 1u)] = g;
-            else if (L > ListCfg<2, BASE>::CAP || L3D_LISTS_NO_TIER2) lp.list4[atomicAdd(&lp.flags[4], 1u)] = g;   // (L3D_LISTS_NO_TIER2: A/B switch)
+            else if (L > ListCfg<2, BASE>::CAP) lp.list4[atomicAdd(&lp.flags[4], 1u)] = g;
             else lp.list2[atomicAdd(&lp.flags[7], 1u)] = g;
         }
     } else {
@@ -916,10 +897,7 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
 // contiguous, so a flat launch over (pool, index) runs the same arithmetic with full waves; what was wave-uniform there
 // (the segment's view, its rays) is gathered per lane here -- neighbouring lanes mostly share it.  The list pass leaves
 // the segment in the record's `sim` word; this kernel replaces it by the similarity, or by -1.
-#ifndef L3D_EDGES_WAVES
-#define L3D_EDGES_WAVES 4
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(L3D_EDGES_WAVES))) void k_cand_exact(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_cand_exact(
         const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ gseg_view,
         const SimConst sc, const ListPools lp) {
     if (lp.flags[0] | lp.flags[2]) return;   // the candidate pools overflowed: the pass is discarded
@@ -1059,11 +1037,9 @@ __device__ __forceinline__ void edges_of_segment(const PairDesc* __restrict__ pa
     }
 }
 
-// grid (ceil(scap / L3D_EDGES_SPLIT), pools): a wave takes every gridDim.x-th segment header of its pool.  One wave per
+// grid (ceil(scap / kEdgesSplit), pools): a wave takes every gridDim.x-th segment header of its pool.  One wave per
 // header over the pools' CAPACITY launched 144 k waves on C1 of which 100 k found nothing to do.
-#ifndef L3D_EDGES_SPLIT
-#define L3D_EDGES_SPLIT 4
-#endif
+constexpr uint32_t kEdgesSplit = 4;
 __global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
                                                const uint32_t* __restrict__ gseg_view, const Slot* __restrict__ slots,
                                                const ListPools lp, uint32_t* __restrict__ seg_of_g) {
@@ -1084,15 +1060,10 @@ __global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views,
 
 // ---- the chain as a monotone fixed point ------------------------------------------------------------------------
 // grid (header blocks, pools).  Launch s runs only if launch s-1 changed something (changed[] is zeroed by the host).
-// Inside a launch an undecided header may look again (L3D_SWEEP_LOOKS): all headers are resident at once, so a bit set by
-// another thread (device-scope store / load, the L2 is the meeting point) can travel down a dependency chain within the
-// same launch.  Measured in round 5 (profiles/r05_ab_phase_b.txt): it does not pay -- `finish` of C1 0.571 / 0.580 / 0.641 /
-// 0.717 ms with 1 / 2 / 6 / 16 looks (a look re-reads the edges of every undecided header and sleeps): one look, and the
-// launches the last call needed + 1.
-#ifndef L3D_SWEEP_LOOKS
-#define L3D_SWEEP_LOOKS 1
-#endif
-constexpr uint32_t kSweepLooks = L3D_SWEEP_LOOKS;
+// ONE look per launch: letting an undecided header look again inside a launch (all headers are resident, a bit set by another
+// thread can travel down a chain within the launch) was measured in round 5 and does not pay -- `finish` of C1 0.571 / 0.580 /
+// 0.641 / 0.717 ms with 1 / 2 / 6 / 16 looks (profiles/r05_ab_phase_b.txt); fetching four edges per round trip loses the exit at
+// the first satisfied edge.  The launches enqueued: the largest need of the last four calls + 3 (l3d_phase_b.hip).
 __global__ void k_chain_sweep(const ListPools lp, uint8_t* __restrict__ positive, uint32_t* __restrict__ changed,
                               uint32_t sweep) {
     if (lp.flags[0] | lp.flags[2]) return;                    // an overflowed pass is discarded: its records are incomplete
@@ -1103,47 +1074,14 @@ __global__ void k_chain_sweep(const ListPools lp, uint8_t* __restrict__ positive
     if (h.pair_flags & kHypInv) return;                       // an inverse hypothesis exists iff its SOURCE is positive
     if (__hip_atomic_load(&positive[h.ref], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const uint32_t n = h.edge_cnt, e0 = h.edge_begin;
-#if L3D_CHAIN_BATCH
-    if (kSweepLooks == 1) {
-        // (a header has a handful of edges, each an edge record and -- for an inverse supporter -- its existence byte: two
-        // dependent global round trips per edge, one edge after the other.  Four edges and their bytes per round trip; any
-        // satisfied edge decides, whichever comes first.)
-        bool any_inverse = false;
-        for (uint32_t e = 0; e < n; e += 4) {
-            EdgeRec ed[4]; uint8_t ok[4];
-#pragma unroll
-            for (uint32_t i = 0; i < 4; ++i) ed[i] = lp.edges[e0 + min(e + i, n - 1)];
-#pragma unroll
-            for (uint32_t i = 0; i < 4; ++i) {
-                const bool inv = (ed[i].j_cam & kEdgeInv) != 0;
-                any_inverse |= inv;
-                ok[i] = inv ? __hip_atomic_load(&positive[ed[i].ref_j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)1;
-            }
-            if (ok[0] | ok[1] | ok[2] | ok[3]) {
-                __hip_atomic_store(&positive[h.ref], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                changed[sweep] = 1;
-                return;
-            }
+    for (uint32_t e = 0; e < n; ++e) {
+        const EdgeRec& ed = lp.edges[e0 + e];
+        // a fresh supporter always exists (line3D.cc:1680)
+        if (!(ed.j_cam & kEdgeInv) || __hip_atomic_load(&positive[ed.ref_j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(&positive[h.ref], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            changed[sweep] = 1;
+            return;
         }
-        (void)any_inverse;
-        return;
-    }
-#endif
-    for (uint32_t look = 0; look < kSweepLooks; ++look) {
-        bool any_inverse = false;
-        for (uint32_t e = 0; e < n; ++e) {
-            const EdgeRec& ed = lp.edges[e0 + e];
-            const bool inv = (ed.j_cam & kEdgeInv) != 0;
-            any_inverse |= inv;
-            // a fresh supporter always exists (line3D.cc:1680)
-            if (!inv || __hip_atomic_load(&positive[ed.ref_j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(&positive[h.ref], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                changed[sweep] = 1;
-                return;
-            }
-        }
-        if (!any_inverse) return;                             // cannot become positive
-        __builtin_amdgcn_s_sleep(8);
     }
 }
 
@@ -1163,7 +1101,6 @@ __global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ pos
         const bool exists = !inv || positive[h.ref] != 0;
         float cur = 0.0f;
         uint32_t cur_cam = kEmpty;
-#if L3D_LISTS_BATCH
         if (exists) {
             // (four edge records, then their existence bytes, per global round trip; accumulated in the list's order)
             const uint32_t n = h.edge_cnt, e0 = h.edge_begin;
@@ -1184,18 +1121,6 @@ __global__ void k_hyp_scores(const ListPools lp, const uint8_t* __restrict__ pos
                 }
             }
         }
-#else
-        if (exists)
-            for (uint32_t e = 0; e < h.edge_cnt; ++e) {
-                const EdgeRec ed = lp.edges[h.edge_begin + e];
-                if ((ed.j_cam & kEdgeInv) && !positive[ed.ref_j]) continue;
-                if (ed.tv_j == cur_cam) {
-                    if (ed.sim > cur) { score3D -= cur; score3D += ed.sim; cur = ed.sim; }
-                } else {
-                    score3D += ed.sim; cur = ed.sim; cur_cam = ed.tv_j;
-                }
-            }
-#endif
         h.score3D = score3D;
         h.state = exists ? kHypExists : 0u;
         // (the slot's own copy of the score, for l3d_get_pair_slots.  A rank of a multi-GPU run holds the slots of the
@@ -1421,9 +1346,7 @@ hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, uint32
     return hipGetLastError();
 }
 
-#ifndef L3D_LISTS2_GRID
-#define L3D_LISTS2_GRID 16384   // fixed grid of the two-wave tier (its workgroups stride over the hand-over list)
-#endif
+constexpr uint32_t kLists2Grid = 16384;    // fixed grid of the two-wave tier (its workgroups stride over the hand-over list)
 hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev* views, const PairDesc* pairs,
                         const ListView* lviews, const OutPair* opairs, const InPair* ipairs, const uint32_t* gseg_view,
                         const uint32_t* poff, const uint32_t* inv, const float2* hyp_p, const float2* hyp_q, const Slot* slots, uint32_t uniform_K,
@@ -1448,12 +1371,12 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
                                gseg_view, poff, inv, hyp_p, hyp_q, uniform_K, lp, v0 + a);                                        \
         }                                                                                                                  \
         /* lists beyond one wave's capacity: two waves up to 2x, four up to 4x (fixed grids over the hand-over lists) */   \
-        hipLaunchKernelGGL((k_lists<2, B>), dim3(L3D_LISTS2_GRID), dim3(128), lds2, st, views, pairs, lviews, opairs, ipairs, \
+        hipLaunchKernelGGL((k_lists<2, B>), dim3(kLists2Grid), dim3(128), lds2, st, views, pairs, lviews, opairs, ipairs, \
                            gseg_view, poff, inv, hyp_p, hyp_q, uniform_K, lp, 0u);                                                \
         /* (the four-wave tier is left out while the passes hand it no list -- C1: an empty grid of 16 us --, like      */    \
         /* k_lists_huge below: a pass that then does hand one over is repeated with it, flags[4], check_pass)           */    \
         if (hsa.run_tier4)                                                                                                 \
-        hipLaunchKernelGGL((k_lists<4, B>), dim3(L3D_LISTS4_GRID), dim3(256), lds4, st, views, pairs, lviews, opairs, ipairs, \
+        hipLaunchKernelGGL((k_lists<4, B>), dim3(kLists4Grid), dim3(256), lds4, st, views, pairs, lviews, opairs, ipairs, \
                            gseg_view, poff, inv, hyp_p, hyp_q, uniform_K, lp, 0u);                                                \
     } while (0)
     if (wide) L3D_LISTS(256); else L3D_LISTS(128);
@@ -1468,7 +1391,7 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
         hipLaunchKernelGGL(k_lists_huge, dim3(256), dim3(256), 0, st, views, pairs, lviews, opairs, ipairs, gseg_view, poff,
                            inv, hyp_p, hyp_q, lp, hs);
     hipLaunchKernelGGL(k_cand_exact, dim3((lp.ccap + 255) / 256, lp.npools), dim3(256), 0, st, views, pairs, gseg_view, sc, lp);
-    hipLaunchKernelGGL(k_edges, dim3((lp.scap + L3D_EDGES_SPLIT - 1) / L3D_EDGES_SPLIT, lp.npools), dim3(64), 0, st, views, pairs,
+    hipLaunchKernelGGL(k_edges, dim3((lp.scap + kEdgesSplit - 1) / kEdgesSplit, lp.npools), dim3(64), 0, st, views, pairs,
                        gseg_view, slots, lp, seg_of_g);
     if (lp.npools < kListPools) hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, st, lp);   // sharded pass
     return hipGetLastError();

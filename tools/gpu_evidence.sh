@@ -7,7 +7,7 @@
 #   gpurun --timeout 1500 -- 'bash tools/gpu_evidence.sh bench r04'
 #       smoke, the five bench lines (C2 / C4 against the stored full-size records), kernel statistics of C1 / C2 / C4
 #       -> gpurun_out/<tag>final/
-R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; T=${2:-r05}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; T=${2:-r06}
 if [ "$1" = pmc ]; then
   ( time bash tools/pmc_bench.sh $T C1 ) 2>&1 | tail -3
   ( time bash tools/valu_fit.sh $T ) 2>&1 | tail -2
