@@ -1189,8 +1189,8 @@ __device__ __forceinline__ Band tgt_band(const PairCull& pc, const float4 s, flo
     return make_band(lo, hi, cls);
 }
 
-// bitonic sort of n2 (power of two) 64-bit keys in place (LDS or, for the views beyond the LDS capacity, global memory):
-// one barrier per stage
+// bitonic sort of n2 (power of two) 64-bit keys in place, one barrier per stage: the views beyond the LDS capacity, whose keys
+// (class | exact band start | element) live in global scratch
 __device__ void lds_sort(uint64_t* keys, uint32_t n2) {
     for (uint32_t k = 2; k <= n2; k <<= 1)
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -1207,16 +1207,25 @@ __device__ void lds_sort(uint64_t* keys, uint32_t n2) {
     __syncthreads();
 }
 
-// The same network for n2 = KPT * kCullBlock keys in LDS with the keys held in REGISTERS, thread t owning the KPT
-// consecutive elements t*KPT ..: a stage whose partner distance j is below KPT is a register exchange, up to
-// 32 threads away a lane exchange inside the wave, and only the last three distances (64, 128, 256 threads) go through
-// LDS with barriers -- for 2048 keys 6 stages with barriers instead of 66 (the sort was 80 % of k_cull_prepare).
-// The keys are distinct (the element index is part of them), so "keep the smaller / the larger" is an exact exchange.
+// ---- round 6: 32-BIT KEYS for the views that sort in LDS ---------------------------------------------------------------
+// key = class (3 bits) | band start, quantised linearly over the span of the source wedges (29 - B bits) | element (B = log2 n2
+// bits).  The order of the rows / targets only decides how tight the hulls of 64 consecutive elements are -- every band that is
+// stored, compared or reduced afterwards is the element's own exact band --, so a quantised start is as good as the exact one
+// as long as its resolution is far below a chunk's extent (16 384 targets: 15 bits over the span, ~0.1 px, against ~15 px per
+// chunk; equal starts fall back to the element index).  Half the LDS (two workgroups per CU at 16 384 segments where one
+// fitted), half the lane exchanges of the sort's in-wave stages, and a compare-exchange is v_min_u32 / v_max_u32 + one select.
+// The bitonic network for n2 = KPT * kCullBlock keys in LDS with the keys held in REGISTERS, thread t owning the KPT consecutive
+// elements t*KPT ..: a stage whose partner distance j is below KPT is a register exchange (v_min_u32 / v_max_u32), up to 32
+// threads away a lane exchange inside the wave, and only the last three distances (64, 128, 256 threads) go through LDS with
+// barriers -- for 2048 keys 6 stages with barriers instead of 66.  The keys are distinct (the element index is part of them).
+// (A first 32-bit version selected by lane masks built on the scalar unit, as the list pass of phase B does with its two to
+// four keys per thread: with 32 keys per thread the scalar unit became the bound and the kernel was 25 % SLOWER than the
+// 64-bit one, profiles/r06_ab_cull_prepare.txt.)
 template <int KPT>
-__device__ void reg_sort(uint64_t* keys) {
+__device__ void reg_sort32(uint32_t* keys) {
     constexpr uint32_t n2 = KPT * kCullBlock;
     const uint32_t t = threadIdx.x;
-    uint64_t v[KPT];
+    uint32_t v[KPT];
 #pragma unroll
     for (int r = 0; r < KPT; ++r) v[r] = keys[t * KPT + r];
     for (uint32_t k = 2; k <= n2; k <<= 1) {
@@ -1230,9 +1239,9 @@ __device__ void reg_sort(uint64_t* keys) {
             const bool lower = (t & (j / KPT)) == 0;
 #pragma unroll
             for (int r = 0; r < KPT; ++r) {
-                const uint64_t o = keys[pt * KPT + r];
+                const uint32_t o = keys[pt * KPT + r];
                 const bool up = ((t * KPT + r) & k) == 0;
-                v[r] = (lower == up) ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
+                v[r] = (lower == up) ? min(v[r], o) : max(v[r], o);
             }
         }
         // ---- partner in this wave ----
@@ -1241,9 +1250,9 @@ __device__ void reg_sort(uint64_t* keys) {
             const bool lower = (t & d) == 0;
 #pragma unroll
             for (int r = 0; r < KPT; ++r) {
-                const uint64_t o = __shfl_xor((unsigned long long)v[r], (int)d);
+                const uint32_t o = __shfl_xor(v[r], (int)d);
                 const bool up = ((t * KPT + r) & k) == 0;
-                v[r] = (lower == up) ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
+                v[r] = (lower == up) ? min(v[r], o) : max(v[r], o);
             }
         }
         // ---- partner in this thread ----
@@ -1253,9 +1262,9 @@ __device__ void reg_sort(uint64_t* keys) {
 #pragma unroll
                 for (int r = 0; r < KPT; ++r) {
                     if ((r & jj) == 0) {
-                        const uint64_t a = v[r], b = v[r | jj];
+                        const uint32_t a = v[r], b = v[r | jj];
                         const bool up = ((t * KPT + r) & k) == 0;
-                        if ((a > b) == up) { v[r] = b; v[r | jj] = a; }
+                        v[r] = up ? min(a, b) : max(a, b); v[r | jj] = up ? max(a, b) : min(a, b);
                     }
                 }
             }
@@ -1266,22 +1275,15 @@ __device__ void reg_sort(uint64_t* keys) {
     for (int r = 0; r < KPT; ++r) keys[t * KPT + r] = v[r];
     __syncthreads();
 }
-
-// n2 >= kCullBlock keys in LDS (a power of two up to KMAX * kCullBlock), or any power of two in global memory.
-// KMAX is a template parameter of the kernel: the register budget (two per key and thread) is that of the largest view
-// of the LAUNCH, not of the largest the code can handle.
 template <int KMAX>
-__device__ void cull_sort(uint64_t* keys, uint32_t n2, bool in_lds) {
-    if (in_lds) {
-        const uint32_t kpt = n2 / kCullBlock;
-        if (kpt == 1) { reg_sort<1>(keys); return; }
-        if constexpr (KMAX >= 2) if (kpt == 2) { reg_sort<2>(keys); return; }
-        if constexpr (KMAX >= 4) if (kpt == 4) { reg_sort<4>(keys); return; }
-        if constexpr (KMAX >= 8) if (kpt == 8) { reg_sort<8>(keys); return; }
-        if constexpr (KMAX >= 16) if (kpt == 16) { reg_sort<16>(keys); return; }
-        if constexpr (KMAX >= 32) if (kpt == 32) { reg_sort<32>(keys); return; }
-    }
-    lds_sort(keys, n2);
+__device__ void cull_sort32(uint32_t* keys, uint32_t n2) {
+    const uint32_t kpt = n2 / kCullBlock;
+    if (kpt == 1) { reg_sort32<1>(keys); return; }
+    if constexpr (KMAX >= 2) if (kpt == 2) { reg_sort32<2>(keys); return; }
+    if constexpr (KMAX >= 4) if (kpt == 4) { reg_sort32<4>(keys); return; }
+    if constexpr (KMAX >= 8) if (kpt == 8) { reg_sort32<8>(keys); return; }
+    if constexpr (KMAX >= 16) if (kpt == 16) { reg_sort32<16>(keys); return; }
+    if constexpr (KMAX >= 32) if (kpt == 32) { reg_sort32<32>(keys); return; }
 }
 
 }  // namespace
@@ -1396,7 +1398,8 @@ hipError_t launch_order_items(const PairDesc* pairs, uint32_t first, uint32_t co
 template <int KMAX>
 __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __restrict__ views,
                                                              const PairDesc* __restrict__ pairs, uint32_t first,
-                                                             const CullPools cp, const uint32_t tile_rows) {
+                                                             const CullPools cp, const uint32_t tile_rows,
+                                                             const uint32_t band_cache) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t p = first + blockIdx.x;
     const PairCull& pc = cp.cull[p];
@@ -1414,9 +1417,54 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
     while (n2s < Ms) n2s <<= 1;
     const bool big = pc.k_off != ~0ull;
     uint64_t* keys = big ? cp.big_keys + pc.k_off + (tgt_side ? n2s : 0u) : (uint64_t*)smem;
-    uint32_t* cb = big ? (uint32_t*)smem : (uint32_t*)(keys + n2);       // [2 * n2/64] chunk bands, orderable floats
+    // (round 6) views that sort in LDS: 32-bit keys -- class | quantised band start | element
+    uint32_t* keys32 = (uint32_t*)smem;
+    const bool k32 = !big;
+    uint32_t* cb = big ? (uint32_t*)smem : (keys32 + n2);                // [2 * n2/64] chunk bands, orderable floats
+    // (round 6) BAND CACHE, sides of up to kCullBandCacheSegs elements: a band costs two or three double-precision divisions
+    // and was evaluated three times per element (span / key, key, final write) -- half of the kernel's time; the side's own
+    // bands are kept in LDS after their first evaluation (lo, hi: 8 bytes per element)
+    const bool cache = k32 && band_cache != 0;   // (the launch's decision: its LDS is sized by its largest view)
+    float2* bandc = (float2*)(cb + 2 * (n2 / 64));
     __shared__ uint32_t span[2];
     const uint32_t tid = threadIdx.x;
+    uint32_t kbits = 0;
+    while ((1u << kbits) < n2) ++kbits;                                  // element bits of a 32-bit key
+    const uint32_t idx_mask = k32 ? (1u << kbits) - 1u : 0xFFFFFFu, qmax = (1u << (29u - kbits)) - 1u;
+    auto key_elem = [&](uint32_t i) -> uint32_t { return k32 ? (keys32[i] & idx_mask) : (uint32_t)(keys[i] & 0xFFFFFFu); };
+
+    // The range the 32-bit keys quantise a band start over, span[0 .. 1] as orderable floats: the target side takes the span of
+    // all bounded source wedges (it needs that span anyway -- empty: no bounded row, nothing can be widened, nothing is culled
+    // either --; a target outside it meets no wedge, where it sorts is of no consequence), the source side the range of its own
+    // bounded starts, reduced while it builds its keys
+    if (tid == 0) { span[0] = 0xFFFFFFFFu; span[1] = 0u; }
+    __syncthreads();
+    auto reduce_span = [&](uint32_t lo_o, uint32_t hi_o) {   // (one LDS atomic per wave: two per segment on the same two
+                                                             // addresses serialised the whole pass)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo_o = min(lo_o, (uint32_t)__shfl_xor(lo_o, o)); hi_o = max(hi_o, (uint32_t)__shfl_xor(hi_o, o)); }
+        if ((tid & 63u) == 0) { atomicMin(&span[0], lo_o); atomicMax(&span[1], hi_o); }
+    };
+    if (tgt_side) {
+        uint32_t lo_o = 0xFFFFFFFFu, hi_o = 0u;
+        for (uint32_t i = tid; i < Ms; i += kCullBlock) {
+            const Band b = src_band(pc, vs.seg4[i]);
+            if (b.cls) { lo_o = min(lo_o, f2ord(b.lo)); hi_o = max(hi_o, f2ord(b.hi)); }
+        }
+        reduce_span(lo_o, hi_o);
+        __syncthreads();
+    }
+    // linear over [qlo, qhi], clamped; an empty or degenerate range quantises everything to 0 (element order)
+    auto key32_of = [&](uint32_t cls, float lo, uint32_t i, float qlo, float qscale) -> uint32_t {
+        float q = (lo - qlo) * qscale;
+        q = q > 0.0f ? q : 0.0f;                                        // (NaN / -inf -> 0)
+        const uint32_t qi = q < (float)qmax ? (uint32_t)q : qmax;
+        return (cls << 29) | (qi << kbits) | i;
+    };
+    auto qscale_of = [&](uint32_t o_lo, uint32_t o_hi) -> float {
+        const float a = ord2f(o_lo), b = ord2f(o_hi);
+        return (o_lo <= o_hi && b > a && (b - a) < 1e30f) ? (float)qmax / (b - a) : 0.0f;
+    };
 
     if (!tgt_side) {
         // ---- source rows: key = (class, lo, row) ----
@@ -1431,10 +1479,13 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
         const float ref = vt.cx + vt.cy;   // (width + height) / 2
         const bool two = Ms >= 8192;
         const float w1 = Ms >= 4096 ? ref * (two ? 1.0f / 32.0f : 1.0f / 16.0f) : __builtin_inff(), w2 = ref * (1.0f / 8.0f);
+        uint32_t own_lo = 0xFFFFFFFFu, own_hi = 0u;
         for (uint32_t i = tid; i < n2; i += kCullBlock) {
             uint64_t key = ~0ull;
             if (i < Ms) {
                 const Band b = src_band(pc, vs.seg4[i]);
+                if (cache) bandc[i] = make_float2(b.lo, b.hi);
+                if (b.cls) { own_lo = min(own_lo, f2ord(b.lo)); own_hi = max(own_hi, f2ord(b.lo)); }
                 // order: unbounded, widest, wide, plain -- the row groups with the largest hulls are the longest work
                 // items and must start first (ordered last they lengthen the ramp-down tail of the launch)
                 uint32_t cls = b.cls;   // 0: unbounded, 2: bounded
@@ -1453,11 +1504,22 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
                     else cls = w > w1 ? ((two && w > w2) ? 1u : 2u) : 3u;
                 }
                 key = ((uint64_t)cls << 56) | ((uint64_t)f2ord(b.lo) << 24) | i;
+                // (provisional: the start with its low three bits given to the class, until the range is known)
+                if (k32) keys32[i] = (f2ord(b.lo) & ~7u) | cls;
+            } else if (k32) keys32[i] = ~0u;
+            if (!k32) keys[i] = key;
+        }
+        if (k32) {
+            reduce_span(own_lo, own_hi);
+            __syncthreads();
+            const float qlo = ord2f(span[0]), qs = qscale_of(span[0], span[1]);
+            for (uint32_t i = tid; i < Ms; i += kCullBlock) {
+                const uint32_t tmp = keys32[i];
+                keys32[i] = key32_of(tmp & 7u, ord2f(tmp & ~7u), i, qlo, qs);
             }
-            keys[i] = key;
         }
         __syncthreads();
-        cull_sort<KMAX>(keys, n2, !big);
+        if (k32) cull_sort32<KMAX>(keys32, n2); else lds_sort(keys, n2);   // (beyond the LDS capacity: 64-bit keys in global scratch)
         if (tile_rows) {
             // Tile form (k_match_pairs<..., TILE>): a work item is R consecutive positions, and its hull must not straddle
             // two classes (the last rows of one class and the first of the next are far apart in tau: such an item would
@@ -1473,7 +1535,10 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
             if (tid <= kTileClasses) {          // first sorted position of class tid (binary search; padding keys sort last)
                 const uint64_t want = (uint64_t)tid << 56;
                 uint32_t lo = 0, hi = Ms;
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (k32 ? (keys32[mid] >> 29) < tid : keys[mid] < want) lo = mid + 1; else hi = mid;
+                }
                 cstart[tid] = lo;
             }
             __syncthreads();
@@ -1484,9 +1549,8 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
             }
             __syncthreads();                    // (also: the kEmpty fill above is complete before the rows are placed)
             for (uint32_t i = tid; i < Ms; i += kCullBlock) {
-                const uint64_t key = keys[i];
-                const uint32_t row = (uint32_t)(key & 0xFFFFFFu), k = (uint32_t)(key >> 56);
-                const Band b = src_band(pc, vs.seg4[row]);
+                const uint32_t row = key_elem(i), k = k32 ? keys32[i] >> 29 : (uint32_t)(keys[i] >> 56);
+                const Band b = cache ? Band{bandc[row].x, bandc[row].y, 0u} : src_band(pc, vs.seg4[row]);
                 const uint32_t at = cbase[k] + (i - cstart[k]);
                 cp.src_perm[pc.s_off + at] = row;
                 cp.src_band[pc.s_off + at] = make_float2(b.lo, b.hi);
@@ -1494,52 +1558,38 @@ __global__ __launch_bounds__(kCullBlock) void k_cull_prepare(const ViewDev* __re
             return;
         }
         for (uint32_t i = tid; i < Ms; i += kCullBlock) {
-            const uint32_t row = (uint32_t)(keys[i] & 0xFFFFFFu);
-            const Band b = src_band(pc, vs.seg4[row]);
+            const uint32_t row = key_elem(i);
+            const Band b = cache ? Band{bandc[row].x, bandc[row].y, 0u} : src_band(pc, vs.seg4[row]);
             cp.src_perm[pc.s_off + i] = row;
             cp.src_band[pc.s_off + i] = make_float2(b.lo, b.hi);
         }
         return;
     }
-    // span of all bounded source wedges (empty: no bounded row -> nothing can be widened, nothing is culled
-    // either because every row band is unbounded)
-    if (tid == 0) { span[0] = 0xFFFFFFFFu; span[1] = 0u; }
-    __syncthreads();
-    {   // (one LDS atomic per wave: two per segment on the same two addresses serialised the whole pass -- a third of
-        // the kernel's time on C1)
-        uint32_t lo_o = 0xFFFFFFFFu, hi_o = 0u;
-        for (uint32_t i = tid; i < Ms; i += kCullBlock) {
-            const Band b = src_band(pc, vs.seg4[i]);
-            if (b.cls) { lo_o = min(lo_o, f2ord(b.lo)); hi_o = max(hi_o, f2ord(b.hi)); }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { lo_o = min(lo_o, (uint32_t)__shfl_xor(lo_o, o)); hi_o = max(hi_o, (uint32_t)__shfl_xor(hi_o, o)); }
-        if ((tid & 63u) == 0) { atomicMin(&span[0], lo_o); atomicMax(&span[1], hi_o); }
-    }
-    __syncthreads();
-    const float slo = ord2f(span[0]), shi = ord2f(span[1]);
-
     // ---- target segments ----
+    const float slo = ord2f(span[0]), shi = ord2f(span[1]);
+    const float tq = qscale_of(span[0], span[1]);
     const uint32_t nchunk = (Mt + 63) / 64;
     for (uint32_t i = tid; i < nchunk; i += kCullBlock) { cb[2 * i] = 0xFFFFFFFFu; cb[2 * i + 1] = 0u; }
     for (uint32_t i = tid; i < n2; i += kCullBlock) {
         uint64_t key = ~0ull;
         if (i < Mt) {
             const Band b = tgt_band(pc, vt.seg4[i], slo, shi);
+            if (cache) bandc[i] = make_float2(b.lo, b.hi);
             key = ((uint64_t)b.cls << 56) | ((uint64_t)f2ord(b.lo) << 24) | i;
-        }
-        keys[i] = key;
+            if (k32) keys32[i] = key32_of(b.cls, b.lo, i, slo, tq);
+        } else if (k32) keys32[i] = ~0u;
+        if (!k32) keys[i] = key;
     }
     __syncthreads();
-    cull_sort<KMAX>(keys, n2, !big);
+    if (k32) cull_sort32<KMAX>(keys32, n2); else lds_sort(keys, n2);   // (beyond the LDS capacity: 64-bit keys in global scratch)
     // (i = tid + k * 512: the 64 lanes of a wave hold exactly one 64-target chunk, so its band is a wave reduction and
     // one plain store -- 128 LDS atomics per chunk on two addresses before)
     for (uint32_t i0 = 0; i0 < Mt; i0 += kCullBlock) {
         const uint32_t i = i0 + tid;
         uint32_t lo_o = 0xFFFFFFFFu, hi_o = 0u;
         if (i < Mt) {
-            const uint32_t seg = (uint32_t)(keys[i] & 0xFFFFFFu);
-            const Band b = tgt_band(pc, vt.seg4[seg], slo, shi);
+            const uint32_t seg = key_elem(i);
+            const Band b = cache ? Band{bandc[seg].x, bandc[seg].y, 0u} : tgt_band(pc, vt.seg4[seg], slo, shi);
             cp.tgt_perm[pc.t_off + i] = seg;
             cp.tgt_sf[pc.t_off + i] = *(const float4*)&vt.segf[seg];
             if (pc.sorted_copy) {
@@ -1564,7 +1614,7 @@ hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint
     uint32_t n2 = kCullBlock;
     while (n2 < max_M) n2 <<= 1;
     // (views beyond the LDS capacity keep their keys in global scratch: only the chunk bands stay in LDS)
-    const size_t lds = n2 <= kCullLdsSegs ? (size_t)n2 * 8 + (size_t)(n2 / 64) * 8
+    const size_t lds = n2 <= kCullLdsSegs ? (size_t)n2 * 4 + (size_t)(n2 / 64) * 8 + (n2 <= kCullBandCacheSegs ? (size_t)n2 * 8 : 0)   // (32-bit keys; band cache)
                                            : std::max<size_t>((size_t)kCullLdsSegs * 8 + (kCullLdsSegs / 64) * 8, (size_t)(n2 / 64) * 8);
 #define L3D_CULL(K)                                                                                                        \
     do {                                                                                                                   \
@@ -1572,7 +1622,7 @@ hipError_t launch_cull_prepare(const ViewDev* views, const PairDesc* pairs, uint
                                            (int)lds);                                                                      \
         if (e != hipSuccess) return e;                                                                                     \
         hipLaunchKernelGGL(k_cull_prepare<K>, dim3(count, 2), dim3(kCullBlock), lds, stream, views, pairs, first, pools,   \
-                           tile_rows);                                                                                     \
+                           tile_rows, n2 <= kCullBandCacheSegs ? 1u : 0u);                                                 \
     } while (0)
     const uint32_t kmax = std::min(n2, kCullLdsSegs) / kCullBlock;
     if (kmax <= 1) L3D_CULL(1); else if (kmax == 2) L3D_CULL(2); else if (kmax == 4) L3D_CULL(4);

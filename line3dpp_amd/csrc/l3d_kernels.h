@@ -83,6 +83,7 @@ struct CullPools {
 };
 constexpr uint32_t kOrderBuckets = 1024;
 constexpr uint32_t kCullLdsSegs = 16384;   // LDS sort capacity of k_cull_prepare (larger views sort in global memory)
+constexpr uint32_t kCullBandCacheSegs = 4096;   // ... sides of up to this many elements keep their bands in LDS (8 bytes each)
 constexpr uint32_t kCullMaxSegs = 1u << 20; // 20 index bits in the sort keys beside class and band
 
 // the orientation filter of phase B fused into whatever produces a slot (match epilogue, exchange expansion)
