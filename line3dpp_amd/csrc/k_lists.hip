@@ -1064,23 +1064,63 @@ __global__ __launch_bounds__(64) void k_edges(const ViewDev* __restrict__ views,
 // thread can travel down a chain within the launch) was measured in round 5 and does not pay -- `finish` of C1 0.571 / 0.580 /
 // 0.641 / 0.717 ms with 1 / 2 / 6 / 16 looks (profiles/r05_ab_phase_b.txt); fetching four edges per round trip loses the exit at
 // the first satisfied edge.  The launches enqueued: the largest need of the last four calls + 3 (l3d_phase_b.hip).
+// Round 6: the FIRST sweep decides most headers (a fresh supporter always exists: every header with one is positive at once)
+// and files the rest -- fresh hypotheses whose supporters are all inverse and not yet positive -- in a compact list; the
+// following sweeps walk that list instead of all headers (C2: 3.5 M headers of 64 bytes per sweep, 60-125 us each, nine
+// launches per call; the list holds a few per cent of them).  One list per pool (its region of `undecided`, an output array
+// the tail writes later; its length in the pool's counter word 7): ONE counter for all waves made the first sweep five
+// times as long as the round-5 sweep it replaced -- 55 000 returned atomics on one address.
 __global__ void k_chain_sweep(const ListPools lp, uint8_t* __restrict__ positive, uint32_t* __restrict__ changed,
-                              uint32_t sweep) {
+                              uint32_t* __restrict__ undecided) {
     if (lp.flags[0] | lp.flags[2]) return;                    // an overflowed pass is discarded: its records are incomplete
-    if (sweep && !changed[sweep - 1]) return;
-    const uint32_t pool = lp.pool0 + blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;   // (grid.y = lp.npools: all pools)
-    if (k >= min(lp.cnt[pool * 16 + 1], lp.hcap)) return;
-    const HypHdr& h = lp.hyps[pool * lp.hcap + k];
-    if (h.pair_flags & kHypInv) return;                       // an inverse hypothesis exists iff its SOURCE is positive
-    if (__hip_atomic_load(&positive[h.ref], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    const uint32_t n = h.edge_cnt, e0 = h.edge_begin;
-    for (uint32_t e = 0; e < n; ++e) {
-        const EdgeRec& ed = lp.edges[e0 + e];
-        // a fresh supporter always exists (line3D.cc:1680)
-        if (!(ed.j_cam & kEdgeInv) || __hip_atomic_load(&positive[ed.ref_j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            __hip_atomic_store(&positive[h.ref], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            changed[sweep] = 1;
-            return;
+    const uint32_t pool = lp.pool0 + blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;   // (grid.y = lp.npools)
+    bool later = false;
+    if (k < min(lp.cnt[pool * 16 + 1], lp.hcap)) {
+        const HypHdr& h = lp.hyps[pool * lp.hcap + k];
+        // (an inverse hypothesis exists iff its SOURCE is positive: it has no bit of its own)
+        if (!(h.pair_flags & kHypInv) && !__hip_atomic_load(&positive[h.ref], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            const uint32_t n = h.edge_cnt, e0 = h.edge_begin;
+            bool done = false, any_inverse = false;
+            for (uint32_t e = 0; e < n && !done; ++e) {
+                const EdgeRec& ed = lp.edges[e0 + e];
+                const bool inv = (ed.j_cam & kEdgeInv) != 0;
+                any_inverse |= inv;
+                // a fresh supporter always exists (line3D.cc:1680)
+                if (!inv || __hip_atomic_load(&positive[ed.ref_j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(&positive[h.ref], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    changed[0] = 1;
+                    done = true;
+                }
+            }
+            later = !done && any_inverse;                     // (no inverse supporter: can never become positive)
+        }
+    }
+    const uint64_t m = __builtin_amdgcn_ballot_w64(later);
+    if (m) {
+        uint32_t base = 0;
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&lp.cnt[pool * 16 + 7], (uint32_t)__popcll(m));
+        base = __shfl(base, __builtin_ctzll(m));
+        if (later) undecided[pool * lp.hcap + base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63u)) - 1ull))] = pool * lp.hcap + k;
+    }
+}
+constexpr uint32_t kChainListBlocks = 4;                     // workgroups per pool that walk its list
+__global__ void k_chain_sweep_list(const ListPools lp, uint8_t* __restrict__ positive, uint32_t* __restrict__ changed,
+                                   uint32_t sweep, const uint32_t* __restrict__ undecided) {
+    if (lp.flags[0] | lp.flags[2]) return;
+    if (!changed[sweep - 1]) return;                          // the previous sweep found nothing new: the fixed point is reached
+    const uint32_t pool = lp.pool0 + blockIdx.y;
+    const uint32_t n_u = min(lp.cnt[pool * 16 + 7], lp.hcap);
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n_u; idx += gridDim.x * blockDim.x) {
+        const HypHdr& h = lp.hyps[undecided[pool * lp.hcap + idx]];
+        if (__hip_atomic_load(&positive[h.ref], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+        const uint32_t n = h.edge_cnt, e0 = h.edge_begin;
+        for (uint32_t e = 0; e < n; ++e) {
+            const EdgeRec& ed = lp.edges[e0 + e];
+            if ((ed.j_cam & kEdgeInv) && __hip_atomic_load(&positive[ed.ref_j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(&positive[h.ref], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                changed[sweep] = 1;
+                break;
+            }
         }
     }
 }
@@ -1399,8 +1439,9 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
 
 static dim3 hyp_grid(const ListPools& lp) { return dim3((lp.hcap + 255) / 256, lp.npools); }   // the pools of lp: pool0 + blockIdx.y
 
-hipError_t launch_chain_sweep(ListPools lp, uint8_t* positive, uint32_t* changed, uint32_t sweep, hipStream_t st) {
-    hipLaunchKernelGGL(k_chain_sweep, hyp_grid(lp), dim3(256), 0, st, lp, positive, changed, sweep);
+hipError_t launch_chain_sweep(ListPools lp, uint8_t* positive, uint32_t* changed, uint32_t sweep, uint32_t* undecided, hipStream_t st) {
+    if (sweep == 0) hipLaunchKernelGGL(k_chain_sweep, hyp_grid(lp), dim3(256), 0, st, lp, positive, changed, undecided);
+    else hipLaunchKernelGGL(k_chain_sweep_list, dim3(kChainListBlocks, lp.npools), dim3(256), 0, st, lp, positive, changed, sweep, undecided);
     return hipGetLastError();
 }
 hipError_t launch_hyp_scores(ListPools lp, const uint8_t* positive, const uint32_t* gseg_view, Slot* slots,

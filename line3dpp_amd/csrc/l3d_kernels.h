@@ -159,7 +159,8 @@ hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev*
                         const uint32_t* poff, const uint32_t* inv_refs, const float2* hyp_p, const float2* hyp_q,
                         const Slot* slots, uint32_t uniform_K,
                         SimConst sc, ListPools lp, uint32_t* seg_of_g, HugeScratchArgs hsa, hipStream_t st);
-hipError_t launch_chain_sweep(ListPools lp, uint8_t* positive, uint32_t* changed, uint32_t sweep, hipStream_t st);
+hipError_t launch_chain_sweep(ListPools lp, uint8_t* positive, uint32_t* changed, uint32_t sweep, uint32_t* undecided,
+                              hipStream_t st);   // sweep 0: all headers of lp, files the undecided ones per pool; later sweeps: those lists
 hipError_t launch_hyp_scores(ListPools lp, const uint8_t* positive, const uint32_t* gseg_view, Slot* slots,
                              const uint8_t* pair_present, uint32_t* max_score_bits, hipStream_t st);
 hipError_t launch_hyp_filter(ListPools lp, uint32_t g0, uint32_t g1, const uint32_t* gseg_view, const uint32_t* max_score_bits,

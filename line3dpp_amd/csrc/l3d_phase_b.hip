@@ -408,8 +408,12 @@ static int tail_count_run(l3d_ctx* c, bool fresh, const TailShard& ts) {
     const uint32_t need = std::max(std::max(c->chain_hist[0], c->chain_hist[1]), std::max(c->chain_hist[2], c->chain_hist[3]));
     const uint32_t n_sweeps = std::min(kChainSweeps, std::max(4u, need + 3));
     c->chain_enqueued = n_sweeps;
+    // (the lists of undecided headers, one per pool: in the array of the surviving matches' target segments, which the tail
+    // writes after the chain -- one word per header at most, reserved by lists_reserve; their lengths: word 7 of every pool's
+    // counters, zero after the list pass)
+    if (!fresh) L3D_HIP_CHECK(hipMemset2DAsync(c->d_lzero.p + 7, 64, 0, 4, kListPools, st));
     for (uint32_t s2 = 0; s2 < n_sweeps; ++s2)
-        L3D_HIP_CHECK(launch_chain_sweep(lp, positive_of(c), changed, s2, st));
+        L3D_HIP_CHECK(launch_chain_sweep(lp, positive_of(c), changed, s2, c->d_surv_tg.p, st));
     g_trace.mark("chain sweeps enqueued");
     // which pairs' slots this rank holds (sharded calls only: on one GPU every pair is present)
     const uint8_t* present = nullptr;
