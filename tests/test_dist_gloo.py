@@ -658,3 +658,54 @@ def test_a_rank_that_fails_locally_takes_all_ranks_out_of_the_call_together(wher
         assert all(r[2] in ("idle", "matched") for r in res), res
     else:
         assert all(r[2] == "idle" for r in res), res
+
+
+# ---- the affinity fill's fallback (round 6: ADVICE r5 + the status levels) ---------------------------------------------------
+def _aff_fallback_worker(rank, world, port, q, mode):
+    """mode "none_can": no rank can shard (the tail was not sharded) -> every rank takes the replicated fill, no exchange, no
+    status all-reduce at the default level.  mode "one_cannot": ONE rank's begin fails although its peers' succeed (a local
+    failure); with the single-rank guards on (L3D_DIST_STATUS=2) the peers close their open shards WITHOUT the bookkeeping
+    pass (affinityShardAbort) and all ranks take the replicated fill together."""
+    sys.path.insert(0, ROOT)
+    from line3dpp_amd import dist
+    from line3dpp_amd.scene import make_scene
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["L3D_DIST_STATUS"] = "2" if mode == "one_cannot" else "1"
+    os.environ["L3D_SHARD_TAIL"] = "0" if mode == "none_can" else "1"
+    dist_t.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        scene = make_scene(9, 40, n_neighbors=4, seed=6)
+        ctx = _HaloReplayContext(scene, 5, rank, world)
+        if mode == "one_cannot" and rank == 1:
+            ctx.affinityShardBegin = lambda r, w: None            # this rank's begin fails
+        real = dist.device_tensor
+        dist.device_tensor = lambda arr, nbytes, device: torch.from_numpy(arr.view(np.uint8))[:nbytes]
+        try:
+            ok = dist.match_images_sharded(ctx, rank, world, device=None, kNN=5)
+            ok = ok and dist.compute_affinity_sharded(ctx, rank, world, device=None)
+        finally:
+            dist.device_tensor = real
+        q.put((rank, bool(ok), [x for x in ctx.log if x.startswith("aff") or x == "affinity"]))
+    finally:
+        dist_t.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["none_can", "one_cannot"])
+def test_affinity_fill_falls_back_on_every_rank_together(mode):
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_aff_fallback_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    if mode == "none_can":
+        assert all(r[2] == ["affinity"] for r in res), res
+    else:
+        assert res[1][2] == ["affinity"], res                       # the failing rank never opened a shard
+        assert all(r[2] == ["aff_begin", "aff_abort", "affinity"] for r in (res[0], res[2])), res
