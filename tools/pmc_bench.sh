@@ -17,7 +17,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VAL
            "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" \
            "SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64" \
            "FETCH_SIZE" "WRITE_SIZE"; do
-  timeout 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/$n -o p -- python $R/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline > $out/pass$n.log 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/$n -o p -- python $R/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-cold > $out/pass$n.log 2>&1
   n=$((n+1))
 done
 cd $R
