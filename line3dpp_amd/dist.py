@@ -353,7 +353,9 @@ def match_images_halo(l3d, rank, world_size, device=None, group=None, **params):
     # the context's stream = torch's current one); l3d_shard_options
     if hasattr(l3d, "shardOptions"):
         ordered = False
-        if device is not None and getattr(l3d, "stream", None) is not None and dist.get_backend(group) == "nccl":
+        # (L3D_DIST_ORDERED=0: the sharded entries wait for the device before they return, whatever the backend)
+        if device is not None and getattr(l3d, "stream", None) is not None and dist.get_backend(group) == "nccl" and \
+                os.environ.get("L3D_DIST_ORDERED", "1") != "0":
             import torch
             ordered = int(torch.cuda.current_stream(device).cuda_stream) == int(l3d.stream)
         if not l3d.shardOptions(min(needs[rank] + [rank]), ordered):
