@@ -406,11 +406,12 @@ __device__ __forceinline__ uint32_t process_list(uint32_t vi, uint32_t seg, uint
         } else {
             for (uint32_t q = q0; q < q0 + nq; ++q) {
                 const OutPair op = opairs[q];
-                const uint64_t row0 = op.slot_off + (uint64_t)seg * op.K;
-                for (uint32_t j0 = 0; j0 < op.K; j0 += GS) {
+                uint64_t row0; uint32_t Kr;                               // (ragged rows in the keep-all mode: l3d_lists.h)
+                out_row_slots(op, seg, lp, row0, Kr);
+                for (uint32_t j0 = 0; j0 < Kr; j0 += GS) {
                     bool alive = false;
                     float2 s = make_float2(0.0f, 0.0f);
-                    if (j0 + t < op.K) {
+                    if (j0 + t < Kr) {
                         s = hyp_p[row0 + j0 + t];
                         alive = s.x == s.x;
                     }
@@ -587,7 +588,8 @@ __global__ __launch_bounds__(kCsrBlock) void k_pair_csr(const PairDesc* __restri
                                                         const uint32_t* __restrict__ inv_tgt,
                                                         uint32_t* __restrict__ poff, uint32_t* __restrict__ refs,
                                                         uint32_t* __restrict__ dummy, uint32_t tgt_v0, uint32_t tgt_v1,
-                                                        uint32_t lds_segs, uint32_t stage_cap) {
+                                                        uint32_t lds_segs, uint32_t stage_cap,
+                                                        const uint32_t* __restrict__ row_start) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t part[kCsrBlock];
     const uint32_t pi = first_pair + blockIdx.x;
@@ -597,7 +599,12 @@ __global__ __launch_bounds__(kCsrBlock) void k_pair_csr(const PairDesc* __restri
     if (pd.tgt < tgt_v0 || pd.tgt >= tgt_v1) return;                // only the target views of this pass
     const uint32_t Mt = pd.Mt, tid = threadIdx.x;
     if ((Mt <= lds_segs) != LDSCNT) return;                         // the other instantiation takes this pair
-    const uint32_t S = pd.Ms * pd.K;                                // (< 2^32: l3d_match_begin limits the slot buffer)
+    // slots of the pair (< 2^32: l3d_match_begin limits the slot buffer); ragged rows (keep-all mode): from the rows' starts
+    const uint32_t S = row_start ? row_start[pd.row_off + pd.Ms] - row_start[pd.row_off] : pd.Ms * pd.K;
+    if (!S) {                                                       // (a ragged pair without a match: all runs are empty)
+        for (uint32_t t = threadIdx.x; t <= pd.Mt; t += kCsrBlock) poff[pcs.base + pcs.q + (size_t)t * pcs.ni] = 0;
+        return;
+    }
     typedef typename std::conditional<TGT16, uint16_t, uint32_t>::type tgt_t;     // (0xFFFF / 0xFFFFFFFF: none -- both >= Mt)
     const tgt_t* __restrict__ it = (const tgt_t*)inv_tgt + pd.slot_off;
     // end of run t = start of run t + 1 lives at row t + 1 of the transposed table, column q of this pair
@@ -776,8 +783,9 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
         mine_n = 0;
         for (uint32_t q = lv.q0; q < lv.q0 + lv.nq; ++q) {
             const OutPair op = opairs[q];
-            const uint64_t row0 = op.slot_off + (uint64_t)seg * op.K;
-            for (uint32_t j = t; j < op.K; j += 256) {
+            uint64_t row0; uint32_t Kr;
+            out_row_slots(op, seg, lp, row0, Kr);
+            for (uint32_t j = t; j < Kr; j += 256) {
                 const float2 s = hyp_p[row0 + j];
                 mine_n += s.x == s.x ? 1u : 0u;
             }
@@ -828,11 +836,12 @@ __global__ __launch_bounds__(256) void k_lists_huge(const ViewDev* __restrict__ 
         }
         for (uint32_t q = lv.q0; q < lv.q0 + lv.nq; ++q) {
             const OutPair op = opairs[q];
-            const uint64_t row0 = op.slot_off + (uint64_t)seg * op.K;
-            for (uint32_t j0 = 0; j0 < op.K; j0 += 256) {
+            uint64_t row0; uint32_t Kr;
+            out_row_slots(op, seg, lp, row0, Kr);
+            for (uint32_t j0 = 0; j0 < Kr; j0 += 256) {
                 bool alive = false;
                 float2 s = make_float2(0.0f, 0.0f);
-                if (j0 + t < op.K) { s = hyp_p[row0 + j0 + t]; alive = s.x == s.x; }
+                if (j0 + t < Kr) { s = hyp_p[row0 + j0 + t]; alive = s.x == s.x; }
                 uint32_t total;
                 const uint32_t at = pos + group_scan<4>(alive ? 1u : 0u, total, red);
                 if (alive && at < L) { e_d1[at] = s.x; e_d2[at] = s.y; e_tv[at] = op.tgt; e_ref[at] = (uint32_t)(row0 + j0 + t); e_pf[at] = op.pair; }
@@ -1020,7 +1029,7 @@ __device__ __forceinline__ void edges_of_segment(const PairDesc* __restrict__ pa
                     const Slot hs = slots[r.ref_i];
                     const bool hinv = (r.pf_i & kHypInv) != 0;
                     const PairDesc& hp = pairs[r.pf_i & 0x7FFFFFFFu];
-                    hdr.tgt_seg = hinv ? (uint32_t)((r.ref_i - hp.slot_off) / hp.K) : hs.tgt_seg;
+                    hdr.tgt_seg = !hinv ? hs.tgt_seg : lp.slot_row ? lp.slot_row[r.ref_i] : (uint32_t)((r.ref_i - hp.slot_off) / hp.K);
                     hdr.overlap = hs.overlap;
                     hdr.oq1 = hinv ? hs.dp1 : hs.dq1; hdr.oq2 = hinv ? hs.dp2 : hs.dq2;
                 }
@@ -1302,7 +1311,8 @@ std::atomic<uint64_t> g_csr_global_launches{0};   // test hook (l3d_debug_counte
 
 hipError_t launch_pair_csr(const PairDesc* pairs, uint32_t n_pairs, uint32_t max_Mt, const PairCsr* pair_poff,
                            const uint32_t* inv_tgt, uint32_t tgt16, uint32_t* poff, uint32_t* refs,
-                           uint32_t* dummy, uint32_t tgt_v0, uint32_t tgt_v1, uint64_t max_pair_slots, hipStream_t st) {
+                           uint32_t* dummy, uint32_t tgt_v0, uint32_t tgt_v1, uint64_t max_pair_slots,
+                           const uint32_t* row_start, hipStream_t st) {
     if (!n_pairs) return hipSuccess;
     // (L3D_CSR_GLOBAL=1, test hook: every pair takes the global-memory form that views beyond the LDS capacity need.  Read
     // PER CALL, as lists_run reads it when it sizes `dummy`: a process-wide static here was latched by whichever test ran
@@ -1336,16 +1346,16 @@ hipError_t launch_pair_csr(const PairDesc* pairs, uint32_t n_pairs, uint32_t max
         static const hipError_t attr2 = hipFuncSetAttribute((const void*)k_pair_csr<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
         if (attr2 != hipSuccess) return attr2;
         hipLaunchKernelGGL((k_pair_csr<true, true, true>), dim3(n_pairs), dim3(kCsrBlock), cur_bytes + cap * 4, st, pairs, 0u, pair_poff, inv_tgt,
-                           poff, refs, dummy, tgt_v0, tgt_v1, lds_segs, (uint32_t)cap);
+                           poff, refs, dummy, tgt_v0, tgt_v1, lds_segs, (uint32_t)cap, row_start);
         return hipGetLastError();
     }
 #define L3D_CSR(T16)                                                                                                      \
     do {                                                                                                                  \
         hipLaunchKernelGGL((k_pair_csr<true, T16, false>), dim3(n_pairs), dim3(kCsrBlock), lds, st, pairs, 0u, pair_poff, inv_tgt, \
-                           poff, refs, dummy, tgt_v0, tgt_v1, lds_segs, 0u);                                              \
+                           poff, refs, dummy, tgt_v0, tgt_v1, lds_segs, 0u, row_start);                                   \
         if (max_Mt > lds_segs) { /* views beyond the LDS capacity: cursors in global memory (dummy: 64 words per pair) */ \
             hipLaunchKernelGGL((k_pair_csr<false, T16, false>), dim3(n_pairs), dim3(kCsrBlock), 0, st, pairs, 0u, pair_poff, inv_tgt, \
-                               poff, refs, dummy, tgt_v0, tgt_v1, lds_segs, 0u);                                          \
+                               poff, refs, dummy, tgt_v0, tgt_v1, lds_segs, 0u, row_start);                               \
             g_csr_global_launches.fetch_add(1, std::memory_order_relaxed);                                                \
         }                                                                                                                 \
     } while (0)

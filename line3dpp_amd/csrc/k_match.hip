@@ -194,7 +194,7 @@ __device__ __forceinline__ void store_inverse_target(const OrientFuse& of, uint6
 //   * one ballot + one compaction per 64 lane-tests (two per 128 in the row form), no scalar bit scan, no record address
 //     arithmetic on the scalar unit.
 #ifndef L3D_MATCH_WAVES
-#define L3D_MATCH_WAVES (TILE ? L3D_TILE_WAVES : (WPG == 2 ? 7 : 6))
+#define L3D_MATCH_WAVES (TILE ? L3D_TILE_WAVES : MODE == 1 ? 5 : (WPG == 2 ? 7 : 6))   // (MODE 1: the keep-all pass holds both ray records)
 #endif
 #ifndef L3D_ROW_CACHE
 #define L3D_ROW_CACHE 1   // 0: never stage the source rows' records in LDS (A/B)
@@ -521,6 +521,7 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
         uint32_t tg = ent & 0x7FFFFFu;
         bool pending = false;
         PairResult res{};
+        uint32_t keep_flags = 0;
         // the ring of a wave only holds rows of that wave: the source segment comes from the owning lane
         const uint32_t sg = __shfl(src, sl);
         if (has) {
@@ -535,6 +536,13 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
             if (ov > thr && ov >= need) {
                 res.overlap = ov;
                 L3D_STAT(2, 1);
+                if (MODE == 1) {
+                    // (the single pass of the keep-all mode keeps the whole slot: checkMatchOrientation here, on the ray records
+                    // the depth test has loaded -- the target's is a gather of 104 bytes per candidate, paid once)
+                    const SegX sxx = vs.segx[sg], txx = vt.segx[tg];
+                    pending = exact_depths(sxx, txx, vs.C, vt.C, res);
+                    if (pending && of.keep_rec) keep_flags = fuse_orientation(of, vs.C, vt.C, sxx, txx, res, pd.tgt > pd.src);
+                } else
                 pending = exact_depths(vs.segx[sg], vt.segx[tg], vs.C, vt.C, res);
                 if (pending) L3D_STAT(3, 1);
             }
@@ -562,6 +570,15 @@ __global__ __launch_bounds__(kBlock * WPG) __attribute__((amdgpu_waves_per_eu(L3
                 pending = false;
                 const uint32_t c = L.cnt[sl];
                 if (MODE == 1) {
+                    // (the single culled pass of the keep-all mode: the accepted match is kept at its arrival index, in the
+                    // row's scratch; k_keep_assemble puts the rows into ascending target order)
+                    if (of.keep_rec && c < of.keep_cap) {
+                        Slot o;
+                        o.tgt_seg = tg; o.overlap = res.overlap;
+                        o.dp1 = res.dp1; o.dp2 = res.dp2; o.dq1 = res.dq1; o.dq2 = res.dq2;
+                        o.score3D = 0.0f; o.flags = keep_flags;
+                        of.keep_rec[(size_t)(pd.row_off + sg) * of.keep_cap + c] = o;
+                    }
                     L.cnt[sl] = c + 1;
                 } else if (MODE == 2) {
                     Slot o;
@@ -1864,6 +1881,134 @@ hipError_t launch_match_tied_rows(const ViewDev* views, const PairDesc* pairs, S
     if (!of.tie_count || !of.tie_next || !of.tie_total || !of.tie_list || !scratch) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_match_tied_rows, dim3(match_tied_grid(scratch_stride)), dim3(kTieBlock), (size_t)maxK * 8, stream,
                        views, pairs, slots, thr, of, cp, scratch, scratch_stride);
+    return hipGetLastError();
+}
+
+// ---- keep-all mode (kNN <= 0, line3D.cc:982-992): the rows of the single culled pass ----------------------------------
+// Round 6.  Until then the mode walked every pair twice -- a count pass through the culled walk, then (the rows sized by the
+// host from the counts, K of a pair = its LONGEST row) a fill pass streamed unculled because the reference keeps a row's matches
+// in ascending target order, writing every slot of the padded rows: C1 65.5 M slots of 32 bytes for 19.0 M matches.  Now the
+// count pass keeps what it accepts -- the slot, as a 32-byte cell -- at (row, arrival index) in a per-row scratch, a scan of the
+// counts gives every row its place in a RAGGED slot buffer (row r of a pair = slots [row_start[row_off + r], row_start[row_off
+// + r + 1])), and k_keep_assemble ranks each record among its row's by target index, applies checkMatchOrientation and writes
+// the slot, the streams of phase B and the slot's source row.
+// k_keep_pair_info (grid = pairs): per pair {first slot, longest row, number of slots (64 bits)} for the host, which sizes the
+// slot buffer; per row its pair; per block of kKeepBlock slots the row that holds the block's first slot.
+__global__ __launch_bounds__(256) void k_keep_pair_info(const PairDesc* __restrict__ pairs, const uint32_t* __restrict__ row_counts,
+                                                        const uint32_t* __restrict__ row_start, uint4* __restrict__ info,
+                                                        uint32_t* __restrict__ row_pair, uint32_t* __restrict__ blk_row,
+                                                        uint32_t n_blk, uint32_t* __restrict__ longest) {
+    __shared__ uint32_t s_max[4];
+    __shared__ unsigned long long s_sum[4];
+    const PairDesc& pd = pairs[blockIdx.x];
+    uint32_t mx = 0;
+    unsigned long long sum = 0;
+    for (uint32_t r = threadIdx.x; r < pd.Ms; r += 256) {
+        const uint32_t gr = pd.row_off + r, c = row_counts[gr], s = row_start[gr];
+        mx = max(mx, c); sum += c;
+        row_pair[gr] = blockIdx.x;
+        // (32-bit slot indices: a scene beyond 2^32 matches is refused by the host, which sees the 64-bit sums; its marks are unused)
+        // (n_blk marks: rows x scratch cells -- only a pass with rows beyond the scratch, which is repeated, can want more)
+        for (uint32_t b = (s + kKeepBlock - 1) / kKeepBlock; c && b < n_blk && (uint64_t)b * kKeepBlock < (uint64_t)s + c; ++b) blk_row[b] = gr;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); sum += (unsigned long long)__shfl_xor((long long)sum, o); }
+    if ((threadIdx.x & 63u) == 0) { s_max[threadIdx.x >> 6] = mx; s_sum[threadIdx.x >> 6] = sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { mx = max(mx, s_max[w]); sum += s_sum[w]; }
+        info[blockIdx.x] = make_uint4(row_start[pd.row_off], mx, (uint32_t)sum, (uint32_t)(sum >> 32));
+        atomicMax(longest, mx);                                   // (the assembly behind this kernel checks it against the scratch)
+    }
+}
+
+// grid = blocks of kKeepBlock slots of the whole (ragged) slot buffer: one thread per accepted match = per slot.  A thread finds
+// its row among the row starts its workgroup staged in LDS (from the block's first row, k_keep_pair_info) and its place in the
+// row by counting the row's smaller targets, which its neighbours hold: through LDS.  (First form: one grid per pair, the row by
+// a binary search in memory and the count through vector loads -- ~50 loads per wave of the counting loop, every one a
+// quarter-rate address pass of 64 lanes whatever they coalesce to, behind 11 dependent loads of the search: 0.70 ms for C1's
+// 19 M records.)
+constexpr uint32_t kAsmRows = 2048;
+__global__ __launch_bounds__(kKeepBlock) void k_keep_assemble(const ViewDev* __restrict__ views, const PairDesc* __restrict__ pairs,
+                                                              uint32_t n_rows, uint32_t slot_cap,
+                                                              const uint32_t* __restrict__ rs, const uint32_t* __restrict__ row_pair,
+                                                              const uint32_t* __restrict__ blk_row,
+                                                              const uint32_t* __restrict__ longest,
+                                                              Slot* __restrict__ slots, const OrientFuse of) {
+    __shared__ uint32_t s_tg[kKeepBlock];
+    __shared__ uint32_t s_rs[kAsmRows];
+    // The launch is enqueued right behind the scan, before the host knows the number of slots: the grid covers the CAPACITY of
+    // the output arrays (sized from the previous call), the number of slots is read here; more slots than capacity: nothing is
+    // written, the host sees the total with the pair table, enlarges the arrays and launches again.
+    const uint32_t n_slots = rs[n_rows];
+    const uint32_t at0 = blockIdx.x * kKeepBlock, tid = threadIdx.x;
+    if (n_slots > slot_cap || at0 >= n_slots) return;             // (uniform)
+    if (*longest > of.keep_cap) return;                           // a row outgrew the scratch: the pass is repeated, its records are incomplete
+    const uint32_t rf = blk_row[blockIdx.x];                      // the row that holds slot at0 (rs[rf] <= at0 < rs[rf + 1])
+    for (uint32_t i = tid; i < kAsmRows; i += kKeepBlock) s_rs[i] = rs[min(rf + i, n_rows)];   // (rs[n_rows] = n_slots)
+    __syncthreads();
+    const uint32_t at = at0 + tid;
+    const bool on = at < n_slots;
+    uint32_t gr = 0, r0 = 0, n = 0, tg = ~0u;
+    Slot me{};
+    const Slot* __restrict__ rec = of.keep_rec;
+    if (on) {
+        // the last row that starts at or before `at` (empty rows share their successor's start)
+        uint32_t l = 0, h = kAsmRows;                             // s_rs[l] <= at; s_rs[h] > at or h = kAsmRows
+        while (h - l > 1) { const uint32_t m = (l + h) >> 1; if (s_rs[m] <= at) l = m; else h = m; }
+        gr = rf + l;
+        if (l == kAsmRows - 1) {                                  // (more rows than are staged -- mostly empty ones: go on in memory)
+            uint32_t lo = gr, hi = n_rows;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rs[mid] <= at) lo = mid; else hi = mid; }
+            gr = lo;
+            r0 = rs[gr]; n = rs[gr + 1] - r0;
+        } else { r0 = s_rs[l]; n = s_rs[l + 1] - r0; }
+        rec += (size_t)gr * of.keep_cap;
+        me = rec[at - r0];
+        tg = me.tgt_seg;
+    }
+    s_tg[tid] = tg;
+    __syncthreads();
+    if (!on) return;
+    // place in the row = targets of the row below mine (the targets of a row are distinct).  The row's records inside the
+    // block come from LDS, those of a row the block's ends cut from the scratch.
+    const uint32_t j_lo = r0 < at0 ? at0 - r0 : 0u, j_hi = min(n, at0 + kKeepBlock - r0);
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < j_lo; ++j) rank += rec[j].tgt_seg < tg ? 1u : 0u;
+    {
+        const uint32_t* __restrict__ q = s_tg + (r0 + j_lo - at0);   // the row's records j_lo .. j_hi - 1 (r0 + j_lo >= at0)
+        const uint32_t m = j_hi > j_lo ? j_hi - j_lo : 0u;
+        uint32_t k = 0;
+        for (; k + 4 <= m; k += 4)
+            rank += (q[k] < tg ? 1u : 0u) + (q[k + 1] < tg ? 1u : 0u) + (q[k + 2] < tg ? 1u : 0u) + (q[k + 3] < tg ? 1u : 0u);
+        for (; k < m; ++k) rank += q[k] < tg ? 1u : 0u;
+    }
+    for (uint32_t j = j_hi; j < n; ++j) rank += rec[j].tgt_seg < tg ? 1u : 0u;
+    const uint32_t row = gr - pairs[row_pair[gr]].row_off;
+    const uint64_t to = (uint64_t)r0 + rank;
+    slots[to] = me;
+    const Slot& o = me;
+    store_inverse_target(of, to, o);
+    of.slot_row[to] = row;
+}
+
+hipError_t launch_keep_pair_info(const PairDesc* pairs, uint32_t n_pairs, const uint32_t* row_counts, const uint32_t* row_start,
+                                 uint4* info, uint32_t* row_pair, uint32_t* blk_row, uint32_t n_blk, uint32_t* longest, hipStream_t stream) {
+    if (!n_pairs) return hipSuccess;
+    hipError_t e = hipMemsetAsync(longest, 0, 4, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_keep_pair_info, dim3(n_pairs), dim3(256), 0, stream, pairs, row_counts, row_start, info, row_pair, blk_row, n_blk, longest);
+    return hipGetLastError();
+}
+hipError_t launch_keep_assemble(const ViewDev* views, const PairDesc* pairs, uint32_t n_rows, uint64_t slot_cap, const uint32_t* row_start,
+                                const uint32_t* row_pair, const uint32_t* blk_row, const uint32_t* longest, Slot* slots, OrientFuse of,
+                                hipStream_t stream) {
+    if (!slot_cap) return hipSuccess;
+    if (!of.keep_rec || !of.slot_row || !of.inv_tgt || !of.hyp_p || !of.hyp_q) return hipErrorInvalidValue;
+    slot_cap = std::min<uint64_t>(slot_cap, 0xFFFFFFFFull);
+    const uint32_t nb = (uint32_t)((slot_cap + kKeepBlock - 1) / kKeepBlock);
+    hipLaunchKernelGGL(k_keep_assemble, dim3(nb), dim3(kKeepBlock), 0, stream, views, pairs, n_rows, (uint32_t)slot_cap, row_start, row_pair,
+                       blk_row, longest, slots, of);
     return hipGetLastError();
 }
 

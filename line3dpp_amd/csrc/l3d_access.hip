@@ -60,6 +60,21 @@ int l3d_get_pair_slots(l3d_ctx* c, uint32_t pi, l3d_slot* out, uint64_t cap, uin
     if (out) {
         const uint64_t m = std::min<uint64_t>(cap, (uint64_t)pd.Ms * pd.K);
         L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->ragged) {
+            // ragged rows on the device (keep-all mode, k_keep_assemble): handed out in the padded Ms x K form of this
+            // interface -- a row's matches in ascending target order, then empty slots up to the pair's longest row
+            std::vector<uint32_t> rs((size_t)pd.Ms + 1);
+            L3D_HIP_CHECK(hipMemcpy(rs.data(), c->d_row_start.p + pd.row_off, rs.size() * 4, hipMemcpyDeviceToHost));
+            std::vector<l3d_slot> rows(rs[pd.Ms] - rs[0]);
+            if (!rows.empty()) L3D_HIP_CHECK(hipMemcpy(rows.data(), c->d_slots.p + rs[0], rows.size() * sizeof(l3d_slot), hipMemcpyDeviceToHost));
+            l3d_slot empty{};
+            empty.tgt_seg = kEmpty;
+            for (uint64_t i = 0; i < m; ++i) {
+                const uint32_t r = (uint32_t)(i / pd.K), j = (uint32_t)(i % pd.K);
+                out[i] = j < rs[r + 1] - rs[r] ? rows[rs[r] - rs[0] + j] : empty;
+            }
+            return L3D_OK;
+        }
         if (m) L3D_HIP_CHECK(hipMemcpy(out, c->d_slots.p + pd.slot_off, m * sizeof(l3d_slot), hipMemcpyDeviceToHost));
     }
     return L3D_OK;
@@ -150,6 +165,7 @@ int l3d_get_sparse_matrix(l3d_ctx* c, int sort_by_row, l3d_float4* entries, int3
 unsigned long long l3d_debug_counter(const char* name) {
     if (name && std::string(name) == "csr_global_launches") return g_csr_global_launches.load(std::memory_order_relaxed);
     if (name && std::string(name) == "knn_replay_calls") return g_knn_replay_calls.load(std::memory_order_relaxed);
+    if (name && std::string(name) == "keep_all_repeats") return g_keep_all_repeats.load(std::memory_order_relaxed);
     return ~0ull;
 }
 

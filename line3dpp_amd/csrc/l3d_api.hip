@@ -312,6 +312,7 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
     (void)hipEventElapsedTime(&ms, a, b);
     return ms;
 }
+std::atomic<uint64_t> g_keep_all_repeats{0};    // test hook: count passes of the keep-all mode repeated with a larger row scratch
 std::atomic<uint64_t> g_knn_replay_calls{0};   // test hook (l3d_debug_counter): calls whose kNN exceeded the LDS tables of k_match_pairs
 
 float ev_ms(const ::l3d_ctx* c, int a, int b) { return c->ev_on(a) && c->ev_on(b) ? ev_ms(c->ev[a], c->ev[b]) : 0.0f; }
@@ -410,7 +411,7 @@ void l3d_destroy(l3d_ctx* c) {
     c->d_lsegs.release(); c->d_lcands.release(); c->d_lchdrs.release(); c->d_ltab.release(); c->h_ltab.release();
     c->d_cull.release(); c->d_src_perm.release(); c->d_tgt_perm.release(); c->d_src_band.release();
     c->d_chunk_band.release(); c->d_cull_keys.release(); c->d_tgt_sf.release(); c->d_tgt_band.release(); c->d_tgt_s4.release(); c->d_tgt_sd.release();
-    c->d_row_counts.release();
+    c->d_row_counts.release(); c->d_keep_rec.release(); c->d_row_start.release(); c->d_slot_row.release(); c->d_keep_info.release(); c->d_row_pair.release(); c->d_blk_row.release(); c->h_keep_info.release();
     c->d_seg_base.release(); c->d_gseg_view.release();
     c->d_scal.release();
     c->d_surv_off.release(); c->d_hyp_off.release();
@@ -736,6 +737,7 @@ static int match_begin_body(l3d_ctx* c) {
     g_trace.mark(same_scene ? "begin: pair list kept" : "begin: pair list, fundamental matrices, cull descriptors built");
     c->pair_done.assign(c->pairs.size(), 0);
     c->pair_counted.assign(c->pairs.size(), 0);
+    c->ragged = false;
     c->shard_world = 0; c->lists_ready = false; c->lists_prepared = false;
     int rc = upload_views(*c);
     if (rc) return rc;
@@ -874,6 +876,7 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
     // bounded kNN: the orientation filter of phase B is fused into the epilogue
     OrientFuse of{mode == 0 ? c->d_inv_tgt.p : nullptr, c->tgt16, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr,
                   mode == 0 ? c->d_hyp_p.p : nullptr, mode == 0 ? c->d_hyp_q.p : nullptr};
+    if (mode == 1 && c->ragged) { of.keep_rec = c->d_keep_rec.p; of.keep_cap = c->keep_cap; }   // (the single pass of the keep-all mode)
     uint32_t tie_stride = 0;
     if (mode == 0) {   // rows with equal overlaps are collected here and replayed in the reference's heap order
         uint32_t mt = 0;
@@ -911,6 +914,95 @@ static int run_match_kernel(l3d_ctx* c, int mode, uint32_t first, uint32_t count
 
 static int match_pairs_impl(l3d_ctx* c, uint32_t first, uint32_t count, bool sync);
 
+// ---- keep-all mode (kNN <= 0): one culled pass + assembly of ragged rows ----------------------------------------------
+// The count pass keeps every accepted match at (row, arrival index) in a scratch of keep_cap records per row; a scan of the
+// counts places the rows, the host learns {first slot, longest row, slots} of every pair (ONE small read-back: it has to size
+// the slot buffer), k_keep_assemble writes slots, flags and the streams of phase B.  A row longer than the scratch: the pass
+// is repeated with a larger one (the counts are exact either way); a scratch beyond kKeepScratchMax: the two-pass form.
+static constexpr int kKeepAllTwoPass = -1000;
+static constexpr uint64_t kKeepScratchMax = 48ull << 30;
+static int keep_all_single_pass(l3d_ctx* c, uint32_t first, uint32_t count) {
+    const uint32_t P = (uint32_t)c->pairs.size(), R = c->n_rows_total;
+    if (!P || !R) return kKeepAllTwoPass;
+    hipStream_t st = c->stream;
+    if (!c->keep_cap) {   // (L3D_KEEPALL_CAP: the first scratch size of a context -- a test hook for the repeat with a larger one)
+        const char* e = std::getenv("L3D_KEEPALL_CAP");
+        c->keep_cap = e && std::atoi(e) > 0 ? (uint32_t)std::atoi(e) : 96u;
+    }
+    L3D_HIP_CHECK(c->d_row_start.reserve((size_t)R + 3));   // (row starts [R + 1] | the scan's total | the longest row)
+    L3D_HIP_CHECK(c->d_keep_info.reserve(P)); L3D_HIP_CHECK(c->d_row_pair.reserve(R)); L3D_HIP_CHECK(c->h_keep_info.reserve(P));
+    L3D_HIP_CHECK(c->d_scan_ws.reserve_zeroed(scan_ws_words((size_t)R + 1, 4), st));
+    const uint4* info = c->h_keep_info.p;
+    c->ragged = true;
+    auto outputs = [&](uint64_t ns) -> hipError_t {   // the arrays k_keep_assemble writes; returns through `cap` what they hold
+        hipError_t e = c->d_slots.reserve(ns);
+        if (e == hipSuccess) e = c->d_slot_row.reserve(ns);
+        if (e == hipSuccess) e = c->d_inv_tgt.reserve(ns);
+        if (e == hipSuccess) e = c->d_hyp_p.reserve(ns);
+        if (e == hipSuccess) e = c->d_hyp_q.reserve(ns);
+        return e;
+    };
+    auto assemble = [&](uint64_t cap) -> hipError_t {
+        OrientFuse of{c->d_inv_tgt.p, c->tgt16, OrientThr{c->orient_lo, c->orient_hi}, nullptr, nullptr, 0u, nullptr, nullptr,
+                      c->d_hyp_p.p, c->d_hyp_q.p};
+        of.keep_rec = c->d_keep_rec.p; of.keep_cap = c->keep_cap; of.slot_row = c->d_slot_row.p;
+        return launch_keep_assemble(c->d_views.p, c->d_pairs.p, R, cap, c->d_row_start.p, c->d_row_pair.p, c->d_blk_row.p, c->d_row_start.p + R + 2, c->d_slots.p, of, st);
+    };
+    // The outputs are sized BEFORE the pass -- from the previous call of the context, else 16 slots per row -- and the assembly
+    // is enqueued right behind the scan: the host reads the pair table back once, at the end, and only launches the assembly
+    // again when the guess was too small (the kernel writes nothing then).
+    const uint64_t guess = std::min<uint64_t>(std::max<uint64_t>(c->keep_last_total + c->keep_last_total / 8 + (1u << 16), (uint64_t)R * 16), 0xFFFFFFFFull);
+    L3D_HIP_CHECK(outputs(guess));
+    uint64_t cap = std::min<uint64_t>({c->d_slots.cap, c->d_slot_row.cap, c->d_hyp_p.cap, c->d_hyp_q.cap,
+                                       c->d_inv_tgt.cap * (c->tgt16 ? 2u : 1u), (size_t)0xFFFFFFFFull});
+    cap = std::min<uint64_t>(cap, guess + guess / 2);    // (a block cache may hand out far larger arrays: the grid covers `cap`)
+    for (int attempt = 0;; ++attempt) {
+        if ((uint64_t)R * c->keep_cap * sizeof(Slot) > kKeepScratchMax || attempt > 2) { c->ragged = false; return kKeepAllTwoPass; }
+        L3D_HIP_CHECK(c->d_keep_rec.reserve((size_t)R * c->keep_cap));
+        // (a block mark per kKeepBlock slots of at most min(rows x cap, 2^32) slots)
+        const uint32_t n_blk = (uint32_t)(std::min<uint64_t>((uint64_t)R * c->keep_cap, 1ull << 32) / kKeepBlock) + 2;
+        L3D_HIP_CHECK(c->d_blk_row.reserve(n_blk));
+        int rc = run_match_kernel(c, 1, first, count);
+        if (rc) { c->ragged = false; return rc; }
+        L3D_HIP_CHECK(launch_scan(c->d_row_counts.p, R, c->d_row_start.p, c->d_scan_ws.p, c->d_row_start.p + R + 1, st));
+        L3D_HIP_CHECK(launch_keep_pair_info(c->d_pairs.p, P, c->d_row_counts.p, c->d_row_start.p, c->d_keep_info.p, c->d_row_pair.p, c->d_blk_row.p, n_blk, c->d_row_start.p + R + 2, st));
+        L3D_HIP_CHECK(assemble(cap));
+        if (c->ev_on(5)) L3D_HIP_CHECK(hipEventRecord(c->ev[5], st));   // (the kernel time of the call: pass + scan + assembly)
+        L3D_HIP_CHECK(hipMemcpyAsync(c->h_keep_info.p, c->d_keep_info.p, (size_t)P * sizeof(uint4), hipMemcpyDeviceToHost, st));
+        L3D_HIP_CHECK(hipStreamSynchronize(st));
+        collect_match_timing(c);
+        uint32_t longest = 0;
+        for (uint32_t p = 0; p < P; ++p) longest = std::max(longest, info[p].y);
+        if (longest <= c->keep_cap) break;
+        c->keep_cap = (longest + longest / 8 + 31u) & ~31u;   // (kept for the calls to come)
+        l3d::g_keep_all_repeats.fetch_add(1, std::memory_order_relaxed);
+    }
+    uint64_t total = 0;
+    c->pair_nslots.assign(P, 0);
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint64_t n = (uint64_t)info[p].z | ((uint64_t)info[p].w << 32);
+        c->pair_nslots[p] = n; total += n;
+    }
+    if (total >= (1ull << 32)) { c->ragged = false; return fail(L3D_ERR_LIMIT, "slot buffer exceeds the 32-bit slot indices of phase B"); }
+    for (uint32_t p = 0; p < P; ++p) {           // (K: the longest row, what l3d_get_pair_slots pads the rows to)
+        c->pairs[p].slot_off = info[p].x; c->pairs[p].K = std::max(info[p].y, 1u);
+    }
+    c->n_slots = total; c->keep_last_total = total;
+    if (total > cap) {                           // the guess was too small: nothing has been written
+        L3D_HIP_CHECK(outputs(total));
+        if (c->ev_on(8)) L3D_HIP_CHECK(hipEventRecord(c->ev[8], st));
+        if (c->ev_on(4)) L3D_HIP_CHECK(hipEventRecord(c->ev[4], st));
+        L3D_HIP_CHECK(assemble(total));
+        if (c->ev_on(5)) L3D_HIP_CHECK(hipEventRecord(c->ev[5], st));
+        c->timing_pending = true;
+        l3d::g_keep_all_repeats.fetch_add(1u << 16, std::memory_order_relaxed);   // (high half: assemblies launched twice)
+    } else L3D_HIP_CHECK(outputs(std::max<uint64_t>(total, 1)));   // (no-op: the arrays hold `cap` >= total)
+    // (K and slot_off of the pairs: through the pinned staging copy, which stays the record of what the device holds)
+    L3D_HIP_CHECK(upload_table(c->d_pairs, c->h_pairs, c->pairs.data(), (size_t)P * sizeof(PairDesc), c->up_pairs, st));
+    for (uint32_t p = 0; p < P; ++p) c->pair_counted[p] = 1;   // (flags and streams are written: no k_orient_all in phase B)
+    return L3D_OK;
+}
+
 int l3d_match_pairs(l3d_ctx* c, uint32_t first, uint32_t count) {
     if (!c) return fail(L3D_ERR_ARG, "null argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
@@ -929,10 +1021,28 @@ static int match_pairs_impl(l3d_ctx* c, uint32_t first, uint32_t count, bool syn
     if (c->kNN > 0) {
         rc = run_match_kernel(c, 0, first, count);
     } else {
-        // kNN <= 0: keep every accepted match (line3D.cc:987-992): count, size the rows, fill
+        // kNN <= 0: keep every accepted match (line3D.cc:987-992)
         if (first != 0 || count != c->pairs.size())
             return fail(L3D_ERR_LIMIT, "kNN <= 0 needs all pairs in one l3d_match_pairs call");
-        L3D_HIP_CHECK(c->d_row_counts.reserve(std::max<uint32_t>(c->n_rows_total, 1)));
+        L3D_HIP_CHECK(c->d_row_counts.reserve((size_t)c->n_rows_total + 1));
+        // ONE culled pass that keeps what it accepts + an assembly of RAGGED rows (round 6, k_match.hip: k_keep_assemble).
+        // L3D_KEEPALL_TWO_PASS=1 / L3D_KEEPALL_NO_CULL=1 (A/B, read per call): the form of rounds 3-5 below -- count pass
+        // (culled / streamed), rows sized by the host from the counts (K of a pair = its longest row), fill pass streamed.
+        const bool two_pass = std::getenv("L3D_KEEPALL_TWO_PASS") != nullptr || std::getenv("L3D_KEEPALL_NO_CULL") != nullptr;
+        if (!two_pass) {
+            rc = keep_all_single_pass(c, first, count);
+            if (rc != kKeepAllTwoPass) {
+                if (rc) return rc;
+                if (c->ev_on(3)) L3D_HIP_CHECK(hipEventRecord(c->ev[3], c->stream));
+                if (sync) {
+                    L3D_HIP_CHECK(hipStreamSynchronize(c->stream));
+                    collect_match_timing(c);
+                    c->tm.match_pairs_ms += ev_ms(c, 2, 3);
+                }
+                for (uint32_t p = first; p < first + count; ++p) c->pair_done[p] = 1;
+                return L3D_OK;
+            }
+        }
         rc = run_match_kernel(c, 1, first, count);
         if (rc) return rc;
         L3D_HIP_CHECK(hipStreamSynchronize(c->stream));

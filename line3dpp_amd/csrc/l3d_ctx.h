@@ -189,6 +189,18 @@ struct l3d_ctx {
     bool timing_pending = false;                    // phase-A events recorded but not read yet
     uint32_t pending_launches = 0;
     DevBuf<uint32_t> d_row_counts;
+    // keep-all mode (kNN <= 0), single culled pass with RAGGED rows (round 6; k_match.hip: k_keep_assemble)
+    bool ragged = false;                            // this call's slot buffer is ragged: row r of pair p = slots
+                                                    // [d_row_start[row_off + r], d_row_start[row_off + r + 1])
+    uint32_t keep_cap = 0;                          // records per row of the scratch (grows to the longest row seen)
+    DevBuf<Slot> d_keep_rec;                        // [n_rows_total * keep_cap] accepted matches by (row, arrival index)
+    DevBuf<uint32_t> d_row_pair, d_blk_row;         // [n_rows_total] pair of a row; [slot blocks] row that holds a block's first slot
+    DevBuf<uint32_t> d_row_start, d_slot_row;       // [n_rows_total + 2], [n_slots]
+    DevBuf<uint4> d_keep_info;                      // [pairs] {first slot, longest row, slots lo, slots hi}
+    std::vector<uint64_t> pair_nslots;              // slots of every pair (ragged calls)
+    uint64_t keep_last_total = 0;                   // slots of the previous keep-all call (sizes the outputs before the pass)
+    PinnedBuf<uint4> h_keep_info;
+    uint64_t pair_slots(uint32_t p) const { return ragged ? pair_nslots[p] : (uint64_t)pairs[p].Ms * pairs[p].K; }
     // rows with equal overlaps (k_match_tied_rows): counter, (pair, row) list, heap scratch of the replay kernel
     DevBuf<uint32_t> d_tie_count;
     uint32_t tie_seq = 0;                           // match launches so far: which of the two queue counters is current

@@ -9,6 +9,7 @@ struct l3d_cledge;
 namespace l3d {
 
 extern std::atomic<uint64_t> g_knn_replay_calls;      // l3d_api.hip
+extern std::atomic<uint64_t> g_keep_all_repeats;      // l3d_api.hip
 extern std::atomic<uint64_t> g_csr_global_launches;   // k_lists.hip, test hook read through l3d_debug_counter
 
 constexpr int kMatchRows = 64;   // source rows per work item of k_match_pairs (one wave64): the ROW form (keep-all modes, brute-force
@@ -106,6 +107,12 @@ struct OrientFuse {
                                     // hypotheses of the source segment
     float2* hyp_q;                  // [n_slots] (depth_q1, depth_q2): the depths of a slot's INVERSE hypothesis (read where
                                     // inv_tgt names a target); k_pair_csr carries them into the sorted order of its records
+    // keep-all mode (kNN <= 0), single culled pass (round 6): the count pass leaves every accepted match of row r at
+    // keep_rec[(row_off + r) * keep_cap + arrival index] as a whole 32-byte slot (flags 0: k_keep_assemble sets them and puts
+    // the rows into ascending target order)
+    Slot* keep_rec;                 // nullptr: counts only (the legacy two-pass form)
+    uint32_t keep_cap;              // records kept per row (a longer row: the pass is repeated with a larger scratch)
+    uint32_t* slot_row;             // [n_slots] source segment of a slot (ragged rows), written by k_keep_assemble
 };
 
 // ---- k_match.hip ----
@@ -139,6 +146,15 @@ hipError_t launch_pack_slot_idx(const Slot* slots, uint32_t* idx, uint64_t lo, u
 hipError_t launch_expand_slot_idx(const ViewDev* views, const PairDesc* pairs, uint32_t first, uint32_t count,
                                   uint32_t max_row_slots, const uint32_t* idx, Slot* slots, OrientFuse of,
                                   hipStream_t stream);
+// keep-all mode (kNN <= 0), after the count pass that kept its records (OrientFuse::keep_rec) and the scan of the row counts
+// info[p] = {first slot, longest row, slots lo, slots hi}; row_pair[row] = its pair; blk_row[b] = the row that holds slot b * kKeepBlock
+constexpr uint32_t kKeepBlock = 1024;
+hipError_t launch_keep_pair_info(const PairDesc* pairs, uint32_t n_pairs, const uint32_t* row_counts, const uint32_t* row_start,
+                                 uint4* info, uint32_t* row_pair, uint32_t* blk_row, uint32_t n_blk, uint32_t* longest, hipStream_t stream);   // *longest: the longest row of all
+// (slot_cap: capacity of the output arrays -- the number of slots is read on the device, a pass with more writes nothing)
+hipError_t launch_keep_assemble(const ViewDev* views, const PairDesc* pairs, uint32_t n_rows, uint64_t slot_cap, const uint32_t* row_start,
+                                const uint32_t* row_pair, const uint32_t* blk_row, const uint32_t* longest, Slot* slots, OrientFuse of,
+                                hipStream_t stream);
 // per-segment invariants of all views
 hipError_t launch_prep_views(const ViewDev* views, uint32_t n_views, uint32_t max_M, hipStream_t stream);
 
@@ -151,7 +167,8 @@ hipError_t launch_scan64(const unsigned long long* in, uint32_t n, unsigned long
 // pair, one workgroup each): poff = per-pair CSR offsets over the target's segments, refs = the slot indices in that order
 hipError_t launch_pair_csr(const PairDesc* pairs, uint32_t n_pairs, uint32_t max_Mt, const PairCsr* pair_csr,
                            const uint32_t* inv_tgt, uint32_t tgt16, uint32_t* poff, uint32_t* refs,
-                           uint32_t* dummy, uint32_t tgt_v0, uint32_t tgt_v1, uint64_t max_pair_slots, hipStream_t st);
+                           uint32_t* dummy, uint32_t tgt_v0, uint32_t tgt_v1, uint64_t max_pair_slots,
+                           const uint32_t* row_start, hipStream_t st);   // row_start: ragged rows (l3d_lists.h), else nullptr
 hipError_t launch_seg_index(ListPools lp, uint32_t* seg_of_g, uint32_t G, uint32_t world, hipStream_t st);
 struct ListView; struct OutPair; struct InPair;
 hipError_t launch_lists(uint32_t v0, uint32_t nv, uint32_t max_M, const ViewDev* views, const PairDesc* pairs,

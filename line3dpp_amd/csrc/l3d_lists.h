@@ -57,7 +57,8 @@ static_assert(sizeof(PairCsr) == 16, "PairCsr is 16 bytes");
 struct OutPair {
     uint64_t slot_off;        // first slot of the pair
     uint32_t tgt, pair, K;    // target view, pair index, slots per source segment
-    uint32_t pad[3];
+    uint32_t row_off;         // first row of the pair in ListPools::row_start (ragged rows: the keep-all mode)
+    uint32_t pad[2];
 };
 static_assert(sizeof(ListView) == 32 && sizeof(OutPair) == 32, "table records are 32 bytes");
 
@@ -140,6 +141,16 @@ struct ListPools {
     uint32_t count_entries; // 1: the list pass adds every list's length to cnt[pool * 16 + 5] (statistics; L3D_NO_LIST_STAT=1: off)
     uint32_t pool0, npools; // the pools this pass allocates from (all of them on one GPU; a rank's share when the list
                             // pass is sharded: the filled pools of all ranks are all-gathered slab by slab)
+    // RAGGED rows (kNN <= 0, round 6): a row holds exactly its accepted matches -- row r of a pair occupies the slots
+    // [row_start[row_off + r], row_start[row_off + r + 1]) and slot_row[slot] is the source segment of a slot.  nullptr: every
+    // row of a pair has PairDesc::K slots (bounded kNN; the legacy keep-all path).
+    const uint32_t* row_start;
+    const uint32_t* slot_row;
 };
+// the slots of source segment `seg` in an outgoing pair: first slot and count
+__host__ __device__ inline void out_row_slots(const OutPair& op, uint32_t seg, const ListPools& lp, uint64_t& row0, uint32_t& n) {
+    if (lp.row_start) { const uint32_t a = lp.row_start[op.row_off + seg]; row0 = a; n = lp.row_start[op.row_off + seg + 1] - a; }
+    else { row0 = op.slot_off + (uint64_t)seg * op.K; n = op.K; }
+}
 
 }  // namespace l3d

@@ -159,6 +159,7 @@ static ListPools list_pools(l3d_ctx* c, uint32_t pool0 = 0, uint32_t npools = kL
     lp.flags = c->d_lzero.p + kListPools * 16;
     lp.list2 = c->d_list2.p; lp.list4 = c->d_list4.p; lp.listH = c->d_listH.p;
     lp.pool0 = pool0; lp.npools = npools;
+    lp.row_start = c->ragged ? c->d_row_start.p : nullptr; lp.slot_row = c->ragged ? c->d_slot_row.p : nullptr;
     static const bool no_stat = std::getenv("L3D_NO_LIST_STAT") != nullptr;   // diagnostic switch (A/B of the per-list counter)
     lp.count_entries = no_stat ? 0u : 1u;
     return lp;
@@ -207,7 +208,7 @@ static int lists_prepare(l3d_ctx* c, int caps_mode) {
     for (uint32_t vi = 0; vi < V; ++vi) c->seg_base[vi + 1] = c->seg_base[vi] + c->order[vi]->M;
     const uint32_t G = c->G = c->seg_base[V];
     uint64_t max_slots = 0;
-    for (auto& pd : c->pairs) max_slots = std::max<uint64_t>(max_slots, (uint64_t)pd.Ms * pd.K);
+    for (uint32_t p = 0; p < P; ++p) max_slots = std::max<uint64_t>(max_slots, c->pair_slots(p));
     if (2 * c->n_slots >= (1ull << 32)) return fail(L3D_ERR_LIMIT, "more than 2^32 hypotheses");
     L3D_HIP_CHECK(c->d_seg_base.reserve(V + 1)); L3D_HIP_CHECK(c->d_gseg_view.reserve(G + 1));
     L3D_HIP_CHECK(c->d_surv_off.reserve(G + 2)); L3D_HIP_CHECK(c->d_hyp_off.reserve(G + 2));
@@ -257,7 +258,7 @@ static int lists_prepare(l3d_ctx* c, int caps_mode) {
             for (uint32_t p : c->order[vi]->out_pairs) {
                 const PairDesc& pd = c->pairs[p];
                 OutPair op{};
-                op.slot_off = pd.slot_off; op.tgt = pd.tgt; op.pair = p; op.K = pd.K;
+                op.slot_off = pd.slot_off; op.tgt = pd.tgt; op.pair = p; op.K = pd.K; op.row_off = pd.row_off;
                 hp[n++] = op;
             }
             lv.nq = n - lv.q0;
@@ -340,7 +341,7 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
     const ListPools lp = list_pools(c, pool0, npools);
     const SimConst simc = sim_thresholds(c->two_sigA_sqr);
     uint64_t max_slots = 0;
-    for (auto& pd : c->pairs) max_slots = std::max<uint64_t>(max_slots, (uint64_t)pd.Ms * pd.K);
+    for (uint32_t p = 0; p < P; ++p) max_slots = std::max<uint64_t>(max_slots, c->pair_slots(p));
     // one memset per pass: the zero block and, behind it, positive[] (seg_of_g needs none: it is only read for
     // segments with surviving hypotheses, whose header this very pass has written)
     L3D_HIP_CHECK(hipMemsetAsync(c->d_lzero.p, 0, z.words * 4 + std::max<uint64_t>(c->n_slots, 1), st));
@@ -356,7 +357,7 @@ static int lists_run(l3d_ctx* c, uint32_t v0, uint32_t nv, uint32_t pool0, uint3
             // (views beyond the LDS capacity of k_pair_csr keep their cursors in global memory: 64 dummy words per pair)
             if (max_Mt > 32768 || std::getenv("L3D_CSR_GLOBAL")) L3D_HIP_CHECK(c->d_csr_dummy.reserve((size_t)P * 64));
             L3D_HIP_CHECK(launch_pair_csr(c->d_pairs.p, P, max_Mt, pair_poff, c->d_inv_tgt.p, c->tgt16, c->d_poff.p, c->d_inv_refs.p,
-                                          c->d_csr_dummy.p, v0, v0 + nv, max_slots, st));
+                                          c->d_csr_dummy.p, v0, v0 + nv, max_slots, c->ragged ? c->d_row_start.p : nullptr, st));
         }
     }
     g_trace.mark("pair CSRs enqueued");

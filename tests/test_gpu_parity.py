@@ -177,6 +177,49 @@ def test_keep_all_mode_knn_zero():
     _compare_final(g, o2, sc)
 
 
+def test_keep_all_single_pass_against_the_two_pass_form(monkeypatch):
+    """kNN <= 0 since round 6: ONE culled pass that keeps what it accepts (row scratch) + k_keep_assemble into RAGGED rows
+    (k_match.hip).  The form of rounds 3-5 (count pass, rows sized by the host, streamed fill pass: L3D_KEEPALL_TWO_PASS=1) must
+    give the same slots -- the accessor hands both out in the padded Ms x K form -- and the same final result; a row scratch that
+    is too small (L3D_KEEPALL_CAP=2: first size of a context) repeats the pass with a larger one."""
+    from line3dpp_amd import _lib
+    sc = make_scene(5, 300, n_neighbors=3, seed=41)
+    L = _lib.load()
+    runs = {}
+    for name, env in (("two_pass", {"L3D_KEEPALL_TWO_PASS": "1"}), ("single", {}), ("single_small_scratch", {"L3D_KEEPALL_CAP": "2"})):
+        for k in ("L3D_KEEPALL_TWO_PASS", "L3D_KEEPALL_CAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        before = L.l3d_debug_counter(b"keep_all_repeats")
+        g = _gpu(sc)
+        assert g.matchBegin(kNN=0) and g.matchPairs(0, len(g.pairs()[0]))
+        slots = [g.pair_slots(pi) for pi in range(len(g.pairs()[0]))]
+        repeats = L.l3d_debug_counter(b"keep_all_repeats") - before
+        assert g.matchFinish() and g.computeAffinity()
+        runs[name] = (g, slots, repeats)
+    assert runs["two_pass"][2] == 0 and (runs["single_small_scratch"][2] & 0xFFFF) >= 1
+    ref = runs["two_pass"][1]
+    n = 0
+    for name in ("single", "single_small_scratch"):
+        for a, b in zip(ref, runs[name][1]):
+            assert a.shape == b.shape
+            for f in ("tgt_seg", "overlap", "d_p1", "d_p2", "d_q1", "d_q2"):
+                assert np.array_equal(a[f], b[f]), (name, f)
+            n += int((a["tgt_seg"] != 0xFFFFFFFF).sum())
+    assert n > 10_000
+    g0 = runs["two_pass"][0]
+    for name in ("single", "single_small_scratch"):
+        g1 = runs[name][0]
+        for v in sc.views:
+            m0, o0 = g0.matches(v.cam); m1, o1 = g1.matches(v.cam)
+            assert np.array_equal(o0, o1) and m0.tobytes() == m1.tobytes(), (name, v.cam)
+        e0, l0, w0 = g0.affinity(); e1, l1, w1 = g1.affinity()
+        assert np.array_equal(e0, e1) and np.array_equal(l0, l1) and np.array_equal(w0, w1)
+    o = _oracle(sc); o.match_images(kNN=0); o.compute_affinity()
+    _compare_final(runs["single"][0], o, sc)
+
+
 def _compare_final(g, o, sc, exact_sets=True):
     n_surv = 0
     for v in sc.views:
