@@ -197,6 +197,9 @@ int l3d_get_pairs(l3d_ctx*, uint32_t* src_cam, uint32_t* tgt_cam, uint64_t* slot
 int l3d_match_pairs(l3d_ctx*, uint32_t first, uint32_t count);
 int l3d_slot_buffer(l3d_ctx*, void** dev_ptr, uint64_t* n_slots);   /* (halo form of a multi-GPU call: only the regions of
                                                                        * the pairs this rank matched or received hold slots) */
+/* (kNN <= 0, keep every match -- line3D.cc:982-992: the device buffer is RAGGED, a row holds exactly its matches in ascending
+ *  target order and n_slots is their number; l3d_get_pairs' slot_offset is the pair's first slot; l3d_get_pair_slots below
+ *  hands a pair out in the padded Ms x K form, K = its longest row.  The mode runs unsharded.) */
 /* tell the context that the caller's exchange has filled in the slots of all other pairs */
 int l3d_slots_exchanged(l3d_ctx*);
 /* Compact form of the same exchange (kNN > 0): only the target index of every slot travels (4 B instead of 32);
@@ -319,7 +322,8 @@ int l3d_pair_tests(l3d_ctx*, uint64_t* n);
  * seg_offsets has M+1 entries.  Call with out=NULL to get the count. */
 int l3d_get_matches(l3d_ctx*, uint32_t camID, l3d_match* out, uint64_t cap, uint32_t* seg_offsets,
                     uint64_t* n);
-/* fresh phase-A slots of one directed pair: Ms x K slots (K = kNN) */
+/* fresh phase-A slots of one directed pair: Ms x K slots (K = kNN; kNN <= 0: K = the pair's longest row, shorter rows
+ * padded with empty slots) */
 int l3d_get_pair_slots(l3d_ctx*, uint32_t pair_index, l3d_slot* out, uint64_t cap, uint32_t* Ms,
                        uint32_t* K);
 /* estimated_position3D_ (+ entry_map_ keys), ordered by (camID, segID). Coordinates are in the

@@ -186,13 +186,16 @@ def test_keep_all_single_pass_against_the_two_pass_form(monkeypatch):
     sc = make_scene(5, 300, n_neighbors=3, seed=41)
     L = _lib.load()
     runs = {}
-    for name, env in (("two_pass", {"L3D_KEEPALL_TWO_PASS": "1"}), ("single", {}), ("single_small_scratch", {"L3D_KEEPALL_CAP": "2"})):
+    for name, env in (("two_pass", {"L3D_KEEPALL_TWO_PASS": "1"}), ("single", {}), ("single_small_scratch", {"L3D_KEEPALL_CAP": "2"}),
+                      ("single_brute_force", {})):
         for k in ("L3D_KEEPALL_TWO_PASS", "L3D_KEEPALL_CAP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         before = L.l3d_debug_counter(b"keep_all_repeats")
         g = _gpu(sc)
+        if name == "single_brute_force":           # (every pair through the exact test, no culling, no pre-filter: same rows)
+            g.set_brute_force(1)
         assert g.matchBegin(kNN=0) and g.matchPairs(0, len(g.pairs()[0]))
         slots = [g.pair_slots(pi) for pi in range(len(g.pairs()[0]))]
         repeats = L.l3d_debug_counter(b"keep_all_repeats") - before
@@ -201,7 +204,7 @@ def test_keep_all_single_pass_against_the_two_pass_form(monkeypatch):
     assert runs["two_pass"][2] == 0 and (runs["single_small_scratch"][2] & 0xFFFF) >= 1
     ref = runs["two_pass"][1]
     n = 0
-    for name in ("single", "single_small_scratch"):
+    for name in ("single", "single_small_scratch", "single_brute_force"):
         for a, b in zip(ref, runs[name][1]):
             assert a.shape == b.shape
             for f in ("tgt_seg", "overlap", "d_p1", "d_p2", "d_q1", "d_q2"):
@@ -209,7 +212,7 @@ def test_keep_all_single_pass_against_the_two_pass_form(monkeypatch):
             n += int((a["tgt_seg"] != 0xFFFFFFFF).sum())
     assert n > 10_000
     g0 = runs["two_pass"][0]
-    for name in ("single", "single_small_scratch"):
+    for name in ("single", "single_small_scratch", "single_brute_force"):
         g1 = runs[name][0]
         for v in sc.views:
             m0, o0 = g0.matches(v.cam); m1, o1 = g1.matches(v.cam)
@@ -218,6 +221,22 @@ def test_keep_all_single_pass_against_the_two_pass_form(monkeypatch):
         assert np.array_equal(e0, e1) and np.array_equal(l0, l1) and np.array_equal(w0, w1)
     o = _oracle(sc); o.match_images(kNN=0); o.compute_affinity()
     _compare_final(runs["single"][0], o, sc)
+    # tiny views at a strict overlap threshold: (almost) no accepted match -- an empty or near-empty ragged buffer, rows without
+    # slots, pairs without slots; the call still succeeds and agrees with the oracle
+    st = make_scene(4, 3, n_neighbors=3, seed=5)
+    g = _gpu(st)
+    assert g.matchBegin(kNN=0, epipolar_overlap=0.99) and g.matchPairs(0, len(g.pairs()[0]))
+    o = _oracle(st); o.begin_match(kNN=0, epi_overlap=0.99)
+    n_ref = 0
+    for pi, (s_, t_) in enumerate(g.pairs()[0]):
+        om, off = o.match_pair(int(s_), int(t_))
+        sl = g.pair_slots(pi)
+        r = H.compare_pair(sl, om)
+        assert not r["missing"] and not r["extra"] and r["order_mismatch"] == 0
+        n_ref += len(om)
+    o.end_match()
+    assert g.slot_buffer()[1] == n_ref
+    assert g.matchFinish() and g.computeAffinity()
 
 
 def _compare_final(g, o, sc, exact_sets=True):
